@@ -1,0 +1,701 @@
+"""CPU oracle for the gtars hot path -- TEST INFRASTRUCTURE ONLY.
+
+This package is the checker the MI355X path is compared against.  It must only
+be imported from ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``; the product package ``gtars_amd`` never
+imports it and fails loudly when its HIP library is missing.
+
+Two layers:
+
+* ``libgtars_oracle.so`` (``gtars_oracle.c``): plain-C restatement of the
+  integer algorithms (Bits, AIList, multi-chromosome bucketing, tokenizer core,
+  MultiChromOverlapper counts, IndexedRegionSet.find_overlaps, Igd tile walk,
+  LOLA contingency).  Each function cites the reference file:line it follows.
+* this module: the string world on top (BED parsing + sort, Universe/vocab,
+  special tokens, TOML config, fragment files, .gtok) restated in small pure
+  Python, again citing the reference.
+
+Parity pinning: the reference is Rust-only and cannot be built or imported in
+this image, so the oracle is pinned by the reference's own known-answer tests
+and fixture files -- see ``tests/test_oracle_golden.py`` and ``tests/golden``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import gzip
+import os
+import struct
+import subprocess
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgtars_oracle.so")
+
+KIND_BITS = 0
+KIND_AILIST = 1
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle in place (gcc, a second or two)."""
+    src = os.path.join(_HERE, "gtars_oracle.c")
+    hdr = os.path.join(_HERE, "gtars_oracle.h")
+    stale = (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or (os.path.exists(src) and os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "libgtars_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    vp, u32, u64, i32, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64
+    L.orc_index_build.restype = vp
+    L.orc_index_build.argtypes = [_u32p, _u32p, _u32p, _u32p, u64, u32, C.c_int]
+    L.orc_index_free.argtypes = [vp]
+    L.orc_index_chrom_len.restype = u64
+    L.orc_index_chrom_len.argtypes = [vp, u32]
+    L.orc_index_max_len.restype = u32
+    L.orc_index_max_len.argtypes = [vp, u32]
+    L.orc_index_n_headers.restype = u64
+    L.orc_index_n_headers.argtypes = [vp, u32]
+    L.orc_index_headers.argtypes = [vp, u32, _u64p]
+    L.orc_index_stored.argtypes = [vp, u32, _u32p, _u32p, _u32p]
+    L.orc_find.restype = u64
+    L.orc_find.argtypes = [vp, u32, u32, u32, _u32p, _u32p, _u32p, u64]
+    L.orc_bits_count.restype = u64
+    L.orc_bits_count.argtypes = [vp, u32, u32, u32]
+    L.orc_tokenize.restype = u64
+    L.orc_tokenize.argtypes = [vp, _u32p, _u32p, _u32p, u64, _u64p, _u32p, u64]
+    L.orc_count_overlaps.argtypes = [vp, _u32p, _u32p, _u32p, u64, C.c_int, i32, _u64p]
+    L.orc_any_overlaps.argtypes = [vp, _u32p, _u32p, _u32p, u64, C.c_int, i32, _u8p]
+    L.orc_find_overlaps_regions.restype = u64
+    L.orc_find_overlaps_regions.argtypes = [vp, _u32p, _u32p, _u32p, u64, C.c_int, i32, _u64p, _u32p, _u32p, _u32p, u64]
+    L.orc_irs_find_overlaps.restype = u64
+    L.orc_irs_find_overlaps.argtypes = [vp, _u32p, _u32p, _u32p, u64, _u32p, _u32p, _u32p, u64, C.c_int, i32, _u64p, _u64p, u64]
+    L.orc_igd_new.restype = vp
+    L.orc_igd_new.argtypes = [i32]
+    L.orc_igd_free.argtypes = [vp]
+    L.orc_igd_add.argtypes = [vp, u32, i32, i32, i32, u32]
+    L.orc_igd_finalize.argtypes = [vp]
+    L.orc_igd_total_records.restype = u64
+    L.orc_igd_total_records.argtypes = [vp]
+    L.orc_igd_num_contigs.restype = u64
+    L.orc_igd_num_contigs.argtypes = [vp]
+    L.orc_igd_count_overlaps.restype = u32
+    L.orc_igd_count_overlaps.argtypes = [vp, u32, i32, i32, i32, _u64p]
+    L.orc_igd_count_set_overlaps.argtypes = [vp, _u32p, _u32p, _u32p, u64, i32, _u64p, u64]
+    L.orc_igd_count_region_hits.argtypes = [vp, _u32p, _u32p, _u32p, u64, i32, _u64p, u64]
+    L.orc_igd_find_overlaps_regionset.restype = u64
+    L.orc_igd_find_overlaps_regionset.argtypes = [vp, _u32p, _u32p, _u32p, u64, i32, _u32p, _u32p, u64]
+    L.orc_igd_count_overlaps_per_query.argtypes = [vp, _u32p, _u32p, _u32p, u64, i32, _u32p]
+    L.orc_lola_contingency.argtypes = [_u64p, _u64p, u64, i64, i64, _i64p, _i64p, _i64p, _i64p]
+    L.orc_splitmix64.restype = u64
+    L.orc_splitmix64.argtypes = [C.POINTER(u64)]
+    _lib = L
+    return L
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+_EMPTY32 = np.zeros(1, dtype=np.uint32)
+
+
+class Index:
+    """Per-chromosome Bits / AIList collection over integer chromosome ids."""
+
+    def __init__(self, chrom, start, end, val=None, n_chrom: Optional[int] = None, kind: int = KIND_BITS):
+        chrom, start, end = _u32(chrom), _u32(start), _u32(end)
+        n = len(chrom)
+        if val is None:
+            val = np.arange(n, dtype=np.uint32)
+        val = _u32(val)
+        if n_chrom is None:
+            n_chrom = int(chrom.max()) + 1 if n else 0
+        self.n_chrom = int(n_chrom)
+        self.kind = kind
+        pad = lambda a: a if n else _EMPTY32
+        self._h = lib().orc_index_build(pad(chrom), pad(start), pad(end), pad(val), n, self.n_chrom, kind)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_index_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def chrom_len(self, c: int) -> int:
+        return int(lib().orc_index_chrom_len(self._h, c))
+
+    def max_len(self, c: int) -> int:
+        return int(lib().orc_index_max_len(self._h, c))
+
+    def headers(self, c: int) -> List[int]:
+        n = int(lib().orc_index_n_headers(self._h, c))
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        lib().orc_index_headers(self._h, c, out)
+        return [int(x) for x in out[:n]]
+
+    def stored(self, c: int):
+        n = self.chrom_len(c)
+        s, e, v = (np.zeros(max(n, 1), dtype=np.uint32) for _ in range(3))
+        lib().orc_index_stored(self._h, c, s, e, v)
+        return s[:n], e[:n], v[:n]
+
+    def find(self, c: int, qs: int, qe: int):
+        """Overlapper::find -> (starts, ends, vals) in reference result order."""
+        cap = 64
+        while True:
+            s, e, v = (np.zeros(cap, dtype=np.uint32) for _ in range(3))
+            n = int(lib().orc_find(self._h, c, qs, qe, s, e, v, cap))
+            if n <= cap:
+                return s[:n], e[:n], v[:n]
+            cap = n
+
+    def bits_count(self, c: int, qs: int, qe: int) -> int:
+        return int(lib().orc_bits_count(self._h, c, qs, qe))
+
+    def tokenize(self, qc, qs, qe) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (offsets u64[nq+1], ids u32[H]); no batch-level unk applied."""
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        nq = len(qc)
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        if nq == 0:
+            return offsets, np.zeros(0, dtype=np.uint32)
+        h = int(lib().orc_tokenize(self._h, qc, qs, qe, nq, offsets, _EMPTY32, 0))
+        ids = np.zeros(max(h, 1), dtype=np.uint32)
+        lib().orc_tokenize(self._h, qc, qs, qe, nq, offsets, ids, h)
+        return offsets, ids[:h]
+
+    def count_overlaps(self, qc, qs, qe, min_overlap: Optional[int] = None) -> np.ndarray:
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        out = np.zeros(max(len(qc), 1), dtype=np.uint64)
+        if len(qc):
+            lib().orc_count_overlaps(self._h, qc, qs, qe, len(qc), int(min_overlap is not None), int(min_overlap or 0), out)
+        return out[: len(qc)]
+
+    def any_overlaps(self, qc, qs, qe, min_overlap: Optional[int] = None) -> np.ndarray:
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        out = np.zeros(max(len(qc), 1), dtype=np.uint8)
+        if len(qc):
+            lib().orc_any_overlaps(self._h, qc, qs, qe, len(qc), int(min_overlap is not None), int(min_overlap or 0), out)
+        return out[: len(qc)].astype(bool)
+
+    def find_overlaps_regions(self, qc, qs, qe, min_overlap: Optional[int] = None):
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        nq = len(qc)
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        if nq == 0:
+            z = np.zeros(0, dtype=np.uint32)
+            return offsets, z, z, z
+        hm, mo = int(min_overlap is not None), int(min_overlap or 0)
+        h = int(lib().orc_find_overlaps_regions(self._h, qc, qs, qe, nq, hm, mo, offsets, _EMPTY32, _EMPTY32, _EMPTY32, 0))
+        s, e, v = (np.zeros(max(h, 1), dtype=np.uint32) for _ in range(3))
+        lib().orc_find_overlaps_regions(self._h, qc, qs, qe, nq, hm, mo, offsets, s, e, v, h)
+        return offsets, s[:h], e[:h], v[:h]
+
+    def irs_find_overlaps(self, src_chrom, src_start, src_end, qc, qs, qe, min_overlap: Optional[int] = None):
+        sc, ss, se = _u32(src_chrom), _u32(src_start), _u32(src_end)
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        nq = len(qc)
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        if nq == 0 or len(sc) == 0:
+            return offsets, np.zeros(0, dtype=np.uint64)
+        hm, mo = int(min_overlap is not None), int(min_overlap or 0)
+        dummy = np.zeros(1, dtype=np.uint64)
+        h = int(lib().orc_irs_find_overlaps(self._h, sc, ss, se, len(sc), qc, qs, qe, nq, hm, mo, offsets, dummy, 0))
+        out = np.zeros(max(h, 1), dtype=np.uint64)
+        lib().orc_irs_find_overlaps(self._h, sc, ss, se, len(sc), qc, qs, qe, nq, hm, mo, offsets, out, h)
+        return offsets, out[:h]
+
+
+class Igd:
+    """Igd over integer chromosome ids (gtars-igd/src/igd.rs)."""
+
+    def __init__(self, nbp: int = 16384):
+        self._h = lib().orc_igd_new(nbp)
+        self.n_files = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_igd_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def add(self, chrom: int, start: int, end: int, value: int, file_idx: int):
+        lib().orc_igd_add(self._h, chrom, start, end, value, file_idx)
+        self.n_files = max(self.n_files, file_idx + 1)
+
+    def add_arrays(self, chrom, start, end, value, file_idx):
+        L = lib()
+        for c, s, e, v, f in zip(chrom, start, end, value, file_idx):
+            L.orc_igd_add(self._h, int(c), int(s), int(e), int(v), int(f))
+        if len(file_idx):
+            self.n_files = max(self.n_files, int(max(file_idx)) + 1)
+
+    def finalize(self):
+        lib().orc_igd_finalize(self._h)
+
+    def total_records(self) -> int:
+        return int(lib().orc_igd_total_records(self._h))
+
+    def num_contigs(self) -> int:
+        return int(lib().orc_igd_num_contigs(self._h))
+
+    def count_overlaps(self, chrom: int, start: int, end: int, min_overlap: int, hits: np.ndarray) -> int:
+        return int(lib().orc_igd_count_overlaps(self._h, chrom, start, end, min_overlap, hits))
+
+    def count_set_overlaps(self, qc, qs, qe, min_overlap: int = 1, n_files: Optional[int] = None) -> np.ndarray:
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        f = self.n_files if n_files is None else n_files
+        hits = np.zeros(max(f, 1), dtype=np.uint64)
+        if len(qc):
+            lib().orc_igd_count_set_overlaps(self._h, qc, qs, qe, len(qc), min_overlap, hits, f)
+        return hits[:f]
+
+    def count_region_hits(self, qc, qs, qe, min_overlap: int = 1, n_files: Optional[int] = None) -> np.ndarray:
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        f = self.n_files if n_files is None else n_files
+        hits = np.zeros(max(f, 1), dtype=np.uint64)
+        if len(qc):
+            lib().orc_igd_count_region_hits(self._h, qc, qs, qe, len(qc), min_overlap, hits, f)
+        return hits[:f]
+
+    def find_overlaps_regionset(self, qc, qs, qe, min_overlap: int = 1):
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        if len(qc) == 0:
+            z = np.zeros(0, dtype=np.uint32)
+            return z, z
+        n = int(lib().orc_igd_find_overlaps_regionset(self._h, qc, qs, qe, len(qc), min_overlap, _EMPTY32, _EMPTY32, 0))
+        oq, os_ = np.zeros(max(n, 1), dtype=np.uint32), np.zeros(max(n, 1), dtype=np.uint32)
+        lib().orc_igd_find_overlaps_regionset(self._h, qc, qs, qe, len(qc), min_overlap, oq, os_, n)
+        return oq[:n], os_[:n]
+
+    def count_overlaps_per_query(self, qc, qs, qe, min_overlap: int = 1) -> np.ndarray:
+        qc, qs, qe = _u32(qc), _u32(qs), _u32(qe)
+        out = np.zeros(max(len(qc), 1), dtype=np.uint32)
+        if len(qc):
+            lib().orc_igd_count_overlaps_per_query(self._h, qc, qs, qe, len(qc), min_overlap, out)
+        return out[: len(qc)]
+
+
+def lola_contingency(user_hits, universe_hits, user_size: int, universe_size: int):
+    uh = np.ascontiguousarray(user_hits, dtype=np.uint64)
+    vh = np.ascontiguousarray(universe_hits, dtype=np.uint64)
+    f = len(uh)
+    a, b, c, d = (np.zeros(max(f, 1), dtype=np.int64) for _ in range(4))
+    if f:
+        lib().orc_lola_contingency(uh, vh, f, user_size, universe_size, a, b, c, d)
+    return a[:f], b[:f], c[:f], d[:f]
+
+
+class SplitMix64:
+    """splitmix64 stream; identical to orc_splitmix64."""
+
+    MASK = (1 << 64) - 1
+
+    def __init__(self, seed: int):
+        self.s = seed & self.MASK
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & self.MASK
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & self.MASK
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & self.MASK
+        return z ^ (z >> 31)
+
+
+# ---------------------------------------------------------------------------
+# string world (pure Python restatements; small inputs only)
+# ---------------------------------------------------------------------------
+
+
+def _open_text(path: str):
+    """get_dynamic_reader (gtars-core/src/utils.rs:115-126): gz iff extension == 'gz'."""
+    if path.endswith(".gz"):
+        return gzip.open(path, "rt")  # Python's gzip reads concatenated members, like MultiGzDecoder
+    return open(path, "rt")
+
+
+def _rust_lines(f) -> Iterable[str]:
+    """BufRead::lines(): split on \\n, strip one trailing \\r."""
+    for line in f:
+        if line.endswith("\n"):
+            line = line[:-1]
+            if line.endswith("\r"):
+                line = line[:-1]
+        yield line
+
+
+def _parse_u32(s: str) -> Optional[int]:
+    """str::parse::<u32>(): optional leading '+', ASCII digits only, must fit."""
+    t = s[1:] if s.startswith("+") else s
+    if not t or not t.isascii() or not t.isdigit():
+        return None
+    v = int(t)
+    return v if v <= 0xFFFFFFFF else None
+
+
+def _parse_i32(s: str) -> Optional[int]:
+    t = s[1:] if s[:1] in "+-" else s
+    if not t or not t.isascii() or not t.isdigit():
+        return None
+    v = int(s)
+    return v if -(1 << 31) <= v < (1 << 31) else None
+
+
+class RegionSetError(ValueError):
+    pass
+
+
+def read_region_set(path: str, sort: bool = True):
+    """RegionSet::try_from(&Path) (gtars-core/src/models/region_set.rs:52-186)
+    -> list of (chr, start, end, rest) -- sorted like RegionSet::sort (:502-505)."""
+    if not os.path.isfile(path):
+        raise RegionSetError(f"not a file: {path}")
+    regions = []
+    first_line = True
+    with _open_text(path) as f:
+        for line in _rust_lines(f):
+            parts = line.split("\t")
+            if line.startswith("browser") or line.startswith("track") or line.startswith("#"):
+                first_line = False
+                continue
+            if first_line:
+                if len(parts) >= 3 and _parse_u32(parts[1]) is None:
+                    first_line = False
+                    continue
+                first_line = False
+            if len(parts) < 3:
+                raise RegionSetError(f"Error in parsing start position: {parts}")
+            s, e = _parse_u32(parts[1]), _parse_u32(parts[2])
+            if s is None:
+                raise RegionSetError(f"Error in parsing start position: {parts}")
+            if e is None:
+                raise RegionSetError(f"Error in parsing end position: {parts}")
+            rest = "\t".join(parts[3:])
+            regions.append((parts[0], s, e, rest if rest else None))
+    if not regions:
+        raise RegionSetError(f"EmptyRegionSet: {path}")
+    if sort:
+        # stable sort by (chr bytes, start); Rust String Ord is bytewise
+        regions.sort(key=lambda r: (r[0].encode("utf-8"), r[1]))
+    return regions
+
+
+DEFAULT_SPECIALS = ["<unk>", "<pad>", "<mask>", "<cls>", "<eos>", "<bos>", "<sep>"]
+_SPECIAL_SLOTS = ["unk", "pad", "mask", "cls", "eos", "bos", "sep"]  # special_tokens.rs:59-71 order
+
+
+class UniverseError(ValueError):
+    pass
+
+
+class Universe:
+    """gtars-tokenizers/src/universe/mod.rs:35-197."""
+
+    def __init__(self, path: str):
+        with _open_text(path) as f:
+            lines = list(_rust_lines(f))
+        if not lines:
+            raise UniverseError("UnknownUniverseType")
+        first = lines[0]
+        # UniverseFileType::from (universe/utils.rs:7-19)
+        if first.startswith("track"):
+            raise UniverseError("UnknownUniverseType")
+        nparts = len(first.split("\t"))
+        regions: List[str] = []
+        self.names: Optional[Dict[str, str]] = None
+        self.scores: Optional[Dict[str, float]] = None
+        if nparts == 3:
+            for line in lines:
+                parts = line.split()
+                if len(parts) != 3:
+                    raise UniverseError(f"Error parsing line: {line}")
+                regions.append(f"{parts[0]}:{parts[1]}-{parts[2]}")
+        elif nparts >= 5:
+            self.names, self.scores = {}, {}
+            for line in lines:
+                parts = line.split("\t")
+                if len(parts) < 5:
+                    raise UniverseError(f"Error parsing line: {line}")
+                region = f"{parts[0]}:{parts[1]}-{parts[2]}"
+                regions.append(region)
+                self.names[region] = parts[3]
+                self.scores[region] = float(parts[4].strip())
+        else:
+            raise UniverseError("UnknownUniverseType")
+        self.regions = regions
+        # generate_region_string_to_id_map (gtars-core/src/utils.rs:240-252)
+        self.region_to_id: Dict[str, int] = {}
+        for r in regions:
+            if r not in self.region_to_id:
+                self.region_to_id[r] = len(self.region_to_id)
+        # generate_id_to_region_string_map (gtars-core/src/utils.rs:259-271):
+        # current_id only advances when a new id is inserted, so id i <- regions[i]
+        self.id_to_region: Dict[int, str] = {}
+        current_id = 0
+        for r in regions:
+            if current_id not in self.id_to_region:
+                self.id_to_region[current_id] = r
+                current_id += 1
+        self.special_tokens: Optional[List[str]] = None
+
+    def add_token_to_universe(self, region: str):  # universe/mod.rs:51-56
+        new_id = len(self.region_to_id)
+        self.region_to_id[region] = new_id
+        self.id_to_region[new_id] = region
+        self.regions.append(region)
+
+    def add_special_tokens(self, specials: Sequence[str]):  # universe/mod.rs:114-120
+        self.special_tokens = list(specials)
+        for t in specials:
+            self.add_token_to_universe(t)
+
+    def __len__(self):
+        return len(self.region_to_id)
+
+
+class TokenizerConfigError(ValueError):
+    pass
+
+
+def _input_file_type(path: str) -> str:
+    """TokenizerInputFileType::from_path (gtars-tokenizers/src/config.rs:74-95)."""
+    base = os.path.basename(path)
+    stem, ext = os.path.splitext(base)
+    if ext == ".gz":
+        if os.path.splitext(stem)[1] == ".bed":
+            return "bedgz"
+        raise TokenizerConfigError("InvalidFileType")
+    if ext == ".toml":
+        return "toml"
+    if ext == ".bed":
+        return "bed"
+    raise TokenizerConfigError("InvalidFileType")
+
+
+class OracleTokenizer:
+    """gtars-tokenizers/src/tokenizer.rs:36-279 over the C oracle index."""
+
+    def __init__(self, path: str):
+        ftype = _input_file_type(path)
+        specials = dict(zip(_SPECIAL_SLOTS, DEFAULT_SPECIALS))
+        kind = KIND_BITS
+        universe_path = path
+        if ftype == "toml":
+            import tomli
+
+            with open(path, "rb") as f:
+                cfg = tomli.load(f)
+            if "universe" not in cfg or not isinstance(cfg["universe"], str):
+                raise TokenizerConfigError("missing universe")
+            universe_path = os.path.join(os.path.dirname(path), cfg["universe"])
+            for a in cfg.get("special_tokens") or []:
+                if a["name"] not in specials:
+                    raise TokenizerConfigError(f"bad special token name {a['name']}")
+                specials[a["name"]] = a["token"]
+            tt = cfg.get("tokenizer_type")
+            if tt is not None:
+                if tt == "bits":
+                    kind = KIND_BITS
+                elif tt == "ailist":
+                    kind = KIND_AILIST
+                else:
+                    raise TokenizerConfigError(f"unknown tokenizer_type {tt}")
+        self.special = specials
+        self.kind = kind
+        self.universe = Universe(universe_path)
+        self.universe.add_special_tokens([specials[k] for k in _SPECIAL_SLOTS])
+        # create_tokenize_core_from_universe (utils/mod.rs:49-99)
+        self.chrom_ids: Dict[str, int] = {}
+        ch, st, en, va = [], [], [], []
+        for region in self.universe.regions:
+            if region in self.universe.special_tokens:
+                continue
+            parts = region.split(":")
+            se = parts[1].split("-")
+            start, end = _parse_u32(se[0]), _parse_u32(se[1])
+            if start is None or end is None:
+                raise ValueError("unwrap on bad coordinate")
+            cid = self.chrom_ids.setdefault(parts[0], len(self.chrom_ids))
+            ch.append(cid)
+            st.append(start)
+            en.append(end)
+            va.append(self.universe.region_to_id[region])
+        self.index = Index(ch, st, en, va, n_chrom=len(self.chrom_ids), kind=kind)
+
+    UNKNOWN_CHROM = 0xFFFFFFFF
+
+    def _encode_regions(self, regions):
+        qc = [self.chrom_ids.get(r[0], self.UNKNOWN_CHROM) for r in regions]
+        return qc, [r[1] for r in regions], [r[2] for r in regions]
+
+    def encode_regions(self, regions) -> List[int]:
+        """Tokenizer::encode (tokenizer.rs:165-171) on (chr,start,end) tuples."""
+        return [self.universe.region_to_id[t] for t in self.tokenize(regions)]
+
+    def tokenize(self, regions) -> List[str]:
+        """Tokenizer::tokenize (tokenizer.rs:140-163)."""
+        qc, qs, qe = self._encode_regions(regions)
+        _, ids = self.index.tokenize(qc, qs, qe)
+        if len(ids) == 0:
+            return [self.special["unk"]]
+        return [self.universe.id_to_region[int(i)] for i in ids]
+
+    def tokenize_path(self, path: str) -> List[str]:
+        return self.tokenize(read_region_set(path))
+
+    @property
+    def vocab_size(self) -> int:
+        return len(self.universe)
+
+    def token_to_id(self, token: str) -> Optional[int]:
+        return self.universe.region_to_id.get(token)
+
+    def tokenize_fragment_file(self, path: str) -> Dict[str, List[int]]:
+        """tokenize_fragment_file (utils/fragments.rs:61-82)."""
+        res: Dict[str, List[int]] = {}
+        with _open_text(path) as f:
+            for i, line in enumerate(_rust_lines(f)):
+                if line.startswith("#"):
+                    continue
+                parts = line.split()
+                if len(parts) < 5:
+                    raise ValueError(f"Invalid fragment file detected at line: {i}")
+                s, e = _parse_u32(parts[1]), _parse_u32(parts[2])
+                if s is None or e is None:
+                    raise ValueError(f"Failed to parse position at line {i}")
+                ids = self.encode_regions([(parts[0], s, e)])
+                res.setdefault(parts[3], []).extend(ids)
+        return res
+
+
+# --------------------------------------------------------------- IGD front
+
+
+def igd_parse_bed_line(line: str):
+    """Igd::parse_bed_line (gtars-igd/src/igd.rs:850-867)."""
+    fields = line.split("\t")
+    if len(fields) < 3:
+        return None
+    chrom = fields[0]
+    start, end = _parse_i32(fields[1]), _parse_i32(fields[2])
+    if start is None or end is None:
+        return None
+    if len(chrom.encode()) >= 40 or end <= 0:
+        return None
+    score = -1
+    if len(fields) >= 5:
+        v = _parse_i32(fields[4])
+        score = v if v is not None else -1
+    return chrom, start, end, score
+
+
+class OracleIgdDb:
+    """Igd::from_bed_files / from_bed_dir (igd.rs:170-242) with string chroms."""
+
+    def __init__(self, paths: Sequence[str]):
+        self.chrom_ids: Dict[str, int] = {}
+        self.igd = Igd()
+        self.file_info: List[Tuple[str, int, float]] = []
+        for p in paths:
+            try:
+                f = _open_text(p)
+            except OSError:
+                continue
+            count, total_width, has_valid = 0, 0, False
+            file_idx = len(self.file_info)
+            with f:
+                for line in _rust_lines(f):
+                    rec = igd_parse_bed_line(line)
+                    if rec is None:
+                        continue
+                    has_valid = True
+                    chrom, start, end, score = rec
+                    if start >= 0:
+                        cid = self.chrom_ids.setdefault(chrom, len(self.chrom_ids))
+                        self.igd.add(cid, start, end, score, file_idx)
+                        count += 1
+                        total_width += end - start
+            if not has_valid:
+                continue
+            self.file_info.append((os.path.basename(p), count, total_width / count if count else 0.0))
+        self.igd.n_files = len(self.file_info)
+        self.igd.finalize()
+
+    @classmethod
+    def from_bed_dir(cls, d: str) -> "OracleIgdDb":
+        files = sorted(
+            os.path.join(d, n)
+            for n in os.listdir(d)
+            if os.path.isfile(os.path.join(d, n)) and os.path.splitext(n)[1] in (".bed", ".gz")
+        )
+        return cls(files)
+
+    UNKNOWN_CHROM = 0xFFFFFFFF
+
+    def encode(self, regions):
+        qc = [self.chrom_ids.get(r[0], self.UNKNOWN_CHROM) for r in regions]
+        return qc, [r[1] for r in regions], [r[2] for r in regions]
+
+    def count_set_overlaps(self, regions, min_overlap: int = 1):
+        return self.igd.count_set_overlaps(*self.encode(regions), min_overlap=min_overlap, n_files=len(self.file_info))
+
+    def count_region_hits(self, regions, min_overlap: int = 1):
+        return self.igd.count_region_hits(*self.encode(regions), min_overlap=min_overlap, n_files=len(self.file_info))
+
+
+# ------------------------------------------------------------------- gtok
+
+
+def write_tokens_to_gtok(filename: str, tokens: Sequence[int]):
+    """gtars-io/src/gtok.rs:125-165."""
+    parent = os.path.dirname(filename)
+    if parent:
+        os.makedirs(parent, exist_ok=True)
+    small = all(t <= 0xFFFF for t in tokens)
+    with open(filename, "wb") as f:
+        f.write(b"GTOK")
+        f.write(bytes([0x01 if small else 0x02]))
+        fmt = "<H" if small else "<I"
+        for t in tokens:
+            f.write(struct.pack(fmt, t))
+
+
+def read_tokens_from_gtok(filename: str) -> List[int]:
+    """gtars-io/src/gtok.rs:174-210."""
+    with open(filename, "rb") as f:
+        data = f.read()
+    if len(data) < 5 or data[:4] != b"GTOK":
+        raise ValueError("File doesn't appear to be a valid .gtok file.")
+    flag = data[4]
+    body = data[5:]
+    if flag == 0x01:
+        n = len(body) // 2
+        return list(struct.unpack(f"<{n}H", body[: 2 * n]))
+    if flag == 0x02:
+        n = len(body) // 4
+        return list(struct.unpack(f"<{n}I", body[: 4 * n]))
+    raise ValueError("Invalid data format flag found in gtok file")
