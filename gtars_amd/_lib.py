@@ -1,0 +1,147 @@
+"""ctypes binding of libgtars_amd.so (the C ABI in include/gtars_amd.h).
+
+There is no fallback: if the shared library is missing this module raises at
+import time, and every compute call fails with GTARS_ERR_NO_DEVICE when no
+MI355X is visible.  The CPU oracle under ``oracle/`` is never imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgtars_amd.so")
+
+GTARS_OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_IO, ERR_PARSE, ERR_EMPTY, ERR_CONFIG, ERR_INTERNAL = range(1, 10)
+
+KIND_BITS = 0
+KIND_AILIST = 1
+UNKNOWN_CHROM = 0xFFFFFFFF
+
+
+class GtarsError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[gtars_amd status {status}] {message}")
+        self.status = status
+        self.message = message
+
+
+class NoDeviceError(GtarsError):
+    pass
+
+
+class CapacityError(GtarsError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950).  gtars_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+vp, u32, u64, i32, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64
+pp = C.POINTER(C.c_void_p)
+pu64 = C.POINTER(C.c_uint64)
+
+_SIG = {
+    "gtars_last_error": (C.c_char_p, []),
+    "gtars_version": (C.c_char_p, []),
+    "gtars_device_count": (C.c_int, []),
+    "gtars_free": (None, [vp]),
+    "gtars_index_build": (C.c_int, [vp, vp, vp, vp, u64, u32, C.c_int, pp]),
+    "gtars_index_free": (None, [vp]),
+    "gtars_index_len": (u64, [vp]),
+    "gtars_index_n_chrom": (u32, [vp]),
+    "gtars_index_kind": (C.c_int, [vp]),
+    "gtars_index_chrom_len": (u64, [vp, u32]),
+    "gtars_index_stored": (C.c_int, [vp, u32, vp, vp, vp]),
+    "gtars_index_max_len": (u32, [vp, u32]),
+    "gtars_index_n_sublists": (u64, [vp, u32]),
+    "gtars_index_sublist_offsets": (C.c_int, [vp, u32, vp]),
+    "gtars_tokenize_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64, vp]),
+    "gtars_fill_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, vp]),
+    "gtars_tokenize": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
+    "gtars_count_overlaps_device": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, vp]),
+    "gtars_count_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp]),
+    "gtars_any_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp]),
+    "gtars_find_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, pp, pp, pp, pu64]),
+    "gtars_find_overlap_indices": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, pp, pu64]),
+    "gtars_igd_build": (C.c_int, [vp, vp, vp, vp, vp, u64, u32, u32, pp]),
+    "gtars_igd_free": (None, [vp]),
+    "gtars_igd_len": (u64, [vp]),
+    "gtars_igd_n_files": (u32, [vp]),
+    "gtars_igd_total_records": (u64, [vp, i32]),
+    "gtars_igd_count_device": (C.c_int, [vp, vp, vp, vp, u64, i32, C.c_int, vp, vp]),
+    "gtars_igd_count": (C.c_int, [vp, vp, vp, vp, u64, i32, C.c_int, vp]),
+    "gtars_igd_count_per_query": (C.c_int, [vp, vp, vp, vp, u64, i32, vp]),
+    "gtars_igd_find_pairs": (C.c_int, [vp, vp, vp, vp, u64, i32, pp, pp, pu64]),
+    "gtars_lola_contingency_device": (C.c_int, [vp, vp, u64, i64, i64, vp, vp, vp, vp, vp]),
+    "gtars_prof_enable": (None, [C.c_int]),
+    "gtars_prof_reset": (None, []),
+    "gtars_prof_read": (C.c_int, [vp, vp, vp, C.c_int]),
+}
+
+# every symbol include/gtars_amd.h declares must resolve -- fail loudly otherwise
+for _name, (_res, _args) in _SIG.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED_SYMBOLS = tuple(_SIG)
+
+
+def last_error() -> str:
+    return (lib.gtars_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(status: int):
+    if status == GTARS_OK:
+        return
+    msg = last_error()
+    if status == ERR_NO_DEVICE:
+        raise NoDeviceError(status, msg)
+    if status == ERR_CAPACITY:
+        raise CapacityError(status, msg)
+    if status == ERR_IO:
+        raise FileNotFoundError(msg)
+    if status in (ERR_PARSE, ERR_EMPTY, ERR_CONFIG, ERR_INVALID_ARG):
+        raise ValueError(msg)
+    raise GtarsError(status, msg)
+
+
+def device_count() -> int:
+    return int(lib.gtars_device_count())
+
+
+def as_u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def ptr(a: np.ndarray):
+    return C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
+
+
+def take_u32(p: C.c_void_p, n: int) -> np.ndarray:
+    """Copy a library-allocated u32 array into numpy and free it."""
+    try:
+        if n == 0 or not p.value:
+            return np.zeros(0, dtype=np.uint32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n,)).copy()
+    finally:
+        if p.value:
+            lib.gtars_free(p)
+
+
+def prof_read():
+    cap = 64
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    launches = (C.c_uint64 * cap)()
+    n = lib.gtars_prof_read(C.cast(names, vp), C.cast(ms, vp), C.cast(launches, vp), cap)
+    return {names[i].decode(): {"total_ms": ms[i], "launches": int(launches[i])} for i in range(min(n, cap))}

@@ -1,0 +1,904 @@
+// api.hip -- C ABI of the integer-level engine: index / IGD handles, host and
+// device entry points (declared in include/gtars_amd.h).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <numeric>
+
+#include "common.h"
+
+namespace gtars {
+
+// ------------------------------------------------------------------- errors
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+gtars_status fail(gtars_status st, const std::string &msg) {
+    g_last_error = msg;
+    return st;
+}
+
+gtars_status hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    g_last_error = buf;
+    (void)hipGetLastError();
+    return GTARS_ERR_HIP;
+}
+
+gtars_status require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(GTARS_ERR_NO_DEVICE,
+                    "no HIP device available: libgtars_amd has no CPU fallback (the oracle under oracle/ is "
+                    "test infrastructure, not a product path)");
+    }
+    return GTARS_OK;
+}
+
+// ---------------------------------------------------------------- workspace
+gtars_status Workspace::reserve(size_t need) {
+    int dev = 0;
+    GT_HIP(hipGetDevice(&dev));
+    if (ptr && device == dev && bytes >= need) return GTARS_OK;
+    if (ptr) {
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    size_t want = std::max<size_t>(need, 1 << 20);
+    want = (want + (1 << 20) - 1) & ~(size_t)((1 << 20) - 1);
+    GT_HIP(hipMalloc(&ptr, want));
+    bytes = want;
+    device = dev;
+    return GTARS_OK;
+}
+
+Workspace::~Workspace() {
+    // Process teardown order vs. the HIP runtime is not defined; leaking at
+    // exit is harmless, freeing after runtime shutdown is not.
+}
+
+Workspace &tls_workspace(int slot) {
+    static thread_local Workspace ws[4];
+    return ws[slot & 3];
+}
+
+// ---------------------------------------------------------------- profiling
+struct ProfEntry {
+    std::string name;
+    double total_ms = 0;
+    u64 launches = 0;
+};
+struct PendingEvent {
+    int entry;
+    hipEvent_t e0, e1;
+};
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<ProfEntry> g_prof_entries;
+static thread_local std::vector<PendingEvent> g_prof_pending;
+
+static int prof_entry(const char *name) {
+    for (size_t i = 0; i < g_prof_entries.size(); ++i)
+        if (g_prof_entries[i].name == name) return (int)i;
+    g_prof_entries.push_back(ProfEntry{name, 0, 0});
+    return (int)g_prof_entries.size() - 1;
+}
+
+ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), st(s) {
+    on = g_prof_on;
+    if (!on) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        on = false;
+        return;
+    }
+    (void)hipEventRecord(e0, st);
+}
+
+ProfScope::~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e1, st);
+    g_prof_pending.push_back(PendingEvent{prof_entry(name), e0, e1});
+}
+
+static void prof_drain() {
+    for (auto &p : g_prof_pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            g_prof_entries[p.entry].total_ms += ms;
+            g_prof_entries[p.entry].launches += 1;
+        }
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    g_prof_pending.clear();
+}
+
+// -------------------------------------------------------------- device bufs
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    gtars_status upload(const std::vector<T> &h) {
+        n = h.size();
+        GT_HIP(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
+        if (n) GT_HIP(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        return GTARS_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct ScopedDev {
+    void *p = nullptr;
+    ~ScopedDev() {
+        if (p) (void)hipFree(p);
+    }
+    gtars_status alloc(size_t bytes) {
+        GT_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        return GTARS_OK;
+    }
+    template <class T>
+    T *as() {
+        return (T *)p;
+    }
+};
+
+}  // namespace gtars
+
+using namespace gtars;
+
+// ================================================================== handles
+
+struct gtars_index {
+    int kind = 0;
+    u32 n_chrom = 0;
+    u64 n = 0;
+    int device = 0;
+    // host mirrors (small: metadata only) + full host copy of the stored order
+    std::vector<u32> h_starts, h_ends, h_vals, h_max_ends;
+    std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
+    DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
+    IndexView view() const {
+        IndexView v;
+        v.starts = starts.p;
+        v.ends = ends.p;
+        v.vals = vals.p;
+        v.max_ends = max_ends.p;
+        v.chrom_off = chrom_off.p;
+        v.chrom_aux = chrom_aux.p;
+        v.chrom_sub = chrom_sub.p;
+        v.sub_off = sub_off.p;
+        v.n_chrom = n_chrom;
+        v.n = (u32)n;
+        return v;
+    }
+};
+
+struct gtars_igd {
+    u32 n_chrom = 0, n_files = 0;
+    u64 n = 0;
+    std::vector<i32> h_starts, h_ends;
+    DevBuf<i32> starts, ends, values, chrom_maxlen;
+    DevBuf<u32> files, chrom_off;
+    IgdView view() const {
+        IgdView v;
+        v.starts = starts.p;
+        v.ends = ends.p;
+        v.files = files.p;
+        v.values = values.p;
+        v.chrom_off = chrom_off.p;
+        v.chrom_maxlen = chrom_maxlen.p;
+        v.n_chrom = n_chrom;
+        v.n = (u32)n;
+        v.n_files = n_files;
+        return v;
+    }
+};
+
+extern "C" {
+
+const char *gtars_last_error(void) { return g_last_error.c_str(); }
+const char *gtars_version(void) { return "gtars_amd 0.1.0 (gfx950)"; }
+
+int gtars_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void gtars_free(void *p) { free(p); }
+
+void gtars_prof_enable(int on) { g_prof_on = on != 0; }
+void gtars_prof_reset(void) {
+    prof_drain();
+    g_prof_entries.clear();
+}
+int gtars_prof_read(const char **names, double *total_ms, uint64_t *launches, int cap) {
+    prof_drain();
+    int n = (int)g_prof_entries.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = g_prof_entries[i].name.c_str();
+        if (total_ms) total_ms[i] = g_prof_entries[i].total_ms;
+        if (launches) launches[i] = g_prof_entries[i].launches;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------- index build
+
+gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, const uint32_t *end,
+                               const uint32_t *val, uint64_t n, uint32_t n_chrom, int kind,
+                               gtars_index_t **out) {
+    if (!out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (kind != GTARS_KIND_BITS && kind != GTARS_KIND_AILIST)
+        return fail(GTARS_ERR_INVALID_ARG, "kind must be GTARS_KIND_BITS or GTARS_KIND_AILIST");
+    if (n && (!chrom || !start || !end)) return fail(GTARS_ERR_INVALID_ARG, "NULL interval arrays");
+    if (n >= 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "too many intervals for a u32-indexed index");
+    gtars_status st = require_device();
+    if (st) return st;
+
+    // bucket by chromosome, keeping input order (utils/mod.rs:57-87)
+    std::vector<u32> cnt(n_chrom + 1, 0);
+    for (u64 i = 0; i < n; ++i) {
+        if (chrom[i] >= n_chrom) return fail(GTARS_ERR_INVALID_ARG, "interval chromosome id >= n_chrom");
+        cnt[chrom[i] + 1]++;
+    }
+    std::vector<u32> off(n_chrom + 1, 0);
+    for (u32 c = 0; c < n_chrom; ++c) off[c + 1] = off[c] + cnt[c + 1];
+    std::vector<u32> perm(n);
+    {
+        std::vector<u32> fillp(off.begin(), off.end() - 1);
+        for (u64 i = 0; i < n; ++i) perm[fillp[chrom[i]]++] = (u32)i;
+    }
+
+    auto *ix = new gtars_index();
+    ix->kind = kind;
+    ix->n_chrom = n_chrom;
+    ix->n = n;
+    ix->h_chrom_off = off;
+    ix->h_starts.resize(n);
+    ix->h_ends.resize(n);
+    ix->h_vals.resize(n);
+    ix->h_chrom_aux.assign(n_chrom, 0);
+
+    if (kind == GTARS_KIND_BITS) {
+        for (u32 c = 0; c < n_chrom; ++c) {
+            // Bits::build: stable sort by (start, end) (bits.rs:105, interval.rs:18-31)
+            std::stable_sort(perm.begin() + off[c], perm.begin() + off[c + 1], [&](u32 a, u32 b) {
+                if (start[a] != start[b]) return start[a] < start[b];
+                return end[a] < end[b];
+            });
+            u32 max_len = 0;
+            for (u32 p = off[c]; p < off[c + 1]; ++p) {
+                const u32 i = perm[p];
+                const u32 len = end[i] >= start[i] ? end[i] - start[i] : 0;  // checked_sub -> 0
+                max_len = std::max(max_len, len);
+            }
+            ix->h_chrom_aux[c] = max_len;
+        }
+        for (u64 p = 0; p < n; ++p) {
+            const u32 i = perm[p];
+            ix->h_starts[p] = start[i];
+            ix->h_ends[p] = end[i];
+            ix->h_vals[p] = val ? val[i] : i;
+        }
+    } else {
+        // AIList::build (ailist.rs:105-151) + decompose (ailist.rs:198-236)
+        ix->h_max_ends.resize(n);
+        ix->h_chrom_sub.assign(n_chrom + 1, 0);
+        const size_t min_cov = 10;
+        u64 filled = 0;
+        for (u32 c = 0; c < n_chrom; ++c) {
+            ix->h_chrom_sub[c] = (u32)ix->h_sub_off.size();
+            std::stable_sort(perm.begin() + off[c], perm.begin() + off[c + 1],
+                             [&](u32 a, u32 b) { return start[a] < start[b]; });
+            std::vector<u32> cur(perm.begin() + off[c], perm.begin() + off[c + 1]), l2;
+            if (cur.empty()) {
+                ix->h_sub_off.push_back((u32)filled);  // terminator only
+                continue;
+            }
+            ix->h_sub_off.push_back((u32)filled);
+            for (;;) {
+                l2.clear();
+                const u64 first = filled;
+                for (size_t idx = 0; idx < cur.size(); ++idx) {
+                    const u32 i = cur[idx];
+                    size_t count = 0;
+                    for (size_t k = 1; k < min_cov * 2; ++k) {
+                        if (idx + k >= cur.size()) break;
+                        if (end[i] > end[cur[idx + k]]) count++;
+                    }
+                    if (count >= min_cov) {
+                        l2.push_back(i);
+                    } else {
+                        ix->h_starts[filled] = start[i];
+                        ix->h_ends[filled] = end[i];
+                        ix->h_vals[filled] = val ? val[i] : i;
+                        filled++;
+                    }
+                }
+                u32 mx = 0;
+                for (u64 p = first; p < filled; ++p) {
+                    mx = std::max(mx, ix->h_ends[p]);
+                    ix->h_max_ends[p] = mx;
+                }
+                cur.swap(l2);
+                if (cur.empty()) break;
+                ix->h_sub_off.push_back((u32)filled);
+            }
+            ix->h_sub_off.push_back((u32)filled);  // terminator for this chromosome
+        }
+        // chrom_sub[c]..chrom_sub[c+1] spans the boundaries incl. terminator
+        ix->h_chrom_sub[n_chrom] = (u32)ix->h_sub_off.size();
+    }
+
+    GT_HIP(hipGetDevice(&ix->device));
+    st = ix->starts.upload(ix->h_starts);
+    if (!st) st = ix->ends.upload(ix->h_ends);
+    if (!st) st = ix->vals.upload(ix->h_vals);
+    if (!st) st = ix->max_ends.upload(ix->h_max_ends);
+    if (!st) st = ix->chrom_off.upload(ix->h_chrom_off);
+    if (!st) st = ix->chrom_aux.upload(ix->h_chrom_aux);
+    if (!st) st = ix->chrom_sub.upload(ix->h_chrom_sub);
+    if (!st) st = ix->sub_off.upload(ix->h_sub_off);
+    if (st) {
+        gtars_index_free(ix);
+        return st;
+    }
+    *out = ix;
+    return GTARS_OK;
+}
+
+void gtars_index_free(gtars_index_t *ix) {
+    if (!ix) return;
+    ix->starts.release();
+    ix->ends.release();
+    ix->vals.release();
+    ix->max_ends.release();
+    ix->chrom_off.release();
+    ix->chrom_aux.release();
+    ix->chrom_sub.release();
+    ix->sub_off.release();
+    delete ix;
+}
+
+uint64_t gtars_index_len(const gtars_index_t *ix) { return ix ? ix->n : 0; }
+uint32_t gtars_index_n_chrom(const gtars_index_t *ix) { return ix ? ix->n_chrom : 0; }
+int gtars_index_kind(const gtars_index_t *ix) { return ix ? ix->kind : -1; }
+
+uint64_t gtars_index_chrom_len(const gtars_index_t *ix, uint32_t c) {
+    if (!ix || c >= ix->n_chrom) return 0;
+    return ix->h_chrom_off[c + 1] - ix->h_chrom_off[c];
+}
+
+gtars_status gtars_index_stored(const gtars_index_t *ix, uint32_t c, uint32_t *start, uint32_t *end,
+                                uint32_t *val) {
+    if (!ix) return fail(GTARS_ERR_INVALID_ARG, "NULL index");
+    if (c >= ix->n_chrom) return GTARS_OK;
+    const u32 lo = ix->h_chrom_off[c], hi = ix->h_chrom_off[c + 1];
+    // read back from the device so that tests see what the kernels see
+    if (hi > lo) {
+        if (start) GT_HIP(hipMemcpy(start, ix->starts.p + lo, (hi - lo) * 4, hipMemcpyDeviceToHost));
+        if (end) GT_HIP(hipMemcpy(end, ix->ends.p + lo, (hi - lo) * 4, hipMemcpyDeviceToHost));
+        if (val) GT_HIP(hipMemcpy(val, ix->vals.p + lo, (hi - lo) * 4, hipMemcpyDeviceToHost));
+    }
+    return GTARS_OK;
+}
+
+uint32_t gtars_index_max_len(const gtars_index_t *ix, uint32_t c) {
+    if (!ix || c >= ix->n_chrom || ix->kind != GTARS_KIND_BITS) return 0;
+    return ix->h_chrom_aux[c];
+}
+
+uint64_t gtars_index_n_sublists(const gtars_index_t *ix, uint32_t c) {
+    if (!ix || c >= ix->n_chrom || ix->kind != GTARS_KIND_AILIST) return 0;
+    const u32 nb = ix->h_chrom_sub[c + 1] - ix->h_chrom_sub[c];
+    return nb ? nb - 1 : 0;
+}
+
+gtars_status gtars_index_sublist_offsets(const gtars_index_t *ix, uint32_t c, uint64_t *out) {
+    if (!ix || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    if (c >= ix->n_chrom || ix->kind != GTARS_KIND_AILIST) return GTARS_OK;
+    const u32 b = ix->h_chrom_sub[c], e = ix->h_chrom_sub[c + 1];
+    for (u32 h = b; h + 1 < e; ++h) out[h - b] = ix->h_sub_off[h] - ix->h_chrom_off[c];
+    return GTARS_OK;
+}
+
+// ----------------------------------------------------------------- queries
+
+static gtars_status check_query_args(const void *ix, const void *a, const void *b, const void *c, u64 nq) {
+    if (!ix) return fail(GTARS_ERR_INVALID_ARG, "NULL handle");
+    if (nq && (!a || !b || !c)) return fail(GTARS_ERR_INVALID_ARG, "NULL query arrays");
+    return GTARS_OK;
+}
+
+gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
+                                   const uint32_t *d_qe, uint64_t nq, uint64_t *d_offsets, uint32_t *d_ids,
+                                   uint64_t ids_capacity, uint64_t *total_hits, void *stream) {
+    gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
+    if (st) return st;
+    if (!d_offsets) return fail(GTARS_ERR_INVALID_ARG, "d_offsets is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace &ws = tls_workspace(0);
+    const size_t scan_bytes = enumerate_fused_ws_bytes(nq);
+    const size_t ctl_off = (scan_bytes + 255) & ~(size_t)255;
+    st = ws.reserve(ctl_off + 256);
+    if (st) return st;
+    u64 *d_total = (u64 *)((char *)ws.ptr + ctl_off);
+    u32 *d_err = (u32 *)((char *)ws.ptr + ctl_off + 8);
+    GT_HIP(hipMemsetAsync(d_total, 0, 16, s));
+    EnumOut out{d_offsets, d_ids, nullptr, nullptr, d_ids ? ids_capacity : 0};
+    st = launch_enumerate_fused(ix->view(), ix->kind, d_qc, d_qs, d_qe, nq, 0, 0, out, d_total, d_err,
+                                ws.ptr, ctl_off, s);
+    if (st) return st;
+    if (total_hits) {
+        u64 host[2] = {0, 0};
+        GT_HIP(hipMemcpyAsync(host, d_total, 16, hipMemcpyDeviceToHost, s));
+        GT_HIP(hipStreamSynchronize(s));
+        *total_hits = host[0];
+        if ((u32)host[1]) return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
+        if (d_ids && host[0] > ids_capacity)
+            return fail(GTARS_ERR_CAPACITY, "ids buffer too small: need " + std::to_string(host[0]));
+    }
+    return GTARS_OK;
+}
+
+gtars_status gtars_fill_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
+                               const uint32_t *d_qe, uint64_t nq, const uint64_t *d_offsets,
+                               uint32_t *d_ids, void *stream) {
+    gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
+    if (st) return st;
+    if (!d_offsets || !d_ids) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
+    return launch_fill(ix->view(), ix->kind, d_qc, d_qs, d_qe, nq, 0, 0, d_offsets, d_ids, nullptr, nullptr,
+                       (hipStream_t)stream);
+}
+
+gtars_status gtars_count_overlaps_device(const gtars_index_t *ix, const uint32_t *d_qc,
+                                         const uint32_t *d_qs, const uint32_t *d_qe, uint64_t nq,
+                                         int has_min, int32_t min_overlap, uint32_t *d_counts,
+                                         void *stream) {
+    gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
+    if (st) return st;
+    if (nq && !d_counts) return fail(GTARS_ERR_INVALID_ARG, "d_counts is NULL");
+    return launch_count(ix->view(), ix->kind, d_qc, d_qs, d_qe, nq, has_min, min_overlap, d_counts, nullptr,
+                        (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// host-pointer helpers -------------------------------------------------------
+
+struct DevQueries {
+    ScopedDev buf;
+    u32 *c = nullptr, *s = nullptr, *e = nullptr;
+    gtars_status upload(const u32 *qc, const u32 *qs, const u32 *qe, u64 nq) {
+        const size_t pad = ((size_t)nq * 4 + 255) & ~(size_t)255;
+        gtars_status st = buf.alloc(pad * 3);
+        if (st) return st;
+        c = (u32 *)buf.p;
+        s = (u32 *)((char *)buf.p + pad);
+        e = (u32 *)((char *)buf.p + 2 * pad);
+        if (nq) {
+            GT_HIP(hipMemcpy(c, qc, nq * 4, hipMemcpyHostToDevice));
+            GT_HIP(hipMemcpy(s, qs, nq * 4, hipMemcpyHostToDevice));
+            GT_HIP(hipMemcpy(e, qe, nq * 4, hipMemcpyHostToDevice));
+        }
+        return GTARS_OK;
+    }
+};
+
+template <class T>
+static T *host_alloc(u64 n) {
+    return (T *)malloc(std::max<u64>(n, 1) * sizeof(T));
+}
+
+// fused enumerate into library-allocated host arrays
+static gtars_status enumerate_to_host(const gtars_index_t *ix, const u32 *qc, const u32 *qs, const u32 *qe,
+                                      u64 nq, int has_min, i32 min_overlap, u64 *offsets, u32 **out_val,
+                                      u32 **out_start, u32 **out_end, u64 *out_n) {
+    gtars_status st = require_device();
+    if (st) return st;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d_off, d_ctl, d_ws;
+    st = d_off.alloc((nq + 1) * 8);
+    if (st) return st;
+    st = d_ctl.alloc(16);
+    if (st) return st;
+    const size_t wsb = enumerate_fused_ws_bytes(nq);
+    st = d_ws.alloc(wsb);
+    if (st) return st;
+    GT_HIP(hipMemset(d_ctl.p, 0, 16));
+    // pass 1: offsets + total only (no payload buffers)
+    EnumOut o1{d_off.as<u64>(), nullptr, nullptr, nullptr, 0};
+    st = launch_enumerate_fused(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, o1,
+                                d_ctl.as<u64>(), (u32 *)((char *)d_ctl.p + 8), d_ws.p, wsb, nullptr);
+    if (st) return st;
+    u64 host[2] = {0, 0};
+    GT_HIP(hipMemcpy(host, d_ctl.p, 16, hipMemcpyDeviceToHost));
+    if ((u32)host[1]) return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
+    const u64 h = host[0];
+    if (offsets) GT_HIP(hipMemcpy(offsets, d_off.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
+    if (out_n) *out_n = h;
+    const int nout = (out_val ? 1 : 0) + (out_start ? 1 : 0) + (out_end ? 1 : 0);
+    if (nout) {
+        ScopedDev d_out;
+        const size_t pad = ((size_t)h * 4 + 255) & ~(size_t)255;
+        st = d_out.alloc(pad * 3);
+        if (st) return st;
+        u32 *dv = out_val ? (u32 *)d_out.p : nullptr;
+        u32 *ds = out_start ? (u32 *)((char *)d_out.p + pad) : nullptr;
+        u32 *de = out_end ? (u32 *)((char *)d_out.p + 2 * pad) : nullptr;
+        st = launch_fill(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d_off.as<u64>(), dv, ds,
+                         de, nullptr);
+        if (st) return st;
+        GT_HIP(hipDeviceSynchronize());
+        auto fetch = [&](u32 **dst, u32 *src) -> gtars_status {
+            if (!dst) return GTARS_OK;
+            *dst = host_alloc<u32>(h);
+            if (!*dst) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+            if (h) GT_HIP(hipMemcpy(*dst, src, h * 4, hipMemcpyDeviceToHost));
+            return GTARS_OK;
+        };
+        if ((st = fetch(out_val, dv))) return st;
+        if ((st = fetch(out_start, ds))) return st;
+        if ((st = fetch(out_end, de))) return st;
+    }
+    return GTARS_OK;
+}
+
+extern "C" {
+
+gtars_status gtars_tokenize(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
+                            const uint32_t *qe, uint64_t nq, uint64_t *offsets, uint32_t **out_ids,
+                            uint64_t *out_n) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (!out_ids || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
+    *out_ids = nullptr;
+    *out_n = 0;
+    // single fused pass with a guessed capacity; second pass only on overflow
+    st = require_device();
+    if (st) return st;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d_off, d_ids;
+    st = d_off.alloc((nq + 1) * 8);
+    if (st) return st;
+    u64 cap = nq * 2 + 1024;
+    st = d_ids.alloc(cap * 4);
+    if (st) return st;
+    u64 total = 0;
+    st = gtars_tokenize_device(ix, q.c, q.s, q.e, nq, d_off.as<u64>(), d_ids.as<u32>(), cap, &total, nullptr);
+    if (st == GTARS_ERR_CAPACITY) {
+        ScopedDev big;
+        st = big.alloc(total * 4);
+        if (st) return st;
+        st = gtars_fill_device(ix, q.c, q.s, q.e, nq, d_off.as<u64>(), big.as<u32>(), nullptr);
+        if (st) return st;
+        GT_HIP(hipDeviceSynchronize());
+        std::swap(d_ids.p, big.p);
+    } else if (st) {
+        return st;
+    }
+    if (offsets) GT_HIP(hipMemcpy(offsets, d_off.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
+    *out_ids = host_alloc<u32>(total);
+    if (!*out_ids) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    if (total) GT_HIP(hipMemcpy(*out_ids, d_ids.p, total * 4, hipMemcpyDeviceToHost));
+    *out_n = total;
+    return GTARS_OK;
+}
+
+gtars_status gtars_count_overlaps(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
+                                  const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
+                                  uint32_t *counts) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (nq && !counts) return fail(GTARS_ERR_INVALID_ARG, "counts is NULL");
+    st = require_device();
+    if (st) return st;
+    if (!nq) return GTARS_OK;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d;
+    st = d.alloc(nq * 4);
+    if (st) return st;
+    st = launch_count(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d.as<u32>(), nullptr, nullptr);
+    if (st) return st;
+    GT_HIP(hipMemcpy(counts, d.p, nq * 4, hipMemcpyDeviceToHost));
+    return GTARS_OK;
+}
+
+gtars_status gtars_any_overlaps(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
+                                const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
+                                uint8_t *out) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (nq && !out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
+    st = require_device();
+    if (st) return st;
+    if (!nq) return GTARS_OK;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d;
+    st = d.alloc(nq);
+    if (st) return st;
+    st = launch_count(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, nullptr, d.as<u8>(), nullptr);
+    if (st) return st;
+    GT_HIP(hipMemcpy(out, d.p, nq, hipMemcpyDeviceToHost));
+    return GTARS_OK;
+}
+
+gtars_status gtars_find_overlaps(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
+                                 const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
+                                 uint64_t *offsets, uint32_t **out_start, uint32_t **out_end,
+                                 uint32_t **out_val, uint64_t *out_n) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (out_start) *out_start = nullptr;
+    if (out_end) *out_end = nullptr;
+    if (out_val) *out_val = nullptr;
+    return enumerate_to_host(ix, qc, qs, qe, nq, has_min, min_overlap, offsets, out_val, out_start, out_end,
+                             out_n);
+}
+
+gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
+                                        const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
+                                        uint64_t *offsets, uint32_t **out_idx, uint64_t *out_n) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (!out_idx || !out_n || !offsets) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
+    *out_idx = nullptr;
+    *out_n = 0;
+    st = require_device();
+    if (st) return st;
+    // Every source row that shares a hit's coordinates is itself a hit (same
+    // overlap, same filter), so "all rows sharing coordinates, sorted, dedup"
+    // (indexed_region_set.rs:246-263) == the hit source indices, sorted.
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d_off, d_ctl, d_ws, d_cnt, d_off2;
+    if ((st = d_off.alloc((nq + 1) * 8))) return st;
+    if ((st = d_off2.alloc((nq + 1) * 8))) return st;
+    if ((st = d_ctl.alloc(16))) return st;
+    if ((st = d_cnt.alloc(nq * 4))) return st;
+    const size_t wsb = std::max(enumerate_fused_ws_bytes(nq), scan_ws_bytes(nq));
+    if ((st = d_ws.alloc(wsb))) return st;
+    GT_HIP(hipMemset(d_ctl.p, 0, 16));
+    EnumOut o1{d_off.as<u64>(), nullptr, nullptr, nullptr, 0};
+    st = launch_enumerate_fused(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, o1,
+                                d_ctl.as<u64>(), (u32 *)((char *)d_ctl.p + 8), d_ws.p, wsb, nullptr);
+    if (st) return st;
+    u64 host[2] = {0, 0};
+    GT_HIP(hipMemcpy(host, d_ctl.p, 16, hipMemcpyDeviceToHost));
+    if ((u32)host[1]) return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
+    const u64 h = host[0];
+    ScopedDev d_val;
+    if ((st = d_val.alloc(h * 4))) return st;
+    st = launch_fill(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d_off.as<u64>(),
+                     d_val.as<u32>(), nullptr, nullptr, nullptr);
+    if (st) return st;
+    st = launch_sort_unique_segments(d_val.as<u32>(), d_off.as<u64>(), nq, d_cnt.as<u32>(), nullptr);
+    if (st) return st;
+    st = launch_scan_u32_to_u64(d_cnt.as<u32>(), nq, d_off2.as<u64>(), d_ws.p, wsb, nullptr);
+    if (st) return st;
+    // compact on the host side of the copy: segments are already contiguous
+    // when nothing was de-duplicated (the overwhelmingly common case)
+    std::vector<u64> off1(nq + 1), off2(nq + 1);
+    GT_HIP(hipMemcpy(off1.data(), d_off.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
+    GT_HIP(hipMemcpy(off2.data(), d_off2.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
+    std::vector<u32> vals(h);
+    if (h) GT_HIP(hipMemcpy(vals.data(), d_val.p, h * 4, hipMemcpyDeviceToHost));
+    const u64 h2 = off2[nq];
+    u32 *res = host_alloc<u32>(h2);
+    if (!res) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    for (u64 qi = 0; qi < nq; ++qi) {
+        const u64 len = off2[qi + 1] - off2[qi];
+        if (len) memcpy(res + off2[qi], vals.data() + off1[qi], len * 4);
+    }
+    memcpy(offsets, off2.data(), (nq + 1) * 8);
+    *out_idx = res;
+    *out_n = h2;
+    return GTARS_OK;
+}
+
+// ---------------------------------------------------------------------- IGD
+
+gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const int32_t *end,
+                             const int32_t *value, const uint32_t *file_idx, uint64_t n, uint32_t n_chrom,
+                             uint32_t n_files, gtars_igd_t **out) {
+    if (!out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n && (!chrom || !start || !end || !file_idx)) return fail(GTARS_ERR_INVALID_ARG, "NULL record arrays");
+    gtars_status st = require_device();
+    if (st) return st;
+    // Igd::add drop rule (igd.rs:114-116)
+    std::vector<u32> keep;
+    keep.reserve(n);
+    for (u64 i = 0; i < n; ++i) {
+        if (start[i] < 0 || end[i] < 0 || start[i] >= end[i]) continue;
+        if (chrom[i] >= n_chrom) return fail(GTARS_ERR_INVALID_ARG, "record chromosome id >= n_chrom");
+        if (file_idx[i] >= n_files) return fail(GTARS_ERR_INVALID_ARG, "record file_idx >= n_files");
+        keep.push_back((u32)i);
+    }
+    if (keep.size() >= 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "too many records");
+    // chromosome-major, then start, ties in insertion order (finalize: stable sort by start, igd.rs:157-167)
+    std::stable_sort(keep.begin(), keep.end(), [&](u32 a, u32 b) {
+        if (chrom[a] != chrom[b]) return chrom[a] < chrom[b];
+        return start[a] < start[b];
+    });
+    auto *g = new gtars_igd();
+    g->n_chrom = n_chrom;
+    g->n_files = n_files;
+    g->n = keep.size();
+    std::vector<i32> hv(g->n), hml(n_chrom, 0);
+    std::vector<u32> hf(g->n), hoff(n_chrom + 1, 0);
+    g->h_starts.resize(g->n);
+    g->h_ends.resize(g->n);
+    for (u64 p = 0; p < g->n; ++p) {
+        const u32 i = keep[p];
+        g->h_starts[p] = start[i];
+        g->h_ends[p] = end[i];
+        hv[p] = value ? value[i] : 0;
+        hf[p] = file_idx[i];
+        hoff[chrom[i] + 1]++;
+        hml[chrom[i]] = std::max(hml[chrom[i]], end[i] - start[i]);
+    }
+    for (u32 c = 0; c < n_chrom; ++c) hoff[c + 1] += hoff[c];
+    st = g->starts.upload(g->h_starts);
+    if (!st) st = g->ends.upload(g->h_ends);
+    if (!st) st = g->values.upload(hv);
+    if (!st) st = g->files.upload(hf);
+    if (!st) st = g->chrom_off.upload(hoff);
+    if (!st) st = g->chrom_maxlen.upload(hml);
+    if (st) {
+        gtars_igd_free(g);
+        return st;
+    }
+    *out = g;
+    return GTARS_OK;
+}
+
+void gtars_igd_free(gtars_igd_t *g) {
+    if (!g) return;
+    g->starts.release();
+    g->ends.release();
+    g->values.release();
+    g->files.release();
+    g->chrom_off.release();
+    g->chrom_maxlen.release();
+    delete g;
+}
+
+uint64_t gtars_igd_len(const gtars_igd_t *g) { return g ? g->n : 0; }
+uint32_t gtars_igd_n_files(const gtars_igd_t *g) { return g ? g->n_files : 0; }
+
+uint64_t gtars_igd_total_records(const gtars_igd_t *g, int32_t nbp) {
+    if (!g) return 0;
+    if (nbp <= 0) nbp = 16384;
+    u64 t = 0;
+    for (u64 i = 0; i < g->n; ++i) t += (u64)((g->h_ends[i] - 1) / nbp - g->h_starts[i] / nbp + 1);
+    return t;
+}
+
+gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, const uint32_t *d_qs,
+                                    const uint32_t *d_qe, uint64_t nq, int32_t min_overlap, int binary,
+                                    uint64_t *d_hits, void *stream) {
+    gtars_status st = check_query_args(g, d_qc, d_qs, d_qe, nq);
+    if (st) return st;
+    if (min_overlap < 1) return fail(GTARS_ERR_INVALID_ARG, "IGD queries are defined for min_overlap >= 1");
+    if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
+    return launch_igd_count(g->view(), d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
+}
+
+gtars_status gtars_igd_count(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+                             uint64_t nq, int32_t min_overlap, int binary, uint64_t *hits) {
+    gtars_status st = check_query_args(g, qc, qs, qe, nq);
+    if (st) return st;
+    if (!hits && g->n_files) return fail(GTARS_ERR_INVALID_ARG, "hits is NULL");
+    st = require_device();
+    if (st) return st;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d;
+    st = d.alloc((size_t)std::max<u32>(g->n_files, 1) * 8);
+    if (st) return st;
+    st = gtars_igd_count_device(g, q.c, q.s, q.e, nq, min_overlap, binary, d.as<u64>(), nullptr);
+    if (st) return st;
+    if (g->n_files) GT_HIP(hipMemcpy(hits, d.p, (size_t)g->n_files * 8, hipMemcpyDeviceToHost));
+    return GTARS_OK;
+}
+
+gtars_status gtars_igd_count_per_query(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs,
+                                       const uint32_t *qe, uint64_t nq, int32_t min_overlap,
+                                       uint32_t *counts) {
+    gtars_status st = check_query_args(g, qc, qs, qe, nq);
+    if (st) return st;
+    if (min_overlap < 1) return fail(GTARS_ERR_INVALID_ARG, "IGD queries are defined for min_overlap >= 1");
+    st = require_device();
+    if (st) return st;
+    if (!nq) return GTARS_OK;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d;
+    st = d.alloc(nq * 4);
+    if (st) return st;
+    st = launch_igd_count_per_query(g->view(), q.c, q.s, q.e, nq, min_overlap, d.as<u32>(), nullptr);
+    if (st) return st;
+    GT_HIP(hipMemcpy(counts, d.p, nq * 4, hipMemcpyDeviceToHost));
+    return GTARS_OK;
+}
+
+gtars_status gtars_igd_find_pairs(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs,
+                                  const uint32_t *qe, uint64_t nq, int32_t min_overlap, uint32_t **out_q,
+                                  uint32_t **out_s, uint64_t *out_n) {
+    gtars_status st = check_query_args(g, qc, qs, qe, nq);
+    if (st) return st;
+    if (!out_q || !out_s || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
+    *out_q = *out_s = nullptr;
+    *out_n = 0;
+    if (min_overlap < 1) return fail(GTARS_ERR_INVALID_ARG, "IGD queries are defined for min_overlap >= 1");
+    st = require_device();
+    if (st) return st;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d_cnt, d_off, d_ws;
+    if ((st = d_cnt.alloc(nq * 4))) return st;
+    if ((st = d_off.alloc((nq + 1) * 8))) return st;
+    const size_t wsb = scan_ws_bytes(nq);
+    if ((st = d_ws.alloc(wsb))) return st;
+    st = launch_igd_count_per_query(g->view(), q.c, q.s, q.e, nq, min_overlap, d_cnt.as<u32>(), nullptr);
+    if (st) return st;
+    st = launch_scan_u32_to_u64(d_cnt.as<u32>(), nq, d_off.as<u64>(), d_ws.p, wsb, nullptr);
+    if (st) return st;
+    u64 h = 0;
+    GT_HIP(hipMemcpy(&h, d_off.as<u64>() + nq, 8, hipMemcpyDeviceToHost));
+    ScopedDev d_q, d_s;
+    if ((st = d_q.alloc(h * 4))) return st;
+    if ((st = d_s.alloc(h * 4))) return st;
+    st = launch_igd_fill_pairs(g->view(), q.c, q.s, q.e, nq, min_overlap, d_off.as<u64>(), d_q.as<u32>(),
+                               d_s.as<u32>(), nullptr);
+    if (st) return st;
+    *out_q = host_alloc<u32>(h);
+    *out_s = host_alloc<u32>(h);
+    if (!*out_q || !*out_s) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    if (h) {
+        GT_HIP(hipMemcpy(*out_q, d_q.p, h * 4, hipMemcpyDeviceToHost));
+        GT_HIP(hipMemcpy(*out_s, d_s.p, h * 4, hipMemcpyDeviceToHost));
+    }
+    *out_n = h;
+    return GTARS_OK;
+}
+
+gtars_status gtars_lola_contingency_device(const uint64_t *d_user_hits, const uint64_t *d_universe_hits,
+                                           uint64_t n_files, int64_t user_size, int64_t universe_size,
+                                           int64_t *d_a, int64_t *d_b, int64_t *d_c, int64_t *d_d,
+                                           void *stream) {
+    if (n_files && (!d_user_hits || !d_universe_hits || !d_a || !d_b || !d_c || !d_d))
+        return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    return launch_lola_contingency(d_user_hits, d_universe_hits, n_files, user_size, universe_size, d_a, d_b,
+                                   d_c, d_d, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// Internal declarations shared by the HIP translation units of libgtars_amd.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/gtars_amd.h"
+
+namespace gtars {
+
+using u8 = uint8_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i32 = int32_t;
+using i64 = int64_t;
+
+// ---- error plumbing --------------------------------------------------------
+void set_error(const std::string &msg);
+gtars_status fail(gtars_status st, const std::string &msg);
+gtars_status hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define GT_HIP(expr)                                                            \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return ::gtars::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+gtars_status require_device();
+
+// ---- device views ----------------------------------------------------------
+// One genome-wide overlap index: every chromosome's intervals concatenated in
+// chromosome-id order, SoA, u32.
+//  Bits kind  : within a chromosome sorted by (start, end, input order)
+//               (bits.rs:105); chrom_aux[c] = max_len (bits.rs:110-119).
+//  AIList kind: within a chromosome sub-list major (ailist.rs:127-141), each
+//               sub-list sorted by start; max_ends = running max of ends per
+//               sub-list (ailist.rs:229-235); sub_off[chrom_sub[c]..chrom_sub[c+1]]
+//               are the sub-list start offsets (global positions), with one
+//               terminating entry per chromosome.
+struct IndexView {
+    const u32 *starts;
+    const u32 *ends;
+    const u32 *vals;
+    const u32 *max_ends;   // AIList only
+    const u32 *chrom_off;  // [n_chrom + 1]
+    const u32 *chrom_aux;  // Bits: max_len [n_chrom]
+    const u32 *chrom_sub;  // AIList: [n_chrom + 1] into sub_off
+    const u32 *sub_off;    // AIList: sub-list boundaries (global positions)
+    u32 n_chrom;
+    u32 n;
+};
+
+// IGD database: all stored intervals (tile replicas are NOT materialised),
+// chromosome-major, sorted by (start, insertion order) within a chromosome.
+struct IgdView {
+    const i32 *starts;
+    const i32 *ends;
+    const u32 *files;
+    const i32 *values;
+    const u32 *chrom_off;  // [n_chrom + 1]
+    const i32 *chrom_maxlen;  // [n_chrom] max(end-start)
+    u32 n_chrom;
+    u32 n;
+    u32 n_files;
+};
+
+// ---- per-thread grow-only device workspace ----------------------------------
+struct Workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+    gtars_status reserve(size_t need);
+    ~Workspace();
+};
+Workspace &tls_workspace(int slot);
+
+// ---- launchers (kernels.hip) ------------------------------------------------
+struct EnumOut {
+    u64 *offsets;    // [nq+1] device
+    u32 *vals;       // may be null
+    u32 *starts;     // may be null
+    u32 *ends;       // may be null
+    u64 capacity;    // elements available in each non-null output
+};
+
+// fused single pass (chained scan).  d_total: device u64 receiving H.
+gtars_status launch_enumerate_fused(const IndexView &v, int kind, const u32 *qc, const u32 *qs,
+                                    const u32 *qe, u64 nq, int has_min, i32 min_overlap,
+                                    const EnumOut &out, u64 *d_total, u32 *d_err,
+                                    void *scan_ws, size_t scan_ws_bytes, hipStream_t st);
+size_t enumerate_fused_ws_bytes(u64 nq);
+
+gtars_status launch_count(const IndexView &v, int kind, const u32 *qc, const u32 *qs, const u32 *qe,
+                          u64 nq, int has_min, i32 min_overlap, u32 *counts, u8 *any,
+                          hipStream_t st);
+// ids for existing offsets
+gtars_status launch_fill(const IndexView &v, int kind, const u32 *qc, const u32 *qs, const u32 *qe,
+                         u64 nq, int has_min, i32 min_overlap, const u64 *offsets, u32 *vals,
+                         u32 *starts, u32 *ends, hipStream_t st);
+// exclusive scan u32 counts -> u64 offsets[n+1]
+gtars_status launch_scan_u32_to_u64(const u32 *counts, u64 n, u64 *offsets, void *ws, size_t ws_bytes,
+                                    hipStream_t st);
+size_t scan_ws_bytes(u64 n);
+
+gtars_status launch_igd_count(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
+                              i32 min_overlap, int binary, u64 *hits, hipStream_t st);
+gtars_status launch_igd_count_per_query(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe,
+                                        u64 nq, i32 min_overlap, u32 *counts, hipStream_t st);
+gtars_status launch_igd_fill_pairs(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
+                                   i32 min_overlap, const u64 *offsets, u32 *out_q, u32 *out_s,
+                                   hipStream_t st);
+gtars_status launch_lola_contingency(const u64 *user_hits, const u64 *universe_hits, u64 n_files,
+                                     i64 user_size, i64 universe_size, i64 *a, i64 *b, i64 *c, i64 *d,
+                                     hipStream_t st);
+gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, u32 *new_counts,
+                                         hipStream_t st);
+
+// ---- profiling hooks --------------------------------------------------------
+struct ProfScope {
+    ProfScope(const char *name, hipStream_t st);
+    ~ProfScope();
+    const char *name;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool on = false;
+};
+
+}  // namespace gtars

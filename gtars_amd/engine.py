@@ -1,0 +1,210 @@
+"""Integer-level engine objects over the C ABI: ``OverlapIndex`` and ``IgdIndex``.
+
+These are the array fast path underneath the reference-shaped classes in
+``gtars_amd.tokenizers`` / ``gtars_amd.models`` / ``gtars_amd.igd``: chromosome
+names are already dictionary-encoded to dense u32 ids, coordinates are u32
+arrays.  Host arrays are numpy; the ``*_device`` methods take raw device
+pointers (e.g. ``tensor.data_ptr()``) and a HIP stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import KIND_AILIST, KIND_BITS, as_u32, check, lib, ptr, take_u32
+
+
+def _minargs(min_overlap: Optional[int]):
+    return (0, 0) if min_overlap is None else (1, int(min_overlap))
+
+
+class OverlapIndex:
+    """Genome-wide Bits / AIList index resident in HBM.
+
+    Mirrors ``Overlapper::build`` per chromosome (bits.rs:101-128,
+    ailist.rs:105-151) behind ``MultiChromOverlapper`` bucketing
+    (multi_chrom_overlapper.rs:325-351).
+    """
+
+    def __init__(self, chrom, start, end, val=None, n_chrom: Optional[int] = None, kind: int = KIND_BITS):
+        chrom, start, end = as_u32(chrom), as_u32(start), as_u32(end)
+        if not (len(chrom) == len(start) == len(end)):
+            raise ValueError("chrom, start, end must have the same length")
+        n = len(chrom)
+        v = None if val is None else as_u32(val)
+        if n_chrom is None:
+            n_chrom = int(chrom.max()) + 1 if n else 0
+        h = C.c_void_p()
+        check(lib.gtars_index_build(ptr(chrom), ptr(start), ptr(end), ptr(v) if v is not None else None, n,
+                                    int(n_chrom), int(kind), C.byref(h)))
+        self._h = h
+        self.kind = kind
+        self.n_chrom = int(n_chrom)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.gtars_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(lib.gtars_index_len(self._h))
+
+    # -- introspection (tests) -------------------------------------------------
+    def chrom_len(self, c: int) -> int:
+        return int(lib.gtars_index_chrom_len(self._h, c))
+
+    def max_len(self, c: int) -> int:
+        return int(lib.gtars_index_max_len(self._h, c))
+
+    def stored(self, c: int):
+        n = self.chrom_len(c)
+        s, e, v = (np.zeros(n, dtype=np.uint32) for _ in range(3))
+        check(lib.gtars_index_stored(self._h, c, ptr(s), ptr(e), ptr(v)))
+        return s, e, v
+
+    def sublist_offsets(self, c: int):
+        n = int(lib.gtars_index_n_sublists(self._h, c))
+        out = np.zeros(n, dtype=np.uint64)
+        check(lib.gtars_index_sublist_offsets(self._h, c, ptr(out)))
+        return [int(x) for x in out]
+
+    # -- host-array queries ----------------------------------------------------
+    def tokenize(self, qc, qs, qe) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (offsets u64[nq+1], ids u32[H]) in reference order; no batch-level unk."""
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        nq = len(qc)
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib.gtars_tokenize(self._h, ptr(qc), ptr(qs), ptr(qe), nq, ptr(offsets), C.byref(p), C.byref(n)))
+        return offsets, take_u32(p, n.value)
+
+    def count_overlaps(self, qc, qs, qe, min_overlap: Optional[int] = None) -> np.ndarray:
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        out = np.zeros(len(qc), dtype=np.uint32)
+        hm, mo = _minargs(min_overlap)
+        check(lib.gtars_count_overlaps(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), hm, mo, ptr(out)))
+        return out
+
+    def any_overlaps(self, qc, qs, qe, min_overlap: Optional[int] = None) -> np.ndarray:
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        out = np.zeros(len(qc), dtype=np.uint8)
+        hm, mo = _minargs(min_overlap)
+        check(lib.gtars_any_overlaps(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), hm, mo, ptr(out)))
+        return out.astype(bool)
+
+    def find_overlaps(self, qc, qs, qe, min_overlap: Optional[int] = None):
+        """-> (offsets, starts, ends, vals) (find_overlaps_regions, multi_chrom_overlapper.rs:525-550)."""
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        nq = len(qc)
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        ps, pe, pv, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        hm, mo = _minargs(min_overlap)
+        check(lib.gtars_find_overlaps(self._h, ptr(qc), ptr(qs), ptr(qe), nq, hm, mo, ptr(offsets), C.byref(ps),
+                                      C.byref(pe), C.byref(pv), C.byref(n)))
+        return offsets, take_u32(ps, n.value), take_u32(pe, n.value), take_u32(pv, n.value)
+
+    def find_overlap_indices(self, qc, qs, qe, min_overlap: Optional[int] = None):
+        """IndexedRegionSet::find_overlaps (indexed_region_set.rs:246-263) -> (offsets, sorted unique idx)."""
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        nq = len(qc)
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        p, n = C.c_void_p(), C.c_uint64()
+        hm, mo = _minargs(min_overlap)
+        check(lib.gtars_find_overlap_indices(self._h, ptr(qc), ptr(qs), ptr(qe), nq, hm, mo, ptr(offsets),
+                                             C.byref(p), C.byref(n)))
+        return offsets, take_u32(p, n.value)
+
+    # -- device-pointer queries --------------------------------------------------
+    def tokenize_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_offsets: int, d_ids: int,
+                        ids_capacity: int, stream: int = 0, sync: bool = True) -> Optional[int]:
+        """Single fused pass on device buffers.  Returns H when ``sync`` (else None)."""
+        total = C.c_uint64()
+        check(lib.gtars_tokenize_device(self._h, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, ids_capacity,
+                                        C.byref(total) if sync else None, stream))
+        return int(total.value) if sync else None
+
+    def fill_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_offsets: int, d_ids: int, stream: int = 0):
+        check(lib.gtars_fill_device(self._h, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, stream))
+
+    def count_overlaps_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_counts: int,
+                              min_overlap: Optional[int] = None, stream: int = 0):
+        hm, mo = _minargs(min_overlap)
+        check(lib.gtars_count_overlaps_device(self._h, d_qc, d_qs, d_qe, nq, hm, mo, d_counts, stream))
+
+
+class IgdIndex:
+    """IGD database resident in HBM (gtars-igd/src/igd.rs), one record per stored interval."""
+
+    def __init__(self, chrom, start, end, file_idx, value=None, n_chrom: Optional[int] = None,
+                 n_files: Optional[int] = None):
+        chrom = as_u32(chrom)
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32)
+        file_idx = as_u32(file_idx)
+        v = None if value is None else np.ascontiguousarray(value, dtype=np.int32)
+        n = len(chrom)
+        if n_chrom is None:
+            n_chrom = int(chrom.max()) + 1 if n else 0
+        if n_files is None:
+            n_files = int(file_idx.max()) + 1 if n else 0
+        h = C.c_void_p()
+        check(lib.gtars_igd_build(ptr(chrom), ptr(start), ptr(end), ptr(v) if v is not None else None,
+                                  ptr(file_idx), n, int(n_chrom), int(n_files), C.byref(h)))
+        self._h = h
+        self.n_files = int(n_files)
+        self.n_chrom = int(n_chrom)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.gtars_igd_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(lib.gtars_igd_len(self._h))
+
+    def total_records(self, nbp: int = 16384) -> int:
+        return int(lib.gtars_igd_total_records(self._h, nbp))
+
+    def count_set_overlaps(self, qc, qs, qe, min_overlap: int = 1) -> np.ndarray:
+        return self._count(qc, qs, qe, min_overlap, 0)
+
+    def count_region_hits(self, qc, qs, qe, min_overlap: int = 1) -> np.ndarray:
+        return self._count(qc, qs, qe, min_overlap, 1)
+
+    def _count(self, qc, qs, qe, min_overlap, binary):
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        hits = np.zeros(self.n_files, dtype=np.uint64)
+        check(lib.gtars_igd_count(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), int(min_overlap), binary, ptr(hits)))
+        return hits
+
+    def count_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_hits: int, min_overlap: int = 1,
+                     binary: bool = False, stream: int = 0):
+        check(lib.gtars_igd_count_device(self._h, d_qc, d_qs, d_qe, nq, int(min_overlap), int(binary), d_hits, stream))
+
+    def count_overlaps_per_query(self, qc, qs, qe, min_overlap: int = 1) -> np.ndarray:
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        out = np.zeros(len(qc), dtype=np.uint32)
+        check(lib.gtars_igd_count_per_query(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), int(min_overlap), ptr(out)))
+        return out
+
+    def find_overlaps_regionset(self, qc, qs, qe, min_overlap: int = 1):
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        pq, ps, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        check(lib.gtars_igd_find_pairs(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), int(min_overlap), C.byref(pq),
+                                       C.byref(ps), C.byref(n)))
+        return take_u32(pq, n.value), take_u32(ps, n.value)

@@ -1,0 +1,231 @@
+/*
+ * gtars_amd.h -- C ABI of libgtars_amd.so, the MI355X (gfx950) engine for the
+ * gtars interval-overlap / region-set tokenization hot path.
+ *
+ * The reference (databio/gtars) has no C ABI: its seams are Rust traits and
+ * structs called from pyo3.  Each entry point below names the reference
+ * interface it replaces (file:line, relative to the reference checkout); a
+ * Rust `-sys` crate, ctypes or cgo can bind these directly
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - every function returns a gtars_status (0 = OK); gtars_last_error() gives
+ *    a thread-local message for the last failure on the calling thread;
+ *  - chromosomes are dense u32 ids assigned by the caller's string dictionary
+ *    (the tokenizer/regionset layer in this library does that for BED input);
+ *    ids >= n_chrom, or chromosomes with no indexed interval, are "unknown
+ *    chromosome" and yield no hits (tokenizer.rs:143-150,
+ *    multi_chrom_overlapper.rs:231-234);
+ *  - `*_device` entry points take DEVICE pointers and enqueue on `stream`
+ *    (a hipStream_t passed as void*; NULL = the null stream) and only
+ *    synchronise where the signature returns a host value; the plain entry
+ *    points take HOST pointers and do the transfers themselves;
+ *  - handles are immutable after build and may be queried concurrently from
+ *    several host threads (each call brings its own workspace);
+ *  - memory returned through `T** out` is freed with gtars_free().
+ *
+ * There is no CPU fallback: without a HIP device every compute entry point
+ * fails with GTARS_ERR_NO_DEVICE.
+ */
+#ifndef GTARS_AMD_H
+#define GTARS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gtars_status {
+    GTARS_OK = 0,
+    GTARS_ERR_INVALID_ARG = 1,
+    GTARS_ERR_NO_DEVICE = 2,
+    GTARS_ERR_HIP = 3,        /* a HIP runtime call failed */
+    GTARS_ERR_CAPACITY = 4,   /* caller-provided output buffer too small */
+    GTARS_ERR_IO = 5,         /* file missing / unreadable */
+    GTARS_ERR_PARSE = 6,      /* malformed BED / TOML / .gtok / .igd */
+    GTARS_ERR_EMPTY = 7,      /* empty region set (RegionSetError::EmptyRegionSet) */
+    GTARS_ERR_CONFIG = 8,     /* bad extension / bad tokenizer_type */
+    GTARS_ERR_INTERNAL = 9
+} gtars_status;
+
+/* OverlapperType (gtars-overlaprs/src/lib.rs:139-144) */
+#define GTARS_KIND_BITS 0
+#define GTARS_KIND_AILIST 1
+
+#define GTARS_UNKNOWN_CHROM 0xFFFFFFFFu
+
+const char *gtars_last_error(void);
+const char *gtars_version(void);
+/* number of HIP devices visible (0 when there is none; never fails) */
+int gtars_device_count(void);
+void gtars_free(void *p);
+
+/* ------------------------------------------------------------------------
+ * Overlap index: per-chromosome Bits or AIList, SoA in HBM.
+ * Replaces Overlapper::build for a whole genome:
+ *   Bits::build        gtars-overlaprs/src/bits.rs:101-128
+ *   AIList::build      gtars-overlaprs/src/ailist.rs:105-151, 198-236
+ *   per-chrom buckets  gtars-tokenizers/src/utils/mod.rs:49-99,
+ *                      gtars-overlaprs/src/multi_chrom_overlapper.rs:325-351
+ * ---------------------------------------------------------------------- */
+typedef struct gtars_index gtars_index_t;
+
+/* Host arrays of n intervals. val may be NULL (val[i] = i).  Intervals with
+ * chrom[i] >= n_chrom are rejected (GTARS_ERR_INVALID_ARG). */
+gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start,
+                               const uint32_t *end, const uint32_t *val,
+                               uint64_t n, uint32_t n_chrom, int kind,
+                               gtars_index_t **out);
+void gtars_index_free(gtars_index_t *ix);
+
+uint64_t gtars_index_len(const gtars_index_t *ix);
+uint32_t gtars_index_n_chrom(const gtars_index_t *ix);
+int gtars_index_kind(const gtars_index_t *ix);
+/* Overlapper::iter(): stored order of one chromosome copied back to the host
+ * (Bits: sorted (start,end); AIList: sub-list major).  Returns its length;
+ * out pointers may be NULL. */
+uint64_t gtars_index_chrom_len(const gtars_index_t *ix, uint32_t chrom);
+gtars_status gtars_index_stored(const gtars_index_t *ix, uint32_t chrom,
+                                uint32_t *start, uint32_t *end, uint32_t *val);
+/* Bits.max_len (bits.rs:110-119) / AIList.header_list (ailist.rs:127-141) */
+uint32_t gtars_index_max_len(const gtars_index_t *ix, uint32_t chrom);
+uint64_t gtars_index_n_sublists(const gtars_index_t *ix, uint32_t chrom);
+gtars_status gtars_index_sublist_offsets(const gtars_index_t *ix, uint32_t chrom,
+                                         uint64_t *out);
+
+/* ------------------------------------------------------------------------
+ * Tokenize / enumerate: for every query, the vals of all indexed intervals
+ * with  iv.start < q_end && iv.end > q_start  (interval.rs:47-50), in the
+ * index's result order, concatenated in query order.
+ * Replaces the inner loop of Tokenizer::tokenize / encode
+ *   gtars-tokenizers/src/tokenizer.rs:140-171
+ * i.e. Overlapper::find  bits.rs:141-156,433-446 / ailist.rs:153-178,238-263.
+ * The batch-level "[unk] when nothing overlapped" rule (tokenizer.rs:158-160)
+ * is applied by gtars_tokenizer_* below, not here.
+ * ---------------------------------------------------------------------- */
+
+/* Single pass, device pointers.  d_offsets: nq+1 u64 (CSR); d_ids: room for
+ * ids_capacity u32.  *total_hits (host) receives H after the stream has been
+ * synchronised.  If H > ids_capacity the offsets are complete and valid, ids
+ * beyond the capacity are not written and GTARS_ERR_CAPACITY is returned
+ * (re-run with a larger buffer, or call gtars_fill_device).  total_hits may
+ * be NULL: then nothing is synchronised and overflow is not reported. */
+gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qchrom,
+                                   const uint32_t *d_qstart, const uint32_t *d_qend,
+                                   uint64_t nq, uint64_t *d_offsets, uint32_t *d_ids,
+                                   uint64_t ids_capacity, uint64_t *total_hits,
+                                   void *stream);
+
+/* Second pass of a two-pass caller: ids for existing offsets. */
+gtars_status gtars_fill_device(const gtars_index_t *ix, const uint32_t *d_qchrom,
+                               const uint32_t *d_qstart, const uint32_t *d_qend,
+                               uint64_t nq, const uint64_t *d_offsets, uint32_t *d_ids,
+                               void *stream);
+
+/* Host pointers; *out_ids is library-allocated (gtars_free). */
+gtars_status gtars_tokenize(const gtars_index_t *ix, const uint32_t *qchrom,
+                            const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
+                            uint64_t *offsets, uint32_t **out_ids, uint64_t *out_n);
+
+/* ------------------------------------------------------------------------
+ * Counts / any / find with the optional min-overlap filter.
+ * Replaces MultiChromOverlapper::count_overlaps / any_overlaps /
+ * find_overlaps_regions (multi_chrom_overlapper.rs:483-550) and
+ * IndexedRegionSet::count/any/find_overlaps (indexed_region_set.rs:234-263).
+ * has_min = 0 is `None`; the filter  overlap_bp >= min_overlap  is applied
+ * only when min_overlap > 1 (multi_chrom_overlapper.rs:491).
+ * ---------------------------------------------------------------------- */
+gtars_status gtars_count_overlaps_device(const gtars_index_t *ix, const uint32_t *d_qchrom,
+                                         const uint32_t *d_qstart, const uint32_t *d_qend,
+                                         uint64_t nq, int has_min, int32_t min_overlap,
+                                         uint32_t *d_counts, void *stream);
+gtars_status gtars_count_overlaps(const gtars_index_t *ix, const uint32_t *qchrom,
+                                  const uint32_t *qstart, const uint32_t *qend,
+                                  uint64_t nq, int has_min, int32_t min_overlap,
+                                  uint32_t *counts);
+gtars_status gtars_any_overlaps(const gtars_index_t *ix, const uint32_t *qchrom,
+                                const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
+                                int has_min, int32_t min_overlap, uint8_t *out);
+/* CSR of hits; any of out_start/out_end/out_val may be NULL. */
+gtars_status gtars_find_overlaps(const gtars_index_t *ix, const uint32_t *qchrom,
+                                 const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
+                                 int has_min, int32_t min_overlap, uint64_t *offsets,
+                                 uint32_t **out_start, uint32_t **out_end,
+                                 uint32_t **out_val, uint64_t *out_n);
+/* IndexedRegionSet::find_overlaps (indexed_region_set.rs:246-263): per query
+ * the sorted, de-duplicated source indices.  The index must have been built
+ * with val == NULL (val[i] = i). */
+gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t *qchrom,
+                                        const uint32_t *qstart, const uint32_t *qend,
+                                        uint64_t nq, int has_min, int32_t min_overlap,
+                                        uint64_t *offsets, uint32_t **out_idx,
+                                        uint64_t *out_n);
+
+/* ------------------------------------------------------------------------
+ * IGD: multi-file interval database, per-file hit counting.
+ * Replaces gtars-igd/src/igd.rs: Igd::add (:109-153), finalize (:157-167),
+ * count_set_overlaps (:544-556), count_region_hits (:563-590),
+ * from_single_region_set (:609-634), find_overlaps_regionset (:645-678),
+ * count_overlaps_per_query (:690-722); walk_tile_overlaps (:753-847).
+ * Defined for min_overlap >= 1 (GTARS_ERR_INVALID_ARG otherwise).
+ * ---------------------------------------------------------------------- */
+typedef struct gtars_igd gtars_igd_t;
+
+/* Host arrays of n records; the same drop rules as Igd::add apply
+ * (start<0 || end<0 || start>=end are skipped). value may be NULL (0). */
+gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start,
+                             const int32_t *end, const int32_t *value,
+                             const uint32_t *file_idx, uint64_t n, uint32_t n_chrom,
+                             uint32_t n_files, gtars_igd_t **out);
+void gtars_igd_free(gtars_igd_t *g);
+uint64_t gtars_igd_len(const gtars_igd_t *g);          /* stored intervals */
+uint32_t gtars_igd_n_files(const gtars_igd_t *g);
+/* what Igd::total_records() would report for nbp (tile replicas counted) */
+uint64_t gtars_igd_total_records(const gtars_igd_t *g, int32_t nbp);
+
+/* binary = 0: Igd::count_set_overlaps (pairwise);
+ * binary = 1: Igd::count_region_hits (at most 1 per query per file).
+ * Query coordinates are u32 cast to i32 as the reference does (igd.rs:549-550).
+ * d_hits: n_files u64, overwritten. */
+gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qchrom,
+                                    const uint32_t *d_qstart, const uint32_t *d_qend,
+                                    uint64_t nq, int32_t min_overlap, int binary,
+                                    uint64_t *d_hits, void *stream);
+gtars_status gtars_igd_count(const gtars_igd_t *g, const uint32_t *qchrom,
+                             const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
+                             int32_t min_overlap, int binary, uint64_t *hits);
+/* Igd::count_overlaps_per_query (distinct `value`s per query) */
+gtars_status gtars_igd_count_per_query(const gtars_igd_t *g, const uint32_t *qchrom,
+                                       const uint32_t *qstart, const uint32_t *qend,
+                                       uint64_t nq, int32_t min_overlap, uint32_t *counts);
+/* Igd::find_overlaps_regionset: (query, subject) pairs in reference walk order */
+gtars_status gtars_igd_find_pairs(const gtars_igd_t *g, const uint32_t *qchrom,
+                                  const uint32_t *qstart, const uint32_t *qend,
+                                  uint64_t nq, int32_t min_overlap, uint32_t **out_q,
+                                  uint32_t **out_s, uint64_t *out_n);
+
+/* LOLA contingency cells from support vectors (gtars-lola/src/enrichment.rs:214-220);
+ * device pointers, one thread per file. */
+gtars_status gtars_lola_contingency_device(const uint64_t *d_user_hits,
+                                           const uint64_t *d_universe_hits,
+                                           uint64_t n_files, int64_t user_size,
+                                           int64_t universe_size, int64_t *d_a,
+                                           int64_t *d_b, int64_t *d_c, int64_t *d_d,
+                                           void *stream);
+
+/* ------------------------------------------------------------------------
+ * Instrumentation used by bench.py: when enabled every kernel launch made by
+ * this library on the calling thread is bracketed by HIP events on its own
+ * stream; gtars_prof_read() synchronises and returns accumulated times.
+ * ---------------------------------------------------------------------- */
+void gtars_prof_enable(int on);
+void gtars_prof_reset(void);
+/* fills up to cap entries; returns number of distinct kernels seen */
+int gtars_prof_read(const char **names, double *total_ms, uint64_t *launches, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,429 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Integer / index work: every comparison is exact equality (token ids AND their
+order, CSR offsets, counts, per-file hit vectors).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import KIND_AILIST, KIND_BITS
+
+pytestmark = pytest.mark.gpu
+
+BOTH = [KIND_BITS, KIND_AILIST]
+UNK = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import gtars_amd
+
+    assert gtars_amd.device_count() > 0, "no MI355X visible: -m gpu tests must run on the GPU box"
+    return gtars_amd
+
+
+def _pair(ga, chrom, start, end, val=None, n_chrom=None, kind=KIND_BITS):
+    if n_chrom is None:
+        n_chrom = int(max(chrom)) + 1 if len(chrom) else 0
+    g = ga.OverlapIndex(chrom, start, end, val, n_chrom=n_chrom, kind=kind)
+    o = oracle.Index(chrom, start, end, val, n_chrom=n_chrom, kind=kind)
+    return g, o
+
+
+def _assert_same_queries(g, o, qc, qs, qe, min_overlaps=(None,)):
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    assert off_g.tolist() == off_o.tolist()
+    assert ids_g.tolist() == ids_o.tolist()
+    for mo in min_overlaps:
+        assert g.count_overlaps(qc, qs, qe, mo).tolist() == o.count_overlaps(qc, qs, qe, mo).tolist()
+        assert g.any_overlaps(qc, qs, qe, mo).tolist() == o.any_overlaps(qc, qs, qe, mo).tolist()
+        fg = g.find_overlaps(qc, qs, qe, mo)
+        fo = o.find_overlaps_regions(qc, qs, qe, mo)
+        for a, b in zip(fg, fo):
+            assert a.tolist() == b.tolist()
+
+
+# ------------------------------------------------------------ reference KATs
+
+
+@pytest.mark.parametrize("kind", BOTH)
+def test_kat_abcd(ga, kind):
+    # bits.rs:545-616 / ailist.rs:385-457
+    g, o = _pair(ga, [0] * 4, [1, 3, 6, 8], [5, 7, 10, 12], kind=kind)
+    _assert_same_queries(g, o, [0, 0, 0, 0, 9], [2, 9, 13, 0, 2], [4, 11, 15, 1, 4])
+    off, ids = g.tokenize([0, 0, 0], [2, 9, 13], [4, 11, 15])
+    assert sorted(ids[off[0]:off[1]].tolist()) == [0, 1]
+    assert sorted(ids[off[1]:off[2]].tolist()) == [2, 3]
+    assert off[3] == off[2]
+
+
+def test_kat_ailist_26(ga):
+    # ailist.rs:550-601
+    from test_oracle_golden import AILIST_26
+
+    s = [a for a, _ in AILIST_26]
+    e = [b for _, b in AILIST_26]
+    g, o = _pair(ga, [0] * 26, s, e, kind=KIND_AILIST)
+    assert g.sublist_offsets(0) == [0, 24] == o.headers(0)
+    off, fs, fe, _ = g.find_overlaps([0, 0, 0], [6, 30, 101], [8, 35, 150])
+    assert off.tolist() == [0, 5, 8, 8]
+    assert list(zip(fs[:5].tolist(), fe[:5].tolist())) == [(5, 15), (5, 15), (0, 10), (0, 10), (0, 30)]
+    gs, ge, gv = g.stored(0)
+    os_, oe, ov = o.stored(0)
+    assert gs.tolist() == os_.tolist() and ge.tolist() == oe.tolist() and gv.tolist() == ov.tolist()
+
+
+def test_kat_bits_order_and_maxlen(ga):
+    g, o = _pair(ga, [0] * 5, [10, 10, 5, 10, 5], [30, 20, 50, 20, 50], [0, 1, 2, 3, 4])
+    off, ids = g.tokenize([0], [0], [100])
+    assert ids.tolist() == [2, 4, 1, 3, 0]
+    assert g.max_len(0) == 45 == o.max_len(0)
+
+
+@pytest.mark.parametrize("kind", BOTH)
+def test_kat_mco(ga, kind):
+    # multi_chrom_overlapper.rs:1070-1130, :878-943
+    g, o = _pair(ga, [0, 0, 0], [150, 250, 500], [200, 350, 600], kind=kind)
+    assert g.count_overlaps([0], [100], [300]).tolist() == [2]
+    g, o = _pair(ga, [0], [150], [250], kind=kind)
+    assert g.any_overlaps([0, 0], [100, 300], [200, 400]).tolist() == [True, False]
+    g, o = _pair(ga, [0], [100], [110], kind=kind)
+    assert g.count_overlaps([0], [105], [200], 5).tolist() == [1]
+    assert g.count_overlaps([0], [105], [200], 6).tolist() == [0]
+    assert g.any_overlaps([0], [105], [200], 6).tolist() == [False]
+    g, o = _pair(ga, [0], [100], [200], kind=kind)
+    assert g.count_overlaps([0, 99], [200, 100], [300, 200]).tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("kind", BOTH)
+def test_kat_python_regionset_ops(ga, kind):
+    # gtars-python/tests/test_regionset.py:37-54
+    g, o = _pair(ga, [0, 0], [150, 550], [250, 650], kind=kind)
+    qc, qs, qe = [0, 0, 0], [100, 300, 500], [200, 400, 600]
+    assert g.count_overlaps(qc, qs, qe).tolist() == [1, 0, 1]
+    assert g.any_overlaps(qc, qs, qe).tolist() == [True, False, True]
+    off, idx = g.find_overlap_indices(qc, qs, qe)
+    assert off.tolist() == [0, 1, 1, 2] and idx.tolist() == [0, 1]
+
+
+@pytest.mark.parametrize("kind", BOTH)
+def test_empty_index_and_empty_query(ga, kind):
+    # multi_chrom_overlapper.rs:1132-1158, bits.rs:607-616
+    g, o = _pair(ga, [], [], [], n_chrom=1, kind=kind)
+    assert g.count_overlaps([0], [100], [200]).tolist() == [0]
+    off, ids = g.tokenize([0], [100], [200])
+    assert off.tolist() == [0, 0] and len(ids) == 0
+    g, o = _pair(ga, [0], [100], [200], kind=kind)
+    off, ids = g.tokenize([], [], [])
+    assert off.tolist() == [0] and len(ids) == 0
+    assert g.count_overlaps([], [], []).tolist() == []
+
+
+def test_scoring_matrix_through_gpu(ga, golden_dir):
+    # fragment_scoring.rs:178-206 (inverted end probe)
+    import gzip
+    import os
+
+    cons = oracle.read_region_set(os.path.join(golden_dir, "consensus", "consensus1.bed"))
+    ids = {}
+    c = [ids.setdefault(r[0], len(ids)) for r in cons]
+    g = ga.OverlapIndex(c, [r[1] for r in cons], [r[2] for r in cons], n_chrom=len(ids))
+    mat = np.zeros((2, 4), dtype=np.int64)
+    for row, name in enumerate(["fragments1.bed.gz", "fragments2.bed.gz"]):
+        qc, qs, qe = [], [], []
+        with gzip.open(os.path.join(golden_dir, "fragments", "region_scoring", name), "rt") as f:
+            for line in f:
+                p = line.split()
+                if not p:
+                    continue
+                cid = ids.get(p[0], UNK)
+                s, e = int(p[1]), int(p[2])
+                qc += [cid, cid]
+                qs += [s + 4, e - 5]
+                qe += [s + 5, e - 6]
+        _, hit = g.tokenize(qc, qs, qe)
+        np.add.at(mat[row], hit, 1)
+    assert mat.tolist() == [[2, 2, 1, 3], [4, 1, 3, 1]]
+
+
+# ------------------------------------------------------- randomized differential
+
+
+def _random_case(rng, n, nq, n_chrom, span, wmax, dup_frac=0.1, weird_frac=0.05):
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, span, n)
+    w = rng.integers(0, wmax, n)  # includes zero-length index intervals
+    e = s + w
+    ndup = int(n * dup_frac)
+    if ndup and n:
+        src = rng.integers(0, n, ndup)
+        dst = rng.integers(0, n, ndup)
+        c[dst], s[dst], e[dst] = c[src], s[src], e[src]
+    qc = rng.integers(0, n_chrom + 2, nq)  # some unknown chromosome ids
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, span, nq)
+    qw = rng.integers(0, wmax * 2, nq)
+    qe = qs + qw
+    nweird = int(nq * weird_frac)
+    if nweird:
+        k = rng.integers(0, nq, nweird)
+        qe[k] = np.maximum(qs[k] - rng.integers(0, 5, nweird), 0)  # zero-length and inverted queries
+    return c, s, e, qc, qs, qe
+
+
+@pytest.mark.parametrize("kind", BOTH)
+@pytest.mark.parametrize("seed,n,nq,n_chrom,span,wmax", [
+    (1, 50, 300, 1, 200, 30),
+    (2, 2000, 5000, 3, 20_000, 400),
+    (3, 20_000, 30_000, 25, 1_000_000, 2_000),
+    (4, 5000, 8000, 2, 5_000, 3_000),   # heavy coverage -> AIList decomposition into many sub-lists
+    (5, 3000, 3000, 40, 100, 20),       # tiny span: many ties in (start,end)
+])
+def test_random_differential(ga, kind, seed, n, nq, n_chrom, span, wmax):
+    rng = np.random.default_rng(seed)
+    c, s, e, qc, qs, qe = _random_case(rng, n, nq, n_chrom, span, wmax)
+    val = rng.permutation(n).astype(np.uint32)
+    g, o = _pair(ga, c, s, e, val, n_chrom=n_chrom, kind=kind)
+    for ch in range(n_chrom):
+        for a, b in zip(g.stored(ch), o.stored(ch)):
+            assert a.tolist() == b.tolist()
+    _assert_same_queries(g, o, qc, qs, qe, min_overlaps=(None, 0, 1, 2, 5, 10))
+
+
+def test_ailist_heavy_nesting(ga):
+    # >= 10 of the next 19 intervals contained -> pushed to the next sub-list (ailist.rs:198-236)
+    rng = np.random.default_rng(11)
+    big_s = np.arange(0, 4000, 100)
+    big_e = big_s + 5000
+    small_s = rng.integers(0, 9000, 3000)
+    small_e = small_s + rng.integers(1, 20, 3000)
+    s = np.concatenate([big_s, small_s])
+    e = np.concatenate([big_e, small_e])
+    c = np.zeros(len(s), dtype=np.uint32)
+    g, o = _pair(ga, c, s, e, kind=KIND_AILIST)
+    assert len(o.headers(0)) >= 2
+    assert g.sublist_offsets(0) == o.headers(0)
+    qs = rng.integers(0, 9500, 4000)
+    qe = qs + rng.integers(0, 300, 4000)
+    _assert_same_queries(g, o, np.zeros(4000, dtype=np.uint32), qs, qe, min_overlaps=(None, 3))
+
+
+@pytest.mark.parametrize("kind", BOTH)
+def test_irs_find_overlap_indices_random(ga, kind):
+    rng = np.random.default_rng(21)
+    c, s, e, qc, qs, qe = _random_case(rng, 3000, 4000, 4, 8000, 300, dup_frac=0.3)
+    g = ga.OverlapIndex(c, s, e, None, n_chrom=4, kind=kind)
+    o = oracle.Index(c, s, e, None, n_chrom=4, kind=kind)
+    for mo in (None, 4):
+        og, ig = g.find_overlap_indices(qc, qs, qe, mo)
+        oo, io = o.irs_find_overlaps(c, s, e, qc, qs, qe, mo)
+        assert og.tolist() == oo.tolist()
+        assert ig.tolist() == io.tolist()
+
+
+def test_config1_1k_by_1k(ga):
+    # BASELINE config 1: 1k x 1k single chromosome
+    from gtars_amd import synth
+
+    c, s, e = synth.make_single_chrom(1000, 1)
+    qc, qs, qe = synth.make_single_chrom(1000, 2)
+    for kind in BOTH:
+        g, o = _pair(ga, c, s, e, n_chrom=1, kind=kind)
+        _assert_same_queries(g, o, qc, qs, qe, min_overlaps=(None, 50))
+        og, ig = g.find_overlap_indices(qc, qs, qe)
+        oo, io = o.irs_find_overlaps(c, s, e, qc, qs, qe)
+        assert og.tolist() == oo.tolist() and ig.tolist() == io.tolist()
+
+
+@pytest.mark.parametrize("overlapping", [False, True])
+def test_config2_tokenize_1m_vs_100k(ga, overlapping):
+    # BASELINE config 2: 1M hg38-shaped queries vs a 100k-region universe, bit-exact ids and offsets
+    from gtars_amd import synth
+
+    u = synth.make_universe(100_000, overlapping=overlapping)
+    q = synth.make_queries(u, 1_000_000)
+    for kind in ([KIND_BITS] if not overlapping else BOTH):
+        g, o = _pair(ga, u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM, kind=kind)
+        off_g, ids_g = g.tokenize(q["chrom"], q["start"], q["end"])
+        off_o, ids_o = o.tokenize(q["chrom"], q["start"], q["end"])
+        assert np.array_equal(off_g, off_o)
+        assert np.array_equal(ids_g, ids_o)
+        assert np.array_equal(g.count_overlaps(q["chrom"], q["start"], q["end"]),
+                              o.count_overlaps(q["chrom"], q["start"], q["end"]).astype(np.uint32))
+
+
+def test_device_pointer_path_and_capacity(ga):
+    """gtars_tokenize_device on torch buffers; CAPACITY overflow -> offsets valid, fill pass completes."""
+    import torch
+    from gtars_amd import synth
+
+    u = synth.make_universe(20_000)
+    q = synth.make_queries(u, 200_001)  # not a multiple of the tile, exercises the ragged tail
+    g, o = _pair(ga, u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev).to(torch.int32)  # u32 bit patterns in int32
+    qc = torch.from_numpy(q["chrom"].view(np.int32)).to(dev)
+    qs = torch.from_numpy(q["start"].view(np.int32)).to(dev)
+    qe = torch.from_numpy(q["end"].view(np.int32)).to(dev)
+    nq = len(q["chrom"])
+    offsets = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+    ids = torch.empty(2 * nq, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    h = g.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(),
+                          ids.numel(), stream)
+    off_o, ids_o = o.tokenize(q["chrom"], q["start"], q["end"])
+    assert h == len(ids_o)
+    assert np.array_equal(offsets.cpu().numpy().view(np.uint64), off_o)
+    assert np.array_equal(ids[:h].cpu().numpy().view(np.uint32), ids_o)
+    # misaligned views (scalar load path) give the same answer
+    qc1, qs1, qe1 = qc[1:], qs[1:], qe[1:]
+    h1 = g.tokenize_device(qc1.data_ptr(), qs1.data_ptr(), qe1.data_ptr(), nq - 1, offsets.data_ptr(),
+                           ids.data_ptr(), ids.numel(), stream)
+    off_1, ids_1 = o.tokenize(q["chrom"][1:], q["start"][1:], q["end"][1:])
+    assert h1 == len(ids_1)
+    assert np.array_equal(ids[:h1].cpu().numpy().view(np.uint32), ids_1)
+    # too-small capacity: status CAPACITY, offsets still complete; the fill pass then produces the ids
+    small = torch.empty(16, dtype=torch.int32, device=dev)
+    with pytest.raises(ga.CapacityError):
+        g.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, offsets.data_ptr(), small.data_ptr(),
+                          small.numel(), stream)
+    assert np.array_equal(offsets.cpu().numpy().view(np.uint64), off_o)
+    g.fill_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(ids[: len(ids_o)].cpu().numpy().view(np.uint32), ids_o)
+
+
+def test_full_size_properties(ga):
+    """Size-independent properties at a size the oracle is not asked to check in full (16M queries):
+    offsets monotone, offsets[-1] == H, counts == diff(offsets), ids within the universe, and a
+    sub-sample of queries agrees with the oracle."""
+    import torch
+    from gtars_amd import synth
+
+    u = synth.make_universe(100_000)
+    base = synth.make_queries(u, 1_000_000)
+    rep = 16
+    q = {k: np.tile(v, rep) for k, v in base.items()}
+    nq = len(q["chrom"])
+    g, o = _pair(ga, u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    dev = torch.device("cuda:0")
+    qc, qs, qe = (torch.from_numpy(q[k].view(np.int32)).to(dev) for k in ("chrom", "start", "end"))
+    offsets = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+    ids = torch.empty(nq, dtype=torch.int32, device=dev)
+    counts = torch.empty(nq, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    h = g.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(),
+                          ids.numel(), st)
+    g.count_overlaps_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, counts.data_ptr(), None, st)
+    torch.cuda.synchronize()
+    d = offsets[1:] - offsets[:-1]
+    assert int(offsets[0]) == 0 and int(offsets[-1]) == h
+    assert bool((d >= 0).all())
+    assert bool((d == counts.to(torch.int64)).all())
+    assert int(ids[:h].max()) < len(u["chrom"]) and int(ids[:h].min()) >= 0
+    # periodicity: the batch is `rep` copies of the 1M base, so every copy must tokenize identically
+    off_o, ids_o = o.tokenize(base["chrom"], base["start"], base["end"])
+    assert h == rep * len(ids_o)
+    ids_h = ids[:h].cpu().numpy().view(np.uint32)
+    for r in (0, 7, rep - 1):
+        assert np.array_equal(ids_h[r * len(ids_o):(r + 1) * len(ids_o)], ids_o)
+
+
+# ---------------------------------------------------------------------- IGD
+
+
+def _igd_pair(ga, c, s, e, f, v=None, n_chrom=None, n_files=None):
+    g = ga.IgdIndex(c, s, e, f, v, n_chrom=n_chrom, n_files=n_files)
+    o = oracle.Igd()
+    o.add_arrays(c, s, e, v if v is not None else np.zeros(len(c), dtype=np.int64), f)
+    o.n_files = n_files if n_files is not None else o.n_files
+    o.finalize()
+    return g, o
+
+
+def test_igd_kats(ga):
+    # igd.rs:914-1016, 1161-1221
+    g, o = _igd_pair(ga, [0, 0, 0], [100, 300, 150], [200, 400, 250], [0, 0, 1], n_files=2)
+    assert g.count_set_overlaps([0], [120], [180]).tolist() == [1, 1]
+    assert g.count_set_overlaps([0], [350], [380]).tolist() == [1, 0]
+    assert g.count_set_overlaps([0], [500], [600]).tolist() == [0, 0]
+    g, o = _igd_pair(ga, [0], [100], [200], [0], n_files=1)
+    assert [int(g.count_set_overlaps([0], [190], [250], mo)[0]) for mo in (1, 10, 11)] == [1, 1, 0]
+    g, o = _igd_pair(ga, [0], [10000], [20000], [0], n_files=1)
+    assert g.total_records() == 2 == o.total_records()
+    assert g.count_set_overlaps([0, 0, 0], [11000, 17000, 15000], [12000, 18000, 19000]).tolist() == [3]
+    g, o = _igd_pair(ga, [0, 0, 0], [100, 120, 140], [200, 220, 240], [0, 0, 0], n_files=1)
+    assert g.count_set_overlaps([0], [150], [190]).tolist() == [3]
+    assert g.count_region_hits([0], [150], [190]).tolist() == [1]
+    # unknown chrom, invalid queries (igd.rs:514-517)
+    assert g.count_set_overlaps([7, 0, 0], [150, 190, 150], [190, 150, 150]).tolist() == [0]
+
+
+def test_igd_two_set_kats(ga):
+    # igd.rs:1256-1369
+    g, o = _igd_pair(ga, [0, 0, 0], [100, 300, 500], [200, 400, 600], [0, 0, 0], [0, 1, 2], n_files=1)
+    q, s = g.find_overlaps_regionset([0, 0, 0], [150, 550, 700], [350, 650, 800])
+    assert sorted(zip(q.tolist(), s.tolist())) == [(0, 0), (0, 1), (1, 2)]
+    g, o = _igd_pair(ga, [0, 0, 0], [100, 150, 500], [200, 250, 600], [0, 0, 0], [0, 1, 2], n_files=1)
+    assert g.count_overlaps_per_query([0, 0, 0], [160, 550, 700], [180, 580, 800]).tolist() == [2, 1, 0]
+    g, o = _igd_pair(ga, [0], [10000], [40000], [0], [0], n_files=1)
+    q, s = g.find_overlaps_regionset([0], [15000], [35000])
+    assert list(zip(q.tolist(), s.tolist())) == [(0, 0)]
+
+
+@pytest.mark.parametrize("seed,n,nq,F,span,wmax", [
+    (1, 4000, 3000, 5, 200_000, 40_000),     # long records spanning several 16384-bp tiles
+    (2, 20_000, 20_000, 300, 2_000_000, 900),
+    (3, 3000, 2000, 9000, 100_000, 500),     # F > LDS bins -> global-atomic path
+])
+def test_igd_random_differential(ga, seed, n, nq, F, span, wmax):
+    rng = np.random.default_rng(seed)
+    n_chrom = 3
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(0, wmax, n)  # some zero-length records are dropped by add()
+    s[:5] = -3  # negative starts dropped
+    f = rng.integers(0, F, n)
+    v = np.arange(n)
+    g, o = _igd_pair(ga, c, s, e, f, v, n_chrom=n_chrom, n_files=F)
+    assert len(g) == int(((s >= 0) & (e > s)).sum())
+    assert g.total_records() == o.total_records()
+    qc = rng.integers(0, n_chrom + 1, nq)
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, span, nq)
+    qe = qs + rng.integers(0, wmax, nq)
+    # tile-edge cases
+    qs[:50] = (rng.integers(1, 10, 50) * 16384)
+    qe[:50] = qs[:50] + rng.integers(1, 40000, 50)
+    for mo in (1, 2, 10):
+        assert g.count_set_overlaps(qc, qs, qe, mo).tolist() == o.count_set_overlaps(qc, qs, qe, mo, n_files=F).tolist()
+        assert g.count_region_hits(qc, qs, qe, mo).tolist() == o.count_region_hits(qc, qs, qe, mo, n_files=F).tolist()
+    if n <= 4000:
+        for mo in (1, 10):
+            assert g.count_overlaps_per_query(qc, qs, qe, mo).tolist() == o.count_overlaps_per_query(qc, qs, qe, mo).tolist()
+            gq, gs = g.find_overlaps_regionset(qc, qs, qe, mo)
+            oq, os_ = o.find_overlaps_regionset(qc, qs, qe, mo)
+            assert gq.tolist() == oq.tolist() and gs.tolist() == os_.tolist()  # same walk order
+
+
+def test_lola_contingency_device(ga):
+    import ctypes as C
+
+    import torch
+    from gtars_amd._lib import check, lib
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    uh = rng.integers(0, 1000, 2000)
+    vh = uh + rng.integers(-5, 5000, 2000).clip(min=-3)
+    vh = np.maximum(vh, 0)
+    a, b, c, d = oracle.lola_contingency(uh, vh, 1000, 100000)
+    tu, tv = torch.from_numpy(uh.astype(np.int64)).to(dev), torch.from_numpy(vh.astype(np.int64)).to(dev)
+    out = [torch.empty(2000, dtype=torch.int64, device=dev) for _ in range(4)]
+    check(lib.gtars_lola_contingency_device(tu.data_ptr(), tv.data_ptr(), 2000, 1000, 100000,
+                                            *[o.data_ptr() for o in out], torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for got, exp in zip(out, (a, b, c, d)):
+        assert got.cpu().numpy().tolist() == exp.tolist()
