@@ -43,6 +43,15 @@ if not os.path.exists(LIB_PATH):
         "(hipcc --offload-arch=gfx950).  gtars_amd has no CPU fallback."
     )
 
+# One process must hold ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64.so.7; if this library
+# pulled in /opt/rocm's copy first, torch would later fail with "No HIP GPUs are available".  Importing torch
+# first makes the dynamic linker resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped.
+if os.environ.get("GTARS_AMD_NO_TORCH") != "1":
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # torch is plumbing (device buffers, torch.distributed), not a hard dependency
+        pass
+
 lib = C.CDLL(LIB_PATH)
 
 vp, u32, u64, i32, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64
