@@ -167,6 +167,24 @@ struct gtars_index {
     std::vector<u32> h_starts, h_ends, h_vals, h_max_ends;
     std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
+    // blocked acceleration structure (Bits kind), see AccelView in common.h
+    DevBuf<u32> acc_blocks, acc_blk_first, acc_top, acc_chrom_blk_off;
+    u32 acc_n_blocks = 0, acc_n_top = 0, acc_top_shift = 0, acc_max_chrom_top = 0;
+    bool has_accel = false;
+    AccelView accel() const {
+        AccelView a;
+        a.blocks = reinterpret_cast<const uint4 *>(acc_blocks.p);
+        a.blk_first = acc_blk_first.p;
+        a.top = acc_top.p;
+        a.chrom_blk_off = acc_chrom_blk_off.p;
+        a.chrom_maxlen = chrom_aux.p;
+        a.n_blocks = acc_n_blocks;
+        a.n_top = acc_n_top;
+        a.top_shift = acc_top_shift;
+        a.n_chrom = n_chrom;
+        a.max_chrom_top = acc_max_chrom_top;
+        return a;
+    }
     IndexView view() const {
         IndexView v;
         v.starts = starts.p;
@@ -345,8 +363,70 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         ix->h_chrom_sub[n_chrom] = (u32)ix->h_sub_off.size();
     }
 
+    std::vector<u32> h_blocks, h_blk_first, h_top, h_cblk;
+    if (kind == GTARS_KIND_BITS && n > 0) {
+        // top-level budget: entries kept in LDS by k_tok_lds (env override for experiments)
+        u32 top_max = 13312;
+        if (const char *e = getenv("GTARS_TOP_MAX")) {
+            const long v = atol(e);
+            if (v >= 64) top_max = (u32)v;
+        }
+        u32 shift = 0;
+        for (;;) {
+            // padded block count at this shift
+            u64 nb = 0;
+            const u64 g = 1ull << shift;
+            for (u32 c = 0; c < n_chrom; ++c) {
+                const u64 b = (off[c + 1] - off[c] + ACC_BS - 1) / ACC_BS;
+                nb += (b + g - 1) / g * g;
+            }
+            if ((nb >> shift) <= top_max || shift >= 16) break;
+            ++shift;
+        }
+        const u64 g = 1ull << shift;
+        h_cblk.assign(n_chrom + 1, 0);
+        for (u32 c = 0; c < n_chrom; ++c) {
+            const u64 b = (off[c + 1] - off[c] + ACC_BS - 1) / ACC_BS;
+            h_cblk[c + 1] = h_cblk[c] + (u32)((b + g - 1) / g * g);
+        }
+        const u32 nb = h_cblk[n_chrom];
+        h_blocks.assign((size_t)nb * 32, 0);
+        h_blk_first.assign(nb, 0xFFFFFFFFu);
+        u32 max_ct = 0;
+        for (u32 c = 0; c < n_chrom; ++c) {
+            max_ct = std::max<u32>(max_ct, (h_cblk[c + 1] - h_cblk[c]) >> shift);
+            for (u32 b = h_cblk[c]; b < h_cblk[c + 1]; ++b) {
+                u32 *rec = &h_blocks[(size_t)b * 32];
+                for (int k = 0; k < ACC_BS; ++k) {
+                    const u64 p = (u64)off[c] + (u64)(b - h_cblk[c]) * ACC_BS + k;
+                    if (p < off[c + 1]) {
+                        rec[k] = ix->h_starts[p];
+                        rec[8 + k] = ix->h_ends[p];
+                        rec[16 + k] = ix->h_vals[p];
+                    } else {
+                        rec[k] = 0xFFFFFFFFu;  // sentinel: never < q_end, stops the scan
+                        rec[8 + k] = 0;
+                        rec[16 + k] = 0;
+                    }
+                }
+                h_blk_first[b] = rec[0];
+            }
+        }
+        h_top.resize(nb >> shift);
+        for (u32 t = 0; t < h_top.size(); ++t) h_top[t] = h_blk_first[(size_t)t << shift];
+        ix->acc_n_blocks = nb;
+        ix->acc_n_top = (u32)h_top.size();
+        ix->acc_top_shift = shift;
+        ix->acc_max_chrom_top = max_ct;
+        ix->has_accel = nb > 0;
+    }
+
     GT_HIP(hipGetDevice(&ix->device));
     st = ix->starts.upload(ix->h_starts);
+    if (!st && ix->has_accel) st = ix->acc_blocks.upload(h_blocks);
+    if (!st && ix->has_accel) st = ix->acc_blk_first.upload(h_blk_first);
+    if (!st && ix->has_accel) st = ix->acc_top.upload(h_top);
+    if (!st && ix->has_accel) st = ix->acc_chrom_blk_off.upload(h_cblk);
     if (!st) st = ix->ends.upload(ix->h_ends);
     if (!st) st = ix->vals.upload(ix->h_vals);
     if (!st) st = ix->max_ends.upload(ix->h_max_ends);
@@ -372,6 +452,10 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->chrom_aux.release();
     ix->chrom_sub.release();
     ix->sub_off.release();
+    ix->acc_blocks.release();
+    ix->acc_blk_first.release();
+    ix->acc_top.release();
+    ix->acc_chrom_blk_off.release();
     delete ix;
 }
 
@@ -419,6 +503,31 @@ gtars_status gtars_index_sublist_offsets(const gtars_index_t *ix, uint32_t c, ui
 
 // ----------------------------------------------------------------- queries
 
+// fused enumerate dispatcher: LDS-tiled fast path for Bits, generic kernel otherwise
+static size_t fused_ws_bytes(const gtars_index *ix, u64 nq) {
+    return std::max(enumerate_fused_ws_bytes(nq), tokenize_lds_ws_bytes(nq));
+}
+static bool use_lds_path(const gtars_index *ix) {
+    static const bool disabled = getenv("GTARS_NO_LDS_PATH") != nullptr;
+    return !disabled && ix->kind == GTARS_KIND_BITS && ix->has_accel && tokenize_lds_supported(ix->accel());
+}
+static gtars_status run_fused(const gtars_index *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
+                              int has_min, i32 min_overlap, const EnumOut &out, void *ws, size_t ws_bytes,
+                              hipStream_t s) {
+    if (use_lds_path(ix))
+        return launch_tokenize_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, s);
+    return launch_enumerate_fused(ix->view(), ix->kind, qc, qs, qe, nq, has_min, min_overlap, out, ws,
+                                  ws_bytes, s);
+}
+static gtars_status read_scan_head(const void *ws, hipStream_t s, u64 *total) {
+    ScanHead h;
+    GT_HIP(hipMemcpyAsync(&h, ws, sizeof h, hipMemcpyDeviceToHost, s));
+    GT_HIP(hipStreamSynchronize(s));
+    if (total) *total = h.total;
+    if (h.err) return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
+    return GTARS_OK;
+}
+
 static gtars_status check_query_args(const void *ix, const void *a, const void *b, const void *c, u64 nq) {
     if (!ix) return fail(GTARS_ERR_INVALID_ARG, "NULL handle");
     if (nq && (!a || !b || !c)) return fail(GTARS_ERR_INVALID_ARG, "NULL query arrays");
@@ -433,25 +542,17 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
     if (!d_offsets) return fail(GTARS_ERR_INVALID_ARG, "d_offsets is NULL");
     hipStream_t s = (hipStream_t)stream;
     Workspace &ws = tls_workspace(0);
-    const size_t scan_bytes = enumerate_fused_ws_bytes(nq);
-    const size_t ctl_off = (scan_bytes + 255) & ~(size_t)255;
-    st = ws.reserve(ctl_off + 256);
+    const size_t wsb = fused_ws_bytes(ix, nq);
+    st = ws.reserve(wsb);
     if (st) return st;
-    u64 *d_total = (u64 *)((char *)ws.ptr + ctl_off);
-    u32 *d_err = (u32 *)((char *)ws.ptr + ctl_off + 8);
-    GT_HIP(hipMemsetAsync(d_total, 0, 16, s));
     EnumOut out{d_offsets, d_ids, nullptr, nullptr, d_ids ? ids_capacity : 0};
-    st = launch_enumerate_fused(ix->view(), ix->kind, d_qc, d_qs, d_qe, nq, 0, 0, out, d_total, d_err,
-                                ws.ptr, ctl_off, s);
+    st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, s);
     if (st) return st;
     if (total_hits) {
-        u64 host[2] = {0, 0};
-        GT_HIP(hipMemcpyAsync(host, d_total, 16, hipMemcpyDeviceToHost, s));
-        GT_HIP(hipStreamSynchronize(s));
-        *total_hits = host[0];
-        if ((u32)host[1]) return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
-        if (d_ids && host[0] > ids_capacity)
-            return fail(GTARS_ERR_CAPACITY, "ids buffer too small: need " + std::to_string(host[0]));
+        st = read_scan_head(ws.ptr, s, total_hits);
+        if (st) return st;
+        if (d_ids && *total_hits > ids_capacity)
+            return fail(GTARS_ERR_CAPACITY, "ids buffer too small: need " + std::to_string(*total_hits));
     }
     return GTARS_OK;
 }
@@ -514,24 +615,19 @@ static gtars_status enumerate_to_host(const gtars_index_t *ix, const u32 *qc, co
     DevQueries q;
     st = q.upload(qc, qs, qe, nq);
     if (st) return st;
-    ScopedDev d_off, d_ctl, d_ws;
+    ScopedDev d_off, d_ws;
     st = d_off.alloc((nq + 1) * 8);
     if (st) return st;
-    st = d_ctl.alloc(16);
-    if (st) return st;
-    const size_t wsb = enumerate_fused_ws_bytes(nq);
+    const size_t wsb = fused_ws_bytes(ix, nq);
     st = d_ws.alloc(wsb);
     if (st) return st;
-    GT_HIP(hipMemset(d_ctl.p, 0, 16));
     // pass 1: offsets + total only (no payload buffers)
     EnumOut o1{d_off.as<u64>(), nullptr, nullptr, nullptr, 0};
-    st = launch_enumerate_fused(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, o1,
-                                d_ctl.as<u64>(), (u32 *)((char *)d_ctl.p + 8), d_ws.p, wsb, nullptr);
+    st = run_fused(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, nullptr);
     if (st) return st;
-    u64 host[2] = {0, 0};
-    GT_HIP(hipMemcpy(host, d_ctl.p, 16, hipMemcpyDeviceToHost));
-    if ((u32)host[1]) return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
-    const u64 h = host[0];
+    u64 h = 0;
+    st = read_scan_head(d_ws.p, nullptr, &h);
+    if (st) return st;
     if (offsets) GT_HIP(hipMemcpy(offsets, d_off.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
     if (out_n) *out_n = h;
     const int nout = (out_val ? 1 : 0) + (out_start ? 1 : 0) + (out_end ? 1 : 0);
@@ -675,22 +771,18 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
     DevQueries q;
     st = q.upload(qc, qs, qe, nq);
     if (st) return st;
-    ScopedDev d_off, d_ctl, d_ws, d_cnt, d_off2;
+    ScopedDev d_off, d_ws, d_cnt, d_off2;
     if ((st = d_off.alloc((nq + 1) * 8))) return st;
     if ((st = d_off2.alloc((nq + 1) * 8))) return st;
-    if ((st = d_ctl.alloc(16))) return st;
     if ((st = d_cnt.alloc(nq * 4))) return st;
-    const size_t wsb = std::max(enumerate_fused_ws_bytes(nq), scan_ws_bytes(nq));
+    const size_t wsb = std::max(fused_ws_bytes(ix, nq), scan_ws_bytes(nq));
     if ((st = d_ws.alloc(wsb))) return st;
-    GT_HIP(hipMemset(d_ctl.p, 0, 16));
     EnumOut o1{d_off.as<u64>(), nullptr, nullptr, nullptr, 0};
-    st = launch_enumerate_fused(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, o1,
-                                d_ctl.as<u64>(), (u32 *)((char *)d_ctl.p + 8), d_ws.p, wsb, nullptr);
+    st = run_fused(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, nullptr);
     if (st) return st;
-    u64 host[2] = {0, 0};
-    GT_HIP(hipMemcpy(host, d_ctl.p, 16, hipMemcpyDeviceToHost));
-    if ((u32)host[1]) return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
-    const u64 h = host[0];
+    u64 h = 0;
+    st = read_scan_head(d_ws.p, nullptr, &h);
+    if (st) return st;
     ScopedDev d_val;
     if ((st = d_val.alloc(h * 4))) return st;
     st = launch_fill(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d_off.as<u64>(),

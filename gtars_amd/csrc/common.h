@@ -54,6 +54,29 @@ struct IndexView {
     u32 n;
 };
 
+// Blocked acceleration structure of a Bits-kind index (built once at index
+// build): every chromosome's sorted intervals are cut into blocks of
+// ACC_BS = 8 and stored as one 128-byte record per block
+//     u32 starts[8] | u32 ends[8] | u32 vals[8] | u32 reserved[8]
+// so that one L2 line holds everything a query needs about a block.  Unused
+// slots are sentinels (start = 0xFFFFFFFF, end = 0: never overlap, and stop
+// the forward scan).  blk_first[b] = starts[0] of block b.  `top` samples
+// blk_first every 2^top_shift blocks and is what the workgroups keep in LDS;
+// each chromosome's block range is padded to a multiple of 2^top_shift.
+constexpr int ACC_BS = 8;
+struct AccelView {
+    const uint4 *blocks;      // [n_blocks * 8] (128 B per block)
+    const u32 *blk_first;     // [n_blocks]
+    const u32 *top;           // [n_top]
+    const u32 *chrom_blk_off; // [n_chrom + 1]
+    const u32 *chrom_maxlen;  // [n_chrom]
+    u32 n_blocks;
+    u32 n_top;
+    u32 top_shift;
+    u32 n_chrom;
+    u32 max_chrom_top;        // max top entries of one chromosome (search depth)
+};
+
 // IGD database: all stored intervals (tile replicas are NOT materialised),
 // chromosome-major, sorted by (start, insertion order) within a chromosome.
 struct IgdView {
@@ -87,12 +110,27 @@ struct EnumOut {
     u64 capacity;    // elements available in each non-null output
 };
 
-// fused single pass (chained scan).  d_total: device u64 receiving H.
+// Head of every fused-scan workspace; after the launch has completed the host
+// reads {err, total} from here (total = H, err != 0: look-back spin limit hit).
+struct ScanHead {
+    u32 ticket;
+    u32 err;
+    u64 total;
+};
+
+// fused single pass (chained scan); scan_ws is zeroed by the launcher.
 gtars_status launch_enumerate_fused(const IndexView &v, int kind, const u32 *qc, const u32 *qs,
                                     const u32 *qe, u64 nq, int has_min, i32 min_overlap,
-                                    const EnumOut &out, u64 *d_total, u32 *d_err,
-                                    void *scan_ws, size_t scan_ws_bytes, hipStream_t st);
+                                    const EnumOut &out, void *scan_ws, size_t scan_ws_bytes,
+                                    hipStream_t st);
 size_t enumerate_fused_ws_bytes(u64 nq);
+
+// LDS-tiled fused tokenizer (tokenize_lds.hip), Bits order only
+gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
+                                 int has_min, i32 min_overlap, const EnumOut &out, void *scan_ws,
+                                 size_t scan_ws_bytes, hipStream_t st);
+size_t tokenize_lds_ws_bytes(u64 nq);
+bool tokenize_lds_supported(const AccelView &a);
 
 gtars_status launch_count(const IndexView &v, int kind, const u32 *qc, const u32 *qs, const u32 *qe,
                           u64 nq, int has_min, i32 min_overlap, u32 *counts, u8 *any,

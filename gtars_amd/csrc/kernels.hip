@@ -20,6 +20,7 @@
 //   min-overlap filter  gtars-overlaprs/src/multi_chrom_overlapper.rs:483-563
 //   IGD hit rule        gtars-igd/src/igd.rs:504-540, 753-847
 #include "common.h"
+#include "scan.cuh"
 
 namespace gtars {
 
@@ -117,40 +118,6 @@ k_count(IndexView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs, con
     }
 }
 
-// ------------------------------------------------------- wave / block scans
-
-__device__ __forceinline__ u32 wave_inclusive_scan_u32(u32 x, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    return x;
-}
-
-__device__ __forceinline__ u64 wave_reduce_sum_u64(u64 x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-    return x;
-}
-
-// exclusive scan of one u32 per thread across a 256-thread block; returns the
-// exclusive prefix and the block total.  lds: >= 4 u32.
-__device__ __forceinline__ u32 block_exclusive_scan_256(u32 x, u32 *lds, u32 &total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 inc = wave_inclusive_scan_u32(x, lane);
-    if (lane == 63) lds[wave] = inc;
-    __syncthreads();
-    const u32 w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
-    total = w0 + w1 + w2 + w3;
-    u32 base = 0;
-    if (wave > 0) base += w0;
-    if (wave > 1) base += w1;
-    if (wave > 2) base += w2;
-    __syncthreads();
-    return base + inc - x;
-}
-
 // ------------------------------------------- three-phase scan (two-pass path)
 
 constexpr int SCAN_TPB = 256;
@@ -217,7 +184,7 @@ k_scan_apply(const u32 *__restrict__ counts, u64 n, const u64 *__restrict__ part
         s += c[j];
     }
     u32 total;
-    u32 ex = block_exclusive_scan_256(s, lds, total);
+    u32 ex = block_exclusive_scan<SCAN_TPB>(s, lds, total);
     u64 run = partials[blockIdx.x] + ex;
 #pragma unroll
     for (int j = 0; j < SCAN_IPT; ++j) {
@@ -293,64 +260,8 @@ constexpr int ENUM_TPB = 256;
 constexpr int ENUM_QPT = 4;
 constexpr int ENUM_TILE = ENUM_TPB * ENUM_QPT;
 
-constexpr u64 ST_SHIFT = 62;
-constexpr u64 ST_AGG = 1ull << ST_SHIFT;
-constexpr u64 ST_INC = 2ull << ST_SHIFT;
-constexpr u64 ST_MASK = 3ull << ST_SHIFT;
-constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
-
-struct ScanWs {
-    u32 ticket;
-    u32 pad;
-    u64 state[1];  // [num_tiles]
-};
-
 size_t enumerate_fused_ws_bytes(u64 nq) {
-    const u64 nt = (nq + ENUM_TILE - 1) / ENUM_TILE;
-    return sizeof(u64) * (nt + 2);
-}
-
-__device__ __forceinline__ u64 ld_state(const u64 *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_state(u64 *p, u64 v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// executed by wave 0 (all 64 lanes); returns the tile's exclusive global prefix
-__device__ __forceinline__ u64 lookback(u64 *state, u32 tile, u64 agg, int lane, u32 *err) {
-    if (tile == 0) {
-        if (lane == 0) st_state(&state[0], ST_INC | agg);
-        return 0;
-    }
-    if (lane == 0) st_state(&state[tile], ST_AGG | agg);
-    u64 excl = 0;
-    i64 pred = (i64)tile - 1;
-    u32 spins = 0;
-    for (;;) {
-        const i64 idx = pred - lane;
-        u64 val = idx >= 0 ? ld_state(&state[idx]) : ST_INC;  // before tile 0: inclusive 0
-        const u64 status = val & ST_MASK;
-        const unsigned long long b_inc = __ballot(status == ST_INC);
-        const unsigned long long b_inv = __ballot(status == 0);
-        const int first_inc = b_inc ? __ffsll((long long)b_inc) - 1 : 64;
-        const unsigned long long need =
-            first_inc >= 63 ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);
-        if (b_inv & need) {
-            if (++spins > LOOKBACK_SPIN_LIMIT) {
-                if (lane == 0) atomicOr(err, 1u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        const u64 contrib = (lane <= first_inc) ? (val & ~ST_MASK) : 0ull;
-        excl += wave_reduce_sum_u64(contrib);
-        if (first_inc < 64) break;
-        pred -= 64;
-    }
-    if (lane == 0) st_state(&state[tile], ST_INC | (excl + agg));
-    return excl;
+    return scan_ws_bytes_for_tiles((nq + ENUM_TILE - 1) / ENUM_TILE);
 }
 
 template <int KIND, bool FILTER>
@@ -358,7 +269,7 @@ __global__ void __launch_bounds__(ENUM_TPB)
 k_enum_fused(IndexView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
              const u32 *__restrict__ qe, u64 nq, i32 min_bp, u64 *__restrict__ offsets,
              u32 *__restrict__ ovals, u32 *__restrict__ ostarts, u32 *__restrict__ oends, u64 cap,
-             ScanWs *ws, u64 *__restrict__ d_total, u32 *err) {
+             ScanWs *ws) {
     __shared__ u32 s_tile;
     __shared__ u64 s_prefix;
     __shared__ u32 s_scan[4];
@@ -397,10 +308,10 @@ k_enum_fused(IndexView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs
             tsum += cnt[j];
         }
         u32 block_total;
-        const u32 excl = block_exclusive_scan_256(tsum, s_scan, block_total);
+        const u32 excl = block_exclusive_scan<ENUM_TPB>(tsum, s_scan, block_total);
 
         if (threadIdx.x < 64) {
-            const u64 p = lookback(ws->state, tile, (u64)block_total, lane, err);
+            const u64 p = lookback(ws->state, tile, (u64)block_total, lane, &ws->err);
             if (lane == 0) s_prefix = p;
         }
         __syncthreads();
@@ -409,7 +320,7 @@ k_enum_fused(IndexView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs
             // last thread of the last tile holds the grand total
             const u64 tot = s_prefix + (u64)block_total;
             offsets[nq] = tot;
-            if (d_total) *d_total = tot;
+            ws->total = tot;
         }
 #pragma unroll
         for (int j = 0; j < ENUM_QPT; ++j) {
@@ -433,11 +344,9 @@ k_enum_fused(IndexView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs
 
 template <int KIND, bool FILTER>
 static void launch_enum_t(const IndexView &v, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
-                          i32 min_bp, const EnumOut &out, ScanWs *ws, u64 *d_total, u32 *d_err,
-                          unsigned grid, hipStream_t st) {
+                          i32 min_bp, const EnumOut &out, ScanWs *ws, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((k_enum_fused<KIND, FILTER>), dim3(grid), dim3(ENUM_TPB), 0, st, v, qc, qs, qe, nq,
-                       min_bp, out.offsets, out.vals, out.starts, out.ends, out.capacity, ws, d_total,
-                       d_err);
+                       min_bp, out.offsets, out.vals, out.starts, out.ends, out.capacity, ws);
 }
 
 static unsigned persistent_grid(u64 tiles, int blocks_per_cu) {
@@ -454,11 +363,11 @@ static unsigned persistent_grid(u64 tiles, int blocks_per_cu) {
 
 gtars_status launch_enumerate_fused(const IndexView &v, int kind, const u32 *qc, const u32 *qs,
                                     const u32 *qe, u64 nq, int has_min, i32 min_overlap,
-                                    const EnumOut &out, u64 *d_total, u32 *d_err, void *scan_ws,
-                                    size_t scan_ws_bytes_, hipStream_t st) {
+                                    const EnumOut &out, void *scan_ws, size_t scan_ws_bytes_,
+                                    hipStream_t st) {
     if (nq == 0) {
         GT_HIP(hipMemsetAsync(out.offsets, 0, sizeof(u64), st));
-        if (d_total) GT_HIP(hipMemsetAsync(d_total, 0, sizeof(u64), st));
+        GT_HIP(hipMemsetAsync(scan_ws, 0, sizeof(ScanWs), st));
         return GTARS_OK;
     }
     const u64 tiles = (nq + ENUM_TILE - 1) / ENUM_TILE;
@@ -474,14 +383,14 @@ gtars_status launch_enumerate_fused(const IndexView &v, int kind, const u32 *qc,
         ProfScope p(kind == GTARS_KIND_BITS ? "k_enum_fused<bits>" : "k_enum_fused<ailist>", st);
         if (kind == GTARS_KIND_BITS) {
             if (filter)
-                launch_enum_t<0, true>(v, qc, qs, qe, nq, min_bp, out, ws, d_total, d_err, grid, st);
+                launch_enum_t<0, true>(v, qc, qs, qe, nq, min_bp, out, ws, grid, st);
             else
-                launch_enum_t<0, false>(v, qc, qs, qe, nq, min_bp, out, ws, d_total, d_err, grid, st);
+                launch_enum_t<0, false>(v, qc, qs, qe, nq, min_bp, out, ws, grid, st);
         } else {
             if (filter)
-                launch_enum_t<1, true>(v, qc, qs, qe, nq, min_bp, out, ws, d_total, d_err, grid, st);
+                launch_enum_t<1, true>(v, qc, qs, qe, nq, min_bp, out, ws, grid, st);
             else
-                launch_enum_t<1, false>(v, qc, qs, qe, nq, min_bp, out, ws, d_total, d_err, grid, st);
+                launch_enum_t<1, false>(v, qc, qs, qe, nq, min_bp, out, ws, grid, st);
         }
     }
     GT_HIP(hipGetLastError());

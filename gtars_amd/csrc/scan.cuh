@@ -1,0 +1,107 @@
+// scan.cuh -- wave/workgroup scans and the chained ("decoupled look-back")
+// cross-workgroup prefix sum shared by the fused enumerate kernels.
+#pragma once
+#include "common.h"
+
+namespace gtars {
+
+__device__ __forceinline__ u32 wave_inclusive_scan_u32(u32 x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ u64 wave_reduce_sum_u64(u64 x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+// Exclusive scan of one u32 per thread across a TPB-thread workgroup; returns
+// the exclusive prefix and the workgroup total.  lds: >= TPB/64 u32.
+template <int TPB>
+__device__ __forceinline__ u32 block_exclusive_scan(u32 x, u32 *lds, u32 &total) {
+    constexpr int NW = TPB / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 inc = wave_inclusive_scan_u32(x, lane);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const u32 v = lds[w];
+        if (w < wave) base += v;
+        tot += v;
+    }
+    total = tot;
+    __syncthreads();
+    return base + inc - x;
+}
+
+// ---- chained scan state ------------------------------------------------------
+// One 8-byte granule per tile: status in the top two bits, value below.  Flag
+// and payload travel in the same naturally aligned 64-bit word, written and
+// read with relaxed agent-scope atomics (L1-bypassing), so no fence is needed
+// and nothing depends on dispatch order or XCD placement.  Tiles are handed
+// out by a ticket counter, so a tile only waits on tiles that already started.
+constexpr u64 ST_SHIFT = 62;
+constexpr u64 ST_AGG = 1ull << ST_SHIFT;
+constexpr u64 ST_INC = 2ull << ST_SHIFT;
+constexpr u64 ST_MASK = 3ull << ST_SHIFT;
+constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
+
+struct ScanWs {
+    u32 ticket;
+    u32 err;
+    u64 total;
+    u64 state[1];  // [num_tiles]
+};
+
+inline size_t scan_ws_bytes_for_tiles(u64 tiles) { return sizeof(u64) * (tiles + 3); }
+
+__device__ __forceinline__ u64 ld_state(const u64 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_state(u64 *p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// executed by wave 0 (all 64 lanes); returns the tile's exclusive global prefix
+__device__ __forceinline__ u64 lookback(u64 *state, u32 tile, u64 agg, int lane, u32 *err) {
+    if (tile == 0) {
+        if (lane == 0) st_state(&state[0], ST_INC | agg);
+        return 0;
+    }
+    if (lane == 0) st_state(&state[tile], ST_AGG | agg);
+    u64 excl = 0;
+    i64 pred = (i64)tile - 1;
+    u32 spins = 0;
+    for (;;) {
+        const i64 idx = pred - lane;
+        u64 val = idx >= 0 ? ld_state(&state[idx]) : ST_INC;  // before tile 0: inclusive 0
+        const u64 status = val & ST_MASK;
+        const unsigned long long b_inc = __ballot(status == ST_INC);
+        const unsigned long long b_inv = __ballot(status == 0);
+        const int first_inc = b_inc ? __ffsll((long long)b_inc) - 1 : 64;
+        const unsigned long long need = first_inc >= 63 ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);
+        if (b_inv & need) {
+            if (++spins > LOOKBACK_SPIN_LIMIT) {
+                if (lane == 0) atomicOr(err, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        const u64 contrib = (lane <= first_inc) ? (val & ~ST_MASK) : 0ull;
+        excl += wave_reduce_sum_u64(contrib);
+        if (first_inc < 64) break;
+        pred -= 64;
+    }
+    if (lane == 0) st_state(&state[tile], ST_INC | (excl + agg));
+    return excl;
+}
+
+}  // namespace gtars
