@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgtars_amd.so")
+LIB_PATH = os.environ.get("GTARS_AMD_LIB") or os.path.join(_HERE, "libgtars_amd.so")
 
 GTARS_OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_IO, ERR_PARSE, ERR_EMPTY, ERR_CONFIG, ERR_INTERNAL = range(1, 10)

@@ -409,11 +409,21 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
                         rec[16 + k] = 0;
                     }
                 }
-                h_blk_first[b] = rec[0];
+                // search key of the block: its LAST start (sentinel-padded blocks: 0xFFFFFFFF)
+                h_blk_first[b] = rec[ACC_BS - 1];
+                // look-ahead: the first two intervals of the next block of the same chromosome
+                for (int k = 0; k < 2; ++k) {
+                    const u64 p = (u64)off[c] + (u64)(b - h_cblk[c] + 1) * ACC_BS + k;
+                    const bool ok = p < off[c + 1];
+                    rec[24 + 2 * k] = ok ? ix->h_starts[p] : 0xFFFFFFFFu;
+                    rec[25 + 2 * k] = ok ? ix->h_ends[p] : 0u;
+                    rec[28 + k] = ok ? ix->h_vals[p] : 0u;
+                }
             }
         }
+        // top[t] = last start of the last block of group t (non-decreasing inside a chromosome)
         h_top.resize(nb >> shift);
-        for (u32 t = 0; t < h_top.size(); ++t) h_top[t] = h_blk_first[(size_t)t << shift];
+        for (u32 t = 0; t < h_top.size(); ++t) h_top[t] = h_blk_first[(((size_t)t + 1) << shift) - 1];
         ix->acc_n_blocks = nb;
         ix->acc_n_top = (u32)h_top.size();
         ix->acc_top_shift = shift;

@@ -57,16 +57,18 @@ struct IndexView {
 // Blocked acceleration structure of a Bits-kind index (built once at index
 // build): every chromosome's sorted intervals are cut into blocks of
 // ACC_BS = 8 and stored as one 128-byte record per block
-//     u32 starts[8] | u32 ends[8] | u32 vals[8] | u32 reserved[8]
+//     u32 starts[8] | u32 ends[8] | u32 vals[8] | look-ahead: ns0 ne0 ns1 ne1 nv0 nv1 - -
+// (the look-ahead is a copy of the first two intervals of the next block)
 // so that one L2 line holds everything a query needs about a block.  Unused
 // slots are sentinels (start = 0xFFFFFFFF, end = 0: never overlap, and stop
-// the forward scan).  blk_first[b] = starts[0] of block b.  `top` samples
-// blk_first every 2^top_shift blocks and is what the workgroups keep in LDS;
-// each chromosome's block range is padded to a multiple of 2^top_shift.
+// the forward scan).  blk_first[b] = the block's LAST start (its search key;
+// 0xFFFFFFFF for sentinel-padded blocks).  `top[t]` is the key of the last
+// block of every group of 2^top_shift blocks and is what the workgroups keep
+// in LDS; each chromosome's block range is padded to a multiple of 2^top_shift.
 constexpr int ACC_BS = 8;
 struct AccelView {
     const uint4 *blocks;      // [n_blocks * 8] (128 B per block)
-    const u32 *blk_first;     // [n_blocks]
+    const u32 *blk_first;     // [n_blocks] last start of each block
     const u32 *top;           // [n_top]
     const u32 *chrom_blk_off; // [n_chrom + 1]
     const u32 *chrom_maxlen;  // [n_chrom]

@@ -5,6 +5,15 @@
 
 namespace gtars {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// every outstanding global load/store of the wave (s_waitcnt vmcnt(0)), which
+// would put the latency of in-flight result stores and prefetches on the
+// critical path of every tile; the kernels here hand data between waves of a
+// workgroup through LDS only.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ u32 wave_inclusive_scan_u32(u32 x, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -60,7 +69,7 @@ struct ScanWs {
     u64 state[1];  // [num_tiles]
 };
 
-inline size_t scan_ws_bytes_for_tiles(u64 tiles) { return sizeof(u64) * (tiles + 3); }
+inline size_t scan_ws_bytes_for_tiles(u64 tiles) { return sizeof(u64) * (tiles + 3 + 8); }  // +8: debug words
 
 __device__ __forceinline__ u64 ld_state(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -69,39 +78,70 @@ __device__ __forceinline__ void st_state(u64 *p, u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// executed by wave 0 (all 64 lanes); returns the tile's exclusive global prefix
-__device__ __forceinline__ u64 lookback(u64 *state, u32 tile, u64 agg, int lane, u32 *err) {
-    if (tile == 0) {
-        if (lane == 0) st_state(&state[0], ST_INC | agg);
-        return 0;
-    }
-    if (lane == 0) st_state(&state[tile], ST_AGG | agg);
+// Executed by wave 0 (all 64 lanes); returns the tile's exclusive global prefix.
+// Every round reads LB_W * 64 predecessor granules with independent loads (one
+// memory round trip), because with ~10^3 tiles in flight the nearest tile that
+// already knows its inclusive prefix is typically a few hundred tiles back and
+// each dependent round trip costs microseconds under load.
+constexpr int LB_W = 8;
+
+// publish a tile's aggregate (tile 0: its inclusive prefix) -- one lane
+__device__ __forceinline__ void publish_aggregate(u64 *state, u32 tile, u64 agg) {
+    st_state(&state[tile], (tile == 0 ? ST_INC : ST_AGG) | agg);
+}
+
+// resolve the exclusive prefix of `tile` (whose aggregate is already
+// published) and publish its inclusive prefix
+__device__ __forceinline__ u64 resolve_prefix(u64 *state, u32 tile, u64 agg, int lane, u32 *err) {
+    if (tile == 0) return 0;
     u64 excl = 0;
     i64 pred = (i64)tile - 1;
     u32 spins = 0;
-    for (;;) {
-        const i64 idx = pred - lane;
-        u64 val = idx >= 0 ? ld_state(&state[idx]) : ST_INC;  // before tile 0: inclusive 0
-        const u64 status = val & ST_MASK;
-        const unsigned long long b_inc = __ballot(status == ST_INC);
-        const unsigned long long b_inv = __ballot(status == 0);
-        const int first_inc = b_inc ? __ffsll((long long)b_inc) - 1 : 64;
-        const unsigned long long need = first_inc >= 63 ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);
-        if (b_inv & need) {
+    bool done = false;
+    while (!done) {
+        u64 val[LB_W];
+#pragma unroll
+        for (int w = 0; w < LB_W; ++w) {
+            const i64 idx = pred - (i64)w * 64 - lane;
+            val[w] = idx >= 0 ? ld_state(&state[idx]) : ST_INC;  // before tile 0: inclusive 0
+        }
+        // consume the windows nearest-first; stop at the first window that is
+        // not fully published up to its first inclusive entry
+        int consumed = 0;
+#pragma unroll
+        for (int w = 0; w < LB_W; ++w) {
+            if (done || consumed != w) continue;
+            const u64 status = val[w] & ST_MASK;
+            const unsigned long long b_inc = __ballot(status == ST_INC);
+            const unsigned long long b_inv = __ballot(status == 0);
+            const int first_inc = b_inc ? __ffsll((long long)b_inc) - 1 : 64;
+            const unsigned long long need = first_inc >= 63 ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);
+#if defined(GTARS_ABLATE) && (GTARS_ABLATE & 64)
+            (void)b_inv; (void)need;  // timing experiment: never wait (results wrong)
+#else
+            if (b_inv & need) continue;  // not ready: re-read from this window on
+#endif
+            const u64 contrib = (lane <= first_inc) ? (val[w] & ~ST_MASK) : 0ull;
+            excl += wave_reduce_sum_u64(contrib);
+            consumed = w + 1;
+            if (first_inc < 64) done = true;
+        }
+        pred -= (i64)consumed * 64;
+        if (!done && consumed == 0) {
             if (++spins > LOOKBACK_SPIN_LIMIT) {
                 if (lane == 0) atomicOr(err, 1u);
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
-            continue;
         }
-        const u64 contrib = (lane <= first_inc) ? (val & ~ST_MASK) : 0ull;
-        excl += wave_reduce_sum_u64(contrib);
-        if (first_inc < 64) break;
-        pred -= 64;
     }
     if (lane == 0) st_state(&state[tile], ST_INC | (excl + agg));
     return excl;
+}
+
+__device__ __forceinline__ u64 lookback(u64 *state, u32 tile, u64 agg, int lane, u32 *err) {
+    if (lane == 0) publish_aggregate(state, tile, agg);
+    return resolve_prefix(state, tile, agg, lane, err);
 }
 
 }  // namespace gtars

@@ -10,13 +10,15 @@
 // LDS once, then take tiles of TPB*4 consecutive queries through a ticket
 // counter.  Per query:
 //   1. LDS binary search of `top` (lock-step over the thread's 4 queries so the
-//      4 searches overlap) for the last sampled block whose first start is
-//      < q_start - max_len  -- Bits::find's lower_bound, bits.rs:144-147;
-//      (+ a short search of blk_first in L2 when top_shift > 0);
-//   2. ONE 128-byte block fetch (4 x dwordx4 per lane), overlap test of its 8
-//      intervals in registers -> 8-bit hit mask; the scan continues into the
-//      following blocks only while the block's last start is still < q_end
-//      (iv.start >= stop ends the reference scan, bits.rs:441-443);
+//      4 searches overlap) for the first block whose LAST start is
+//      >= q_start - max_len: the block that holds Bits::find's lower_bound
+//      (bits.rs:144-147) (+ a short search of blk_first[] in L2 when top_shift > 0;
+//      despite its name that array then holds per-block last starts);
+//   2. ONE 128-byte record fetch (4 x dwordx4 per lane), overlap test of its 8
+//      intervals in registers -> hit mask; if the block's last start is still
+//      < q_end (iv.start >= stop ends the reference scan, bits.rs:441-443) the
+//      two look-ahead intervals stored in the same record are tested too, and
+//      only a query that runs past those walks into the following blocks;
 //   3. wave shuffles + one LDS word per wave scan the per-thread hit counts,
 //      wave 0 resolves the tile's global base by chained look-back (scan.cuh);
 //   4. CSR offsets (u64) and token ids (u32) are written once, in place.
@@ -33,44 +35,109 @@ namespace gtars {
 
 constexpr int TOK_QPT = 4;
 
+// Timing experiments only (tools/ablate.sh builds a separate library with
+// -DGTARS_ABLATE=<bits>; results are then WRONG by construction):
+//  1: no LDS search (arithmetic block guess)   2: no block fetch
+//  4: no id writes   8: no offset writes   16: no look-back   32: starts-only fetch
+#ifndef GTARS_ABLATE
+#define GTARS_ABLATE 0
+#endif
+
 __device__ __forceinline__ i64 overlap_bp_tok(u32 as, u32 ae, u32 bs, u32 be) {
     u32 mn = ae < be ? ae : be;
     u32 mx = as > bs ? as : bs;
     return (i64)mn - (i64)mx;
 }
 
-// hit mask of one block for one query; *more = the scan must continue
 template <bool FILTER>
-__device__ __forceinline__ u32 block_mask(const uint4 *__restrict__ blk, u32 qs, u32 qe, i32 min_bp, bool &more) {
+__device__ __forceinline__ bool hit_test(u32 s, u32 e, u32 qs, u32 qe, i32 min_bp) {
+    bool hit = (s < qe) & (e > qs);  // Interval::overlap, interval.rs:47-50
+    if (FILTER) hit = hit && overlap_bp_tok(qs, qe, s, e) >= (i64)min_bp;
+    return hit;
+}
+
+// Block record (32 words = 128 B = one L2 line), see AccelView:
+//   [0..7] starts  [8..15] ends  [16..23] vals
+//   [24] ns0 [25] ne0 [26] ns1 [27] ne1   look-ahead: first two intervals of the next block
+//   [28] nv0 [29] nv1 [30..31] unused
+// 8-bit hit mask of the block's own intervals; more = the scan runs past them
+template <bool FILTER>
+__device__ __forceinline__ u32 block_mask8(const uint4 *__restrict__ blk, u32 qs, u32 qe, i32 min_bp, bool &more) {
     const uint4 s0 = blk[0], s1 = blk[1], e0 = blk[2], e1 = blk[3];
     const u32 s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const u32 e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
     u32 m = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        bool hit = (s[k] < qe) & (e[k] > qs);
-        if (FILTER) hit = hit && overlap_bp_tok(qs, qe, s[k], e[k]) >= (i64)min_bp;
-        m |= (hit ? 1u : 0u) << k;
-    }
-    more = s[7] < qe;  // starts ascend inside a block: no stop seen yet
+    for (int k = 0; k < 8; ++k) m |= (hit_test<FILTER>(s[k], e[k], qs, qe, min_bp) ? 1u : 0u) << k;
+    more = s[7] < qe;  // starts ascend inside a block: no stop seen yet (bits.rs:441-443)
     return m;
 }
+
+// look-ahead part: bits 8,9; more2 = the scan runs past the look-ahead too
+template <bool FILTER>
+__device__ __forceinline__ u32 lookahead_mask(const uint4 *__restrict__ blk, u32 qs, u32 qe, i32 min_bp, bool &more2) {
+    const uint4 la = blk[6];
+    u32 m = 0;
+    m |= (hit_test<FILTER>(la.x, la.y, qs, qe, min_bp) ? 1u : 0u) << 8;
+    m |= (hit_test<FILTER>(la.z, la.w, qs, qe, min_bp) ? 1u : 0u) << 9;
+    more2 = la.z < qe;
+    return m;
+}
+
+// word index (inside the block record) of the val of hit bit k (0..9)
+__device__ __forceinline__ u32 val_word(int k) { return k < 8 ? 16u + (u32)k : 20u + (u32)k; }
+
+// Per-query state kept between the count phase and the write phase, in ONE
+// register: first block (22 bits) + 10-bit hit mask (8 own + 2 look-ahead).
+constexpr u32 B0_BITS = 22;
+constexpr u32 B0_MASK = (1u << B0_BITS) - 1u;
+
+// Tail of a query that runs past block b0's look-ahead (rare): blocks b0+1..,
+// skipping the first two intervals of block b0+1 (they were the look-ahead).
+// f(block, k) is called for every hit in scan order; returns the hit count.
+template <bool FILTER, class F>
+__device__ __forceinline__ u32 walk_tail(const AccelView &a, u32 b0, u32 be, u32 qs, u32 qe, i32 min_bp, F &&f) {
+    u32 n = 0;
+    bool mr = true;
+    for (u32 b = b0 + 1; mr && b < be; ++b) {
+        u32 m = block_mask8<FILTER>(a.blocks + (size_t)b * 8, qs, qe, min_bp, mr);
+        if (b == b0 + 1) m &= ~3u;
+        n += __popc(m);
+        while (m) {
+            const int k = __ffs((int)m) - 1;
+            m &= m - 1;
+            f(b, k);
+        }
+    }
+    return n;
+}
+
+struct TileState {
+    u32 st[TOK_QPT];  // b0 | mask10 << 22
+    u32 v0[TOK_QPT];  // ids of the first two hits: loaded during the count phase,
+    u32 v1[TOK_QPT];  //   stored one tile later (their latency is off the critical path)
+    u32 excl;         // exclusive hit offset of the thread's queries inside the tile
+    u32 more_bits;    // bit j: query j runs past its first block's look-ahead
+    u32 total;        // hits of the whole tile
+    u32 tile;
+};
 
 template <int TPB, bool FILTER>
 __global__ void __launch_bounds__(TPB)
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
-          u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u32 *__restrict__ ostarts,
-          u32 *__restrict__ oends, u64 cap, ScanWs *ws, u32 search_steps) {
+          u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
+          u32 search_steps) {
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
     __shared__ u32 s_tile;
     __shared__ u64 s_prefix;
-    __shared__ u32 s_scan[TPB / 64];
+    constexpr int NW = TPB / 64;
+    __shared__ u32 s_scan[NW];
     constexpr int TILE = TPB * TOK_QPT;
 
     const u32 n_top = a.n_top;
     const u32 n_top_pad = (n_top + 3u) & ~3u;
     u32 *s_top = smem;
-    u32 *s_cboff = smem + n_top_pad;       // [n_chrom + 1]
+    u32 *s_cboff = smem + n_top_pad;        // [n_chrom + 1]
     u32 *s_cmax = s_cboff + a.n_chrom + 1;  // [n_chrom]
     for (u32 i = threadIdx.x; i < n_top; i += TPB) s_top[i] = a.top[i];
     for (u32 i = threadIdx.x; i <= a.n_chrom; i += TPB) s_cboff[i] = a.chrom_blk_off[i];
@@ -78,186 +145,243 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     __syncthreads();
 
     const u32 num_tiles = (u32)((nq + TILE - 1) / TILE);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec_ok = ((((uintptr_t)qc) | ((uintptr_t)qs) | ((uintptr_t)qe)) & 15u) == 0;
+    const bool off_vec_ok = (((uintptr_t)offsets) & 15u) == 0;
     const u32 shift = a.top_shift;
     const u32 *blkw = reinterpret_cast<const u32 *>(a.blocks);
 
+    // Software pipeline across tiles: a tile's hit count (its "aggregate") is
+    // published as soon as it is known, but its global base is resolved -- and
+    // its outputs written -- only after the NEXT tile has been counted.  By then
+    // every predecessor has had a whole tile time to publish, so the look-back
+    // rarely waits and its latency is off the critical path.
+    TileState cur, prev;
+    bool have_prev = false;
+#if GTARS_ABLATE & 128
+    long long t_ticket = 0, t_count = 0, t_scan = 0, t_resolve = 0, t_write = 0, t_mark;
+#define GT_STAMP(acc) do { const long long _n = clock64(); acc += _n - t_mark; t_mark = _n; } while (0)
+    t_mark = clock64();
+#else
+#define GT_STAMP(acc) do { } while (0)
+#endif
+
     for (;;) {
         if (threadIdx.x == 0) s_tile = atomicAdd(&ws->ticket, 1u);
-        __syncthreads();
+        lds_barrier();
         const u32 tile = s_tile;
-        if (tile >= num_tiles) break;
+        const bool has_cur = tile < num_tiles;
+        GT_STAMP(t_ticket);
 
-        const u64 q0 = (u64)tile * TILE + (u64)threadIdx.x * TOK_QPT;
-        u32 c[TOK_QPT], s[TOK_QPT], e[TOK_QPT];
-        if (vec_ok && q0 + TOK_QPT <= nq) {
-            const uint4 c4 = *reinterpret_cast<const uint4 *>(qc + q0);
-            const uint4 s4 = *reinterpret_cast<const uint4 *>(qs + q0);
-            const uint4 e4 = *reinterpret_cast<const uint4 *>(qe + q0);
-            c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
-            s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
-            e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
-        } else {
+        if (has_cur) {
+            // =============== count phase: 4 consecutive queries per thread ===============
+            const u64 q0 = (u64)tile * TILE + (u64)threadIdx.x * TOK_QPT;
+            u32 c[TOK_QPT], s[TOK_QPT], e[TOK_QPT];
+            if (vec_ok && q0 + TOK_QPT <= nq) {
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(qc + q0);
+                const uint4 s4 = *reinterpret_cast<const uint4 *>(qs + q0);
+                const uint4 e4 = *reinterpret_cast<const uint4 *>(qe + q0);
+                c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+                s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
+                e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < TOK_QPT; ++j) {
-                const bool ok = q0 + j < nq;
-                c[j] = ok ? qc[q0 + j] : GTARS_UNKNOWN_CHROM;
-                s[j] = ok ? qs[q0 + j] : 0;
-                e[j] = ok ? qe[q0 + j] : 0;
-            }
-        }
-
-        // ---- 1. search: last (sampled) block whose first start < key ----------
-        u32 key[TOK_QPT], lo[TOK_QPT], len[TOK_QPT], tbase[TOK_QPT], be[TOK_QPT];
-#pragma unroll
-        for (int j = 0; j < TOK_QPT; ++j) {
-            const bool valid = c[j] < a.n_chrom;
-            const u32 cc = valid ? c[j] : 0u;
-            const u32 bb = s_cboff[cc];
-            be[j] = valid ? s_cboff[cc + 1] : bb;  // invalid -> empty range
-            const u32 ml = s_cmax[cc];
-            key[j] = s[j] >= ml ? s[j] - ml : 0u;
-            tbase[j] = bb >> shift;
-            lo[j] = tbase[j];
-            len[j] = (be[j] - bb) >> shift;
-        }
-        for (u32 it = 0; it < search_steps; ++it) {
-#pragma unroll
-            for (int j = 0; j < TOK_QPT; ++j) {
-                const u32 half = len[j] >> 1;
-                const u32 mid = lo[j] + half;
-                const u32 v = s_top[mid < n_top ? mid : n_top - 1];
-                const bool pred = (len[j] > 0) & (v < key[j]);
-                lo[j] = pred ? mid + 1 : lo[j];
-                len[j] = pred ? len[j] - half - 1 : half;
-            }
-        }
-        u32 b0[TOK_QPT];
-#pragma unroll
-        for (int j = 0; j < TOK_QPT; ++j) {
-            const u32 nlt = lo[j] - tbase[j];                 // sampled entries < key
-            const u32 t0 = tbase[j] + (nlt ? nlt - 1 : 0u);
-            u32 b = t0 << shift;
-            if (shift) {
-                // blocks [b, b + 2^shift): count blk_first < key (first entry is top[t0])
-                u32 l2 = b, n2 = (be[j] > b) ? min(1u << shift, be[j] - b) : 0u;
-                while (n2 > 0) {
-                    const u32 half = n2 >> 1, mid = l2 + half;
-                    const bool pred = a.blk_first[mid] < key[j];
-                    l2 = pred ? mid + 1 : l2;
-                    n2 = pred ? n2 - half - 1 : half;
+                for (int j = 0; j < TOK_QPT; ++j) {
+                    const bool ok = q0 + j < nq;
+                    c[j] = ok ? qc[q0 + j] : GTARS_UNKNOWN_CHROM;
+                    s[j] = ok ? qs[q0 + j] : 0;
+                    e[j] = ok ? qe[q0 + j] : 0;
                 }
-                const u32 nlt2 = l2 - b;
-                b += nlt2 ? nlt2 - 1 : 0u;
             }
-            b0[j] = b;
-        }
 
-        // ---- 2. first block of every query (independent 128-B fetches) --------
-        u32 mask[TOK_QPT], cnt[TOK_QPT];
-        bool more[TOK_QPT];
-#pragma unroll
-        for (int j = 0; j < TOK_QPT; ++j) {
-            const bool act = b0[j] < be[j];
-            const u32 b = act ? b0[j] : 0u;
-            bool mr;
-            const u32 m = block_mask<FILTER>(a.blocks + (size_t)b * 8, s[j], e[j], min_bp, mr);
-            mask[j] = act ? m : 0u;
-            more[j] = act && mr;
-        }
-        // continuation blocks (rare: the query reaches past the block's last start)
-        u32 tsum = 0;
-#pragma unroll
-        for (int j = 0; j < TOK_QPT; ++j) {
-            u32 n = __popc(mask[j]);
-            if (more[j]) {
-                u32 b = b0[j] + 1;
-                bool mr = true;
-                while (mr && b < be[j]) {
-                    const u32 m = block_mask<FILTER>(a.blocks + (size_t)b * 8, s[j], e[j], min_bp, mr);
-                    if (b == b0[j] + 1) mask[j] |= m << 8;
-                    n += __popc(m);
-                    ++b;
-                }
-                // more[j] stays true only if blocks beyond the second were visited
-                more[j] = b > b0[j] + 2;
-            }
-            cnt[j] = n;
-            tsum += n;
-        }
-
-        // ---- 3. scan ------------------------------------------------------------
-        u32 block_total;
-        const u32 excl = block_exclusive_scan<TPB>(tsum, s_scan, block_total);
-        if (threadIdx.x < 64) {
-            const u64 p = lookback(ws->state, tile, (u64)block_total, lane, &ws->err);
-            if (lane == 0) s_prefix = p;
-        }
-        __syncthreads();
-        const u64 prefix = s_prefix;
-        u64 run = prefix + excl;
-        if (tile == num_tiles - 1 && threadIdx.x == TPB - 1) {
-            const u64 tot = prefix + (u64)block_total;
-            offsets[nq] = tot;
-            ws->total = tot;
-        }
-
-        // ---- 4. write offsets + payloads ----------------------------------------
-        if (q0 + TOK_QPT <= nq && ((((uintptr_t)offsets) & 15u) == 0)) {
-            const u64 o0 = run, o1 = o0 + cnt[0], o2 = o1 + cnt[1], o3 = o2 + cnt[2];
-            ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(offsets + q0);
-            dst[0] = make_ulonglong2(o0, o1);
-            dst[1] = make_ulonglong2(o2, o3);
-        } else {
-            u64 r = run;
+            // ---- 1. search: first block whose LAST start is >= key (it holds the lower_bound) ----
+            u32 key[TOK_QPT], lo[TOK_QPT], len[TOK_QPT], be[TOK_QPT];
 #pragma unroll
             for (int j = 0; j < TOK_QPT; ++j) {
-                if (q0 + j < nq) offsets[q0 + j] = r;
-                r += cnt[j];
+                const bool valid = c[j] < a.n_chrom;
+                const u32 cc = valid ? c[j] : 0u;
+                const u32 bb = s_cboff[cc];
+                be[j] = valid ? s_cboff[cc + 1] : bb;  // invalid -> empty range
+                const u32 ml = s_cmax[cc];
+                key[j] = s[j] >= ml ? s[j] - ml : 0u;
+                lo[j] = bb >> shift;
+                len[j] = (be[j] - bb) >> shift;
             }
-        }
+            for (u32 it = 0; it < search_steps; ++it) {
 #pragma unroll
-        for (int j = 0; j < TOK_QPT; ++j) {
-            if (cnt[j]) {
-                u64 o = run;
-                u32 m = mask[j];
-                while (m) {
-                    const int k = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    const u32 w = (b0[j] + (u32)(k >> 3)) * 32u + (u32)(k & 7);
-                    if (o < cap) {
-                        if (ovals) ovals[o] = blkw[w + 16];
-                        if (ostarts) ostarts[o] = blkw[w];
-                        if (oends) oends[o] = blkw[w + 8];
+                for (int j = 0; j < TOK_QPT; ++j) {
+                    const u32 half = len[j] >> 1;
+                    const u32 mid = lo[j] + half;
+                    const u32 v = s_top[mid < n_top ? mid : n_top - 1];
+                    const bool pred = (len[j] > 0) & (v < key[j]);
+                    lo[j] = pred ? mid + 1 : lo[j];
+                    len[j] = pred ? len[j] - half - 1 : half;
+                }
+            }
+            u32 b0[TOK_QPT];
+#pragma unroll
+            for (int j = 0; j < TOK_QPT; ++j) {
+                u32 b = lo[j] << shift;  // first group whose max last-start >= key (or == be: no candidate)
+                if (shift) {
+                    // inside the group: first block with blk_last >= key
+                    u32 l2 = b, n2 = (be[j] > b) ? min(1u << shift, be[j] - b) : 0u;
+                    while (n2 > 0) {
+                        const u32 half = n2 >> 1, mid = l2 + half;
+                        const bool pred = a.blk_first[mid] < key[j];
+                        l2 = pred ? mid + 1 : l2;
+                        n2 = pred ? n2 - half - 1 : half;
                     }
-                    ++o;
+                    b = l2;
                 }
+                b0[j] = b;
+            }
+
+            // ---- 2. one 128-byte record per query (4 independent fetches per thread) ----
+            u32 mask[TOK_QPT];
+            bool more[TOK_QPT];
+#pragma unroll
+            for (int j = 0; j < TOK_QPT; ++j) {
+                const bool act = b0[j] < be[j];
+                const u32 b = act ? b0[j] : 0u;
+                bool mr;
+                u32 m;
+                if (GTARS_ABLATE & 2) {
+                    m = (s[j] >> 3) & 1u;
+                    mr = false;
+                } else {
+                    m = block_mask8<FILTER>(a.blocks + (size_t)b * 8, s[j], e[j], min_bp, mr);
+                }
+                mask[j] = act ? m : 0u;
+                more[j] = act && mr;
+            }
+            u32 tsum = 0;
+            cur.more_bits = 0;
+#pragma unroll
+            for (int j = 0; j < TOK_QPT; ++j) {
+                bool more2 = false;
                 if (more[j]) {
-                    // blocks beyond the second: recompute their masks
-                    u32 b = b0[j] + 2;
-                    bool mr = true;
-                    while (mr && b < be[j]) {
-                        u32 mm = block_mask<FILTER>(a.blocks + (size_t)b * 8, s[j], e[j], min_bp, mr);
-                        while (mm) {
-                            const int k = __ffs((int)mm) - 1;
-                            mm &= mm - 1;
-                            const u32 w = b * 32u + (u32)k;
-                            if (o < cap) {
-                                if (ovals) ovals[o] = blkw[w + 16];
-                                if (ostarts) ostarts[o] = blkw[w];
-                                if (oends) oends[o] = blkw[w + 8];
-                            }
-                            ++o;
-                        }
-                        ++b;
+                    // the query reaches past the block's last start: test the two look-ahead
+                    // intervals stored in the same record (an L1 hit)
+                    mask[j] |= lookahead_mask<FILTER>(a.blocks + (size_t)b0[j] * 8, s[j], e[j], min_bp, more2);
+                    more2 = more2 && (b0[j] + 1 < be[j]);
+                }
+                u32 n = __popc(mask[j]);
+                if (more2) n += walk_tail<FILTER>(a, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
+                tsum += n;
+                cur.st[j] = (b0[j] & B0_MASK) | (mask[j] << B0_BITS);
+                cur.more_bits |= (more2 ? 1u : 0u) << j;
+                // issue the id loads of the first two hits now; they are stored one tile later
+                u32 m = mask[j];
+                const u32 base = b0[j] * 32u;
+                cur.v0[j] = m ? blkw[base + val_word(__ffs((int)m) - 1)] : 0u;
+                m &= m - 1;
+                cur.v1[j] = m ? blkw[base + val_word(__ffs((int)m) - 1)] : 0u;
+            }
+            GT_STAMP(t_count);
+
+            // =============== workgroup scan of the per-thread hit counts ===============
+            const u32 inc = wave_inclusive_scan_u32(tsum, lane);
+            if (lane == 63) s_scan[wave] = inc;
+            lds_barrier();
+            u32 wbase = 0, block_total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const u32 v = s_scan[w];
+                if (w < wave) wbase += v;
+                block_total += v;
+            }
+            cur.excl = wbase + inc - tsum;
+            cur.total = block_total;
+            cur.tile = tile;
+            if (threadIdx.x == 0 && !(GTARS_ABLATE & 16)) publish_aggregate(ws->state, tile, (u64)block_total);
+            GT_STAMP(t_scan);
+        }
+
+        // =============== resolve + write the PREVIOUS tile ===============
+        if (have_prev) {
+            if (threadIdx.x < 64) {
+                const u64 p = (GTARS_ABLATE & 16) ? (u64)prev.tile * 600u
+                                                  : resolve_prefix(ws->state, prev.tile, (u64)prev.total, lane, &ws->err);
+                if (lane == 0) s_prefix = p;
+            }
+            lds_barrier();
+            GT_STAMP(t_resolve);
+            const u64 prefix = s_prefix;
+            if (prev.tile == num_tiles - 1 && threadIdx.x == TPB - 1) {
+                const u64 tot = prefix + (u64)prev.total;
+                offsets[nq] = tot;
+                ws->total = tot;
+            }
+            const u64 q0 = (u64)prev.tile * TILE + (u64)threadIdx.x * TOK_QPT;
+            u64 run = prefix + prev.excl;
+            u64 o4[TOK_QPT];
+            // sweep 1: offsets, plus the rare paths (3rd+ hit of a record, tails).  Their loads
+            // wait on vmcnt, which also counts stores, so they go BEFORE the common stores.
+#pragma unroll
+            for (int j = 0; j < TOK_QPT; ++j) {
+                o4[j] = run;
+                const u32 b0 = prev.st[j] & B0_MASK;
+                u32 m = prev.st[j] >> B0_BITS;
+                u64 o = run + (u64)__popc(m);
+                if (!(GTARS_ABLATE & 4)) {
+                    m &= m - 1;
+                    m &= m - 1;  // first two hits: v0 / v1, stored in sweep 2
+                    u64 o3 = run + 2;
+                    while (m) {
+                        const int k = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        if (o3 < cap) ovals[o3] = blkw[b0 * 32u + val_word(k)];
+                        ++o3;
+                    }
+                    if (prev.more_bits & (1u << j)) {
+                        const u32 cq = qc[q0 + j], sq = qs[q0 + j], eq = qe[q0 + j];
+                        const u32 be = s_cboff[cq + 1];
+                        u64 ot = o;
+                        o += walk_tail<FILTER>(a, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
+                            if (ot < cap) ovals[ot] = blkw[b * 32u + 16u + (u32)k];
+                            ++ot;
+                        });
                     }
                 }
+                run = o;
             }
-            run += cnt[j];
+            // sweep 2: the common stores
+            if (!(GTARS_ABLATE & 4)) {
+#pragma unroll
+                for (int j = 0; j < TOK_QPT; ++j) {
+                    const u32 n = __popc(prev.st[j] >> B0_BITS);
+                    if (n >= 1 && o4[j] < cap) ovals[o4[j]] = prev.v0[j];
+                    if (n >= 2 && o4[j] + 1 < cap) ovals[o4[j] + 1] = prev.v1[j];
+                }
+            }
+            if (GTARS_ABLATE & 8) {
+            } else if (off_vec_ok && q0 + TOK_QPT <= nq) {
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(offsets + q0);
+                dst[0] = make_ulonglong2(o4[0], o4[1]);
+                dst[1] = make_ulonglong2(o4[2], o4[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TOK_QPT; ++j)
+                    if (q0 + j < nq) offsets[q0 + j] = o4[j];
+            }
         }
-        __syncthreads();  // s_tile / s_prefix reuse
+        lds_barrier();  // s_tile / s_prefix / s_scan reuse
+        GT_STAMP(t_write);
+        if (!has_cur) break;
+        prev = cur;
+        have_prev = true;
     }
+#if GTARS_ABLATE & 128
+    if (threadIdx.x == 0) {
+        unsigned long long *dbg = (unsigned long long *)(ws->state + num_tiles);  // 8 spare words
+        atomicAdd(&dbg[0], (unsigned long long)t_ticket);
+        atomicAdd(&dbg[1], (unsigned long long)t_count);
+        atomicAdd(&dbg[2], (unsigned long long)t_scan);
+        atomicAdd(&dbg[3], (unsigned long long)t_resolve);
+        atomicAdd(&dbg[4], (unsigned long long)t_write);
+        atomicAdd(&dbg[5], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- launcher
@@ -273,13 +397,14 @@ static size_t tok_lds_bytes(const AccelView &a) {
 }
 
 bool tokenize_lds_supported(const AccelView &a) {
-    return a.n_blocks > 0 && a.n_top > 0 && tok_lds_bytes(a) <= 120 * 1024;
+    return a.n_blocks > 0 && a.n_blocks <= ((1u << 22) - 1u) && a.n_top > 0 && tok_lds_bytes(a) <= 120 * 1024;
 }
 
-static int choose_tpb(u64 nq) {
-    const int forced = env_int("GTARS_TOK_TPB", 0);
-    if (forced == 256 || forced == 512 || forced == 1024) return forced;
-    return nq >= (1ull << 22) ? 512 : 256;
+// launch geometry: threads per workgroup (a tile is TPB * 4 queries)
+static void choose_geometry(u64 nq, int &tpb) {
+    tpb = nq >= (1ull << 22) ? 512 : 256;
+    const int f_tpb = env_int("GTARS_TOK_TPB", 0);
+    if (f_tpb == 256 || f_tpb == 512 || f_tpb == 1024) tpb = f_tpb;
 }
 
 size_t tokenize_lds_ws_bytes(u64 nq) {
@@ -306,27 +431,44 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     int dev = 0, cus = 256;
     GT_HIP(hipGetDevice(&dev));
     GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const u64 tiles = (nq + (u64)TPB * TOK_QPT - 1) / ((u64)TPB * TOK_QPT);
+    const u64 tile_q = (u64)TPB * TOK_QPT;
+    const u64 tiles = (nq + tile_q - 1) / tile_q;
     u64 grid = (u64)cus * per_cu;
     if (grid > tiles) grid = tiles;
     u32 steps = 0;
     while ((1u << steps) <= a.max_chrom_top) ++steps;  // iterations until len == 0
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq, min_bp, out.offsets,
-                       out.vals, out.starts, out.ends, out.capacity, ws, steps);
+                       out.vals, out.vals ? out.capacity : 0, ws, steps);
     GT_HIP(hipGetLastError());
+#if GTARS_ABLATE & 128
+    {
+        static int printed = 0;
+        if (printed++ < 2) {
+            unsigned long long h[6];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, (char *)ws + sizeof(u64) * (2 + tiles), sizeof h, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[phase cycles per WG, %llu WGs, %llu tiles] ticket %.0f count %.0f scan %.0f resolve %.0f write %.0f\n",
+                    h[5], (unsigned long long)tiles, (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5],
+                    (double)h[3] / h[5], (double)h[4] / h[5]);
+        }
+    }
+#endif
     return GTARS_OK;
 }
 
 gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  int has_min, i32 min_overlap, const EnumOut &out, void *scan_ws,
                                  size_t scan_ws_bytes, hipStream_t st) {
+    if (out.starts || out.ends) return fail(GTARS_ERR_INTERNAL, "k_tok_lds writes vals only");
     if (nq == 0) {
         GT_HIP(hipMemsetAsync(out.offsets, 0, sizeof(u64), st));
         GT_HIP(hipMemsetAsync(scan_ws, 0, sizeof(ScanWs), st));
         return GTARS_OK;
     }
-    const int tpb = choose_tpb(nq);
-    const u64 tiles = (nq + (u64)tpb * TOK_QPT - 1) / ((u64)tpb * TOK_QPT);
+    int tpb;
+    choose_geometry(nq, tpb);
+    const u64 tile_q = (u64)tpb * TOK_QPT;
+    const u64 tiles = (nq + tile_q - 1) / tile_q;
     if (tiles > 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "query batch too large for one launch");
     const size_t need = scan_ws_bytes_for_tiles(tiles);
     if (scan_ws_bytes < need) return fail(GTARS_ERR_INTERNAL, "fused scan workspace too small");
@@ -335,14 +477,15 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     const i32 min_bp = has_min ? min_overlap : 0;
     ScanWs *ws = (ScanWs *)scan_ws;
     ProfScope p("k_tok_lds", st);
-    if (tpb == 256)
-        return filter ? launch_tok_t<256, true>(a, qc, qs, qe, nq, min_bp, out, ws, st)
-                      : launch_tok_t<256, false>(a, qc, qs, qe, nq, min_bp, out, ws, st);
-    if (tpb == 512)
-        return filter ? launch_tok_t<512, true>(a, qc, qs, qe, nq, min_bp, out, ws, st)
-                      : launch_tok_t<512, false>(a, qc, qs, qe, nq, min_bp, out, ws, st);
-    return filter ? launch_tok_t<1024, true>(a, qc, qs, qe, nq, min_bp, out, ws, st)
-                  : launch_tok_t<1024, false>(a, qc, qs, qe, nq, min_bp, out, ws, st);
+#define GT_TOK_CASE(T)                                                                        \
+    if (tpb == T)                                                                             \
+        return filter ? launch_tok_t<T, true>(a, qc, qs, qe, nq, min_bp, out, ws, st)         \
+                      : launch_tok_t<T, false>(a, qc, qs, qe, nq, min_bp, out, ws, st);
+    GT_TOK_CASE(256)
+    GT_TOK_CASE(512)
+    GT_TOK_CASE(1024)
+#undef GT_TOK_CASE
+    return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");
 }
 
 }  // namespace gtars

@@ -33,16 +33,17 @@ def main():
     q = synth.make_queries(u, 1_000_000)
     ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
     sizes = [int(x) for x in os.environ.get("SIZES", "1000000,16000000,64000000").split(",")]
-    configs = [c for c in os.environ.get("CONFIGS", "256:0,512:0").split(",")]
+    configs = [c for c in os.environ.get("CONFIGS", "512:0:4").split(",")]
     for cfg in configs:
-        tpb, wg = cfg.split(":")
+        tpb, wg, rr = (cfg.split(":") + ["0", "0"])[:3]
+        os.environ["GTARS_TOK_ROUNDS"] = rr
         os.environ["GTARS_TOK_TPB"] = tpb
         os.environ["GTARS_TOK_WG_PER_CU"] = wg
         for n in sizes:
             reps = max(3, min(200, int(4e8 // n)))
             n2, h, dt = run(ix, q, n, reps, dev)
             byts = 12 * n2 + 8 * (n2 + 1) + 4 * h + 12 * len(u["chrom"])
-            print(json.dumps({"tpb": tpb, "wg_per_cu": wg, "nq": n2, "us": round(dt * 1e6, 2), "gqps": round(n2 / dt / 1e9, 2),
+            print(json.dumps({"tpb": tpb, "wg_per_cu": wg, "rounds": rr, "nq": n2, "us": round(dt * 1e6, 2), "gqps": round(n2 / dt / 1e9, 2),
                               "hbm_frac": round(byts / dt / 8e12, 4)}), flush=True)
 if __name__ == "__main__":
     main()
