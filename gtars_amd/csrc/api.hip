@@ -47,10 +47,12 @@ gtars_status Workspace::reserve(size_t need) {
     GT_HIP(hipGetDevice(&dev));
     if (ptr && device == dev && bytes >= need) return GTARS_OK;
     if (ptr) {
+        (void)hipDeviceSynchronize();  // a launch may still be using the old buffer
         (void)hipFree(ptr);
         ptr = nullptr;
         bytes = 0;
     }
+    ep = ScanEpoch();
     size_t want = std::max<size_t>(need, 1 << 20);
     want = (want + (1 << 20) - 1) & ~(size_t)((1 << 20) - 1);
     GT_HIP(hipMalloc(&ptr, want));
@@ -426,6 +428,7 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         for (u32 t = 0; t < h_top.size(); ++t) h_top[t] = h_blk_first[(((size_t)t + 1) << shift) - 1];
         ix->acc_n_blocks = nb;
         ix->acc_n_top = (u32)h_top.size();
+        h_top.resize((h_top.size() + 3) & ~(size_t)3, 0xFFFFFFFFu);  // k_tok_lds copies it with 16-byte loads
         ix->acc_top_shift = shift;
         ix->acc_max_chrom_top = max_ct;
         ix->has_accel = nb > 0;
@@ -523,9 +526,10 @@ static bool use_lds_path(const gtars_index *ix) {
 }
 static gtars_status run_fused(const gtars_index *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               int has_min, i32 min_overlap, const EnumOut &out, void *ws, size_t ws_bytes,
-                              hipStream_t s) {
-    if (use_lds_path(ix))
-        return launch_tokenize_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, s);
+                              ScanEpoch &ep, hipStream_t s) {
+    if (use_lds_path(ix) && !out.starts && !out.ends)
+        return launch_tokenize_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s);
+    ep = ScanEpoch();  // the generic kernel clears the workspace itself
     return launch_enumerate_fused(ix->view(), ix->kind, qc, qs, qe, nq, has_min, min_overlap, out, ws,
                                   ws_bytes, s);
 }
@@ -534,7 +538,10 @@ static gtars_status read_scan_head(const void *ws, hipStream_t s, u64 *total) {
     GT_HIP(hipMemcpyAsync(&h, ws, sizeof h, hipMemcpyDeviceToHost, s));
     GT_HIP(hipStreamSynchronize(s));
     if (total) *total = h.total;
-    if (h.err) return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
+    if (h.err) {
+        (void)hipMemsetAsync(const_cast<void *>(ws), 0, sizeof(ScanHead), s);
+        return fail(GTARS_ERR_INTERNAL, "chained scan timed out (look-back spin limit)");
+    }
     return GTARS_OK;
 }
 
@@ -556,11 +563,14 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
     st = ws.reserve(wsb);
     if (st) return st;
     EnumOut out{d_offsets, d_ids, nullptr, nullptr, d_ids ? ids_capacity : 0};
-    st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, s);
+    st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s);
     if (st) return st;
     if (total_hits) {
         st = read_scan_head(ws.ptr, s, total_hits);
-        if (st) return st;
+        if (st) {
+            ws.ep = ScanEpoch();  // force a clean workspace next time
+            return st;
+        }
         if (d_ids && *total_hits > ids_capacity)
             return fail(GTARS_ERR_CAPACITY, "ids buffer too small: need " + std::to_string(*total_hits));
     }
@@ -633,7 +643,8 @@ static gtars_status enumerate_to_host(const gtars_index_t *ix, const u32 *qc, co
     if (st) return st;
     // pass 1: offsets + total only (no payload buffers)
     EnumOut o1{d_off.as<u64>(), nullptr, nullptr, nullptr, 0};
-    st = run_fused(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, nullptr);
+    ScanEpoch ep;
+    st = run_fused(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, ep, nullptr);
     if (st) return st;
     u64 h = 0;
     st = read_scan_head(d_ws.p, nullptr, &h);
@@ -788,7 +799,8 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
     const size_t wsb = std::max(fused_ws_bytes(ix, nq), scan_ws_bytes(nq));
     if ((st = d_ws.alloc(wsb))) return st;
     EnumOut o1{d_off.as<u64>(), nullptr, nullptr, nullptr, 0};
-    st = run_fused(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, nullptr);
+    ScanEpoch ep;
+    st = run_fused(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, ep, nullptr);
     if (st) return st;
     u64 h = 0;
     st = read_scan_head(d_ws.p, nullptr, &h);

@@ -94,10 +94,19 @@ struct IgdView {
 };
 
 // ---- per-thread grow-only device workspace ----------------------------------
+// host-side bookkeeping of a chained-scan workspace that is reused across launches without
+// being cleared (see scan.cuh): current epoch, tickets drawn so far, bytes known to be zeroed
+struct ScanEpoch {
+    u32 epoch = 0;
+    u32 ticket_base = 0;
+    size_t cleared_bytes = 0;
+};
+
 struct Workspace {
     void *ptr = nullptr;
     size_t bytes = 0;
     int device = -1;
+    ScanEpoch ep;
     gtars_status reserve(size_t need);
     ~Workspace();
 };
@@ -130,7 +139,7 @@ size_t enumerate_fused_ws_bytes(u64 nq);
 // LDS-tiled fused tokenizer (tokenize_lds.hip), Bits order only
 gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  int has_min, i32 min_overlap, const EnumOut &out, void *scan_ws,
-                                 size_t scan_ws_bytes, hipStream_t st);
+                                 size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st);
 size_t tokenize_lds_ws_bytes(u64 nq);
 bool tokenize_lds_supported(const AccelView &a);
 

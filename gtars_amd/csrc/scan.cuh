@@ -56,10 +56,17 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 x, u32 *lds, u32 &total)
 // read with relaxed agent-scope atomics (L1-bypassing), so no fence is needed
 // and nothing depends on dispatch order or XCD placement.  Tiles are handed
 // out by a ticket counter, so a tile only waits on tiles that already started.
+//
+// Bits 61..48 carry the launch's epoch: a granule written by an earlier launch
+// reads as "not published", so a workspace that is reused launch after launch
+// never has to be cleared (saves a memset kernel per call); bits 47..0 the value.
 constexpr u64 ST_SHIFT = 62;
 constexpr u64 ST_AGG = 1ull << ST_SHIFT;
 constexpr u64 ST_INC = 2ull << ST_SHIFT;
 constexpr u64 ST_MASK = 3ull << ST_SHIFT;
+constexpr u64 EP_SHIFT = 48;
+constexpr u32 EP_MAX = 0x3FFFu;
+constexpr u64 VAL_MASK = (1ull << EP_SHIFT) - 1ull;
 constexpr u32 LOOKBACK_SPIN_LIMIT = 1u << 22;
 
 struct ScanWs {
@@ -86,13 +93,13 @@ __device__ __forceinline__ void st_state(u64 *p, u64 v) {
 constexpr int LB_W = 8;
 
 // publish a tile's aggregate (tile 0: its inclusive prefix) -- one lane
-__device__ __forceinline__ void publish_aggregate(u64 *state, u32 tile, u64 agg) {
-    st_state(&state[tile], (tile == 0 ? ST_INC : ST_AGG) | agg);
+__device__ __forceinline__ void publish_aggregate(u64 *state, u32 tile, u64 agg, u32 epoch = 0) {
+    st_state(&state[tile], (tile == 0 ? ST_INC : ST_AGG) | ((u64)epoch << EP_SHIFT) | agg);
 }
 
 // resolve the exclusive prefix of `tile` (whose aggregate is already
 // published) and publish its inclusive prefix
-__device__ __forceinline__ u64 resolve_prefix(u64 *state, u32 tile, u64 agg, int lane, u32 *err) {
+__device__ __forceinline__ u64 resolve_prefix(u64 *state, u32 tile, u64 agg, int lane, u32 *err, u32 epoch = 0) {
     if (tile == 0) return 0;
     u64 excl = 0;
     i64 pred = (i64)tile - 1;
@@ -103,7 +110,12 @@ __device__ __forceinline__ u64 resolve_prefix(u64 *state, u32 tile, u64 agg, int
 #pragma unroll
         for (int w = 0; w < LB_W; ++w) {
             const i64 idx = pred - (i64)w * 64 - lane;
-            val[w] = idx >= 0 ? ld_state(&state[idx]) : ST_INC;  // before tile 0: inclusive 0
+            u64 v = ST_INC;  // before tile 0: inclusive 0
+            if (idx >= 0) {
+                v = ld_state(&state[idx]);
+                if ((u32)((v >> EP_SHIFT) & EP_MAX) != epoch) v = 0;  // left over from an earlier launch
+            }
+            val[w] = v;
         }
         // consume the windows nearest-first; stop at the first window that is
         // not fully published up to its first inclusive entry
@@ -121,7 +133,7 @@ __device__ __forceinline__ u64 resolve_prefix(u64 *state, u32 tile, u64 agg, int
 #else
             if (b_inv & need) continue;  // not ready: re-read from this window on
 #endif
-            const u64 contrib = (lane <= first_inc) ? (val[w] & ~ST_MASK) : 0ull;
+            const u64 contrib = (lane <= first_inc) ? (val[w] & VAL_MASK) : 0ull;
             excl += wave_reduce_sum_u64(contrib);
             consumed = w + 1;
             if (first_inc < 64) done = true;
@@ -135,7 +147,7 @@ __device__ __forceinline__ u64 resolve_prefix(u64 *state, u32 tile, u64 agg, int
             __builtin_amdgcn_s_sleep(1);
         }
     }
-    if (lane == 0) st_state(&state[tile], ST_INC | (excl + agg));
+    if (lane == 0) st_state(&state[tile], ST_INC | ((u64)epoch << EP_SHIFT) | (excl + agg));
     return excl;
 }
 

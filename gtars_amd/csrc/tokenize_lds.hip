@@ -126,7 +126,7 @@ template <int TPB, bool FILTER>
 __global__ void __launch_bounds__(TPB)
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
-          u32 search_steps) {
+          u32 search_steps, u32 epoch, u32 ticket_base) {
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
     __shared__ u32 s_tile;
     __shared__ u64 s_prefix;
@@ -139,7 +139,21 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     u32 *s_top = smem;
     u32 *s_cboff = smem + n_top_pad;        // [n_chrom + 1]
     u32 *s_cmax = s_cboff + a.n_chrom + 1;  // [n_chrom]
-    for (u32 i = threadIdx.x; i < n_top; i += TPB) s_top[i] = a.top[i];
+    {
+        // the top array is padded to a multiple of 4 words on the device: 16-byte loads, 4 in flight
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.top);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_top);
+        const u32 n4 = n_top_pad >> 2;
+        // every workgroup copies the same array: start each one at a different place so that they
+        // do not all queue on the same L2 channel at the same time
+        const u32 rot = n4 ? (u32)(((u64)blockIdx.x * 2654435761ull) % n4) : 0u;
+#pragma unroll 4
+        for (u32 i = threadIdx.x; i < n4; i += TPB) {
+            u32 k = i + rot;
+            k = k >= n4 ? k - n4 : k;
+            dst[k] = src[k];
+        }
+    }
     for (u32 i = threadIdx.x; i <= a.n_chrom; i += TPB) s_cboff[i] = a.chrom_blk_off[i];
     for (u32 i = threadIdx.x; i < a.n_chrom; i += TPB) s_cmax[i] = a.chrom_maxlen[i];
     __syncthreads();
@@ -166,10 +180,23 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
 #define GT_STAMP(acc) do { } while (0)
 #endif
 
+    // Tile assignment: the grid never exceeds what is resident at once (launcher), so every
+    // workgroup's FIRST tile is simply its block index -- no atomic while the whole grid starts up.
+    // Further tiles are drawn from a ticket counter, so a tile only ever waits on tiles that are
+    // already running, whatever the dispatch order.
+    bool first_iter = true;
     for (;;) {
-        if (threadIdx.x == 0) s_tile = atomicAdd(&ws->ticket, 1u);
-        lds_barrier();
-        const u32 tile = s_tile;
+        u32 tile;
+        if (first_iter) {
+            tile = blockIdx.x;
+            first_iter = false;
+        } else if (num_tiles <= gridDim.x) {
+            tile = num_tiles;  // one tile per workgroup: nothing left to draw
+        } else {
+            if (threadIdx.x == 0) s_tile = gridDim.x + (atomicAdd(&ws->ticket, 1u) - ticket_base);
+            lds_barrier();
+            tile = s_tile;
+        }
         const bool has_cur = tile < num_tiles;
         GT_STAMP(t_ticket);
 
@@ -293,7 +320,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             cur.excl = wbase + inc - tsum;
             cur.total = block_total;
             cur.tile = tile;
-            if (threadIdx.x == 0 && !(GTARS_ABLATE & 16)) publish_aggregate(ws->state, tile, (u64)block_total);
+            if (threadIdx.x == 0 && !(GTARS_ABLATE & 16)) publish_aggregate(ws->state, tile, (u64)block_total, epoch);
             GT_STAMP(t_scan);
         }
 
@@ -301,7 +328,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         if (have_prev) {
             if (threadIdx.x < 64) {
                 const u64 p = (GTARS_ABLATE & 16) ? (u64)prev.tile * 600u
-                                                  : resolve_prefix(ws->state, prev.tile, (u64)prev.total, lane, &ws->err);
+                                                  : resolve_prefix(ws->state, prev.tile, (u64)prev.total, lane, &ws->err, epoch);
                 if (lane == 0) s_prefix = p;
             }
             lds_barrier();
@@ -402,7 +429,8 @@ bool tokenize_lds_supported(const AccelView &a) {
 
 // launch geometry: threads per workgroup (a tile is TPB * 4 queries)
 static void choose_geometry(u64 nq, int &tpb) {
-    tpb = nq >= (1ull << 22) ? 512 : 256;
+    // small batches: one big workgroup per CU (one LDS fill, one tile each); large: two 512-thread ones
+    tpb = nq >= (1ull << 24) ? 512 : 1024;
     const int f_tpb = env_int("GTARS_TOK_TPB", 0);
     if (f_tpb == 256 || f_tpb == 512 || f_tpb == 1024) tpb = f_tpb;
 }
@@ -414,23 +442,35 @@ size_t tokenize_lds_ws_bytes(u64 nq) {
 
 template <int TPB, bool FILTER>
 static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
-                                 i32 min_bp, const EnumOut &out, ScanWs *ws, hipStream_t st) {
+                                 i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, hipStream_t st) {
     const size_t lds = tok_lds_bytes(a);
     auto kern = k_tok_lds<TPB, FILTER>;
-    static thread_local size_t attr_set = 0;
-    if (lds > 48 * 1024 && lds > attr_set) {
-        GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = lds;
+    // occupancy / attribute queries cost tens of microseconds of host time: do them once per
+    // (kernel instantiation, LDS size, device) and cache the result
+    struct Cfg {
+        size_t lds = 0;
+        int dev = -1, per_cu = 0, cus = 0;
+    };
+    static thread_local Cfg cfg;
+    int dev = 0;
+    GT_HIP(hipGetDevice(&dev));
+    if (cfg.dev != dev || cfg.lds != lds) {
+        if (lds > 48 * 1024)
+            GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu_q = 0, cus_q = 256;
+        GT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_q, kern, TPB, lds));
+        if (per_cu_q < 1) return fail(GTARS_ERR_INTERNAL, "k_tok_lds does not fit on a CU");
+        GT_HIP(hipDeviceGetAttribute(&cus_q, hipDeviceAttributeMultiprocessorCount, dev));
+        cfg.dev = dev;
+        cfg.lds = lds;
+        cfg.per_cu = per_cu_q;
+        cfg.cus = cus_q;
     }
-    int per_cu = 0;
-    GT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, TPB, lds));
-    if (per_cu < 1) return fail(GTARS_ERR_INTERNAL, "k_tok_lds does not fit on a CU");
+    int per_cu = cfg.per_cu;
+    const int cus = cfg.cus;
     const int cap_per_cu = env_int("GTARS_TOK_WG_PER_CU", 0);
     if (cap_per_cu > 0 && per_cu > cap_per_cu) per_cu = cap_per_cu;
-    int dev = 0, cus = 256;
-    GT_HIP(hipGetDevice(&dev));
-    GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const u64 tile_q = (u64)TPB * TOK_QPT;
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     u64 grid = (u64)cus * per_cu;
@@ -438,8 +478,10 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     u32 steps = 0;
     while ((1u << steps) <= a.max_chrom_top) ++steps;  // iterations until len == 0
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq, min_bp, out.offsets,
-                       out.vals, out.vals ? out.capacity : 0, ws, steps);
+                       out.vals, out.vals ? out.capacity : 0, ws, steps, ep.epoch, ep.ticket_base);
     GT_HIP(hipGetLastError());
+    // tickets drawn by this launch: the tiles beyond the first `grid`, plus one failing draw per workgroup
+    if (tiles > grid) ep.ticket_base += (u32)tiles;
 #if GTARS_ABLATE & 128
     {
         static int printed = 0;
@@ -458,11 +500,11 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
 
 gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  int has_min, i32 min_overlap, const EnumOut &out, void *scan_ws,
-                                 size_t scan_ws_bytes, hipStream_t st) {
+                                 size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st) {
     if (out.starts || out.ends) return fail(GTARS_ERR_INTERNAL, "k_tok_lds writes vals only");
     if (nq == 0) {
         GT_HIP(hipMemsetAsync(out.offsets, 0, sizeof(u64), st));
-        GT_HIP(hipMemsetAsync(scan_ws, 0, sizeof(ScanWs), st));
+        GT_HIP(hipMemsetAsync(&((ScanHead *)scan_ws)->total, 0, sizeof(u64), st));
         return GTARS_OK;
     }
     int tpb;
@@ -472,15 +514,23 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     if (tiles > 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "query batch too large for one launch");
     const size_t need = scan_ws_bytes_for_tiles(tiles);
     if (scan_ws_bytes < need) return fail(GTARS_ERR_INTERNAL, "fused scan workspace too small");
-    GT_HIP(hipMemsetAsync(scan_ws, 0, need, st));
+    // The workspace is cleared only when it is new (ep.epoch == 0), when it has to grow past what
+    // was cleared, or when the 14-bit epoch wraps; otherwise stale granules are told apart by epoch.
+    if (ep.epoch == 0 || ep.epoch >= EP_MAX || need > ep.cleared_bytes) {
+        GT_HIP(hipMemsetAsync(scan_ws, 0, scan_ws_bytes, st));
+        ep.cleared_bytes = scan_ws_bytes;
+        ep.epoch = 0;
+        ep.ticket_base = 0;
+    }
+    ep.epoch += 1;
     const bool filter = has_min && min_overlap > 1;
     const i32 min_bp = has_min ? min_overlap : 0;
     ScanWs *ws = (ScanWs *)scan_ws;
     ProfScope p("k_tok_lds", st);
 #define GT_TOK_CASE(T)                                                                        \
     if (tpb == T)                                                                             \
-        return filter ? launch_tok_t<T, true>(a, qc, qs, qe, nq, min_bp, out, ws, st)         \
-                      : launch_tok_t<T, false>(a, qc, qs, qe, nq, min_bp, out, ws, st);
+        return filter ? launch_tok_t<T, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st)         \
+                      : launch_tok_t<T, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st);
     GT_TOK_CASE(256)
     GT_TOK_CASE(512)
     GT_TOK_CASE(1024)
