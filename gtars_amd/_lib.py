@@ -96,13 +96,91 @@ _SIG = {
     "gtars_prof_read": (C.c_int, [vp, vp, vp, C.c_int]),
 }
 
-# every symbol include/gtars_amd.h declares must resolve -- fail loudly otherwise
-for _name, (_res, _args) in _SIG.items():
-    _fn = getattr(lib, _name)
-    _fn.restype = _res
-    _fn.argtypes = _args
+pvp = C.POINTER(C.c_void_p)
+
+
+class FragmentTokens(C.Structure):
+    _fields_ = [
+        ("n_barcodes", C.c_uint64),
+        ("barcodes", C.POINTER(C.c_char_p)),
+        ("offsets", C.POINTER(C.c_uint64)),
+        ("ids", C.POINTER(C.c_uint32)),
+    ]
+
+
+cstr = C.c_char_p
+# include/gtars_amd_host.h
+_HOST_SIG = {
+    "gtars_regionset_from_bed": (C.c_int, [cstr, pp]),
+    "gtars_regionset_from_arrays": (C.c_int, [vp, vp, vp, vp, u64, pp]),
+    "gtars_regionset_free": (None, [vp]),
+    "gtars_regionset_len": (u64, [vp]),
+    "gtars_regionset_header": (cstr, [vp]),
+    "gtars_regionset_n_chrom": (u32, [vp]),
+    "gtars_regionset_chrom_name": (cstr, [vp, u32]),
+    "gtars_regionset_chrom_ids": (vp, [vp]),
+    "gtars_regionset_starts": (vp, [vp]),
+    "gtars_regionset_ends": (vp, [vp]),
+    "gtars_regionset_rest": (cstr, [vp, u64]),
+    "gtars_regionset_count_overlaps": (C.c_int, [vp, vp, C.c_int, C.c_int, i32, vp]),
+    "gtars_regionset_any_overlaps": (C.c_int, [vp, vp, C.c_int, C.c_int, i32, vp]),
+    "gtars_regionset_find_overlaps": (C.c_int, [vp, vp, C.c_int, C.c_int, i32, vp, pp, pu64]),
+    "gtars_tokenizer_from_auto": (C.c_int, [cstr, pp]),
+    "gtars_tokenizer_from_config": (C.c_int, [cstr, pp]),
+    "gtars_tokenizer_from_bed": (C.c_int, [cstr, pp]),
+    "gtars_tokenizer_free": (None, [vp]),
+    "gtars_tokenizer_vocab_size": (u64, [vp]),
+    "gtars_tokenizer_kind": (C.c_int, [vp]),
+    "gtars_tokenizer_id_to_token": (cstr, [vp, u32]),
+    "gtars_tokenizer_token_to_id": (i64, [vp, cstr]),
+    "gtars_tokenizer_vocab_token": (cstr, [vp, u64, C.POINTER(C.c_uint32)]),
+    "gtars_tokenizer_special_token": (cstr, [vp, C.c_int]),
+    "gtars_tokenizer_region_name": (cstr, [vp, cstr]),
+    "gtars_tokenizer_region_score": (C.c_double, [vp, cstr]),
+    "gtars_tokenizer_chrom_id": (i64, [vp, cstr]),
+    "gtars_tokenizer_n_chrom": (u32, [vp]),
+    "gtars_tokenizer_chrom_name": (cstr, [vp, u32]),
+    "gtars_tokenizer_index": (vp, [vp]),
+    "gtars_tokenizer_encode_regionset": (C.c_int, [vp, vp, pp, pu64]),
+    "gtars_tokenizer_encode_arrays": (C.c_int, [vp, vp, vp, vp, u64, pp, pu64]),
+    "gtars_tokenizer_encode_ids": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
+    "gtars_tokenizer_tokenize_fragment_file": (C.c_int, [vp, cstr, C.POINTER(C.POINTER(FragmentTokens))]),
+    "gtars_fragment_tokens_free": (None, [C.POINTER(FragmentTokens)]),
+    "gtars_gtok_write": (C.c_int, [cstr, vp, u64]),
+    "gtars_gtok_read": (C.c_int, [cstr, pp, pu64]),
+    "gtars_igddb_from_bed_files": (C.c_int, [vp, u64, pp]),
+    "gtars_igddb_from_bed_dir": (C.c_int, [cstr, pp]),
+    "gtars_igddb_free": (None, [vp]),
+    "gtars_igddb_n_files": (u32, [vp]),
+    "gtars_igddb_n_contigs": (u32, [vp]),
+    "gtars_igddb_file_name": (cstr, [vp, u32]),
+    "gtars_igddb_file_num_regions": (u32, [vp, u32]),
+    "gtars_igddb_file_avg_width": (C.c_double, [vp, u32]),
+    "gtars_igddb_chrom_id": (i64, [vp, cstr]),
+    "gtars_igddb_engine": (vp, [vp]),
+    "gtars_igddb_count_regionset": (C.c_int, [vp, vp, i32, C.c_int, vp]),
+}
+
+# every symbol the headers declare must resolve -- fail loudly otherwise
+for _table in (_SIG, _HOST_SIG):
+    for _name, (_res, _args) in _table.items():
+        _fn = getattr(lib, _name)
+        _fn.restype = _res
+        _fn.argtypes = _args
 
 EXPORTED_SYMBOLS = tuple(_SIG)
+EXPORTED_HOST_SYMBOLS = tuple(_HOST_SIG)
+
+
+def cstr_array(strings):
+    """list[str] -> (char*[] ctypes array, keepalive)."""
+    enc = [s.encode("utf-8") if s is not None else None for s in strings]
+    arr = (C.c_char_p * max(len(enc), 1))(*enc)
+    return arr, enc
+
+
+def dec(b):
+    return None if b is None else b.decode("utf-8", "replace")
 
 
 def last_error() -> str:

@@ -1,0 +1,1313 @@
+// host.cpp -- host ("string world") layer of libgtars_amd.so: BED / BED.gz
+// parsing, RegionSet, Universe + Tokenizer, fragment files, .gtok, IGD
+// databases from BED files.  Declared in include/gtars_amd_host.h; every
+// function cites the reference code whose behaviour it reproduces.  All
+// overlap / tokenization compute goes through the engine C ABI (gtars_amd.h),
+// i.e. the HIP kernels -- nothing here searches intervals on the CPU.
+#include <dirent.h>
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/gtars_amd_host.h"
+
+namespace gtars {
+gtars_status fail(gtars_status st, const std::string &msg);
+}
+using gtars::fail;
+
+namespace {
+
+// ------------------------------------------------------------------ file IO
+
+bool ends_with(const std::string &s, const char *suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+std::string extension_of(const std::string &path) {
+    // std::path::Path::extension of the final component
+    const size_t slash = path.find_last_of('/');
+    const std::string base = slash == std::string::npos ? path : path.substr(slash + 1);
+    const size_t dot = base.find_last_of('.');
+    if (dot == std::string::npos || dot == 0) return "";
+    return base.substr(dot + 1);
+}
+
+std::string file_stem(const std::string &path) {
+    const size_t slash = path.find_last_of('/');
+    const std::string base = slash == std::string::npos ? path : path.substr(slash + 1);
+    const size_t dot = base.find_last_of('.');
+    if (dot == std::string::npos || dot == 0) return base;
+    return base.substr(0, dot);
+}
+
+std::string parent_dir(const std::string &path) {
+    const size_t slash = path.find_last_of('/');
+    if (slash == std::string::npos) return "";
+    if (slash == 0) return "/";
+    return path.substr(0, slash);
+}
+
+std::string base_name(const std::string &path) {
+    const size_t slash = path.find_last_of('/');
+    return slash == std::string::npos ? path : path.substr(slash + 1);
+}
+
+bool is_regular_file(const std::string &p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+// get_dynamic_reader (gtars-core/src/utils.rs:115-126): gzip iff the extension is "gz"
+// (MultiGzDecoder: concatenated members, which zlib's gzread handles too).
+bool read_all(const std::string &path, std::string &out, std::string &err) {
+    out.clear();
+    if (extension_of(path) == "gz") {
+        FILE *probe = fopen(path.c_str(), "rb");
+        if (!probe) {
+            err = "Failed to open file: \"" + path + "\": " + strerror(errno);
+            return false;
+        }
+        fclose(probe);
+        gzFile f = gzopen(path.c_str(), "rb");
+        if (!f) {
+            err = "Failed to open file: \"" + path + "\"";
+            return false;
+        }
+        gzbuffer(f, 1 << 20);
+        std::vector<char> buf(1 << 20);
+        for (;;) {
+            const int n = gzread(f, buf.data(), (unsigned)buf.size());
+            if (n < 0) {
+                int e = 0;
+                err = std::string("gzip read error: ") + gzerror(f, &e);
+                gzclose(f);
+                return false;
+            }
+            if (n == 0) break;
+            out.append(buf.data(), (size_t)n);
+        }
+        gzclose(f);
+        return true;
+    }
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
+        err = "Failed to open file: \"" + path + "\": " + strerror(errno);
+        return false;
+    }
+    std::vector<char> buf(1 << 20);
+    size_t n;
+    while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) out.append(buf.data(), n);
+    fclose(f);
+    return true;
+}
+
+// BufRead::lines(): split on '\n', strip one trailing '\r'; no empty last line after a final '\n'
+struct LineIter {
+    const std::string &s;
+    size_t pos = 0;
+    explicit LineIter(const std::string &str) : s(str) {}
+    bool next(std::string &line) {
+        if (pos >= s.size()) return false;
+        size_t nl = s.find('\n', pos);
+        size_t end = nl == std::string::npos ? s.size() : nl;
+        size_t e2 = end;
+        if (nl != std::string::npos && e2 > pos && s[e2 - 1] == '\r') --e2;
+        line.assign(s, pos, e2 - pos);
+        pos = nl == std::string::npos ? s.size() : nl + 1;
+        return true;
+    }
+};
+
+std::vector<std::string> split_char(const std::string &s, char sep) {
+    std::vector<std::string> out;
+    size_t pos = 0;
+    for (;;) {
+        size_t k = s.find(sep, pos);
+        if (k == std::string::npos) {
+            out.push_back(s.substr(pos));
+            break;
+        }
+        out.push_back(s.substr(pos, k - pos));
+        pos = k + 1;
+    }
+    return out;
+}
+
+// str::split_whitespace (ASCII subset: BED files)
+std::vector<std::string> split_ws(const std::string &s) {
+    std::vector<std::string> out;
+    size_t i = 0;
+    while (i < s.size()) {
+        while (i < s.size() && isspace((unsigned char)s[i])) ++i;
+        size_t j = i;
+        while (j < s.size() && !isspace((unsigned char)s[j])) ++j;
+        if (j > i) out.push_back(s.substr(i, j - i));
+        i = j;
+    }
+    return out;
+}
+
+// str::parse::<u32>(): optional '+', ASCII digits, must fit
+bool parse_u32(const std::string &s, uint32_t &out) {
+    size_t i = 0;
+    if (!s.empty() && s[0] == '+') i = 1;
+    if (i >= s.size()) return false;
+    uint64_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + (uint64_t)(s[i] - '0');
+        if (v > 0xFFFFFFFFull) return false;
+    }
+    out = (uint32_t)v;
+    return true;
+}
+
+// str::parse::<i32>()
+bool parse_i32(const std::string &s, int32_t &out) {
+    size_t i = 0;
+    bool neg = false;
+    if (!s.empty() && (s[0] == '+' || s[0] == '-')) {
+        neg = s[0] == '-';
+        i = 1;
+    }
+    if (i >= s.size()) return false;
+    int64_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + (s[i] - '0');
+        if (v > 2147483648ll) return false;
+    }
+    if (neg) v = -v;
+    if (v < -2147483648ll || v > 2147483647ll) return false;
+    out = (int32_t)v;
+    return true;
+}
+
+bool parse_f64(const std::string &s_in, double &out) {
+    std::string s = s_in;
+    while (!s.empty() && isspace((unsigned char)s.back())) s.pop_back();
+    size_t b = 0;
+    while (b < s.size() && isspace((unsigned char)s[b])) ++b;
+    s = s.substr(b);
+    if (s.empty() || s.find_first_of("xX") != std::string::npos) return false;
+    char *end = nullptr;
+    errno = 0;
+    out = strtod(s.c_str(), &end);
+    return end && *end == '\0';
+}
+
+char *dup_cstr(const std::string &s) {
+    char *p = (char *)malloc(s.size() + 1);
+    if (p) memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+// string -> dense id dictionary in first-seen order
+struct Dict {
+    std::unordered_map<std::string, uint32_t> ids;
+    std::vector<std::string> names;
+    uint32_t get_or_add(const std::string &s) {
+        auto it = ids.find(s);
+        if (it != ids.end()) return it->second;
+        const uint32_t id = (uint32_t)names.size();
+        ids.emplace(s, id);
+        names.push_back(s);
+        return id;
+    }
+    int64_t find(const std::string &s) const {
+        auto it = ids.find(s);
+        return it == ids.end() ? -1 : (int64_t)it->second;
+    }
+};
+
+}  // namespace
+
+// =============================================================== RegionSet
+
+struct gtars_regionset {
+    Dict chroms;
+    std::vector<uint32_t> chrom_ids, starts, ends;
+    std::vector<std::string> rest;
+    std::vector<uint8_t> has_rest;
+    std::string header;
+    bool has_header = false;
+    size_t size() const { return starts.size(); }
+};
+
+namespace {
+
+struct ParsedRegion {
+    std::string chr;
+    uint32_t start, end;
+    std::string rest;
+    bool has_rest;
+};
+
+void regionset_assign(gtars_regionset *rs, std::vector<ParsedRegion> &regs) {
+    const size_t n = regs.size();
+    rs->chrom_ids.resize(n);
+    rs->starts.resize(n);
+    rs->ends.resize(n);
+    rs->rest.resize(n);
+    rs->has_rest.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        rs->chrom_ids[i] = rs->chroms.get_or_add(regs[i].chr);
+        rs->starts[i] = regs[i].start;
+        rs->ends[i] = regs[i].end;
+        rs->has_rest[i] = regs[i].has_rest;
+        if (regs[i].has_rest) rs->rest[i].swap(regs[i].rest);
+    }
+}
+
+// encode the chromosomes of `q` in the id space of dictionary `d` (unknown -> GTARS_UNKNOWN_CHROM)
+std::vector<uint32_t> translate_chroms(const gtars_regionset *q, const Dict &d) {
+    std::vector<uint32_t> map(q->chroms.names.size());
+    for (size_t i = 0; i < map.size(); ++i) {
+        const int64_t id = d.find(q->chroms.names[i]);
+        map[i] = id < 0 ? GTARS_UNKNOWN_CHROM : (uint32_t)id;
+    }
+    std::vector<uint32_t> out(q->size());
+    for (size_t i = 0; i < out.size(); ++i) out[i] = map[q->chrom_ids[i]];
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+// RegionSet::try_from(&Path) -- gtars-core/src/models/region_set.rs:52-186
+gtars_status gtars_regionset_from_bed(const char *path, gtars_regionset_t **out) {
+    if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    const std::string p(path);
+    if (!is_regular_file(p))
+        return fail(GTARS_ERR_IO, "The file " + p + " does not exist or is not a file (http input is not supported)");
+    std::string data, err;
+    if (!read_all(p, data, err)) return fail(GTARS_ERR_IO, err);
+
+    std::vector<ParsedRegion> regs;
+    std::string header, line;
+    bool first_line = true;
+    LineIter it(data);
+    while (it.next(line)) {
+        if (line.compare(0, 7, "browser") == 0 || line.compare(0, 5, "track") == 0 || (!line.empty() && line[0] == '#')) {
+            header += line;
+            first_line = false;
+            continue;
+        }
+        std::vector<std::string> parts = split_char(line, '\t');
+        if (first_line) {
+            // column headers like `chr start end ...` without '#'
+            if (parts.size() >= 3) {
+                uint32_t tmp;
+                if (!parse_u32(parts[1], tmp)) {
+                    header += line;
+                    first_line = false;
+                    continue;
+                }
+            }
+            first_line = false;
+        }
+        if (parts.size() < 3) return fail(GTARS_ERR_PARSE, "Error in parsing start position: \"" + line + "\"");
+        ParsedRegion r;
+        r.chr = parts[0];
+        if (!parse_u32(parts[1], r.start)) return fail(GTARS_ERR_PARSE, "Error in parsing start position: \"" + line + "\"");
+        if (!parse_u32(parts[2], r.end)) return fail(GTARS_ERR_PARSE, "Error in parsing end position: \"" + line + "\"");
+        for (size_t k = 3; k < parts.size(); ++k) {
+            if (k > 3) r.rest += '\t';
+            r.rest += parts[k];
+        }
+        r.has_rest = !r.rest.empty();
+        regs.push_back(std::move(r));
+    }
+    if (regs.empty()) return fail(GTARS_ERR_EMPTY, "EmptyRegionSet: " + p);
+    // RegionSet::sort (region_set.rs:502-505): stable by (chr bytes, start)
+    std::stable_sort(regs.begin(), regs.end(), [](const ParsedRegion &a, const ParsedRegion &b) {
+        const int c = a.chr.compare(b.chr);
+        if (c != 0) return c < 0;
+        return a.start < b.start;
+    });
+    auto *rs = new gtars_regionset();
+    regionset_assign(rs, regs);
+    rs->header = header;
+    rs->has_header = !header.empty();
+    *out = rs;
+    return GTARS_OK;
+}
+
+// From<Vec<Region>> -- region_set.rs:212-220 (not sorted)
+gtars_status gtars_regionset_from_arrays(const char *const *chrs, const uint32_t *starts, const uint32_t *ends,
+                                         const char *const *rest, uint64_t n, gtars_regionset_t **out) {
+    if (!out || (n && (!chrs || !starts || !ends))) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    std::vector<ParsedRegion> regs(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!chrs[i]) return fail(GTARS_ERR_INVALID_ARG, "NULL chromosome name");
+        regs[i].chr = chrs[i];
+        regs[i].start = starts[i];
+        regs[i].end = ends[i];
+        regs[i].has_rest = rest && rest[i] && rest[i][0];
+        if (regs[i].has_rest) regs[i].rest = rest[i];
+    }
+    auto *rs = new gtars_regionset();
+    regionset_assign(rs, regs);
+    *out = rs;
+    return GTARS_OK;
+}
+
+void gtars_regionset_free(gtars_regionset_t *rs) { delete rs; }
+uint64_t gtars_regionset_len(const gtars_regionset_t *rs) { return rs ? rs->size() : 0; }
+const char *gtars_regionset_header(const gtars_regionset_t *rs) {
+    return rs && rs->has_header ? rs->header.c_str() : nullptr;
+}
+uint32_t gtars_regionset_n_chrom(const gtars_regionset_t *rs) { return rs ? (uint32_t)rs->chroms.names.size() : 0; }
+const char *gtars_regionset_chrom_name(const gtars_regionset_t *rs, uint32_t id) {
+    return rs && id < rs->chroms.names.size() ? rs->chroms.names[id].c_str() : nullptr;
+}
+const uint32_t *gtars_regionset_chrom_ids(const gtars_regionset_t *rs) { return rs ? rs->chrom_ids.data() : nullptr; }
+const uint32_t *gtars_regionset_starts(const gtars_regionset_t *rs) { return rs ? rs->starts.data() : nullptr; }
+const uint32_t *gtars_regionset_ends(const gtars_regionset_t *rs) { return rs ? rs->ends.data() : nullptr; }
+const char *gtars_regionset_rest(const gtars_regionset_t *rs, uint64_t i) {
+    return rs && i < rs->size() && rs->has_rest[i] ? rs->rest[i].c_str() : nullptr;
+}
+
+}  // extern "C"
+
+namespace {
+
+// IndexedRegionSet::new(other) on the GPU (build_indexed_overlapper, multi_chrom_overlapper.rs:325-351)
+struct ScopedIndex {
+    gtars_index_t *ix = nullptr;
+    ~ScopedIndex() { gtars_index_free(ix); }
+};
+
+gtars_status build_other_index(const gtars_regionset *other, int kind, ScopedIndex &out) {
+    return gtars_index_build(other->chrom_ids.data(), other->starts.data(), other->ends.data(), nullptr,
+                             other->size(), (uint32_t)other->chroms.names.size(), kind, &out.ix);
+}
+
+}  // namespace
+
+extern "C" {
+
+gtars_status gtars_regionset_count_overlaps(const gtars_regionset_t *self, const gtars_regionset_t *other,
+                                            int kind, int has_min, int32_t min_overlap, uint32_t *counts) {
+    if (!self || !other) return fail(GTARS_ERR_INVALID_ARG, "NULL region set");
+    ScopedIndex ix;
+    gtars_status st = build_other_index(other, kind, ix);
+    if (st) return st;
+    const std::vector<uint32_t> qc = translate_chroms(self, other->chroms);
+    return gtars_count_overlaps(ix.ix, qc.data(), self->starts.data(), self->ends.data(), self->size(), has_min,
+                                min_overlap, counts);
+}
+
+gtars_status gtars_regionset_any_overlaps(const gtars_regionset_t *self, const gtars_regionset_t *other, int kind,
+                                          int has_min, int32_t min_overlap, uint8_t *out) {
+    if (!self || !other) return fail(GTARS_ERR_INVALID_ARG, "NULL region set");
+    ScopedIndex ix;
+    gtars_status st = build_other_index(other, kind, ix);
+    if (st) return st;
+    const std::vector<uint32_t> qc = translate_chroms(self, other->chroms);
+    return gtars_any_overlaps(ix.ix, qc.data(), self->starts.data(), self->ends.data(), self->size(), has_min,
+                              min_overlap, out);
+}
+
+gtars_status gtars_regionset_find_overlaps(const gtars_regionset_t *self, const gtars_regionset_t *other,
+                                           int kind, int has_min, int32_t min_overlap, uint64_t *offsets,
+                                           uint32_t **out_idx, uint64_t *out_n) {
+    if (!self || !other) return fail(GTARS_ERR_INVALID_ARG, "NULL region set");
+    ScopedIndex ix;
+    gtars_status st = build_other_index(other, kind, ix);
+    if (st) return st;
+    const std::vector<uint32_t> qc = translate_chroms(self, other->chroms);
+    return gtars_find_overlap_indices(ix.ix, qc.data(), self->starts.data(), self->ends.data(), self->size(),
+                                      has_min, min_overlap, offsets, out_idx, out_n);
+}
+
+}  // extern "C"
+
+// ================================================================ Tokenizer
+
+struct gtars_tokenizer {
+    // Universe (gtars-tokenizers/src/universe/mod.rs:35-42)
+    std::vector<std::string> regions;
+    std::unordered_map<std::string, uint32_t> region_to_id;
+    std::vector<std::string> vocab_order;  // keys of region_to_id in insertion order
+    std::unordered_map<uint32_t, std::string> id_to_region;
+    std::unordered_map<std::string, std::string> names;
+    std::unordered_map<std::string, double> scores;
+    bool has_scores = false;
+    std::string special[7];  // unk,pad,mask,cls,eos,bos,sep
+    int kind = GTARS_KIND_BITS;
+    Dict chroms;
+    gtars_index_t *index = nullptr;
+    uint32_t unk_id = 0;
+};
+
+namespace {
+
+const char *kSpecialSlots[7] = {"unk", "pad", "mask", "cls", "eos", "bos", "sep"};
+const char *kSpecialDefaults[7] = {"<unk>", "<pad>", "<mask>", "<cls>", "<eos>", "<bos>", "<sep>"};
+
+// ---- minimal TOML reader for TokenizerConfig (gtars-tokenizers/src/config.rs:27-41):
+//   universe = "<path>"            (required)
+//   tokenizer_type = "bits"|"ailist"   (optional; anything else is an error, tokenizer.rs:336-341)
+//   special_tokens = [ {name="unk", token="<UNKNOWN>"}, ... ]  or  [[special_tokens]] tables
+// Unknown keys are ignored (serde default).
+struct TomlCfg {
+    bool has_universe = false;
+    std::string universe;
+    bool has_type = false;
+    std::string type;
+    std::vector<std::pair<std::string, std::string>> specials;  // (name, token)
+};
+
+struct TomlParser {
+    const std::string &s;
+    size_t i = 0;
+    std::string err;
+    explicit TomlParser(const std::string &str) : s(str) {}
+
+    void skip_ws_inline() {
+        while (i < s.size() && (s[i] == ' ' || s[i] == '\t')) ++i;
+    }
+    void skip_ws_all() {
+        for (;;) {
+            while (i < s.size() && (s[i] == ' ' || s[i] == '\t' || s[i] == '\r' || s[i] == '\n')) ++i;
+            if (i < s.size() && s[i] == '#') {
+                while (i < s.size() && s[i] != '\n') ++i;
+                continue;
+            }
+            break;
+        }
+    }
+    bool parse_string(std::string &out) {
+        if (i >= s.size()) return false;
+        const char q = s[i];
+        if (q != '"' && q != '\'') return false;
+        ++i;
+        out.clear();
+        while (i < s.size() && s[i] != q) {
+            if (q == '"' && s[i] == '\\' && i + 1 < s.size()) {
+                const char c = s[i + 1];
+                switch (c) {
+                    case 'n': out += '\n'; break;
+                    case 't': out += '\t'; break;
+                    case 'r': out += '\r'; break;
+                    case '"': out += '"'; break;
+                    case '\\': out += '\\'; break;
+                    default: err = "unsupported escape in TOML string"; return false;
+                }
+                i += 2;
+            } else {
+                if (s[i] == '\n') {
+                    err = "newline in TOML string";
+                    return false;
+                }
+                out += s[i++];
+            }
+        }
+        if (i >= s.size()) {
+            err = "unterminated TOML string";
+            return false;
+        }
+        ++i;
+        return true;
+    }
+    bool parse_key(std::string &k) {
+        skip_ws_inline();
+        k.clear();
+        if (i < s.size() && (s[i] == '"' || s[i] == '\'')) return parse_string(k);
+        while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '_' || s[i] == '-')) k += s[i++];
+        return !k.empty();
+    }
+    // skip any value we do not care about (string / number / bool / array / inline table)
+    bool skip_value() {
+        skip_ws_inline();
+        if (i >= s.size()) return false;
+        if (s[i] == '"' || s[i] == '\'') {
+            std::string t;
+            return parse_string(t);
+        }
+        if (s[i] == '[' || s[i] == '{') {
+            const char open = s[i], close = open == '[' ? ']' : '}';
+            int depth = 0;
+            while (i < s.size()) {
+                if (s[i] == '"' || s[i] == '\'') {
+                    std::string t;
+                    if (!parse_string(t)) return false;
+                    continue;
+                }
+                if (s[i] == '#') {
+                    while (i < s.size() && s[i] != '\n') ++i;
+                    continue;
+                }
+                if (s[i] == open) ++depth;
+                if (s[i] == close) {
+                    --depth;
+                    if (depth == 0) {
+                        ++i;
+                        return true;
+                    }
+                }
+                ++i;
+            }
+            return false;
+        }
+        while (i < s.size() && s[i] != '\n' && s[i] != '#' && s[i] != ',' && s[i] != '}' && s[i] != ']') ++i;
+        return true;
+    }
+    bool parse_inline_special(TomlCfg &cfg) {
+        // { name = "unk", token = "<X>" }
+        if (s[i] != '{') {
+            err = "special_tokens entries must be inline tables";
+            return false;
+        }
+        ++i;
+        std::string name, token;
+        bool hn = false, ht = false;
+        for (;;) {
+            skip_ws_all();
+            if (i < s.size() && s[i] == '}') {
+                ++i;
+                break;
+            }
+            std::string k;
+            if (!parse_key(k)) {
+                err = "bad key in special_tokens entry";
+                return false;
+            }
+            skip_ws_inline();
+            if (i >= s.size() || s[i] != '=') {
+                err = "expected '=' in special_tokens entry";
+                return false;
+            }
+            ++i;
+            skip_ws_inline();
+            std::string v;
+            if (!parse_string(v)) {
+                if (err.empty()) err = "special_tokens values must be strings";
+                return false;
+            }
+            if (k == "name") {
+                name = v;
+                hn = true;
+            } else if (k == "token") {
+                token = v;
+                ht = true;
+            }
+            skip_ws_all();
+            if (i < s.size() && s[i] == ',') ++i;
+        }
+        if (!hn || !ht) {
+            err = "special_tokens entry needs name and token";
+            return false;
+        }
+        cfg.specials.emplace_back(name, token);
+        return true;
+    }
+    bool parse(TomlCfg &cfg) {
+        bool in_special_table = false, in_other_table = false;
+        std::string cur_name, cur_token;
+        bool cn = false, ct = false;
+        auto flush_table = [&]() -> bool {
+            if (in_special_table) {
+                if (!cn || !ct) {
+                    err = "special_tokens entry needs name and token";
+                    return false;
+                }
+                cfg.specials.emplace_back(cur_name, cur_token);
+            }
+            in_special_table = false;
+            cn = ct = false;
+            return true;
+        };
+        for (;;) {
+            skip_ws_all();
+            if (i >= s.size()) break;
+            if (s[i] == '[') {
+                if (!flush_table()) return false;
+                const bool dbl = i + 1 < s.size() && s[i + 1] == '[';
+                i += dbl ? 2 : 1;
+                std::string k;
+                if (!parse_key(k)) {
+                    err = "bad TOML table header";
+                    return false;
+                }
+                skip_ws_inline();
+                while (i < s.size() && s[i] == ']') ++i;
+                in_special_table = dbl && k == "special_tokens";
+                in_other_table = !in_special_table;
+                continue;
+            }
+            std::string k;
+            if (!parse_key(k)) {
+                err = "bad TOML key";
+                return false;
+            }
+            skip_ws_inline();
+            if (i >= s.size() || s[i] != '=') {
+                err = "expected '=' after TOML key '" + k + "'";
+                return false;
+            }
+            ++i;
+            skip_ws_inline();
+            if (in_special_table) {
+                std::string v;
+                if (!parse_string(v)) {
+                    if (err.empty()) err = "special_tokens values must be strings";
+                    return false;
+                }
+                if (k == "name") {
+                    cur_name = v;
+                    cn = true;
+                } else if (k == "token") {
+                    cur_token = v;
+                    ct = true;
+                }
+                continue;
+            }
+            if (in_other_table) {
+                if (!skip_value()) {
+                    err = "bad TOML value";
+                    return false;
+                }
+                continue;
+            }
+            if (k == "universe" || k == "tokenizer_type") {
+                std::string v;
+                if (!parse_string(v)) {
+                    if (err.empty()) err = "'" + k + "' must be a string";
+                    return false;
+                }
+                if (k == "universe") {
+                    cfg.universe = v;
+                    cfg.has_universe = true;
+                } else {
+                    cfg.type = v;
+                    cfg.has_type = true;
+                }
+            } else if (k == "special_tokens") {
+                if (i >= s.size() || s[i] != '[') {
+                    err = "special_tokens must be an array";
+                    return false;
+                }
+                ++i;
+                for (;;) {
+                    skip_ws_all();
+                    if (i < s.size() && s[i] == ']') {
+                        ++i;
+                        break;
+                    }
+                    if (i >= s.size()) {
+                        err = "unterminated special_tokens array";
+                        return false;
+                    }
+                    if (!parse_inline_special(cfg)) return false;
+                    skip_ws_all();
+                    if (i < s.size() && s[i] == ',') ++i;
+                }
+            } else {
+                if (!skip_value()) {
+                    err = "bad TOML value";
+                    return false;
+                }
+            }
+        }
+        return flush_table();
+    }
+};
+
+// TokenizerInputFileType::from_path (config.rs:74-95): 0 toml, 1 bed, 2 bed.gz, -1 invalid
+int input_file_type(const std::string &path) {
+    const std::string ext = extension_of(path);
+    if (ext == "gz") {
+        const std::string stem = file_stem(path);
+        return extension_of(stem) == "bed" ? 2 : -1;
+    }
+    if (ext == "toml") return 0;
+    if (ext == "bed") return 1;
+    return -1;
+}
+
+// Universe::try_from(&Path) -- universe/mod.rs:123-197, universe/utils.rs:7-19
+gtars_status load_universe(const std::string &path, gtars_tokenizer *t) {
+    std::string data, err;
+    if (!read_all(path, data, err)) return fail(GTARS_ERR_IO, err);
+    LineIter it(data);
+    std::string line;
+    std::vector<std::string> lines;
+    while (it.next(line)) lines.push_back(line);
+    if (lines.empty()) return fail(GTARS_ERR_PARSE, "Could not determine the universe type from the file");
+    const std::string &first = lines[0];
+    if (first.compare(0, 5, "track") == 0)
+        return fail(GTARS_ERR_PARSE, "Could not determine the universe type from the file");
+    const size_t nparts = split_char(first, '\t').size();
+    if (nparts == 3) {
+        for (const std::string &l : lines) {
+            const std::vector<std::string> parts = split_ws(l);
+            if (parts.size() != 3) return fail(GTARS_ERR_PARSE, "Error parsing line: " + l);
+            t->regions.push_back(parts[0] + ":" + parts[1] + "-" + parts[2]);
+        }
+    } else if (nparts >= 5) {
+        t->has_scores = true;
+        for (const std::string &l : lines) {
+            const std::vector<std::string> parts = split_char(l, '\t');
+            if (parts.size() < 5) return fail(GTARS_ERR_PARSE, "Error parsing line: " + l);
+            const std::string region = parts[0] + ":" + parts[1] + "-" + parts[2];
+            double score;
+            if (!parse_f64(parts[4], score)) return fail(GTARS_ERR_PARSE, "bad score in universe line: " + l);
+            t->regions.push_back(region);
+            t->names[region] = parts[3];
+            t->scores[region] = score;
+        }
+    } else {
+        return fail(GTARS_ERR_PARSE, "Could not determine the universe type from the file");
+    }
+    // generate_region_string_to_id_map (gtars-core/src/utils.rs:240-252): dense ids over DISTINCT strings
+    for (const std::string &r : t->regions) {
+        if (t->region_to_id.find(r) == t->region_to_id.end()) {
+            const uint32_t id = (uint32_t)t->region_to_id.size();
+            t->region_to_id.emplace(r, id);
+            t->vocab_order.push_back(r);
+        }
+    }
+    // generate_id_to_region_string_map (utils.rs:259-271): id i <- regions[i], one per LINE
+    for (size_t i = 0; i < t->regions.size(); ++i) t->id_to_region.emplace((uint32_t)i, t->regions[i]);
+    return GTARS_OK;
+}
+
+// Universe::add_token_to_universe (universe/mod.rs:51-56)
+void add_token(gtars_tokenizer *t, const std::string &tok) {
+    const uint32_t new_id = (uint32_t)t->region_to_id.size();
+    if (t->region_to_id.find(tok) == t->region_to_id.end()) t->vocab_order.push_back(tok);
+    t->region_to_id[tok] = new_id;
+    t->id_to_region[new_id] = tok;
+    t->regions.push_back(tok);
+}
+
+// prepare_universe_and_special_tokens + create_tokenize_core_from_universe (utils/mod.rs:34-99)
+gtars_status finish_tokenizer(const std::string &universe_path, gtars_tokenizer *t) {
+    gtars_status st = load_universe(universe_path, t);
+    if (st) return st;
+    const size_t n_real = t->regions.size();
+    for (int k = 0; k < 7; ++k) add_token(t, t->special[k]);  // add_special_tokens (universe/mod.rs:114-120)
+    std::vector<uint32_t> ch, s, e, v;
+    ch.reserve(n_real);
+    for (const std::string &region : t->regions) {
+        bool is_special = false;
+        for (int k = 0; k < 7; ++k) is_special = is_special || region == t->special[k];
+        if (is_special) continue;
+        // region.split(":") -> parts[0], parts[1]; parts[1].split("-") -> [0], [1]
+        const std::vector<std::string> parts = split_char(region, ':');
+        if (parts.size() < 2) return fail(GTARS_ERR_PARSE, "universe region is not chr:start-end: " + region);
+        const std::vector<std::string> se = split_char(parts[1], '-');
+        uint32_t start, end;
+        if (se.size() < 2 || !parse_u32(se[0], start) || !parse_u32(se[1], end))
+            return fail(GTARS_ERR_PARSE, "universe region has non-numeric coordinates: " + region);
+        ch.push_back(t->chroms.get_or_add(parts[0]));
+        s.push_back(start);
+        e.push_back(end);
+        v.push_back(t->region_to_id[region]);
+    }
+    t->unk_id = t->region_to_id[t->special[0]];
+    return gtars_index_build(ch.data(), s.data(), e.data(), v.data(), ch.size(), (uint32_t)t->chroms.names.size(),
+                             t->kind, &t->index);
+}
+
+gtars_status tokenizer_from_config(const std::string &path, gtars_tokenizer_t **out) {
+    std::string data, err;
+    {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return fail(GTARS_ERR_IO, "Failed to open file: \"" + path + "\": " + strerror(errno));
+        char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+        fclose(f);
+    }
+    TomlCfg cfg;
+    TomlParser p(data);
+    if (!p.parse(cfg)) return fail(GTARS_ERR_CONFIG, "invalid tokenizer config " + path + ": " + p.err);
+    if (!cfg.has_universe) return fail(GTARS_ERR_CONFIG, "invalid tokenizer config " + path + ": missing field `universe`");
+    auto *t = new gtars_tokenizer();
+    for (int k = 0; k < 7; ++k) t->special[k] = kSpecialDefaults[k];
+    for (const auto &sp : cfg.specials) {
+        int slot = -1;
+        for (int k = 0; k < 7; ++k)
+            if (sp.first == kSpecialSlots[k]) slot = k;
+        if (slot < 0) {
+            delete t;
+            return fail(GTARS_ERR_CONFIG, "invalid tokenizer config: unknown special token name `" + sp.first + "`");
+        }
+        t->special[slot] = sp.second;
+    }
+    if (cfg.has_type) {
+        if (cfg.type == "bits")
+            t->kind = GTARS_KIND_BITS;
+        else if (cfg.type == "ailist")
+            t->kind = GTARS_KIND_AILIST;
+        else {
+            delete t;
+            return fail(GTARS_ERR_CONFIG, "Invalid tokenizer type in config file: `" + cfg.type + "`");
+        }
+    }
+    // the universe path is relative to the config file's directory (tokenizer.rs:64-65)
+    const std::string dir = parent_dir(path);
+    std::string upath = cfg.universe;
+    if (!(upath.size() && upath[0] == '/')) upath = dir.empty() ? upath : (dir == "/" ? "/" + upath : dir + "/" + upath);
+    gtars_status st = finish_tokenizer(upath, t);
+    if (st) {
+        gtars_tokenizer_free(t);
+        return st;
+    }
+    *out = t;
+    return GTARS_OK;
+}
+
+gtars_status tokenizer_from_bed(const std::string &path, gtars_tokenizer_t **out) {
+    auto *t = new gtars_tokenizer();
+    for (int k = 0; k < 7; ++k) t->special[k] = kSpecialDefaults[k];
+    t->kind = GTARS_KIND_BITS;  // tokenizer.rs:93
+    gtars_status st = finish_tokenizer(path, t);
+    if (st) {
+        gtars_tokenizer_free(t);
+        return st;
+    }
+    *out = t;
+    return GTARS_OK;
+}
+
+// core of Tokenizer::encode on chromosome ids of this tokenizer's dictionary
+gtars_status encode_core(const gtars_tokenizer *t, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+                         uint64_t n, uint32_t **out_ids, uint64_t *out_n) {
+    *out_ids = nullptr;
+    *out_n = 0;
+    uint32_t *ids = nullptr;
+    uint64_t h = 0;
+    gtars_status st = gtars_tokenize(t->index, qc, qs, qe, n, nullptr, &ids, &h);
+    if (st) return st;
+    if (h == 0) {
+        // tokenizer.rs:158-160: nothing overlapped in the whole batch -> [unk]
+        gtars_free(ids);
+        ids = (uint32_t *)malloc(sizeof(uint32_t));
+        if (!ids) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+        ids[0] = t->unk_id;
+        h = 1;
+    }
+    *out_ids = ids;
+    *out_n = h;
+    return GTARS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+gtars_status gtars_tokenizer_from_auto(const char *path, gtars_tokenizer_t **out) {
+    if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    const std::string p(path);
+    switch (input_file_type(p)) {
+        case 0: return tokenizer_from_config(p, out);
+        case 1:
+        case 2: return tokenizer_from_bed(p, out);
+        default:
+            return fail(GTARS_ERR_CONFIG,
+                        "Missing or invalid file extension in tokenizer config file. It must be `toml`, `bed` or `bed.gz`");
+    }
+}
+
+gtars_status gtars_tokenizer_from_config(const char *path, gtars_tokenizer_t **out) {
+    if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    return tokenizer_from_config(path, out);
+}
+
+gtars_status gtars_tokenizer_from_bed(const char *path, gtars_tokenizer_t **out) {
+    if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    return tokenizer_from_bed(path, out);
+}
+
+void gtars_tokenizer_free(gtars_tokenizer_t *t) {
+    if (!t) return;
+    gtars_index_free(t->index);
+    delete t;
+}
+
+uint64_t gtars_tokenizer_vocab_size(const gtars_tokenizer_t *t) { return t ? t->region_to_id.size() : 0; }
+int gtars_tokenizer_kind(const gtars_tokenizer_t *t) { return t ? t->kind : -1; }
+
+const char *gtars_tokenizer_id_to_token(const gtars_tokenizer_t *t, uint32_t id) {
+    if (!t) return nullptr;
+    auto it = t->id_to_region.find(id);
+    return it == t->id_to_region.end() ? nullptr : it->second.c_str();
+}
+
+int64_t gtars_tokenizer_token_to_id(const gtars_tokenizer_t *t, const char *token) {
+    if (!t || !token) return -1;
+    auto it = t->region_to_id.find(token);
+    return it == t->region_to_id.end() ? -1 : (int64_t)it->second;
+}
+
+const char *gtars_tokenizer_vocab_token(const gtars_tokenizer_t *t, uint64_t i, uint32_t *id) {
+    if (!t || i >= t->vocab_order.size()) return nullptr;
+    const std::string &k = t->vocab_order[i];
+    if (id) *id = t->region_to_id.at(k);
+    return k.c_str();
+}
+
+const char *gtars_tokenizer_special_token(const gtars_tokenizer_t *t, int which) {
+    return t && which >= 0 && which < 7 ? t->special[which].c_str() : nullptr;
+}
+
+const char *gtars_tokenizer_region_name(const gtars_tokenizer_t *t, const char *region) {
+    if (!t || !region) return nullptr;
+    auto it = t->names.find(region);
+    return it == t->names.end() ? nullptr : it->second.c_str();
+}
+
+double gtars_tokenizer_region_score(const gtars_tokenizer_t *t, const char *region) {
+    if (!t || !region) return std::numeric_limits<double>::quiet_NaN();
+    auto it = t->scores.find(region);
+    return it == t->scores.end() ? std::numeric_limits<double>::quiet_NaN() : it->second;
+}
+
+int64_t gtars_tokenizer_chrom_id(const gtars_tokenizer_t *t, const char *chr) {
+    return t && chr ? t->chroms.find(chr) : -1;
+}
+uint32_t gtars_tokenizer_n_chrom(const gtars_tokenizer_t *t) { return t ? (uint32_t)t->chroms.names.size() : 0; }
+const char *gtars_tokenizer_chrom_name(const gtars_tokenizer_t *t, uint32_t id) {
+    return t && id < t->chroms.names.size() ? t->chroms.names[id].c_str() : nullptr;
+}
+const gtars_index_t *gtars_tokenizer_index(const gtars_tokenizer_t *t) { return t ? t->index : nullptr; }
+
+gtars_status gtars_tokenizer_encode_regionset(const gtars_tokenizer_t *t, const gtars_regionset_t *rs,
+                                              uint32_t **out_ids, uint64_t *out_n) {
+    if (!t || !rs || !out_ids || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    const std::vector<uint32_t> qc = translate_chroms(rs, t->chroms);
+    return encode_core(t, qc.data(), rs->starts.data(), rs->ends.data(), rs->size(), out_ids, out_n);
+}
+
+gtars_status gtars_tokenizer_encode_arrays(const gtars_tokenizer_t *t, const char *const *chrs,
+                                           const uint32_t *starts, const uint32_t *ends, uint64_t n,
+                                           uint32_t **out_ids, uint64_t *out_n) {
+    if (!t || !out_ids || !out_n || (n && (!chrs || !starts || !ends))) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    std::vector<uint32_t> qc(n);
+    // consecutive regions usually share a chromosome: one-entry cache in front of the hash lookup
+    const char *last = nullptr;
+    uint32_t last_id = GTARS_UNKNOWN_CHROM;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!chrs[i]) return fail(GTARS_ERR_INVALID_ARG, "NULL chromosome name");
+        if (!last || strcmp(last, chrs[i]) != 0) {
+            const int64_t id = t->chroms.find(chrs[i]);
+            last_id = id < 0 ? GTARS_UNKNOWN_CHROM : (uint32_t)id;
+            last = chrs[i];
+        }
+        qc[i] = last_id;
+    }
+    return encode_core(t, qc.data(), starts, ends, n, out_ids, out_n);
+}
+
+gtars_status gtars_tokenizer_encode_ids(const gtars_tokenizer_t *t, const uint32_t *chrom_ids,
+                                        const uint32_t *starts, const uint32_t *ends, uint64_t n,
+                                        uint64_t *offsets, uint32_t **out_ids, uint64_t *out_n) {
+    if (!t || !out_ids || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    return gtars_tokenize(t->index, chrom_ids, starts, ends, n, offsets, out_ids, out_n);
+}
+
+// tokenize_fragment_file -- gtars-tokenizers/src/utils/fragments.rs:12-82
+gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, const char *path,
+                                                    gtars_fragment_tokens_t **out) {
+    if (!t || !path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    std::string data, err;
+    if (!read_all(path, data, err)) return fail(GTARS_ERR_IO, err);
+    Dict barcodes;
+    std::vector<uint32_t> qc, qs, qe, bc;
+    LineIter it(data);
+    std::string line;
+    size_t line_num = 0;
+    while (it.next(line)) {
+        const size_t ln = line_num++;
+        if (!line.empty() && line[0] == '#') continue;
+        const std::vector<std::string> parts = split_ws(line);
+        if (parts.size() < 5)
+            return fail(GTARS_ERR_PARSE, "Invalid fragment file detected at line: " + std::to_string(ln));
+        uint32_t s, e;
+        if (!parse_u32(parts[1], s))
+            return fail(GTARS_ERR_PARSE, "Failed to parse start position at line " + std::to_string(ln));
+        if (!parse_u32(parts[2], e))
+            return fail(GTARS_ERR_PARSE, "Failed to parse end position at line " + std::to_string(ln));
+        const int64_t cid = t->chroms.find(parts[0]);
+        qc.push_back(cid < 0 ? GTARS_UNKNOWN_CHROM : (uint32_t)cid);
+        qs.push_back(s);
+        qe.push_back(e);
+        bc.push_back(barcodes.get_or_add(parts[3]));
+    }
+    const uint64_t n = qc.size();
+    std::vector<uint64_t> off(n + 1, 0);
+    uint32_t *ids = nullptr;
+    uint64_t h = 0;
+    gtars_status st = gtars_tokenize(t->index, qc.data(), qs.data(), qe.data(), n, off.data(), &ids, &h);
+    if (st) return st;
+    // one tokenize() per fragment: a fragment without hits contributes exactly one unk id
+    const uint64_t nb = barcodes.names.size();
+    std::vector<uint64_t> cnt(nb + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t k = off[i + 1] - off[i];
+        cnt[bc[i] + 1] += k ? k : 1;
+    }
+    for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
+    auto *ft = (gtars_fragment_tokens_t *)calloc(1, sizeof(gtars_fragment_tokens_t));
+    ft->n_barcodes = nb;
+    ft->barcodes = (char **)calloc(nb ? nb : 1, sizeof(char *));
+    ft->offsets = (uint64_t *)malloc((nb + 1) * sizeof(uint64_t));
+    ft->ids = (uint32_t *)malloc((cnt[nb] ? cnt[nb] : 1) * sizeof(uint32_t));
+    memcpy(ft->offsets, cnt.data(), (nb + 1) * sizeof(uint64_t));
+    for (uint64_t b = 0; b < nb; ++b) ft->barcodes[b] = dup_cstr(barcodes.names[b]);
+    std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t &w = fill[bc[i]];
+        if (off[i + 1] == off[i]) {
+            ft->ids[w++] = t->unk_id;
+        } else {
+            for (uint64_t k = off[i]; k < off[i + 1]; ++k) ft->ids[w++] = ids[k];
+        }
+    }
+    gtars_free(ids);
+    *out = ft;
+    return GTARS_OK;
+}
+
+void gtars_fragment_tokens_free(gtars_fragment_tokens_t *ft) {
+    if (!ft) return;
+    for (uint64_t b = 0; b < ft->n_barcodes; ++b) free(ft->barcodes[b]);
+    free(ft->barcodes);
+    free(ft->offsets);
+    free(ft->ids);
+    free(ft);
+}
+
+// ===================================================================== gtok
+
+// write_tokens_to_gtok -- gtars-io/src/gtok.rs:125-165
+gtars_status gtars_gtok_write(const char *path, const uint32_t *tokens, uint64_t n) {
+    if (!path || (n && !tokens)) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    // create_dir_all(parent)
+    const std::string dir = parent_dir(path);
+    if (!dir.empty() && dir != "/") {
+        std::string acc;
+        for (const std::string &comp : split_char(dir, '/')) {
+            if (comp.empty()) {
+                acc += "/";
+                continue;
+            }
+            acc += (acc.empty() || acc.back() == '/') ? comp : "/" + comp;
+            if (mkdir(acc.c_str(), 0777) != 0 && errno != EEXIST)
+                return fail(GTARS_ERR_IO, "Failed to create parent directories for gtok file: " + acc);
+        }
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(GTARS_ERR_IO, std::string("Failed to create gtok file: ") + path);
+    bool small = true;
+    for (uint64_t i = 0; i < n; ++i) small = small && tokens[i] <= 0xFFFFu;
+    fwrite("GTOK", 1, 4, f);
+    const unsigned char flag = small ? 0x01 : 0x02;
+    fwrite(&flag, 1, 1, f);
+    if (small) {
+        std::vector<uint16_t> v(n);
+        for (uint64_t i = 0; i < n; ++i) v[i] = (uint16_t)tokens[i];
+        if (n) fwrite(v.data(), 2, n, f);  // little-endian host
+    } else if (n) {
+        fwrite(tokens, 4, n, f);
+    }
+    fclose(f);
+    return GTARS_OK;
+}
+
+// read_tokens_from_gtok -- gtars-io/src/gtok.rs:174-210
+gtars_status gtars_gtok_read(const char *path, uint32_t **out_tokens, uint64_t *out_n) {
+    if (!path || !out_tokens || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out_tokens = nullptr;
+    *out_n = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(GTARS_ERR_IO, std::string("Failed to open file: ") + path);
+    std::string data;
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+    fclose(f);
+    if (data.size() < 5 || data.compare(0, 4, "GTOK") != 0)
+        return fail(GTARS_ERR_PARSE, "File doesn't appear to be a valid .gtok file.");
+    const unsigned char flag = (unsigned char)data[4];
+    const size_t body = data.size() - 5;
+    uint64_t cnt;
+    uint32_t *res;
+    if (flag == 0x01) {
+        cnt = body / 2;
+        res = (uint32_t *)malloc((cnt ? cnt : 1) * 4);
+        for (uint64_t i = 0; i < cnt; ++i) {
+            uint16_t v;
+            memcpy(&v, data.data() + 5 + 2 * i, 2);
+            res[i] = v;
+        }
+    } else if (flag == 0x02) {
+        cnt = body / 4;
+        res = (uint32_t *)malloc((cnt ? cnt : 1) * 4);
+        if (cnt) memcpy(res, data.data() + 5, cnt * 4);
+    } else {
+        return fail(GTARS_ERR_PARSE, "Invalid data format flag found in gtok file");
+    }
+    *out_tokens = res;
+    *out_n = cnt;
+    return GTARS_OK;
+}
+
+}  // extern "C"
+
+// =================================================================== IGD DB
+
+struct gtars_igddb {
+    Dict chroms;
+    struct FileInfo {
+        std::string filename;
+        uint32_t num_regions;
+        double avg_width;
+    };
+    std::vector<FileInfo> files;
+    gtars_igd_t *igd = nullptr;
+};
+
+namespace {
+
+// Igd::parse_bed_line -- gtars-igd/src/igd.rs:850-867
+bool igd_parse_bed_line(const std::string &line, std::string &chrom, int32_t &start, int32_t &end, int32_t &score) {
+    const std::vector<std::string> f = split_char(line, '\t');
+    if (f.size() < 3) return false;
+    if (!parse_i32(f[1], start) || !parse_i32(f[2], end)) return false;
+    chrom = f[0];
+    if (chrom.size() >= 40 || end <= 0) return false;
+    score = -1;
+    if (f.size() >= 5) {
+        int32_t v;
+        if (parse_i32(f[4], v)) score = v;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Igd::from_bed_files -- gtars-igd/src/igd.rs:191-242
+gtars_status gtars_igddb_from_bed_files(const char *const *paths, uint64_t n_paths, gtars_igddb_t **out) {
+    if (!out || (n_paths && !paths)) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    auto *db = new gtars_igddb();
+    std::vector<uint32_t> ch, fi;
+    std::vector<int32_t> st, en, va;
+    for (uint64_t pi = 0; pi < n_paths; ++pi) {
+        const std::string p(paths[pi] ? paths[pi] : "");
+        std::string data, err;
+        if (!read_all(p, data, err)) continue;  // Err(_) => continue
+        uint32_t count = 0;
+        uint64_t total_width = 0;
+        bool has_valid = false;
+        const uint32_t file_idx = (uint32_t)db->files.size();
+        LineIter it(data);
+        std::string line, chrom;
+        int32_t s, e, score;
+        while (it.next(line)) {
+            if (!igd_parse_bed_line(line, chrom, s, e, score)) continue;
+            has_valid = true;
+            if (s >= 0) {
+                ch.push_back(db->chroms.get_or_add(chrom));
+                st.push_back(s);
+                en.push_back(e);
+                va.push_back(score);
+                fi.push_back(file_idx);
+                count += 1;
+                total_width += (uint64_t)(int64_t)(e - s);
+            }
+        }
+        if (!has_valid) {
+            // the records of a skipped file were never added in the reference either: has_valid == false
+            // means no line parsed, so nothing was pushed
+            continue;
+        }
+        db->files.push_back({base_name(p), count, count ? (double)total_width / (double)count : 0.0});
+    }
+    gtars_status s2 = gtars_igd_build(ch.data(), st.data(), en.data(), va.data(), fi.data(), ch.size(),
+                                      (uint32_t)db->chroms.names.size(), (uint32_t)db->files.size(), &db->igd);
+    if (s2) {
+        gtars_igddb_free(db);
+        return s2;
+    }
+    *out = db;
+    return GTARS_OK;
+}
+
+// Igd::from_bed_dir -- gtars-igd/src/igd.rs:170-188
+gtars_status gtars_igddb_from_bed_dir(const char *dir, gtars_igddb_t **out) {
+    if (!dir || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    DIR *d = opendir(dir);
+    if (!d) return fail(GTARS_ERR_IO, std::string("cannot read directory: ") + dir);
+    std::vector<std::string> files;
+    while (dirent *ent = readdir(d)) {
+        const std::string name = ent->d_name;
+        if (name == "." || name == "..") continue;
+        const std::string full = std::string(dir) + (ends_with(dir, "/") ? "" : "/") + name;
+        const std::string ext = extension_of(name);
+        if ((ext == "bed" || ext == "gz") && is_regular_file(full)) files.push_back(full);
+    }
+    closedir(d);
+    std::sort(files.begin(), files.end());
+    std::vector<const char *> ptrs;
+    for (const std::string &f : files) ptrs.push_back(f.c_str());
+    return gtars_igddb_from_bed_files(ptrs.data(), ptrs.size(), out);
+}
+
+void gtars_igddb_free(gtars_igddb_t *db) {
+    if (!db) return;
+    gtars_igd_free(db->igd);
+    delete db;
+}
+
+uint32_t gtars_igddb_n_files(const gtars_igddb_t *db) { return db ? (uint32_t)db->files.size() : 0; }
+uint32_t gtars_igddb_n_contigs(const gtars_igddb_t *db) { return db ? (uint32_t)db->chroms.names.size() : 0; }
+const char *gtars_igddb_file_name(const gtars_igddb_t *db, uint32_t i) {
+    return db && i < db->files.size() ? db->files[i].filename.c_str() : nullptr;
+}
+uint32_t gtars_igddb_file_num_regions(const gtars_igddb_t *db, uint32_t i) {
+    return db && i < db->files.size() ? db->files[i].num_regions : 0;
+}
+double gtars_igddb_file_avg_width(const gtars_igddb_t *db, uint32_t i) {
+    return db && i < db->files.size() ? db->files[i].avg_width : 0.0;
+}
+int64_t gtars_igddb_chrom_id(const gtars_igddb_t *db, const char *chr) { return db && chr ? db->chroms.find(chr) : -1; }
+const gtars_igd_t *gtars_igddb_engine(const gtars_igddb_t *db) { return db ? db->igd : nullptr; }
+
+gtars_status gtars_igddb_count_regionset(const gtars_igddb_t *db, const gtars_regionset_t *rs, int32_t min_overlap,
+                                         int binary, uint64_t *hits) {
+    if (!db || !rs) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    const std::vector<uint32_t> qc = translate_chroms(rs, db->chroms);
+    return gtars_igd_count(db->igd, qc.data(), rs->starts.data(), rs->ends.data(), rs->size(), min_overlap, binary,
+                           hits);
+}
+
+}  // extern "C"

@@ -1,0 +1,418 @@
+"""``gtars.lola`` mirror: ``RegionDB`` and ``run_lola``.
+
+The counting step -- the hot part of LOLA -- runs on the GPU:
+``universe_hits`` / ``user_hits`` are ``Igd::count_region_hits`` support vectors
+(gtars-igd/src/igd.rs:563-590, K5 binary kernel) and the 2x2 cells
+``a, b, c, d`` (gtars-lola/src/enrichment.rs:214-220) come from the contingency
+kernel.  The statistics tail stays on the host in f64 like the reference:
+Fisher's exact p-value (enrichment.rs:19-53), CMLE odds ratio
+(enrichment.rs:62-160, own Brent solver :400-486), min-ranks (:353-394), BH-FDR
+(output.rs:35-113).
+
+Parity note: the reference gets hypergeometric sf/cdf from the third-party
+crate statrs 0.18, which is not part of the reference checkout; here they come
+from scipy.stats.hypergeom, so ``pValueLog`` agrees to floating-point tolerance
+only ("parity unpinned").  The integer columns (support, b, c, d)
+are exact.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .igd import Igd
+from .models import RegionSet
+
+_EPS = np.finfo(np.float64).eps
+
+
+# --------------------------------------------------------------------------- RegionDB
+
+
+class RegionDB:
+    """gtars.lola.RegionDB (gtars-lola/src/database.rs:38-49)."""
+
+    def __init__(self, igd: Igd, region_sets: List[RegionSet], region_anno: List[dict],
+                 collection_anno: Optional[List[dict]] = None, db_location: Optional[str] = None):
+        self.igd = igd
+        self.region_sets = region_sets
+        self._region_anno = region_anno
+        self._collection_anno = collection_anno or []
+        self.db_location = db_location
+
+    @staticmethod
+    def _anno(filename, collection=None, description=None, **kw) -> dict:
+        d = {"filename": filename, "cellType": None, "description": description, "tissue": None, "dataSource": None,
+             "antibody": None, "treatment": None, "collection": collection}
+        d.update(kw)
+        return d
+
+    @staticmethod
+    def from_bed_files(bed_files: Sequence[str], filenames: Optional[Sequence[str]] = None) -> "RegionDB":
+        """gtars-python/src/lola/mod.rs:49-99"""
+        names = list(filenames) if filenames is not None else [os.path.basename(p) or p for p in bed_files]
+        sets, anno = [], []
+        for i, p in enumerate(bed_files):
+            try:
+                rs = RegionSet(p)
+            except RuntimeError as e:
+                raise RuntimeError(f"Failed to read {p}: {e}") from None
+            name = names[i] if i < len(names) else ""
+            sets.append(rs)
+            anno.append(RegionDB._anno(name))
+        igd = Igd.from_named_region_sets([(a["filename"], rs) for a, rs in zip(anno, sets)])
+        return RegionDB(igd, sets, anno)
+
+    @staticmethod
+    def from_folder(db_path: str, collections: Optional[Sequence[str]] = None, limit: Optional[int] = None) -> "RegionDB":
+        """RegionDB::from_lola_folder (database.rs:52-181)."""
+        if not os.path.isdir(db_path):
+            raise RuntimeError(f"Failed to load RegionDB: {db_path} is not a directory")
+        colls = sorted(
+            d for d in os.listdir(db_path)
+            if os.path.isdir(os.path.join(db_path, d, "regions")) and (collections is None or d in collections)
+        )
+        sets, anno, canno = [], [], []
+        for coll in colls:
+            cpath = os.path.join(db_path, coll)
+            canno.append(_parse_collection_txt(os.path.join(cpath, "collection.txt"), coll))
+            index = {a["filename"]: a for a in _parse_index_txt(os.path.join(cpath, "index.txt"), coll)}
+            rdir = os.path.join(cpath, "regions")
+            files = sorted(f for f in os.listdir(rdir) if os.path.isfile(os.path.join(rdir, f)))
+            loaded = 0
+            for f in files:
+                if limit is not None and loaded >= limit:
+                    break
+                try:
+                    rs = RegionSet(os.path.join(rdir, f))
+                except RuntimeError:
+                    continue  # "Warning: skipping ..."
+                a = dict(index.get(f) or RegionDB._anno(f, collection=coll))
+                if a.get("description") is None:
+                    a["description"] = coll
+                sets.append(rs)
+                anno.append(a)
+                loaded += 1
+        igd = Igd.from_named_region_sets([(a["filename"], rs) for a, rs in zip(anno, sets)])
+        return RegionDB(igd, sets, anno, canno, db_path)
+
+    @property
+    def num_region_sets(self) -> int:
+        return len(self.region_sets)
+
+    def list_region_sets(self, collections: Optional[Sequence[str]] = None) -> List[str]:
+        return [a["filename"] for a in self._region_anno if collections is None or a.get("collection") in collections]
+
+    def get_region_sets(self, indices: Optional[Sequence[int]] = None) -> List[RegionSet]:
+        idx = range(len(self.region_sets)) if indices is None else indices
+        return [self.region_sets[i] for i in idx if 0 <= i < len(self.region_sets)]
+
+    @property
+    def region_anno(self) -> List[dict]:
+        return [dict(a) for a in self._region_anno]
+
+    @property
+    def collection_anno(self) -> List[dict]:
+        return [dict(a) for a in self._collection_anno]
+
+    def __repr__(self) -> str:
+        return f"RegionDB({self.num_region_sets} region sets, {self.igd.num_contigs()} contigs)"
+
+
+def _read_tsv(path: str) -> Tuple[List[str], List[List[str]]]:
+    if not os.path.exists(path):
+        return [], []
+    with open(path, "rt") as f:
+        lines = [l.rstrip("\n").rstrip("\r") for l in f]
+    lines = [l for l in lines if l.strip()]
+    if not lines:
+        return [], []
+    return lines[0].split("\t"), [l.split("\t") for l in lines[1:]]
+
+
+def _parse_collection_txt(path: str, name: str) -> dict:
+    out = {"collectionname": name, "collector": "", "date": "", "source": "", "description": ""}
+    hdr, rows = _read_tsv(path)
+    if rows:
+        for k, v in zip(hdr, rows[0]):
+            k = k.strip().lower()
+            if k in out and k != "collectionname":
+                out[k] = v.strip()
+    return out
+
+
+def _parse_index_txt(path: str, coll: str) -> List[dict]:
+    hdr, rows = _read_tsv(path)
+    cols = {h.strip().lower(): i for i, h in enumerate(hdr)}
+    if "filename" not in cols:
+        return []
+    key = {"celltype": "cellType", "description": "description", "tissue": "tissue", "datasource": "dataSource",
+           "antibody": "antibody", "treatment": "treatment"}
+    out = []
+    for r in rows:
+        def get(c):
+            i = cols.get(c)
+            v = r[i].strip() if i is not None and i < len(r) else ""
+            return v or None
+        fn = get("filename")
+        if not fn:
+            continue
+        a = RegionDB._anno(fn, collection=coll)
+        for c, k in key.items():
+            a[k] = get(c)
+        out.append(a)
+    return out
+
+
+# --------------------------------------------------------------------------- statistics (host f64)
+
+
+def fisher_pvalue(a: int, b: int, c: int, d: int, enrichment: bool = True) -> float:
+    """ContingencyTable::fisher_pvalue (enrichment.rs:19-53)."""
+    from scipy.stats import hypergeom
+
+    n_pop, k_success, n_draws = a + b + c + d, a + b, a + c
+    if n_pop == 0 or k_success == 0 or n_draws == 0:
+        return 1.0
+    if k_success > n_pop or n_draws > n_pop:
+        return 1.0
+    if enrichment:
+        return 1.0 if a == 0 else float(hypergeom.sf(a - 1, n_pop, k_success, n_draws))
+    return float(hypergeom.cdf(a, n_pop, k_success, n_draws))
+
+
+def _brent(f, a: float, b: float, tol: float, max_iter: int) -> float:
+    """enrichment.rs:400-486, statement for statement."""
+    fa, fb = f(a), f(b)
+    if abs(fa) < tol:
+        return a
+    if abs(fb) < tol:
+        return b
+    if fa * fb > 0.0:
+        return (a + b) / 2.0
+    c, fc = a, fa
+    d = b - a
+    e = d
+    for _ in range(max_iter):
+        if fb * fc > 0.0:
+            c, fc = a, fa
+            d = b - a
+            e = d
+        if abs(fc) < abs(fb):
+            a, b, c = b, c, b
+            fa, fb, fc = fb, fc, fb
+        tol1 = 2.0 * _EPS * abs(b) + 0.5 * tol
+        m = 0.5 * (c - b)
+        if abs(m) <= tol1 or fb == 0.0:
+            return b
+        if abs(e) >= tol1 and abs(fa) > abs(fb):
+            s = fb / fa
+            if abs(a - c) < _EPS:
+                p = 2.0 * m * s
+                q = 1.0 - s
+            else:
+                qv = fa / fc
+                r = fb / fc
+                p = s * (2.0 * m * qv * (qv - r) - (b - a) * (r - 1.0))
+                q = (qv - 1.0) * (r - 1.0) * (s - 1.0)
+            if p > 0.0:
+                q = -q
+            else:
+                p = -p
+            if 2.0 * p < min(3.0 * m * q - abs(tol1 * q), e * q):
+                e = d
+                d = p / q
+            else:
+                d = m
+                e = m
+        else:
+            d = m
+            e = m
+        a, fa = b, fb
+        if abs(d) > tol1:
+            b += d
+        else:
+            b += tol1 if m > 0.0 else -tol1
+        fb = f(b)
+    return b
+
+
+def odds_ratio(a: int, b: int, c: int, d: int) -> float:
+    """ContingencyTable::odds_ratio -- CMLE as R's fisher.test (enrichment.rs:62-160)."""
+    m, n, k, x = a + c, b + d, a + b, a
+    lo = k - n if k > n else 0
+    hi = min(k, m)
+    if lo == hi:
+        return float("nan")
+    if x == lo:
+        return 0.0
+    if x == hi:
+        return float("inf")
+    size = hi - lo + 1
+    logdc = np.zeros(size, dtype=np.float64)
+    for i in range(1, size):
+        y = lo + i - 1
+        logdc[i] = logdc[i - 1] + (math.log(m - y) + math.log(k - y) - math.log(y + 1) - math.log(n - k + y + 1))
+    ys = lo + np.arange(size, dtype=np.float64)
+
+    def mean_nhyper(omega: float) -> float:
+        if omega == 0.0:
+            return float(lo)
+        if math.isinf(omega):
+            return float(hi)
+        lv = logdc + ys * math.log(omega)
+        w = np.exp(lv - lv.max())
+        return math.fsum(ys * w) / math.fsum(w)
+
+    xf = float(x)
+    mu1 = mean_nhyper(1.0)
+    if abs(mu1 - xf) < 1e-12:
+        return 1.0
+    if mu1 > xf:
+        return _brent(lambda t: mean_nhyper(t) - xf, 0.0, 1.0, 1e-8, 100)
+    t = _brent(lambda t: mean_nhyper(1.0 / t) - xf, _EPS, 1.0, 1e-8, 100)
+    return 1.0 / t
+
+
+def _min_ranks(order: List[int], key) -> Dict[int, int]:
+    """assign_min_ranks_* (enrichment.rs:310-351): ties.method = "min" on a pre-sorted index list."""
+    ranks: Dict[int, int] = {}
+    rank = 1
+    for pos, idx in enumerate(order):
+        if pos > 0:
+            p, c = key(order[pos - 1]), key(idx)
+            tied = (p == c) or (isinstance(p, float) and isinstance(c, float) and math.isnan(p) and math.isnan(c))
+            if not tied:
+                rank = pos + 1
+        ranks[idx] = rank
+    return ranks
+
+
+def _rank_results(rows: List[dict]) -> None:
+    """rank_results (enrichment.rs:353-394); Python's sort is stable like Rust's sort_by."""
+    n = len(rows)
+    idx = list(range(n))
+    by_pv = sorted(idx, key=lambda i: -rows[i]["pValueLog"])
+    r_pv = _min_ranks(by_pv, lambda i: rows[i]["pValueLog"])
+
+    def or_key(i):
+        v = rows[i]["oddsRatio"]
+        return (1, 0.0) if math.isnan(v) else (0, -v)
+
+    by_or = sorted(idx, key=or_key)
+    r_or = _min_ranks(by_or, lambda i: rows[i]["oddsRatio"])
+    by_sup = sorted(idx, key=lambda i: -rows[i]["support"])
+    r_sup = _min_ranks(by_sup, lambda i: rows[i]["support"])
+    for i in idx:
+        rows[i]["rnkPV"], rows[i]["rnkOR"], rows[i]["rnkSup"] = r_pv[i], r_or[i], r_sup[i]
+        rows[i]["maxRnk"] = max(r_pv[i], r_or[i], r_sup[i])
+        rows[i]["meanRnk"] = (r_pv[i] + r_or[i] + r_sup[i]) / 3.0
+
+
+def _apply_fdr(rows: List[dict]) -> None:
+    """apply_fdr_correction (output.rs:35-113): Benjamini-Hochberg per user set."""
+    if not rows:
+        return
+    for us in range(max(r["userSet"] for r in rows) + 1):
+        idx = [i for i, r in enumerate(rows) if r["userSet"] == us]
+        if not idx:
+            continue
+        n = len(idx)
+        idx.sort(key=lambda i: -rows[i]["pValueLog"])
+        p = [0.0 if rows[i]["pValueLog"] == float("inf") else 10.0 ** (-rows[i]["pValueLog"]) for i in idx]
+        q = [0.0] * n
+        q[n - 1] = min(p[n - 1] * n / n, 1.0)
+        for i in range(n - 2, -1, -1):
+            q[i] = min(min(p[i] * n / (i + 1), q[i + 1]), 1.0)
+        for j, i in enumerate(idx):
+            rows[i]["qValue"] = q[j]
+
+
+# --------------------------------------------------------------------------- run_lola
+
+
+def _as_regions(x) -> List[Tuple[str, int, int]]:
+    if isinstance(x, RegionSet):
+        names, ids, s, e = x.chrom_names, x.chrom_ids, x.starts, x.ends
+        return [(names[int(ids[i])], int(s[i]), int(e[i])) for i in range(len(x))]
+    if isinstance(x, dict):
+        return list(zip(x["chr"], x["start"], x["end"]))
+    return [(r[0], int(r[1]), int(r[2])) for r in x]
+
+
+def lola_counts(user_sets, universe, region_db: RegionDB, min_overlap: int = 1):
+    """The GPU part of run_lola (enrichment.rs:198-221): support vectors and a, b, c, d per (user set, db set).
+
+    Returns (universe_hits u64[F], [user_hits u64[F] ...], [(a, b, c, d) int64[F] ...])."""
+    import torch
+
+    from ._lib import check, lib
+
+    igd = region_db.igd
+    n_db = igd.num_files()
+    if n_db == 0:
+        raise RuntimeError("LOLA error: EmptyDatabase")
+    uni = _as_regions(universe)
+    if len(uni) == 0:
+        raise RuntimeError("LOLA error: EmptyUniverse")
+    universe_hits = igd.count_region_hits(uni, min_overlap)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_uni = torch.from_numpy(universe_hits.astype(np.int64)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    all_hits, cells = [], []
+    for us in user_sets:
+        regs = _as_regions(us)
+        hits = igd.count_region_hits(regs, min_overlap)
+        d_user = torch.from_numpy(hits.astype(np.int64)).to(dev)
+        out = [torch.empty(n_db, dtype=torch.int64, device=dev) for _ in range(4)]
+        check(lib.gtars_lola_contingency_device(d_user.data_ptr(), d_uni.data_ptr(), n_db, len(regs), len(uni),
+                                                *[o.data_ptr() for o in out], stream))
+        torch.cuda.synchronize()
+        all_hits.append(hits)
+        cells.append(tuple(o.cpu().numpy() for o in out))
+    return universe_hits, all_hits, cells
+
+
+def run_lola(user_sets, universe, region_db: RegionDB, min_overlap: int = 1, direction: str = "enrichment") -> Dict[str, list]:
+    """py_run_lola (gtars-python/src/lola/mod.rs:180-271): column dict, rows ordered like the reference."""
+    if direction in ("depletion", "less"):
+        enrichment = False
+    elif direction in ("enrichment", "greater"):
+        enrichment = True
+    else:
+        raise ValueError("direction must be 'enrichment' or 'depletion'")
+    _, _, cells = lola_counts(user_sets, universe, region_db, min_overlap)
+    igd = region_db.igd
+    rows_all: List[dict] = []
+    for us_idx, (a, b, c, d) in enumerate(cells):
+        rows = []
+        for f in range(len(a)):
+            av, bv, cv, dv = int(a[f]), int(b[f]), int(c[f]), int(d[f])
+            if bv < 0 or cv < 0 or dv < 0:
+                pv_log, orr = 0.0, float("nan")
+            else:
+                pv_log = -math.log10(fisher_pvalue(av, bv, cv, dv, enrichment) + 1e-322)
+                orr = odds_ratio(av, bv, cv, dv)
+            rows.append({"userSet": us_idx, "dbSet": f, "pValueLog": pv_log, "oddsRatio": orr, "support": av,
+                         "b": bv, "c": cv, "d": dv, "qValue": None,
+                         "filename": igd.file_info[f].filename if f < len(igd.file_info) else ""})
+        _rank_results(rows)
+        rows_all.extend(rows)
+    # global order: pValueLog descending, then meanRnk ascending (enrichment.rs:285-294)
+    rows_all.sort(key=lambda r: (-r["pValueLog"], r["meanRnk"]))
+    anno = region_db.region_anno
+    for r in rows_all:
+        a = anno[r["dbSet"]] if r["dbSet"] < len(anno) else {}
+        desc = a.get("description")
+        r.update({"collection": a.get("collection"), "description": desc[:80] if desc is not None else None,
+                  "cellType": a.get("cellType"), "tissue": a.get("tissue"), "antibody": a.get("antibody"),
+                  "treatment": a.get("treatment"), "dataSource": a.get("dataSource"),
+                  "size": len(region_db.region_sets[r["dbSet"]]) if r["dbSet"] < len(region_db.region_sets) else 0})
+    _apply_fdr(rows_all)
+    cols = ["userSet", "dbSet", "collection", "pValueLog", "oddsRatio", "support", "rnkPV", "rnkOR", "rnkSup", "maxRnk",
+            "meanRnk", "b", "c", "d", "description", "cellType", "tissue", "antibody", "treatment", "dataSource",
+            "filename", "qValue", "size"]
+    return {c: [r.get(c) for r in rows_all] for c in cols}

@@ -1,0 +1,159 @@
+/*
+ * gtars_amd_host.h -- C ABI of the host ("string world") layer of
+ * libgtars_amd.so: BED / BED.gz parsing, RegionSet, Universe + Tokenizer,
+ * fragment files, .gtok, IGD databases from BED files.  It sits on top of the
+ * integer engine in gtars_amd.h and mirrors the reference's Rust types
+ * (cited per entry point, file:line relative to the reference checkout), so a
+ * binding (pyo3-style, ctypes, cgo, extendr) can expose the same classes.
+ *
+ * Strings are UTF-8, NUL terminated.  `const char*` results are borrowed from
+ * the handle they were asked of and stay valid until that handle is freed.
+ * Same status / error conventions as gtars_amd.h.
+ */
+#ifndef GTARS_AMD_HOST_H
+#define GTARS_AMD_HOST_H
+
+#include "gtars_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * RegionSet  (gtars-core/src/models/region_set.rs:40-45)
+ * ---------------------------------------------------------------------- */
+typedef struct gtars_regionset gtars_regionset_t;
+
+/* RegionSet::try_from(&Path) (region_set.rs:52-186): BED or BED.gz (by
+ * extension, utils.rs:115-126); header / comment handling (:112-135); rest =
+ * columns 4+ joined by tabs; EmptyRegionSet -> GTARS_ERR_EMPTY; the result is
+ * stably sorted by (chr, start) (:182, :502-505). */
+gtars_status gtars_regionset_from_bed(const char *path, gtars_regionset_t **out);
+/* From<Vec<Region>> (region_set.rs:212-220): in-memory, NOT sorted. rest may
+ * be NULL (all None) and individual entries may be NULL. */
+gtars_status gtars_regionset_from_arrays(const char *const *chrs, const uint32_t *starts,
+                                         const uint32_t *ends, const char *const *rest,
+                                         uint64_t n, gtars_regionset_t **out);
+void gtars_regionset_free(gtars_regionset_t *rs);
+uint64_t gtars_regionset_len(const gtars_regionset_t *rs);
+const char *gtars_regionset_header(const gtars_regionset_t *rs); /* NULL if none */
+/* dictionary-encoded columns (ids index gtars_regionset_chrom_name) */
+uint32_t gtars_regionset_n_chrom(const gtars_regionset_t *rs);
+const char *gtars_regionset_chrom_name(const gtars_regionset_t *rs, uint32_t id);
+const uint32_t *gtars_regionset_chrom_ids(const gtars_regionset_t *rs);
+const uint32_t *gtars_regionset_starts(const gtars_regionset_t *rs);
+const uint32_t *gtars_regionset_ends(const gtars_regionset_t *rs);
+const char *gtars_regionset_rest(const gtars_regionset_t *rs, uint64_t i); /* NULL if None */
+
+/* IndexedRegionSet::new(other) then count / any / find_overlaps(self)
+ * (gtars-overlaprs/src/indexed_region_set.rs:111-113, 234-263) -- the
+ * semantics of python RegionSet.count_overlaps / any_overlaps / find_overlaps
+ * (gtars-python/src/models/region_set.rs:445-478): `self` queries, `other` is
+ * indexed on the GPU.  kind: GTARS_KIND_AILIST is the reference default. */
+gtars_status gtars_regionset_count_overlaps(const gtars_regionset_t *self,
+                                            const gtars_regionset_t *other, int kind,
+                                            int has_min, int32_t min_overlap, uint32_t *counts);
+gtars_status gtars_regionset_any_overlaps(const gtars_regionset_t *self,
+                                          const gtars_regionset_t *other, int kind,
+                                          int has_min, int32_t min_overlap, uint8_t *out);
+gtars_status gtars_regionset_find_overlaps(const gtars_regionset_t *self,
+                                           const gtars_regionset_t *other, int kind,
+                                           int has_min, int32_t min_overlap, uint64_t *offsets,
+                                           uint32_t **out_idx, uint64_t *out_n);
+
+/* ------------------------------------------------------------------------
+ * Tokenizer  (gtars-tokenizers/src/tokenizer.rs:36-279, universe/mod.rs,
+ * config.rs, utils/mod.rs:34-99, utils/special_tokens.rs)
+ * ---------------------------------------------------------------------- */
+typedef struct gtars_tokenizer gtars_tokenizer_t;
+
+/* Tokenizer::from_auto / from_config / from_bed (tokenizer.rs:61-138) */
+gtars_status gtars_tokenizer_from_auto(const char *path, gtars_tokenizer_t **out);
+gtars_status gtars_tokenizer_from_config(const char *path, gtars_tokenizer_t **out);
+gtars_status gtars_tokenizer_from_bed(const char *path, gtars_tokenizer_t **out);
+void gtars_tokenizer_free(gtars_tokenizer_t *t);
+
+uint64_t gtars_tokenizer_vocab_size(const gtars_tokenizer_t *t);       /* get_vocab_size */
+int gtars_tokenizer_kind(const gtars_tokenizer_t *t);                  /* GTARS_KIND_* */
+/* convert_id_to_token / convert_token_to_id (universe/mod.rs:64-80) */
+const char *gtars_tokenizer_id_to_token(const gtars_tokenizer_t *t, uint32_t id); /* NULL: none */
+int64_t gtars_tokenizer_token_to_id(const gtars_tokenizer_t *t, const char *token); /* -1: none */
+/* get_vocab(): the i-th (token, id) pair of region_to_id, i < vocab_size */
+const char *gtars_tokenizer_vocab_token(const gtars_tokenizer_t *t, uint64_t i, uint32_t *id);
+/* special tokens in the order unk,pad,mask,cls,eos,bos,sep (special_tokens.rs:59-71) */
+const char *gtars_tokenizer_special_token(const gtars_tokenizer_t *t, int which);
+/* universe metadata (BED5+ universes): name / score of a region string, NULL / NaN if absent */
+const char *gtars_tokenizer_region_name(const gtars_tokenizer_t *t, const char *region);
+double gtars_tokenizer_region_score(const gtars_tokenizer_t *t, const char *region);
+
+/* chromosome dictionary of the core (for array fast paths): -1 = unknown */
+int64_t gtars_tokenizer_chrom_id(const gtars_tokenizer_t *t, const char *chr);
+uint32_t gtars_tokenizer_n_chrom(const gtars_tokenizer_t *t);
+const char *gtars_tokenizer_chrom_name(const gtars_tokenizer_t *t, uint32_t id);
+/* borrowed engine handle for gtars_tokenize_device & friends */
+const gtars_index_t *gtars_tokenizer_index(const gtars_tokenizer_t *t);
+
+/* Tokenizer::encode (tokenizer.rs:165-171) of a region set: ids in reference
+ * order, [unk] when nothing overlapped (tokenizer.rs:158-160). */
+gtars_status gtars_tokenizer_encode_regionset(const gtars_tokenizer_t *t,
+                                              const gtars_regionset_t *rs, uint32_t **out_ids,
+                                              uint64_t *out_n);
+/* same on parallel arrays with chromosome NAMES */
+gtars_status gtars_tokenizer_encode_arrays(const gtars_tokenizer_t *t, const char *const *chrs,
+                                           const uint32_t *starts, const uint32_t *ends,
+                                           uint64_t n, uint32_t **out_ids, uint64_t *out_n);
+/* additive array fast path: chromosome IDS of this tokenizer's dictionary
+ * (GTARS_UNKNOWN_CHROM for unknown); returns the CSR too (offsets n+1) and
+ * does NOT apply the batch-level unk rule. */
+gtars_status gtars_tokenizer_encode_ids(const gtars_tokenizer_t *t, const uint32_t *chrom_ids,
+                                        const uint32_t *starts, const uint32_t *ends, uint64_t n,
+                                        uint64_t *offsets, uint32_t **out_ids, uint64_t *out_n);
+
+/* tokenize_fragment_file (utils/fragments.rs:61-82): one single-region
+ * tokenize per fragment line (so every non-overlapping fragment yields one
+ * unk id), grouped by barcode.  Result: n_barcodes names (first-seen order)
+ * and a CSR of ids per barcode. */
+typedef struct gtars_fragment_tokens {
+    uint64_t n_barcodes;
+    char **barcodes;      /* n_barcodes strings */
+    uint64_t *offsets;    /* n_barcodes + 1 */
+    uint32_t *ids;        /* offsets[n_barcodes] */
+} gtars_fragment_tokens_t;
+gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, const char *path,
+                                                    gtars_fragment_tokens_t **out);
+void gtars_fragment_tokens_free(gtars_fragment_tokens_t *ft);
+
+/* ------------------------------------------------------------------------
+ * .gtok  (gtars-io/src/gtok.rs:125-210, consts.rs:1-3)
+ * ---------------------------------------------------------------------- */
+gtars_status gtars_gtok_write(const char *path, const uint32_t *tokens, uint64_t n);
+gtars_status gtars_gtok_read(const char *path, uint32_t **out_tokens, uint64_t *out_n);
+
+/* ------------------------------------------------------------------------
+ * IGD database built from BED files (gtars-igd/src/igd.rs:170-242, 850-867)
+ * ---------------------------------------------------------------------- */
+typedef struct gtars_igddb gtars_igddb_t;
+
+/* Igd::from_bed_files: unreadable files and files without a parseable line
+ * are skipped; lines with start < 0 are parsed but not added. */
+gtars_status gtars_igddb_from_bed_files(const char *const *paths, uint64_t n_paths,
+                                        gtars_igddb_t **out);
+/* Igd::from_bed_dir: *.bed / *.gz regular files of the directory, sorted */
+gtars_status gtars_igddb_from_bed_dir(const char *dir, gtars_igddb_t **out);
+void gtars_igddb_free(gtars_igddb_t *db);
+uint32_t gtars_igddb_n_files(const gtars_igddb_t *db);
+uint32_t gtars_igddb_n_contigs(const gtars_igddb_t *db);
+/* FileInfo (igd.rs:52-59) */
+const char *gtars_igddb_file_name(const gtars_igddb_t *db, uint32_t i);
+uint32_t gtars_igddb_file_num_regions(const gtars_igddb_t *db, uint32_t i);
+double gtars_igddb_file_avg_width(const gtars_igddb_t *db, uint32_t i);
+int64_t gtars_igddb_chrom_id(const gtars_igddb_t *db, const char *chr); /* -1 unknown */
+const gtars_igd_t *gtars_igddb_engine(const gtars_igddb_t *db);        /* borrowed */
+/* Igd::count_set_overlaps (binary=0) / count_region_hits (binary=1) of a region set */
+gtars_status gtars_igddb_count_regionset(const gtars_igddb_t *db, const gtars_regionset_t *rs,
+                                         int32_t min_overlap, int binary, uint64_t *hits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -38,6 +38,8 @@ def test_ctypes_binding_covers_the_header():
 
     declared = set(_declared_symbols("gtars_amd.h"))
     assert declared == set(L.EXPORTED_SYMBOLS)
+    declared_host = set(_declared_symbols("gtars_amd_host.h"))
+    assert declared_host == set(L.EXPORTED_HOST_SYMBOLS)
 
 
 def test_library_is_gfx950_code_object():

@@ -1,0 +1,356 @@
+"""GPU tests of the reference-shaped Python surface (gtars.tokenizers / gtars.models / gtars.lola
+mirrors): the reference's own python/rust test literals re-expressed, plus differential checks
+against the oracle's string-level restatement."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tk(golden_dir):
+    import gtars_amd
+
+    assert gtars_amd.device_count() > 0
+    from gtars_amd.tokenizers import Tokenizer
+
+    return lambda name: Tokenizer(os.path.join(golden_dir, "tokenizers", name))
+
+
+def R(*a):
+    from gtars_amd.models import Region
+
+    return Region(*a)
+
+
+# ---- gtars-python/tests/test_tokenizers.py, same order ---------------------------------------
+
+
+def test_tokenizer_initialization_variants(golden_dir):
+    from gtars_amd.tokenizers import Tokenizer
+
+    d = os.path.join(golden_dir, "tokenizers")
+    assert Tokenizer.from_config(os.path.join(d, "tokenizer.toml")).vocab_size == 32
+    assert Tokenizer.from_bed(os.path.join(d, "peaks.bed")).vocab_size == 32
+    assert Tokenizer.from_bed(os.path.join(d, "peaks.bed.gz")).vocab_size == 32
+    for n in ["peaks.bed", "peaks.bed.gz", "tokenizer.toml", "tokenizer_ordered.toml", "tokenizer_custom_specials.toml",
+              "tokenizer_ailist.toml", "tokenizer_bits.toml"]:
+        t = Tokenizer(os.path.join(d, n))
+        assert t.vocab_size == 32 and len(t) == 32 and repr(t) == "Tokenizer(32 total regions)"
+    with pytest.raises(Exception):
+        Tokenizer.from_config(os.path.join(d, "tokenizer_bad_ttype.toml"))
+    with pytest.raises(Exception):
+        Tokenizer(os.path.join(d, "peaks.txt"))
+    with pytest.raises(Exception):
+        Tokenizer(os.path.join(d, "does_not_exist.bed"))
+
+
+def test_tokenizer_custom_special_tokens(tk):
+    t = tk("tokenizer_custom_specials.toml")
+    assert t.vocab_size == 32
+    assert t.unk_token == "<UNKNOWN>" and t.pad_token == "<pad>"
+    assert t.special_tokens_map["unk_token"] == "<UNKNOWN>"
+
+
+@pytest.mark.parametrize("cfg", ["tokenizer.toml", "tokenizer_ailist.toml", "peaks.bed"])
+def test_tokenize_kats(tk, cfg):
+    t = tk(cfg)
+    tok = t.tokenize([R("chr1", 50, 150, None)])
+    assert len(tok) == 1 and t.convert_tokens_to_ids(tok[0]) == 25
+    tok = t.tokenize([R("chr999", 50, 150, None)])
+    assert len(tok) == 1 and t.convert_tokens_to_ids(tok[0]) == 25
+    tok = t.tokenize([R("chr1", 151399441, 151399547, None), R("chr2", 203871220, 203871381, None)])
+    assert tok == ["chr1:151399431-151399527", "chr2:203871200-203871375"]
+    assert [t.convert_tokens_to_ids(x) for x in tok] == [6, 7]
+
+
+def test_tokenize_with_multi_overlap(tk):
+    t = tk("tokenizer.toml")
+    tok = t.tokenize([R("chr2", 203871346, 203871616, None)])
+    assert tok == ["chr2:203871200-203871375", "chr2:203871387-203871588"]
+    assert t.convert_tokens_to_ids(tok) == [7, 8]
+
+
+def test_vocab_specials_encode_decode(tk):
+    t = tk("peaks.scored.bed")
+    vocab = t.get_vocab()
+    assert len(vocab) == 32 and all(isinstance(k, str) and isinstance(v, int) for k, v in vocab.items())
+    m = t.special_tokens_map
+    assert isinstance(m, dict) and all(isinstance(k, str) and isinstance(v, str) for k, v in m.items())
+    assert t.encode("chr9:3526071-3526165") == [11]
+    assert t.encode(["chr9:3526071-3526165", "nope"]) == [11, 25]
+    assert t.decode([11]) == ["chr9:3526071-3526165"] and t.decode(11) == ["chr9:3526071-3526165"]
+    assert t.convert_ids_to_tokens(11) == "chr9:3526071-3526165"
+    assert t.convert_ids_to_tokens([11, 9999]) == ["chr9:3526071-3526165", "<unk>"]
+    assert t.get_special_tokens_mask(["<pad>", "chr9:3526071-3526165", "<unk>"]) == [1, 0, 1]
+    assert (t.unk_token_id, t.pad_token_id, t.mask_token_id, t.cls_token_id, t.eos_token_id, t.bos_token_id,
+            t.sep_token_id) == (25, 26, 27, 28, 29, 30, 31)
+
+
+def test_tokenizer_call_and_subclass(tk, golden_dir):
+    from gtars_amd.tokenizers import Tokenizer
+
+    t = tk("peaks.scored.bed")
+    enc = t([R("chr9", 3526178, 3526249, None)])
+    assert enc["input_ids"] == [10] and enc["attention_mask"] == [1]
+    with pytest.raises(Exception):
+        enc["token_type_ids"]
+
+    class MoreTokenizer(Tokenizer):
+        def __new__(cls, *args, **kwargs):
+            return super().__new__(cls, *args, **kwargs)
+
+        def __init__(self, *args, **kwargs):
+            super().__init__()
+
+        def add_two(self, x, y):
+            return x + y
+
+        @property
+        def value(self):
+            return self._value
+
+        @value.setter
+        def value(self, val):
+            self._value = val
+
+    mt = MoreTokenizer(os.path.join(golden_dir, "tokenizers", "peaks.scored.bed"))
+    mt.value = 5
+    enc = mt([R("chr9", 3526178, 3526249, None)])
+    assert enc["input_ids"] == [10] and enc["attention_mask"] == [1]
+    assert mt.add_two(2, 3) == 5 and mt.value == 5
+
+
+def test_tokenize_path_is_sorted_first(tk, golden_dir):
+    t = tk("peaks.bed")
+    p = os.path.join(golden_dir, "to_tokenize.bed")
+    assert t(p)["input_ids"] == [22, 23, 24]
+    with pytest.raises(FileNotFoundError):
+        t.tokenize(os.path.join(golden_dir, "nope.bed"))
+
+
+@pytest.mark.parametrize("cfg", ["tokenizer.toml", "tokenizer_ailist.toml", "peaks.scored.bed"])
+def test_tokenizer_differential_vs_oracle(golden_dir, cfg):
+    from gtars_amd.tokenizers import Tokenizer
+
+    path = os.path.join(golden_dir, "tokenizers", cfg)
+    t, o = Tokenizer(path), oracle.OracleTokenizer(path)
+    assert t.get_vocab() == o.universe.region_to_id
+    rng = np.random.default_rng(3)
+    regs = oracle.read_region_set(os.path.join(golden_dir, "tokenizers", "peaks.bed"))
+    queries = []
+    for _ in range(400):
+        c, s, e, _r = regs[rng.integers(0, len(regs))]
+        d = int(rng.integers(-300, 300))
+        w = int(rng.integers(0, 800))
+        qs = max(s + d, 0)
+        queries.append((c if rng.random() > 0.05 else "chrUn", qs, qs + w))
+    got = t.tokenize([R(c, s, e, None) for c, s, e in queries])
+    assert got == o.tokenize(queries)
+    for q in queries[:40]:
+        assert t.tokenize([R(*q, None)]) == o.tokenize([q])
+    off, ids = t.encode_arrays([q[0] for q in queries], [q[1] for q in queries], [q[2] for q in queries])
+    qc, qs, qe = o._encode_regions(queries)
+    off_o, ids_o = o.index.tokenize(qc, qs, qe)
+    assert off.tolist() == off_o.tolist() and ids.tolist() == ids_o.tolist()
+
+
+def test_duplicate_universe_lines_quirk(tmp_path):
+    """Appendix A.7: region_to_id is dense over DISTINCT strings, id_to_region has one entry per line."""
+    from gtars_amd.tokenizers import Tokenizer
+
+    p = tmp_path / "dup.bed"
+    p.write_text("chr1\t100\t200\nchr1\t300\t400\nchr1\t100\t200\nchr2\t5\t50\n")
+    t, o = Tokenizer(str(p)), oracle.OracleTokenizer(str(p))
+    assert t.vocab_size == o.vocab_size == 3 + 7
+    assert t.get_vocab() == o.universe.region_to_id
+    for i in range(12):
+        assert t.convert_ids_to_tokens(i) == o.universe.id_to_region.get(i, "<unk>")
+    q = [("chr1", 150, 160), ("chr2", 1, 10)]
+    assert t.tokenize([R(*x, None) for x in q]) == o.tokenize(q)
+
+
+def test_fragment_file_tokenization(golden_dir):
+    from gtars_amd.tokenizers import Tokenizer, count_fragments_by_barcode, tokenize_fragment_file
+
+    cons = os.path.join(golden_dir, "consensus", "consensus1.bed")
+    t, o = Tokenizer(cons), oracle.OracleTokenizer(cons)
+    for name in ("fragments1.bed.gz", "fragments2.bed.gz"):
+        f = os.path.join(golden_dir, "fragments", "region_scoring", name)
+        got = tokenize_fragment_file(f, t)
+        assert got == o.tokenize_fragment_file(f)
+        assert len(got) == 2  # utils/fragments.rs:114-156
+        cnt = count_fragments_by_barcode(f, t)
+        assert {k: sum(v.values()) for k, v in cnt.items()} == {k: len(v) for k, v in got.items()}
+
+
+# ---- gtars-python/tests/test_regionset.py::TestOverlapOps --------------------------------------
+
+
+def _rs(*specs):
+    from gtars_amd.models import RegionSet
+
+    return RegionSet.from_regions([R(s[0], s[1], s[2], None) for s in specs])
+
+
+def test_regionset_overlap_ops():
+    a = _rs(("chr1", 100, 200), ("chr1", 300, 400), ("chr1", 500, 600))
+    b = _rs(("chr1", 150, 250), ("chr1", 550, 650))
+    assert len(a.subset_by_overlaps(b)) == 2
+    assert a.count_overlaps(b) == [1, 0, 1]
+    assert a.any_overlaps(b) == [True, False, True]
+    assert a.find_overlaps(b) == [[0], [], [1]]
+    # indexed_region_set.rs:519-539
+    ref = _rs(("chr1", 100, 200), ("chr2", 100, 200), ("chr3", 100, 200))
+    q = _rs(("chr1", 150, 250), ("chr2", 150, 250), ("chr4", 150, 250))
+    assert q.count_overlaps(ref) == [1, 1, 0] and q.any_overlaps(ref) == [True, True, False]
+    # empty sides (indexed_region_set.rs:484-516)
+    empty = _rs()
+    assert _rs(("chr1", 100, 200)).count_overlaps(empty) == [0]
+    assert empty.count_overlaps(ref) == []
+
+
+def test_regionset_files_vs_oracle(golden_dir):
+    from gtars_amd.models import RegionSet
+
+    a_path = os.path.join(golden_dir, "lola_multi_db", "collection1", "regions", "vistaEnhancers.bed")
+    b_path = os.path.join(golden_dir, "lola_multi_db", "collection1", "regions", "laminB1Lads.bed")
+    a, b = RegionSet(a_path), RegionSet(b_path)
+    ra, rb = oracle.read_region_set(a_path), oracle.read_region_set(b_path)
+    ids = {}
+    bc = [ids.setdefault(r[0], len(ids)) for r in rb]
+    ox = oracle.Index(bc, [r[1] for r in rb], [r[2] for r in rb], None, n_chrom=len(ids), kind=oracle.KIND_AILIST)
+    qc = [ids.get(r[0], 0xFFFFFFFF) for r in ra]
+    qs, qe = [r[1] for r in ra], [r[2] for r in ra]
+    assert a.count_overlaps(b) == ox.count_overlaps(qc, qs, qe).tolist()
+    off, idx = ox.irs_find_overlaps(bc, [r[1] for r in rb], [r[2] for r in rb], qc, qs, qe)
+    assert a.find_overlaps(b) == [idx[int(off[i]):int(off[i + 1])].tolist() for i in range(len(ra))]
+
+
+# ---- IGD from BED files + LOLA ------------------------------------------------------------------
+
+
+def test_igd_from_bed_dir_kats(golden_dir):
+    from gtars_amd.igd import Igd
+    from gtars_amd.models import RegionSet
+
+    # igd.rs:1034-1057 and gtars-igd/src/lib.rs:389-470
+    g = Igd.from_bed_dir(os.path.join(golden_dir, "igd_file_list_01"))
+    assert g.num_files() == 1 and g.num_contigs() == 3
+    q = RegionSet(os.path.join(golden_dir, "igd_query_files", "query1.bed"))
+    assert g.count_set_overlaps(q).tolist() == [8]
+    hits = np.zeros(1, dtype=np.uint64)
+    assert g.count_overlaps("chr1", 1, 100, 1, hits) == 1 and hits[0] == 1
+    for d in ("igd_file_list_01", "igd_file_list_02"):
+        g = Igd.from_bed_dir(os.path.join(golden_dir, d))
+        o = oracle.OracleIgdDb.from_bed_dir(os.path.join(golden_dir, d))
+        assert [(f.filename, f.num_regions) for f in g.file_info] == [(f[0], f[1]) for f in o.file_info]
+        assert all(abs(f.avg_region_width - of[2]) < 1e-12 for f, of in zip(g.file_info, o.file_info))
+        for qn in ("query1.bed", "query2.bed"):
+            qp = os.path.join(golden_dir, "igd_query_files", qn)
+            regs = oracle.read_region_set(qp)
+            for mo in (1, 5):
+                assert g.count_set_overlaps(RegionSet(qp), mo).tolist() == o.count_set_overlaps(regs, mo).tolist()
+                assert g.count_region_hits(RegionSet(qp), mo).tolist() == o.count_region_hits(regs, mo).tolist()
+
+
+def test_igd_api_kats():
+    from gtars_amd.igd import FileInfo, Igd
+
+    # igd.rs:914-959
+    g = Igd()
+    g.file_info = [FileInfo("file0.bed", 2, 100.0), FileInfo("file1.bed", 1, 50.0)]
+    g.add("chr1", 100, 200, 0, 0)
+    g.add("chr1", 300, 400, 0, 0)
+    g.add("chr1", 150, 250, 0, 1)
+    g.finalize()
+    h = np.zeros(2, dtype=np.uint64)
+    assert g.count_overlaps("chr1", 120, 180, 1, h) == 2 and h.tolist() == [1, 1]
+    assert g.count_overlaps("chrZ", 120, 180, 1, h) == 0
+    # igd.rs:1418-1435 negative start is clamped, both negative -> 0
+    g = Igd.from_region_sets([("test.bed", [("chr1", 100, 200)])])
+    h = np.zeros(1, dtype=np.uint64)
+    assert g.count_overlaps("chr1", -50, 150, 1, h) == 1
+    assert g.count_overlaps("chr1", -100, -50, 1, h) == 0
+    # igd.rs:1371-1392 invalid intervals skipped in count / width
+    g = Igd.from_region_sets([("test.bed", [("chr1", 100, 200), ("chr1", 300, 300), ("chr1", 500, 400), ("chr1", 600, 700)])])
+    assert g.file_info[0].num_regions == 2 and abs(g.file_info[0].avg_region_width - 100.0) < 1e-9
+    # igd.rs:1256-1275, 1321-1339
+    from gtars_amd.models import RegionSet
+
+    subject = RegionSet.from_vectors(["chr1"] * 3, [100, 300, 500], [200, 400, 600])
+    query = RegionSet.from_vectors(["chr1"] * 3, [150, 550, 700], [350, 650, 800])
+    g = Igd.from_single_region_set(subject)
+    assert sorted(g.find_overlaps_regionset(query, 1)) == [(0, 0), (0, 1), (1, 2)]
+    assert g.count_overlaps_per_query(query, 1) == [2, 1, 0]
+
+
+def _write_beds(tmp_path, specs):
+    paths = []
+    for name, regs in specs:
+        p = tmp_path / name
+        p.write_text("".join(f"{c}\t{s}\t{e}\n" for c, s, e in regs))
+        paths.append(str(p))
+    return paths
+
+
+def test_run_lola_kats(tmp_path):
+    from gtars_amd.lola import RegionDB, lola_counts, run_lola
+
+    # enrichment.rs:724-775 (basic), :879-923 (a,b,c,d = 1,1,2,6), :830-853 (binary counting)
+    paths = _write_beds(tmp_path, [("db0.bed", [("chr1", 100, 200), ("chr1", 300, 400)])])
+    db = RegionDB.from_bed_files(paths)
+    user = [("chr1", 150, 180), ("chr1", 500, 600), ("chr1", 700, 800)]
+    universe = [("chr1", 50, 250), ("chr1", 250, 450), ("chr1", 450, 550), ("chr1", 550, 650), ("chr1", 650, 750),
+                ("chr1", 750, 850), ("chr1", 850, 950), ("chr1", 950, 1050), ("chr1", 1050, 1150), ("chr1", 1150, 1250)]
+    res = run_lola([user], universe, db)
+    assert (res["support"], res["b"], res["c"], res["d"]) == ([1], [1], [2], [6])
+    assert res["filename"] == ["db0.bed"] and res["rnkPV"] == [1] and res["size"] == [2]
+    assert 0.0 <= res["qValue"][0] <= 1.0
+
+    paths = _write_beds(tmp_path, [("db3.bed", [("chr1", 100, 200), ("chr1", 120, 220), ("chr1", 140, 240)])])
+    db = RegionDB.from_bed_files(paths)
+    res = run_lola([[("chr1", 150, 190)]], [("chr1", 50, 300), ("chr1", 400, 500)], db)
+    assert res["support"] == [1]
+
+    # two db sets / two user sets (enrichment.rs:724-775, 796-828) + python test fixture shape
+    paths = _write_beds(tmp_path, [("db1.bed", [("chr1", 100, 200), ("chr1", 500, 600)]),
+                                   ("db2.bed", [("chr1", 150, 250), ("chr1", 700, 800)])])
+    db = RegionDB.from_bed_files(paths)
+    assert db.num_region_sets == 2 and db.list_region_sets() == ["db1.bed", "db2.bed"]
+    universe = [("chr1", 50, 250), ("chr1", 450, 650), ("chr1", 650, 850), ("chr1", 900, 1000), ("chr1", 1100, 1200)]
+    res = run_lola([[("chr1", 120, 180)], [("chr1", 120, 180), ("chr1", 520, 560)]], universe, db)
+    assert len(res["userSet"]) == 4
+    rows = {(u, f): s for u, f, s in zip(res["userSet"], res["dbSet"], res["support"])}
+    assert rows == {(0, 0): 1, (0, 1): 1, (1, 0): 2, (1, 1): 1}
+    assert res["pValueLog"] == sorted(res["pValueLog"], reverse=True)
+    with pytest.raises(ValueError):
+        run_lola([[("chr1", 1, 2)]], universe, db, direction="sideways")
+    with pytest.raises(RuntimeError):
+        run_lola([[("chr1", 1, 2)]], [], db)
+    # the counts agree with the oracle's Igd on the same inputs
+    o = oracle.OracleIgdDb(paths)
+    uni_hits, user_hits, _ = lola_counts([[("chr1", 120, 180), ("chr1", 520, 560)]], universe, db)
+    assert uni_hits.tolist() == o.count_region_hits(universe).tolist()
+    assert user_hits[0].tolist() == o.count_region_hits([("chr1", 120, 180), ("chr1", 520, 560)]).tolist()
+
+
+def test_lola_from_folder(golden_dir):
+    from gtars_amd.lola import RegionDB, run_lola
+
+    db = RegionDB.from_folder(os.path.join(golden_dir, "lola_multi_db"))
+    annos = db.collection_anno
+    assert isinstance(annos, list) and len(annos) >= 1
+    assert set(annos[0].keys()) == {"collectionname", "collector", "date", "source", "description"}
+    assert "collection1" in [a["collectionname"] for a in annos]
+    assert db.num_region_sets == 6
+    user = oracle.read_region_set(os.path.join(golden_dir, "lola_multi_db", "collection1", "regions", "vistaEnhancers.bed"))
+    uni = user + oracle.read_region_set(os.path.join(golden_dir, "lola_multi_db", "collection1", "regions", "cpgIslandExt.bed"))
+    res = run_lola([[r[:3] for r in user[:50]]], [r[:3] for r in uni], db)
+    assert len(res["dbSet"]) == 6
+    k = res["filename"].index("vistaEnhancers.bed")
+    assert res["support"][k] == min(50, len(user))

@@ -1,0 +1,121 @@
+"""Host layer checks that need no GPU: BED/BED.gz parsing + sort through the C ABI against the
+oracle's restatement of RegionSet::try_from, .gtok bytes, error mapping."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+BEDS = [
+    "tokenizers/peaks.bed", "tokenizers/peaks.bed.gz", "tokenizers/peaks.scored.bed", "to_tokenize.bed",
+    "consensus/consensus1.bed", "igd_file_list_01/igd_bed_file_1.bed", "igd_file_list_02/igd_bed_file_2.bed",
+    "igd_query_files/query1.bed", "igd_query_files/query2.bed", "regionset/dummy.bed", "regionset/dummy_b.bed",
+    "regionset/dummy_headers.bed", "regionset/dummy.narrowPeak", "regionset/dummy.narrowPeak.bed.gz",
+    "test_sorted_small.bed", "test_unsorted_small.bed", "test_unknown_chrom.bed",
+    "lola_multi_db/collection1/regions/vistaEnhancers.bed", "fragments/region_scoring/fragments1.bed.gz",
+]
+
+
+@pytest.mark.parametrize("rel", BEDS)
+def test_regionset_parse_matches_oracle(golden_dir, rel):
+    from gtars_amd.models import RegionSet
+
+    path = os.path.join(golden_dir, rel)
+    try:
+        exp = oracle.read_region_set(path)
+    except oracle.RegionSetError:
+        with pytest.raises(RuntimeError):
+            RegionSet(path)
+        return
+    rs = RegionSet(path)
+    got = [(r.chr, r.start, r.end, r.rest) for r in rs]
+    assert got == exp
+    assert len(rs) == len(exp)
+
+
+def test_regionset_kats(golden_dir):
+    from gtars_amd.models import Region, RegionSet
+
+    # gtars-core/src/lib.rs:25-60: 25 regions, sorted (chr lexicographic, start)
+    rs = RegionSet(os.path.join(golden_dir, "tokenizers", "peaks.bed"))
+    assert len(rs) == 25
+    keys = [(r.chr.encode(), r.start) for r in rs]
+    assert keys == sorted(keys)
+    # gtars-python/tests/test_regionset.py:17-29
+    rs = RegionSet.from_regions([Region(chr="chr1", start=14, end=514, rest=None), Region(chr="chr19", start=19, end=810, rest=None)])
+    assert isinstance(rs, RegionSet) and len(rs) == 2
+    # from_regions does NOT sort (region_set.rs:212-220)
+    rs = RegionSet.from_regions([Region("chr2", 5, 9, None), Region("chr1", 1, 2, "a\tb")])
+    assert [str(r) for r in rs] == ["chr2\t5\t9", "chr1\t1\t2\ta\tb"]
+    rs = RegionSet.from_vectors(["chr1", "chrX"], [1, 2], [5, 9])
+    assert [r.chr for r in rs] == ["chr1", "chrX"] and rs.strands == ["*", "*"]
+    with pytest.raises(ValueError):
+        RegionSet.from_vectors(["chr1"], [1, 2], [5, 9])
+    r = Region("chr1", 10, 25, None)
+    assert len(r) == 15 and repr(r) == "Region -> chr1 10 25" and r == Region("chr1", 10, 25, "x")
+
+
+def test_regionset_errors(tmp_path, golden_dir):
+    from gtars_amd.models import RegionSet
+
+    with pytest.raises(RuntimeError):
+        RegionSet(str(tmp_path / "missing.bed"))
+    empty = tmp_path / "empty.bed"
+    empty.write_text("# only a comment\n")
+    with pytest.raises(RuntimeError):  # EmptyRegionSet (region_set.rs:169-171)
+        RegionSet(str(empty))
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chr1\t10\t20\nchr1\tx\t30\n")
+    with pytest.raises(RuntimeError):
+        RegionSet(str(bad))
+    # header line without '#': skipped because column 2 is not numeric (region_set.rs:120-135)
+    hdr = tmp_path / "hdr.bed"
+    hdr.write_text("chrom\tstart\tend\nchr2\t5\t9\nchr1\t7\t8\r\n")
+    rs = RegionSet(str(hdr))
+    assert [(r.chr, r.start, r.end) for r in rs] == [("chr1", 7, 8), ("chr2", 5, 9)]
+    assert rs.header == "chrom\tstart\tend"
+
+
+def test_gtok_roundtrip_and_golden_bytes(golden_dir, tmp_path):
+    from gtars_amd import utils
+
+    assert utils.read_tokens_from_gtok(os.path.join(golden_dir, "out", "peaks.gtok")) == list(range(25))
+    assert utils.read_tokens_from_gtok(os.path.join(golden_dir, "out", "tokens.gtok")) == [42, 101, 999]
+    p = str(tmp_path / "sub" / "dir" / "t.gtok")
+    utils.write_tokens_to_gtok(p, list(range(25)))
+    assert open(p, "rb").read() == open(os.path.join(golden_dir, "out", "peaks.gtok"), "rb").read()
+    utils.write_tokens_to_gtok(p, [1, 70000, 3])
+    assert open(p, "rb").read()[:5] == b"GTOK\x02"
+    assert utils.read_tokens_from_gtok(p) == [1, 70000, 3]
+    assert utils.read_tokens_from_gtok_as_strings(p) == ["1", "70000", "3"]
+    # same bytes as the oracle's writer
+    q = str(tmp_path / "o.gtok")
+    oracle.write_tokens_to_gtok(q, [1, 70000, 3])
+    assert open(p, "rb").read() == open(q, "rb").read()
+    bad = tmp_path / "bad.gtok"
+    bad.write_bytes(b"NOPE\x01\x00\x00")
+    with pytest.raises(ValueError):
+        utils.read_tokens_from_gtok(str(bad))
+
+
+def test_lola_statistics_tail_kats():
+    from gtars_amd import lola
+
+    # enrichment.rs:498-515: CMLE vs R fisher.test(matrix(c(10,30,20,40), nrow=2))$estimate = 0.6693434
+    assert abs(lola.odds_ratio(10, 20, 30, 40) - 0.6693434) < 1e-3
+    # enrichment.rs:517-537 boundaries
+    assert lola.odds_ratio(10, 0, 5, 100) == float("inf")
+    assert lola.odds_ratio(0, 5, 10, 100) == 0.0
+    # enrichment.rs:538-575: p-value inequalities only (statrs absent: parity unpinned, scipy used)
+    assert lola.fisher_pvalue(50, 10, 10, 1000, True) < 1e-10
+    assert lola.fisher_pvalue(1, 100, 100, 10, False) < 0.01
+    assert lola.fisher_pvalue(0, 5, 5, 100, True) == 1.0
+    rows = [{"userSet": 0, "dbSet": i, "pValueLog": p, "oddsRatio": o, "support": s} for i, (p, o, s) in
+            enumerate([(5.0, 2.0, 10), (5.0, float("nan"), 10), (1.0, 3.0, 20)])]
+    lola._rank_results(rows)
+    assert [r["rnkPV"] for r in rows] == [1, 1, 3]        # ties.method = "min"
+    assert [r["rnkOR"] for r in rows] == [2, 3, 1]        # NaN ranks last
+    assert [r["rnkSup"] for r in rows] == [2, 2, 1]
+    lola._apply_fdr(rows)
+    assert all(0.0 <= r["qValue"] <= 1.0 for r in rows)
