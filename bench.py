@@ -141,20 +141,35 @@ def main():
         elapsed = float(t.item())
 
     # ---- dominant-kernel duration with HIP events on the launch stream ----
+    # One step is exactly one k_tok_lds launch (the chained-scan workspace is epoch-tagged, so there is
+    # no memset kernel); K launches are bracketed by ONE pair of HIP events recorded on the stream the
+    # kernel is launched on, so the average includes the ~1 us inter-launch gap but no event overhead.
     roofline = None
     if rank == 0:
         _lib.lib.gtars_prof_reset()
         _lib.lib.gtars_prof_enable(1)
-        prof_steps = min(args.steps, 50)
+        step()
+        torch.cuda.synchronize()
+        names = list(_lib.prof_read())
+        _lib.lib.gtars_prof_enable(0)
+        name = names[0] if len(names) == 1 else "+".join(names)
+        prof_steps = max(args.steps, 50)
+        ts = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(ts)
         for _ in range(prof_steps):
             step()
+        e1.record(ts)
         torch.cuda.synchronize()
-        prof = _lib.prof_read()
-        _lib.lib.gtars_prof_enable(0)
-        name = max(prof, key=lambda k: prof[k]["total_ms"])
-        avg_ms = prof[name]["total_ms"] / max(prof[name]["launches"], 1)
+        avg_ms = e0.elapsed_time(e1) / prof_steps
         bytes_per_launch = algorithmic_bytes(nq, h, nu)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_tokenize_1M.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj["workload"]["queries_per_step"] == nq and tj["workload"]["universe_regions"] == args.universe:
+                traffic = tj["traffic_bytes_per_launch"]  # rocprofv3 PMC passes, see that file for the recipe
         roofline = {
             "bound": "hbm",
             "kernel": name,
@@ -162,7 +177,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "avg_kernel_ms": avg_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "bytes_per_query": bytes_per_launch / nq,
