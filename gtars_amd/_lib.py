@@ -86,6 +86,7 @@ _SIG = {
     "gtars_igd_len": (u64, [vp]),
     "gtars_igd_n_files": (u32, [vp]),
     "gtars_igd_total_records": (u64, [vp, i32]),
+    "gtars_igd_export": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "gtars_igd_count_device": (C.c_int, [vp, vp, vp, vp, u64, i32, C.c_int, vp, vp]),
     "gtars_igd_count": (C.c_int, [vp, vp, vp, vp, u64, i32, C.c_int, vp]),
     "gtars_igd_count_per_query": (C.c_int, [vp, vp, vp, vp, u64, i32, vp]),
@@ -157,6 +158,7 @@ _HOST_SIG = {
     "gtars_igddb_file_num_regions": (u32, [vp, u32]),
     "gtars_igddb_file_avg_width": (C.c_double, [vp, u32]),
     "gtars_igddb_chrom_id": (i64, [vp, cstr]),
+    "gtars_igddb_chrom_name": (cstr, [vp, u32]),
     "gtars_igddb_engine": (vp, [vp]),
     "gtars_igddb_count_regionset": (C.c_int, [vp, vp, i32, C.c_int, vp]),
 }

@@ -913,6 +913,24 @@ uint64_t gtars_igd_total_records(const gtars_igd_t *g, int32_t nbp) {
     return t;
 }
 
+gtars_status gtars_igd_export(const gtars_igd_t *g, uint32_t *chrom, int32_t *start, int32_t *end, int32_t *value,
+                              uint32_t *file_idx) {
+    if (!g) return fail(GTARS_ERR_INVALID_ARG, "NULL handle");
+    const size_t n = g->n;
+    if (!n) return GTARS_OK;
+    if (start) memcpy(start, g->h_starts.data(), n * 4);
+    if (end) memcpy(end, g->h_ends.data(), n * 4);
+    if (value) GT_HIP(hipMemcpy(value, g->values.p, n * 4, hipMemcpyDeviceToHost));
+    if (file_idx) GT_HIP(hipMemcpy(file_idx, g->files.p, n * 4, hipMemcpyDeviceToHost));
+    if (chrom) {
+        std::vector<u32> off(g->n_chrom + 1);
+        GT_HIP(hipMemcpy(off.data(), g->chrom_off.p, off.size() * 4, hipMemcpyDeviceToHost));
+        for (u32 c = 0; c < g->n_chrom; ++c)
+            for (u32 i = off[c]; i < off[c + 1]; ++i) chrom[i] = c;
+    }
+    return GTARS_OK;
+}
+
 gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, const uint32_t *d_qs,
                                     const uint32_t *d_qe, uint64_t nq, int32_t min_overlap, int binary,
                                     uint64_t *d_hits, void *stream) {

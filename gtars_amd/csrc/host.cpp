@@ -1235,11 +1235,15 @@ gtars_status gtars_igddb_from_bed_files(const char *const *paths, uint64_t n_pat
             if (!igd_parse_bed_line(line, chrom, s, e, score)) continue;
             has_valid = true;
             if (s >= 0) {
-                ch.push_back(db->chroms.get_or_add(chrom));
-                st.push_back(s);
-                en.push_back(e);
-                va.push_back(score);
-                fi.push_back(file_idx);
+                // Igd::add creates the contig only for a record it keeps (igd.rs:114-133); count and
+                // total_width are updated regardless (igd.rs:213-217)
+                if (s < e) {
+                    ch.push_back(db->chroms.get_or_add(chrom));
+                    st.push_back(s);
+                    en.push_back(e);
+                    va.push_back(score);
+                    fi.push_back(file_idx);
+                }
                 count += 1;
                 total_width += (uint64_t)(int64_t)(e - s);
             }
@@ -1300,6 +1304,9 @@ double gtars_igddb_file_avg_width(const gtars_igddb_t *db, uint32_t i) {
     return db && i < db->files.size() ? db->files[i].avg_width : 0.0;
 }
 int64_t gtars_igddb_chrom_id(const gtars_igddb_t *db, const char *chr) { return db && chr ? db->chroms.find(chr) : -1; }
+const char *gtars_igddb_chrom_name(const gtars_igddb_t *db, uint32_t id) {
+    return db && id < db->chroms.names.size() ? db->chroms.names[id].c_str() : nullptr;
+}
 const gtars_igd_t *gtars_igddb_engine(const gtars_igddb_t *db) { return db ? db->igd : nullptr; }
 
 gtars_status gtars_igddb_count_regionset(const gtars_igddb_t *db, const gtars_regionset_t *rs, int32_t min_overlap,

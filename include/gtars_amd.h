@@ -184,6 +184,11 @@ uint64_t gtars_igd_len(const gtars_igd_t *g);          /* stored intervals */
 uint32_t gtars_igd_n_files(const gtars_igd_t *g);
 /* what Igd::total_records() would report for nbp (tile replicas counted) */
 uint64_t gtars_igd_total_records(const gtars_igd_t *g, int32_t nbp);
+/* copy the stored records back to the host, in device order = (chrom, start, insertion order), which
+ * restricted to one nbp-tile is exactly the order of that tile in the reference (igd.rs:157-167);
+ * used to write .igd files (igd.rs:425-486).  Each array has gtars_igd_len() entries; any may be NULL. */
+gtars_status gtars_igd_export(const gtars_igd_t *g, uint32_t *chrom, int32_t *start, int32_t *end,
+                              int32_t *value, uint32_t *file_idx);
 
 /* binary = 0: Igd::count_set_overlaps (pairwise);
  * binary = 1: Igd::count_region_hits (at most 1 per query per file).

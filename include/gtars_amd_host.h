@@ -148,6 +148,7 @@ const char *gtars_igddb_file_name(const gtars_igddb_t *db, uint32_t i);
 uint32_t gtars_igddb_file_num_regions(const gtars_igddb_t *db, uint32_t i);
 double gtars_igddb_file_avg_width(const gtars_igddb_t *db, uint32_t i);
 int64_t gtars_igddb_chrom_id(const gtars_igddb_t *db, const char *chr); /* -1 unknown */
+const char *gtars_igddb_chrom_name(const gtars_igddb_t *db, uint32_t id); /* contigs in creation order */
 const gtars_igd_t *gtars_igddb_engine(const gtars_igddb_t *db);        /* borrowed */
 /* Igd::count_set_overlaps (binary=0) / count_region_hits (binary=1) of a region set */
 gtars_status gtars_igddb_count_regionset(const gtars_igddb_t *db, const gtars_regionset_t *rs,

@@ -354,3 +354,47 @@ def test_lola_from_folder(golden_dir):
     assert len(res["dbSet"]) == 6
     k = res["filename"].index("vistaEnhancers.bed")
     assert res["support"][k] == min(50, len(user))
+
+
+def test_igd_save_and_reload(tmp_path, golden_dir):
+    """igd.rs:1085-1124 (save/reload equality) + the on-disk layout of igd.rs:425-486."""
+    import struct
+
+    from gtars_amd.igd import FileInfo, Igd
+
+    g = Igd()
+    g.file_info = [FileInfo("file0.bed", 2, 100.0), FileInfo("file1.bed", 1, 100.0)]
+    g.add("chr1", 100, 200, 5, 0)
+    g.add("chr1", 10000, 40000, 7, 0)   # spans tiles 0..2 -> three replicas on disk
+    g.add("chr2", 150, 250, 9, 1)
+    g.finalize()
+    p = str(tmp_path / "out" / "db.igd")
+    g.save(p)
+    raw = open(p, "rb").read()
+    nbp, gtype, nctg = struct.unpack_from("<3i", raw, 0)
+    assert (nbp, gtype, nctg) == (16384, 1, 2)
+    ntiles = struct.unpack_from("<2i", raw, 12)
+    assert ntiles == (3, 1)
+    counts = struct.unpack_from("<4i", raw, 20)
+    assert counts == (2, 1, 1, 1) and sum(counts) == g.total_records() == 5
+    assert raw[36:40] == b"chr1" and raw[36 + 40:36 + 44] == b"chr2"
+    first = struct.unpack_from("<4i", raw, 36 + 80)
+    assert first == (0, 100, 200, 5)
+    assert len(raw) == 36 + 80 + 16 * 5
+    tsv = open(str(tmp_path / "out" / "db.tsv")).read().splitlines()
+    assert tsv[0] == "Index\tFile\tNumber of Regions\tAvg size" and tsv[1] == "0\tfile0.bed\t2\t100.00"
+    r = Igd.from_igd_file(p)
+    assert r.num_files() == 2 and r.num_contigs() == 2 and r.total_records() == 5
+    q = [("chr1", 120, 180), ("chr1", 15000, 35000), ("chr2", 100, 300), ("chr3", 1, 2)]
+    assert r.count_set_overlaps(q).tolist() == g.count_set_overlaps(q).tolist() == [2, 1]
+    assert r.count_region_hits(q).tolist() == g.count_region_hits(q).tolist()
+    # a database built by the C++ host from BED files survives the round trip too
+    d = Igd.from_bed_dir(os.path.join(golden_dir, "igd_file_list_02"))
+    p2 = str(tmp_path / "two.igd")
+    d.save(p2)
+    d2 = Igd.from_igd_file(p2)
+    o = oracle.OracleIgdDb.from_bed_dir(os.path.join(golden_dir, "igd_file_list_02"))
+    assert d2.total_records() == o.igd.total_records()
+    regs = oracle.read_region_set(os.path.join(golden_dir, "igd_query_files", "query1.bed"))
+    assert d2.count_set_overlaps(regs).tolist() == o.count_set_overlaps(regs).tolist()
+    assert [f.filename for f in d2.file_info] == [f[0] for f in o.file_info]

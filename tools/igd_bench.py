@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: IGD batch query, synthetic intervals vs an indexed multi-file database."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import gtars_amd
+from gtars_amd import synth
+
+def main():
+    ndb = int(os.environ.get("NDB", "50000000")); nq = int(os.environ.get("NQ", "10000000")); F = int(os.environ.get("F", "1000"))
+    dev = torch.device("cuda:0")
+    t = time.time(); db = synth.make_igd_db(ndb, F); q = synth.make_background_queries(nq); tgen = time.time() - t
+    t = time.time(); g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=F); tbuild = time.time() - t
+    qc, qs, qe = (torch.from_numpy(q[k].view(np.int32)).to(dev) for k in ("chrom", "start", "end"))
+    hits = torch.zeros(F, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    out = {"ndb": ndb, "nq": nq, "F": F, "gen_s": round(tgen, 2), "build_s": round(tbuild, 2)}
+    for binary in (False, True):
+        g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, hits.data_ptr(), 1, binary, st)
+        torch.cuda.synchronize()
+        reps = 3
+        t = time.perf_counter()
+        for _ in range(reps):
+            g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, hits.data_ptr(), 1, binary, st)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / reps
+        byts = 12 * nq + 16 * ndb + 8 * F
+        out["binary" if binary else "pairwise"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt), "hbm_frac": round(byts / dt / 8e12, 5),
+                                                   "total_hits": int(hits.sum())}
+    if os.environ.get("CHECK", "1") == "1":
+        # parity on a sample of the queries against the oracle's literal tile walk (full DB)
+        import oracle
+        ns = int(os.environ.get("NSAMPLE", "20000"))
+        o = oracle.Igd()
+        t = time.time()
+        L = oracle.lib()
+        c, s, e, f = db["chrom"], db["start"], db["end"], db["file"]
+        sel = np.nonzero(c == 20)[0]  # chr21 only: keeps the oracle build small
+        for i in sel:
+            L.orc_igd_add(o._h, int(c[i]), int(s[i]), int(e[i]), 0, int(f[i]))
+        o.n_files = F; o.finalize()
+        qsel = np.nonzero(q["chrom"] == 20)[0][:ns]
+        exp_p = o.count_set_overlaps(q["chrom"][qsel], q["start"][qsel], q["end"][qsel], 1, n_files=F)
+        exp_b = o.count_region_hits(q["chrom"][qsel], q["start"][qsel], q["end"][qsel], 1, n_files=F)
+        got_p = g.count_set_overlaps(q["chrom"][qsel], q["start"][qsel], q["end"][qsel], 1)
+        got_b = g.count_region_hits(q["chrom"][qsel], q["start"][qsel], q["end"][qsel], 1)
+        out["parity_sample"] = {"queries": int(len(qsel)), "pairwise_equal": bool(np.array_equal(exp_p, got_p)),
+                                "binary_equal": bool(np.array_equal(exp_b, got_b)), "oracle_s": round(time.time() - t, 1)}
+    print(json.dumps(out))
+if __name__ == "__main__":
+    main()
