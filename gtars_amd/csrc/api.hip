@@ -158,6 +158,32 @@ struct ScopedDev {
 
 using namespace gtars;
 
+// K1 policy: large builds are ordered by the device radix sort, small ones by std::stable_sort
+// (identical results; GTARS_DEVICE_SORT=0/1 forces one path, used by the tests)
+static bool use_device_sort(u64 n) {
+    if (const char *e = getenv("GTARS_DEVICE_SORT")) return atoi(e) != 0;
+    return n >= (1u << 16);
+}
+
+// perm[p] = input row of sorted position p, ordered by (chrom, k1, [k2], input order) on the device
+static gtars_status sorted_perm_device(const std::vector<u32> &chrom, const std::vector<u32> &k1,
+                                       const std::vector<u32> *k2, u32 n_chrom, std::vector<u32> &perm) {
+    const u32 n = (u32)chrom.size();
+    perm.resize(n);
+    if (!n) return GTARS_OK;
+    ScopedDev buf;
+    gtars_status st = buf.alloc((size_t)n * 4 * 4);
+    if (st) return st;
+    u32 *dc = buf.as<u32>(), *d1 = dc + n, *d2 = d1 + n, *dp = d2 + n;
+    GT_HIP(hipMemcpy(dc, chrom.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    GT_HIP(hipMemcpy(d1, k1.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    if (k2) GT_HIP(hipMemcpy(d2, k2->data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    st = device_sort_perm(dc, d1, k2 ? d2 : nullptr, n, n_chrom, dp, nullptr);
+    if (st) return st;
+    GT_HIP(hipMemcpy(perm.data(), dp, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GTARS_OK;
+}
+
 // ================================================================== handles
 
 struct gtars_index {
@@ -295,12 +321,23 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
     ix->h_chrom_aux.assign(n_chrom, 0);
 
     if (kind == GTARS_KIND_BITS) {
+        const bool dev_sort = use_device_sort(n);
+        if (dev_sort) {
+            // K1: (chrom, start, end, input order) by stable radix passes on the device
+            std::vector<u32> hc(chrom, chrom + n), hs(start, start + n), he(end, end + n);
+            gtars_status s1 = sorted_perm_device(hc, hs, &he, n_chrom, perm);
+            if (s1) {
+                delete ix;
+                return s1;
+            }
+        }
         for (u32 c = 0; c < n_chrom; ++c) {
             // Bits::build: stable sort by (start, end) (bits.rs:105, interval.rs:18-31)
-            std::stable_sort(perm.begin() + off[c], perm.begin() + off[c + 1], [&](u32 a, u32 b) {
-                if (start[a] != start[b]) return start[a] < start[b];
-                return end[a] < end[b];
-            });
+            if (!dev_sort)
+                std::stable_sort(perm.begin() + off[c], perm.begin() + off[c + 1], [&](u32 a, u32 b) {
+                    if (start[a] != start[b]) return start[a] < start[b];
+                    return end[a] < end[b];
+                });
             u32 max_len = 0;
             for (u32 p = off[c]; p < off[c + 1]; ++p) {
                 const u32 i = perm[p];
@@ -855,10 +892,23 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
     }
     if (keep.size() >= 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "too many records");
     // chromosome-major, then start, ties in insertion order (finalize: stable sort by start, igd.rs:157-167)
-    std::stable_sort(keep.begin(), keep.end(), [&](u32 a, u32 b) {
-        if (chrom[a] != chrom[b]) return chrom[a] < chrom[b];
-        return start[a] < start[b];
-    });
+    if (use_device_sort(keep.size())) {
+        std::vector<u32> hc(keep.size()), hs(keep.size()), perm;
+        for (size_t k = 0; k < keep.size(); ++k) {
+            hc[k] = chrom[keep[k]];
+            hs[k] = (u32)start[keep[k]];  // kept starts are >= 0: u32 order == i32 order
+        }
+        st = sorted_perm_device(hc, hs, nullptr, n_chrom, perm);
+        if (st) return st;
+        std::vector<u32> sorted(keep.size());
+        for (size_t k = 0; k < keep.size(); ++k) sorted[k] = keep[perm[k]];
+        keep.swap(sorted);
+    } else {
+        std::stable_sort(keep.begin(), keep.end(), [&](u32 a, u32 b) {
+            if (chrom[a] != chrom[b]) return chrom[a] < chrom[b];
+            return start[a] < start[b];
+        });
+    }
     auto *g = new gtars_igd();
     g->n_chrom = n_chrom;
     g->n_files = n_files;

@@ -168,6 +168,12 @@ gtars_status launch_lola_contingency(const u64 *user_hits, const u64 *universe_h
 gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, u32 *new_counts,
                                          hipStream_t st);
 
+// K1 (sort.hip): permutation that orders rows by (chrom, k1, [k2], input order); device columns in/out
+gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
+                              hipStream_t st);
+
+gtars_status device_gather_u32(const u32 *src, const u32 *idx, u32 n, u32 *dst, hipStream_t st);
+
 // ---- profiling hooks --------------------------------------------------------
 struct ProfScope {
     ProfScope(const char *name, hipStream_t st);

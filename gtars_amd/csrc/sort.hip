@@ -1,0 +1,196 @@
+// sort.hip -- K1: stable LSD radix sort of (u32 key, u32 payload) pairs on the device, used to build
+// the indexes in the reference's stable orders:
+//   Bits::build     sort by (start, end), ties in input order      (gtars-overlaprs/src/bits.rs:105)
+//   Igd::finalize   sort by start, ties in insertion order         (gtars-igd/src/igd.rs:157-167)
+//   per-chromosome bucketing = one more stable pass on the chromosome id
+//                                                                  (gtars-tokenizers/src/utils/mod.rs:55-87)
+// i.e. a per-chromosome segmented sort realised as stable passes from the least significant key up:
+// end (4 x 8 bits), start (4 x 8 bits), chrom (ceil(bits/8)).  The payload is the original index, so
+// stability == "ties in input order" by construction.
+//
+// Per 8-bit pass: (1) per-tile LDS histogram -> digit-major table, (2) exclusive scan of the table,
+// (3) scatter with stable in-tile ranks: a wave finds its equal-digit peers with 8 ballots
+// (64-wide "match-any"), waves are ordered through a small LDS table, rounds through a running base.
+// Bound: HBM, 16 B moved per element per pass (8 B in, 8 B out) + one 4-B random gather per key word.
+#include "common.h"
+#include "scan.cuh"
+
+namespace gtars {
+
+constexpr int RS_TPB = 256;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_TPB * RS_ITEMS;
+constexpr int RS_NW = RS_TPB / 64;
+
+__global__ void __launch_bounds__(RS_TPB)
+k_radix_hist(const u32 *__restrict__ keys, u32 n, int shift, u32 *__restrict__ table, u32 n_tiles) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 i = base + r * RS_TPB + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    table[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];  // digit-major
+}
+
+__global__ void __launch_bounds__(RS_TPB)
+k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 n, int shift,
+                const u64 *__restrict__ table_off, u32 n_tiles, u32 *__restrict__ okeys,
+                u32 *__restrict__ ovals) {
+    __shared__ u32 wc[RS_NW][256];  // per-wave digit counts of the current round
+    __shared__ u32 run[256];        // elements of each digit already placed by earlier rounds
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    run[threadIdx.x] = 0;
+    const u64 my_digit_base = table_off[(size_t)threadIdx.x * n_tiles + blockIdx.x];
+    __shared__ u64 gbase[256];
+    gbase[threadIdx.x] = my_digit_base;
+    const u32 base = blockIdx.x * RS_TILE;
+    for (int r = 0; r < RS_ITEMS; ++r) {
+#pragma unroll
+        for (int w = 0; w < RS_NW; ++w) wc[w][threadIdx.x] = 0;
+        __syncthreads();
+        const u32 i = base + r * RS_TPB + threadIdx.x;
+        const bool ok = i < n;
+        const u32 k = ok ? keys[i] : 0u;
+        const u32 v = ok ? vals[i] : 0u;
+        const u32 d = (k >> shift) & 0xFFu;
+        // peers = lanes of this wave holding the same digit (and in range)
+        unsigned long long peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const u32 rank_in_wave = __popcll(peers & ((1ull << lane) - 1ull));
+        if (ok && rank_in_wave == 0) wc[wave][d] = __popcll(peers);  // one lane per digit writes the count
+        __syncthreads();
+        if (ok) {
+            u32 before = run[d];
+#pragma unroll
+            for (int w = 0; w < RS_NW; ++w)
+                if (w < wave) before += wc[w][d];
+            const u64 pos = gbase[d] + before + rank_in_wave;
+            okeys[pos] = k;
+            ovals[pos] = v;
+        }
+        __syncthreads();
+        {
+            u32 add = 0;
+#pragma unroll
+            for (int w = 0; w < RS_NW; ++w) add += wc[w][threadIdx.x];
+            run[threadIdx.x] += add;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_iota(u32 *__restrict__ p, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+__global__ void k_gather_u32(const u32 *__restrict__ src, const u32 *__restrict__ idx, u32 n, u32 *__restrict__ dst) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+gtars_status device_gather_u32(const u32 *src, const u32 *idx, u32 n, u32 *dst, hipStream_t st) {
+    if (n == 0) return GTARS_OK;
+    ProfScope p("k_gather_u32", st);
+    hipLaunchKernelGGL(k_gather_u32, dim3((n + 255) / 256), dim3(256), 0, st, src, idx, n, dst);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
+size_t radix_sort_ws_bytes(u32 n) {
+    const u32 tiles = (n + RS_TILE - 1) / RS_TILE;
+    const size_t table = (size_t)256 * tiles;
+    // table u32 | table offsets u64 (+1) | scan partials
+    return table * 4 + (table + 1) * 8 + scan_ws_bytes(table) + 256;
+}
+
+// Sort (keys, vals) by bits [begin_bit, end_bit) of keys, stable.  Ping-pongs between (k0,v0) and
+// (k1,v1); returns which pair holds the result through *in_first (0: k0/v0, 1: k1/v1).
+gtars_status radix_sort_pairs(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u32 n, int begin_bit, int end_bit, void *ws,
+                              size_t ws_bytes, int *result_in, hipStream_t st) {
+    *result_in = 0;
+    if (n == 0) return GTARS_OK;
+    const u32 tiles = (n + RS_TILE - 1) / RS_TILE;
+    const size_t table = (size_t)256 * tiles;
+    if (ws_bytes < radix_sort_ws_bytes(n)) return fail(GTARS_ERR_INTERNAL, "radix sort workspace too small");
+    u32 *d_table = (u32 *)ws;
+    u64 *d_off = (u64 *)((char *)ws + ((table * 4 + 15) & ~(size_t)15));
+    void *d_scan = (char *)d_off + (((table + 1) * 8 + 15) & ~(size_t)15);
+    const size_t scan_bytes = ws_bytes - (size_t)((char *)d_scan - (char *)ws);
+    u32 *ki = k0, *vi = v0, *ko = k1, *vo = v1;
+    int cur = 0;
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        {
+            ProfScope p("k_radix_hist", st);
+            hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(RS_TPB), 0, st, ki, n, shift, d_table, tiles);
+        }
+        gtars_status s = launch_scan_u32_to_u64(d_table, table, d_off, d_scan, scan_bytes, st);
+        if (s) return s;
+        {
+            ProfScope p("k_radix_scatter", st);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(RS_TPB), 0, st, ki, vi, n, shift, d_off, tiles, ko, vo);
+        }
+        std::swap(ki, ko);
+        std::swap(vi, vo);
+        cur ^= 1;
+    }
+    GT_HIP(hipGetLastError());
+    *result_in = cur;
+    return GTARS_OK;
+}
+
+// Order of the reference for one index: perm such that
+//   (chrom, k1, k2, input order) ascending, k2 optional (Bits: k1 = start, k2 = end; IGD: k1 = start).
+// d_perm (n u32) receives the permutation.  d_chrom/d_k1/d_k2 are the unsorted device columns.
+gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
+                              hipStream_t st) {
+    if (n == 0) return GTARS_OK;
+    u32 *buf = nullptr;
+    const size_t wsb = radix_sort_ws_bytes(n);
+    GT_HIP(hipMalloc((void **)&buf, (size_t)n * 4 * 3 + wsb + 64));
+    u32 *kA = buf, *kB = buf + n, *vB = buf + 2 * (size_t)n;
+    void *ws = (void *)(buf + 3 * (size_t)n);
+    u32 *vA = d_perm;
+    const unsigned g = (n + 255) / 256;
+    hipLaunchKernelGGL(k_iota, dim3(g), dim3(256), 0, st, vA, n);
+    gtars_status s = GTARS_OK;
+    u32 *kc = kA, *vc = vA, *ko = kB, *vo = vB;
+    auto pass = [&](const u32 *col, int bits) -> gtars_status {
+        hipLaunchKernelGGL(k_gather_u32, dim3(g), dim3(256), 0, st, col, vc, n, kc);
+        int res = 0;
+        gtars_status r = radix_sort_pairs(kc, vc, ko, vo, n, 0, bits, ws, wsb, &res, st);
+        if (r) return r;
+        if (res) {
+            std::swap(kc, ko);
+            std::swap(vc, vo);
+        }
+        return GTARS_OK;
+    };
+    if (d_k2) s = pass(d_k2, 32);
+    if (!s) s = pass(d_k1, 32);
+    if (!s && n_chrom > 1) {
+        int bits = 0;
+        while ((1u << bits) < n_chrom) ++bits;
+        bits = (bits + 7) & ~7;
+        s = pass(d_chrom, bits);
+    }
+    if (!s && vc != d_perm) {
+        GT_HIP(hipMemcpyAsync(d_perm, vc, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    if (s) return s;
+    GT_HIP(e);
+    return GTARS_OK;
+}
+
+}  // namespace gtars

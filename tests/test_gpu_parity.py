@@ -427,3 +427,43 @@ def test_lola_contingency_device(ga):
     torch.cuda.synchronize()
     for got, exp in zip(out, (a, b, c, d)):
         assert got.cpu().numpy().tolist() == exp.tolist()
+
+
+# ------------------------------------------------------------------ K1: device radix sort
+
+
+@pytest.mark.parametrize("n,n_chrom,span", [(5000, 3, 300), (70_000, 25, 1_000_000), (40_000, 700, 5_000)])
+def test_device_sort_builds_the_same_index(ga, monkeypatch, n, n_chrom, span):
+    """The device radix sort (stable LSD passes) must give exactly the reference's stable orders:
+    Bits (start,end,input) per chromosome, IGD (start, insertion); many ties on purpose."""
+    rng = np.random.default_rng(n)
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(0, 50, n)
+    val = rng.permutation(n).astype(np.uint32)
+    o = oracle.Index(c, s, e, val, n_chrom=n_chrom, kind=KIND_BITS)
+    monkeypatch.setenv("GTARS_DEVICE_SORT", "1")
+    g_dev = ga.OverlapIndex(c, s, e, val, n_chrom=n_chrom, kind=KIND_BITS)
+    monkeypatch.setenv("GTARS_DEVICE_SORT", "0")
+    g_host = ga.OverlapIndex(c, s, e, val, n_chrom=n_chrom, kind=KIND_BITS)
+    for ch in range(0, n_chrom, max(1, n_chrom // 40)):
+        exp = [x.tolist() for x in o.stored(ch)]
+        assert [x.tolist() for x in g_dev.stored(ch)] == exp
+        assert [x.tolist() for x in g_host.stored(ch)] == exp
+        assert g_dev.max_len(ch) == o.max_len(ch)
+    qc = rng.integers(0, n_chrom, 5000)
+    qs = rng.integers(0, span, 5000)
+    qe = qs + rng.integers(0, 100, 5000)
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    off_g, ids_g = g_dev.tokenize(qc, qs, qe)
+    assert off_g.tolist() == off_o.tolist() and ids_g.tolist() == ids_o.tolist()
+    # IGD: walk order of find_overlaps_regionset depends on the (start, insertion) order
+    F = 11
+    f = rng.integers(0, F, n)
+    monkeypatch.setenv("GTARS_DEVICE_SORT", "1")
+    gi, oi = _igd_pair(ga, c, s, e + 1, f, np.arange(n), n_chrom=n_chrom, n_files=F)
+    assert gi.count_set_overlaps(qc, qs, qe + 1).tolist() == oi.count_set_overlaps(qc, qs, qe + 1, 1, n_files=F).tolist()
+    q2 = slice(0, 400)
+    gq, gs = gi.find_overlaps_regionset(qc[q2], qs[q2], qe[q2] + 1)
+    oq, os_ = oi.find_overlaps_regionset(qc[q2], qs[q2], qe[q2] + 1)
+    assert gq.tolist() == oq.tolist() and gs.tolist() == os_.tolist()
