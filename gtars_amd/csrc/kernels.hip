@@ -542,15 +542,26 @@ k_igd_count(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                     atomicAdd(&hits[f], 1ull);
             });
         } else {
-            // count file f once per query: only at the first hit (in scan
-            // order) that belongs to f.  Checking "is there an earlier hit of
-            // the same file" re-walks the (short) prefix.
+            // count file f once per query: only at the first hit (in scan order) that belongs to f.
+            // "Is there an earlier hit of the same file" looks at the file ids of the (short) scanned
+            // prefix first and tests the overlap only for records of the same file.
+            const u32 seg_lo = c < v.n_chrom ? v.chrom_off[c] : 0u;
+            const i32 max_len = c < v.n_chrom ? v.chrom_maxlen[c] : 0;
+            const i32 key = s > max_len ? s - max_len : 0;
+            const u32 lo = c < v.n_chrom ? lower_bound_i32(v.starts, seg_lo, v.chrom_off[c + 1], key) : 0u;
             igd_walk(v, c, s, e, min_overlap, [&](u32 i) {
                 const u32 f = v.files[i];
                 bool first = true;
-                igd_walk(v, c, s, e, min_overlap, [&](u32 k) {
-                    if (k < i && v.files[k] == f) first = false;
-                });
+                for (u32 k = lo; k < i; ++k) {
+                    if (v.files[k] == f) {
+                        const i32 ks = v.starts[k], ke = v.ends[k];
+                        const i32 ov = (ke < e ? ke : e) - (ks > s ? ks : s);
+                        if (ov >= min_overlap) {
+                            first = false;
+                            break;
+                        }
+                    }
+                }
                 if (first) {
                     if (USE_LDS)
                         atomicAdd(&bins[f], 1u);
