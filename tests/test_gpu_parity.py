@@ -467,3 +467,34 @@ def test_device_sort_builds_the_same_index(ga, monkeypatch, n, n_chrom, span):
     gq, gs = gi.find_overlaps_regionset(qc[q2], qs[q2], qe[q2] + 1)
     oq, os_ = oi.find_overlaps_regionset(qc[q2], qs[q2], qe[q2] + 1)
     assert gq.tolist() == oq.tolist() and gs.tolist() == os_.tolist()
+
+
+@pytest.mark.parametrize("top_max", ["64", "300", "4096"])
+def test_lds_path_with_sampled_top_level(ga, monkeypatch, top_max):
+    """Universes too large for the LDS top level use a sampled top (top_shift > 0) plus a short search of
+    the block keys in L2; force that path with a tiny LDS budget and compare with the oracle."""
+    from gtars_amd import synth
+
+    monkeypatch.setenv("GTARS_TOP_MAX", top_max)
+    rng = np.random.default_rng(int(top_max))
+    for overlapping in (False, True):
+        u = synth.make_universe(60_000, seed=11, overlapping=overlapping)
+        q = synth.make_queries(u, 150_001, seed=12)
+        g, o = _pair(ga, u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+        off_g, ids_g = g.tokenize(q["chrom"], q["start"], q["end"])
+        off_o, ids_o = o.tokenize(q["chrom"], q["start"], q["end"])
+        assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+    # dense, heavily overlapping index with long intervals: multi-block tails, many hits per query
+    n = 30_000
+    c = rng.integers(0, 3, n)
+    s = rng.integers(0, 200_000, n)
+    e = s + rng.integers(1, 5_000, n)
+    g, o = _pair(ga, c, s, e, n_chrom=3)
+    qc = rng.integers(0, 4, 20_000)
+    qc = np.where(qc >= 3, UNK, qc)
+    qs = rng.integers(0, 210_000, 20_000)
+    qe = qs + rng.integers(0, 3_000, 20_000)
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+    assert len(ids_o) > 50 * len(qc)  # really many hits per query
