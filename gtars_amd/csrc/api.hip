@@ -235,6 +235,9 @@ struct gtars_igd {
     std::vector<i32> h_starts, h_ends;
     DevBuf<i32> starts, ends, values, chrom_maxlen;
     DevBuf<u32> files, chrom_off;
+    // tiles of IGD_TILE_RECORDS consecutive records of one chromosome (batch sweep, igd_sweep.hip)
+    DevBuf<u32> tile_first, tile_cnt, tile_chrom;
+    u32 n_tiles = 0;
     IgdView view() const {
         IgdView v;
         v.starts = starts.p;
@@ -927,7 +930,18 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
         hml[chrom[i]] = std::max(hml[chrom[i]], end[i] - start[i]);
     }
     for (u32 c = 0; c < n_chrom; ++c) hoff[c + 1] += hoff[c];
+    std::vector<u32> tf, tc, tch;
+    for (u32 c = 0; c < n_chrom; ++c)
+        for (u32 p = hoff[c]; p < hoff[c + 1]; p += IGD_TILE_RECORDS) {
+            tf.push_back(p);
+            tc.push_back(std::min<u32>(IGD_TILE_RECORDS, hoff[c + 1] - p));
+            tch.push_back(c);
+        }
+    g->n_tiles = (u32)tf.size();
     st = g->starts.upload(g->h_starts);
+    if (!st) st = g->tile_first.upload(tf);
+    if (!st) st = g->tile_cnt.upload(tc);
+    if (!st) st = g->tile_chrom.upload(tch);
     if (!st) st = g->ends.upload(g->h_ends);
     if (!st) st = g->values.upload(hv);
     if (!st) st = g->files.upload(hf);
@@ -949,6 +963,9 @@ void gtars_igd_free(gtars_igd_t *g) {
     g->files.release();
     g->chrom_off.release();
     g->chrom_maxlen.release();
+    g->tile_first.release();
+    g->tile_cnt.release();
+    g->tile_chrom.release();
     delete g;
 }
 
@@ -988,6 +1005,14 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
     if (st) return st;
     if (min_overlap < 1) return fail(GTARS_ERR_INVALID_ARG, "IGD queries are defined for min_overlap >= 1");
     if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
+    if (igd_sweep_supported(g->view(), nq)) {
+        // large batch: sort the queries once, stream the database once (igd_sweep.hip)
+        Workspace &ws = tls_workspace(2);
+        st = ws.reserve(igd_sweep_ws_bytes(nq, g->n_tiles, g->n_chrom));
+        if (st) return st;
+        return launch_igd_sweep(g->view(), g->tile_first.p, g->tile_cnt.p, g->tile_chrom.p, g->n_tiles, d_qc, d_qs,
+                                d_qe, nq, min_overlap, binary, d_hits, ws.ptr, ws.bytes, (hipStream_t)stream);
+    }
     return launch_igd_count(g->view(), d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
 }
 

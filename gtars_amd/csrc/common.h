@@ -172,6 +172,16 @@ gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, 
 gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
                               hipStream_t st);
 
+size_t device_sort_perm_ws_bytes(u32 n);
+gtars_status device_sort_perm_ws(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
+                                 void *scratch, size_t scratch_bytes, hipStream_t st);
+// IGD batch sweep (igd_sweep.hip)
+bool igd_sweep_supported(const IgdView &v, u64 nq);
+size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom);
+gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
+                              u32 n_tiles, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, i32 min_overlap,
+                              int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st);
+constexpr u32 IGD_TILE_RECORDS = 2048;
 gtars_status device_gather_u32(const u32 *src, const u32 *idx, u32 n, u32 *dst, hipStream_t st);
 
 // ---- profiling hooks --------------------------------------------------------

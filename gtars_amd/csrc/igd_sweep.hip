@@ -1,0 +1,247 @@
+// igd_sweep.hip -- K5, batch form: Igd::count_set_overlaps / count_region_hits
+// (gtars-igd/src/igd.rs:544-590) for a large query batch as ONE streaming pass over the database.
+//
+// The per-query kernel in kernels.hip binary-searches a 5e7-record array for every query (random HBM
+// accesses).  Here the roles are swapped: the QUERIES are sorted once by (chromosome, start) with the
+// device radix sort (K1), the database -- already sorted by (chromosome, start) -- is cut into tiles of
+// IGD_TILE records, and each workgroup stages one tile in LDS (coalesced 16-byte loads: the database is
+// read from HBM once, plus a 256-record halo) and serves the queries it OWNS: a query belongs to the
+// tile that holds its lower_bound position (first record with start >= q.start - max_len), which is a
+// contiguous range [ql, qh) of the sorted queries, found per tile by two binary searches in a tiny
+// pre-pass (one thread per tile).  The owner does an LDS binary search and scans forward while
+// start < q.end -- through the halo and, for the rare long scan, on into global memory -- applying
+// exactly the reference's hit rule
+//     min(r.end, qe) - max(r.start, qs) >= min_overlap                           (igd.rs:792-795)
+// One thread sees all hits of a query, in database order, so pairwise counts see each (query, record)
+// pair once and binary (LOLA support) counting credits a (query, file) pair at its first hit.
+// Per-file counts go to u32 LDS bins, flushed once per workgroup with u64 atomics.
+//
+// Bound: HBM.  Algorithmic bytes 12*Nq + 16*Ndb + 8*F; no MFMA (integer compare/scan).
+#include <algorithm>
+
+#include "common.h"
+#include "scan.cuh"
+
+namespace gtars {
+
+constexpr int IGD_TILE = (int)IGD_TILE_RECORDS;
+constexpr int SW_TPB = 512;
+
+constexpr int IGD_HALO = 256;
+constexpr int IGD_SEEN = 32;   // per-thread list of credited files (binary counting)  // records after the tile kept in LDS too (a query's scan may run past its tile)
+
+// ---- query preparation: validity rules of Igd::count_overlaps (igd.rs:514-517) ------------------
+__global__ void k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
+                                   u32 nq, u32 n_chrom, u32 *__restrict__ kc, u32 *__restrict__ ks,
+                                   u32 *__restrict__ ke) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    i32 s = (i32)qs[i], e = (i32)qe[i];  // `as i32` (igd.rs:549-550)
+    u32 c = qc[i];
+    if (s >= e || e <= 0 || c >= n_chrom) {
+        c = n_chrom;  // sorts behind every real chromosome; never served
+        s = 0;
+        e = 0;
+    } else if (s < 0) {
+        s = 0;  // clamp (igd.rs:517)
+    }
+    kc[i] = c;
+    ks[i] = (u32)s;
+    ke[i] = (u32)e;
+}
+
+// first index in [lo, hi) with a[i] >= key
+__device__ __forceinline__ u32 lb_u32(const u32 *__restrict__ a, u32 lo, u32 hi, u64 key) {
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if ((u64)a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// per-chromosome segments of the sorted queries
+__global__ void k_igd_chrom_segments(const u32 *__restrict__ sorted_chrom, u32 nq, u32 n_chrom, u32 *__restrict__ cq_off) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= n_chrom) cq_off[c] = lb_u32(sorted_chrom, 0, nq, c);
+}
+
+// Every query is OWNED by exactly one tile: the tile that holds its lower_bound position
+// p = first record of the chromosome with start >= key, key = max(q.start - max_len, 0).
+// key is monotone in q.start, so the owned queries of a tile are a contiguous range [ql, qh) of the
+// sorted queries:   last_start(previous tile) < key <= last_start(this tile).
+__global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
+                                  const u32 *__restrict__ tile_chrom, u32 n_tiles, const u32 *__restrict__ sorted_qs,
+                                  const u32 *__restrict__ cq_off, u32 *__restrict__ ql, u32 *__restrict__ qh) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const u32 c = tile_chrom[t], p0 = tile_first[t], cnt = tile_cnt[t];
+    const u64 max_len = (u64)v.chrom_maxlen[c];
+    const u32 lo = cq_off[c], hi = cq_off[c + 1];
+    const bool first_of_chrom = p0 == v.chrom_off[c];
+    // key > prev_last  <=>  q.start >= prev_last + max_len + 1   (keys clamped to 0 belong to the first tile)
+    ql[t] = first_of_chrom ? lo : lb_u32(sorted_qs, lo, hi, (u64)v.starts[p0 - 1] + max_len + 1);
+    qh[t] = lb_u32(sorted_qs, lo, hi, (u64)v.starts[p0 + cnt - 1] + max_len + 1);
+}
+
+// ---- the sweep ---------------------------------------------------------------------------------
+template <bool BINARY>
+__global__ void __launch_bounds__(SW_TPB)
+k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
+            const u32 *__restrict__ tile_chrom, u32 n_tiles, const u32 *__restrict__ sqs, const u32 *__restrict__ sqe,
+            const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap,
+            unsigned long long *__restrict__ hits) {
+    extern __shared__ __attribute__((aligned(16))) u32 sm[];
+    constexpr int CAP = IGD_TILE + IGD_HALO;
+    i32 *t_s = reinterpret_cast<i32 *>(sm);
+    i32 *t_e = t_s + CAP;
+    u32 *t_f = reinterpret_cast<u32 *>(t_e + CAP);
+    u32 *bins = t_f + CAP;  // [n_files]
+    for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
+
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();  // previous tile fully served (and bins zeroed) before LDS is overwritten
+        const u32 p0 = tile_first[tile], cnt = tile_cnt[tile], c = tile_chrom[tile];
+        const u32 seg_hi = v.chrom_off[c + 1];
+        const u32 n_lds = min((u32)CAP, seg_hi - p0);  // tile + halo, never past the chromosome
+        for (u32 i = threadIdx.x; i < n_lds; i += SW_TPB) {
+            t_s[i] = v.starts[p0 + i];
+            t_e[i] = v.ends[p0 + i];
+            t_f[i] = v.files[p0 + i];
+        }
+        __syncthreads();
+        const i32 max_len = v.chrom_maxlen[c];
+        const u32 n_seg = seg_hi - p0;  // records from the tile start to the end of the chromosome
+        // record i (relative to p0): LDS if staged, global otherwise (rare: scans longer than the halo)
+        auto r_start = [&](u32 i) -> i32 { return i < n_lds ? t_s[i] : v.starts[p0 + i]; };
+        auto r_end = [&](u32 i) -> i32 { return i < n_lds ? t_e[i] : v.ends[p0 + i]; };
+        auto r_file = [&](u32 i) -> u32 { return i < n_lds ? t_f[i] : v.files[p0 + i]; };
+        const u32 q_lo = ql[tile], q_hi = qh[tile];
+        for (u32 qi = q_lo + threadIdx.x; qi < q_hi; qi += SW_TPB) {
+            const i32 s = (i32)sqs[qi], e = (i32)sqe[qi];
+            const i32 key = s > max_len ? s - max_len : 0;
+            // lower_bound of key: inside the tile by ownership
+            u32 lo = 0, hi = cnt;
+            while (lo < hi) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (t_s[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            // binary counting: the files already credited to this query, as packed u16 pairs in
+            // registers (no memory latency in the membership test); 0xFFFF = empty (n_files <= 16384)
+            u32 n_seen = 0;
+            u32 sl[IGD_SEEN / 2];
+#pragma unroll
+            for (int k = 0; k < IGD_SEEN / 2; ++k) sl[k] = 0xFFFFFFFFu;
+            for (u32 r = lo; r < n_seg; ++r) {
+                const i32 rs = r_start(r);
+                if (rs >= e) break;
+                const i32 re = r_end(r);
+                const i32 ov = (re < e ? re : e) - (rs > s ? rs : s);
+                if (ov < min_overlap) continue;
+                const u32 f = r_file(r);
+                if (BINARY) {
+                    // credit (query, file) only at its first hit in database order (igd.rs:563-590):
+                    // compare with the files already credited to this query
+                    bool first = true;
+#pragma unroll
+                    for (int k = 0; k < IGD_SEEN / 2; ++k)
+                        first = first && ((sl[k] & 0xFFFFu) != f) && ((sl[k] >> 16) != f);
+                    if (first && n_seen >= (u32)IGD_SEEN) {
+                        // list overflow (a query with very many distinct files): exact look-back over the
+                        // earlier records
+                        for (u32 k = lo; k < r; ++k) {
+                            if (r_file(k) == f) {
+                                const i32 ks = r_start(k), ke = r_end(k);
+                                if ((ke < e ? ke : e) - (ks > s ? ks : s) >= min_overlap) {
+                                    first = false;
+                                    break;
+                                }
+                            }
+                        }
+                    }
+                    if (!first) continue;
+#pragma unroll
+                    for (int k = 0; k < IGD_SEEN / 2; ++k) {
+                        if ((u32)k == (n_seen >> 1)) sl[k] = (n_seen & 1u) ? ((sl[k] & 0xFFFFu) | (f << 16)) : ((sl[k] & 0xFFFF0000u) | f);
+                    }
+                    ++n_seen;
+                }
+                atomicAdd(&bins[f], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) {
+        const u32 b = bins[i];
+        if (b) atomicAdd(&hits[i], (unsigned long long)b);
+    }
+}
+
+// ---- launcher ------------------------------------------------------------------------------------
+
+bool igd_sweep_supported(const IgdView &v, u64 nq) {
+    if (getenv("GTARS_NO_IGD_SWEEP")) return false;
+    const u64 min_q = getenv("GTARS_IGD_SWEEP_MIN") ? (u64)atoll(getenv("GTARS_IGD_SWEEP_MIN")) : (1u << 16);
+    // u32 LDS bins: a workgroup adds at most (its queries x hits) -- keep the batch below 2^31 queries
+    return v.n > 0 && v.n_files > 0 && v.n_files <= 16384 && nq >= min_q && nq < (1ull << 31);
+}
+
+size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom) {
+    // kc ks ke | sorted qs qe chrom | perm | ql qh | cq_off | max_qlen | sort scratch
+    return (size_t)nq * 4 * 7 + (size_t)n_tiles * 8 + ((size_t)n_chrom + 2) * 4 + 256 + device_sort_perm_ws_bytes((u32)nq);
+}
+
+gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
+                              u32 n_tiles, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq64, i32 min_overlap,
+                              int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st) {
+    const u32 nq = (u32)nq64;
+    if (ws_bytes < igd_sweep_ws_bytes(nq, n_tiles, v.n_chrom)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
+    GT_HIP(hipMemsetAsync(hits, 0, sizeof(u64) * v.n_files, st));
+    u32 *kc = (u32 *)ws, *ks = kc + nq, *ke = ks + nq;
+    u32 *sc = ke + nq, *ss = sc + nq, *se = ss + nq, *perm = se + nq;
+    u32 *ql = perm + nq, *qh = ql + n_tiles, *cq_off = qh + n_tiles;
+    void *sort_ws = (void *)(((uintptr_t)(cq_off + v.n_chrom + 2) + 63) & ~(uintptr_t)63);
+    const size_t sort_ws_bytes = device_sort_perm_ws_bytes(nq);
+    const unsigned g = (nq + 255) / 256;
+    {
+        ProfScope p("k_igd_prep_queries", st);
+        hipLaunchKernelGGL(k_igd_prep_queries, dim3(g), dim3(256), 0, st, qc, qs, qe, nq, v.n_chrom, kc, ks, ke);
+    }
+    // K1: order the queries by (chromosome, start)
+    gtars_status s1 = device_sort_perm_ws(kc, ks, nullptr, nq, v.n_chrom + 1, perm, sort_ws, sort_ws_bytes, st);
+    if (s1) return s1;
+    if ((s1 = device_gather_u32(kc, perm, nq, sc, st))) return s1;
+    if ((s1 = device_gather_u32(ks, perm, nq, ss, st))) return s1;
+    if ((s1 = device_gather_u32(ke, perm, nq, se, st))) return s1;
+    {
+        ProfScope p("k_igd_tile_ranges", st);
+        hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, sc, nq, v.n_chrom, cq_off);
+        hipLaunchKernelGGL(k_igd_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tile_first, tile_cnt,
+                           tile_chrom, n_tiles, ss, cq_off, ql, qh);
+    }
+    const size_t lds = ((size_t)(IGD_TILE + IGD_HALO) * 3 + v.n_files) * 4;
+    int dev = 0, cus = 256;
+    GT_HIP(hipGetDevice(&dev));
+    GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    auto kern = binary ? k_igd_sweep<true> : k_igd_sweep<false>;
+    if (lds > 48 * 1024)
+        GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1;
+    GT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SW_TPB, lds));
+    if (per_cu < 1) return fail(GTARS_ERR_INTERNAL, "k_igd_sweep does not fit on a CU");
+    const unsigned grid = (unsigned)std::min<u64>((u64)cus * per_cu, n_tiles);
+    {
+        ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tile_first, tile_cnt, tile_chrom, n_tiles, ss, se,
+                           ql, qh, min_overlap, (unsigned long long *)hits);
+    }
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
+}  // namespace gtars

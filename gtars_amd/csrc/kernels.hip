@@ -549,10 +549,16 @@ k_igd_count(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             const i32 max_len = c < v.n_chrom ? v.chrom_maxlen[c] : 0;
             const i32 key = s > max_len ? s - max_len : 0;
             const u32 lo = c < v.n_chrom ? lower_bound_i32(v.starts, seg_lo, v.chrom_off[c + 1], key) : 0u;
+            unsigned long long seen0 = 0, seen1 = 0;  // 128-bit filter of files already credited
             igd_walk(v, c, s, e, min_overlap, [&](u32 i) {
                 const u32 f = v.files[i];
+                const u32 hb = (f * 2654435761u) >> 25;
+                const unsigned long long bit = 1ull << (hb & 63u);
+                unsigned long long &word = (hb & 64u) ? seen1 : seen0;
+                const bool maybe_dup = (word & bit) != 0;
+                word |= bit;
                 bool first = true;
-                for (u32 k = lo; k < i; ++k) {
+                for (u32 k = lo; maybe_dup && k < i; ++k) {
                     if (v.files[k] == f) {
                         const i32 ks = v.starts[k], ke = v.ends[k];
                         const i32 ov = (ke < e ? ke : e) - (ks > s ? ks : s);

@@ -151,12 +151,15 @@ gtars_status radix_sort_pairs(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u32 n, int beg
 // Order of the reference for one index: perm such that
 //   (chrom, k1, k2, input order) ascending, k2 optional (Bits: k1 = start, k2 = end; IGD: k1 = start).
 // d_perm (n u32) receives the permutation.  d_chrom/d_k1/d_k2 are the unsorted device columns.
-gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
-                              hipStream_t st) {
+size_t device_sort_perm_ws_bytes(u32 n) { return (size_t)n * 4 * 3 + radix_sort_ws_bytes(n) + 64; }
+
+// asynchronous form: caller provides the scratch buffer, nothing is synchronised
+gtars_status device_sort_perm_ws(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
+                                 void *scratch, size_t scratch_bytes, hipStream_t st) {
     if (n == 0) return GTARS_OK;
-    u32 *buf = nullptr;
+    if (scratch_bytes < device_sort_perm_ws_bytes(n)) return fail(GTARS_ERR_INTERNAL, "sort scratch too small");
+    u32 *buf = (u32 *)scratch;
     const size_t wsb = radix_sort_ws_bytes(n);
-    GT_HIP(hipMalloc((void **)&buf, (size_t)n * 4 * 3 + wsb + 64));
     u32 *kA = buf, *kB = buf + n, *vB = buf + 2 * (size_t)n;
     void *ws = (void *)(buf + 3 * (size_t)n);
     u32 *vA = d_perm;
@@ -183,9 +186,17 @@ gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_
         bits = (bits + 7) & ~7;
         s = pass(d_chrom, bits);
     }
-    if (!s && vc != d_perm) {
-        GT_HIP(hipMemcpyAsync(d_perm, vc, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-    }
+    if (!s && vc != d_perm) GT_HIP(hipMemcpyAsync(d_perm, vc, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    return s;
+}
+
+gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
+                              hipStream_t st) {
+    if (n == 0) return GTARS_OK;
+    void *buf = nullptr;
+    const size_t bytes = device_sort_perm_ws_bytes(n);
+    GT_HIP(hipMalloc(&buf, bytes));
+    gtars_status s = device_sort_perm_ws(d_chrom, d_k1, d_k2, n, n_chrom, d_perm, buf, bytes, st);
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(buf);
     if (s) return s;

@@ -498,3 +498,35 @@ def test_lds_path_with_sampled_top_level(ga, monkeypatch, top_max):
     off_o, ids_o = o.tokenize(qc, qs, qe)
     assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
     assert len(ids_o) > 50 * len(qc)  # really many hits per query
+
+
+@pytest.mark.parametrize("seed,n,nq,F,span,wmax", [
+    (1, 4000, 3000, 5, 200_000, 40_000),       # records much longer than a 2048-record tile spans
+    (2, 60_000, 50_000, 300, 2_000_000, 900),  # many tiles per chromosome
+    (3, 9000, 4000, 9000, 100_000, 500),       # more files than LDS-friendly, still < 16384 bins
+    (4, 30_000, 20_000, 40, 50_000, 3_000),    # dense: most queries straddle tile boundaries
+])
+def test_igd_sweep_matches_oracle(ga, monkeypatch, seed, n, nq, F, span, wmax):
+    """The batch sweep (sorted queries x database tiles in LDS) against the oracle's literal tile walk,
+    pairwise and binary, including invalid / clamped / unknown-chromosome queries."""
+    monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
+    rng = np.random.default_rng(100 + seed)
+    n_chrom = 3
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, wmax, n)
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=n_chrom, n_files=F)
+    qc = rng.integers(0, n_chrom + 1, nq)
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, span, nq).astype(np.int64)
+    qe = qs + rng.integers(0, wmax, nq)           # some zero-length (invalid) queries
+    qs[:20] = 0xFFFFFFF0                           # negative as i32: clamped to 0
+    qe[:20] = rng.integers(1, span, 20)
+    qe[20:40] = 0                                  # end <= 0: rejected
+    for mo in (1, 7):
+        assert g.count_set_overlaps(qc, qs, qe, mo).tolist() == o.count_set_overlaps(qc, qs, qe, mo, n_files=F).tolist()
+        assert g.count_region_hits(qc, qs, qe, mo).tolist() == o.count_region_hits(qc, qs, qe, mo, n_files=F).tolist()
+    # and the per-query kernel gives the same vectors
+    monkeypatch.setenv("GTARS_NO_IGD_SWEEP", "1")
+    assert g.count_region_hits(qc, qs, qe, 1).tolist() == o.count_region_hits(qc, qs, qe, 1, n_files=F).tolist()

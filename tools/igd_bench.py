@@ -29,6 +29,13 @@ def main():
         byts = 12 * nq + 16 * ndb + 8 * F
         out["binary" if binary else "pairwise"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt), "hbm_frac": round(byts / dt / 8e12, 5),
                                                    "total_hits": int(hits.sum())}
+    from gtars_amd import _lib
+    _lib.lib.gtars_prof_reset(); _lib.lib.gtars_prof_enable(1)
+    for binary in (False, True):
+        g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, hits.data_ptr(), 1, binary, st)
+    torch.cuda.synchronize()
+    out["kernels_ms"] = {k: round(v["total_ms"], 3) for k, v in _lib.prof_read().items()}
+    _lib.lib.gtars_prof_enable(0)
     if os.environ.get("CHECK", "1") == "1":
         # parity on a sample of the queries against the oracle's literal tile walk (full DB)
         import oracle
