@@ -66,9 +66,12 @@ Workspace::~Workspace() {
     // exit is harmless, freeing after runtime shutdown is not.
 }
 
-Workspace &tls_workspace(int slot) {
-    static thread_local Workspace ws[4];
-    return ws[slot & 3];
+// One grow-only workspace per (host thread, stream, purpose): calls issued by one thread on DIFFERENT
+// streams may overlap on the device, so they must not share scratch memory; calls on the same stream are
+// ordered by the stream.
+Workspace &tls_workspace(int slot, hipStream_t stream) {
+    static thread_local std::map<std::pair<hipStream_t, int>, Workspace> ws;
+    return ws[std::make_pair(stream, slot)];
 }
 
 // ---------------------------------------------------------------- profiling
@@ -598,7 +601,7 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
     if (st) return st;
     if (!d_offsets) return fail(GTARS_ERR_INVALID_ARG, "d_offsets is NULL");
     hipStream_t s = (hipStream_t)stream;
-    Workspace &ws = tls_workspace(0);
+    Workspace &ws = tls_workspace(0, s);
     const size_t wsb = fused_ws_bytes(ix, nq);
     st = ws.reserve(wsb);
     if (st) return st;
@@ -1007,7 +1010,7 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
     if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
     if (igd_sweep_supported(g->view(), nq)) {
         // large batch: sort the queries once, stream the database once (igd_sweep.hip)
-        Workspace &ws = tls_workspace(2);
+        Workspace &ws = tls_workspace(2, (hipStream_t)stream);
         st = ws.reserve(igd_sweep_ws_bytes(nq, g->n_tiles, g->n_chrom));
         if (st) return st;
         return launch_igd_sweep(g->view(), g->tile_first.p, g->tile_cnt.p, g->tile_chrom.p, g->n_tiles, d_qc, d_qs,

@@ -110,7 +110,7 @@ struct Workspace {
     gtars_status reserve(size_t need);
     ~Workspace();
 };
-Workspace &tls_workspace(int slot);
+Workspace &tls_workspace(int slot, hipStream_t stream);
 
 // ---- launchers (kernels.hip) ------------------------------------------------
 struct EnumOut {

@@ -21,7 +21,9 @@
  *    synchronise where the signature returns a host value; the plain entry
  *    points take HOST pointers and do the transfers themselves;
  *  - handles are immutable after build and may be queried concurrently from
- *    several host threads (each call brings its own workspace);
+ *    several host threads and on several streams: scratch memory is kept per
+ *    (host thread, stream) and grows on demand -- the first call on a stream
+ *    may allocate, so issue it once before capturing a HIP graph;
  *  - memory returned through `T** out` is freed with gtars_free().
  *
  * There is no CPU fallback: without a HIP device every compute entry point
