@@ -398,3 +398,27 @@ def test_igd_save_and_reload(tmp_path, golden_dir):
     regs = oracle.read_region_set(os.path.join(golden_dir, "igd_query_files", "query1.bed"))
     assert d2.count_set_overlaps(regs).tolist() == o.count_set_overlaps(regs).tolist()
     assert [f.filename for f in d2.file_info] == [f[0] for f in o.file_info]
+
+
+def test_region_scoring_matrix_kat(golden_dir):
+    """gtars-scoring/src/fragment_scoring.rs:178-206: ATAC-mode matrix [[2,2,1,3],[4,1,3,1]] (2 files x 4 peaks)."""
+    from gtars_amd.scoring import barcode_scoring_from_fragments, region_scoring_from_fragments
+
+    cons = os.path.join(golden_dir, "consensus", "consensus1.bed")
+    mat = region_scoring_from_fragments(os.path.join(golden_dir, "fragments", "region_scoring", "*.bed.gz"), cons, "atac")
+    assert mat.shape == (2, 4) and mat.tolist() == [[2, 2, 1, 3], [4, 1, 3, 1]]
+    chip = region_scoring_from_fragments(os.path.join(golden_dir, "fragments", "region_scoring", "*.bed.gz"), cons, "chip")
+    # ChIP mode == per-fragment overlaps: same as the tokenizer's view of the file
+    t = oracle.OracleTokenizer(cons)
+    for row, name in enumerate(["fragments1.bed.gz", "fragments2.bed.gz"]):
+        toks = t.tokenize_fragment_file(os.path.join(golden_dir, "fragments", "region_scoring", name))
+        exp = np.zeros(4, dtype=np.int64)
+        for ids in toks.values():
+            for i in ids:
+                if i < 4:
+                    exp[i] += 1
+        assert chip[row].tolist() == exp.tolist()
+    bc = barcode_scoring_from_fragments(os.path.join(golden_dir, "fragments", "region_scoring", "fragments1.bed.gz"), cons)
+    assert sum(sum(d.values()) for d in bc.values()) == int(chip[0].sum())
+    with pytest.raises(ValueError):
+        region_scoring_from_fragments([], cons, "nope")
