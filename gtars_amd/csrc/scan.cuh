@@ -87,10 +87,14 @@ __device__ __forceinline__ void st_state(u64 *p, u64 v) {
 
 // Executed by wave 0 (all 64 lanes); returns the tile's exclusive global prefix.
 // Every round reads LB_W * 64 predecessor granules with independent loads (one
-// memory round trip), because with ~10^3 tiles in flight the nearest tile that
-// already knows its inclusive prefix is typically a few hundred tiles back and
-// each dependent round trip costs microseconds under load.
-constexpr int LB_W = 8;
+// memory round trip).  Measured on MI355X (tools/ablate.sh, EXTRA=-DGTARS_LB_W=n):
+// with the cross-tile software pipeline of k_tok_lds the nearest inclusive prefix is
+// usually inside the first window, and wider rounds only add loads of cold lines:
+// LB_W = 1 / 2 / 4 / 8 / 16 -> 952 / 964 / 1003 / 1076 / 1194 us for 64M queries.
+#ifndef GTARS_LB_W
+#define GTARS_LB_W 1
+#endif
+constexpr int LB_W = GTARS_LB_W;
 
 // publish a tile's aggregate (tile 0: its inclusive prefix) -- one lane
 __device__ __forceinline__ void publish_aggregate(u64 *state, u32 tile, u64 agg, u32 epoch = 0) {

@@ -33,7 +33,6 @@
 
 namespace gtars {
 
-constexpr int TOK_QPT = 4;
 
 // Timing experiments only (tools/ablate.sh builds a separate library with
 // -DGTARS_ABLATE=<bits>; results are then WRONG by construction):
@@ -112,6 +111,7 @@ __device__ __forceinline__ u32 walk_tail(const AccelView &a, u32 b0, u32 be, u32
     return n;
 }
 
+template <int TOK_QPT>
 struct TileState {
     u32 st[TOK_QPT];  // b0 | mask10 << 22
     u32 v0[TOK_QPT];  // ids of the first two hits: loaded during the count phase,
@@ -122,8 +122,10 @@ struct TileState {
     u32 tile;
 };
 
-template <int TPB, bool FILTER>
-__global__ void __launch_bounds__(TPB)
+// TOK_QPT = queries per thread: 4, or 2 with a register budget that admits 6 waves per SIMD
+// (three 512-thread workgroups per CU, the most the per-workgroup LDS copy of `top` allows).
+template <int TPB, int TOK_QPT, bool FILTER>
+__global__ void __launch_bounds__(TPB, (TOK_QPT == 2 ? 6 : 4))
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
           u32 search_steps, u32 epoch, u32 ticket_base) {
@@ -170,7 +172,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     // its outputs written -- only after the NEXT tile has been counted.  By then
     // every predecessor has had a whole tile time to publish, so the look-back
     // rarely waits and its latency is off the critical path.
-    TileState cur, prev;
+    TileState<TOK_QPT> cur, prev;
     bool have_prev = false;
 #if GTARS_ABLATE & 128
     long long t_ticket = 0, t_count = 0, t_scan = 0, t_resolve = 0, t_write = 0, t_mark;
@@ -205,12 +207,21 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             const u64 q0 = (u64)tile * TILE + (u64)threadIdx.x * TOK_QPT;
             u32 c[TOK_QPT], s[TOK_QPT], e[TOK_QPT];
             if (vec_ok && q0 + TOK_QPT <= nq) {
-                const uint4 c4 = *reinterpret_cast<const uint4 *>(qc + q0);
-                const uint4 s4 = *reinterpret_cast<const uint4 *>(qs + q0);
-                const uint4 e4 = *reinterpret_cast<const uint4 *>(qe + q0);
-                c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
-                s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
-                e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
+                if constexpr (TOK_QPT == 4) {
+                    const uint4 c4 = *reinterpret_cast<const uint4 *>(qc + q0);
+                    const uint4 s4 = *reinterpret_cast<const uint4 *>(qs + q0);
+                    const uint4 e4 = *reinterpret_cast<const uint4 *>(qe + q0);
+                    c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+                    s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
+                    e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
+                } else {
+                    const uint2 c2 = *reinterpret_cast<const uint2 *>(qc + q0);
+                    const uint2 s2 = *reinterpret_cast<const uint2 *>(qs + q0);
+                    const uint2 e2 = *reinterpret_cast<const uint2 *>(qe + q0);
+                    c[0] = c2.x; c[1] = c2.y;
+                    s[0] = s2.x; s[1] = s2.y;
+                    e[0] = e2.x; e[1] = e2.y;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < TOK_QPT; ++j) {
@@ -385,7 +396,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             } else if (off_vec_ok && q0 + TOK_QPT <= nq) {
                 ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(offsets + q0);
                 dst[0] = make_ulonglong2(o4[0], o4[1]);
-                dst[1] = make_ulonglong2(o4[2], o4[3]);
+                if constexpr (TOK_QPT == 4) dst[1] = make_ulonglong2(o4[2], o4[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < TOK_QPT; ++j)
@@ -427,24 +438,27 @@ bool tokenize_lds_supported(const AccelView &a) {
     return a.n_blocks > 0 && a.n_blocks <= ((1u << 22) - 1u) && a.n_top > 0 && tok_lds_bytes(a) <= 120 * 1024;
 }
 
-// launch geometry: threads per workgroup (a tile is TPB * 4 queries)
-static void choose_geometry(u64 nq, int &tpb) {
+// launch geometry: threads per workgroup and queries per thread (a tile is TPB * QPT queries)
+static void choose_geometry(u64 nq, int &tpb, int &qpt) {
     // small batches: one big workgroup per CU (one LDS fill, one tile each); large: two 512-thread ones
     tpb = nq >= (1ull << 24) ? 512 : 1024;
+    qpt = 4;
     const int f_tpb = env_int("GTARS_TOK_TPB", 0);
     if (f_tpb == 256 || f_tpb == 512 || f_tpb == 1024) tpb = f_tpb;
+    const int f_q = env_int("GTARS_TOK_QPT", 0);
+    if (f_q == 2 || f_q == 4) qpt = f_q;
 }
 
 size_t tokenize_lds_ws_bytes(u64 nq) {
-    // sized for the smallest tile (256 threads x 4 queries)
-    return scan_ws_bytes_for_tiles((nq + 256 * TOK_QPT - 1) / (256 * TOK_QPT));
+    // sized for the smallest tile (256 threads x 2 queries)
+    return scan_ws_bytes_for_tiles((nq + 256 * 2 - 1) / (256 * 2));
 }
 
-template <int TPB, bool FILTER>
+template <int TPB, int TOK_QPT, bool FILTER>
 static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, hipStream_t st) {
     const size_t lds = tok_lds_bytes(a);
-    auto kern = k_tok_lds<TPB, FILTER>;
+    auto kern = k_tok_lds<TPB, TOK_QPT, FILTER>;
     // occupancy / attribute queries cost tens of microseconds of host time: do them once per
     // (kernel instantiation, LDS size, device) and cache the result
     struct Cfg {
@@ -507,9 +521,9 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
         GT_HIP(hipMemsetAsync(&((ScanHead *)scan_ws)->total, 0, sizeof(u64), st));
         return GTARS_OK;
     }
-    int tpb;
-    choose_geometry(nq, tpb);
-    const u64 tile_q = (u64)tpb * TOK_QPT;
+    int tpb, qpt;
+    choose_geometry(nq, tpb, qpt);
+    const u64 tile_q = (u64)tpb * qpt;
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     if (tiles > 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "query batch too large for one launch");
     const size_t need = scan_ws_bytes_for_tiles(tiles);
@@ -527,13 +541,16 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     const i32 min_bp = has_min ? min_overlap : 0;
     ScanWs *ws = (ScanWs *)scan_ws;
     ProfScope p("k_tok_lds", st);
-#define GT_TOK_CASE(T)                                                                        \
-    if (tpb == T)                                                                             \
-        return filter ? launch_tok_t<T, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st)         \
-                      : launch_tok_t<T, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st);
-    GT_TOK_CASE(256)
-    GT_TOK_CASE(512)
-    GT_TOK_CASE(1024)
+#define GT_TOK_CASE(T, Q)                                                                     \
+    if (tpb == T && qpt == Q)                                                                 \
+        return filter ? launch_tok_t<T, Q, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st)      \
+                      : launch_tok_t<T, Q, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st);
+    GT_TOK_CASE(256, 4)
+    GT_TOK_CASE(512, 4)
+    GT_TOK_CASE(1024, 4)
+    GT_TOK_CASE(256, 2)
+    GT_TOK_CASE(512, 2)
+    GT_TOK_CASE(1024, 2)
 #undef GT_TOK_CASE
     return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");
 }

@@ -36,6 +36,7 @@ def main():
     configs = [c for c in os.environ.get("CONFIGS", "512:0:4").split(",")]
     for cfg in configs:
         tpb, wg, rr = (cfg.split(":") + ["0", "0"])[:3]
+        os.environ["GTARS_TOK_QPT"] = rr
         os.environ["GTARS_TOK_ROUNDS"] = rr
         os.environ["GTARS_TOK_TPB"] = tpb
         os.environ["GTARS_TOK_WG_PER_CU"] = wg
