@@ -129,6 +129,9 @@ __global__ void __launch_bounds__(TPB, (TOK_QPT == 2 ? 6 : 4))
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
           u32 search_steps, u32 epoch, u32 ticket_base) {
+#if GTARS_ABLATE & 128
+    const long long t_entry = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
     __shared__ u32 s_tile;
     __shared__ u64 s_prefix;
@@ -176,6 +179,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     bool have_prev = false;
 #if GTARS_ABLATE & 128
     long long t_ticket = 0, t_count = 0, t_scan = 0, t_resolve = 0, t_write = 0, t_mark;
+    const long long t_fill = clock64() - t_entry;
 #define GT_STAMP(acc) do { const long long _n = clock64(); acc += _n - t_mark; t_mark = _n; } while (0)
     t_mark = clock64();
 #else
@@ -418,6 +422,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         atomicAdd(&dbg[3], (unsigned long long)t_resolve);
         atomicAdd(&dbg[4], (unsigned long long)t_write);
         atomicAdd(&dbg[5], 1ull);
+        atomicAdd(&dbg[6], (unsigned long long)t_fill);
     }
 #endif
 }
@@ -500,11 +505,11 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     {
         static int printed = 0;
         if (printed++ < 2) {
-            unsigned long long h[6];
+            unsigned long long h[7];
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(h, (char *)ws + sizeof(u64) * (2 + tiles), sizeof h, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[phase cycles per WG, %llu WGs, %llu tiles] ticket %.0f count %.0f scan %.0f resolve %.0f write %.0f\n",
-                    h[5], (unsigned long long)tiles, (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5],
+            fprintf(stderr, "[phase cycles per WG, %llu WGs, %llu tiles] fill %.0f ticket %.0f count %.0f scan %.0f resolve %.0f write %.0f\n",
+                    h[5], (unsigned long long)tiles, (double)h[6] / h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5],
                     (double)h[3] / h[5], (double)h[4] / h[5]);
         }
     }

@@ -1,0 +1,66 @@
+"""Fold a rocprofv3 run directory (gpurun_out/prof_*) into the tracked profiles/<round>/ summaries.
+
+usage: python tools/collect_profiles.py gpurun_out/prof_r1b profiles/r01
+Expects <src>/trace (kernel-trace --stats), <src>/fetch and <src>/write (separate --pmc passes of
+bench.py) and optionally <src>/igd (kernel-trace --stats of tools/igd_bench.py).
+"""
+import csv
+import glob
+import json
+import shutil
+import sys
+
+
+def pmc(src, which, kernel):
+    f = glob.glob(f"{src}/{which}/**/*counter_collection.csv", recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
+    with open(f) as fh:
+        head = fh.readline()
+    return f, head, rows
+
+
+def main(src, dst):
+    kernel = "k_tok_lds"
+    ks = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)[0]
+    shutil.copy(ks, f"{dst}/kernel_stats_bench_1M.csv")
+    shutil.copy(f"{src}/bench_trace.json", f"{dst}/bench_under_rocprof_trace.json")
+    out = {}
+    for which, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f, head, rows = pmc(src, which, kernel)
+        with open(f"{dst}/pmc_{name}_{kernel}.csv", "w") as fh:
+            fh.write(head)
+            w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
+            for r in rows:
+                w.writerow(r)
+        v = [float(r["Counter_Value"]) for r in rows]
+        out[name] = {"dispatches": len(v), "mean_kb": sum(v) / len(v), "min_kb": min(v), "max_kb": max(v)}
+    bench = json.loads(open(f"{src}/bench_trace.json").read().strip().splitlines()[-1])
+    fetch = out["FETCH_SIZE"]["mean_kb"] * 1024 * 2
+    write = out["WRITE_SIZE"]["mean_kb"] * 1024
+    doc = {
+        "workload": {"queries_per_step": bench["config"]["queries_per_step_per_gpu"],
+                     "universe_regions": bench["config"]["universe_regions"]},
+        "kernel": kernel,
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 20 "
+                   "--warmup 5 --no-cpu-baseline (two separate passes)",
+        "fetch_size_kb_raw": out["FETCH_SIZE"],
+        "write_size_kb_raw": out["WRITE_SIZE"],
+        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B for wide coalesced reads; "
+                      "MI355X_MICROARCH.md section HBM); WRITE_SIZE as read",
+        "fetch_bytes_per_launch": fetch,
+        "write_bytes_per_launch": write,
+        "traffic_bytes_per_launch": fetch + write,
+        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "note": "fetch = 12.0 MB query stream + ~13 MB index (1.6 MB of block records + 50 KB top level pulled "
+                "into each of the 8 XCD L2s); writes match 8*(Nq+1)+4*H exactly",
+    }
+    json.dump(doc, open(f"{dst}/traffic_tokenize_1M.json", "w"), indent=1)
+    igd = glob.glob(f"{src}/igd/**/*kernel_stats.csv", recursive=True)
+    if igd:
+        shutil.copy(igd[0], f"{dst}/kernel_stats_igd_config3.csv")
+        shutil.copy(f"{src}/igd.json", f"{dst}/igd_config3.json")
+    print(json.dumps(doc["fetch_size_kb_raw"]), doc["traffic_bytes_per_launch"])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
