@@ -199,21 +199,19 @@ struct gtars_index {
     std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
     // blocked acceleration structure (Bits kind), see AccelView in common.h
-    DevBuf<u32> acc_blocks, acc_blk_first, acc_top, acc_chrom_blk_off;
-    u32 acc_n_blocks = 0, acc_n_top = 0, acc_top_shift = 0, acc_max_chrom_top = 0;
+    DevBuf<u32> acc_blocks, acc_blk_first, acc_top, acc_chrom_tab;
+    u32 acc_n_blocks = 0, acc_n_top = 0, acc_top_shift = 0;
     bool has_accel = false;
     AccelView accel() const {
         AccelView a;
         a.blocks = reinterpret_cast<const uint4 *>(acc_blocks.p);
         a.blk_first = acc_blk_first.p;
         a.top = acc_top.p;
-        a.chrom_blk_off = acc_chrom_blk_off.p;
-        a.chrom_maxlen = chrom_aux.p;
+        a.chrom_tab = reinterpret_cast<const uint4 *>(acc_chrom_tab.p);
         a.n_blocks = acc_n_blocks;
         a.n_top = acc_n_top;
         a.top_shift = acc_top_shift;
         a.n_chrom = n_chrom;
-        a.max_chrom_top = acc_max_chrom_top;
         return a;
     }
     IndexView view() const {
@@ -408,7 +406,7 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         ix->h_chrom_sub[n_chrom] = (u32)ix->h_sub_off.size();
     }
 
-    std::vector<u32> h_blocks, h_blk_first, h_top, h_cblk;
+    std::vector<u32> h_blocks, h_blk_first, h_top, h_cblk, h_ctab;
     if (kind == GTARS_KIND_BITS && n > 0) {
         // top-level budget: entries kept in LDS by k_tok_lds (env override for experiments)
         u32 top_max = 13312;
@@ -437,9 +435,7 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         const u32 nb = h_cblk[n_chrom];
         h_blocks.assign((size_t)nb * 32, 0);
         h_blk_first.assign(nb, 0xFFFFFFFFu);
-        u32 max_ct = 0;
         for (u32 c = 0; c < n_chrom; ++c) {
-            max_ct = std::max<u32>(max_ct, (h_cblk[c + 1] - h_cblk[c]) >> shift);
             for (u32 b = h_cblk[c]; b < h_cblk[c + 1]; ++b) {
                 u32 *rec = &h_blocks[(size_t)b * 32];
                 for (int k = 0; k < ACC_BS; ++k) {
@@ -466,15 +462,30 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
                 }
             }
         }
-        // top[t] = last start of the last block of group t (non-decreasing inside a chromosome)
+        // top[t] = last start of the last block of group t, moved into one ascending key space:
+        // chromosome c's keys live in [gbase[c], gbase[c] + span[c]], span = max start + 1, the upper
+        // end being the sentinel key (partly filled / padding blocks).  See AccelView.
+        h_ctab.assign((size_t)n_chrom * 4, 0);
+        u64 gbase = 0;
         h_top.resize(nb >> shift);
-        for (u32 t = 0; t < h_top.size(); ++t) h_top[t] = h_blk_first[(((size_t)t + 1) << shift) - 1];
+        for (u32 c = 0; c < n_chrom; ++c) {
+            const u64 span = off[c + 1] > off[c] ? (u64)ix->h_starts[off[c + 1] - 1] + 1 : 0;  // sorted by start
+            h_ctab[4 * (size_t)c + 0] = (u32)std::min<u64>(gbase, 0xFFFFFFFFu);
+            h_ctab[4 * (size_t)c + 1] = (u32)std::min<u64>(span, 0xFFFFFFFFu);
+            h_ctab[4 * (size_t)c + 2] = ix->h_chrom_aux[c];
+            h_ctab[4 * (size_t)c + 3] = h_cblk[c + 1];
+            for (u32 t = h_cblk[c] >> shift; t < (h_cblk[c + 1] >> shift); ++t) {
+                const u64 k = h_blk_first[(((size_t)t + 1) << shift) - 1];
+                h_top[t] = (u32)(gbase + std::min<u64>(k, span));
+            }
+            gbase += span + 1;
+        }
         ix->acc_n_blocks = nb;
         ix->acc_n_top = (u32)h_top.size();
         h_top.resize((h_top.size() + 3) & ~(size_t)3, 0xFFFFFFFFu);  // k_tok_lds copies it with 16-byte loads
         ix->acc_top_shift = shift;
-        ix->acc_max_chrom_top = max_ct;
-        ix->has_accel = nb > 0;
+        // the global key space must fit 32 bits (hg38: 3.1e9); wider universes use the generic kernels
+        ix->has_accel = nb > 0 && gbase <= 0xFFFFFFFFull;
     }
 
     GT_HIP(hipGetDevice(&ix->device));
@@ -482,7 +493,7 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
     if (!st && ix->has_accel) st = ix->acc_blocks.upload(h_blocks);
     if (!st && ix->has_accel) st = ix->acc_blk_first.upload(h_blk_first);
     if (!st && ix->has_accel) st = ix->acc_top.upload(h_top);
-    if (!st && ix->has_accel) st = ix->acc_chrom_blk_off.upload(h_cblk);
+    if (!st && ix->has_accel) st = ix->acc_chrom_tab.upload(h_ctab);
     if (!st) st = ix->ends.upload(ix->h_ends);
     if (!st) st = ix->vals.upload(ix->h_vals);
     if (!st) st = ix->max_ends.upload(ix->h_max_ends);
@@ -511,7 +522,7 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->acc_blocks.release();
     ix->acc_blk_first.release();
     ix->acc_top.release();
-    ix->acc_chrom_blk_off.release();
+    ix->acc_chrom_tab.release();
     delete ix;
 }
 

@@ -65,18 +65,21 @@ struct IndexView {
 // 0xFFFFFFFF for sentinel-padded blocks).  `top[t]` is the key of the last
 // block of every group of 2^top_shift blocks and is what the workgroups keep
 // in LDS; each chromosome's block range is padded to a multiple of 2^top_shift.
+// The top keys are GLOBAL: chromosome c's keys are offset by gbase[c] (the sum
+// of span+1 of all earlier chromosomes, span = max start + 1), sentinel keys
+// become gbase[c] + span[c], so the whole array ascends and every lane of a
+// wave searches the same range with the same (scalar) step sequence.
+// chrom_tab[c] = {gbase, span, max_len, end of the chromosome's block range}.
 constexpr int ACC_BS = 8;
 struct AccelView {
     const uint4 *blocks;      // [n_blocks * 8] (128 B per block)
     const u32 *blk_first;     // [n_blocks] last start of each block
     const u32 *top;           // [n_top]
-    const u32 *chrom_blk_off; // [n_chrom + 1]
-    const u32 *chrom_maxlen;  // [n_chrom]
+    const uint4 *chrom_tab;   // [n_chrom] {gbase, span, max_len, blk_end}
     u32 n_blocks;
     u32 n_top;
     u32 top_shift;
     u32 n_chrom;
-    u32 max_chrom_top;        // max top entries of one chromosome (search depth)
 };
 
 // IGD database: all stored intervals (tile replicas are NOT materialised),

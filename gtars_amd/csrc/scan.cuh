@@ -76,7 +76,7 @@ struct ScanWs {
     u64 state[1];  // [num_tiles]
 };
 
-inline size_t scan_ws_bytes_for_tiles(u64 tiles) { return sizeof(u64) * (tiles + 3 + 8); }  // +8: debug words
+inline size_t scan_ws_bytes_for_tiles(u64 tiles) { return sizeof(u64) * (tiles + 3 + 16); }  // +16: debug words
 
 __device__ __forceinline__ u64 ld_state(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

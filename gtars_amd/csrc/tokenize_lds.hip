@@ -41,6 +41,10 @@ namespace gtars {
 #ifndef GTARS_ABLATE
 #define GTARS_ABLATE 0
 #endif
+// 1: the next tile's queries are loaded right after the count phase; 0: at the top of its own iteration
+#ifndef GTARS_TOK_PREFETCH
+#define GTARS_TOK_PREFETCH 1
+#endif
 
 __device__ __forceinline__ i64 overlap_bp_tok(u32 as, u32 ae, u32 bs, u32 be) {
     u32 mn = ae < be ? ae : be;
@@ -128,7 +132,7 @@ template <int TPB, int TOK_QPT, bool FILTER>
 __global__ void __launch_bounds__(TPB, (TOK_QPT == 2 ? 6 : 4))
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
-          u32 search_steps, u32 epoch, u32 ticket_base) {
+          u32 epoch, u32 ticket_base) {
 #if GTARS_ABLATE & 128
     const long long t_entry = clock64();
 #endif
@@ -142,8 +146,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     const u32 n_top = a.n_top;
     const u32 n_top_pad = (n_top + 3u) & ~3u;
     u32 *s_top = smem;
-    u32 *s_cboff = smem + n_top_pad;        // [n_chrom + 1]
-    u32 *s_cmax = s_cboff + a.n_chrom + 1;  // [n_chrom]
+    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + n_top_pad);  // [n_chrom] {gbase, span, max_len, blk_end}
     {
         // the top array is padded to a multiple of 4 words on the device: 16-byte loads, 4 in flight
         const uint4 *src = reinterpret_cast<const uint4 *>(a.top);
@@ -159,8 +162,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             dst[k] = src[k];
         }
     }
-    for (u32 i = threadIdx.x; i <= a.n_chrom; i += TPB) s_cboff[i] = a.chrom_blk_off[i];
-    for (u32 i = threadIdx.x; i < a.n_chrom; i += TPB) s_cmax[i] = a.chrom_maxlen[i];
+    for (u32 i = threadIdx.x; i < a.n_chrom; i += TPB) s_ctab[i] = a.chrom_tab[i];
     __syncthreads();
 
     const u32 num_tiles = (u32)((nq + TILE - 1) / TILE);
@@ -178,7 +180,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     TileState<TOK_QPT> cur, prev;
     bool have_prev = false;
 #if GTARS_ABLATE & 128
-    long long t_ticket = 0, t_count = 0, t_scan = 0, t_resolve = 0, t_write = 0, t_mark;
+    long long t_ticket = 0, t_count = 0, t_scan = 0, t_resolve = 0, t_write = 0, t_c1 = 0, t_c2 = 0, t_c3 = 0, t_mark;
     const long long t_fill = clock64() - t_entry;
 #define GT_STAMP(acc) do { const long long _n = clock64(); acc += _n - t_mark; t_mark = _n; } while (0)
     t_mark = clock64();
@@ -190,80 +192,97 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     // workgroup's FIRST tile is simply its block index -- no atomic while the whole grid starts up.
     // Further tiles are drawn from a ticket counter, so a tile only ever waits on tiles that are
     // already running, whatever the dispatch order.
-    bool first_iter = true;
-    for (;;) {
-        u32 tile;
-        if (first_iter) {
-            tile = blockIdx.x;
-            first_iter = false;
-        } else if (num_tiles <= gridDim.x) {
-            tile = num_tiles;  // one tile per workgroup: nothing left to draw
+    //
+    // Latency plan: the ticket of the NEXT tile is drawn (one lane, asynchronously) before the
+    // current tile is counted and handed round through the scan's barrier; the next tile's queries
+    // are loaded into the (by then dead) query registers right after the count phase, so the HBM
+    // stream stays in flight through the scan / resolve / write of the previous tile.  vmcnt retires
+    // in order, so that prefetch is placed AFTER the record fetches of the count phase, and wave 0
+    // issues it only after its look-back loads.
+    u32 c[TOK_QPT], s[TOK_QPT], e[TOK_QPT];
+    auto load_queries = [&](u32 t) {
+        const u64 q0 = (u64)t * TILE + (u64)threadIdx.x * TOK_QPT;
+        if (t >= num_tiles) return;
+        if (vec_ok && q0 + TOK_QPT <= nq) {
+            if constexpr (TOK_QPT == 4) {
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(qc + q0);
+                const uint4 s4 = *reinterpret_cast<const uint4 *>(qs + q0);
+                const uint4 e4 = *reinterpret_cast<const uint4 *>(qe + q0);
+                c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+                s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
+                e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
+            } else {
+                const uint2 c2 = *reinterpret_cast<const uint2 *>(qc + q0);
+                const uint2 s2 = *reinterpret_cast<const uint2 *>(qs + q0);
+                const uint2 e2 = *reinterpret_cast<const uint2 *>(qe + q0);
+                c[0] = c2.x; c[1] = c2.y;
+                s[0] = s2.x; s[1] = s2.y;
+                e[0] = e2.x; e[1] = e2.y;
+            }
         } else {
-            if (threadIdx.x == 0) s_tile = gridDim.x + (atomicAdd(&ws->ticket, 1u) - ticket_base);
-            lds_barrier();
-            tile = s_tile;
+#pragma unroll
+            for (int j = 0; j < TOK_QPT; ++j) {
+                const bool ok = q0 + j < nq;
+                c[j] = ok ? qc[q0 + j] : GTARS_UNKNOWN_CHROM;
+                s[j] = ok ? qs[q0 + j] : 0;
+                e[j] = ok ? qe[q0 + j] : 0;
+            }
         }
+    };
+    const bool draw = num_tiles > gridDim.x;  // otherwise one tile per workgroup: nothing to draw
+    u32 tile = blockIdx.x;
+    if (GTARS_TOK_PREFETCH) load_queries(tile);
+    for (;;) {
         const bool has_cur = tile < num_tiles;
+        u32 next_tile = num_tiles;
         GT_STAMP(t_ticket);
 
         if (has_cur) {
+            u32 ticket = 0;
+            if (draw && threadIdx.x == 0) ticket = atomicAdd(&ws->ticket, 1u);  // consumed after the count phase
+            if (!GTARS_TOK_PREFETCH) load_queries(tile);
             // =============== count phase: 4 consecutive queries per thread ===============
-            const u64 q0 = (u64)tile * TILE + (u64)threadIdx.x * TOK_QPT;
-            u32 c[TOK_QPT], s[TOK_QPT], e[TOK_QPT];
-            if (vec_ok && q0 + TOK_QPT <= nq) {
-                if constexpr (TOK_QPT == 4) {
-                    const uint4 c4 = *reinterpret_cast<const uint4 *>(qc + q0);
-                    const uint4 s4 = *reinterpret_cast<const uint4 *>(qs + q0);
-                    const uint4 e4 = *reinterpret_cast<const uint4 *>(qe + q0);
-                    c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
-                    s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
-                    e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
-                } else {
-                    const uint2 c2 = *reinterpret_cast<const uint2 *>(qc + q0);
-                    const uint2 s2 = *reinterpret_cast<const uint2 *>(qs + q0);
-                    const uint2 e2 = *reinterpret_cast<const uint2 *>(qe + q0);
-                    c[0] = c2.x; c[1] = c2.y;
-                    s[0] = s2.x; s[1] = s2.y;
-                    e[0] = e2.x; e[1] = e2.y;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < TOK_QPT; ++j) {
-                    const bool ok = q0 + j < nq;
-                    c[j] = ok ? qc[q0 + j] : GTARS_UNKNOWN_CHROM;
-                    s[j] = ok ? qs[q0 + j] : 0;
-                    e[j] = ok ? qe[q0 + j] : 0;
-                }
-            }
 
             // ---- 1. search: first block whose LAST start is >= key (it holds the lower_bound) ----
-            u32 key[TOK_QPT], lo[TOK_QPT], len[TOK_QPT], be[TOK_QPT];
+            // The top keys ascend over the whole array (AccelView), so all lanes run the same scalar
+            // (base, len) halving sequence: per step one add, one LDS read, one compare, one select.
+            u32 key[TOK_QPT], gkey[TOK_QPT], pos[TOK_QPT], be[TOK_QPT];
 #pragma unroll
             for (int j = 0; j < TOK_QPT; ++j) {
                 const bool valid = c[j] < a.n_chrom;
-                const u32 cc = valid ? c[j] : 0u;
-                const u32 bb = s_cboff[cc];
-                be[j] = valid ? s_cboff[cc + 1] : bb;  // invalid -> empty range
-                const u32 ml = s_cmax[cc];
-                key[j] = s[j] >= ml ? s[j] - ml : 0u;
-                lo[j] = bb >> shift;
-                len[j] = (be[j] - bb) >> shift;
+                const uint4 ct = s_ctab[valid ? c[j] : 0u];
+                key[j] = s[j] >= ct.z ? s[j] - ct.z : 0u;
+                gkey[j] = ct.x + (key[j] < ct.y ? key[j] : ct.y);  // beyond the last start: the sentinel key
+                be[j] = valid ? ct.w : 0u;                         // invalid -> empty range
             }
-            for (u32 it = 0; it < search_steps; ++it) {
+            {
+                // pos[] holds LDS byte addresses (32-bit, address space 3) so a step needs no address math
+                typedef const __attribute__((address_space(3))) u32 *lds_cu32;
+                const u32 tb = (u32)(uintptr_t)(lds_cu32)s_top - 4u;  // &top[-1]
+#pragma unroll
+                for (int j = 0; j < TOK_QPT; ++j) pos[j] = tb;
+                u32 len = n_top;
+                while (len > 1) {
+                    const u32 half = len >> 1;
+#pragma unroll
+                    for (int j = 0; j < TOK_QPT; ++j) {
+                        const u32 cand = pos[j] + (half << 2);
+                        const u32 v = *(lds_cu32)(uintptr_t)cand;  // top[base + half - 1]
+                        pos[j] = v < gkey[j] ? cand : pos[j];
+                    }
+                    len -= half;
+                }
 #pragma unroll
                 for (int j = 0; j < TOK_QPT; ++j) {
-                    const u32 half = len[j] >> 1;
-                    const u32 mid = lo[j] + half;
-                    const u32 v = s_top[mid < n_top ? mid : n_top - 1];
-                    const bool pred = (len[j] > 0) & (v < key[j]);
-                    lo[j] = pred ? mid + 1 : lo[j];
-                    len[j] = pred ? len[j] - half - 1 : half;
+                    const u32 v = *(lds_cu32)(uintptr_t)(pos[j] + 4u);
+                    pos[j] = ((pos[j] - tb) >> 2) + (v < gkey[j] ? 1u : 0u);  // first group with key >= gkey (or n_top)
                 }
             }
+            GT_STAMP(t_c1);
             u32 b0[TOK_QPT];
 #pragma unroll
             for (int j = 0; j < TOK_QPT; ++j) {
-                u32 b = lo[j] << shift;  // first group whose max last-start >= key (or == be: no candidate)
+                u32 b = pos[j] << shift;  // first block of that group (>= be: no candidate)
                 if (shift) {
                     // inside the group: first block with blk_last >= key
                     u32 l2 = b, n2 = (be[j] > b) ? min(1u << shift, be[j] - b) : 0u;
@@ -296,6 +315,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                 mask[j] = act ? m : 0u;
                 more[j] = act && mr;
             }
+            GT_STAMP(t_c2);
             u32 tsum = 0;
             cur.more_bits = 0;
 #pragma unroll
@@ -319,12 +339,14 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                 m &= m - 1;
                 cur.v1[j] = m ? blkw[base + val_word(__ffs((int)m) - 1)] : 0u;
             }
-            GT_STAMP(t_count);
+            GT_STAMP(t_c3);
 
             // =============== workgroup scan of the per-thread hit counts ===============
             const u32 inc = wave_inclusive_scan_u32(tsum, lane);
             if (lane == 63) s_scan[wave] = inc;
+            if (draw && threadIdx.x == 0) s_tile = gridDim.x + (ticket - ticket_base);
             lds_barrier();
+            if (draw) next_tile = s_tile;
             u32 wbase = 0, block_total = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
@@ -337,15 +359,17 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             cur.tile = tile;
             if (threadIdx.x == 0 && !(GTARS_ABLATE & 16)) publish_aggregate(ws->state, tile, (u64)block_total, epoch);
             GT_STAMP(t_scan);
+            if (GTARS_TOK_PREFETCH && wave != 0) load_queries(next_tile);  // c/s/e are dead from here on: prefetch the next tile
         }
 
         // =============== resolve + write the PREVIOUS tile ===============
+        if (have_prev && threadIdx.x < 64) {
+            const u64 p = (GTARS_ABLATE & 16) ? (u64)prev.tile * 600u
+                                              : resolve_prefix(ws->state, prev.tile, (u64)prev.total, lane, &ws->err, epoch);
+            if (lane == 0) s_prefix = p;
+        }
+        if (GTARS_TOK_PREFETCH && has_cur && wave == 0) load_queries(next_tile);  // after the look-back: vmcnt retires in order
         if (have_prev) {
-            if (threadIdx.x < 64) {
-                const u64 p = (GTARS_ABLATE & 16) ? (u64)prev.tile * 600u
-                                                  : resolve_prefix(ws->state, prev.tile, (u64)prev.total, lane, &ws->err, epoch);
-                if (lane == 0) s_prefix = p;
-            }
             lds_barrier();
             GT_STAMP(t_resolve);
             const u64 prefix = s_prefix;
@@ -377,7 +401,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                     }
                     if (prev.more_bits & (1u << j)) {
                         const u32 cq = qc[q0 + j], sq = qs[q0 + j], eq = qe[q0 + j];
-                        const u32 be = s_cboff[cq + 1];
+                        const u32 be = s_ctab[cq].w;
                         u64 ot = o;
                         o += walk_tail<FILTER>(a, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
                             if (ot < cap) ovals[ot] = blkw[b * 32u + 16u + (u32)k];
@@ -412,6 +436,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         if (!has_cur) break;
         prev = cur;
         have_prev = true;
+        tile = next_tile;
     }
 #if GTARS_ABLATE & 128
     if (threadIdx.x == 0) {
@@ -423,6 +448,9 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         atomicAdd(&dbg[4], (unsigned long long)t_write);
         atomicAdd(&dbg[5], 1ull);
         atomicAdd(&dbg[6], (unsigned long long)t_fill);
+        atomicAdd(&dbg[7], (unsigned long long)t_c1);
+        atomicAdd(&dbg[8], (unsigned long long)t_c2);
+        atomicAdd(&dbg[9], (unsigned long long)t_c3);
     }
 #endif
 }
@@ -436,7 +464,7 @@ static int env_int(const char *name, int dflt) {
 
 static size_t tok_lds_bytes(const AccelView &a) {
     const size_t n_top_pad = ((size_t)a.n_top + 3) & ~(size_t)3;
-    return (n_top_pad + 2 * (size_t)a.n_chrom + 1) * sizeof(u32);
+    return (n_top_pad + 4 * (size_t)a.n_chrom) * sizeof(u32);
 }
 
 bool tokenize_lds_supported(const AccelView &a) {
@@ -494,10 +522,8 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     u64 grid = (u64)cus * per_cu;
     if (grid > tiles) grid = tiles;
-    u32 steps = 0;
-    while ((1u << steps) <= a.max_chrom_top) ++steps;  // iterations until len == 0
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq, min_bp, out.offsets,
-                       out.vals, out.vals ? out.capacity : 0, ws, steps, ep.epoch, ep.ticket_base);
+                       out.vals, out.vals ? out.capacity : 0, ws, ep.epoch, ep.ticket_base);
     GT_HIP(hipGetLastError());
     // tickets drawn by this launch: the tiles beyond the first `grid`, plus one failing draw per workgroup
     if (tiles > grid) ep.ticket_base += (u32)tiles;
@@ -505,11 +531,11 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     {
         static int printed = 0;
         if (printed++ < 2) {
-            unsigned long long h[7];
+            unsigned long long h[10];
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(h, (char *)ws + sizeof(u64) * (2 + tiles), sizeof h, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[phase cycles per WG, %llu WGs, %llu tiles] fill %.0f ticket %.0f count %.0f scan %.0f resolve %.0f write %.0f\n",
-                    h[5], (unsigned long long)tiles, (double)h[6] / h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5],
+            fprintf(stderr, "[phase cycles per WG, %llu WGs, %llu tiles] fill %.0f ticket %.0f count %.0f (search %.0f fetch+mask %.0f lookahead+ids %.0f) scan %.0f resolve %.0f write %.0f\n",
+                    h[5], (unsigned long long)tiles, (double)h[6] / h[5], (double)h[0] / h[5], (double)(h[7] + h[8] + h[9]) / h[5], (double)h[7] / h[5], (double)h[8] / h[5], (double)h[9] / h[5], (double)h[2] / h[5],
                     (double)h[3] / h[5], (double)h[4] / h[5]);
         }
     }
