@@ -199,18 +199,21 @@ struct gtars_index {
     std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
     // blocked acceleration structure (Bits kind), see AccelView in common.h
-    DevBuf<u32> acc_blocks, acc_blk_first, acc_top, acc_chrom_tab;
-    u32 acc_n_blocks = 0, acc_n_top = 0, acc_top_shift = 0;
+    DevBuf<u32> acc_blocks, acc_blk_first, acc_top, acc_qkeys, acc_chrom_tab;
+    u32 acc_n_blocks = 0, acc_n_top = 0, acc_n_units = 0, acc_top_shift = 0, acc_q_shift = 0;
     bool has_accel = false;
     AccelView accel() const {
         AccelView a;
         a.blocks = reinterpret_cast<const uint4 *>(acc_blocks.p);
         a.blk_first = acc_blk_first.p;
         a.top = acc_top.p;
+        a.qkeys = acc_qkeys.p;
         a.chrom_tab = reinterpret_cast<const uint4 *>(acc_chrom_tab.p);
         a.n_blocks = acc_n_blocks;
         a.n_top = acc_n_top;
+        a.n_units = acc_n_units;
         a.top_shift = acc_top_shift;
+        a.q_shift = acc_q_shift;
         a.n_chrom = n_chrom;
         return a;
     }
@@ -406,13 +409,18 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         ix->h_chrom_sub[n_chrom] = (u32)ix->h_sub_off.size();
     }
 
-    std::vector<u32> h_blocks, h_blk_first, h_top, h_cblk, h_ctab;
+    std::vector<u32> h_blocks, h_blk_first, h_top, h_q, h_cblk, h_ctab;
     if (kind == GTARS_KIND_BITS && n > 0) {
-        // top-level budget: entries kept in LDS by k_tok_lds (env override for experiments)
-        u32 top_max = 13312;
+        // LDS budget of k_tok_lds: two workgroups per CU, each with its own copy of the level-1 keys
+        // (4 B per 16 units), the level-2 keys (2 B per unit) and the chromosome table (16 B each)
+        u32 unit_max = 1024;
+        {
+            const long budget = 78 * 1024 - 16l * (long)n_chrom;
+            if (budget > 4096) unit_max = (u32)((budget * 4 / 9) / ACC_GROUP * ACC_GROUP);
+        }
         if (const char *e = getenv("GTARS_TOP_MAX")) {
             const long v = atol(e);
-            if (v >= 64) top_max = (u32)v;
+            if (v >= 64) unit_max = (u32)v;
         }
         u32 shift = 0;
         for (;;) {
@@ -423,7 +431,7 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
                 const u64 b = (off[c + 1] - off[c] + ACC_BS - 1) / ACC_BS;
                 nb += (b + g - 1) / g * g;
             }
-            if ((nb >> shift) <= top_max || shift >= 16) break;
+            if ((nb >> shift) <= unit_max || shift >= 16) break;
             ++shift;
         }
         const u64 g = 1ull << shift;
@@ -433,57 +441,76 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
             h_cblk[c + 1] = h_cblk[c] + (u32)((b + g - 1) / g * g);
         }
         const u32 nb = h_cblk[n_chrom];
-        h_blocks.assign((size_t)nb * 32, 0);
+        h_blocks.assign((size_t)nb * 16, 0);
         h_blk_first.assign(nb, 0xFFFFFFFFu);
         for (u32 c = 0; c < n_chrom; ++c) {
             for (u32 b = h_cblk[c]; b < h_cblk[c + 1]; ++b) {
-                u32 *rec = &h_blocks[(size_t)b * 32];
-                for (int k = 0; k < ACC_BS; ++k) {
+                u32 *rec = &h_blocks[(size_t)b * 16];
+                // slots 0..2: own intervals, slot 3: look-ahead = first interval of the next block;
+                // quad 3 = {ns1, ne1, nv1, ns2}: the second interval of the next block and the start of its third
+                auto at = [&](int k, u32 &st_, u32 &en_, u32 &va_) {
                     const u64 p = (u64)off[c] + (u64)(b - h_cblk[c]) * ACC_BS + k;
-                    if (p < off[c + 1]) {
-                        rec[k] = ix->h_starts[p];
-                        rec[8 + k] = ix->h_ends[p];
-                        rec[16 + k] = ix->h_vals[p];
-                    } else {
-                        rec[k] = 0xFFFFFFFFu;  // sentinel: never < q_end, stops the scan
-                        rec[8 + k] = 0;
-                        rec[16 + k] = 0;
-                    }
-                }
-                // search key of the block: its LAST start (sentinel-padded blocks: 0xFFFFFFFF)
-                h_blk_first[b] = rec[ACC_BS - 1];
-                // look-ahead: the first two intervals of the next block of the same chromosome
-                for (int k = 0; k < 2; ++k) {
-                    const u64 p = (u64)off[c] + (u64)(b - h_cblk[c] + 1) * ACC_BS + k;
                     const bool ok = p < off[c + 1];
-                    rec[24 + 2 * k] = ok ? ix->h_starts[p] : 0xFFFFFFFFu;
-                    rec[25 + 2 * k] = ok ? ix->h_ends[p] : 0u;
-                    rec[28 + k] = ok ? ix->h_vals[p] : 0u;
-                }
+                    st_ = ok ? ix->h_starts[p] : 0xFFFFFFFFu;  // sentinel: never < q_end, stops the scan
+                    en_ = ok ? ix->h_ends[p] : 0u;
+                    va_ = ok ? ix->h_vals[p] : 0u;
+                };
+                for (int k = 0; k <= ACC_BS; ++k) at(k, rec[k], rec[4 + k], rec[8 + k]);
+                at(ACC_BS + 1, rec[12], rec[13], rec[14]);
+                u32 dummy_e, dummy_v;
+                at(ACC_BS + 2, rec[15], dummy_e, dummy_v);
+                // search key of the block: its LAST own start (partly filled blocks: 0xFFFFFFFF)
+                h_blk_first[b] = rec[ACC_BS - 1];
             }
         }
-        // top[t] = last start of the last block of group t, moved into one ascending key space:
-        // chromosome c's keys live in [gbase[c], gbase[c] + span[c]], span = max start + 1, the upper
-        // end being the sentinel key (partly filled / padding blocks).  See AccelView.
-        h_ctab.assign((size_t)n_chrom * 4, 0);
+        // Unit keys (last block of every 2^shift blocks) in one ascending key space: chromosome c's
+        // keys live in [gbase[c], gbase[c] + span[c]], the upper end being the sentinel key.
+        // Consecutive chromosomes are 2^q_shift apart, so that the floor-quantised level-2 search can
+        // never stop on a block of an EARLIER chromosome (its keys quantise strictly below the target).
+        const u32 n_units = nb >> shift;
+        const u32 n1 = (n_units + ACC_GROUP - 1) / ACC_GROUP;
+        std::vector<u64> uk(n_units);
+        u32 qsh = 0;
         u64 gbase = 0;
-        h_top.resize(nb >> shift);
-        for (u32 c = 0; c < n_chrom; ++c) {
-            const u64 span = off[c + 1] > off[c] ? (u64)ix->h_starts[off[c + 1] - 1] + 1 : 0;  // sorted by start
-            h_ctab[4 * (size_t)c + 0] = (u32)std::min<u64>(gbase, 0xFFFFFFFFu);
-            h_ctab[4 * (size_t)c + 1] = (u32)std::min<u64>(span, 0xFFFFFFFFu);
-            h_ctab[4 * (size_t)c + 2] = ix->h_chrom_aux[c];
-            h_ctab[4 * (size_t)c + 3] = h_cblk[c + 1];
-            for (u32 t = h_cblk[c] >> shift; t < (h_cblk[c + 1] >> shift); ++t) {
-                const u64 k = h_blk_first[(((size_t)t + 1) << shift) - 1];
-                h_top[t] = (u32)(gbase + std::min<u64>(k, span));
+        for (;;) {
+            h_ctab.assign((size_t)n_chrom * 4, 0);
+            gbase = 0;
+            for (u32 c = 0; c < n_chrom; ++c) {
+                const u64 span = off[c + 1] > off[c] ? (u64)ix->h_starts[off[c + 1] - 1] + 1 : 0;  // sorted by start
+                h_ctab[4 * (size_t)c + 0] = (u32)std::min<u64>(gbase, 0xFFFFFFFFu);
+                h_ctab[4 * (size_t)c + 1] = (u32)std::min<u64>(span, 0xFFFFFFFFu);
+                h_ctab[4 * (size_t)c + 2] = ix->h_chrom_aux[c];
+                h_ctab[4 * (size_t)c + 3] = h_cblk[c + 1];
+                for (u32 t = h_cblk[c] >> shift; t < (h_cblk[c + 1] >> shift); ++t)
+                    uk[t] = gbase + std::min<u64>(h_blk_first[(((size_t)t + 1) << shift) - 1], span);
+                gbase += span + (1ull << qsh);
             }
-            gbase += span + 1;
+            u64 max_delta = 0;
+            for (u32 t = 0; t < n1; ++t) {
+                const u64 k = uk[std::min<u64>((u64)t * ACC_GROUP + ACC_GROUP - 1, n_units - 1)];
+                max_delta = std::max(max_delta, k - (t ? uk[(u64)t * ACC_GROUP - 1] : 0));
+            }
+            u32 need = 0;
+            while ((max_delta >> need) > 0xFFFEull) ++need;  // 0xFFFF is the padding value
+            if (need <= qsh) break;
+            qsh = need;
         }
+        h_top.assign(((size_t)n1 + 3) & ~(size_t)3, 0xFFFFFFFFu);  // k_tok_lds copies it with 16-byte loads
+        for (u32 t = 0; t < n1; ++t)
+            h_top[t] = (u32)std::min<u64>(uk[std::min<u64>((u64)t * ACC_GROUP + ACC_GROUP - 1, n_units - 1)], 0xFFFFFFFFu);
+        std::vector<uint16_t> q16((size_t)n1 * ACC_GROUP, 0xFFFFu);
+        for (u32 u = 0; u < n_units; ++u) {
+            const u32 t = u / ACC_GROUP;
+            const u64 base = t ? uk[(u64)t * ACC_GROUP - 1] : 0;
+            q16[u] = (uint16_t)((uk[u] - base) >> qsh);
+        }
+        h_q.assign((size_t)n1 * ACC_GROUP / 2, 0);
+        memcpy(h_q.data(), q16.data(), q16.size() * sizeof(uint16_t));
         ix->acc_n_blocks = nb;
-        ix->acc_n_top = (u32)h_top.size();
-        h_top.resize((h_top.size() + 3) & ~(size_t)3, 0xFFFFFFFFu);  // k_tok_lds copies it with 16-byte loads
+        ix->acc_n_top = n1;
+        ix->acc_n_units = n_units;
         ix->acc_top_shift = shift;
+        ix->acc_q_shift = qsh;
         // the global key space must fit 32 bits (hg38: 3.1e9); wider universes use the generic kernels
         ix->has_accel = nb > 0 && gbase <= 0xFFFFFFFFull;
     }
@@ -493,6 +520,7 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
     if (!st && ix->has_accel) st = ix->acc_blocks.upload(h_blocks);
     if (!st && ix->has_accel) st = ix->acc_blk_first.upload(h_blk_first);
     if (!st && ix->has_accel) st = ix->acc_top.upload(h_top);
+    if (!st && ix->has_accel) st = ix->acc_qkeys.upload(h_q);
     if (!st && ix->has_accel) st = ix->acc_chrom_tab.upload(h_ctab);
     if (!st) st = ix->ends.upload(ix->h_ends);
     if (!st) st = ix->vals.upload(ix->h_vals);
@@ -522,6 +550,7 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->acc_blocks.release();
     ix->acc_blk_first.release();
     ix->acc_top.release();
+    ix->acc_qkeys.release();
     ix->acc_chrom_tab.release();
     delete ix;
 }

@@ -55,30 +55,48 @@ struct IndexView {
 };
 
 // Blocked acceleration structure of a Bits-kind index (built once at index
-// build): every chromosome's sorted intervals are cut into blocks of
-// ACC_BS = 8 and stored as one 128-byte record per block
-//     u32 starts[8] | u32 ends[8] | u32 vals[8] | look-ahead: ns0 ne0 ns1 ne1 nv0 nv1 - -
-// (the look-ahead is a copy of the first two intervals of the next block)
-// so that one L2 line holds everything a query needs about a block.  Unused
-// slots are sentinels (start = 0xFFFFFFFF, end = 0: never overlap, and stop
-// the forward scan).  blk_first[b] = the block's LAST start (its search key;
-// 0xFFFFFFFF for sentinel-padded blocks).  `top[t]` is the key of the last
-// block of every group of 2^top_shift blocks and is what the workgroups keep
-// in LDS; each chromosome's block range is padded to a multiple of 2^top_shift.
-// The top keys are GLOBAL: chromosome c's keys are offset by gbase[c] (the sum
-// of span+1 of all earlier chromosomes, span = max start + 1), sentinel keys
-// become gbase[c] + span[c], so the whole array ascends and every lane of a
-// wave searches the same range with the same (scalar) step sequence.
+// build).  Every chromosome's sorted intervals are cut into blocks of
+// ACC_BS = 3 and stored as one 64-byte record (4 x uint4) per block:
+//     quad 0: s0 s1 s2 ns0    quad 1: e0 e1 e2 ne0    quad 2: v0 v1 v2 nv0    quad 3: ns1 ne1 nv1 ns2
+// (ns0/ne0/nv0 and ns1/ne1/nv1 = copies of the NEXT block's first two intervals, the "look-ahead";
+// ns2 = the start of its third: the scan goes on past the record only if ns2 < q_end).
+// Why this shape: a query's record fetch is one burst of three 16-byte requests
+// to one random L2 line, and on gfx950 a CU pays max(2.3 clk per distinct line
+// filled into its vector L1, 1 clk per 16-byte lane request) -- with 16 waves
+// of divergent fetches in flight the L1 thrashes, so any LATER access to the same
+// line is a fresh fill (tools/ubench/gather.hip).  Four requests = 4 clk and
+// carry everything all but ~0.2 % of the queries need: own intervals, the two
+// intervals the scan would look at next, and the token ids; no dependent loads
+// (a dependent load costs every wave a round trip: with 256 queries per wave
+// even a 3 % case is hit by nearly every wave).
+// Unused slots are sentinels (start = 0xFFFFFFFF, end = 0: never overlap and
+// stop the forward scan).  blk_first[b] = the block's LAST own start (its
+// search key; 0xFFFFFFFF for partly filled blocks).
+//
+// Search keys kept in LDS by the workgroups, over "units" of 2^top_shift blocks
+// (each chromosome's block range is padded to a multiple of 2^top_shift):
+//  * all keys live in ONE ascending key space: chromosome c's keys are offset by
+//    gbase[c] (sum of span+1 of the earlier chromosomes, span = max start + 1) and
+//    sentinel keys become gbase[c] + span[c]; every lane of a wave then searches
+//    the same range with the same scalar step sequence;
+//  * level 1 `top[g]`: exact u32 key of the last unit of every group of 16 units;
+//  * level 2 `qkeys[u]`: u16, (key(u) - top[g-1]) >> q_shift, floor-quantised.  The
+//    level-2 search may stop one unit early (never late); the record scan then
+//    simply walks on, so results stay exact.
 // chrom_tab[c] = {gbase, span, max_len, end of the chromosome's block range}.
-constexpr int ACC_BS = 8;
+constexpr int ACC_BS = 3;
+constexpr int ACC_GROUP = 16;  // units per level-1 key
 struct AccelView {
-    const uint4 *blocks;      // [n_blocks * 8] (128 B per block)
-    const u32 *blk_first;     // [n_blocks] last start of each block
-    const u32 *top;           // [n_top]
+    const uint4 *blocks;      // [n_blocks * 4] (64 B per block)
+    const u32 *blk_first;     // [n_blocks] last own start of each block (local coordinates)
+    const u32 *top;           // [n_top] level-1 keys (global key space)
+    const u32 *qkeys;         // [n_top * 8] words = n_top * 16 u16 level-2 keys (0xFFFF padding)
     const uint4 *chrom_tab;   // [n_chrom] {gbase, span, max_len, blk_end}
     u32 n_blocks;
-    u32 n_top;
+    u32 n_top;                // level-1 keys = ceil(n_units / 16)
+    u32 n_units;
     u32 top_shift;
+    u32 q_shift;
     u32 n_chrom;
 };
 

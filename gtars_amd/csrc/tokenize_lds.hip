@@ -2,32 +2,35 @@
 // (gtars-tokenizers/src/tokenizer.rs:140-171 -> Bits::find, bits.rs:141-156,
 // 433-446) for a Bits-kind index.
 //
-// Data layout (AccelView, common.h): the sorted index is cut into 8-interval
-// blocks, one 128-byte record (= one L2 line) per block; the first start of
-// every 2^top_shift-th block forms a small "top" array.
+// Data layout (AccelView, common.h): the sorted index is cut into 3-interval
+// blocks, one 64-byte record per block that also carries a copy of the next
+// block's first interval (the look-ahead); two levels of search keys over the
+// blocks' last starts are small enough to live in LDS.
 //
-// Kernel: persistent workgroups copy `top` (+ the per-chromosome tables) into
-// LDS once, then take tiles of TPB*4 consecutive queries through a ticket
-// counter.  Per query:
-//   1. LDS binary search of `top` (lock-step over the thread's 4 queries so the
-//      4 searches overlap) for the first block whose LAST start is
-//      >= q_start - max_len: the block that holds Bits::find's lower_bound
-//      (bits.rs:144-147) (+ a short search of blk_first[] in L2 when top_shift > 0;
-//      despite its name that array then holds per-block last starts);
-//   2. ONE 128-byte record fetch (4 x dwordx4 per lane), overlap test of its 8
-//      intervals in registers -> hit mask; if the block's last start is still
-//      < q_end (iv.start >= stop ends the reference scan, bits.rs:441-443) the
-//      two look-ahead intervals stored in the same record are tested too, and
-//      only a query that runs past those walks into the following blocks;
+// Kernel: persistent workgroups copy the keys (+ the per-chromosome table) into
+// LDS once, then take tiles of TPB*4 consecutive queries.  Per query:
+//   1. LDS search for the first block whose LAST start is >= q_start - max_len:
+//      the block that holds Bits::find's lower_bound (bits.rs:144-147).  Level 1
+//      is a lock-step binary search with a scalar step sequence (all keys live in
+//      one ascending key space), level 2 four steps over 16 quantised u16 keys;
+//      (+ a short search of blk_first[] in L2 when top_shift > 0);
+//   2. ONE burst of three 16-byte loads from the block's record: starts, ends and
+//      token ids of its 3 intervals and of the look-ahead interval.  The overlap
+//      test runs in registers -> 4-bit hit mask and the first two ids; only a
+//      query that runs past the look-ahead start (iv.start >= stop ends the
+//      reference scan, bits.rs:441-443) walks into the following blocks;
 //   3. wave shuffles + one LDS word per wave scan the per-thread hit counts,
 //      wave 0 resolves the tile's global base by chained look-back (scan.cuh);
 //   4. CSR offsets (u64) and token ids (u32) are written once, in place.
-// Starting the scan at a block boundary instead of the exact lower_bound only
-// adds intervals with start < q_start - max_len, which cannot satisfy
-// end > q_start, so the hit set and its order are exactly Bits::find's.
+// Starting the scan at a block boundary (or, after the quantised level 2, one
+// block early) instead of the exact lower_bound only adds intervals with
+// start < q_start - max_len, which cannot satisfy end > q_start, so the hit set
+// and its order are exactly Bits::find's.
 //
 // Bound: HBM stream of queries in / offsets+ids out (23.5 B per query at
-// config 2); the index itself stays L2/LDS resident.  No MFMA: integer search.
+// config 2); the index itself stays L2/LDS resident.  What the count phase
+// actually pays is the CU's vector-L1 fill rate for one random line per query
+// (see AccelView).  No MFMA: integer search.
 #include "common.h"
 #include "scan.cuh"
 
@@ -43,7 +46,7 @@ namespace gtars {
 #endif
 // 1: the next tile's queries are loaded right after the count phase; 0: at the top of its own iteration
 #ifndef GTARS_TOK_PREFETCH
-#define GTARS_TOK_PREFETCH 1
+#define GTARS_TOK_PREFETCH 0
 #endif
 
 __device__ __forceinline__ i64 overlap_bp_tok(u32 as, u32 ae, u32 bs, u32 be) {
@@ -59,39 +62,28 @@ __device__ __forceinline__ bool hit_test(u32 s, u32 e, u32 qs, u32 qe, i32 min_b
     return hit;
 }
 
-// Block record (32 words = 128 B = one L2 line), see AccelView:
-//   [0..7] starts  [8..15] ends  [16..23] vals
-//   [24] ns0 [25] ne0 [26] ns1 [27] ne1   look-ahead: first two intervals of the next block
-//   [28] nv0 [29] nv1 [30..31] unused
-// 8-bit hit mask of the block's own intervals; more = the scan runs past them
+// Block record (16 words = 64 B), see AccelView:
+//   quad 0: s0 s1 s2 ns0   quad 1: e0 e1 e2 ne0   quad 2: v0 v1 v2 nv0   quad 3: ns1 ne1 nv1 ns2
+// 5-bit hit mask: the three own intervals (bits 0..2) and the two look-ahead intervals (bits 3,4);
+// more = the reference scan would run past the look-ahead too.
 template <bool FILTER>
-__device__ __forceinline__ u32 block_mask8(const uint4 *__restrict__ blk, u32 qs, u32 qe, i32 min_bp, bool &more) {
-    const uint4 s0 = blk[0], s1 = blk[1], e0 = blk[2], e1 = blk[3];
-    const u32 s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const u32 e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+__device__ __forceinline__ u32 block_mask5(const uint4 &S, const uint4 &E, const uint4 &L, u32 qs, u32 qe, i32 min_bp,
+                                           bool &more) {
     u32 m = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) m |= (hit_test<FILTER>(s[k], e[k], qs, qe, min_bp) ? 1u : 0u) << k;
-    more = s[7] < qe;  // starts ascend inside a block: no stop seen yet (bits.rs:441-443)
+    m |= (hit_test<FILTER>(S.x, E.x, qs, qe, min_bp) ? 1u : 0u);
+    m |= (hit_test<FILTER>(S.y, E.y, qs, qe, min_bp) ? 1u : 0u) << 1;
+    m |= (hit_test<FILTER>(S.z, E.z, qs, qe, min_bp) ? 1u : 0u) << 2;
+    m |= (hit_test<FILTER>(S.w, E.w, qs, qe, min_bp) ? 1u : 0u) << 3;
+    m |= (hit_test<FILTER>(L.x, L.y, qs, qe, min_bp) ? 1u : 0u) << 4;
+    more = L.w < qe;  // starts ascend: no stop seen yet (bits.rs:441-443)
     return m;
 }
 
-// look-ahead part: bits 8,9; more2 = the scan runs past the look-ahead too
-template <bool FILTER>
-__device__ __forceinline__ u32 lookahead_mask(const uint4 *__restrict__ blk, u32 qs, u32 qe, i32 min_bp, bool &more2) {
-    const uint4 la = blk[6];
-    u32 m = 0;
-    m |= (hit_test<FILTER>(la.x, la.y, qs, qe, min_bp) ? 1u : 0u) << 8;
-    m |= (hit_test<FILTER>(la.z, la.w, qs, qe, min_bp) ? 1u : 0u) << 9;
-    more2 = la.z < qe;
-    return m;
-}
-
-// word index (inside the block record) of the val of hit bit k (0..9)
-__device__ __forceinline__ u32 val_word(int k) { return k < 8 ? 16u + (u32)k : 20u + (u32)k; }
+// word index (inside the block record) of the val of hit bit k (0..4)
+__device__ __forceinline__ u32 val_word(int k) { return k < 4 ? 8u + (u32)k : 14u; }
 
 // Per-query state kept between the count phase and the write phase, in ONE
-// register: first block (22 bits) + 10-bit hit mask (8 own + 2 look-ahead).
+// register: first block (22 bits) + 5-bit hit mask (3 own + 2 look-ahead).
 constexpr u32 B0_BITS = 22;
 constexpr u32 B0_MASK = (1u << B0_BITS) - 1u;
 
@@ -103,8 +95,13 @@ __device__ __forceinline__ u32 walk_tail(const AccelView &a, u32 b0, u32 be, u32
     u32 n = 0;
     bool mr = true;
     for (u32 b = b0 + 1; mr && b < be; ++b) {
-        u32 m = block_mask8<FILTER>(a.blocks + (size_t)b * 8, qs, qe, min_bp, mr);
+        const uint4 S = a.blocks[(size_t)b * 4], E = a.blocks[(size_t)b * 4 + 1];
+        u32 m = 0;
+        m |= (hit_test<FILTER>(S.x, E.x, qs, qe, min_bp) ? 1u : 0u);
+        m |= (hit_test<FILTER>(S.y, E.y, qs, qe, min_bp) ? 1u : 0u) << 1;
+        m |= (hit_test<FILTER>(S.z, E.z, qs, qe, min_bp) ? 1u : 0u) << 2;
         if (b == b0 + 1) m &= ~3u;
+        mr = S.z < qe;
         n += __popc(m);
         while (m) {
             const int k = __ffs((int)m) - 1;
@@ -117,7 +114,7 @@ __device__ __forceinline__ u32 walk_tail(const AccelView &a, u32 b0, u32 be, u32
 
 template <int TOK_QPT>
 struct TileState {
-    u32 st[TOK_QPT];  // b0 | mask10 << 22
+    u32 st[TOK_QPT];  // b0 | mask5 << 22
     u32 v0[TOK_QPT];  // ids of the first two hits: loaded during the count phase,
     u32 v1[TOK_QPT];  //   stored one tile later (their latency is off the critical path)
     u32 excl;         // exclusive hit offset of the thread's queries inside the tile
@@ -143,23 +140,26 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     __shared__ u32 s_scan[NW];
     constexpr int TILE = TPB * TOK_QPT;
 
+    // LDS: level-1 keys (u32, padded to 4) | level-2 keys (u16, 16 per level-1 key) | chromosome table
     const u32 n_top = a.n_top;
     const u32 n_top_pad = (n_top + 3u) & ~3u;
     u32 *s_top = smem;
-    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + n_top_pad);  // [n_chrom] {gbase, span, max_len, blk_end}
+    u32 *s_q = smem + n_top_pad;                                             // n_top * 8 words
+    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + n_top_pad + n_top * 8);  // [n_chrom] {gbase, span, max_len, blk_end}
     {
-        // the top array is padded to a multiple of 4 words on the device: 16-byte loads, 4 in flight
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.top);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_top);
-        const u32 n4 = n_top_pad >> 2;
-        // every workgroup copies the same array: start each one at a different place so that they
-        // do not all queue on the same L2 channel at the same time
-        const u32 rot = n4 ? (u32)(((u64)blockIdx.x * 2654435761ull) % n4) : 0u;
+        // both key arrays are padded to 16 bytes on the device: 16-byte loads, 4 in flight.  Every
+        // workgroup copies the same arrays: start each one at a different place so that they do not
+        // all queue on the same L2 channel at the same time.
+        const u32 n4a = n_top_pad >> 2, n4 = n4a + n_top * 2;
+        const uint4 *src_a = reinterpret_cast<const uint4 *>(a.top);
+        const uint4 *src_b = reinterpret_cast<const uint4 *>(a.qkeys);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const u32 rot = (u32)(((u64)blockIdx.x * 2654435761ull) % n4);
 #pragma unroll 4
         for (u32 i = threadIdx.x; i < n4; i += TPB) {
             u32 k = i + rot;
             k = k >= n4 ? k - n4 : k;
-            dst[k] = src[k];
+            dst[k] = k < n4a ? src_a[k] : src_b[k - n4a];
         }
     }
     for (u32 i = threadIdx.x; i < a.n_chrom; i += TPB) s_ctab[i] = a.chrom_tab[i];
@@ -272,17 +272,34 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                     }
                     len -= half;
                 }
+                // level 2: 16 quantised u16 keys of group g, relative to the previous group's exact key
+                typedef const __attribute__((address_space(3))) unsigned short *lds_cu16;
+                const u32 qb = (u32)(uintptr_t)(lds_cu16)reinterpret_cast<const unsigned short *>(s_q);
+                const u32 qsh = a.q_shift;
 #pragma unroll
                 for (int j = 0; j < TOK_QPT; ++j) {
                     const u32 v = *(lds_cu32)(uintptr_t)(pos[j] + 4u);
-                    pos[j] = ((pos[j] - tb) >> 2) + (v < gkey[j] ? 1u : 0u);  // first group with key >= gkey (or n_top)
+                    const u32 pg = pos[j] + (v < gkey[j] ? 4u : 0u);  // &top[g - 1], g = first group with key >= gkey
+                    const u32 g = (pg - tb) >> 2;                      // (n_top: beyond every key)
+                    const u32 base = g ? *(lds_cu32)(uintptr_t)pg : 0u;
+                    const u32 tq = (gkey[j] - base) >> qsh;
+                    const u32 gc = g < n_top ? g : n_top - 1u;
+                    u32 p2 = qb + gc * (2u * ACC_GROUP);
+#pragma unroll
+                    for (u32 half = ACC_GROUP / 2; half >= 1; half >>= 1) {
+                        const u32 v2 = *(lds_cu16)(uintptr_t)(p2 + 2u * half - 2u);
+                        p2 = v2 < tq ? p2 + 2u * half : p2;
+                    }
+                    const u32 v2 = *(lds_cu16)(uintptr_t)p2;
+                    const u32 u = ((p2 - qb) >> 1) + (v2 < tq ? 1u : 0u);
+                    pos[j] = g < n_top ? u : 0xFFFFFFFFu >> shift;  // unit index (no candidate: past every block)
                 }
             }
             GT_STAMP(t_c1);
             u32 b0[TOK_QPT];
 #pragma unroll
             for (int j = 0; j < TOK_QPT; ++j) {
-                u32 b = pos[j] << shift;  // first block of that group (>= be: no candidate)
+                u32 b = pos[j] << shift;  // first block of that unit (>= be: no candidate)
                 if (shift) {
                     // inside the group: first block with blk_last >= key
                     u32 l2 = b, n2 = (be[j] > b) ? min(1u << shift, be[j] - b) : 0u;
@@ -297,47 +314,43 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                 b0[j] = b;
             }
 
-            // ---- 2. one 128-byte record per query (4 independent fetches per thread) ----
-            u32 mask[TOK_QPT];
-            bool more[TOK_QPT];
-#pragma unroll
-            for (int j = 0; j < TOK_QPT; ++j) {
-                const bool act = b0[j] < be[j];
-                const u32 b = act ? b0[j] : 0u;
-                bool mr;
-                u32 m;
-                if (GTARS_ABLATE & 2) {
-                    m = (s[j] >> 3) & 1u;
-                    mr = false;
-                } else {
-                    m = block_mask8<FILTER>(a.blocks + (size_t)b * 8, s[j], e[j], min_bp, mr);
-                }
-                mask[j] = act ? m : 0u;
-                more[j] = act && mr;
-            }
-            GT_STAMP(t_c2);
+            // ---- 2. one burst of four 16-byte loads per query: starts, ends, ids (own + look-ahead) ----
             u32 tsum = 0;
             cur.more_bits = 0;
+            uint4 S[TOK_QPT], E[TOK_QPT], V[TOK_QPT], L[TOK_QPT];
+            bool act[TOK_QPT];
 #pragma unroll
             for (int j = 0; j < TOK_QPT; ++j) {
-                bool more2 = false;
-                if (more[j]) {
-                    // the query reaches past the block's last start: test the two look-ahead
-                    // intervals stored in the same record (an L1 hit)
-                    mask[j] |= lookahead_mask<FILTER>(a.blocks + (size_t)b0[j] * 8, s[j], e[j], min_bp, more2);
-                    more2 = more2 && (b0[j] + 1 < be[j]);
+                act[j] = b0[j] < be[j];
+                const uint4 *rec = a.blocks + (size_t)(act[j] ? b0[j] : 0u) * 4;
+                if (!(GTARS_ABLATE & 2)) {
+                    S[j] = rec[0];
+                    E[j] = rec[1];
+                    V[j] = rec[2];
+                    L[j] = rec[3];
+                } else {
+                    S[j] = make_uint4(s[j] ^ 8u, ~0u, ~0u, ~0u);
+                    E[j] = make_uint4(e[j], 0, 0, 0);
+                    V[j] = make_uint4(j, 0, 0, 0);
+                    L[j] = make_uint4(~0u, 0, 0, ~0u);
                 }
-                u32 n = __popc(mask[j]);
+            }
+            GT_STAMP(t_c2);
+#pragma unroll
+            for (int j = 0; j < TOK_QPT; ++j) {
+                bool mr;
+                u32 m = block_mask5<FILTER>(S[j], E[j], L[j], s[j], e[j], min_bp, mr);
+                m = act[j] ? m : 0u;
+                const bool more2 = act[j] && mr && (b0[j] + 1 < be[j]);
+                u32 n = __popc(m);
                 if (more2) n += walk_tail<FILTER>(a, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
                 tsum += n;
-                cur.st[j] = (b0[j] & B0_MASK) | (mask[j] << B0_BITS);
+                cur.st[j] = (b0[j] & B0_MASK) | (m << B0_BITS);
                 cur.more_bits |= (more2 ? 1u : 0u) << j;
-                // issue the id loads of the first two hits now; they are stored one tile later
-                u32 m = mask[j];
-                const u32 base = b0[j] * 32u;
-                cur.v0[j] = m ? blkw[base + val_word(__ffs((int)m) - 1)] : 0u;
-                m &= m - 1;
-                cur.v1[j] = m ? blkw[base + val_word(__ffs((int)m) - 1)] : 0u;
+                // ids of the first two hits, picked out of the ids quad (stored one tile later)
+                cur.v0[j] = (m & 1u) ? V[j].x : (m & 2u) ? V[j].y : (m & 4u) ? V[j].z : (m & 8u) ? V[j].w : L[j].z;
+                const u32 m2 = m & (m - 1u);
+                cur.v1[j] = (m2 & 2u) ? V[j].y : (m2 & 4u) ? V[j].z : (m2 & 8u) ? V[j].w : L[j].z;
             }
             GT_STAMP(t_c3);
 
@@ -396,7 +409,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                     while (m) {
                         const int k = __ffs((int)m) - 1;
                         m &= m - 1;
-                        if (o3 < cap) ovals[o3] = blkw[b0 * 32u + val_word(k)];
+                        if (o3 < cap) ovals[o3] = blkw[b0 * 16u + val_word(k)];
                         ++o3;
                     }
                     if (prev.more_bits & (1u << j)) {
@@ -404,7 +417,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                         const u32 be = s_ctab[cq].w;
                         u64 ot = o;
                         o += walk_tail<FILTER>(a, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
-                            if (ot < cap) ovals[ot] = blkw[b * 32u + 16u + (u32)k];
+                            if (ot < cap) ovals[ot] = blkw[b * 16u + 8u + (u32)k];
                             ++ot;
                         });
                     }
@@ -464,7 +477,7 @@ static int env_int(const char *name, int dflt) {
 
 static size_t tok_lds_bytes(const AccelView &a) {
     const size_t n_top_pad = ((size_t)a.n_top + 3) & ~(size_t)3;
-    return (n_top_pad + 4 * (size_t)a.n_chrom) * sizeof(u32);
+    return (n_top_pad + 8 * (size_t)a.n_top + 4 * (size_t)a.n_chrom) * sizeof(u32);
 }
 
 bool tokenize_lds_supported(const AccelView &a) {

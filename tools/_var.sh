@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export SIZES=1000000,64000000 CONFIGS=512:0:4,512:0:2,256:0:4,256:0:2,1024:0:2
-EXTRA="-DGTARS_TOK_PREFETCH=0" sh tools/ablate.sh 0 2>&1 | grep -v "^$"
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+export SIZES=1000000,64000000 CONFIGS=512:0:4,1024:0:4
+sh tools/ablate.sh "128 0" 2>&1 | grep -v "^$"
