@@ -199,21 +199,26 @@ struct gtars_index {
     std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
     // blocked acceleration structure (Bits kind), see AccelView in common.h
-    DevBuf<u32> acc_blocks, acc_blk_first, acc_top, acc_qkeys, acc_chrom_tab;
-    u32 acc_n_blocks = 0, acc_n_top = 0, acc_n_units = 0, acc_top_shift = 0, acc_q_shift = 0;
+    DevBuf<u32> acc_blocks, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab;
+    u32 acc_n_blocks = 0, acc_n_units = 0, acc_n_buckets = 0, acc_lut_words = 0, acc_q_words = 0;
+    u32 acc_lut_shift = 0, acc_q_shift = 0, acc_search_top = 0, acc_top_shift = 0;
     bool has_accel = false;
     AccelView accel() const {
         AccelView a;
         a.blocks = reinterpret_cast<const uint4 *>(acc_blocks.p);
         a.blk_first = acc_blk_first.p;
-        a.top = acc_top.p;
+        a.lut = acc_lut.p;
         a.qkeys = acc_qkeys.p;
         a.chrom_tab = reinterpret_cast<const uint4 *>(acc_chrom_tab.p);
         a.n_blocks = acc_n_blocks;
-        a.n_top = acc_n_top;
         a.n_units = acc_n_units;
-        a.top_shift = acc_top_shift;
+        a.n_buckets = acc_n_buckets;
+        a.lut_words = acc_lut_words;
+        a.q_words = acc_q_words;
+        a.lut_shift = acc_lut_shift;
         a.q_shift = acc_q_shift;
+        a.search_top = acc_search_top;
+        a.top_shift = acc_top_shift;
         a.n_chrom = n_chrom;
         return a;
     }
@@ -409,18 +414,19 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         ix->h_chrom_sub[n_chrom] = (u32)ix->h_sub_off.size();
     }
 
-    std::vector<u32> h_blocks, h_blk_first, h_top, h_q, h_cblk, h_ctab;
+    std::vector<u32> h_blocks, h_blk_first, h_lut, h_q, h_cblk, h_ctab;
     if (kind == GTARS_KIND_BITS && n > 0) {
-        // LDS budget of k_tok_lds: two workgroups per CU, each with its own copy of the level-1 keys
-        // (4 B per 16 units), the level-2 keys (2 B per unit) and the chromosome table (16 B each)
+        // LDS budget of k_tok_lds: two workgroups per CU, each with its own copy of the unit keys
+        // (2 B per unit), the bucket table (2 B per bucket, at most 4096 + 1) and the chromosome table
+        constexpr u32 kBucketMax = 4096;
         u32 unit_max = 1024;
         {
-            const long budget = 78 * 1024 - 16l * (long)n_chrom;
-            if (budget > 4096) unit_max = (u32)((budget * 4 / 9) / ACC_GROUP * ACC_GROUP);
+            const long budget = 78 * 1024 - 16l * (long)n_chrom - 2l * (kBucketMax + 8);
+            if (budget > 4096) unit_max = (u32)std::min<long>(budget / 2 / 8 * 8, 65528);  // lut entries are u16
         }
         if (const char *e = getenv("GTARS_TOP_MAX")) {
             const long v = atol(e);
-            if (v >= 64) unit_max = (u32)v;
+            if (v >= 64) unit_max = (u32)std::min<long>(v, 65528);
         }
         u32 shift = 0;
         for (;;) {
@@ -465,52 +471,59 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         }
         // Unit keys (last block of every 2^shift blocks) in one ascending key space: chromosome c's
         // keys live in [gbase[c], gbase[c] + span[c]], the upper end being the sentinel key.
-        // Consecutive chromosomes are 2^q_shift apart, so that the floor-quantised level-2 search can
+        // Consecutive chromosomes are 2^q_shift apart, so that the floor-quantised in-bucket search can
         // never stop on a block of an EARLIER chromosome (its keys quantise strictly below the target).
         const u32 n_units = nb >> shift;
-        const u32 n1 = (n_units + ACC_GROUP - 1) / ACC_GROUP;
         std::vector<u64> uk(n_units);
-        u32 qsh = 0;
+        u64 total = 0;
+        for (u32 c = 0; c < n_chrom; ++c) total += (off[c + 1] > off[c] ? (u64)ix->h_starts[off[c + 1] - 1] + 1 : 0) + 1;
+        // bucket width 2^lsh: the smallest that needs <= kBucketMax buckets (padding between chromosomes included)
+        u32 lsh = 4, qsh = 0;
+        for (;; ++lsh) {
+            qsh = lsh > 16 ? lsh - 16 : 0;
+            const u64 padded = total + (u64)n_chrom * (1ull << qsh);
+            if (((padded >> lsh) + 1) <= kBucketMax || lsh >= 40) break;
+        }
         u64 gbase = 0;
-        for (;;) {
-            h_ctab.assign((size_t)n_chrom * 4, 0);
-            gbase = 0;
-            for (u32 c = 0; c < n_chrom; ++c) {
-                const u64 span = off[c + 1] > off[c] ? (u64)ix->h_starts[off[c + 1] - 1] + 1 : 0;  // sorted by start
-                h_ctab[4 * (size_t)c + 0] = (u32)std::min<u64>(gbase, 0xFFFFFFFFu);
-                h_ctab[4 * (size_t)c + 1] = (u32)std::min<u64>(span, 0xFFFFFFFFu);
-                h_ctab[4 * (size_t)c + 2] = ix->h_chrom_aux[c];
-                h_ctab[4 * (size_t)c + 3] = h_cblk[c + 1];
-                for (u32 t = h_cblk[c] >> shift; t < (h_cblk[c + 1] >> shift); ++t)
-                    uk[t] = gbase + std::min<u64>(h_blk_first[(((size_t)t + 1) << shift) - 1], span);
-                gbase += span + (1ull << qsh);
-            }
-            u64 max_delta = 0;
-            for (u32 t = 0; t < n1; ++t) {
-                const u64 k = uk[std::min<u64>((u64)t * ACC_GROUP + ACC_GROUP - 1, n_units - 1)];
-                max_delta = std::max(max_delta, k - (t ? uk[(u64)t * ACC_GROUP - 1] : 0));
-            }
-            u32 need = 0;
-            while ((max_delta >> need) > 0xFFFEull) ++need;  // 0xFFFF is the padding value
-            if (need <= qsh) break;
-            qsh = need;
+        h_ctab.assign((size_t)n_chrom * 4, 0);
+        for (u32 c = 0; c < n_chrom; ++c) {
+            const u64 span = off[c + 1] > off[c] ? (u64)ix->h_starts[off[c + 1] - 1] + 1 : 0;  // sorted by start
+            h_ctab[4 * (size_t)c + 0] = (u32)std::min<u64>(gbase, 0xFFFFFFFFu);
+            h_ctab[4 * (size_t)c + 1] = (u32)std::min<u64>(span, 0xFFFFFFFFu);
+            h_ctab[4 * (size_t)c + 2] = ix->h_chrom_aux[c];
+            h_ctab[4 * (size_t)c + 3] = h_cblk[c + 1];
+            for (u32 t = h_cblk[c] >> shift; t < (h_cblk[c + 1] >> shift); ++t)
+                uk[t] = gbase + std::min<u64>(h_blk_first[(((size_t)t + 1) << shift) - 1], span);
+            gbase += span + (1ull << qsh);
         }
-        h_top.assign(((size_t)n1 + 3) & ~(size_t)3, 0xFFFFFFFFu);  // k_tok_lds copies it with 16-byte loads
-        for (u32 t = 0; t < n1; ++t)
-            h_top[t] = (u32)std::min<u64>(uk[std::min<u64>((u64)t * ACC_GROUP + ACC_GROUP - 1, n_units - 1)], 0xFFFFFFFFu);
-        std::vector<uint16_t> q16((size_t)n1 * ACC_GROUP, 0xFFFFu);
-        for (u32 u = 0; u < n_units; ++u) {
-            const u32 t = u / ACC_GROUP;
-            const u64 base = t ? uk[(u64)t * ACC_GROUP - 1] : 0;
-            q16[u] = (uint16_t)((uk[u] - base) >> qsh);
+        const u32 n_buckets = (u32)std::min<u64>((gbase >> lsh) + 1, 1u << 20);
+        std::vector<uint16_t> lut16(((size_t)n_buckets + 1 + 7) & ~(size_t)7, 0), q16(((size_t)n_units + 7) & ~(size_t)7, 0xFFFFu);
+        u32 max_occ = 0;
+        {
+            u32 u = 0;
+            for (u32 b = 0; b <= n_buckets; ++b) {
+                while (u < n_units && uk[u] < ((u64)b << lsh)) ++u;  // lut[b] = units with key < b << lsh
+                lut16[b] = (uint16_t)u;
+                if (b) max_occ = std::max<u32>(max_occ, (u32)lut16[b] - (u32)lut16[b - 1]);
+            }
+            for (size_t b = n_buckets + 1; b < lut16.size(); ++b) lut16[b] = (uint16_t)n_units;
         }
-        h_q.assign((size_t)n1 * ACC_GROUP / 2, 0);
+        for (u32 u = 0; u < n_units; ++u) q16[u] = (uint16_t)((uk[u] & ((1ull << lsh) - 1)) >> qsh);
+        u32 search_top = 0;  // in-bucket search covers ranges up to 2 * search_top - 1 units
+        while (2 * search_top < max_occ + 1) search_top = search_top ? search_top * 2 : 1;
+        h_lut.assign(lut16.size() / 2, 0);
+        memcpy(h_lut.data(), lut16.data(), lut16.size() * sizeof(uint16_t));
+        h_q.assign(q16.size() / 2, 0);
         memcpy(h_q.data(), q16.data(), q16.size() * sizeof(uint16_t));
         ix->acc_n_blocks = nb;
-        ix->acc_n_top = n1;
         ix->acc_n_units = n_units;
-        ix->acc_top_shift = shift;
+        ix->acc_n_buckets = n_buckets;
+        ix->acc_lut_words = (u32)h_lut.size();
+        ix->acc_q_words = (u32)h_q.size();
+        ix->acc_lut_shift = lsh;
         ix->acc_q_shift = qsh;
+        ix->acc_search_top = search_top;
+        ix->acc_top_shift = shift;
         // the global key space must fit 32 bits (hg38: 3.1e9); wider universes use the generic kernels
         ix->has_accel = nb > 0 && gbase <= 0xFFFFFFFFull;
     }
@@ -519,7 +532,7 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
     st = ix->starts.upload(ix->h_starts);
     if (!st && ix->has_accel) st = ix->acc_blocks.upload(h_blocks);
     if (!st && ix->has_accel) st = ix->acc_blk_first.upload(h_blk_first);
-    if (!st && ix->has_accel) st = ix->acc_top.upload(h_top);
+    if (!st && ix->has_accel) st = ix->acc_lut.upload(h_lut);
     if (!st && ix->has_accel) st = ix->acc_qkeys.upload(h_q);
     if (!st && ix->has_accel) st = ix->acc_chrom_tab.upload(h_ctab);
     if (!st) st = ix->ends.upload(ix->h_ends);
@@ -549,7 +562,7 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->sub_off.release();
     ix->acc_blocks.release();
     ix->acc_blk_first.release();
-    ix->acc_top.release();
+    ix->acc_lut.release();
     ix->acc_qkeys.release();
     ix->acc_chrom_tab.release();
     delete ix;

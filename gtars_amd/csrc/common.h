@@ -73,30 +73,33 @@ struct IndexView {
 // stop the forward scan).  blk_first[b] = the block's LAST own start (its
 // search key; 0xFFFFFFFF for partly filled blocks).
 //
-// Search keys kept in LDS by the workgroups, over "units" of 2^top_shift blocks
+// Search structure kept in LDS by the workgroups, over "units" of 2^top_shift blocks
 // (each chromosome's block range is padded to a multiple of 2^top_shift):
-//  * all keys live in ONE ascending key space: chromosome c's keys are offset by
-//    gbase[c] (sum of span+1 of the earlier chromosomes, span = max start + 1) and
-//    sentinel keys become gbase[c] + span[c]; every lane of a wave then searches
-//    the same range with the same scalar step sequence;
-//  * level 1 `top[g]`: exact u32 key of the last unit of every group of 16 units;
-//  * level 2 `qkeys[u]`: u16, (key(u) - top[g-1]) >> q_shift, floor-quantised.  The
-//    level-2 search may stop one unit early (never late); the record scan then
-//    simply walks on, so results stay exact.
+//  * all unit keys (last start of the unit's last block) live in ONE ascending key space:
+//    chromosome c's keys are offset by gbase[c] (sum of span + 2^q_shift of the earlier
+//    chromosomes, span = max start + 1) and sentinel keys become gbase[c] + span[c];
+//  * `lut[b]` (u16) = number of units whose key is < b << lut_shift: a direct-mapped table
+//    over the key space -- genomic positions spread evenly, so a bucket holds a handful of
+//    units and the search inside it takes `search_top` = 2^(steps-1) halving steps;
+//  * `qkeys[u]` (u16) = (key(u) mod 2^lut_shift) >> q_shift, floor-quantised.  The search
+//    may stop a unit early (never late, never in an earlier chromosome: those are 2^q_shift
+//    away); the record scan then simply walks on, so results stay exact.
 // chrom_tab[c] = {gbase, span, max_len, end of the chromosome's block range}.
 constexpr int ACC_BS = 3;
-constexpr int ACC_GROUP = 16;  // units per level-1 key
 struct AccelView {
     const uint4 *blocks;      // [n_blocks * 4] (64 B per block)
     const u32 *blk_first;     // [n_blocks] last own start of each block (local coordinates)
-    const u32 *top;           // [n_top] level-1 keys (global key space)
-    const u32 *qkeys;         // [n_top * 8] words = n_top * 16 u16 level-2 keys (0xFFFF padding)
+    const u32 *lut;           // [lut_words] packed u16, n_buckets + 1 entries (16-byte padded)
+    const u32 *qkeys;         // [q_words] packed u16, n_units entries (16-byte padded)
     const uint4 *chrom_tab;   // [n_chrom] {gbase, span, max_len, blk_end}
     u32 n_blocks;
-    u32 n_top;                // level-1 keys = ceil(n_units / 16)
     u32 n_units;
-    u32 top_shift;
+    u32 n_buckets;
+    u32 lut_words, q_words;   // multiples of 4
+    u32 lut_shift;
     u32 q_shift;
+    u32 search_top;           // first step of the in-bucket search (power of two, 0: buckets hold <= 0 units)
+    u32 top_shift;
     u32 n_chrom;
 };
 

@@ -140,18 +140,15 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     __shared__ u32 s_scan[NW];
     constexpr int TILE = TPB * TOK_QPT;
 
-    // LDS: level-1 keys (u32, padded to 4) | level-2 keys (u16, 16 per level-1 key) | chromosome table
-    const u32 n_top = a.n_top;
-    const u32 n_top_pad = (n_top + 3u) & ~3u;
-    u32 *s_top = smem;
-    u32 *s_q = smem + n_top_pad;                                             // n_top * 8 words
-    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + n_top_pad + n_top * 8);  // [n_chrom] {gbase, span, max_len, blk_end}
+    // LDS: bucket table (u16) | unit keys (u16) | chromosome table; both key arrays are padded to 16 bytes
+    u32 *s_lut = smem;
+    u32 *s_q = smem + a.lut_words;
+    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + a.lut_words + a.q_words);  // [n_chrom] {gbase, span, max_len, blk_end}
     {
-        // both key arrays are padded to 16 bytes on the device: 16-byte loads, 4 in flight.  Every
-        // workgroup copies the same arrays: start each one at a different place so that they do not
-        // all queue on the same L2 channel at the same time.
-        const u32 n4a = n_top_pad >> 2, n4 = n4a + n_top * 2;
-        const uint4 *src_a = reinterpret_cast<const uint4 *>(a.top);
+        // 16-byte loads, 4 in flight.  Every workgroup copies the same arrays: start each one at a
+        // different place so that they do not all queue on the same L2 channel at the same time.
+        const u32 n4a = a.lut_words >> 2, n4 = n4a + (a.q_words >> 2);
+        const uint4 *src_a = reinterpret_cast<const uint4 *>(a.lut);
         const uint4 *src_b = reinterpret_cast<const uint4 *>(a.qkeys);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const u32 rot = (u32)(((u64)blockIdx.x * 2654435761ull) % n4);
@@ -244,56 +241,42 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             // =============== count phase: 4 consecutive queries per thread ===============
 
             // ---- 1. search: first block whose LAST start is >= key (it holds the lower_bound) ----
-            // The top keys ascend over the whole array (AccelView), so all lanes run the same scalar
-            // (base, len) halving sequence: per step one add, one LDS read, one compare, one select.
-            u32 key[TOK_QPT], gkey[TOK_QPT], pos[TOK_QPT], be[TOK_QPT];
-#pragma unroll
-            for (int j = 0; j < TOK_QPT; ++j) {
-                const bool valid = c[j] < a.n_chrom;
-                const uint4 ct = s_ctab[valid ? c[j] : 0u];
-                key[j] = s[j] >= ct.z ? s[j] - ct.z : 0u;
-                gkey[j] = ct.x + (key[j] < ct.y ? key[j] : ct.y);  // beyond the last start: the sentinel key
-                be[j] = valid ? ct.w : 0u;                         // invalid -> empty range
-            }
+            // All unit keys live in one ascending key space (AccelView).  A direct-mapped bucket table
+            // narrows the range to a handful of units; the in-bucket search then runs the same scalar
+            // step sequence in every lane, clamped to the lane's own range: per step one add, one min,
+            // one LDS read, one compare, one select.
+            u32 key[TOK_QPT], pos[TOK_QPT], be[TOK_QPT];
             {
-                // pos[] holds LDS byte addresses (32-bit, address space 3) so a step needs no address math
-                typedef const __attribute__((address_space(3))) u32 *lds_cu32;
-                const u32 tb = (u32)(uintptr_t)(lds_cu32)s_top - 4u;  // &top[-1]
-#pragma unroll
-                for (int j = 0; j < TOK_QPT; ++j) pos[j] = tb;
-                u32 len = n_top;
-                while (len > 1) {
-                    const u32 half = len >> 1;
-#pragma unroll
-                    for (int j = 0; j < TOK_QPT; ++j) {
-                        const u32 cand = pos[j] + (half << 2);
-                        const u32 v = *(lds_cu32)(uintptr_t)cand;  // top[base + half - 1]
-                        pos[j] = v < gkey[j] ? cand : pos[j];
-                    }
-                    len -= half;
-                }
-                // level 2: 16 quantised u16 keys of group g, relative to the previous group's exact key
+                // LDS byte addresses (32-bit, address space 3) so that a step needs no address math
                 typedef const __attribute__((address_space(3))) unsigned short *lds_cu16;
+                const u32 lb = (u32)(uintptr_t)(lds_cu16)reinterpret_cast<const unsigned short *>(s_lut);
                 const u32 qb = (u32)(uintptr_t)(lds_cu16)reinterpret_cast<const unsigned short *>(s_q);
-                const u32 qsh = a.q_shift;
+                const u32 lsh = a.lut_shift, qsh = a.q_shift;
+                const u32 wmask = (1u << lsh) - 1u;
+                u32 tq[TOK_QPT], last[TOK_QPT];
 #pragma unroll
                 for (int j = 0; j < TOK_QPT; ++j) {
-                    const u32 v = *(lds_cu32)(uintptr_t)(pos[j] + 4u);
-                    const u32 pg = pos[j] + (v < gkey[j] ? 4u : 0u);  // &top[g - 1], g = first group with key >= gkey
-                    const u32 g = (pg - tb) >> 2;                      // (n_top: beyond every key)
-                    const u32 base = g ? *(lds_cu32)(uintptr_t)pg : 0u;
-                    const u32 tq = (gkey[j] - base) >> qsh;
-                    const u32 gc = g < n_top ? g : n_top - 1u;
-                    u32 p2 = qb + gc * (2u * ACC_GROUP);
-#pragma unroll
-                    for (u32 half = ACC_GROUP / 2; half >= 1; half >>= 1) {
-                        const u32 v2 = *(lds_cu16)(uintptr_t)(p2 + 2u * half - 2u);
-                        p2 = v2 < tq ? p2 + 2u * half : p2;
-                    }
-                    const u32 v2 = *(lds_cu16)(uintptr_t)p2;
-                    const u32 u = ((p2 - qb) >> 1) + (v2 < tq ? 1u : 0u);
-                    pos[j] = g < n_top ? u : 0xFFFFFFFFu >> shift;  // unit index (no candidate: past every block)
+                    const bool valid = c[j] < a.n_chrom;
+                    const uint4 ct = s_ctab[valid ? c[j] : 0u];
+                    key[j] = s[j] >= ct.z ? s[j] - ct.z : 0u;
+                    const u32 gkey = ct.x + (key[j] < ct.y ? key[j] : ct.y);  // beyond the last start: the sentinel key
+                    be[j] = valid ? ct.w : 0u;                                // invalid -> empty range
+                    const u32 la = lb + ((gkey >> lsh) << 1);
+                    const u32 lo = *(lds_cu16)(uintptr_t)la, hi = *(lds_cu16)(uintptr_t)(la + 2u);
+                    tq[j] = hi > lo ? (gkey & wmask) >> qsh : 0u;  // empty bucket: no key is < 0
+                    pos[j] = qb + (lo << 1) - 2u;                  // &q[lo - 1]
+                    last[j] = qb + (hi << 1) - 2u;                 // &q[hi - 1]
                 }
+                for (u32 step = a.search_top << 1; step >= 2; step >>= 1) {  // byte steps
+#pragma unroll
+                    for (int j = 0; j < TOK_QPT; ++j) {
+                        const u32 cand = min(pos[j] + step, last[j]);
+                        const u32 v = *(lds_cu16)(uintptr_t)cand;
+                        pos[j] = v < tq[j] ? cand : pos[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TOK_QPT; ++j) pos[j] = (pos[j] + 2u - qb) >> 1;  // first unit with key >= target
             }
             GT_STAMP(t_c1);
             u32 b0[TOK_QPT];
@@ -476,12 +459,11 @@ static int env_int(const char *name, int dflt) {
 }
 
 static size_t tok_lds_bytes(const AccelView &a) {
-    const size_t n_top_pad = ((size_t)a.n_top + 3) & ~(size_t)3;
-    return (n_top_pad + 8 * (size_t)a.n_top + 4 * (size_t)a.n_chrom) * sizeof(u32);
+    return ((size_t)a.lut_words + a.q_words + 4 * (size_t)a.n_chrom) * sizeof(u32);
 }
 
 bool tokenize_lds_supported(const AccelView &a) {
-    return a.n_blocks > 0 && a.n_blocks <= ((1u << 22) - 1u) && a.n_top > 0 && tok_lds_bytes(a) <= 120 * 1024;
+    return a.n_blocks > 0 && a.n_blocks <= ((1u << 22) - 1u) && a.n_units > 0 && tok_lds_bytes(a) <= 120 * 1024;
 }
 
 // launch geometry: threads per workgroup and queries per thread (a tile is TPB * QPT queries)
