@@ -208,6 +208,16 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                 c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
                 s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
                 e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
+            } else if constexpr (TOK_QPT == 8) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint4 c4 = *reinterpret_cast<const uint4 *>(qc + q0 + 4 * h);
+                    const uint4 s4 = *reinterpret_cast<const uint4 *>(qs + q0 + 4 * h);
+                    const uint4 e4 = *reinterpret_cast<const uint4 *>(qe + q0 + 4 * h);
+                    c[4 * h] = c4.x; c[4 * h + 1] = c4.y; c[4 * h + 2] = c4.z; c[4 * h + 3] = c4.w;
+                    s[4 * h] = s4.x; s[4 * h + 1] = s4.y; s[4 * h + 2] = s4.z; s[4 * h + 3] = s4.w;
+                    e[4 * h] = e4.x; e[4 * h + 1] = e4.y; e[4 * h + 2] = e4.z; e[4 * h + 3] = e4.w;
+                }
             } else {
                 const uint2 c2 = *reinterpret_cast<const uint2 *>(qc + q0);
                 const uint2 s2 = *reinterpret_cast<const uint2 *>(qs + q0);
@@ -240,100 +250,107 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             if (!GTARS_TOK_PREFETCH) load_queries(tile);
             // =============== count phase: 4 consecutive queries per thread ===============
 
-            // ---- 1. search: first block whose LAST start is >= key (it holds the lower_bound) ----
-            // All unit keys live in one ascending key space (AccelView).  A direct-mapped bucket table
-            // narrows the range to a handful of units; the in-bucket search then runs the same scalar
-            // step sequence in every lane, clamped to the lane's own range: per step one add, one min,
-            // one LDS read, one compare, one select.
-            u32 key[TOK_QPT], pos[TOK_QPT], be[TOK_QPT];
-            {
-                // LDS byte addresses (32-bit, address space 3) so that a step needs no address math
-                typedef const __attribute__((address_space(3))) unsigned short *lds_cu16;
-                const u32 lb = (u32)(uintptr_t)(lds_cu16)reinterpret_cast<const unsigned short *>(s_lut);
-                const u32 qb = (u32)(uintptr_t)(lds_cu16)reinterpret_cast<const unsigned short *>(s_q);
-                const u32 lsh = a.lut_shift, qsh = a.q_shift;
-                const u32 wmask = (1u << lsh) - 1u;
-                u32 tq[TOK_QPT], last[TOK_QPT];
-#pragma unroll
-                for (int j = 0; j < TOK_QPT; ++j) {
-                    const bool valid = c[j] < a.n_chrom;
-                    const uint4 ct = s_ctab[valid ? c[j] : 0u];
-                    key[j] = s[j] >= ct.z ? s[j] - ct.z : 0u;
-                    const u32 gkey = ct.x + (key[j] < ct.y ? key[j] : ct.y);  // beyond the last start: the sentinel key
-                    be[j] = valid ? ct.w : 0u;                                // invalid -> empty range
-                    const u32 la = lb + ((gkey >> lsh) << 1);
-                    const u32 lo = *(lds_cu16)(uintptr_t)la, hi = *(lds_cu16)(uintptr_t)(la + 2u);
-                    tq[j] = hi > lo ? (gkey & wmask) >> qsh : 0u;  // empty bucket: no key is < 0
-                    pos[j] = qb + (lo << 1) - 2u;                  // &q[lo - 1]
-                    last[j] = qb + (hi << 1) - 2u;                 // &q[hi - 1]
-                }
-                for (u32 step = a.search_top << 1; step >= 2; step >>= 1) {  // byte steps
-#pragma unroll
-                    for (int j = 0; j < TOK_QPT; ++j) {
-                        const u32 cand = min(pos[j] + step, last[j]);
-                        const u32 v = *(lds_cu16)(uintptr_t)cand;
-                        pos[j] = v < tq[j] ? cand : pos[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < TOK_QPT; ++j) pos[j] = (pos[j] + 2u - qb) >> 1;  // first unit with key >= target
-            }
-            GT_STAMP(t_c1);
-            u32 b0[TOK_QPT];
-#pragma unroll
-            for (int j = 0; j < TOK_QPT; ++j) {
-                u32 b = pos[j] << shift;  // first block of that unit (>= be: no candidate)
-                if (shift) {
-                    // inside the group: first block with blk_last >= key
-                    u32 l2 = b, n2 = (be[j] > b) ? min(1u << shift, be[j] - b) : 0u;
-                    while (n2 > 0) {
-                        const u32 half = n2 >> 1, mid = l2 + half;
-                        const bool pred = a.blk_first[mid] < key[j];
-                        l2 = pred ? mid + 1 : l2;
-                        n2 = pred ? n2 - half - 1 : half;
-                    }
-                    b = l2;
-                }
-                b0[j] = b;
-            }
-
-            // ---- 2. one burst of four 16-byte loads per query: starts, ends, ids (own + look-ahead) ----
+            // A thread's TOK_QPT consecutive queries go through search + record fetch in rounds of SUB = 4
+            // (the register budget of one burst); everything per tile -- ticket, scan, look-back,
+            // barriers -- is paid once for all of them.
+            constexpr int SUB = TOK_QPT < 4 ? TOK_QPT : 4;
             u32 tsum = 0;
             cur.more_bits = 0;
-            uint4 S[TOK_QPT], E[TOK_QPT], V[TOK_QPT], L[TOK_QPT];
-            bool act[TOK_QPT];
 #pragma unroll
-            for (int j = 0; j < TOK_QPT; ++j) {
-                act[j] = b0[j] < be[j];
-                const uint4 *rec = a.blocks + (size_t)(act[j] ? b0[j] : 0u) * 4;
-                if (!(GTARS_ABLATE & 2)) {
-                    S[j] = rec[0];
-                    E[j] = rec[1];
-                    V[j] = rec[2];
-                    L[j] = rec[3];
-                } else {
-                    S[j] = make_uint4(s[j] ^ 8u, ~0u, ~0u, ~0u);
-                    E[j] = make_uint4(e[j], 0, 0, 0);
-                    V[j] = make_uint4(j, 0, 0, 0);
-                    L[j] = make_uint4(~0u, 0, 0, ~0u);
+            for (int r0 = 0; r0 < TOK_QPT; r0 += SUB) {
+                // ---- 1. search: first block whose LAST start is >= key (it holds the lower_bound) ----
+                // All unit keys live in one ascending key space (AccelView).  A direct-mapped bucket table
+                // narrows the range to a handful of units; the in-bucket search then runs the same scalar
+                // step sequence in every lane, clamped to the lane's own range: per step one add, one min,
+                // one LDS read, one compare, one select.
+                u32 key[SUB], pos[SUB], be[SUB];
+                {
+                    // LDS byte addresses (32-bit, address space 3) so that a step needs no address math
+                    typedef const __attribute__((address_space(3))) unsigned short *lds_cu16;
+                    const u32 lb = (u32)(uintptr_t)(lds_cu16)reinterpret_cast<const unsigned short *>(s_lut);
+                    const u32 qb = (u32)(uintptr_t)(lds_cu16)reinterpret_cast<const unsigned short *>(s_q);
+                    const u32 lsh = a.lut_shift, qsh = a.q_shift;
+                    const u32 wmask = (1u << lsh) - 1u;
+                    u32 tq[SUB], last[SUB];
+#pragma unroll
+                    for (int j = 0; j < SUB; ++j) {
+                        const bool valid = c[r0 + j] < a.n_chrom;
+                        const uint4 ct = s_ctab[valid ? c[r0 + j] : 0u];
+                        key[j] = s[r0 + j] >= ct.z ? s[r0 + j] - ct.z : 0u;
+                        const u32 gkey = ct.x + (key[j] < ct.y ? key[j] : ct.y);  // beyond the last start: the sentinel key
+                        be[j] = valid ? ct.w : 0u;                                // invalid -> empty range
+                        const u32 la = lb + ((gkey >> lsh) << 1);
+                        const u32 lo = *(lds_cu16)(uintptr_t)la, hi = *(lds_cu16)(uintptr_t)(la + 2u);
+                        tq[j] = hi > lo ? (gkey & wmask) >> qsh : 0u;  // empty bucket: no key is < 0
+                        pos[j] = qb + (lo << 1) - 2u;                  // &q[lo - 1]
+                        last[j] = qb + (hi << 1) - 2u;                 // &q[hi - 1]
+                    }
+                    for (u32 step = a.search_top << 1; step >= 2; step >>= 1) {  // byte steps
+#pragma unroll
+                        for (int j = 0; j < SUB; ++j) {
+                            const u32 cand = min(pos[j] + step, last[j]);
+                            const u32 v = *(lds_cu16)(uintptr_t)cand;
+                            pos[j] = v < tq[j] ? cand : pos[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < SUB; ++j) pos[j] = (pos[j] + 2u - qb) >> 1;  // first unit with key >= target
                 }
-            }
-            GT_STAMP(t_c2);
+                GT_STAMP(t_c1);
+                u32 b0[SUB];
 #pragma unroll
-            for (int j = 0; j < TOK_QPT; ++j) {
-                bool mr;
-                u32 m = block_mask5<FILTER>(S[j], E[j], L[j], s[j], e[j], min_bp, mr);
-                m = act[j] ? m : 0u;
-                const bool more2 = act[j] && mr && (b0[j] + 1 < be[j]);
-                u32 n = __popc(m);
-                if (more2) n += walk_tail<FILTER>(a, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
-                tsum += n;
-                cur.st[j] = (b0[j] & B0_MASK) | (m << B0_BITS);
-                cur.more_bits |= (more2 ? 1u : 0u) << j;
-                // ids of the first two hits, picked out of the ids quad (stored one tile later)
-                cur.v0[j] = (m & 1u) ? V[j].x : (m & 2u) ? V[j].y : (m & 4u) ? V[j].z : (m & 8u) ? V[j].w : L[j].z;
-                const u32 m2 = m & (m - 1u);
-                cur.v1[j] = (m2 & 2u) ? V[j].y : (m2 & 4u) ? V[j].z : (m2 & 8u) ? V[j].w : L[j].z;
+                for (int j = 0; j < SUB; ++j) {
+                    u32 b = pos[j] << shift;  // first block of that unit (>= be: no candidate)
+                    if (shift) {
+                        // inside the group: first block with blk_last >= key
+                        u32 l2 = b, n2 = (be[j] > b) ? min(1u << shift, be[j] - b) : 0u;
+                        while (n2 > 0) {
+                            const u32 half = n2 >> 1, mid = l2 + half;
+                            const bool pred = a.blk_first[mid] < key[j];
+                            l2 = pred ? mid + 1 : l2;
+                            n2 = pred ? n2 - half - 1 : half;
+                        }
+                        b = l2;
+                    }
+                    b0[j] = b;
+                }
+
+                // ---- 2. one burst of four 16-byte loads per query: starts, ends, ids (own + look-ahead) ----
+                uint4 S[SUB], E[SUB], V[SUB], L[SUB];
+                bool act[SUB];
+#pragma unroll
+                for (int j = 0; j < SUB; ++j) {
+                    act[j] = b0[j] < be[j];
+                    const uint4 *rec = a.blocks + (size_t)(act[j] ? b0[j] : 0u) * 4;
+                    if (!(GTARS_ABLATE & 2)) {
+                        S[j] = rec[0];
+                        E[j] = rec[1];
+                        V[j] = rec[2];
+                        L[j] = rec[3];
+                    } else {
+                        S[j] = make_uint4(s[r0 + j] ^ 8u, ~0u, ~0u, ~0u);
+                        E[j] = make_uint4(e[r0 + j], 0, 0, 0);
+                        V[j] = make_uint4((u32)j, 0, 0, 0);
+                        L[j] = make_uint4(~0u, 0, 0, ~0u);
+                    }
+                }
+                GT_STAMP(t_c2);
+#pragma unroll
+                for (int j = 0; j < SUB; ++j) {
+                    bool mr;
+                    u32 m = block_mask5<FILTER>(S[j], E[j], L[j], s[r0 + j], e[r0 + j], min_bp, mr);
+                    m = act[j] ? m : 0u;
+                    const bool more2 = act[j] && mr && (b0[j] + 1 < be[j]);
+                    u32 n = __popc(m);
+                    if (more2) n += walk_tail<FILTER>(a, b0[j], be[j], s[r0 + j], e[r0 + j], min_bp, [](u32, int) {});
+                    tsum += n;
+                    cur.st[r0 + j] = (b0[j] & B0_MASK) | (m << B0_BITS);
+                    cur.more_bits |= (more2 ? 1u : 0u) << (r0 + j);
+                    // ids of the first two hits, picked out of the ids quad (stored one tile later)
+                    cur.v0[r0 + j] = (m & 1u) ? V[j].x : (m & 2u) ? V[j].y : (m & 4u) ? V[j].z : (m & 8u) ? V[j].w : L[j].z;
+                    const u32 m2 = m & (m - 1u);
+                    cur.v1[r0 + j] = (m2 & 2u) ? V[j].y : (m2 & 4u) ? V[j].z : (m2 & 8u) ? V[j].w : L[j].z;
+                }
             }
             GT_STAMP(t_c3);
 
@@ -419,8 +436,8 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             if (GTARS_ABLATE & 8) {
             } else if (off_vec_ok && q0 + TOK_QPT <= nq) {
                 ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(offsets + q0);
-                dst[0] = make_ulonglong2(o4[0], o4[1]);
-                if constexpr (TOK_QPT == 4) dst[1] = make_ulonglong2(o4[2], o4[3]);
+#pragma unroll
+                for (int h = 0; h < TOK_QPT / 2; ++h) dst[h] = make_ulonglong2(o4[2 * h], o4[2 * h + 1]);
             } else {
 #pragma unroll
                 for (int j = 0; j < TOK_QPT; ++j)
@@ -469,17 +486,17 @@ bool tokenize_lds_supported(const AccelView &a) {
 // launch geometry: threads per workgroup and queries per thread (a tile is TPB * QPT queries)
 static void choose_geometry(u64 nq, int &tpb, int &qpt) {
     // small batches: one big workgroup per CU (one LDS fill, one tile each); large: two 512-thread ones
-    tpb = nq >= (1ull << 24) ? 512 : 1024;
+    tpb = nq >= (1ull << 23) ? 512 : 1024;
     qpt = 4;
-    const int f_tpb = env_int("GTARS_TOK_TPB", 0);
-    if (f_tpb == 256 || f_tpb == 512 || f_tpb == 1024) tpb = f_tpb;
     const int f_q = env_int("GTARS_TOK_QPT", 0);
     if (f_q == 2 || f_q == 4) qpt = f_q;
+    const int f_tpb = env_int("GTARS_TOK_TPB", 0);
+    if (f_tpb == 512 || (f_tpb == 1024 && qpt == 4)) tpb = f_tpb;
 }
 
 size_t tokenize_lds_ws_bytes(u64 nq) {
-    // sized for the smallest tile (256 threads x 2 queries)
-    return scan_ws_bytes_for_tiles((nq + 256 * 2 - 1) / (256 * 2));
+    // sized for the smallest tile (512 threads x 2 queries)
+    return scan_ws_bytes_for_tiles((nq + 512 * 2 - 1) / (512 * 2));
 }
 
 template <int TPB, int TOK_QPT, bool FILTER>
@@ -571,12 +588,9 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     if (tpb == T && qpt == Q)                                                                 \
         return filter ? launch_tok_t<T, Q, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st)      \
                       : launch_tok_t<T, Q, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st);
-    GT_TOK_CASE(256, 4)
     GT_TOK_CASE(512, 4)
     GT_TOK_CASE(1024, 4)
-    GT_TOK_CASE(256, 2)
-    GT_TOK_CASE(512, 2)
-    GT_TOK_CASE(1024, 2)
+    GT_TOK_CASE(512, 2)  // experiments (GTARS_TOK_QPT): 8 queries per thread spills, 2 under-uses the bursts
 #undef GT_TOK_CASE
     return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");
 }

@@ -44,6 +44,22 @@ __global__ void __launch_bounds__(256) k_gather(const uint4 *__restrict__ tab, u
             if (MODE == 5) { uint4 v = p[lane & 1]; acc ^= v.x ^ v.w; }
             if (MODE == 14) { uint4 a = p[0], b = p[1], c = p[2]; acc ^= a.x ^ b.y ^ c.z; }
             if (MODE == 15) { const uint4 *q = tab + (size_t)(r % (n_lines * 2)) * 4; uint4 a = q[0], b = q[1], c = q[2]; acc ^= a.x ^ b.y ^ c.z; }
+            if (MODE == 16) { const uint2 *q = reinterpret_cast<const uint2 *>(tab + (size_t)(r % (n_lines * 2)) * 4); uint2 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = q[i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc ^= v[i].x ^ v[i].y; }
+            if (MODE == 17) { const u32 *q = reinterpret_cast<const u32 *>(tab + (size_t)(r % (n_lines * 2)) * 4); u32 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = q[i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc ^= v[i]; }
+            if (MODE == 18) { const uint2 *q = reinterpret_cast<const uint2 *>(tab + (size_t)(r % (n_lines * 2)) * 4); uint2 v[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) v[i] = q[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) acc ^= v[i].x ^ v[i].y; }
+            if (MODE == 19) { const uint4 *q = tab + (size_t)(r % (n_lines * 2)) * 4; uint4 a = q[0], b = q[1], c = q[2], d = q[3]; acc ^= a.x ^ b.y ^ c.z ^ d.w; }
             if (MODE == 7) { uint4 a = p[0], b = p[1]; acc ^= a.x ^ b.y; }
             if (MODE == 8) { uint4 a = p[0]; acc ^= a.x; if ((a.x ^ r) % 100u < 65u) { uint4 b = p[1 + (r >> 20) % 7]; acc ^= b.y; } }
             if (MODE == 9) { uint4 a = p[0], c = p[1]; acc ^= a.x ^ c.z; if ((a.x ^ r) % 100u < 65u) { uint4 b = p[2 + (r >> 20) % 6]; acc ^= b.y; } }
@@ -78,10 +94,14 @@ static void run(const char *name, const uint4 *tab, u32 n_lines, int wg_per_cu, 
 
 int main() {
     u32 *out; hipMalloc(&out, 256 * 16 * 256 * 4);
-    for (u32 n_lines : {12500u, 16700u}) {  // 1.6 MB (L2), 12.8 MB (MALL), 205 MB (HBM/MALL)
+    for (u32 n_lines : {16700u}) {  // 1.6 MB (L2), 12.8 MB (MALL), 205 MB (HBM/MALL)
         uint4 *tab; hipMalloc(&tab, (size_t)n_lines * 128);
         hipMemset(tab, 1, (size_t)n_lines * 128);
         for (int wg : {8}) {
+            run<19>("4 x x4, 64-B record", tab, n_lines, wg, out, 4, 64);
+            run<16>("8 x x2, 64-B record", tab, n_lines, wg, out, 8, 64);
+            run<17>("16 x dword, 64-B record", tab, n_lines, wg, out, 16, 64);
+            run<18>("6 x x2, 48 B of a 64-B record", tab, n_lines, wg, out, 6, 48);
             run<14>("3 x x4 same line", tab, n_lines, wg, out, 3, 48);
             run<15>("3 x x4, 64-B records (2 per line)", tab, n_lines, wg, out, 3, 48);
             run<7>("2 x x4 same line", tab, n_lines, wg, out, 2, 32);
