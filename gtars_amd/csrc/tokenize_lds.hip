@@ -140,28 +140,6 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     __shared__ u32 s_scan[NW];
     constexpr int TILE = TPB * TOK_QPT;
 
-    // LDS: bucket table (u16) | unit keys (u16) | chromosome table; both key arrays are padded to 16 bytes
-    u32 *s_lut = smem;
-    u32 *s_q = smem + a.lut_words;
-    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + a.lut_words + a.q_words);  // [n_chrom] {gbase, span, max_len, blk_end}
-    {
-        // 16-byte loads, 4 in flight.  Every workgroup copies the same arrays: start each one at a
-        // different place so that they do not all queue on the same L2 channel at the same time.
-        const u32 n4a = a.lut_words >> 2, n4 = n4a + (a.q_words >> 2);
-        const uint4 *src_a = reinterpret_cast<const uint4 *>(a.lut);
-        const uint4 *src_b = reinterpret_cast<const uint4 *>(a.qkeys);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        const u32 rot = (u32)(((u64)blockIdx.x * 2654435761ull) % n4);
-#pragma unroll 4
-        for (u32 i = threadIdx.x; i < n4; i += TPB) {
-            u32 k = i + rot;
-            k = k >= n4 ? k - n4 : k;
-            dst[k] = k < n4a ? src_a[k] : src_b[k - n4a];
-        }
-    }
-    for (u32 i = threadIdx.x; i < a.n_chrom; i += TPB) s_ctab[i] = a.chrom_tab[i];
-    __syncthreads();
-
     const u32 num_tiles = (u32)((nq + TILE - 1) / TILE);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec_ok = ((((uintptr_t)qc) | ((uintptr_t)qs) | ((uintptr_t)qe)) & 15u) == 0;
@@ -169,33 +147,6 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     const u32 shift = a.top_shift;
     const u32 *blkw = reinterpret_cast<const u32 *>(a.blocks);
 
-    // Software pipeline across tiles: a tile's hit count (its "aggregate") is
-    // published as soon as it is known, but its global base is resolved -- and
-    // its outputs written -- only after the NEXT tile has been counted.  By then
-    // every predecessor has had a whole tile time to publish, so the look-back
-    // rarely waits and its latency is off the critical path.
-    TileState<TOK_QPT> cur, prev;
-    bool have_prev = false;
-#if GTARS_ABLATE & 128
-    long long t_ticket = 0, t_count = 0, t_scan = 0, t_resolve = 0, t_write = 0, t_c1 = 0, t_c2 = 0, t_c3 = 0, t_mark;
-    const long long t_fill = clock64() - t_entry;
-#define GT_STAMP(acc) do { const long long _n = clock64(); acc += _n - t_mark; t_mark = _n; } while (0)
-    t_mark = clock64();
-#else
-#define GT_STAMP(acc) do { } while (0)
-#endif
-
-    // Tile assignment: the grid never exceeds what is resident at once (launcher), so every
-    // workgroup's FIRST tile is simply its block index -- no atomic while the whole grid starts up.
-    // Further tiles are drawn from a ticket counter, so a tile only ever waits on tiles that are
-    // already running, whatever the dispatch order.
-    //
-    // Latency plan: the ticket of the NEXT tile is drawn (one lane, asynchronously) before the
-    // current tile is counted and handed round through the scan's barrier; the next tile's queries
-    // are loaded into the (by then dead) query registers right after the count phase, so the HBM
-    // stream stays in flight through the scan / resolve / write of the previous tile.  vmcnt retires
-    // in order, so that prefetch is placed AFTER the record fetches of the count phase, and wave 0
-    // issues it only after its look-back loads.
     u32 c[TOK_QPT], s[TOK_QPT], e[TOK_QPT];
     auto load_queries = [&](u32 t) {
         const u64 q0 = (u64)t * TILE + (u64)threadIdx.x * TOK_QPT;
@@ -236,9 +187,61 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             }
         }
     };
+    // the first tile's queries come from HBM: issue their loads before the LDS fill so that both overlap
+    load_queries(blockIdx.x);
+
+    // LDS: bucket table (u16) | unit keys (u16) | chromosome table; both key arrays are padded to 16 bytes
+    u32 *s_lut = smem;
+    u32 *s_q = smem + a.lut_words;
+    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + a.lut_words + a.q_words);  // [n_chrom] {gbase, span, max_len, blk_end}
+    {
+        // 16-byte loads, 4 in flight.  Every workgroup copies the same arrays: start each one at a
+        // different place so that they do not all queue on the same L2 channel at the same time.
+        const u32 n4a = a.lut_words >> 2, n4 = n4a + (a.q_words >> 2);
+        const uint4 *src_a = reinterpret_cast<const uint4 *>(a.lut);
+        const uint4 *src_b = reinterpret_cast<const uint4 *>(a.qkeys);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const u32 rot = (u32)(((u64)blockIdx.x * 2654435761ull) % n4);
+#pragma unroll 4
+        for (u32 i = threadIdx.x; i < n4; i += TPB) {
+            u32 k = i + rot;
+            k = k >= n4 ? k - n4 : k;
+            dst[k] = k < n4a ? src_a[k] : src_b[k - n4a];
+        }
+    }
+    for (u32 i = threadIdx.x; i < a.n_chrom; i += TPB) s_ctab[i] = a.chrom_tab[i];
+    __syncthreads();
+
+    // Software pipeline across tiles: a tile's hit count (its "aggregate") is
+    // published as soon as it is known, but its global base is resolved -- and
+    // its outputs written -- only after the NEXT tile has been counted.  By then
+    // every predecessor has had a whole tile time to publish, so the look-back
+    // rarely waits and its latency is off the critical path.
+    TileState<TOK_QPT> cur, prev;
+    bool have_prev = false;
+#if GTARS_ABLATE & 128
+    long long t_ticket = 0, t_count = 0, t_scan = 0, t_resolve = 0, t_write = 0, t_c1 = 0, t_c2 = 0, t_c3 = 0, t_mark;
+    const long long t_fill = clock64() - t_entry;
+#define GT_STAMP(acc) do { const long long _n = clock64(); acc += _n - t_mark; t_mark = _n; } while (0)
+    t_mark = clock64();
+#else
+#define GT_STAMP(acc) do { } while (0)
+#endif
+
+    // Tile assignment: the grid never exceeds what is resident at once (launcher), so every
+    // workgroup's FIRST tile is simply its block index -- no atomic while the whole grid starts up.
+    // Further tiles are drawn from a ticket counter, so a tile only ever waits on tiles that are
+    // already running, whatever the dispatch order.
+    //
+    // Latency plan: the ticket of the NEXT tile is drawn (one lane, asynchronously) before the
+    // current tile is counted and handed round through the scan's barrier; the next tile's queries
+    // are loaded into the (by then dead) query registers right after the count phase, so the HBM
+    // stream stays in flight through the scan / resolve / write of the previous tile.  vmcnt retires
+    // in order, so that prefetch is placed AFTER the record fetches of the count phase, and wave 0
+    // issues it only after its look-back loads.
     const bool draw = num_tiles > gridDim.x;  // otherwise one tile per workgroup: nothing to draw
     u32 tile = blockIdx.x;
-    if (GTARS_TOK_PREFETCH) load_queries(tile);
+    bool loaded = true;  // the first tile's queries are already in flight
     for (;;) {
         const bool has_cur = tile < num_tiles;
         u32 next_tile = num_tiles;
@@ -247,7 +250,8 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         if (has_cur) {
             u32 ticket = 0;
             if (draw && threadIdx.x == 0) ticket = atomicAdd(&ws->ticket, 1u);  // consumed after the count phase
-            if (!GTARS_TOK_PREFETCH) load_queries(tile);
+            if (!GTARS_TOK_PREFETCH && !loaded) load_queries(tile);
+            loaded = false;
             // =============== count phase: 4 consecutive queries per thread ===============
 
             // A thread's TOK_QPT consecutive queries go through search + record fetch in rounds of SUB = 4

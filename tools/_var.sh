@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-GTARS_TOK_QPT=8 GTARS_TOK_TPB=512 timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-SIZES=16000000,64000000,256000000 CONFIGS=512:0:4,512:0:8,1024:0:8 python tools/kbench.py
+export SIZES=1000000 CONFIGS=1024:0:4
+sh tools/ablate.sh "128 0 2 12 30" 2>&1 | grep -v "^$"
