@@ -51,8 +51,10 @@ def main(src, dst):
         "write_bytes_per_launch": write,
         "traffic_bytes_per_launch": fetch + write,
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-        "note": "fetch = 12.0 MB query stream + ~13 MB index (1.6 MB of block records + 50 KB top level pulled "
-                "into each of the 8 XCD L2s); writes match 8*(Nq+1)+4*H exactly",
+        "note": "fetch = 12.0 MB query stream + 8 x 2.2 MB index (2.13 MB of 64-B block records + 75 KB of LDS search "
+                "keys, pulled once into each of the 8 non-coherent XCD L2s; FETCH_SIZE counts L2->fabric requests, so the "
+                "7 repeat copies are most likely served by the 256 MB Infinity Cache rather than HBM); writes match "
+                "8*(Nq+1)+4*H exactly",
     }
     json.dump(doc, open(f"{dst}/traffic_tokenize_1M.json", "w"), indent=1)
     igd = glob.glob(f"{src}/igd/**/*kernel_stats.csv", recursive=True)
