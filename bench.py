@@ -236,7 +236,7 @@ def main():
         }
         if sweep:
             out["batch_sweep"] = sweep
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(u, q)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -33,21 +33,34 @@ constexpr int IGD_SEEN = 32;   // per-thread list of credited files (binary coun
 // ---- query preparation: validity rules of Igd::count_overlaps (igd.rs:514-517) ------------------
 __global__ void k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
                                    u32 nq, u32 n_chrom, u32 *__restrict__ kc, u32 *__restrict__ ks,
-                                   u32 *__restrict__ ke) {
+                                   u32 *__restrict__ ke, u32 *__restrict__ unsorted) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
-    i32 s = (i32)qs[i], e = (i32)qe[i];  // `as i32` (igd.rs:549-550)
-    u32 c = qc[i];
-    if (s >= e || e <= 0 || c >= n_chrom) {
-        c = n_chrom;  // sorts behind every real chromosome; never served
-        s = 0;
-        e = 0;
-    } else if (s < 0) {
-        s = 0;  // clamp (igd.rs:517)
-    }
+    auto prep = [&](u32 k, u32 &c, i32 &s, i32 &e) {
+        s = (i32)qs[k];
+        e = (i32)qe[k];  // `as i32` (igd.rs:549-550)
+        c = qc[k];
+        if (s >= e || e <= 0 || c >= n_chrom) {
+            c = n_chrom;  // sorts behind every real chromosome; never served
+            s = 0;
+            e = 0;
+        } else if (s < 0) {
+            s = 0;  // clamp (igd.rs:517)
+        }
+    };
+    u32 c;
+    i32 s, e;
+    prep(i, c, s, e);
     kc[i] = c;
     ks[i] = (u32)s;
     ke[i] = (u32)e;
+    if (i > 0) {
+        // already in (chromosome, start) order?  then the sweep can skip its sort (BED inputs usually are)
+        u32 pc;
+        i32 ps, pe;
+        prep(i - 1, pc, ps, pe);
+        if (pc > c || (pc == c && (u32)ps > (u32)s)) *unsorted = 1u;
+    }
 }
 
 // first index in [lo, hi) with a[i] >= key
@@ -208,16 +221,29 @@ gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32
     void *sort_ws = (void *)(((uintptr_t)(cq_off + v.n_chrom + 2) + 63) & ~(uintptr_t)63);
     const size_t sort_ws_bytes = device_sort_perm_ws_bytes(nq);
     const unsigned g = (nq + 255) / 256;
+    u32 *d_unsorted = (u32 *)((char *)ws + igd_sweep_ws_bytes(nq, n_tiles, v.n_chrom) - 64);  // inside the slack
+    GT_HIP(hipMemsetAsync(d_unsorted, 0, sizeof(u32), st));
     {
         ProfScope p("k_igd_prep_queries", st);
-        hipLaunchKernelGGL(k_igd_prep_queries, dim3(g), dim3(256), 0, st, qc, qs, qe, nq, v.n_chrom, kc, ks, ke);
+        hipLaunchKernelGGL(k_igd_prep_queries, dim3(g), dim3(256), 0, st, qc, qs, qe, nq, v.n_chrom, kc, ks, ke, d_unsorted);
     }
-    // K1: order the queries by (chromosome, start)
-    gtars_status s1 = device_sort_perm_ws(kc, ks, nullptr, nq, v.n_chrom + 1, perm, sort_ws, sort_ws_bytes, st);
-    if (s1) return s1;
-    if ((s1 = device_gather_u32(kc, perm, nq, sc, st))) return s1;
-    if ((s1 = device_gather_u32(ks, perm, nq, ss, st))) return s1;
-    if ((s1 = device_gather_u32(ke, perm, nq, se, st))) return s1;
+    u32 h_unsorted = 1;
+    if (!getenv("GTARS_IGD_ALWAYS_SORT")) {
+        GT_HIP(hipMemcpyAsync(&h_unsorted, d_unsorted, sizeof(u32), hipMemcpyDeviceToHost, st));
+        GT_HIP(hipStreamSynchronize(st));
+    }
+    if (h_unsorted) {
+        // K1: order the queries by (chromosome, start)
+        gtars_status s1 = device_sort_perm_ws(kc, ks, nullptr, nq, v.n_chrom + 1, perm, sort_ws, sort_ws_bytes, st);
+        if (s1) return s1;
+        if ((s1 = device_gather_u32(kc, perm, nq, sc, st))) return s1;
+        if ((s1 = device_gather_u32(ks, perm, nq, ss, st))) return s1;
+        if ((s1 = device_gather_u32(ke, perm, nq, se, st))) return s1;
+    } else {
+        sc = kc;  // the batch is in (chromosome, start) order already
+        ss = ks;
+        se = ke;
+    }
     {
         ProfScope p("k_igd_tile_ranges", st);
         hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, sc, nq, v.n_chrom, cq_off);

@@ -530,3 +530,37 @@ def test_igd_sweep_matches_oracle(ga, monkeypatch, seed, n, nq, F, span, wmax):
     # and the per-query kernel gives the same vectors
     monkeypatch.setenv("GTARS_NO_IGD_SWEEP", "1")
     assert g.count_region_hits(qc, qs, qe, 1).tolist() == o.count_region_hits(qc, qs, qe, 1, n_files=F).tolist()
+
+
+def test_igd_sweep_presorted_batch_skips_the_sort(ga, monkeypatch):
+    """A batch already in (chromosome, start) order takes the sweep without the device sort; same vectors
+    as the oracle and as the forced-sort path."""
+    monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
+    rng = np.random.default_rng(321)
+    n, nq, F, n_chrom, span = 40_000, 30_000, 64, 4, 500_000
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 2_000, n)
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=n_chrom, n_files=F)
+    qc = rng.integers(0, n_chrom, nq)
+    qs = rng.integers(0, span, nq).astype(np.int64)
+    order = np.lexsort((qs, qc))
+    qc, qs = qc[order], qs[order]
+    qe = qs + rng.integers(1, 3_000, nq)
+    qc = np.concatenate([qc, np.full(50, UNK)])  # unknown chromosomes sort last
+    qs = np.concatenate([qs, rng.integers(0, span, 50)])
+    qe = np.concatenate([qe, qs[-50:] + 10])
+    exp_p = o.count_set_overlaps(qc, qs, qe, 1, n_files=F).tolist()
+    exp_b = o.count_region_hits(qc, qs, qe, 1, n_files=F).tolist()
+    _lib = ga._lib
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == exp_p
+    assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
+    names = set(_lib.prof_read())
+    _lib.lib.gtars_prof_enable(0)
+    assert any(k.startswith("k_igd_sweep") for k in names) and "k_radix_scatter" not in names, names
+    monkeypatch.setenv("GTARS_IGD_ALWAYS_SORT", "1")
+    assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == exp_p
+    assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
