@@ -416,12 +416,12 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
 
     std::vector<u32> h_blocks, h_blk_first, h_lut, h_q, h_cblk, h_ctab;
     if (kind == GTARS_KIND_BITS && n > 0) {
-        // LDS budget of k_tok_lds: two workgroups per CU, each with its own copy of the unit keys
+        // LDS budget of k_tok_lds: one 1024-thread workgroup per CU with its copy of the unit keys
         // (2 B per unit), the bucket table (2 B per bucket, at most 4096 + 1) and the chromosome table
         constexpr u32 kBucketMax = 4096;
         u32 unit_max = 1024;
         {
-            const long budget = 78 * 1024 - 16l * (long)n_chrom - 2l * (kBucketMax + 8);
+            const long budget = 148 * 1024 - 16l * (long)n_chrom - 2l * (kBucketMax + 8);
             if (budget > 4096) unit_max = (u32)std::min<long>(budget / 2 / 8 * 8, 65528);  // lut entries are u16
         }
         if (const char *e = getenv("GTARS_TOP_MAX")) {
