@@ -78,6 +78,8 @@ _SIG = {
     "gtars_tokenize": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
     "gtars_count_overlaps_device": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, vp]),
     "gtars_count_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp]),
+    "gtars_bits_count_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp]),
+    "gtars_bits_count": (C.c_int, [vp, vp, vp, vp, u64, vp]),
     "gtars_any_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp]),
     "gtars_find_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, pp, pp, pp, pu64]),
     "gtars_find_overlap_indices": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, pp, pu64]),

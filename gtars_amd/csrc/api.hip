@@ -203,6 +203,10 @@ struct gtars_index {
     u32 acc_n_blocks = 0, acc_n_units = 0, acc_n_buckets = 0, acc_lut_words = 0, acc_q_words = 0;
     u32 acc_lut_shift = 0, acc_q_shift = 0, acc_search_top = 0, acc_top_shift = 0;
     bool has_accel = false;
+    // per-chromosome sorted copy of the ends, built on the first Bits::count call (bits.rs:118-121)
+    mutable std::mutex ends_mu;
+    mutable DevBuf<u32> ends_sorted;
+    mutable bool ends_ready = false;
     AccelView accel() const {
         AccelView a;
         a.blocks = reinterpret_cast<const uint4 *>(acc_blocks.p);
@@ -563,6 +567,7 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->acc_blocks.release();
     ix->acc_blk_first.release();
     ix->acc_lut.release();
+    ix->ends_sorted.release();
     ix->acc_qkeys.release();
     ix->acc_chrom_tab.release();
     delete ix;
@@ -835,6 +840,49 @@ gtars_status gtars_count_overlaps(const gtars_index_t *ix, const uint32_t *qc, c
     st = launch_count(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d.as<u32>(), nullptr, nullptr);
     if (st) return st;
     GT_HIP(hipMemcpy(counts, d.p, nq * 4, hipMemcpyDeviceToHost));
+    return GTARS_OK;
+}
+
+static gtars_status bits_count_prepare(const gtars_index_t *ix) {
+    if (ix->kind != GTARS_KIND_BITS) return fail(GTARS_ERR_INVALID_ARG, "Bits::count needs a Bits-kind index");
+    std::lock_guard<std::mutex> lk(ix->ends_mu);
+    if (ix->ends_ready) return GTARS_OK;
+    std::vector<u32> e(ix->h_ends);
+    for (u32 c = 0; c < ix->n_chrom; ++c) std::sort(e.begin() + ix->h_chrom_off[c], e.begin() + ix->h_chrom_off[c + 1]);
+    gtars_status st = ix->ends_sorted.upload(e);
+    if (st) return st;
+    ix->ends_ready = true;
+    return GTARS_OK;
+}
+
+gtars_status gtars_bits_count_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
+                                     const uint32_t *d_qe, uint64_t nq, uint64_t *d_counts, void *stream) {
+    if (!ix) return fail(GTARS_ERR_INVALID_ARG, "index is NULL");
+    if (nq && (!d_qc || !d_qs || !d_qe || !d_counts)) return fail(GTARS_ERR_INVALID_ARG, "NULL device pointer");
+    gtars_status st = require_device();
+    if (st) return st;
+    if ((st = bits_count_prepare(ix))) return st;
+    return launch_bits_count(ix->view(), ix->ends_sorted.p, d_qc, d_qs, d_qe, nq, (u64 *)d_counts, (hipStream_t)stream);
+}
+
+gtars_status gtars_bits_count(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+                              uint64_t nq, uint64_t *counts) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (nq && !counts) return fail(GTARS_ERR_INVALID_ARG, "counts is NULL");
+    st = require_device();
+    if (st) return st;
+    if ((st = bits_count_prepare(ix))) return st;
+    if (!nq) return GTARS_OK;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d;
+    st = d.alloc(nq * 8);
+    if (st) return st;
+    st = launch_bits_count(ix->view(), ix->ends_sorted.p, q.c, q.s, q.e, nq, d.as<u64>(), nullptr);
+    if (st) return st;
+    GT_HIP(hipMemcpy(counts, d.p, nq * 8, hipMemcpyDeviceToHost));
     return GTARS_OK;
 }
 

@@ -405,6 +405,49 @@ static unsigned stream_grid(u64 n, int tpb) {
     return (unsigned)g;
 }
 
+// Bits::count (bits.rs:337-344): len - #{ends < start + 1} - #{starts >= stop} by two runs of the reference's
+// bsearch_seq (bits.rs:304-322) over the separately sorted starts / ends.  `start + 1` wraps and the final
+// subtraction wraps, as release-mode Rust does (the result differs from find().len() only for zero-length
+// or inverted queries).
+__device__ __forceinline__ u64 bsearch_seq_dev(u32 key, const u32 *__restrict__ elems, u64 n) {
+    if (n == 0 || elems[0] >= key) return 0;
+    if (elems[n - 1] < key) return n;
+    u64 cursor = 0, length = n;
+    while (length > 1) {
+        const u64 half = length >> 1;
+        length -= half;
+        cursor += (elems[cursor + half - 1] < key) ? half : 0;
+    }
+    return cursor;
+}
+
+__global__ void k_bits_count(IndexView v, const u32 *__restrict__ ends_sorted, const u32 *__restrict__ qc,
+                             const u32 *__restrict__ qs, const u32 *__restrict__ qe, u64 nq, u64 *__restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (u64)gridDim.x * blockDim.x) {
+        const u32 c = qc[i];
+        u64 r = 0;
+        if (c < v.n_chrom) {
+            const u32 lo = v.chrom_off[c], hi = v.chrom_off[c + 1];
+            const u64 len = hi - lo;
+            if (len) {  // a chromosome without intervals has no index (MultiChromOverlapper: count 0)
+                const u64 first = bsearch_seq_dev(qs[i] + 1u, ends_sorted + lo, len);
+                const u64 last = bsearch_seq_dev(qe[i], v.starts + lo, len);
+                r = len - first - (len - last);
+            }
+        }
+        out[i] = r;
+    }
+}
+
+gtars_status launch_bits_count(const IndexView &v, const u32 *ends_sorted, const u32 *qc, const u32 *qs, const u32 *qe,
+                               u64 nq, u64 *out, hipStream_t st) {
+    if (nq == 0) return GTARS_OK;
+    ProfScope p("k_bits_count", st);
+    hipLaunchKernelGGL(k_bits_count, dim3(stream_grid(nq, 256)), dim3(256), 0, st, v, ends_sorted, qc, qs, qe, nq, out);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
 gtars_status launch_count(const IndexView &v, int kind, const u32 *qc, const u32 *qs, const u32 *qe,
                           u64 nq, int has_min, i32 min_overlap, u32 *counts, u8 *any, hipStream_t st) {
     if (nq == 0) return GTARS_OK;

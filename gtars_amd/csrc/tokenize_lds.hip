@@ -513,7 +513,7 @@ static void choose_geometry(u64 nq, int &tpb, int &qpt) {
     const int f_q = env_int("GTARS_TOK_QPT", 0);
     if (f_q == 2 || f_q == 4) qpt = f_q;
     const int f_tpb = env_int("GTARS_TOK_TPB", 0);
-    if (f_tpb == 512 || (f_tpb == 1024 && qpt == 4)) tpb = f_tpb;
+    if (f_tpb == 512 || f_tpb == 1024) tpb = f_tpb;
 }
 
 size_t tokenize_lds_ws_bytes(u64 nq) {
@@ -612,6 +612,7 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
                       : launch_tok_t<T, Q, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st);
     GT_TOK_CASE(512, 4)
     GT_TOK_CASE(1024, 4)
+    GT_TOK_CASE(1024, 2)
     GT_TOK_CASE(512, 2)  // experiments (GTARS_TOK_QPT): 8 queries per thread spills, 2 under-uses the bursts
 #undef GT_TOK_CASE
     return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");

@@ -94,6 +94,13 @@ class OverlapIndex:
         check(lib.gtars_count_overlaps(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), hm, mo, ptr(out)))
         return out
 
+    def bits_count(self, qc, qs, qe) -> np.ndarray:
+        """Bits::count (bits.rs:337-344) per query: u64, the reference's wrapping arithmetic included."""
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        out = np.zeros(len(qc), dtype=np.uint64)
+        check(lib.gtars_bits_count(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), ptr(out)))
+        return out
+
     def any_overlaps(self, qc, qs, qe, min_overlap: Optional[int] = None) -> np.ndarray:
         qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
         out = np.zeros(len(qc), dtype=np.uint8)

@@ -147,6 +147,15 @@ gtars_status gtars_count_overlaps(const gtars_index_t *ix, const uint32_t *qchro
                                   const uint32_t *qstart, const uint32_t *qend,
                                   uint64_t nq, int has_min, int32_t min_overlap,
                                   uint32_t *counts);
+/* Bits::count (gtars-overlaprs/src/bits.rs:337-344, bsearch_seq :304-322): per query
+ * len - #{ends < start+1} - #{starts >= stop} on the chromosome's separately sorted starts / ends,
+ * with the reference's wrapping arithmetic (equals find().len() except for zero-length / inverted
+ * queries).  Bits-kind indexes only; unknown chromosome -> 0.  Counts are u64 (Rust usize). */
+gtars_status gtars_bits_count_device(const gtars_index_t *ix, const uint32_t *d_qchrom,
+                                     const uint32_t *d_qstart, const uint32_t *d_qend, uint64_t nq,
+                                     uint64_t *d_counts, void *stream);
+gtars_status gtars_bits_count(const gtars_index_t *ix, const uint32_t *qchrom, const uint32_t *qstart,
+                              const uint32_t *qend, uint64_t nq, uint64_t *counts);
 gtars_status gtars_any_overlaps(const gtars_index_t *ix, const uint32_t *qchrom,
                                 const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
                                 int has_min, int32_t min_overlap, uint8_t *out);

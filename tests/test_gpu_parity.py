@@ -564,3 +564,32 @@ def test_igd_sweep_presorted_batch_skips_the_sort(ga, monkeypatch):
     monkeypatch.setenv("GTARS_IGD_ALWAYS_SORT", "1")
     assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == exp_p
     assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
+
+
+def test_bits_count_matches_reference_formula(ga):
+    """Bits::count (bits.rs:337-344): equal to the oracle's restatement bit for bit -- including the wrapping
+    results for zero-length / inverted queries -- and equal to find().len() for ordinary queries."""
+    rng = np.random.default_rng(77)
+    n, nq, n_chrom = 30_000, 20_000, 5
+    c = rng.integers(0, n_chrom - 1, n)          # the last chromosome stays empty
+    s = rng.integers(0, 1_000_000, n)
+    e = s + rng.integers(1, 3_000, n)
+    g, o = _pair(ga, c, s, e, n_chrom=n_chrom, kind=KIND_BITS)
+    qc = rng.integers(0, n_chrom + 1, nq)
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, 1_000_000, nq)
+    qe = qs + rng.integers(1, 5_000, nq)
+    k = rng.integers(0, nq, 500)
+    qe[k] = np.maximum(qs[k] - rng.integers(0, 50, 500), 0)   # zero-length and inverted
+    qs[:5] = 0xFFFFFFFF                                          # start + 1 wraps
+    got = g.bits_count(qc, qs, qe)
+    exp = np.array([o.bits_count(int(a) if a != UNK else 0xFFFFFFFF, int(b), int(d)) for a, b, d in zip(qc, qs, qe)],
+                   dtype=np.uint64)
+    assert np.array_equal(got, exp)
+    ordinary = (qe > qs) & (qs != 0xFFFFFFFF)
+    assert np.array_equal(got[ordinary], g.count_overlaps(qc, qs, qe)[ordinary].astype(np.uint64))
+    # the reference KAT (bits.rs tests / tests/test_oracle_golden.py)
+    g2, o2 = _pair(ga, np.zeros(3, dtype=np.uint32), [1, 5, 10], [6, 9, 15], n_chrom=1, kind=KIND_BITS)
+    assert g2.bits_count([0], [5], [11]).tolist() == [o2.bits_count(0, 5, 11)]
+    with pytest.raises(Exception):
+        ga.OverlapIndex(c, s, e, n_chrom=n_chrom, kind=KIND_AILIST).bits_count(qc[:4], qs[:4], qe[:4])
