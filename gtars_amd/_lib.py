@@ -151,6 +151,17 @@ _HOST_SIG = {
     "gtars_fragment_tokens_free": (None, [C.POINTER(FragmentTokens)]),
     "gtars_gtok_write": (C.c_int, [cstr, vp, u64]),
     "gtars_gtok_read": (C.c_int, [cstr, pp, pu64]),
+    "gtars_fragments_read": (C.c_int, [cstr, pp]),
+    "gtars_fragments_free": (None, [vp]),
+    "gtars_fragments_len": (u64, [vp]),
+    "gtars_fragments_n_chrom": (u32, [vp]),
+    "gtars_fragments_n_barcodes": (u32, [vp]),
+    "gtars_fragments_chrom_name": (cstr, [vp, u32]),
+    "gtars_fragments_barcode_name": (cstr, [vp, u32]),
+    "gtars_fragments_chrom_ids": (vp, [vp]),
+    "gtars_fragments_starts": (vp, [vp]),
+    "gtars_fragments_ends": (vp, [vp]),
+    "gtars_fragments_barcode_ids": (vp, [vp]),
     "gtars_igddb_from_bed_files": (C.c_int, [vp, u64, pp]),
     "gtars_igddb_from_bed_dir": (C.c_int, [cstr, pp]),
     "gtars_igddb_free": (None, [vp]),

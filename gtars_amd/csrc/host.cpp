@@ -14,9 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <map>
+#include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -1030,34 +1033,230 @@ gtars_status gtars_tokenizer_encode_ids(const gtars_tokenizer_t *t, const uint32
 }
 
 // tokenize_fragment_file -- gtars-tokenizers/src/utils/fragments.rs:12-82
+// ------------------------------------------------------------ fragment files: SoA ingest
+// (gtars-tokenizers/src/utils/fragments.rs:12-56 parse_fragment_line)
+// The decompressed text is cut at line ends into one chunk per host thread; every chunk is scanned in
+// place (no per-line or per-field allocation) into SoA columns with chunk-local dictionaries, which are
+// then merged in chunk order -- so dictionary ids are in first-seen order, exactly as a serial pass.
+namespace {
+
+// open-addressing string -> id table; keys are views into `names` (stable: deque)
+struct ViewDict {
+    std::deque<std::string> names;
+    std::vector<uint32_t> slots;  // id + 1, 0 = empty
+    size_t mask = 0;
+    static uint64_t hash(const char *p, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+        return h ^ (h >> 29);
+    }
+    void grow() {
+        const size_t cap = slots.empty() ? 64 : slots.size() * 2;
+        slots.assign(cap, 0);
+        mask = cap - 1;
+        for (uint32_t id = 0; id < names.size(); ++id) {
+            size_t k = hash(names[id].data(), names[id].size()) & mask;
+            while (slots[k]) k = (k + 1) & mask;
+            slots[k] = id + 1;
+        }
+    }
+    uint32_t get_or_add(const char *p, size_t n) {
+        if (names.size() * 2 >= slots.size()) grow();
+        size_t k = hash(p, n) & mask;
+        while (slots[k]) {
+            const std::string &nm = names[slots[k] - 1];
+            if (nm.size() == n && memcmp(nm.data(), p, n) == 0) return slots[k] - 1;
+            k = (k + 1) & mask;
+        }
+        names.emplace_back(p, n);
+        slots[k] = (uint32_t)names.size();
+        return (uint32_t)names.size() - 1;
+    }
+};
+
+inline bool is_ws(char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); }  // isspace() in the C locale
+
+// str::parse::<u32>(): optional '+', ASCII digits, must fit
+inline bool parse_u32_view(const char *p, size_t n, uint32_t &out) {
+    size_t i = (n && p[0] == '+') ? 1 : 0;
+    if (i >= n) return false;
+    uint64_t v = 0;
+    for (; i < n; ++i) {
+        const unsigned d = (unsigned char)p[i] - '0';
+        if (d > 9) return false;
+        v = v * 10 + d;
+        if (v > 0xFFFFFFFFull) return false;
+    }
+    out = (uint32_t)v;
+    return true;
+}
+
+struct FragChunk {
+    std::vector<uint32_t> c, s, e, b;
+    ViewDict chroms, barcodes;
+    size_t n_lines = 0;           // every line of the chunk, comments included (for error line numbers)
+    int err = 0;                  // 0 ok, 1 < 5 fields, 2 bad start, 3 bad end
+    size_t err_line = 0;          // line index inside the chunk
+};
+
+void parse_fragment_chunk(const char *p, const char *end, FragChunk &out) {
+    const size_t guess = (size_t)(end - p) / 30 + 16;
+    out.c.reserve(guess); out.s.reserve(guess); out.e.reserve(guess); out.b.reserve(guess);
+    uint32_t last_c = 0, last_b = 0;
+    const char *last_c_p = nullptr, *last_b_p = nullptr;
+    size_t last_c_n = 0, last_b_n = 0;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *next = nl ? nl + 1 : end;
+        if (nl && le > p && le[-1] == '\r') --le;  // BufRead::lines strips "\r\n"
+        const size_t ln = out.n_lines++;
+        if (le > p && *p == '#') { p = next; continue; }
+        const char *f[5]; size_t fl[5]; int nf = 0;
+        const char *q = p;
+        while (q < le && nf < 5) {
+            while (q < le && is_ws(*q)) ++q;
+            const char *st = q;
+            while (q < le && !is_ws(*q)) ++q;
+            if (q > st) { f[nf] = st; fl[nf] = (size_t)(q - st); ++nf; }
+        }
+        uint32_t sv, ev;
+        if (nf < 5) { out.err = 1; out.err_line = ln; return; }
+        if (!parse_u32_view(f[1], fl[1], sv)) { out.err = 2; out.err_line = ln; return; }
+        if (!parse_u32_view(f[2], fl[2], ev)) { out.err = 3; out.err_line = ln; return; }
+        // fragment files are sorted by chromosome and barcodes repeat: try the previous line's ids first
+        if (!(last_c_p && last_c_n == fl[0] && memcmp(last_c_p, f[0], fl[0]) == 0)) {
+            last_c = out.chroms.get_or_add(f[0], fl[0]); last_c_p = f[0]; last_c_n = fl[0];
+        }
+        if (!(last_b_p && last_b_n == fl[3] && memcmp(last_b_p, f[3], fl[3]) == 0)) {
+            last_b = out.barcodes.get_or_add(f[3], fl[3]); last_b_p = f[3]; last_b_n = fl[3];
+        }
+        out.c.push_back(last_c); out.s.push_back(sv); out.e.push_back(ev); out.b.push_back(last_b);
+        p = next;
+    }
+}
+
+struct FragTable {
+    std::vector<uint32_t> c, s, e, b;
+    std::vector<std::string> chroms, barcodes;
+};
+
+gtars_status read_fragment_table(const char *path, FragTable &ft) {
+    std::string data, err;
+    if (!read_all(path, data, err)) return fail(GTARS_ERR_IO, err);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("GTARS_HOST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    nt = std::max(1u, std::min(nt, 32u));
+    nt = (unsigned)std::min<size_t>(nt, data.size() / (1u << 20) + 1);
+    std::vector<size_t> cut(nt + 1, data.size());
+    cut[0] = 0;
+    for (unsigned i = 1; i < nt; ++i) {
+        size_t pos = data.size() / nt * i;
+        const size_t nl = data.find('\n', pos);
+        cut[i] = nl == std::string::npos ? data.size() : nl + 1;
+    }
+    for (unsigned i = 1; i <= nt; ++i) cut[i] = std::max(cut[i], cut[i - 1]);
+    std::vector<FragChunk> chunks(nt);
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; ++i)
+            th.emplace_back([&, i] { parse_fragment_chunk(data.data() + cut[i], data.data() + cut[i + 1], chunks[i]); });
+        parse_fragment_chunk(data.data() + cut[0], data.data() + cut[1], chunks[0]);
+        for (auto &t : th) t.join();
+    }
+    size_t line0 = 0, total = 0;
+    for (unsigned i = 0; i < nt; ++i) {
+        if (chunks[i].err) {
+            const std::string ln = std::to_string(line0 + chunks[i].err_line);
+            if (chunks[i].err == 1) return fail(GTARS_ERR_PARSE, "Invalid fragment file detected at line: " + ln);
+            return fail(GTARS_ERR_PARSE, std::string("Failed to parse ") + (chunks[i].err == 2 ? "start" : "end") +
+                                             " position at line " + ln);
+        }
+        line0 += chunks[i].n_lines;
+        total += chunks[i].c.size();
+    }
+    // merge the dictionaries in chunk order (first-seen order of a serial pass), then the columns
+    ViewDict gc, gb;
+    std::vector<std::vector<uint32_t>> mapc(nt), mapb(nt);
+    for (unsigned i = 0; i < nt; ++i) {
+        for (const std::string &n : chunks[i].chroms.names) mapc[i].push_back(gc.get_or_add(n.data(), n.size()));
+        for (const std::string &n : chunks[i].barcodes.names) mapb[i].push_back(gb.get_or_add(n.data(), n.size()));
+    }
+    ft.c.resize(total); ft.s.resize(total); ft.e.resize(total); ft.b.resize(total);
+    std::vector<size_t> base(nt + 1, 0);
+    for (unsigned i = 0; i < nt; ++i) base[i + 1] = base[i] + chunks[i].c.size();
+    {
+        auto merge = [&](unsigned i) {
+            const FragChunk &ck = chunks[i];
+            const size_t o = base[i], m = ck.c.size();
+            for (size_t k = 0; k < m; ++k) {
+                ft.c[o + k] = mapc[i][ck.c[k]];
+                ft.b[o + k] = mapb[i][ck.b[k]];
+            }
+            if (m) {
+                memcpy(&ft.s[o], ck.s.data(), m * sizeof(uint32_t));
+                memcpy(&ft.e[o], ck.e.data(), m * sizeof(uint32_t));
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; ++i) th.emplace_back(merge, i);
+        merge(0);
+        for (auto &t : th) t.join();
+    }
+    ft.chroms.assign(gc.names.begin(), gc.names.end());
+    ft.barcodes.assign(gb.names.begin(), gb.names.end());
+    return GTARS_OK;
+}
+
+}  // namespace
+
+struct gtars_fragments {
+    FragTable t;
+    std::vector<const char *> chrom_ptrs, barcode_ptrs;
+};
+
+gtars_status gtars_fragments_read(const char *path, gtars_fragments_t **out) {
+    if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    std::unique_ptr<gtars_fragments> f(new gtars_fragments());
+    gtars_status st = read_fragment_table(path, f->t);
+    if (st) return st;
+    *out = f.release();
+    return GTARS_OK;
+}
+void gtars_fragments_free(gtars_fragments_t *f) { delete f; }
+uint64_t gtars_fragments_len(const gtars_fragments_t *f) { return f ? f->t.c.size() : 0; }
+uint32_t gtars_fragments_n_chrom(const gtars_fragments_t *f) { return f ? (uint32_t)f->t.chroms.size() : 0; }
+uint32_t gtars_fragments_n_barcodes(const gtars_fragments_t *f) { return f ? (uint32_t)f->t.barcodes.size() : 0; }
+const char *gtars_fragments_chrom_name(const gtars_fragments_t *f, uint32_t id) {
+    return f && id < f->t.chroms.size() ? f->t.chroms[id].c_str() : nullptr;
+}
+const char *gtars_fragments_barcode_name(const gtars_fragments_t *f, uint32_t id) {
+    return f && id < f->t.barcodes.size() ? f->t.barcodes[id].c_str() : nullptr;
+}
+const uint32_t *gtars_fragments_chrom_ids(const gtars_fragments_t *f) { return f ? f->t.c.data() : nullptr; }
+const uint32_t *gtars_fragments_starts(const gtars_fragments_t *f) { return f ? f->t.s.data() : nullptr; }
+const uint32_t *gtars_fragments_ends(const gtars_fragments_t *f) { return f ? f->t.e.data() : nullptr; }
+const uint32_t *gtars_fragments_barcode_ids(const gtars_fragments_t *f) { return f ? f->t.b.data() : nullptr; }
+
 gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, const char *path,
                                                     gtars_fragment_tokens_t **out) {
     if (!t || !path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
-    std::string data, err;
-    if (!read_all(path, data, err)) return fail(GTARS_ERR_IO, err);
-    Dict barcodes;
-    std::vector<uint32_t> qc, qs, qe, bc;
-    LineIter it(data);
-    std::string line;
-    size_t line_num = 0;
-    while (it.next(line)) {
-        const size_t ln = line_num++;
-        if (!line.empty() && line[0] == '#') continue;
-        const std::vector<std::string> parts = split_ws(line);
-        if (parts.size() < 5)
-            return fail(GTARS_ERR_PARSE, "Invalid fragment file detected at line: " + std::to_string(ln));
-        uint32_t s, e;
-        if (!parse_u32(parts[1], s))
-            return fail(GTARS_ERR_PARSE, "Failed to parse start position at line " + std::to_string(ln));
-        if (!parse_u32(parts[2], e))
-            return fail(GTARS_ERR_PARSE, "Failed to parse end position at line " + std::to_string(ln));
-        const int64_t cid = t->chroms.find(parts[0]);
-        qc.push_back(cid < 0 ? GTARS_UNKNOWN_CHROM : (uint32_t)cid);
-        qs.push_back(s);
-        qe.push_back(e);
-        bc.push_back(barcodes.get_or_add(parts[3]));
+    FragTable frag;
+    {
+        gtars_status st0 = read_fragment_table(path, frag);
+        if (st0) return st0;
     }
+    // the file's chromosome dictionary -> the tokenizer's
+    std::vector<uint32_t> cmap(frag.chroms.size());
+    for (size_t i = 0; i < cmap.size(); ++i) {
+        const int64_t cid = t->chroms.find(frag.chroms[i]);
+        cmap[i] = cid < 0 ? GTARS_UNKNOWN_CHROM : (uint32_t)cid;
+    }
+    std::vector<uint32_t> &qc = frag.c, &qs = frag.s, &qe = frag.e, &bc = frag.b;
+    for (uint32_t &v : qc) v = cmap[v];
+    struct { const std::vector<std::string> &names; } barcodes{frag.barcodes};
     const uint64_t n = qc.size();
     std::vector<uint64_t> off(n + 1, 0);
     uint32_t *ids = nullptr;

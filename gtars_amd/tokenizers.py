@@ -284,6 +284,22 @@ def tokenize_fragment_file(file: str, tokenizer: Tokenizer) -> Dict[str, List[in
         lib.gtars_fragment_tokens_free(out)
 
 
+def tokenize_fragment_files(files, tokenizer: Tokenizer, workers: int = 16) -> List[Dict[str, List[int]]]:
+    """``tokenize_fragment_file`` over many files with ``workers`` host threads (additive).
+
+    Fragment files are independent: gunzip + parse dominate and run outside the GIL
+    (the C call releases it), every thread has its own device workspace, the index is shared read-only.
+    Results come back in input order.
+    """
+    from concurrent.futures import ThreadPoolExecutor
+
+    files = list(files)
+    if workers <= 1 or len(files) <= 1:
+        return [tokenize_fragment_file(f, tokenizer) for f in files]
+    with ThreadPoolExecutor(max_workers=min(workers, len(files))) as ex:
+        return list(ex.map(lambda f: tokenize_fragment_file(f, tokenizer), files))
+
+
 def count_fragments_by_barcode(file: str, tokenizer: Tokenizer) -> Dict[str, Dict[int, int]]:
     """count_fragments_by_barcode (gtars-tokenizers/src/utils/fragments.rs:87-112)."""
     res: Dict[str, Dict[int, int]] = {}

@@ -23,3 +23,42 @@ def read_tokens_from_gtok(filename: str) -> List[int]:
 
 def read_tokens_from_gtok_as_strings(filename: str) -> List[str]:
     return [str(v) for v in read_tokens_from_gtok(filename)]
+
+
+def read_fragments(path: str):
+    """Fragment file (``chr start end barcode count``, optionally .gz) -> SoA columns.
+
+    The multi-threaded in-place parser of the host layer (parse_fragment_line,
+    gtars-tokenizers/src/utils/fragments.rs:12-40).  Returns a dict with ``chrom`` / ``barcode``
+    dictionary codes (u32, first-seen order), ``start`` / ``end`` (u32) and the two name lists.
+    """
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+
+    h = C.c_void_p()
+    if _lib.lib.gtars_fragments_read(str(path).encode(), C.byref(h)) != 0:
+        raise RuntimeError(_lib.last_error())
+    try:
+        n = int(_lib.lib.gtars_fragments_len(h))
+
+        def col(fn):
+            p = fn(h)
+            if not n:
+                return np.zeros(0, dtype=np.uint32)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n,)).copy()
+
+        return {
+            "chrom": col(_lib.lib.gtars_fragments_chrom_ids),
+            "start": col(_lib.lib.gtars_fragments_starts),
+            "end": col(_lib.lib.gtars_fragments_ends),
+            "barcode": col(_lib.lib.gtars_fragments_barcode_ids),
+            "chrom_names": [_lib.lib.gtars_fragments_chrom_name(h, i).decode()
+                            for i in range(_lib.lib.gtars_fragments_n_chrom(h))],
+            "barcode_names": [_lib.lib.gtars_fragments_barcode_name(h, i).decode()
+                              for i in range(_lib.lib.gtars_fragments_n_barcodes(h))],
+        }
+    finally:
+        _lib.lib.gtars_fragments_free(h)

@@ -109,6 +109,27 @@ gtars_status gtars_tokenizer_encode_ids(const gtars_tokenizer_t *t, const uint32
                                         const uint32_t *starts, const uint32_t *ends, uint64_t n,
                                         uint64_t *offsets, uint32_t **out_ids, uint64_t *out_n);
 
+/* ------------------------------------------------------------------------
+ * Fragment files as SoA columns (parse_fragment_line, utils/fragments.rs:12-40):
+ * `chr start end barcode count` split on whitespace, lines starting with '#'
+ * skipped, fewer than 5 fields / unparsable start or end -> GTARS_ERR_PARSE with
+ * the reference's message and 0-based line number.  .gz by extension.  The text
+ * is parsed in place by all host threads (GTARS_HOST_THREADS overrides);
+ * chromosome and barcode ids are dictionary codes in first-seen order.
+ * ---------------------------------------------------------------------- */
+typedef struct gtars_fragments gtars_fragments_t;
+gtars_status gtars_fragments_read(const char *path, gtars_fragments_t **out);
+void gtars_fragments_free(gtars_fragments_t *f);
+uint64_t gtars_fragments_len(const gtars_fragments_t *f);
+uint32_t gtars_fragments_n_chrom(const gtars_fragments_t *f);
+uint32_t gtars_fragments_n_barcodes(const gtars_fragments_t *f);
+const char *gtars_fragments_chrom_name(const gtars_fragments_t *f, uint32_t id);
+const char *gtars_fragments_barcode_name(const gtars_fragments_t *f, uint32_t id);
+const uint32_t *gtars_fragments_chrom_ids(const gtars_fragments_t *f);
+const uint32_t *gtars_fragments_starts(const gtars_fragments_t *f);
+const uint32_t *gtars_fragments_ends(const gtars_fragments_t *f);
+const uint32_t *gtars_fragments_barcode_ids(const gtars_fragments_t *f);
+
 /* tokenize_fragment_file (utils/fragments.rs:61-82): one single-region
  * tokenize per fragment line (so every non-overlapping fragment yields one
  * unk id), grouped by barcode.  Result: n_barcodes names (first-seen order)

@@ -119,3 +119,80 @@ def test_lola_statistics_tail_kats():
     assert [r["rnkSup"] for r in rows] == [2, 2, 1]
     lola._apply_fdr(rows)
     assert all(0.0 <= r["qValue"] <= 1.0 for r in rows)
+
+
+def _py_parse_fragments(text):
+    rows = []
+    for line in text.split("\n")[:-1] if text.endswith("\n") else text.split("\n"):
+        if line.endswith("\r"):
+            line = line[:-1]
+        if line.startswith("#"):
+            continue
+        p = line.split()
+        rows.append((p[0], int(p[1]), int(p[2]), p[3]))
+    return rows
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "8"])
+def test_fragment_reader_matches_a_plain_python_parse(tmp_path, monkeypatch, golden_dir, threads):
+    """gtars_fragments_read: SoA columns + first-seen-order dictionaries, whatever the thread count."""
+    import gzip
+
+    from gtars_amd import utils
+
+    monkeypatch.setenv("GTARS_HOST_THREADS", threads)
+    rng = np.random.default_rng(5)
+    n = 120_000   # > 1 MB of text, so that several chunks are cut
+    chroms = ["chr1", "chr10", "chr2", "chrX", "chrUn_x"]
+    c = np.sort(rng.integers(0, len(chroms), n))
+    s = rng.integers(0, 2**32 - 700, n, dtype=np.uint64)
+    e = s + rng.integers(1, 600, n).astype(np.uint64)
+    b = rng.integers(0, 300, n)
+    lines = [f"{chroms[a]}\t{x}\t{y}\tBC{z:04d}-1\t{1 + z % 3}" for a, x, y, z in zip(c, s, e, b)]
+    lines[1000] = "# a comment in the middle"
+    lines[5] = "chr1   77 \t +88  BCspace   1   extra fields are fine"
+    text = "\n".join(lines) + "\r\n"
+    plain = tmp_path / "f.tsv"
+    plain.write_text(text)
+    gz = tmp_path / "f.tsv.gz"
+    with gzip.open(gz, "wt") as fh:
+        fh.write(text)
+    exp = _py_parse_fragments(text)
+    for path in (plain, gz):
+        d = utils.read_fragments(str(path))
+        got = list(zip([d["chrom_names"][i] for i in d["chrom"]], d["start"].tolist(), d["end"].tolist(),
+                       [d["barcode_names"][i] for i in d["barcode"]]))
+        assert got == exp
+        # dictionaries are in first-seen order
+        seen = []
+        for row in exp:
+            if row[3] not in seen:
+                seen.append(row[3])
+        assert d["barcode_names"] == seen
+    # the golden fragment fixture of the reference's scoring tests
+    d = utils.read_fragments(os.path.join(str(golden_dir), "fragments/region_scoring/fragments1.bed.gz"))
+    import gzip as _gz
+    with _gz.open(os.path.join(str(golden_dir), "fragments/region_scoring/fragments1.bed.gz"), "rt") as fh:
+        exp = _py_parse_fragments(fh.read())
+    assert list(zip(d["start"].tolist(), d["end"].tolist())) == [(r[1], r[2]) for r in exp]
+
+
+def test_fragment_reader_errors_carry_the_reference_line_numbers(tmp_path, monkeypatch):
+    from gtars_amd import utils
+
+    monkeypatch.setenv("GTARS_HOST_THREADS", "4")
+    good = "chr1\t10\t20\tAAAC-1\t1\n"
+    n = 60_000  # several chunks
+    for bad, msg in (("chr1\t10\t20\tAAAC-1\n", "Invalid fragment file detected at line: 41234"),
+                     ("chr1\tx10\t20\tAAAC-1\t1\n", "Failed to parse start position at line 41234"),
+                     ("chr1\t10\t4294967296\tAAAC-1\t1\n", "Failed to parse end position at line 41234")):
+        p = tmp_path / "bad.tsv"
+        p.write_text(good * 41234 + bad + good * (n - 41235))
+        with pytest.raises(RuntimeError) as ei:
+            utils.read_fragments(str(p))
+        assert msg in str(ei.value)
+    with pytest.raises(RuntimeError):
+        utils.read_fragments(str(tmp_path / "missing.tsv"))
+    empty = tmp_path / "empty.tsv"
+    empty.write_text("")
+    assert len(utils.read_fragments(str(empty))["chrom"]) == 0
