@@ -39,17 +39,18 @@ namespace gtars {
 
 // Timing experiments only (tools/ablate.sh builds a separate library with
 // -DGTARS_ABLATE=<bits>; results are then WRONG by construction):
-//  1: no LDS search (arithmetic block guess)   2: no block fetch
-//  4: no id writes   8: no offset writes   16: no look-back   32: starts-only fetch
+//  2: no record fetch   4: no id writes   8: no offset writes   16: no look-back
+//  64: look-back never waits (scan.cuh)   128: per-phase cycle stamps printed by the launcher
 #ifndef GTARS_ABLATE
 #define GTARS_ABLATE 0
 #endif
 // 1: stream queries in / results out with non-temporal accesses so that they do not push the index
-// (2.2 MB per XCD) out of the 4 MB L2s between launches
+// (2.2 MB per XCD) out of the 4 MB L2 while a launch runs
 #ifndef GTARS_TOK_NT
 #define GTARS_TOK_NT 1
 #endif
-// 1: the next tile's queries are loaded right after the count phase; 0: at the top of its own iteration
+// 1: the next tile's queries are loaded right after the count phase; 0: at the start of its own iteration
+// (measured: 1 is 15 % slower -- vmcnt retires in order, so every later wait also waits for that HBM stream)
 #ifndef GTARS_TOK_PREFETCH
 #define GTARS_TOK_PREFETCH 0
 #endif
@@ -145,8 +146,7 @@ struct TileState {
     u32 tile;
 };
 
-// TOK_QPT = queries per thread: 4, or 2 with a register budget that admits 6 waves per SIMD
-// (three 512-thread workgroups per CU, the most the per-workgroup LDS copy of `top` allows).
+// TOK_QPT = queries per thread: 4 (one burst of 16 loads per round); 2 is kept for experiments.
 template <int TPB, int TOK_QPT, bool FILTER>
 __global__ void __launch_bounds__(TPB, (TOK_QPT == 2 ? 6 : 4))
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
@@ -249,12 +249,10 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     // Further tiles are drawn from a ticket counter, so a tile only ever waits on tiles that are
     // already running, whatever the dispatch order.
     //
-    // Latency plan: the ticket of the NEXT tile is drawn (one lane, asynchronously) before the
-    // current tile is counted and handed round through the scan's barrier; the next tile's queries
-    // are loaded into the (by then dead) query registers right after the count phase, so the HBM
-    // stream stays in flight through the scan / resolve / write of the previous tile.  vmcnt retires
-    // in order, so that prefetch is placed AFTER the record fetches of the count phase, and wave 0
-    // issues it only after its look-back loads.
+    // The ticket of the NEXT tile is drawn (one lane) before the current tile is counted and handed
+    // round through the scan's barrier, so no barrier is spent on it.  With GTARS_TOK_PREFETCH the next
+    // tile's queries are also loaded right after the count phase (wave 0 only after its look-back
+    // loads); that variant is kept for experiments only -- see the macro.
     const bool draw = num_tiles > gridDim.x;  // otherwise one tile per workgroup: nothing to draw
     u32 tile = blockIdx.x;
     bool loaded = true;  // the first tile's queries are already in flight
