@@ -236,6 +236,16 @@ def main():
         }
         if sweep:
             out["batch_sweep"] = sweep
+        if world == 1:
+            # PCIe-inclusive rate through the host-pointer entry point (gtars_tokenize: H2D, kernel, D2H of
+            # offsets + ids).  Reported for context only; it is never `value`.
+            ix.tokenize(q["chrom"], q["start"], q["end"])
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ix.tokenize(q["chrom"], q["start"], q["end"])
+            out["host_buffers_end_to_end"] = {"value": 5 * nq / (time.perf_counter() - t1), "unit": "query intervals/s",
+                                              "note": "pageable numpy buffers in and out, one call per batch"}
+            out["roofline"]["frac_of_measured_copy_6.29TBps"] = roofline["achieved"] / 6290.0
         if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(u, q)
         print(json.dumps(out), flush=True)
