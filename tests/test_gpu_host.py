@@ -422,3 +422,33 @@ def test_region_scoring_matrix_kat(golden_dir):
     assert sum(sum(d.values()) for d in bc.values()) == int(chip[0].sum())
     with pytest.raises(ValueError):
         region_scoring_from_fragments([], cons, "nope")
+
+
+def test_fragment_files_in_parallel_host_threads(tmp_path):
+    """tokenize_fragment_files: many files through a host thread pool (one device workspace per thread, the
+    index shared read-only) give exactly the per-file results, in input order."""
+    import gzip
+
+    from gtars_amd import synth
+    from gtars_amd.tokenizers import Tokenizer, tokenize_fragment_file, tokenize_fragment_files
+
+    u = synth.make_universe(20_000)
+    ub = tmp_path / "u.bed"
+    ub.write_text("".join(f"{synth.CHROM_NAMES[c]}\t{s}\t{e}\n" for c, s, e in zip(u["chrom"], u["start"], u["end"])))
+    tok = Tokenizer.from_bed(str(ub))
+    files = []
+    for k in range(12):
+        q = synth.make_queries(u, 20_000, seed=50 + k)
+        rng = np.random.default_rng(k)
+        text = "".join(f"{synth.CHROM_NAMES[c] if c < synth.N_CHROM else 'chrUn_x'}\t{s}\t{e}\tBC{b:03d}\t1\n"
+                       for c, s, e, b in zip(q["chrom"], q["start"], q["end"], rng.integers(0, 50, len(q["chrom"]))))
+        p = tmp_path / f"f{k}.tsv.gz"
+        with gzip.open(p, "wt") as fh:
+            fh.write(text)
+        files.append(str(p))
+    serial = [tokenize_fragment_file(f, tok) for f in files]
+    for rep in range(3):
+        assert tokenize_fragment_files(files, tok, workers=8) == serial
+    # and against the oracle for one of them
+    o = oracle.OracleTokenizer(str(ub))
+    assert serial[0] == o.tokenize_fragment_file(files[0])
