@@ -1256,7 +1256,6 @@ gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, 
     }
     std::vector<uint32_t> &qc = frag.c, &qs = frag.s, &qe = frag.e, &bc = frag.b;
     for (uint32_t &v : qc) v = cmap[v];
-    struct { const std::vector<std::string> &names; } barcodes{frag.barcodes};
     const uint64_t n = qc.size();
     std::vector<uint64_t> off(n + 1, 0);
     uint32_t *ids = nullptr;
@@ -1264,7 +1263,7 @@ gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, 
     gtars_status st = gtars_tokenize(t->index, qc.data(), qs.data(), qe.data(), n, off.data(), &ids, &h);
     if (st) return st;
     // one tokenize() per fragment: a fragment without hits contributes exactly one unk id
-    const uint64_t nb = barcodes.names.size();
+    const uint64_t nb = frag.barcodes.size();
     std::vector<uint64_t> cnt(nb + 1, 0);
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t k = off[i + 1] - off[i];
@@ -1277,7 +1276,7 @@ gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, 
     ft->offsets = (uint64_t *)malloc((nb + 1) * sizeof(uint64_t));
     ft->ids = (uint32_t *)malloc((cnt[nb] ? cnt[nb] : 1) * sizeof(uint32_t));
     memcpy(ft->offsets, cnt.data(), (nb + 1) * sizeof(uint64_t));
-    for (uint64_t b = 0; b < nb; ++b) ft->barcodes[b] = dup_cstr(barcodes.names[b]);
+    for (uint64_t b = 0; b < nb; ++b) ft->barcodes[b] = dup_cstr(frag.barcodes[b]);
     std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
     for (uint64_t i = 0; i < n; ++i) {
         uint64_t &w = fill[bc[i]];
