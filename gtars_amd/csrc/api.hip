@@ -453,7 +453,9 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         const u32 nb = h_cblk[n_chrom];
         h_blocks.assign((size_t)nb * 16, 0);
         h_blk_first.assign(nb, 0xFFFFFFFFu);
+        std::vector<u64> chrom_span(n_chrom, 0);  // max end + 1 (0: no intervals)
         for (u32 c = 0; c < n_chrom; ++c) {
+            u32 pm = 0;  // prefix max of the ends, in (start, end) order
             for (u32 b = h_cblk[c]; b < h_cblk[c + 1]; ++b) {
                 u32 *rec = &h_blocks[(size_t)b * 16];
                 // slots 0..2: own intervals, slot 3: look-ahead = first interval of the next block;
@@ -469,18 +471,27 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
                 at(ACC_BS + 1, rec[12], rec[13], rec[14]);
                 u32 dummy_e, dummy_v;
                 at(ACC_BS + 2, rec[15], dummy_e, dummy_v);
-                // search key of the block: its LAST own start (partly filled blocks: 0xFFFFFFFF)
-                h_blk_first[b] = rec[ACC_BS - 1];
+                // Search key of the block: the largest end among ALL intervals up to and including its own
+                // (a prefix maximum, so it ascends).  An interval overlaps a query only if its end is
+                // > q_start, hence the first block whose key is > q_start holds the first possible hit --
+                // a tighter start than Bits::find's lower_bound(q_start - max_len) (bits.rs:144-147), with
+                // the same hit set and order, and immune to a few very wide intervals inflating max_len.
+                // Padding blocks (no own interval) keep the sentinel key.
+                const u64 p0 = (u64)off[c] + (u64)(b - h_cblk[c]) * ACC_BS;
+                for (int k = 0; k < ACC_BS; ++k)
+                    if (p0 + k < off[c + 1]) pm = std::max(pm, ix->h_ends[p0 + k]);
+                if (p0 < off[c + 1]) h_blk_first[b] = pm;
             }
+            chrom_span[c] = off[c + 1] > off[c] ? (u64)pm + 1 : 0;
         }
-        // Unit keys (last block of every 2^shift blocks) in one ascending key space: chromosome c's
-        // keys live in [gbase[c], gbase[c] + span[c]], the upper end being the sentinel key.
+        // Unit keys (key of the last block of every 2^shift blocks) in one ascending key space: chromosome
+        // c's keys live in [gbase[c], gbase[c] + span[c]], span = max end + 1 being the sentinel key.
         // Consecutive chromosomes are 2^q_shift apart, so that the floor-quantised in-bucket search can
         // never stop on a block of an EARLIER chromosome (its keys quantise strictly below the target).
         const u32 n_units = nb >> shift;
         std::vector<u64> uk(n_units);
         u64 total = 0;
-        for (u32 c = 0; c < n_chrom; ++c) total += (off[c + 1] > off[c] ? (u64)ix->h_starts[off[c + 1] - 1] + 1 : 0) + 1;
+        for (u32 c = 0; c < n_chrom; ++c) total += chrom_span[c] + 1;
         // bucket width 2^lsh: the smallest that needs <= kBucketMax buckets (padding between chromosomes included)
         u32 lsh = 4, qsh = 0;
         for (;; ++lsh) {
@@ -491,10 +502,10 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         u64 gbase = 0;
         h_ctab.assign((size_t)n_chrom * 4, 0);
         for (u32 c = 0; c < n_chrom; ++c) {
-            const u64 span = off[c + 1] > off[c] ? (u64)ix->h_starts[off[c + 1] - 1] + 1 : 0;  // sorted by start
+            const u64 span = chrom_span[c];
             h_ctab[4 * (size_t)c + 0] = (u32)std::min<u64>(gbase, 0xFFFFFFFFu);
             h_ctab[4 * (size_t)c + 1] = (u32)std::min<u64>(span, 0xFFFFFFFFu);
-            h_ctab[4 * (size_t)c + 2] = ix->h_chrom_aux[c];
+            h_ctab[4 * (size_t)c + 2] = 0;
             h_ctab[4 * (size_t)c + 3] = h_cblk[c + 1];
             for (u32 t = h_cblk[c] >> shift; t < (h_cblk[c + 1] >> shift); ++t)
                 uk[t] = gbase + std::min<u64>(h_blk_first[(((size_t)t + 1) << shift) - 1], span);

@@ -70,28 +70,32 @@ struct IndexView {
 // (a dependent load costs every wave a round trip: with 256 queries per wave
 // even a 3 % case is hit by nearly every wave).
 // Unused slots are sentinels (start = 0xFFFFFFFF, end = 0: never overlap and
-// stop the forward scan).  blk_first[b] = the block's LAST own start (its
-// search key; 0xFFFFFFFF for partly filled blocks).
+// stop the forward scan).  blk_first[b] = the block's search key: the largest END
+// among all intervals of the chromosome up to and including the block's own (a
+// prefix maximum, so it ascends; 0xFFFFFFFF for padding blocks).  Only intervals
+// with end > q_start can overlap a query, so the first block whose key is
+// > q_start is where the scan starts: same hits, same order as Bits::find's
+// lower_bound(q_start - max_len), but never earlier than necessary.
 //
 // Search structure kept in LDS by the workgroups, over "units" of 2^top_shift blocks
 // (each chromosome's block range is padded to a multiple of 2^top_shift):
-//  * all unit keys (last start of the unit's last block) live in ONE ascending key space:
+//  * all unit keys (key of the unit's last block) live in ONE ascending key space:
 //    chromosome c's keys are offset by gbase[c] (sum of span + 2^q_shift of the earlier
-//    chromosomes, span = max start + 1) and sentinel keys become gbase[c] + span[c];
+//    chromosomes, span = max end + 1) and sentinel keys become gbase[c] + span[c];
 //  * `lut[b]` (u16) = number of units whose key is < b << lut_shift: a direct-mapped table
 //    over the key space -- genomic positions spread evenly, so a bucket holds a handful of
 //    units and the search inside it takes `search_top` = 2^(steps-1) halving steps;
 //  * `qkeys[u]` (u16) = (key(u) mod 2^lut_shift) >> q_shift, floor-quantised.  The search
 //    may stop a unit early (never late, never in an earlier chromosome: those are 2^q_shift
 //    away); the record scan then simply walks on, so results stay exact.
-// chrom_tab[c] = {gbase, span, max_len, end of the chromosome's block range}.
+// chrom_tab[c] = {gbase, span, 0, end of the chromosome's block range}.
 constexpr int ACC_BS = 3;
 struct AccelView {
     const uint4 *blocks;      // [n_blocks * 4] (64 B per block)
-    const u32 *blk_first;     // [n_blocks] last own start of each block (local coordinates)
+    const u32 *blk_first;     // [n_blocks] prefix-max end up to each block (local coordinates)
     const u32 *lut;           // [lut_words] packed u16, n_buckets + 1 entries (16-byte padded)
     const u32 *qkeys;         // [q_words] packed u16, n_units entries (16-byte padded)
-    const uint4 *chrom_tab;   // [n_chrom] {gbase, span, max_len, blk_end}
+    const uint4 *chrom_tab;   // [n_chrom] {gbase, span, 0, blk_end}
     u32 n_blocks;
     u32 n_units;
     u32 n_buckets;

@@ -9,10 +9,13 @@
 //
 // Kernel: persistent workgroups copy the keys (+ the per-chromosome table) into
 // LDS once, then take tiles of TPB*4 consecutive queries.  Per query:
-//   1. LDS search for the first block whose LAST start is >= q_start - max_len:
-//      the block that holds Bits::find's lower_bound (bits.rs:144-147).  Level 1
-//      is a lock-step binary search with a scalar step sequence (all keys live in
-//      one ascending key space), level 2 four steps over 16 quantised u16 keys;
+//   1. LDS search for the first block that can hold a hit: the first whose key --
+//      the largest end among all intervals up to and including the block -- is
+//      > q_start.  (Bits::find starts at lower_bound(q_start - max_len),
+//      bits.rs:144-147; every interval between that point and ours has
+//      end <= q_start, so the hit set and its order are the same.)  A bucket
+//      table over the one ascending key space, then a lock-step search with a
+//      scalar step sequence over quantised u16 keys
 //      (+ a short search of blk_first[] in L2 when top_shift > 0);
 //   2. ONE burst of three 16-byte loads from the block's record: starts, ends and
 //      token ids of its 3 intervals and of the look-ahead interval.  The overlap
@@ -22,10 +25,9 @@
 //   3. wave shuffles + one LDS word per wave scan the per-thread hit counts,
 //      wave 0 resolves the tile's global base by chained look-back (scan.cuh);
 //   4. CSR offsets (u64) and token ids (u32) are written once, in place.
-// Starting the scan at a block boundary (or, after the quantised level 2, one
-// block early) instead of the exact lower_bound only adds intervals with
-// start < q_start - max_len, which cannot satisfy end > q_start, so the hit set
-// and its order are exactly Bits::find's.
+// Starting the scan at a block boundary (or, after the quantised search, one
+// block early) only adds intervals with end <= q_start, which cannot overlap,
+// so the hit set and its order are exactly Bits::find's.
 //
 // Bound: HBM stream of queries in / offsets+ids out (23.5 B per query at
 // config 2); the index itself stays L2/LDS resident.  What the count phase
@@ -209,7 +211,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     // LDS: bucket table (u16) | unit keys (u16) | chromosome table; both key arrays are padded to 16 bytes
     u32 *s_lut = smem;
     u32 *s_q = smem + a.lut_words;
-    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + a.lut_words + a.q_words);  // [n_chrom] {gbase, span, max_len, blk_end}
+    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + a.lut_words + a.q_words);  // [n_chrom] {gbase, span, 0, blk_end}
     {
         // 16-byte loads, 4 in flight.  Every workgroup copies the same arrays: start each one at a
         // different place so that they do not all queue on the same L2 channel at the same time.
@@ -276,12 +278,12 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             cur.more_bits = 0;
 #pragma unroll
             for (int r0 = 0; r0 < TOK_QPT; r0 += SUB) {
-                // ---- 1. search: first block whose LAST start is >= key (it holds the lower_bound) ----
+                // ---- 1. search: first block whose key (prefix-max end) is > q_start ----
                 // All unit keys live in one ascending key space (AccelView).  A direct-mapped bucket table
                 // narrows the range to a handful of units; the in-bucket search then runs the same scalar
                 // step sequence in every lane, clamped to the lane's own range: per step one add, one min,
                 // one LDS read, one compare, one select.
-                u32 key[SUB], pos[SUB], be[SUB];
+                u32 pos[SUB], be[SUB];
                 {
                     // LDS byte addresses (32-bit, address space 3) so that a step needs no address math
                     typedef const __attribute__((address_space(3))) unsigned short *lds_cu16;
@@ -293,11 +295,12 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
 #pragma unroll
                     for (int j = 0; j < SUB; ++j) {
                         const bool valid = c[r0 + j] < a.n_chrom;
-                        const uint4 ct = s_ctab[valid ? c[r0 + j] : 0u];
-                        key[j] = s[r0 + j] >= ct.z ? s[r0 + j] - ct.z : 0u;
-                        const u32 gkey = ct.x + (key[j] < ct.y ? key[j] : ct.y);  // beyond the last start: the sentinel key
-                        be[j] = valid ? ct.w : 0u;                                // invalid -> empty range
-                        const u32 la = lb + ((gkey >> lsh) << 1);
+                    const uint4 ct = s_ctab[valid ? c[r0 + j] : 0u];
+                    // target = q_start + 1 in the key space of prefix-max ends (first block with key > q_start);
+                    // at or beyond the chromosome's largest end: the sentinel key
+                    const u32 gkey = ct.x + (s[r0 + j] < ct.y ? s[r0 + j] + 1u : ct.y);
+                    be[j] = valid ? ct.w : 0u;  // invalid -> empty range
+                    const u32 la = lb + ((gkey >> lsh) << 1);
                         const u32 lo = *(lds_cu16)(uintptr_t)la, hi = *(lds_cu16)(uintptr_t)(la + 2u);
                         tq[j] = hi > lo ? (gkey & wmask) >> qsh : 0u;  // empty bucket: no key is < 0
                         pos[j] = qb + (lo << 1) - 2u;                  // &q[lo - 1]
@@ -320,11 +323,11 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                 for (int j = 0; j < SUB; ++j) {
                     u32 b = pos[j] << shift;  // first block of that unit (>= be: no candidate)
                     if (shift) {
-                        // inside the group: first block with blk_last >= key
+                        // inside the unit: first block whose key (prefix-max end) is > q_start
                         u32 l2 = b, n2 = (be[j] > b) ? min(1u << shift, be[j] - b) : 0u;
                         while (n2 > 0) {
                             const u32 half = n2 >> 1, mid = l2 + half;
-                            const bool pred = a.blk_first[mid] < key[j];
+                            const bool pred = a.blk_first[mid] <= s[r0 + j];
                             l2 = pred ? mid + 1 : l2;
                             n2 = pred ? n2 - half - 1 : half;
                         }
