@@ -593,3 +593,39 @@ def test_bits_count_matches_reference_formula(ga):
     assert g2.bits_count([0], [5], [11]).tolist() == [o2.bits_count(0, 5, 11)]
     with pytest.raises(Exception):
         ga.OverlapIndex(c, s, e, n_chrom=n_chrom, kind=KIND_AILIST).bits_count(qc[:4], qs[:4], qe[:4])
+
+
+def test_tokenize_wide_nested_and_degenerate_universe_intervals(ga):
+    """The LDS kernel starts a scan at the first block whose prefix-max END is > q_start instead of
+    lower_bound(q_start - max_len): same hits, same order -- with chromosome-wide intervals, deep nesting,
+    zero-length and inverted universe intervals, and queries at the extremes of u32."""
+    rng = np.random.default_rng(2024)
+    n_chrom, span = 4, 3_000_000
+    s = rng.integers(0, span, 60_000)
+    e = s + rng.integers(1, 400, 60_000)
+    c = rng.integers(0, n_chrom, 60_000)
+    # a few intervals that cover most of a chromosome (max_len ~ span), early and late in start order
+    ws = np.array([0, 10, 500_000, 2_900_000, 1_000, 2_999_000])
+    we = np.array([span, span - 5, 2_500_000, 2_999_999, 2_000_000, 0xFFFFFFFF])
+    wc = np.array([0, 0, 1, 1, 2, 2])
+    # zero-length and inverted universe intervals (never validated by the reference)
+    zs = rng.integers(0, span, 300)
+    ze = np.where(rng.random(300) < 0.5, zs, np.maximum(zs.astype(np.int64) - rng.integers(1, 50, 300), 0))
+    zc = rng.integers(0, n_chrom, 300)
+    S = np.concatenate([s, ws, zs]); E = np.concatenate([e, we, ze]); C_ = np.concatenate([c, wc, zc])
+    val = rng.permutation(len(S)).astype(np.uint32)
+    g, o = _pair(ga, C_, S, E, val, n_chrom=n_chrom, kind=KIND_BITS)
+    nq = 50_000
+    qc = rng.integers(0, n_chrom, nq)
+    qs = rng.integers(0, span, nq).astype(np.int64)
+    qe = qs + rng.integers(0, 2_000, nq)
+    qs[:50] = 0xFFFFFFFF; qe[:50] = 0xFFFFFFFF          # nothing has end > 0xFFFFFFFF
+    qs[50:100] = 0; qe[50:100] = 0xFFFFFFFF             # everything on the chromosome, in order
+    qs[100:150] = span - 1; qe[100:150] = span + 10
+    k = rng.integers(150, nq, 400)
+    qe[k] = np.maximum(qs[k] - rng.integers(0, 30, 400), 0)   # zero-length / inverted queries
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    assert np.array_equal(off_g, off_o)
+    assert np.array_equal(ids_g, ids_o)
+    assert len(ids_o) > 20 * nq  # the wide intervals make every query a multi-hit query
