@@ -18,6 +18,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -236,6 +237,58 @@ struct Dict {
     }
 };
 
+// open-addressing string -> id table; keys are views into `names` (stable: deque)
+struct ViewDict {
+    std::deque<std::string> names;
+    std::vector<uint32_t> slots;  // id + 1, 0 = empty
+    size_t mask = 0;
+    static uint64_t hash(const char *p, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+        return h ^ (h >> 29);
+    }
+    void grow() {
+        const size_t cap = slots.empty() ? 64 : slots.size() * 2;
+        slots.assign(cap, 0);
+        mask = cap - 1;
+        for (uint32_t id = 0; id < names.size(); ++id) {
+            size_t k = hash(names[id].data(), names[id].size()) & mask;
+            while (slots[k]) k = (k + 1) & mask;
+            slots[k] = id + 1;
+        }
+    }
+    uint32_t get_or_add(const char *p, size_t n) {
+        if (names.size() * 2 >= slots.size()) grow();
+        size_t k = hash(p, n) & mask;
+        while (slots[k]) {
+            const std::string &nm = names[slots[k] - 1];
+            if (nm.size() == n && memcmp(nm.data(), p, n) == 0) return slots[k] - 1;
+            k = (k + 1) & mask;
+        }
+        names.emplace_back(p, n);
+        slots[k] = (uint32_t)names.size();
+        return (uint32_t)names.size() - 1;
+    }
+};
+
+inline bool is_ws(char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); }  // isspace() in the C locale
+
+// str::parse::<u32>(): optional '+', ASCII digits, must fit
+inline bool parse_u32_view(const char *p, size_t n, uint32_t &out) {
+    size_t i = (n && p[0] == '+') ? 1 : 0;
+    if (i >= n) return false;
+    uint64_t v = 0;
+    for (; i < n; ++i) {
+        const unsigned d = (unsigned char)p[i] - '0';
+        if (d > 9) return false;
+        v = v * 10 + d;
+        if (v > 0xFFFFFFFFull) return false;
+    }
+    out = (uint32_t)v;
+    return true;
+}
+
+
 }  // namespace
 
 // =============================================================== RegionSet
@@ -243,7 +296,8 @@ struct Dict {
 struct gtars_regionset {
     Dict chroms;
     std::vector<uint32_t> chrom_ids, starts, ends;
-    std::vector<std::string> rest;
+    std::string rest_arena;          // NUL-terminated `rest` strings back to back
+    std::vector<uint64_t> rest_off;  // offset of region i's rest in the arena
     std::vector<uint8_t> has_rest;
     std::string header;
     bool has_header = false;
@@ -264,14 +318,18 @@ void regionset_assign(gtars_regionset *rs, std::vector<ParsedRegion> &regs) {
     rs->chrom_ids.resize(n);
     rs->starts.resize(n);
     rs->ends.resize(n);
-    rs->rest.resize(n);
+    rs->rest_off.assign(n, 0);
     rs->has_rest.resize(n);
     for (size_t i = 0; i < n; ++i) {
         rs->chrom_ids[i] = rs->chroms.get_or_add(regs[i].chr);
         rs->starts[i] = regs[i].start;
         rs->ends[i] = regs[i].end;
         rs->has_rest[i] = regs[i].has_rest;
-        if (regs[i].has_rest) rs->rest[i].swap(regs[i].rest);
+        if (regs[i].has_rest) {
+            rs->rest_off[i] = rs->rest_arena.size();
+            rs->rest_arena.append(regs[i].rest);
+            rs->rest_arena.push_back('\0');
+        }
     }
 }
 
@@ -301,50 +359,152 @@ gtars_status gtars_regionset_from_bed(const char *path, gtars_regionset_t **out)
     std::string data, err;
     if (!read_all(p, data, err)) return fail(GTARS_ERR_IO, err);
 
-    std::vector<ParsedRegion> regs;
-    std::string header, line;
-    bool first_line = true;
-    LineIter it(data);
-    while (it.next(line)) {
-        if (line.compare(0, 7, "browser") == 0 || line.compare(0, 5, "track") == 0 || (!line.empty() && line[0] == '#')) {
-            header += line;
-            first_line = false;
-            continue;
-        }
-        std::vector<std::string> parts = split_char(line, '\t');
-        if (first_line) {
-            // column headers like `chr start end ...` without '#'
-            if (parts.size() >= 3) {
-                uint32_t tmp;
-                if (!parse_u32(parts[1], tmp)) {
-                    header += line;
-                    first_line = false;
+    // The text is cut at line ends into one chunk per host thread and scanned in place (no per-line or
+    // per-field allocation); `rest` stays a view into the text until the final arena is written.
+    struct Chunk {
+        std::vector<uint32_t> c, s, e, rest_len;
+        std::vector<uint64_t> rest_off;
+        ViewDict chroms;
+        std::string header;
+        int err = 0;  // 1: start, 2: end
+        std::string err_line;
+    };
+    auto parse_chunk = [&data](size_t lo, size_t hi, bool file_start, Chunk &out) {
+        const char *base = data.data();
+        const char *p = base + lo, *end = base + hi;
+        const size_t guess = (hi - lo) / 24 + 16;
+        out.c.reserve(guess); out.s.reserve(guess); out.e.reserve(guess); out.rest_off.reserve(guess); out.rest_len.reserve(guess);
+        bool first_line = file_start;
+        const char *last_p = nullptr; size_t last_n = 0; uint32_t last_id = 0;
+        while (p < end) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *le = nl ? nl : end;
+            const char *next = nl ? nl + 1 : end;
+            if (nl && le > p && le[-1] == '\r') --le;
+            const size_t n = (size_t)(le - p);
+            if ((n >= 7 && memcmp(p, "browser", 7) == 0) || (n >= 5 && memcmp(p, "track", 5) == 0) || (n && *p == '#')) {
+                out.header.append(p, n);
+                first_line = false;
+                p = next;
+                continue;
+            }
+            const char *t1 = (const char *)memchr(p, '\t', n);
+            const char *t2 = t1 ? (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1)) : nullptr;
+            const char *t3 = t2 ? (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1)) : nullptr;
+            const char *f2e = t3 ? t3 : le;
+            uint32_t sv = 0, ev = 0;
+            if (first_line) {
+                first_line = false;
+                // column headers like `chr start end ...` without '#'
+                if (t2 && !parse_u32_view(t1 + 1, (size_t)(t2 - t1 - 1), sv)) {
+                    out.header.append(p, n);
+                    p = next;
                     continue;
                 }
             }
-            first_line = false;
+            if (!t2 || !parse_u32_view(t1 + 1, (size_t)(t2 - t1 - 1), sv)) {
+                out.err = 1; out.err_line.assign(p, n); return;
+            }
+            if (!parse_u32_view(t2 + 1, (size_t)(f2e - t2 - 1), ev)) {
+                out.err = 2; out.err_line.assign(p, n); return;
+            }
+            const size_t cn = (size_t)(t1 - p);
+            if (!(last_p && last_n == cn && memcmp(last_p, p, cn) == 0)) {
+                last_id = out.chroms.get_or_add(p, cn); last_p = p; last_n = cn;
+            }
+            out.c.push_back(last_id); out.s.push_back(sv); out.e.push_back(ev);
+            out.rest_off.push_back(t3 ? (uint64_t)(t3 + 1 - base) : 0);
+            out.rest_len.push_back(t3 ? (uint32_t)(le - t3 - 1) : 0u);
+            p = next;
         }
-        if (parts.size() < 3) return fail(GTARS_ERR_PARSE, "Error in parsing start position: \"" + line + "\"");
-        ParsedRegion r;
-        r.chr = parts[0];
-        if (!parse_u32(parts[1], r.start)) return fail(GTARS_ERR_PARSE, "Error in parsing start position: \"" + line + "\"");
-        if (!parse_u32(parts[2], r.end)) return fail(GTARS_ERR_PARSE, "Error in parsing end position: \"" + line + "\"");
-        for (size_t k = 3; k < parts.size(); ++k) {
-            if (k > 3) r.rest += '\t';
-            r.rest += parts[k];
-        }
-        r.has_rest = !r.rest.empty();
-        regs.push_back(std::move(r));
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *ev = getenv("GTARS_HOST_THREADS")) nt = (unsigned)std::max(1, atoi(ev));
+    nt = std::max(1u, std::min(nt, 32u));
+    nt = (unsigned)std::min<size_t>(nt, data.size() / (1u << 20) + 1);
+    std::vector<size_t> cut(nt + 1, data.size());
+    cut[0] = 0;
+    for (unsigned i = 1; i < nt; ++i) {
+        const size_t nl = data.find('\n', data.size() / nt * i);
+        cut[i] = nl == std::string::npos ? data.size() : nl + 1;
     }
-    if (regs.empty()) return fail(GTARS_ERR_EMPTY, "EmptyRegionSet: " + p);
-    // RegionSet::sort (region_set.rs:502-505): stable by (chr bytes, start)
-    std::stable_sort(regs.begin(), regs.end(), [](const ParsedRegion &a, const ParsedRegion &b) {
-        const int c = a.chr.compare(b.chr);
-        if (c != 0) return c < 0;
-        return a.start < b.start;
-    });
+    for (unsigned i = 1; i <= nt; ++i) cut[i] = std::max(cut[i], cut[i - 1]);
+    std::vector<Chunk> chunks(nt);
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; ++i) th.emplace_back([&, i] { parse_chunk(cut[i], cut[i + 1], false, chunks[i]); });
+        parse_chunk(cut[0], cut[1], true, chunks[0]);
+        for (auto &t : th) t.join();
+    }
+    std::string header;
+    size_t n = 0;
+    for (unsigned i = 0; i < nt; ++i) {
+        if (chunks[i].err)
+            return fail(GTARS_ERR_PARSE, std::string("Error in parsing ") + (chunks[i].err == 1 ? "start" : "end") +
+                                             " position: \"" + chunks[i].err_line + "\"");
+        header += chunks[i].header;
+        n += chunks[i].c.size();
+    }
+    if (n == 0) return fail(GTARS_ERR_EMPTY, "EmptyRegionSet: " + p);
+    // chromosome names -> rank in byte order; RegionSet::sort (region_set.rs:502-505) is stable by (chr, start)
+    ViewDict all;
+    std::vector<std::vector<uint32_t>> cmap(nt);
+    for (unsigned i = 0; i < nt; ++i)
+        for (const std::string &nm : chunks[i].chroms.names) cmap[i].push_back(all.get_or_add(nm.data(), nm.size()));
+    const uint32_t n_names = (uint32_t)all.names.size();
+    std::vector<uint32_t> by_name(n_names), rank(n_names);
+    std::iota(by_name.begin(), by_name.end(), 0u);
+    std::sort(by_name.begin(), by_name.end(), [&](uint32_t a, uint32_t b) { return all.names[a] < all.names[b]; });
+    for (uint32_t r = 0; r < n_names; ++r) rank[by_name[r]] = r;
+    std::vector<uint32_t> col_c(n), col_s(n), col_e(n), col_rl(n);
+    std::vector<uint64_t> col_ro(n);
+    {
+        size_t o = 0;
+        for (unsigned i = 0; i < nt; ++i) {
+            const Chunk &ck = chunks[i];
+            for (size_t k = 0; k < ck.c.size(); ++k, ++o) {
+                col_c[o] = rank[cmap[i][ck.c[k]]];
+                col_s[o] = ck.s[k];
+                col_e[o] = ck.e[k];
+                col_ro[o] = ck.rest_off[k];
+                col_rl[o] = ck.rest_len[k];
+            }
+        }
+    }
+    // stable LSD radix sort of the row indices: start (two 16-bit passes), then chromosome rank
+    std::vector<uint32_t> perm(n), tmp(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    {
+        std::vector<size_t> cnt;
+        auto pass = [&](auto key_of, size_t n_keys) {
+            cnt.assign(n_keys + 1, 0);
+            for (size_t i = 0; i < n; ++i) ++cnt[(size_t)key_of(perm[i]) + 1];
+            for (size_t k = 0; k < n_keys; ++k) cnt[k + 1] += cnt[k];
+            for (size_t i = 0; i < n; ++i) tmp[cnt[key_of(perm[i])]++] = perm[i];
+            perm.swap(tmp);
+        };
+        pass([&](uint32_t i) { return col_s[i] & 0xFFFFu; }, 1u << 16);
+        pass([&](uint32_t i) { return col_s[i] >> 16; }, 1u << 16);
+        pass([&](uint32_t i) { return col_c[i]; }, n_names);
+    }
     auto *rs = new gtars_regionset();
-    regionset_assign(rs, regs);
+    for (uint32_t r = 0; r < n_names; ++r) rs->chroms.get_or_add(all.names[by_name[r]]);  // id = rank
+    rs->chrom_ids.resize(n); rs->starts.resize(n); rs->ends.resize(n); rs->rest_off.assign(n, 0); rs->has_rest.resize(n);
+    size_t arena = 0;
+    for (size_t i = 0; i < n; ++i) arena += col_rl[i] ? col_rl[i] + 1 : 0;
+    rs->rest_arena.reserve(arena);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t k = perm[i];
+        rs->chrom_ids[i] = col_c[k];
+        rs->starts[i] = col_s[k];
+        rs->ends[i] = col_e[k];
+        rs->has_rest[i] = col_rl[k] != 0;
+        if (col_rl[k]) {
+            rs->rest_off[i] = rs->rest_arena.size();
+            rs->rest_arena.append(data.data() + col_ro[k], col_rl[k]);
+            rs->rest_arena.push_back('\0');
+        }
+    }
     rs->header = header;
     rs->has_header = !header.empty();
     *out = rs;
@@ -384,7 +544,7 @@ const uint32_t *gtars_regionset_chrom_ids(const gtars_regionset_t *rs) { return 
 const uint32_t *gtars_regionset_starts(const gtars_regionset_t *rs) { return rs ? rs->starts.data() : nullptr; }
 const uint32_t *gtars_regionset_ends(const gtars_regionset_t *rs) { return rs ? rs->ends.data() : nullptr; }
 const char *gtars_regionset_rest(const gtars_regionset_t *rs, uint64_t i) {
-    return rs && i < rs->size() && rs->has_rest[i] ? rs->rest[i].c_str() : nullptr;
+    return rs && i < rs->size() && rs->has_rest[i] ? rs->rest_arena.data() + rs->rest_off[i] : nullptr;
 }
 
 }  // extern "C"
@@ -1039,57 +1199,6 @@ gtars_status gtars_tokenizer_encode_ids(const gtars_tokenizer_t *t, const uint32
 // place (no per-line or per-field allocation) into SoA columns with chunk-local dictionaries, which are
 // then merged in chunk order -- so dictionary ids are in first-seen order, exactly as a serial pass.
 namespace {
-
-// open-addressing string -> id table; keys are views into `names` (stable: deque)
-struct ViewDict {
-    std::deque<std::string> names;
-    std::vector<uint32_t> slots;  // id + 1, 0 = empty
-    size_t mask = 0;
-    static uint64_t hash(const char *p, size_t n) {
-        uint64_t h = 1469598103934665603ull;
-        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
-        return h ^ (h >> 29);
-    }
-    void grow() {
-        const size_t cap = slots.empty() ? 64 : slots.size() * 2;
-        slots.assign(cap, 0);
-        mask = cap - 1;
-        for (uint32_t id = 0; id < names.size(); ++id) {
-            size_t k = hash(names[id].data(), names[id].size()) & mask;
-            while (slots[k]) k = (k + 1) & mask;
-            slots[k] = id + 1;
-        }
-    }
-    uint32_t get_or_add(const char *p, size_t n) {
-        if (names.size() * 2 >= slots.size()) grow();
-        size_t k = hash(p, n) & mask;
-        while (slots[k]) {
-            const std::string &nm = names[slots[k] - 1];
-            if (nm.size() == n && memcmp(nm.data(), p, n) == 0) return slots[k] - 1;
-            k = (k + 1) & mask;
-        }
-        names.emplace_back(p, n);
-        slots[k] = (uint32_t)names.size();
-        return (uint32_t)names.size() - 1;
-    }
-};
-
-inline bool is_ws(char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); }  // isspace() in the C locale
-
-// str::parse::<u32>(): optional '+', ASCII digits, must fit
-inline bool parse_u32_view(const char *p, size_t n, uint32_t &out) {
-    size_t i = (n && p[0] == '+') ? 1 : 0;
-    if (i >= n) return false;
-    uint64_t v = 0;
-    for (; i < n; ++i) {
-        const unsigned d = (unsigned char)p[i] - '0';
-        if (d > 9) return false;
-        v = v * 10 + d;
-        if (v > 0xFFFFFFFFull) return false;
-    }
-    out = (uint32_t)v;
-    return true;
-}
 
 struct FragChunk {
     std::vector<uint32_t> c, s, e, b;
