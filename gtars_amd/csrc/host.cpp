@@ -9,6 +9,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -1501,66 +1502,135 @@ struct gtars_igddb {
 
 namespace {
 
-// Igd::parse_bed_line -- gtars-igd/src/igd.rs:850-867
-bool igd_parse_bed_line(const std::string &line, std::string &chrom, int32_t &start, int32_t &end, int32_t &score) {
-    const std::vector<std::string> f = split_char(line, '\t');
-    if (f.size() < 3) return false;
-    if (!parse_i32(f[1], start) || !parse_i32(f[2], end)) return false;
-    chrom = f[0];
-    if (chrom.size() >= 40 || end <= 0) return false;
-    score = -1;
-    if (f.size() >= 5) {
-        int32_t v;
-        if (parse_i32(f[4], v)) score = v;
+// str::parse::<i32>(): optional sign, ASCII digits, must fit
+inline bool parse_i32_view(const char *p, size_t n, int32_t &out) {
+    size_t i = 0;
+    bool neg = false;
+    if (n && (p[0] == '+' || p[0] == '-')) {
+        neg = p[0] == '-';
+        i = 1;
     }
+    if (i >= n) return false;
+    int64_t v = 0;
+    for (; i < n; ++i) {
+        const unsigned d = (unsigned char)p[i] - '0';
+        if (d > 9) return false;
+        v = v * 10 + d;
+        if (v > 2147483648ll) return false;
+    }
+    if (neg) v = -v;
+    if (v < -2147483648ll || v > 2147483647ll) return false;
+    out = (int32_t)v;
     return true;
+}
+
+// One BED file of an IGD database, parsed in place.  Igd::parse_bed_line (gtars-igd/src/igd.rs:850-867):
+// tab-split; chrom, start, end (i32) required; chrom shorter than 40 bytes and end > 0; column 5 = score
+// if it parses, else -1.  Unparsable lines are skipped.
+struct IgdBedFile {
+    bool readable = false, has_valid = false;
+    uint32_t count = 0;          // lines with start >= 0 (FileInfo.num_regions, igd.rs:213-217)
+    uint64_t total_width = 0;
+    std::vector<uint32_t> c;     // file-local chromosome codes of the KEPT records (start < end)
+    std::vector<int32_t> s, e, v;
+    ViewDict chroms;             // in first-kept order
+};
+
+void parse_igd_bed_file(const std::string &path, IgdBedFile &out) {
+    std::string data, err;
+    if (!read_all(path, data, err)) return;  // Err(_) => continue (igd.rs:203-206)
+    out.readable = true;
+    const char *p = data.data(), *end = p + data.size();
+    const size_t guess = data.size() / 24 + 16;
+    out.c.reserve(guess); out.s.reserve(guess); out.e.reserve(guess); out.v.reserve(guess);
+    const char *last_p = nullptr; size_t last_n = 0; uint32_t last_id = 0;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *next = nl ? nl + 1 : end;
+        if (nl && le > p && le[-1] == '\r') --le;
+        const char *line = p;
+        p = next;
+        const char *t1 = (const char *)memchr(line, '\t', (size_t)(le - line));
+        if (!t1) continue;
+        const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1));
+        if (!t2) continue;
+        const char *t3 = (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1));
+        int32_t sv, ev, score = -1;
+        if (!parse_i32_view(t1 + 1, (size_t)(t2 - t1 - 1), sv)) continue;
+        if (!parse_i32_view(t2 + 1, (size_t)((t3 ? t3 : le) - t2 - 1), ev)) continue;
+        const size_t cn = (size_t)(t1 - line);
+        if (cn >= 40 || ev <= 0) continue;
+        if (t3) {
+            const char *t4 = (const char *)memchr(t3 + 1, '\t', (size_t)(le - t3 - 1));
+            if (t4) {
+                const char *t5 = (const char *)memchr(t4 + 1, '\t', (size_t)(le - t4 - 1));
+                int32_t v;
+                if (parse_i32_view(t4 + 1, (size_t)((t5 ? t5 : le) - t4 - 1), v)) score = v;
+            }
+        }
+        out.has_valid = true;
+        if (sv >= 0) {
+            // Igd::add creates the contig only for a record it keeps (igd.rs:114-133); count and
+            // total_width are updated regardless (igd.rs:213-217)
+            if (sv < ev) {
+                if (!(last_p && last_n == cn && memcmp(last_p, line, cn) == 0)) {
+                    last_id = out.chroms.get_or_add(line, cn); last_p = line; last_n = cn;
+                }
+                // the dictionary copies the name, so the view into `data` may die with this function
+                out.c.push_back(last_id); out.s.push_back(sv); out.e.push_back(ev); out.v.push_back(score);
+            }
+            out.count += 1;
+            out.total_width += (uint64_t)(int64_t)(ev - sv);
+        }
+    }
 }
 
 }  // namespace
 
 extern "C" {
 
-// Igd::from_bed_files -- gtars-igd/src/igd.rs:191-242
+// Igd::from_bed_files -- gtars-igd/src/igd.rs:191-242.  Files are independent: they are parsed by a pool
+// of host threads and merged in argument order (contigs and file indices come out as in a serial pass).
 gtars_status gtars_igddb_from_bed_files(const char *const *paths, uint64_t n_paths, gtars_igddb_t **out) {
     if (!out || (n_paths && !paths)) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
+    std::vector<IgdBedFile> parsed(n_paths);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        if (const char *ev = getenv("GTARS_HOST_THREADS")) nt = (unsigned)std::max(1, atoi(ev));
+        nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(nt, 64u), n_paths));
+        std::atomic<uint64_t> next{0};
+        auto work = [&] {
+            for (uint64_t i = next.fetch_add(1); i < n_paths; i = next.fetch_add(1))
+                parse_igd_bed_file(paths[i] ? paths[i] : "", parsed[i]);
+        };
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; ++i) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    }
     auto *db = new gtars_igddb();
+    uint64_t total = 0;
+    for (const IgdBedFile &f : parsed) total += f.c.size();
     std::vector<uint32_t> ch, fi;
     std::vector<int32_t> st, en, va;
+    ch.reserve(total); fi.reserve(total); st.reserve(total); en.reserve(total); va.reserve(total);
     for (uint64_t pi = 0; pi < n_paths; ++pi) {
-        const std::string p(paths[pi] ? paths[pi] : "");
-        std::string data, err;
-        if (!read_all(p, data, err)) continue;  // Err(_) => continue
-        uint32_t count = 0;
-        uint64_t total_width = 0;
-        bool has_valid = false;
+        IgdBedFile &f = parsed[pi];
+        // unreadable files and files without a parseable line are skipped (igd.rs:203-206, 223-225)
+        if (!f.readable || !f.has_valid) continue;
         const uint32_t file_idx = (uint32_t)db->files.size();
-        LineIter it(data);
-        std::string line, chrom;
-        int32_t s, e, score;
-        while (it.next(line)) {
-            if (!igd_parse_bed_line(line, chrom, s, e, score)) continue;
-            has_valid = true;
-            if (s >= 0) {
-                // Igd::add creates the contig only for a record it keeps (igd.rs:114-133); count and
-                // total_width are updated regardless (igd.rs:213-217)
-                if (s < e) {
-                    ch.push_back(db->chroms.get_or_add(chrom));
-                    st.push_back(s);
-                    en.push_back(e);
-                    va.push_back(score);
-                    fi.push_back(file_idx);
-                }
-                count += 1;
-                total_width += (uint64_t)(int64_t)(e - s);
-            }
-        }
-        if (!has_valid) {
-            // the records of a skipped file were never added in the reference either: has_valid == false
-            // means no line parsed, so nothing was pushed
-            continue;
-        }
-        db->files.push_back({base_name(p), count, count ? (double)total_width / (double)count : 0.0});
+        std::vector<uint32_t> cmap;
+        for (const std::string &nm : f.chroms.names) cmap.push_back(db->chroms.get_or_add(nm));
+        for (size_t k = 0; k < f.c.size(); ++k) ch.push_back(cmap[f.c[k]]);
+        st.insert(st.end(), f.s.begin(), f.s.end());
+        en.insert(en.end(), f.e.begin(), f.e.end());
+        va.insert(va.end(), f.v.begin(), f.v.end());
+        fi.insert(fi.end(), f.c.size(), file_idx);
+        db->files.push_back({base_name(paths[pi] ? paths[pi] : ""), f.count, f.count ? (double)f.total_width / (double)f.count : 0.0});
+        std::vector<uint32_t>().swap(f.c);  // release as we go
+        std::vector<int32_t>().swap(f.s); std::vector<int32_t>().swap(f.e); std::vector<int32_t>().swap(f.v);
     }
     gtars_status s2 = gtars_igd_build(ch.data(), st.data(), en.data(), va.data(), fi.data(), ch.size(),
                                       (uint32_t)db->chroms.names.size(), (uint32_t)db->files.size(), &db->igd);
