@@ -46,10 +46,12 @@ namespace gtars {
 #ifndef GTARS_ABLATE
 #define GTARS_ABLATE 0
 #endif
-// 1: stream queries in / results out with non-temporal accesses so that they do not push the index
-// (2.2 MB per XCD) out of the 4 MB L2 while a launch runs
+// Non-temporal streaming so that the query / result streams do not push the index (2.2 MB per XCD) out
+// of the 4 MB L2 while a launch runs.  Bits: 1 query loads, 2 offset stores (full 32 B per lane), 4 id
+// stores.  The id stores stay temporal: they are scattered 4-byte stores, and as non-temporal ones L2
+// no longer merges them into full lines (WRITE_SIZE 16.2 MB instead of 10.35 MB per 1M queries).
 #ifndef GTARS_TOK_NT
-#define GTARS_TOK_NT 1
+#define GTARS_TOK_NT 3
 #endif
 // 1: the next tile's queries are loaded right after the count phase; 0: at the start of its own iteration
 // (measured: 1 is 15 % slower -- vmcnt retires in order, so every later wait also waits for that HBM stream)
@@ -67,17 +69,17 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x4 ld_stream4(const u32 *p) {
-    return GTARS_TOK_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)) : *reinterpret_cast<const u32x4 *>(p);
+    return (GTARS_TOK_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)) : *reinterpret_cast<const u32x4 *>(p);
 }
 __device__ __forceinline__ u32x2 ld_stream2(const u32 *p) {
-    return GTARS_TOK_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)) : *reinterpret_cast<const u32x2 *>(p);
+    return (GTARS_TOK_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)) : *reinterpret_cast<const u32x2 *>(p);
 }
 __device__ __forceinline__ void st_stream(u32 *p, u32 v) {
-    if (GTARS_TOK_NT) __builtin_nontemporal_store(v, p); else *p = v;
+    if (GTARS_TOK_NT & 4) __builtin_nontemporal_store(v, p); else *p = v;
 }
 __device__ __forceinline__ void st_stream2(u64 *p, u64 a, u64 b) {
     u64x2 v = {a, b};
-    if (GTARS_TOK_NT) __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(p)); else *reinterpret_cast<u64x2 *>(p) = v;
+    if (GTARS_TOK_NT & 2) __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(p)); else *reinterpret_cast<u64x2 *>(p) = v;
 }
 
 template <bool FILTER>
