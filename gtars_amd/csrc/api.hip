@@ -245,7 +245,23 @@ struct gtars_index {
 struct gtars_igd {
     u32 n_chrom = 0, n_files = 0;
     u64 n = 0;
-    std::vector<i32> h_starts, h_ends;
+    // host copy of the stored starts / ends: filled at build by the host-sort path, on first use
+    // (total_records / export) after a device build
+    mutable std::vector<i32> h_starts, h_ends;
+    mutable std::mutex mirror_mu;
+    mutable bool mirror_ready = false;
+    gtars_status ensure_mirror() const {
+        std::lock_guard<std::mutex> lk(mirror_mu);
+        if (mirror_ready) return GTARS_OK;
+        h_starts.resize(n);
+        h_ends.resize(n);
+        if (n) {
+            GT_HIP(hipMemcpy(h_starts.data(), starts.p, n * sizeof(i32), hipMemcpyDeviceToHost));
+            GT_HIP(hipMemcpy(h_ends.data(), ends.p, n * sizeof(i32), hipMemcpyDeviceToHost));
+        }
+        mirror_ready = true;
+        return GTARS_OK;
+    }
     DevBuf<i32> starts, ends, values, chrom_maxlen;
     DevBuf<u32> files, chrom_off;
     // tiles of IGD_TILE_RECORDS consecutive records of one chromosome (batch sweep, igd_sweep.hip)
@@ -999,6 +1015,80 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
     if (n && (!chrom || !start || !end || !file_idx)) return fail(GTARS_ERR_INVALID_ARG, "NULL record arrays");
     gtars_status st = require_device();
     if (st) return st;
+    if (n >= 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "too many records");
+    if (use_device_sort(n)) {
+        // ---- large builds: one sequential host pass (drop rule, bounds, per-chromosome counts and max
+        // length), then upload, radix sort and gather on the device.  Dropped records get the key
+        // n_chrom, so they sort behind every chromosome and are cut off.
+        std::vector<u32> kc(n), hoff(n_chrom + 1, 0);
+        std::vector<i32> hml(n_chrom, 0);
+        u64 kept = 0;
+        for (u64 i = 0; i < n; ++i) {
+            // Igd::add drop rule (igd.rs:114-116)
+            if (start[i] < 0 || end[i] < 0 || start[i] >= end[i]) {
+                kc[i] = n_chrom;
+                continue;
+            }
+            if (chrom[i] >= n_chrom) return fail(GTARS_ERR_INVALID_ARG, "record chromosome id >= n_chrom");
+            if (file_idx[i] >= n_files) return fail(GTARS_ERR_INVALID_ARG, "record file_idx >= n_files");
+            kc[i] = chrom[i];
+            hoff[chrom[i] + 1]++;
+            hml[chrom[i]] = std::max(hml[chrom[i]], end[i] - start[i]);
+            ++kept;
+        }
+        for (u32 c = 0; c < n_chrom; ++c) hoff[c + 1] += hoff[c];
+        auto *g = new gtars_igd();
+        g->n_chrom = n_chrom;
+        g->n_files = n_files;
+        g->n = kept;
+        auto bail = [&](gtars_status e) {
+            gtars_igd_free(g);
+            return e;
+        };
+        ScopedDev in, ws;
+        const u32 n32 = (u32)n;
+        if ((st = in.alloc((size_t)n * 4 * 6))) return bail(st);
+        u32 *d_kc = in.as<u32>(), *d_s = d_kc + n, *d_e = d_s + n, *d_f = d_e + n, *d_v = d_f + n, *d_perm = d_v + n;
+        if (hipMemcpy(d_kc, kc.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_s, start, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_e, end, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_f, file_idx, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            (value ? hipMemcpy(d_v, value, n * 4, hipMemcpyHostToDevice) : hipMemset(d_v, 0, n * 4)) != hipSuccess)
+            return bail(fail(GTARS_ERR_HIP, "IGD build: upload failed"));
+        // chromosome-major, then start, ties in insertion order (finalize: stable sort by start, igd.rs:157-167);
+        // kept starts are >= 0, so u32 order == i32 order
+        const size_t ws_bytes = device_sort_perm_ws_bytes(n32);
+        if ((st = ws.alloc(ws_bytes))) return bail(st);
+        if ((st = device_sort_perm_ws(d_kc, d_s, nullptr, n32, n_chrom + 1, d_perm, ws.p, ws_bytes, nullptr))) return bail(st);
+        const size_t kb = std::max<u64>(kept, 1) * 4;
+        if (hipMalloc((void **)&g->starts.p, kb) != hipSuccess || hipMalloc((void **)&g->ends.p, kb) != hipSuccess ||
+            hipMalloc((void **)&g->files.p, kb) != hipSuccess || hipMalloc((void **)&g->values.p, kb) != hipSuccess)
+            return bail(fail(GTARS_ERR_HIP, "IGD build: device allocation failed"));
+        g->starts.n = g->ends.n = g->files.n = g->values.n = kept;
+        const u32 k32 = (u32)kept;
+        if ((st = device_gather_u32(d_s, d_perm, k32, (u32 *)g->starts.p, nullptr))) return bail(st);
+        if ((st = device_gather_u32(d_e, d_perm, k32, (u32 *)g->ends.p, nullptr))) return bail(st);
+        if ((st = device_gather_u32(d_f, d_perm, k32, g->files.p, nullptr))) return bail(st);
+        if ((st = device_gather_u32(d_v, d_perm, k32, (u32 *)g->values.p, nullptr))) return bail(st);
+        if (hipDeviceSynchronize() != hipSuccess) return bail(fail(GTARS_ERR_HIP, "IGD build: device sort failed"));
+        std::vector<u32> tf, tc, tch;
+        for (u32 c = 0; c < n_chrom; ++c)
+            for (u32 p = hoff[c]; p < hoff[c + 1]; p += IGD_TILE_RECORDS) {
+                tf.push_back(p);
+                tc.push_back(std::min<u32>(IGD_TILE_RECORDS, hoff[c + 1] - p));
+                tch.push_back(c);
+            }
+        g->n_tiles = (u32)tf.size();
+        st = g->tile_first.upload(tf);
+        if (!st) st = g->tile_cnt.upload(tc);
+        if (!st) st = g->tile_chrom.upload(tch);
+        if (!st) st = g->chrom_off.upload(hoff);
+        if (!st) st = g->chrom_maxlen.upload(hml);
+        if (st) return bail(st);
+        *out = g;
+        return GTARS_OK;
+    }
+    // ---- small builds: host stable sort
     // Igd::add drop rule (igd.rs:114-116)
     std::vector<u32> keep;
     keep.reserve(n);
@@ -1008,25 +1098,11 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
         if (file_idx[i] >= n_files) return fail(GTARS_ERR_INVALID_ARG, "record file_idx >= n_files");
         keep.push_back((u32)i);
     }
-    if (keep.size() >= 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "too many records");
     // chromosome-major, then start, ties in insertion order (finalize: stable sort by start, igd.rs:157-167)
-    if (use_device_sort(keep.size())) {
-        std::vector<u32> hc(keep.size()), hs(keep.size()), perm;
-        for (size_t k = 0; k < keep.size(); ++k) {
-            hc[k] = chrom[keep[k]];
-            hs[k] = (u32)start[keep[k]];  // kept starts are >= 0: u32 order == i32 order
-        }
-        st = sorted_perm_device(hc, hs, nullptr, n_chrom, perm);
-        if (st) return st;
-        std::vector<u32> sorted(keep.size());
-        for (size_t k = 0; k < keep.size(); ++k) sorted[k] = keep[perm[k]];
-        keep.swap(sorted);
-    } else {
-        std::stable_sort(keep.begin(), keep.end(), [&](u32 a, u32 b) {
-            if (chrom[a] != chrom[b]) return chrom[a] < chrom[b];
-            return start[a] < start[b];
-        });
-    }
+    std::stable_sort(keep.begin(), keep.end(), [&](u32 a, u32 b) {
+        if (chrom[a] != chrom[b]) return chrom[a] < chrom[b];
+        return start[a] < start[b];
+    });
     auto *g = new gtars_igd();
     g->n_chrom = n_chrom;
     g->n_files = n_files;
@@ -1035,6 +1111,7 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
     std::vector<u32> hf(g->n), hoff(n_chrom + 1, 0);
     g->h_starts.resize(g->n);
     g->h_ends.resize(g->n);
+    g->mirror_ready = true;
     for (u64 p = 0; p < g->n; ++p) {
         const u32 i = keep[p];
         g->h_starts[p] = start[i];
@@ -1090,6 +1167,7 @@ uint32_t gtars_igd_n_files(const gtars_igd_t *g) { return g ? g->n_files : 0; }
 uint64_t gtars_igd_total_records(const gtars_igd_t *g, int32_t nbp) {
     if (!g) return 0;
     if (nbp <= 0) nbp = 16384;
+    if (g->ensure_mirror()) return 0;
     u64 t = 0;
     for (u64 i = 0; i < g->n; ++i) t += (u64)((g->h_ends[i] - 1) / nbp - g->h_starts[i] / nbp + 1);
     return t;
@@ -1100,6 +1178,10 @@ gtars_status gtars_igd_export(const gtars_igd_t *g, uint32_t *chrom, int32_t *st
     if (!g) return fail(GTARS_ERR_INVALID_ARG, "NULL handle");
     const size_t n = g->n;
     if (!n) return GTARS_OK;
+    if (start || end) {
+        gtars_status ms = g->ensure_mirror();
+        if (ms) return ms;
+    }
     if (start) memcpy(start, g->h_starts.data(), n * 4);
     if (end) memcpy(end, g->h_ends.data(), n * 4);
     if (value) GT_HIP(hipMemcpy(value, g->values.p, n * 4, hipMemcpyDeviceToHost));
