@@ -629,3 +629,84 @@ def test_tokenize_wide_nested_and_degenerate_universe_intervals(ga):
     assert np.array_equal(off_g, off_o)
     assert np.array_equal(ids_g, ids_o)
     assert len(ids_o) > 20 * nq  # the wide intervals make every query a multi-hit query
+
+
+def test_config3_igd_full_size_properties(ga):
+    """BASELINE config 3 at full size (5e7 records, F = 1000, 1e7 queries): size-independent properties of
+    the per-file vectors, plus bit-exact parity with the oracle's literal tile walk on one chromosome."""
+    from gtars_amd import synth
+
+    F = 1000
+    db = synth.make_igd_db(50_000_000, F)
+    q = synth.make_background_queries(10_000_000)
+    g = ga.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=F)
+    qc, qs, qe = q["chrom"], q["start"], q["end"]
+    pair = g.count_set_overlaps(qc, qs, qe, 1)
+    binr = g.count_region_hits(qc, qs, qe, 1)
+    assert pair.sum() > 0 and (binr <= pair).all() and (binr <= len(qc)).all()
+    # additivity over a split of the batch (pairwise and binary are both sums over queries)
+    h = len(qc) // 3
+    for fn, whole in ((g.count_set_overlaps, pair), (g.count_region_hits, binr)):
+        a = fn(qc[:h], qs[:h], qe[:h], 1)
+        b = fn(qc[h:], qs[h:], qe[h:], 1)
+        assert np.array_equal(a + b, whole)
+    # order of the queries does not matter: the (chromosome, start)-sorted batch takes the no-sort path
+    order = np.lexsort((qs, qc))
+    assert np.array_equal(g.count_set_overlaps(qc[order], qs[order], qe[order], 1), pair)
+    assert np.array_equal(g.count_region_hits(qc[order], qs[order], qe[order], 1), binr)
+    # a larger min_overlap can only lose hits
+    assert (g.count_set_overlaps(qc[:h], qs[:h], qe[:h], 50) <= g.count_set_overlaps(qc[:h], qs[:h], qe[:h], 1)).all()
+    # oracle parity on chr21 (index 20): literal tile walk over that chromosome's records
+    o = oracle.Igd()
+    L = oracle.lib()
+    sel = np.nonzero(db["chrom"] == 20)[0]
+    for i in sel:
+        L.orc_igd_add(o._h, 20, int(db["start"][i]), int(db["end"][i]), 0, int(db["file"][i]))
+    o.n_files = F
+    o.finalize()
+    qsel = np.nonzero(qc == 20)[0][:20_000]
+    assert np.array_equal(g.count_set_overlaps(qc[qsel], qs[qsel], qe[qsel], 1),
+                          o.count_set_overlaps(qc[qsel], qs[qsel], qe[qsel], 1, n_files=F))
+    assert np.array_equal(g.count_region_hits(qc[qsel], qs[qsel], qe[qsel], 1),
+                          o.count_region_hits(qc[qsel], qs[qsel], qe[qsel], 1, n_files=F))
+
+
+def test_config4_lola_counts_identities(ga):
+    """BASELINE config 4 shape (scaled to 400 DB sets x 25k): support counts through the binary IGD count and
+    the contingency kernel satisfy a+b = universe hits, a+c = |user|, a+b+c+d = |universe|, and equal the
+    oracle's cells on a sample of the DB sets."""
+    from gtars_amd import synth
+
+    F, per = 400, 25_000
+    db = synth.make_igd_db(F * per, F, seed=6)
+    uni = synth.make_universe(200_000, seed=3)
+    rng = np.random.default_rng(9)
+    sel = np.sort(rng.choice(len(uni["chrom"]), 20_000, replace=False))
+    g = ga.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=F)
+    uh = g.count_region_hits(uni["chrom"], uni["start"], uni["end"], 1).astype(np.int64)
+    sh = g.count_region_hits(uni["chrom"][sel], uni["start"][sel], uni["end"][sel], 1).astype(np.int64)
+    import torch
+
+    from gtars_amd._lib import check, lib
+
+    dev = torch.device("cuda:0")
+    d_sh, d_uh = torch.from_numpy(sh).to(dev), torch.from_numpy(uh).to(dev)
+    cells = [torch.empty(F, dtype=torch.int64, device=dev) for _ in range(4)]
+    check(lib.gtars_lola_contingency_device(d_sh.data_ptr(), d_uh.data_ptr(), F, len(sel), len(uni["chrom"]),
+                                            *[x.data_ptr() for x in cells], torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    a, b, c, d = (x.cpu().numpy() for x in cells)
+    for got, exp in zip((a, b, c, d), oracle.lola_contingency(sh, uh, len(sel), len(uni["chrom"]))):
+        assert np.array_equal(got, exp)
+    assert np.array_equal(a + b, uh) and (a + c == len(sel)).all() and (a + b + c + d == len(uni["chrom"])).all()
+    assert (sh <= uh).all()  # the user set is a subset of the universe
+    # oracle parity of the support vectors on the records of 8 DB sets
+    keep = np.isin(db["file"], np.arange(8))
+    o = oracle.Igd()
+    L = oracle.lib()
+    for i in np.nonzero(keep)[0]:
+        L.orc_igd_add(o._h, int(db["chrom"][i]), int(db["start"][i]), int(db["end"][i]), 0, int(db["file"][i]))
+    o.n_files = 8
+    o.finalize()
+    exp = o.count_region_hits(uni["chrom"][sel], uni["start"][sel], uni["end"][sel], 1, n_files=8)
+    assert np.array_equal(sh[:8], exp.astype(np.int64))
