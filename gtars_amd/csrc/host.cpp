@@ -34,6 +34,24 @@ using gtars::fail;
 
 namespace {
 
+// Host threads worth starting: hardware threads, capped by the container's CPU quota (cgroup v2 cpu.max)
+// and by `cap`; GTARS_HOST_THREADS overrides.
+unsigned host_thread_budget(unsigned cap) {
+    if (const char *e = getenv("GTARS_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
+    unsigned nt = std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            nt = std::min<unsigned>(nt, (unsigned)((quota + period - 1) / period));
+        fclose(f);
+    }
+    return std::max(1u, std::min(nt, cap));
+}
+
+}  // namespace
+
+namespace {
+
 // ------------------------------------------------------------------ file IO
 
 bool ends_with(const std::string &s, const char *suf) {
@@ -419,9 +437,7 @@ gtars_status gtars_regionset_from_bed(const char *path, gtars_regionset_t **out)
             p = next;
         }
     };
-    unsigned nt = std::thread::hardware_concurrency();
-    if (const char *ev = getenv("GTARS_HOST_THREADS")) nt = (unsigned)std::max(1, atoi(ev));
-    nt = std::max(1u, std::min(nt, 32u));
+    unsigned nt = host_thread_budget(32);
     nt = (unsigned)std::min<size_t>(nt, data.size() / (1u << 20) + 1);
     std::vector<size_t> cut(nt + 1, data.size());
     cut[0] = 0;
@@ -1254,9 +1270,7 @@ struct FragTable {
 gtars_status read_fragment_table(const char *path, FragTable &ft) {
     std::string data, err;
     if (!read_all(path, data, err)) return fail(GTARS_ERR_IO, err);
-    unsigned nt = std::thread::hardware_concurrency();
-    if (const char *e = getenv("GTARS_HOST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
-    nt = std::max(1u, std::min(nt, 32u));
+    unsigned nt = host_thread_budget(32);
     nt = (unsigned)std::min<size_t>(nt, data.size() / (1u << 20) + 1);
     std::vector<size_t> cut(nt + 1, data.size());
     cut[0] = 0;
@@ -1597,9 +1611,7 @@ gtars_status gtars_igddb_from_bed_files(const char *const *paths, uint64_t n_pat
     *out = nullptr;
     std::vector<IgdBedFile> parsed(n_paths);
     {
-        unsigned nt = std::thread::hardware_concurrency();
-        if (const char *ev = getenv("GTARS_HOST_THREADS")) nt = (unsigned)std::max(1, atoi(ev));
-        nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(nt, 64u), n_paths));
+        unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(host_thread_budget(64), n_paths));
         std::atomic<uint64_t> next{0};
         auto work = [&] {
             for (uint64_t i = next.fetch_add(1); i < n_paths; i = next.fetch_add(1))
