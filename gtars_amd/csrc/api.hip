@@ -652,6 +652,14 @@ static bool use_lds_path(const gtars_index *ix) {
     static const bool disabled = getenv("GTARS_NO_LDS_PATH") != nullptr;
     return !disabled && ix->kind == GTARS_KIND_BITS && ix->has_accel && tokenize_lds_supported(ix->accel());
 }
+
+// K2 dispatch: Bits-kind indexes with the blocked structure count through k_count_lds, everything else
+// (AIList order is irrelevant for counts, but its index has no blocked structure) through k_count
+static gtars_status count_dispatch(const gtars_index *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min,
+                                   i32 min_overlap, u32 *counts, u8 *any, hipStream_t st) {
+    if (use_lds_path(ix)) return launch_count_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, counts, any, st);
+    return launch_count(ix->view(), ix->kind, qc, qs, qe, nq, has_min, min_overlap, counts, any, st);
+}
 static gtars_status run_fused(const gtars_index *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               int has_min, i32 min_overlap, const EnumOut &out, void *ws, size_t ws_bytes,
                               ScanEpoch &ep, hipStream_t s) {
@@ -722,7 +730,7 @@ gtars_status gtars_count_overlaps_device(const gtars_index_t *ix, const uint32_t
     gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (nq && !d_counts) return fail(GTARS_ERR_INVALID_ARG, "d_counts is NULL");
-    return launch_count(ix->view(), ix->kind, d_qc, d_qs, d_qe, nq, has_min, min_overlap, d_counts, nullptr,
+    return count_dispatch(ix, d_qc, d_qs, d_qe, nq, has_min, min_overlap, d_counts, nullptr,
                         (hipStream_t)stream);
 }
 
@@ -864,7 +872,7 @@ gtars_status gtars_count_overlaps(const gtars_index_t *ix, const uint32_t *qc, c
     ScopedDev d;
     st = d.alloc(nq * 4);
     if (st) return st;
-    st = launch_count(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d.as<u32>(), nullptr, nullptr);
+    st = count_dispatch(ix, q.c, q.s, q.e, nq, has_min, min_overlap, d.as<u32>(), nullptr, nullptr);
     if (st) return st;
     GT_HIP(hipMemcpy(counts, d.p, nq * 4, hipMemcpyDeviceToHost));
     return GTARS_OK;
@@ -928,7 +936,7 @@ gtars_status gtars_any_overlaps(const gtars_index_t *ix, const uint32_t *qc, con
     ScopedDev d;
     st = d.alloc(nq);
     if (st) return st;
-    st = launch_count(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, nullptr, d.as<u8>(), nullptr);
+    st = count_dispatch(ix, q.c, q.s, q.e, nq, has_min, min_overlap, nullptr, d.as<u8>(), nullptr);
     if (st) return st;
     GT_HIP(hipMemcpy(out, d.p, nq, hipMemcpyDeviceToHost));
     return GTARS_OK;
