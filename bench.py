@@ -148,14 +148,20 @@ def main():
 
     if not torch.cuda.is_available() or gtars_amd.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: gtars_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; GTARS_BENCH_BACKEND=gloo lets several ranks share a GPU (plumbing test on a 1-GPU box)
+    backend = os.environ.get("GTARS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
 
     # ---- synthetic workload (per rank: its own slice of the global batch) ----
@@ -189,7 +195,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
