@@ -3,7 +3,7 @@
 # usage (on the GPU box): sh tools/pmc_ablate.sh "0 2 12 30"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/pmc_ablate; rm -rf $O; mkdir -p $O
-export SIZES=${SIZES:-64000000} CONFIGS=${CONFIGS:-512:0:4}
+export SIZES=${SIZES:-64000000} CONFIGS=${CONFIGS:-1024:0:4}
 for A in ${1:-0 2 12 30}; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGTARS_ABLATE=$A $EXTRA -I include \
     -o $O/lib_$A.so -x c++ gtars_amd/csrc/host.cpp -x hip gtars_amd/csrc/api.hip \
