@@ -681,6 +681,23 @@ static gtars_status read_scan_head(const void *ws, hipStream_t s, u64 *total) {
     return GTARS_OK;
 }
 
+// run_fused + read back {total, err}.  The LDS kernel assumes that its whole grid is resident; if other
+// work holds CUs and a look-back spin runs into its limit, the batch is redone by the generic kernel, which
+// draws a ticket for every tile and therefore only ever waits on tiles that are running.
+static gtars_status run_fused_sync(const gtars_index *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min,
+                                   i32 min_overlap, const EnumOut &out, void *ws, size_t ws_bytes, ScanEpoch &ep,
+                                   hipStream_t s, u64 *total) {
+    gtars_status st = run_fused(ix, qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s);
+    if (st) return st;
+    st = read_scan_head(ws, s, total);
+    if (st == GTARS_OK && getenv("GTARS_TEST_FORCE_LOOKBACK_TIMEOUT")) st = GTARS_ERR_INTERNAL;  // test hook
+    if (st != GTARS_ERR_INTERNAL || !use_lds_path(ix) || out.starts || out.ends) return st;
+    ep = ScanEpoch();
+    st = launch_enumerate_fused(ix->view(), ix->kind, qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, s);
+    if (st) return st;
+    return read_scan_head(ws, s, total);
+}
+
 static gtars_status check_query_args(const void *ix, const void *a, const void *b, const void *c, u64 nq) {
     if (!ix) return fail(GTARS_ERR_INVALID_ARG, "NULL handle");
     if (nq && (!a || !b || !c)) return fail(GTARS_ERR_INVALID_ARG, "NULL query arrays");
@@ -699,10 +716,9 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
     st = ws.reserve(wsb);
     if (st) return st;
     EnumOut out{d_offsets, d_ids, nullptr, nullptr, d_ids ? ids_capacity : 0};
-    st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s);
-    if (st) return st;
-    if (total_hits) {
-        st = read_scan_head(ws.ptr, s, total_hits);
+    if (!total_hits) return run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s);
+    {
+        st = run_fused_sync(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s, total_hits);
         if (st) {
             ws.ep = ScanEpoch();  // force a clean workspace next time
             return st;
@@ -780,10 +796,8 @@ static gtars_status enumerate_to_host(const gtars_index_t *ix, const u32 *qc, co
     // pass 1: offsets + total only (no payload buffers)
     EnumOut o1{d_off.as<u64>(), nullptr, nullptr, nullptr, 0};
     ScanEpoch ep;
-    st = run_fused(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, ep, nullptr);
-    if (st) return st;
     u64 h = 0;
-    st = read_scan_head(d_ws.p, nullptr, &h);
+    st = run_fused_sync(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, ep, nullptr, &h);
     if (st) return st;
     if (offsets) GT_HIP(hipMemcpy(offsets, d_off.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
     if (out_n) *out_n = h;
@@ -979,10 +993,8 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
     if ((st = d_ws.alloc(wsb))) return st;
     EnumOut o1{d_off.as<u64>(), nullptr, nullptr, nullptr, 0};
     ScanEpoch ep;
-    st = run_fused(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, ep, nullptr);
-    if (st) return st;
     u64 h = 0;
-    st = read_scan_head(d_ws.p, nullptr, &h);
+    st = run_fused_sync(ix, q.c, q.s, q.e, nq, has_min, min_overlap, o1, d_ws.p, wsb, ep, nullptr, &h);
     if (st) return st;
     ScopedDev d_val;
     if ((st = d_val.alloc(h * 4))) return st;

@@ -713,3 +713,23 @@ def test_config4_lola_counts_identities(ga):
     o.finalize()
     exp = o.count_region_hits(uni["chrom"][sel], uni["start"][sel], uni["end"][sel], 1, n_files=8)
     assert np.array_equal(sh[:8], exp.astype(np.int64))
+
+
+def test_lookback_timeout_falls_back_to_the_generic_kernel(ga, monkeypatch):
+    """If the LDS kernel's look-back runs into its spin limit (its grid was not fully resident), synchronous
+    callers get the batch redone by the generic kernel instead of an error.  The timeout is simulated."""
+    from gtars_amd import synth
+
+    u = synth.make_universe(30_000)
+    q = synth.make_queries(u, 120_000)
+    g, o = _pair(ga, u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    off_o, ids_o = o.tokenize(q["chrom"], q["start"], q["end"])
+    monkeypatch.setenv("GTARS_TEST_FORCE_LOOKBACK_TIMEOUT", "1")
+    _lib = ga._lib
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    off_g, ids_g = g.tokenize(q["chrom"], q["start"], q["end"])
+    names = set(_lib.prof_read())
+    _lib.lib.gtars_prof_enable(0)
+    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+    assert "k_tok_lds" in names and any(n.startswith("k_enum_fused") for n in names), names
