@@ -574,7 +574,12 @@ struct ScopedIndex {
     ~ScopedIndex() { gtars_index_free(ix); }
 };
 
+// count / any / sorted-unique indices do not expose the enumeration order, so whatever `kind` the caller
+// names (IndexedRegionSet defaults to AIList, indexed_region_set.rs:111-113) the Bits form is built: same hit
+// sets, no AIList decomposition at build, and the blocked structure's kernels (k_count_lds, k_tok_lds).
 gtars_status build_other_index(const gtars_regionset *other, int kind, ScopedIndex &out) {
+    if (kind != GTARS_KIND_BITS && kind != GTARS_KIND_AILIST) return fail(GTARS_ERR_INVALID_ARG, "unknown index kind");
+    kind = GTARS_KIND_BITS;
     return gtars_index_build(other->chrom_ids.data(), other->starts.data(), other->ends.data(), nullptr,
                              other->size(), (uint32_t)other->chroms.names.size(), kind, &out.ix);
 }
