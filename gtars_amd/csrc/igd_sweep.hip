@@ -114,17 +114,61 @@ k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict
     u32 *bins = t_f + CAP;  // [n_files]
     for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
 
-    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads();  // previous tile fully served (and bins zeroed) before LDS is overwritten
-        const u32 p0 = tile_first[tile], cnt = tile_cnt[tile], c = tile_chrom[tile];
-        const u32 seg_hi = v.chrom_off[c + 1];
-        const u32 n_lds = min((u32)CAP, seg_hi - p0);  // tile + halo, never past the chromosome
-        for (u32 i = threadIdx.x; i < n_lds; i += SW_TPB) {
-            t_s[i] = v.starts[p0 + i];
-            t_e[i] = v.ends[p0 + i];
-            t_f[i] = v.files[p0 + i];
+    // Software pipeline over the workgroup's tiles: the NEXT tile's records are loaded into registers
+    // before the current tile's queries are served and committed to LDS afterwards, so their HBM latency
+    // hides behind the LDS-bound query loop.
+    constexpr int RPT = (CAP + SW_TPB - 1) / SW_TPB;
+    i32 rg_s[RPT], rg_e[RPT];
+    u32 rg_f[RPT];
+    struct TileDesc {
+        u32 p0, cnt, c, seg_hi, n_lds;
+    };
+    auto describe = [&](u32 t) {
+        TileDesc d;
+        d.p0 = tile_first[t];
+        d.cnt = tile_cnt[t];
+        d.c = tile_chrom[t];
+        d.seg_hi = v.chrom_off[d.c + 1];
+        d.n_lds = min((u32)CAP, d.seg_hi - d.p0);  // tile + halo, never past the chromosome
+        return d;
+    };
+    auto issue = [&](const TileDesc &d) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const u32 i = threadIdx.x + (u32)k * SW_TPB;
+            if (i < d.n_lds) {
+                rg_s[k] = v.starts[d.p0 + i];
+                rg_e[k] = v.ends[d.p0 + i];
+                rg_f[k] = v.files[d.p0 + i];
+            }
         }
-        __syncthreads();
+    };
+    auto commit = [&](const TileDesc &d) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const u32 i = threadIdx.x + (u32)k * SW_TPB;
+            if (i < d.n_lds) {
+                t_s[i] = rg_s[k];
+                t_e[i] = rg_e[k];
+                t_f[i] = rg_f[k];
+            }
+        }
+    };
+    TileDesc cur{}, nxt{};
+    if (blockIdx.x < n_tiles) {
+        cur = describe(blockIdx.x);
+        issue(cur);
+        __syncthreads();  // bins zeroed
+        commit(cur);
+    }
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();  // the current tile is in LDS
+        const u32 next = tile + gridDim.x;
+        if (next < n_tiles) {
+            nxt = describe(next);
+            issue(nxt);
+        }
+        const u32 p0 = cur.p0, cnt = cur.cnt, c = cur.c, seg_hi = cur.seg_hi, n_lds = cur.n_lds;
         const i32 max_len = v.chrom_maxlen[c];
         const u32 n_seg = seg_hi - p0;  // records from the tile start to the end of the chromosome
         // record i (relative to p0): LDS if staged, global otherwise (rare: scans longer than the halo)
@@ -186,6 +230,11 @@ k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict
                 }
                 atomicAdd(&bins[f], 1u);
             }
+        }
+        __syncthreads();  // every query of the current tile served: LDS may be overwritten
+        if (next < n_tiles) {
+            commit(nxt);
+            cur = nxt;
         }
     }
     __syncthreads();
