@@ -266,6 +266,9 @@ struct gtars_igd {
     DevBuf<u32> files, chrom_off;
     // tiles of IGD_TILE_RECORDS consecutive records of one chromosome (batch sweep, igd_sweep.hip)
     DevBuf<u32> tile_first, tile_cnt, tile_chrom;
+    // per tile: the largest end among the chromosome's records BEFORE the tile (0: none) -- the carry-in of the
+    // prefix maximum the sweep builds in LDS
+    DevBuf<i32> tile_carry;
     u32 n_tiles = 0;
     IgdView view() const {
         IgdView v;
@@ -1105,6 +1108,23 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
         if (!st) st = g->chrom_off.upload(hoff);
         if (!st) st = g->chrom_maxlen.upload(hml);
         if (st) return bail(st);
+        {
+            // tile_carry: per-tile maximum end on the device, exclusive running maximum per chromosome on the host
+            std::vector<i32> tmax(g->n_tiles, 0), carry(g->n_tiles, 0);
+            ScopedDev d_tmax;
+            if ((st = d_tmax.alloc((size_t)g->n_tiles * 4))) return bail(st);
+            if ((st = launch_igd_tile_max_end(g->ends.p, g->tile_first.p, g->tile_cnt.p, g->n_tiles, d_tmax.as<i32>(), nullptr)))
+                return bail(st);
+            if (g->n_tiles && hipMemcpy(tmax.data(), d_tmax.p, (size_t)g->n_tiles * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                return bail(fail(GTARS_ERR_HIP, "IGD build: tile maxima readback failed"));
+            i32 run = 0;
+            for (u32 t = 0; t < g->n_tiles; ++t) {
+                if (t == 0 || tch[t] != tch[t - 1]) run = 0;
+                carry[t] = run;
+                run = std::max(run, tmax[t]);
+            }
+            if ((st = g->tile_carry.upload(carry))) return bail(st);
+        }
         *out = g;
         return GTARS_OK;
     }
@@ -1150,7 +1170,17 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
             tch.push_back(c);
         }
     g->n_tiles = (u32)tf.size();
-    st = g->starts.upload(g->h_starts);
+    std::vector<i32> carry(g->n_tiles, 0);
+    {
+        i32 run = 0;
+        for (u32 t = 0; t < g->n_tiles; ++t) {
+            if (t == 0 || tch[t] != tch[t - 1]) run = 0;
+            carry[t] = run;
+            for (u32 p = tf[t]; p < tf[t] + tc[t]; ++p) run = std::max(run, g->h_ends[p]);
+        }
+    }
+    st = g->tile_carry.upload(carry);
+    if (!st) st = g->starts.upload(g->h_starts);
     if (!st) st = g->tile_first.upload(tf);
     if (!st) st = g->tile_cnt.upload(tc);
     if (!st) st = g->tile_chrom.upload(tch);
@@ -1178,6 +1208,7 @@ void gtars_igd_free(gtars_igd_t *g) {
     g->tile_first.release();
     g->tile_cnt.release();
     g->tile_chrom.release();
+    g->tile_carry.release();
     delete g;
 }
 
@@ -1227,7 +1258,7 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
         Workspace &ws = tls_workspace(2, (hipStream_t)stream);
         st = ws.reserve(igd_sweep_ws_bytes(nq, g->n_tiles, g->n_chrom));
         if (st) return st;
-        return launch_igd_sweep(g->view(), g->tile_first.p, g->tile_cnt.p, g->tile_chrom.p, g->n_tiles, d_qc, d_qs,
+        return launch_igd_sweep(g->view(), g->tile_first.p, g->tile_cnt.p, g->tile_chrom.p, g->tile_carry.p, g->n_tiles, d_qc, d_qs,
                                 d_qe, nq, min_overlap, binary, d_hits, ws.ptr, ws.bytes, (hipStream_t)stream);
     }
     return launch_igd_count(g->view(), d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);

@@ -210,7 +210,10 @@ gtars_status device_sort_perm_ws(const u32 *d_chrom, const u32 *d_k1, const u32 
 // IGD batch sweep (igd_sweep.hip)
 bool igd_sweep_supported(const IgdView &v, u64 nq);
 size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom);
+gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, const u32 *tile_cnt, u32 n_tiles, i32 *tile_max,
+                                     hipStream_t st);
 gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
+                              const i32 *tile_carry,
                               u32 n_tiles, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, i32 min_overlap,
                               int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st);
 constexpr u32 IGD_TILE_RECORDS = 2048;

@@ -103,7 +103,8 @@ __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first,
 template <bool BINARY>
 __global__ void __launch_bounds__(SW_TPB)
 k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
-            const u32 *__restrict__ tile_chrom, u32 n_tiles, const u32 *__restrict__ sqs, const u32 *__restrict__ sqe,
+            const u32 *__restrict__ tile_chrom, const i32 *__restrict__ tile_carry, u32 n_tiles,
+            const u32 *__restrict__ sqs, const u32 *__restrict__ sqe,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap,
             unsigned long long *__restrict__ hits) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
@@ -111,7 +112,9 @@ k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict
     i32 *t_s = reinterpret_cast<i32 *>(sm);
     i32 *t_e = t_s + CAP;
     u32 *t_f = reinterpret_cast<u32 *>(t_e + CAP);
-    u32 *bins = t_f + CAP;  // [n_files]
+    i32 *t_pm = reinterpret_cast<i32 *>(t_f + CAP);  // prefix maximum of the ends (carry-in included)
+    u32 *bins = reinterpret_cast<u32 *>(t_pm + CAP);  // [n_files]
+    __shared__ i32 s_wmax[SW_TPB / 64];
     for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
 
     // Software pipeline over the workgroup's tiles: the NEXT tile's records are loaded into registers
@@ -122,6 +125,7 @@ k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict
     u32 rg_f[RPT];
     struct TileDesc {
         u32 p0, cnt, c, seg_hi, n_lds;
+        i32 carry;
     };
     auto describe = [&](u32 t) {
         TileDesc d;
@@ -130,6 +134,7 @@ k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict
         d.c = tile_chrom[t];
         d.seg_hi = v.chrom_off[d.c + 1];
         d.n_lds = min((u32)CAP, d.seg_hi - d.p0);  // tile + halo, never past the chromosome
+        d.carry = tile_carry[t];
         return d;
     };
     auto issue = [&](const TileDesc &d) {
@@ -163,6 +168,40 @@ k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict
     }
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();  // the current tile is in LDS
+        {
+            // t_pm[i] = max(carry, ends[0..i]): ascending, so "first record that can overlap a query" is a
+            // binary search for t_pm > q_start.  Blocked layout: thread t owns records [t*RPT, (t+1)*RPT).
+            const u32 base = threadIdx.x * RPT;
+            i32 loc[RPT];
+            i32 run = 0;  // ends are > 0 (Igd::add drop rule)
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const u32 i = base + k;
+                run = max(run, i < cur.n_lds ? t_e[i] : 0);
+                loc[k] = run;
+            }
+            // exclusive maximum over the threads before this one: wave shuffles, then one LDS word per wave
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            i32 inc = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const i32 y = __shfl_up(inc, d, 64);
+                if (lane >= d) inc = max(inc, y);
+            }
+            if (lane == 63) s_wmax[wave] = inc;
+            i32 excl = __shfl_up(inc, 1, 64);
+            if (lane == 0) excl = 0;
+            __syncthreads();
+            i32 before = cur.carry;
+            for (int w = 0; w < wave; ++w) before = max(before, s_wmax[w]);
+            before = max(before, excl);
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const u32 i = base + k;
+                if (i < cur.n_lds) t_pm[i] = max(before, loc[k]);
+            }
+            __syncthreads();
+        }
         const u32 next = tile + gridDim.x;
         if (next < n_tiles) {
             nxt = describe(next);
@@ -178,15 +217,31 @@ k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict
         const u32 q_lo = ql[tile], q_hi = qh[tile];
         for (u32 qi = q_lo + threadIdx.x; qi < q_hi; qi += SW_TPB) {
             const i32 s = (i32)sqs[qi], e = (i32)sqe[qi];
-            const i32 key = s > max_len ? s - max_len : 0;
-            // lower_bound of key: inside the tile by ownership
-            u32 lo = 0, hi = cnt;
-            while (lo < hi) {
-                const u32 mid = lo + ((hi - lo) >> 1);
-                if (t_s[mid] < key)
-                    lo = mid + 1;
-                else
-                    hi = mid;
+            u32 lo = 0, hi;
+            if (min_overlap >= 1) {
+                // an overlap of >= 1 bp needs end > q_start: start at the first staged record whose prefix-max
+                // end is > q_start.  It is never before lower_bound(q_start - max_len) (everything in between
+                // ends at or before q_start), so ownership by this tile still holds; if no staged record
+                // qualifies the scan goes on in global memory from the end of the staged range.
+                hi = n_lds;
+                while (lo < hi) {
+                    const u32 mid = lo + ((hi - lo) >> 1);
+                    if (t_pm[mid] <= s)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+            } else {
+                const i32 key = s > max_len ? s - max_len : 0;
+                // lower_bound of key: inside the tile by ownership
+                hi = cnt;
+                while (lo < hi) {
+                    const u32 mid = lo + ((hi - lo) >> 1);
+                    if (t_s[mid] < key)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
             }
             // binary counting: the files already credited to this query, as packed u16 pairs in
             // registers (no memory latency in the membership test); 0xFFFF = empty (n_files <= 16384)
@@ -195,12 +250,21 @@ k_igd_sweep(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict
 #pragma unroll
             for (int k = 0; k < IGD_SEEN / 2; ++k) sl[k] = 0xFFFFFFFFu;
             for (u32 r = lo; r < n_seg; ++r) {
-                const i32 rs = r_start(r);
+                // the three fields of a record in one LDS round trip
+                i32 rs, re;
+                u32 f;
+                if (r < n_lds) {
+                    rs = t_s[r];
+                    re = t_e[r];
+                    f = t_f[r];
+                } else {
+                    rs = v.starts[p0 + r];
+                    re = v.ends[p0 + r];
+                    f = v.files[p0 + r];
+                }
                 if (rs >= e) break;
-                const i32 re = r_end(r);
                 const i32 ov = (re < e ? re : e) - (rs > s ? rs : s);
                 if (ov < min_overlap) continue;
-                const u32 f = r_file(r);
                 if (BINARY) {
                     // credit (query, file) only at its first hit in database order (igd.rs:563-590):
                     // compare with the files already credited to this query
@@ -258,8 +322,32 @@ size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom) {
     return (size_t)nq * 4 * 7 + (size_t)n_tiles * 8 + ((size_t)n_chrom + 2) * 4 + 256 + device_sort_perm_ws_bytes((u32)nq);
 }
 
+// per-tile maximum end (index build: the carry-in of the sweep's prefix maximum is its running maximum)
+__global__ void k_igd_tile_max_end(const i32 *__restrict__ ends, const u32 *__restrict__ tile_first,
+                                   const u32 *__restrict__ tile_cnt, u32 n_tiles, i32 *__restrict__ tile_max) {
+    __shared__ i32 s_m[4];
+    const u32 t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const u32 p0 = tile_first[t], cnt = tile_cnt[t];
+    i32 m = 0;
+    for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) m = max(m, ends[p0 + i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_max[t] = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+}
+
+gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, const u32 *tile_cnt, u32 n_tiles, i32 *tile_max,
+                                     hipStream_t st) {
+    if (!n_tiles) return GTARS_OK;
+    hipLaunchKernelGGL(k_igd_tile_max_end, dim3(n_tiles), dim3(256), 0, st, ends, tile_first, tile_cnt, n_tiles, tile_max);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
 gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
-                              u32 n_tiles, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq64, i32 min_overlap,
+                              const i32 *tile_carry, u32 n_tiles, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq64, i32 min_overlap,
                               int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st) {
     const u32 nq = (u32)nq64;
     if (ws_bytes < igd_sweep_ws_bytes(nq, n_tiles, v.n_chrom)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
@@ -299,7 +387,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32
         hipLaunchKernelGGL(k_igd_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tile_first, tile_cnt,
                            tile_chrom, n_tiles, ss, cq_off, ql, qh);
     }
-    const size_t lds = ((size_t)(IGD_TILE + IGD_HALO) * 3 + v.n_files) * 4;
+    const size_t lds = ((size_t)(IGD_TILE + IGD_HALO) * 4 + v.n_files) * 4;
     int dev = 0, cus = 256;
     GT_HIP(hipGetDevice(&dev));
     GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -312,7 +400,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32
     const unsigned grid = (unsigned)std::min<u64>((u64)cus * per_cu, n_tiles);
     {
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tile_first, tile_cnt, tile_chrom, n_tiles, ss, se,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tile_first, tile_cnt, tile_chrom, tile_carry, n_tiles, ss, se,
                            ql, qh, min_overlap, (unsigned long long *)hits);
     }
     GT_HIP(hipGetLastError());
