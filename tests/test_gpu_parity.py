@@ -733,3 +733,39 @@ def test_lookback_timeout_falls_back_to_the_generic_kernel(ga, monkeypatch):
     _lib.lib.gtars_prof_enable(0)
     assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
     assert "k_tok_lds" in names and any(n.startswith("k_enum_fused") for n in names), names
+
+
+def test_scan_epoch_wraps_after_16k_launches(ga):
+    """The chained-scan workspace is never cleared between launches: granules carry a 14-bit launch epoch.
+    After 16383 launches on one stream the epoch wraps (one memset); results before, at and after the wrap
+    stay bit-exact, also when batch sizes (and thus tile counts and ticket ranges) change in between."""
+    import torch
+    from gtars_amd import synth
+
+    u = synth.make_universe(5_000)
+    g, o = _pair(ga, u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    batches = []
+    for nq, seed in ((9_000, 1), (300_001, 2)):   # one tile per workgroup / more tiles than workgroups
+        q = synth.make_queries(u, nq, seed=seed)
+        qc, qs, qe = (torch.from_numpy(q[k].view(np.int32)).to(dev) for k in ("chrom", "start", "end"))
+        off_o, ids_o = o.tokenize(q["chrom"], q["start"], q["end"])
+        offsets = torch.empty(len(q["chrom"]) + 1, dtype=torch.int64, device=dev)
+        ids = torch.empty(len(ids_o) + 8, dtype=torch.int32, device=dev)
+        batches.append((qc, qs, qe, offsets, ids, off_o, ids_o))
+
+    def run(b, sync):
+        qc, qs, qe, offsets, ids, off_o, ids_o = b
+        h = g.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), qc.numel(), offsets.data_ptr(), ids.data_ptr(),
+                              ids.numel(), st, sync=sync)
+        if sync:
+            assert h == len(ids_o)
+            assert np.array_equal(offsets.cpu().numpy().view(np.uint64), off_o)
+            assert np.array_equal(ids[:h].cpu().numpy().view(np.uint32), ids_o)
+
+    for i in range(16_600):
+        big = (i % 997 == 0)
+        check = i in (0, 1, 16_380, 16_381, 16_382, 16_383, 16_384, 16_385, 16_599) or big
+        run(batches[1] if big else batches[0], check)
+    run(batches[1], True)
