@@ -76,9 +76,32 @@ __device__ __forceinline__ u32 lb_u32(const u32 *__restrict__ a, u32 lo, u32 hi,
 }
 
 // per-chromosome segments of the sorted queries
-__global__ void k_igd_chrom_segments(const u32 *__restrict__ sorted_chrom, u32 nq, u32 n_chrom, u32 *__restrict__ cq_off) {
+// `perm` (may be NULL: the batch is already ordered) maps a sorted position to its row of `chrom_key`, so the
+// sorted chromosome column never has to be materialised for these n_chrom + 1 binary searches
+__global__ void k_igd_chrom_segments(const u32 *__restrict__ chrom_key, const u32 *__restrict__ perm, u32 nq, u32 n_chrom,
+                                     u32 *__restrict__ cq_off) {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= n_chrom) cq_off[c] = lb_u32(sorted_chrom, 0, nq, c);
+    if (c > n_chrom) return;
+    u32 lo = 0, hi = nq;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (chrom_key[perm ? perm[mid] : mid] < c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    cq_off[c] = lo;
+}
+
+// dst_a[i] = a[idx[i]], dst_b[i] = b[idx[i]]: the two columns the sweep reads, one pass over the permutation
+__global__ void k_gather2_u32(const u32 *__restrict__ a, const u32 *__restrict__ b, const u32 *__restrict__ idx, u32 n,
+                              u32 *__restrict__ dst_a, u32 *__restrict__ dst_b) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const u32 k = idx[i];
+        dst_a[i] = a[k];
+        dst_b[i] = b[k];
+    }
 }
 
 // Every query is OWNED by exactly one tile: the tile that holds its lower_bound position
@@ -373,17 +396,18 @@ gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32
         // K1: order the queries by (chromosome, start)
         gtars_status s1 = device_sort_perm_ws(kc, ks, nullptr, nq, v.n_chrom + 1, perm, sort_ws, sort_ws_bytes, st);
         if (s1) return s1;
-        if ((s1 = device_gather_u32(kc, perm, nq, sc, st))) return s1;
-        if ((s1 = device_gather_u32(ks, perm, nq, ss, st))) return s1;
-        if ((s1 = device_gather_u32(ke, perm, nq, se, st))) return s1;
+        {
+            ProfScope p("k_gather2_u32", st);
+            hipLaunchKernelGGL(k_gather2_u32, dim3(g), dim3(256), 0, st, ks, ke, perm, nq, ss, se);
+        }
     } else {
-        sc = kc;  // the batch is in (chromosome, start) order already
+        perm = nullptr;  // the batch is in (chromosome, start) order already
         ss = ks;
         se = ke;
     }
     {
         ProfScope p("k_igd_tile_ranges", st);
-        hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, sc, nq, v.n_chrom, cq_off);
+        hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, kc, perm, nq, v.n_chrom, cq_off);
         hipLaunchKernelGGL(k_igd_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tile_first, tile_cnt,
                            tile_chrom, n_tiles, ss, cq_off, ql, qh);
     }

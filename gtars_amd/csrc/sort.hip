@@ -10,7 +10,8 @@
 //
 // Per 8-bit pass: (1) per-tile LDS histogram -> digit-major table, (2) exclusive scan of the table,
 // (3) scatter with stable in-tile ranks: a wave finds its equal-digit peers with 8 ballots
-// (64-wide "match-any"), waves are ordered through a small LDS table, rounds through a running base.
+// (64-wide "match-any"), waves are ordered through a small LDS table, rounds through a running base;
+// the tile is reordered by digit in LDS first, so that it leaves as a few contiguous runs per wave.
 // Bound: HBM, 16 B moved per element per pass (8 B in, 8 B out) + one 4-B random gather per key word.
 #include "common.h"
 #include "scan.cuh"
@@ -43,11 +44,21 @@ k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 
                 u32 *__restrict__ ovals) {
     __shared__ u32 wc[RS_NW][256];  // per-wave digit counts of the current round
     __shared__ u32 run[256];        // elements of each digit already placed by earlier rounds
+    __shared__ u32 toff[256];       // first slot of each digit inside the tile (tile-local exclusive scan)
+    __shared__ u64 gbase[256];      // first global position of each digit's run of this tile
+    __shared__ u32 s_k[RS_TILE], s_v[RS_TILE];  // the tile, reordered by digit before it is written out
+    __shared__ u32 s_scan[RS_NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     run[threadIdx.x] = 0;
-    const u64 my_digit_base = table_off[(size_t)threadIdx.x * n_tiles + blockIdx.x];
-    __shared__ u64 gbase[256];
-    gbase[threadIdx.x] = my_digit_base;
+    {
+        // table_off is the exclusive scan of the digit-major count table, so consecutive entries give the
+        // count of (digit, tile) back; their block-wide exclusive scan is the tile-local layout
+        const size_t idx = (size_t)threadIdx.x * n_tiles + blockIdx.x;
+        const u64 o0 = table_off[idx], o1 = table_off[idx + 1];
+        gbase[threadIdx.x] = o0;
+        u32 total;
+        toff[threadIdx.x] = block_exclusive_scan<RS_TPB>((u32)(o1 - o0), s_scan, total);
+    }
     const u32 base = blockIdx.x * RS_TILE;
     for (int r = 0; r < RS_ITEMS; ++r) {
 #pragma unroll
@@ -73,9 +84,9 @@ k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 
 #pragma unroll
             for (int w = 0; w < RS_NW; ++w)
                 if (w < wave) before += wc[w][d];
-            const u64 pos = gbase[d] + before + rank_in_wave;
-            okeys[pos] = k;
-            ovals[pos] = v;
+            const u32 slot = toff[d] + before + rank_in_wave;
+            s_k[slot] = k;
+            s_v[slot] = v;
         }
         __syncthreads();
         {
@@ -85,6 +96,15 @@ k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 
             run[threadIdx.x] += add;
         }
         __syncthreads();
+    }
+    // write the tile out slot by slot: equal digits are adjacent, so a wave writes a few contiguous runs
+    const u32 tile_n = min((u32)RS_TILE, n - base);
+    for (u32 j = threadIdx.x; j < tile_n; j += RS_TPB) {
+        const u32 k = s_k[j];
+        const u32 d = (k >> shift) & 0xFFu;
+        const u64 pos = gbase[d] + (j - toff[d]);
+        okeys[pos] = k;
+        ovals[pos] = s_v[j];
     }
 }
 
