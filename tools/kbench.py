@@ -31,6 +31,9 @@ def main():
     nu = int(os.environ.get("NU", "100000"))
     u = synth.make_universe(nu, overlapping=bool(int(os.environ.get("OVERLAP", "0"))))
     q = synth.make_queries(u, 1_000_000)
+    if int(os.environ.get("SORTED", "0")):  # position-sorted batch (a sorted BED / fragment file): neighbours share records
+        order = np.lexsort((q["start"], q["chrom"]))
+        q = {k: v[order] for k, v in q.items()}
     ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
     sizes = [int(x) for x in os.environ.get("SIZES", "1000000,16000000,64000000").split(",")]
     configs = [c for c in os.environ.get("CONFIGS", "512:0:4").split(",")]
