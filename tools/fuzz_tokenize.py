@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Randomised differential soak: GPU tokenization / counts vs the oracle over many universe shapes.
+
+Not part of the test suite (minutes of run time); run on the GPU box:  python tools/fuzz_tokenize.py [rounds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import gtars_amd
+import oracle
+
+UNK = 0xFFFFFFFF
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    n_chrom = int(rng.integers(1, 60))
+    n = int(rng.choice([1, 2, 3, 7, 50, 1000, 20_000, 150_000]))
+    span = int(rng.choice([50, 5_000, 1_000_000, 200_000_000, 4_000_000_000 // max(n_chrom, 1)]))
+    wmax = int(rng.choice([1, 20, 2_000, max(2, span // 3)]))
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, max(span, 2), n)
+    w = rng.integers(0 if rng.random() < 0.3 else 1, wmax + 1, n)
+    e = np.minimum(s.astype(np.int64) + w, 0xFFFFFFFF)
+    if rng.random() < 0.2 and n > 3:          # a few chromosome-wide intervals
+        k = rng.integers(0, n, 3)
+        s[k] = 0
+        e[k] = min(span + wmax, 0xFFFFFFFF)
+    if rng.random() < 0.2 and n > 3:          # inverted universe intervals
+        k = rng.integers(0, n, 3)
+        e[k] = np.maximum(s[k].astype(np.int64) - 5, 0)
+    val = rng.permutation(n).astype(np.uint32)
+    top_max = rng.choice(["", "64", "512"])
+    if top_max:
+        os.environ["GTARS_TOP_MAX"] = str(top_max)
+    else:
+        os.environ.pop("GTARS_TOP_MAX", None)
+    g = gtars_amd.OverlapIndex(c, s, e, val, n_chrom=n_chrom)
+    o = oracle.Index(c, s, e, val, n_chrom=n_chrom)
+    nq = int(rng.choice([1, 5, 257, 4096, 4097, 70_001]))
+    qc = rng.integers(0, n_chrom + 1, nq)
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, max(span, 2) + wmax, nq).astype(np.int64)
+    qe = np.minimum(qs + rng.integers(0, max(2, wmax * 2), nq), 0xFFFFFFFF)
+    if nq > 10:
+        k = rng.integers(0, nq, max(1, nq // 50))
+        qe[k] = np.maximum(qs[k] - rng.integers(0, 10, len(k)), 0)
+        qs[:2] = 0xFFFFFFFF
+        qe[:2] = 0xFFFFFFFF
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    assert np.array_equal(off_g, off_o), ("offsets", seed)
+    assert np.array_equal(ids_g, ids_o), ("ids", seed)
+    for mo in (None, 1, 3):
+        assert np.array_equal(g.count_overlaps(qc, qs, qe, mo), o.count_overlaps(qc, qs, qe, mo)), ("count", seed, mo)
+    return n, nq, len(ids_o)
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    t = time.time()
+    tot = 0
+    for seed in range(rounds):
+        n, nq, h = one(1000 + seed)
+        tot += h
+    print(f"fuzz_tokenize: {rounds} random configurations bit-exact vs the oracle ({tot} ids compared, {time.time() - t:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()
