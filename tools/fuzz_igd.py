@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Randomised differential soak: IGD batch counts (sweep and per-query kernels) vs the oracle's literal tile walk.
+
+Run on the GPU box:  python tools/fuzz_igd.py [rounds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import gtars_amd
+import oracle
+
+UNK = 0xFFFFFFFF
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    n_chrom = int(rng.integers(1, 6))
+    n = int(rng.choice([1, 10, 3000, 20_000]))
+    F = int(rng.choice([1, 3, 70, 3000]))
+    span = int(rng.choice([100, 40_000, 3_000_000]))
+    wmax = int(rng.choice([2, 300, 20_000, 70_000]))  # up to ~5 IGD tiles (nbp = 16384) per record
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(-5 if rng.random() < 0.2 else 0, span, n)
+    e = s + rng.integers(0 if rng.random() < 0.2 else 1, wmax, n)
+    f = rng.integers(0, F, n)
+    g = gtars_amd.IgdIndex(c, s, e, f, np.arange(n), n_chrom=n_chrom, n_files=F)
+    o = oracle.Igd()
+    o.add_arrays(c, s, e, np.arange(n), f)
+    o.n_files = F
+    o.finalize()
+    nq = int(rng.choice([1, 33, 5000, 12_000]))
+    qc = rng.integers(0, n_chrom + 1, nq)
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, span + wmax, nq).astype(np.int64)
+    qe = qs + rng.integers(0, max(2, wmax), nq)
+    if rng.random() < 0.5:
+        order = np.lexsort((qs, np.where(qc == UNK, n_chrom, qc)))
+        qc, qs, qe = qc[order], qs[order], qe[order]
+    if nq > 40:
+        qs[:5] = 0xFFFFFFF0       # negative as i32: clamped
+        qe[5:10] = 0              # rejected
+    if rng.random() < 0.7:
+        os.environ["GTARS_IGD_SWEEP_MIN"] = "1"
+    else:
+        os.environ.pop("GTARS_IGD_SWEEP_MIN", None)
+    for mo in (1, int(rng.integers(2, 40))):
+        assert np.array_equal(g.count_set_overlaps(qc, qs, qe, mo), o.count_set_overlaps(qc, qs, qe, mo, n_files=F)), ("pair", seed, mo)
+        assert np.array_equal(g.count_region_hits(qc, qs, qe, mo), o.count_region_hits(qc, qs, qe, mo, n_files=F)), ("bin", seed, mo)
+    return nq
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    t = time.time()
+    for seed in range(rounds):
+        one(5000 + seed)
+        if seed % 25 == 24:
+            print(f"  {seed + 1} rounds, {time.time() - t:.0f} s", flush=True)
+    print(f"fuzz_igd: {rounds} random configurations bit-exact vs the oracle ({time.time() - t:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()
