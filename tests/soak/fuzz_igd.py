@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential soak: IGD batch counts (sweep and per-query kernels) vs the oracle's literal tile walk.
 
-Run on the GPU box:  python tools/fuzz_igd.py [rounds]"""
+Run on the GPU box:  python tests/soak/fuzz_igd.py [rounds]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import gtars_amd

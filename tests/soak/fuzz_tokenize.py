@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential soak: GPU tokenization / counts vs the oracle over many universe shapes.
 
-Not part of the test suite (minutes of run time); run on the GPU box:  python tools/fuzz_tokenize.py [rounds]"""
+Not part of the test suite (minutes of run time); run on the GPU box:  python tests/soak/fuzz_tokenize.py [rounds]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import gtars_amd
