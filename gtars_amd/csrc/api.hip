@@ -6,6 +6,7 @@
 #include <map>
 #include <mutex>
 #include <numeric>
+#include <tuple>
 
 #include "common.h"
 
@@ -66,12 +67,15 @@ Workspace::~Workspace() {
     // exit is harmless, freeing after runtime shutdown is not.
 }
 
-// One grow-only workspace per (host thread, stream, purpose): calls issued by one thread on DIFFERENT
+// One grow-only workspace per (host thread, device, stream, purpose): calls issued by one thread on DIFFERENT
 // streams may overlap on the device, so they must not share scratch memory; calls on the same stream are
 // ordered by the stream.
 Workspace &tls_workspace(int slot, hipStream_t stream) {
-    static thread_local std::map<std::pair<hipStream_t, int>, Workspace> ws;
-    return ws[std::make_pair(stream, slot)];
+    // the default stream (NULL) exists on every device: the current device is part of the key
+    static thread_local std::map<std::tuple<int, hipStream_t, int>, Workspace> ws;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return ws[std::make_tuple(dev, stream, slot)];
 }
 
 // ---------------------------------------------------------------- profiling
