@@ -180,15 +180,32 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
     for (int j = 0; j < SUB; ++j) {
         u32 b = ((pos[j] + 2u - qb) >> 1) << shift;  // first block of the first unit with key >= target
         if (shift) {
-            // inside the unit: first block whose key (prefix-max end) is > q_start
-            u32 l2 = b, n2 = (be[j] > b) ? min(1u << shift, be[j] - b) : 0u;
-            while (n2 > 0) {
-                const u32 half = n2 >> 1, mid = l2 + half;
-                const bool pred = a.blk_first[mid] <= s[j];
-                l2 = pred ? mid + 1 : l2;
-                n2 = pred ? n2 - half - 1 : half;
+            // inside the unit: first block whose key (prefix-max end) is > q_start.  The keys ascend and a
+            // chromosome's block range is padded to whole units (padding key 0xFFFFFFFF), so for small units
+            // that is b + #{keys <= q_start}, counted on 16-byte loads that share ONE L2 line: a single
+            // dependent round trip instead of `shift` of them (each a fresh L1 line fill).
+            if (b < be[j]) {
+                if (shift >= 2 && shift <= 4) {
+                    u32 cnt = 0;
+                    const uint4 *kp = reinterpret_cast<const uint4 *>(a.blk_first + b);
+#pragma unroll 4
+                    for (u32 k = 0; k < (1u << (shift - 2)); ++k) {
+                        const uint4 kk = kp[k];
+                        cnt += (kk.x <= s[j] ? 1u : 0u) + (kk.y <= s[j] ? 1u : 0u) + (kk.z <= s[j] ? 1u : 0u) +
+                               (kk.w <= s[j] ? 1u : 0u);
+                    }
+                    b += cnt;
+                } else {
+                    u32 l2 = b, n2 = min(1u << shift, be[j] - b);
+                    while (n2 > 0) {
+                        const u32 half = n2 >> 1, mid = l2 + half;
+                        const bool pred = a.blk_first[mid] <= s[j];
+                        l2 = pred ? mid + 1 : l2;
+                        n2 = pred ? n2 - half - 1 : half;
+                    }
+                    b = l2;
+                }
             }
-            b = l2;
         }
         b0[j] = b;
     }
