@@ -526,9 +526,9 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         h_ctab.assign((size_t)n_chrom * 4, 0);
         for (u32 c = 0; c < n_chrom; ++c) {
             const u64 span = chrom_span[c];
-            h_ctab[4 * (size_t)c + 0] = (u32)std::min<u64>(gbase, 0xFFFFFFFFu);
+            h_ctab[4 * (size_t)c + 0] = (u32)(gbase & 0xFFFFFFFFu);
             h_ctab[4 * (size_t)c + 1] = (u32)std::min<u64>(span, 0xFFFFFFFFu);
-            h_ctab[4 * (size_t)c + 2] = 0;
+            h_ctab[4 * (size_t)c + 2] = (u32)(gbase >> 32);  // the key space is 64 bits wide
             h_ctab[4 * (size_t)c + 3] = h_cblk[c + 1];
             for (u32 t = h_cblk[c] >> shift; t < (h_cblk[c + 1] >> shift); ++t)
                 uk[t] = gbase + std::min<u64>(h_blk_first[(((size_t)t + 1) << shift) - 1], span);
@@ -562,8 +562,8 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         ix->acc_q_shift = qsh;
         ix->acc_search_top = search_top;
         ix->acc_top_shift = shift;
-        // the global key space must fit 32 bits (hg38: 3.1e9); wider universes use the generic kernels
-        ix->has_accel = nb > 0 && gbase <= 0xFFFFFFFFull;
+        // the key space is 64 bits wide (hg38 needs 3.1e9; larger genomes just get wider buckets)
+        ix->has_accel = nb > 0 && (gbase >> lsh) < (1ull << 31);
     }
 
     GT_HIP(hipGetDevice(&ix->device));

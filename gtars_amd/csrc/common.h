@@ -88,14 +88,14 @@ struct IndexView {
 //  * `qkeys[u]` (u16) = (key(u) mod 2^lut_shift) >> q_shift, floor-quantised.  The search
 //    may stop a unit early (never late, never in an earlier chromosome: those are 2^q_shift
 //    away); the record scan then simply walks on, so results stay exact.
-// chrom_tab[c] = {gbase, span, 0, end of the chromosome's block range}.
+// chrom_tab[c] = {gbase low word, span, gbase high word, end of the chromosome's block range}.
 constexpr int ACC_BS = 3;
 struct AccelView {
     const uint4 *blocks;      // [n_blocks * 4] (64 B per block)
     const u32 *blk_first;     // [n_blocks] prefix-max end up to each block (local coordinates)
     const u32 *lut;           // [lut_words] packed u16, n_buckets + 1 entries (16-byte padded)
     const u32 *qkeys;         // [q_words] packed u16, n_units entries (16-byte padded)
-    const uint4 *chrom_tab;   // [n_chrom] {gbase, span, 0, blk_end}
+    const uint4 *chrom_tab;   // [n_chrom] {gbase lo, span, gbase hi, blk_end}
     u32 n_blocks;
     u32 n_units;
     u32 n_buckets;

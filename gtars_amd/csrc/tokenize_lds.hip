@@ -160,11 +160,12 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
         const uint4 ct = s_ctab[valid ? c[j] : 0u];
         // target = q_start + 1 in the key space of prefix-max ends (first block with key > q_start);
         // at or beyond the chromosome's largest end: the sentinel key
-        const u32 gkey = ct.x + (s[j] < ct.y ? s[j] + 1u : ct.y);
+        // (the key space is 64 bits wide: genomes beyond 4.29 Gbp; ct.z = high word of gbase)
+        const u64 gkey = (((u64)ct.z << 32) | ct.x) + (s[j] < ct.y ? s[j] + 1u : ct.y);
         be[j] = valid ? ct.w : 0u;  // invalid -> empty range
-        const u32 la = lb + ((gkey >> lsh) << 1);
+        const u32 la = lb + ((u32)(gkey >> lsh) << 1);
         const u32 lo = *(lds_cu16)(uintptr_t)la, hi = *(lds_cu16)(uintptr_t)(la + 2u);
-        tq[j] = hi > lo ? (gkey & wmask) >> qsh : 0u;  // empty bucket: no key is < 0
+        tq[j] = hi > lo ? ((u32)gkey & wmask) >> qsh : 0u;  // empty bucket: no key is < 0
         pos[j] = qb + (lo << 1) - 2u;                  // &q[lo - 1]
         last[j] = qb + (hi << 1) - 2u;                 // &q[hi - 1]
     }

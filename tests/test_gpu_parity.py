@@ -769,3 +769,29 @@ def test_scan_epoch_wraps_after_16k_launches(ga):
         check = i in (0, 1, 16_380, 16_381, 16_382, 16_383, 16_384, 16_385, 16_599) or big
         run(batches[1] if big else batches[0], check)
     run(batches[1], True)
+
+
+def test_key_space_wider_than_32_bits(ga):
+    """Chromosome coordinates are u32, but the search key space concatenates the chromosomes: with three
+    chromosomes whose ends reach 4e9 it is ~1.2e10 wide.  The LDS kernel handles that (64-bit keys)."""
+    rng = np.random.default_rng(64)
+    n_chrom, n = 3, 60_000
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, 4_000_000_000, n, dtype=np.uint64)
+    e = np.minimum(s + rng.integers(1, 100_000, n).astype(np.uint64), 0xFFFFFFFF)
+    g, o = _pair(ga, c, s, e, n_chrom=n_chrom)
+    nq = 100_000
+    qc = rng.integers(0, n_chrom + 1, nq)
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, 4_100_000_000, nq, dtype=np.uint64)
+    qe = np.minimum(qs + rng.integers(0, 300_000, nq).astype(np.uint64), 0xFFFFFFFF)
+    _lib = ga._lib
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    names = set(_lib.prof_read())
+    _lib.lib.gtars_prof_enable(0)
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+    assert "k_tok_lds" in names, names
+    assert np.array_equal(g.count_overlaps(qc, qs, qe), o.count_overlaps(qc, qs, qe))
