@@ -203,7 +203,8 @@ struct gtars_index {
     std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
     // blocked acceleration structure (Bits kind), see AccelView in common.h
-    DevBuf<u32> acc_blocks, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab;
+    DevBuf<u32> acc_rec2, acc_rec4, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab, acc_idc;
+    bool acc_ids_affine = false;
     u32 acc_n_blocks = 0, acc_n_units = 0, acc_n_buckets = 0, acc_lut_words = 0, acc_q_words = 0;
     u32 acc_lut_shift = 0, acc_q_shift = 0, acc_search_top = 0, acc_top_shift = 0;
     bool has_accel = false;
@@ -213,7 +214,10 @@ struct gtars_index {
     mutable bool ends_ready = false;
     AccelView accel() const {
         AccelView a;
-        a.blocks = reinterpret_cast<const uint4 *>(acc_blocks.p);
+        a.rec2 = reinterpret_cast<const uint4 *>(acc_rec2.p);
+        a.rec4 = reinterpret_cast<const uint4 *>(acc_rec4.p);
+        a.idc = acc_idc.p;
+        a.ids_affine = acc_ids_affine ? 1u : 0u;
         a.blk_first = acc_blk_first.p;
         a.lut = acc_lut.p;
         a.qkeys = acc_qkeys.p;
@@ -441,67 +445,95 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
         ix->h_chrom_sub[n_chrom] = (u32)ix->h_sub_off.size();
     }
 
-    std::vector<u32> h_blocks, h_blk_first, h_lut, h_q, h_cblk, h_ctab;
-    if (kind == GTARS_KIND_BITS && n > 0) {
-        // LDS budget of k_tok_lds: one 1024-thread workgroup per CU with its copy of the unit keys
-        // (2 B per unit), the bucket table (2 B per bucket, at most 4096 + 1) and the chromosome table
+    std::vector<u32> h_rec2, h_rec4, h_blk_first, h_lut, h_q, h_cblk, h_ctab, h_idc;
+    // The blocked structure is skipped (generic kernels serve the index) when it would not fit the LDS
+    // kernels anyway: more units than the LDS budget holds even at the coarsest unit size (thousands of
+    // non-empty contigs: every one needs at least one unit), or more blocks than a query's state word
+    // addresses.  Decided BEFORE anything is allocated: padded block counts are computed in 64 bits.
+    bool build_accel = kind == GTARS_KIND_BITS && n > 0;
+    u32 shift = 0;
+    if (build_accel) {
+        // LDS budget of the tokenizer kernels: one 1024-thread workgroup per CU with its copy of the unit keys
+        // (2 B per unit), the bucket table (2 B per bucket, at most 4096 + 1) and the chromosome tables
         constexpr u32 kBucketMax = 4096;
         u32 unit_max = 1024;
         {
-            const long budget = 148 * 1024 - 16l * (long)n_chrom - 2l * (kBucketMax + 8);
+            const long budget = 148 * 1024 - 20l * (long)n_chrom - 16 - 2l * (kBucketMax + 8);
             if (budget > 4096) unit_max = (u32)std::min<long>(budget / 2 / 8 * 8, 65528);  // lut entries are u16
         }
         if (const char *e = getenv("GTARS_TOP_MAX")) {
             const long v = atol(e);
             if (v >= 64) unit_max = (u32)std::min<long>(v, 65528);
         }
-        u32 shift = 0;
+        u64 nb64 = 0;
         for (;;) {
             // padded block count at this shift
-            u64 nb = 0;
+            nb64 = 0;
             const u64 g = 1ull << shift;
             for (u32 c = 0; c < n_chrom; ++c) {
-                const u64 b = (off[c + 1] - off[c] + ACC_BS - 1) / ACC_BS;
-                nb += (b + g - 1) / g * g;
+                const u64 b = ((u64)off[c + 1] - off[c] + ACC_OWN - 1) / ACC_OWN;
+                nb64 += (b + g - 1) / g * g;
             }
-            if ((nb >> shift) <= unit_max || shift >= 16) break;
+            if ((nb64 >> shift) <= unit_max || shift >= 16) break;
             ++shift;
         }
+        if ((nb64 >> shift) > unit_max || nb64 > (u64)((1u << 22) - 1u)) build_accel = false;
+    }
+    if (build_accel) {
+        constexpr u32 kBucketMax = 4096;
         const u64 g = 1ull << shift;
         h_cblk.assign(n_chrom + 1, 0);
         for (u32 c = 0; c < n_chrom; ++c) {
-            const u64 b = (off[c + 1] - off[c] + ACC_BS - 1) / ACC_BS;
+            const u64 b = ((u64)off[c + 1] - off[c] + ACC_OWN - 1) / ACC_OWN;
             h_cblk[c + 1] = h_cblk[c] + (u32)((b + g - 1) / g * g);
         }
         const u32 nb = h_cblk[n_chrom];
-        h_blocks.assign((size_t)nb * 16, 0);
+        // ids that follow from the position: within every chromosome the stored values ascend by one
+        bool affine = true;
+        h_idc.assign(n_chrom, 0);
+        for (u32 c = 0; c < n_chrom && affine; ++c) {
+            if (off[c + 1] == off[c]) continue;
+            const u32 v0 = ix->h_vals[off[c]];
+            for (u32 p = off[c]; p < off[c + 1]; ++p)
+                if (ix->h_vals[p] != v0 + (p - off[c])) {
+                    affine = false;
+                    break;
+                }
+            h_idc[c] = v0 - (u32)ACC_OWN * h_cblk[c];  // mod 2^32
+        }
+        if (getenv("GTARS_NO_AFFINE_IDS")) affine = false;  // tests: force the id records
+        ix->acc_ids_affine = affine;
+        h_rec2.assign((size_t)nb * 8, 0);
+        if (!affine) h_rec4.assign((size_t)nb * 16, 0);
         h_blk_first.assign(nb, 0xFFFFFFFFu);
         std::vector<u64> chrom_span(n_chrom, 0);  // max end + 1 (0: no intervals)
         for (u32 c = 0; c < n_chrom; ++c) {
             u32 pm = 0;  // prefix max of the ends, in (start, end) order
             for (u32 b = h_cblk[c]; b < h_cblk[c + 1]; ++b) {
-                u32 *rec = &h_blocks[(size_t)b * 16];
-                // slots 0..2: own intervals, slot 3: look-ahead = first interval of the next block;
-                // quad 3 = {ns1, ne1, nv1, ns2}: the second interval of the next block and the start of its third
-                auto at = [&](int k, u32 &st_, u32 &en_, u32 &va_) {
-                    const u64 p = (u64)off[c] + (u64)(b - h_cblk[c]) * ACC_BS + k;
+                // slots 0, 1: own intervals, slots 2, 3: look-ahead = the next block's intervals
+                u32 *r2 = &h_rec2[(size_t)b * 8];
+                u32 *r4 = affine ? nullptr : &h_rec4[(size_t)b * 16];
+                for (int k = 0; k < ACC_SLOTS; ++k) {
+                    const u64 p = (u64)off[c] + (u64)(b - h_cblk[c]) * ACC_OWN + k;
                     const bool ok = p < off[c + 1];
-                    st_ = ok ? ix->h_starts[p] : 0xFFFFFFFFu;  // sentinel: never < q_end, stops the scan
-                    en_ = ok ? ix->h_ends[p] : 0u;
-                    va_ = ok ? ix->h_vals[p] : 0u;
-                };
-                for (int k = 0; k <= ACC_BS; ++k) at(k, rec[k], rec[4 + k], rec[8 + k]);
-                at(ACC_BS + 1, rec[12], rec[13], rec[14]);
-                u32 dummy_e, dummy_v;
-                at(ACC_BS + 2, rec[15], dummy_e, dummy_v);
+                    const u32 st_ = ok ? ix->h_starts[p] : 0xFFFFFFFFu;  // sentinel: never < q_end, stops the scan
+                    const u32 en_ = ok ? ix->h_ends[p] : 0u;
+                    r2[k] = st_;
+                    r2[4 + k] = en_;
+                    if (r4) {
+                        r4[k] = st_;
+                        r4[4 + k] = en_;
+                        r4[8 + k] = ok ? ix->h_vals[p] : 0u;
+                    }
+                }
                 // Search key of the block: the largest end among ALL intervals up to and including its own
                 // (a prefix maximum, so it ascends).  An interval overlaps a query only if its end is
                 // > q_start, hence the first block whose key is > q_start holds the first possible hit --
                 // a tighter start than Bits::find's lower_bound(q_start - max_len) (bits.rs:144-147), with
                 // the same hit set and order, and immune to a few very wide intervals inflating max_len.
                 // Padding blocks (no own interval) keep the sentinel key.
-                const u64 p0 = (u64)off[c] + (u64)(b - h_cblk[c]) * ACC_BS;
-                for (int k = 0; k < ACC_BS; ++k)
+                const u64 p0 = (u64)off[c] + (u64)(b - h_cblk[c]) * ACC_OWN;
+                for (int k = 0; k < ACC_OWN; ++k)
                     if (p0 + k < off[c + 1]) pm = std::max(pm, ix->h_ends[p0 + k]);
                 if (p0 < off[c + 1]) h_blk_first[b] = pm;
             }
@@ -568,7 +600,9 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
 
     GT_HIP(hipGetDevice(&ix->device));
     st = ix->starts.upload(ix->h_starts);
-    if (!st && ix->has_accel) st = ix->acc_blocks.upload(h_blocks);
+    if (!st && ix->has_accel) st = ix->acc_rec2.upload(h_rec2);
+    if (!st && ix->has_accel && !ix->acc_ids_affine) st = ix->acc_rec4.upload(h_rec4);
+    if (!st && ix->has_accel) st = ix->acc_idc.upload(h_idc);
     if (!st && ix->has_accel) st = ix->acc_blk_first.upload(h_blk_first);
     if (!st && ix->has_accel) st = ix->acc_lut.upload(h_lut);
     if (!st && ix->has_accel) st = ix->acc_qkeys.upload(h_q);
@@ -598,7 +632,9 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->chrom_aux.release();
     ix->chrom_sub.release();
     ix->sub_off.release();
-    ix->acc_blocks.release();
+    ix->acc_rec2.release();
+    ix->acc_rec4.release();
+    ix->acc_idc.release();
     ix->acc_blk_first.release();
     ix->acc_lut.release();
     ix->ends_sorted.release();

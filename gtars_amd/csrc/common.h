@@ -56,19 +56,21 @@ struct IndexView {
 
 // Blocked acceleration structure of a Bits-kind index (built once at index
 // build).  Every chromosome's sorted intervals are cut into blocks of
-// ACC_BS = 3 and stored as one 64-byte record (4 x uint4) per block:
-//     quad 0: s0 s1 s2 ns0    quad 1: e0 e1 e2 ne0    quad 2: v0 v1 v2 nv0    quad 3: ns1 ne1 nv1 ns2
-// (ns0/ne0/nv0 and ns1/ne1/nv1 = copies of the NEXT block's first two intervals, the "look-ahead";
-// ns2 = the start of its third: the scan goes on past the record only if ns2 < q_end).
-// Why this shape: a query's record fetch is one burst of three 16-byte requests
-// to one random L2 line, and on gfx950 a CU pays max(2.3 clk per distinct line
-// filled into its vector L1, 1 clk per 16-byte lane request) -- with 16 waves
-// of divergent fetches in flight the L1 thrashes, so any LATER access to the same
-// line is a fresh fill (tools/ubench/gather.hip).  Four requests = 4 clk and
-// carry everything all but ~0.2 % of the queries need: own intervals, the two
-// intervals the scan would look at next, and the token ids; no dependent loads
-// (a dependent load costs every wave a round trip: with 256 queries per wave
-// even a 3 % case is hit by nearly every wave).
+// ACC_OWN = 2; a block's record carries its two intervals and copies of the
+// NEXT block's two (the "look-ahead": the intervals the forward scan looks at
+// next), so that one burst of 16-byte loads from one random line answers a
+// query without a dependent load unless it reaches past BOTH look-ahead intervals
+// (with one look-ahead interval 0.5 % of the C2 queries walked on -- some lane of
+// two wave-tiles out of three, i.e. a dependent round trip for nearly every wave):
+//     rec2 (32 B per block):   quad 0: s0 s1 ns0 ns1    quad 1: e0 e1 ne0 ne1
+//     rec4 (64-B slots):       the same two quads + quad 2: v0 v1 nv0 nv1 (token ids)
+// Why this shape: a CU's vector-memory path prices a divergent 16-byte request at 2.3 clk
+// per lane and every further 16 bytes of the same record at ~1 clk (tools/ubench/ta.hip:
+// 1 / 2 / 3 / 4 quads = 2.3 / 2.4 / 3.2 / 4.0 clk per query), and that path -- not HBM --
+// is what the tokenizer saturates.  rec2 serves counting, and tokenizing whenever the ids
+// follow from the position: ids_affine = every chromosome's stored values ascend by one
+// in stored order (a universe file sorted by position), id = ACC_OWN * block + slot + idc[chrom]
+// (mod 2^32).  rec4 exists only for indexes whose ids do not.
 // Unused slots are sentinels (start = 0xFFFFFFFF, end = 0: never overlap and
 // stop the forward scan).  blk_first[b] = the block's search key: the largest END
 // among all intervals of the chromosome up to and including the block's own (a
@@ -89,13 +91,16 @@ struct IndexView {
 //    may stop a unit early (never late, never in an earlier chromosome: those are 2^q_shift
 //    away); the record scan then simply walks on, so results stay exact.
 // chrom_tab[c] = {gbase low word, span, gbase high word, end of the chromosome's block range}.
-constexpr int ACC_BS = 3;
+constexpr int ACC_OWN = 2;   // own intervals of a block
+constexpr int ACC_SLOTS = 4; // intervals a record carries (own + look-ahead)
 struct AccelView {
-    const uint4 *blocks;      // [n_blocks * 4] (64 B per block)
+    const uint4 *rec2;        // [n_blocks * 2] starts | ends (32 B per block)
+    const uint4 *rec4;        // [n_blocks * 4] starts | ends | ids | unused; null when ids_affine
     const u32 *blk_first;     // [n_blocks] prefix-max end up to each block (local coordinates)
     const u32 *lut;           // [lut_words] packed u16, n_buckets + 1 entries (16-byte padded)
     const u32 *qkeys;         // [q_words] packed u16, n_units entries (16-byte padded)
     const uint4 *chrom_tab;   // [n_chrom] {gbase lo, span, gbase hi, blk_end}
+    const u32 *idc;           // [n_chrom] id of (block b, slot k) = ACC_OWN * b + k + idc[c] when ids_affine
     u32 n_blocks;
     u32 n_units;
     u32 n_buckets;
@@ -105,6 +110,7 @@ struct AccelView {
     u32 search_top;           // first step of the in-bucket search (power of two, 0: buckets hold <= 0 units)
     u32 top_shift;
     u32 n_chrom;
+    u32 ids_affine;
 };
 
 // IGD database: all stored intervals (tile replicas are NOT materialised),
@@ -123,7 +129,7 @@ struct IgdView {
 
 // ---- per-thread grow-only device workspace ----------------------------------
 // host-side bookkeeping of a chained-scan workspace that is reused across launches without
-// being cleared (see scan.cuh): current epoch, tickets drawn so far, bytes known to be zeroed
+// being cleared (see scan.h): current epoch, tickets drawn so far, bytes known to be zeroed
 struct ScanEpoch {
     u32 epoch = 0;
     u32 ticket_base = 0;

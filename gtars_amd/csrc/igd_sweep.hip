@@ -20,7 +20,7 @@
 #include <algorithm>
 
 #include "common.h"
-#include "scan.cuh"
+#include "scan.h"
 
 namespace gtars {
 

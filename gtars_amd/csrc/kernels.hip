@@ -20,7 +20,7 @@
 //   min-overlap filter  gtars-overlaprs/src/multi_chrom_overlapper.rs:483-563
 //   IGD hit rule        gtars-igd/src/igd.rs:504-540, 753-847
 #include "common.h"
-#include "scan.cuh"
+#include "scan.h"
 
 namespace gtars {
 

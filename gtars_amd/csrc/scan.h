@@ -1,4 +1,4 @@
-// scan.cuh -- wave/workgroup scans and the chained ("decoupled look-back")
+// scan.h -- wave/workgroup scans and the chained ("decoupled look-back")
 // cross-workgroup prefix sum shared by the fused enumerate kernels.
 #pragma once
 #include "common.h"

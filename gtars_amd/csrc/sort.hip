@@ -14,7 +14,7 @@
 // the tile is reordered by digit in LDS first, so that it leaves as a few contiguous runs per wave.
 // Bound: HBM, 16 B moved per element per pass (8 B in, 8 B out) + one 4-B random gather per key word.
 #include "common.h"
-#include "scan.cuh"
+#include "scan.h"
 
 namespace gtars {
 

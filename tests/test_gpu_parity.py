@@ -715,24 +715,35 @@ def test_config4_lola_counts_identities(ga):
     assert np.array_equal(sh[:8], exp.astype(np.int64))
 
 
-def test_lookback_timeout_falls_back_to_the_generic_kernel(ga, monkeypatch):
-    """If the LDS kernel's look-back runs into its spin limit (its grid was not fully resident), synchronous
-    callers get the batch redone by the generic kernel instead of an error.  The timeout is simulated."""
-    from gtars_amd import synth
-
-    u = synth.make_universe(30_000)
-    q = synth.make_queries(u, 120_000)
-    g, o = _pair(ga, u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
-    off_o, ids_o = o.tokenize(q["chrom"], q["start"], q["end"])
-    monkeypatch.setenv("GTARS_TEST_FORCE_LOOKBACK_TIMEOUT", "1")
-    _lib = ga._lib
-    _lib.lib.gtars_prof_reset()
-    _lib.lib.gtars_prof_enable(1)
+_HELP_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import gtars_amd, oracle
+from gtars_amd import synth
+u = synth.make_universe(30_000)
+ok = True
+for nq in (900, 120_000, 1_300_000):
+    q = synth.make_queries(u, nq, seed=nq)
+    g = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    o = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM)
     off_g, ids_g = g.tokenize(q["chrom"], q["start"], q["end"])
-    names = set(_lib.prof_read())
-    _lib.lib.gtars_prof_enable(0)
-    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
-    assert "k_tok_lds" in names and any(n.startswith("k_enum_fused") for n in names), names
+    off_o, ids_o = o.tokenize(q["chrom"], q["start"], q["end"])
+    ok = ok and np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+print("HELP_PARITY", ok)
+"""
+
+
+@pytest.mark.parametrize("qpt", ["2", "4"])
+def test_lookback_helps_itself_instead_of_waiting(ga, qpt):
+    """k_tok_wave never depends on a predecessor tile being resident: a look-back that has polled an unpublished
+    predecessor `spin_limit` times counts that tile itself.  With the limit forced to 0 EVERY wait takes that path
+    (own subprocess: the limit is read once per process); results stay bit-exact."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GTARS_TOK_SPIN_LIMIT="0", GTARS_TOK_QPT=qpt)
+    r = subprocess.run([sys.executable, "-c", _HELP_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+    assert "HELP_PARITY True" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_scan_epoch_wraps_after_16k_launches(ga):
@@ -793,5 +804,5 @@ def test_key_space_wider_than_32_bits(ga):
     _lib.lib.gtars_prof_enable(0)
     off_o, ids_o = o.tokenize(qc, qs, qe)
     assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
-    assert "k_tok_lds" in names, names
+    assert names & {"k_tok_lds", "k_tok_wave"}, names
     assert np.array_equal(g.count_overlaps(qc, qs, qe), o.count_overlaps(qc, qs, qe))
