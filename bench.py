@@ -11,19 +11,34 @@ batch that is already resident in HBM.
 
   python bench.py [--gpus N --steps K --warmup W] [--queries Q] [--universe U]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per
-GPU).  The path shards by independent query ranges with the universe index
-replicated, so there is no data-path collective (weak scaling: every rank
-tokenizes its own Q-query slice of the global batch); torch.distributed is used
-only for the timing barrier and the max-over-ranks reduction.
+How the number is taken:
+  * every step works on a DIFFERENT batch and writes DIFFERENT output buffers: the run rotates through
+    --batches (default 32) device-resident batches, 0.7 GB in all, so that neither the 12 MB of queries
+    nor the 10 MB of results of a step are still in the 256 MB Infinity Cache when their turn comes again;
+  * a repetition = K back-to-back steps bracketed by barrier + torch.cuda.synchronize() on both sides, MAX
+    over ranks; `value` is the MEDIAN over the repetitions, of which there are as many as it takes to keep
+    the GPU busy for >= --min-seconds (default 0.6 s; never fewer than 11);
+  * roofline.achieved = algorithmic bytes per launch / average kernel duration, the duration measured with
+    HIP events on the launch stream around the K launches of the same repetitions (the events see only
+    that stream; one step is exactly one k_tok_lds launch);
+  * roofline.traffic is NOT measured in this run (it needs rocprofv3 --pmc passes): it is replayed from the
+    committed PMC summary of this same command under profiles/, and `traffic_source` says so.
 
-Rank 0 prints ONE JSON line.
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  The tokenizer shards by
+independent query ranges with the universe index replicated, so there is no data-path collective (weak
+scaling: every rank tokenizes its own Q-query batches); `with_allgather` additionally reports the rate when
+every rank must end up with the whole batch's CSR (RCCL all-gatherv of offsets and ids, gtars_amd/sharding.py).
+
+Rank 0 prints ONE JSON line.  At N = 1 it also carries: larger batches (`roofline_large`), BASELINE config 3
+(`igd_config3`) and config 4 on one GPU (`lola_config4`), the PCIe-inclusive host-buffer rate and the CPU
+baselines (the oracle on the GPU box's host cores).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,6 +49,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+PROFILE_ROUND = "r02"
 
 
 def algorithmic_bytes(nq: int, h: int, nu: int) -> int:
@@ -78,9 +94,9 @@ def _cpu_max() -> str:
 
 
 def cpu_baseline_all_cores(u, q, budget_s: float = 4.0):
-    """Courtesy multi-core figure (SURVEY section 8d ii): the same oracle on many host threads at once (ctypes
-    releases the GIL), every thread tokenizing whole batches into its own outputs.  Reported next to, not
-    instead of, the reference-faithful single-thread baseline."""
+    """Courtesy multi-core figure (SURVEY section 8d ii): the oracle on every host core the
+    container may use, the batch split in contiguous static chunks (one per thread, outputs land in input
+    order); ctypes releases the GIL.  Reported next to, not instead of, the single-thread baseline."""
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle
@@ -98,29 +114,160 @@ def cpu_baseline_all_cores(u, q, budget_s: float = 4.0):
         avail = min(avail, max(1, -(-int(quota[0]) // int(quota[1]))))  # container CPU quota, rounded up
     threads = max(1, min(avail, 128))
     L = oracle.lib()
-    stop = [False]
+    bounds = np.linspace(0, nq, threads + 1).astype(np.int64)
+    chunks = [(int(bounds[t]), int(bounds[t + 1])) for t in range(threads)]
+    bufs = [(np.zeros(b - a + 1, dtype=np.uint64), np.zeros(2 * (b - a) + 16, dtype=np.uint32)) for a, b in chunks]
 
     def work(t):
-        # whole batches per call (~65 ms each), so the GIL is only touched between calls
-        off = np.zeros(nq + 1, dtype=np.uint64)
-        ids = np.zeros(2 * nq + 16, dtype=np.uint32)
-        done = 0
-        while not stop[0]:
-            L.orc_tokenize(ref._h, qc, qs, qe, nq, off, ids, len(ids))
-            done += nq
-        return done
+        a, b = chunks[t]
+        off, ids = bufs[t]
+        L.orc_tokenize(ref._h, qc[a:b], qs[a:b], qe[a:b], b - a, off, ids, len(ids))
 
     with ThreadPoolExecutor(max_workers=threads) as ex:
-        t0 = time.perf_counter()
-        futs = [ex.submit(work, t) for t in range(threads)]
-        time.sleep(budget_s)
-        stop[0] = True
-        total = sum(f.result() for f in futs)
+        list(ex.map(work, range(threads)))  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            list(ex.map(work, range(threads)))
+            reps += 1
         dt = time.perf_counter() - t0
-    return {"value": total / dt, "unit": "query intervals/s", "cores": threads, "kind": "port",
-            "sample": f"{total // nq} x {nq} queries of the same workload through orc_tokenize on {threads} host "
-                      f"threads (each thread tokenizes whole batches, {dt:.1f} s; CPUs usable under the affinity mask "
-                      f"and cgroup quota: {avail})"}
+    return {"value": reps * nq / dt, "unit": "query intervals/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x {nq} queries of the same workload through orc_tokenize, each batch split in {threads} "
+                      f"contiguous chunks on {threads} host threads ({dt:.1f} s; CPUs usable under the affinity mask and "
+                      f"cgroup quota: {avail})"}
+
+
+def _dev(a, dev):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+
+
+def bench_large(ix, q, nu, sizes, dev, stream):
+    """The same kernel on larger batches (the 1M-query base batch tiled on the device): queries/s and fraction of
+    the HBM peak, median of 5 single-launch timings each (HIP events on the launch stream)."""
+    import torch
+
+    out = []
+    base = {k: _dev(q[k], dev) for k in ("chrom", "start", "end")}
+    nq0 = base["chrom"].numel()
+    for n2 in sizes:
+        rep = max(n2 // nq0, 1)
+        big = {k: v.repeat(rep) for k, v in base.items()}
+        n2 = nq0 * rep
+        off = torch.empty(n2 + 1, dtype=torch.int64, device=dev)
+        run = lambda ids, s=False: ix.tokenize_device(big["chrom"].data_ptr(), big["start"].data_ptr(), big["end"].data_ptr(),
+                                                      n2, off.data_ptr(), ids.data_ptr() if ids is not None else 0,
+                                                      ids.numel() if ids is not None else 0, stream, sync=s)
+        h2 = run(None, True)  # offsets only: sizes the id buffer
+        ids = torch.empty(h2 + 1024, dtype=torch.int32, device=dev)
+        run(ids, True)
+        ts = torch.cuda.current_stream()
+        times = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ts)
+            run(ids)
+            e1.record(ts)
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e-3)
+        dt = statistics.median(times)
+        byts = algorithmic_bytes(n2, h2, nu)
+        out.append({"queries": n2, "hits": h2, "ms": dt * 1e3, "qps": n2 / dt, "achieved_GBps": byts / dt / 1e9,
+                    "frac": byts / dt / 1e9 / HBM_PEAK_GBS})
+        del big, off, ids
+        torch.cuda.empty_cache()
+    return out
+
+
+def bench_igd_config3(dev, stream, ndb=50_000_000, nq=10_000_000, n_files=1000):
+    """BASELINE config 3: 10M shuffled synthetic intervals vs a 50M-interval, 1000-file IGD database on one GPU.
+    Bytes = 12*Nq + 16*Ndb + 8*F.  The headline is the batch AS SPECIFIED (shuffled); the same batch in
+    (chromosome, start) order -- what a sorted BED file delivers -- is reported next to it."""
+    import torch
+
+    import gtars_amd
+    from gtars_amd import synth
+
+    t = time.time()
+    db = synth.make_igd_db(ndb, n_files)
+    q = synth.make_background_queries(nq)
+    tgen = time.time() - t
+    t = time.time()
+    g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=n_files)
+    tbuild = time.time() - t
+    del db
+    hits = torch.zeros(n_files, dtype=torch.int64, device=dev)
+    byts = 12 * nq + 16 * ndb + 8 * n_files
+    out = {"db_intervals": ndb, "queries": nq, "files": n_files, "gen_s": round(tgen, 2), "build_s": round(tbuild, 2),
+           "algorithmic_bytes": byts}
+    order = np.lexsort((q["start"], q["chrom"]))
+    for label, sel in (("shuffled", None), ("sorted_input", order)):
+        qc, qs, qe = (_dev(q[k] if sel is None else q[k][sel], dev) for k in ("chrom", "start", "end"))
+        for binary in (False, True):
+            f = lambda: g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, hits.data_ptr(), 1, binary, stream)
+            f()
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                f()
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            dt = statistics.median(times)
+            out[("binary" if binary else "pairwise") + "_" + label] = {
+                "ms": round(dt * 1e3, 3), "qps": round(nq / dt), "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 5),
+                "total_hits": int(hits.sum())}
+        del qc, qs, qe
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_lola_config4(dev, stream, n_sets=2000, per_set=25_000, n_universe=1_000_000, n_user=100_000):
+    """BASELINE config 4 on ONE GPU: support counts of one user set and of the universe against a 2000-set region DB
+    (two binary IGD counts) + the contingency cells (enrichment.rs:198-221)."""
+    import torch
+
+    import gtars_amd
+    from gtars_amd import synth
+    from gtars_amd._lib import check, lib
+
+    db = synth.make_igd_db(n_sets * per_set, n_sets, seed=6)
+    uni = synth.make_universe(n_universe, seed=3)
+    rng = np.random.default_rng(9)
+    sel = np.sort(rng.choice(len(uni["chrom"]), n_user, replace=False))
+    t = time.time()
+    g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=n_sets)
+    tb = time.time() - t
+    del db
+    uq = [_dev(uni[k], dev) for k in ("chrom", "start", "end")]
+    sq = [_dev(uni[k][sel], dev) for k in ("chrom", "start", "end")]
+    uh = torch.zeros(n_sets, dtype=torch.int64, device=dev)
+    sh = torch.zeros(n_sets, dtype=torch.int64, device=dev)
+    cells = [torch.empty(n_sets, dtype=torch.int64, device=dev) for _ in range(4)]
+    nuni = len(uni["chrom"])
+
+    def run():
+        g.count_device(uq[0].data_ptr(), uq[1].data_ptr(), uq[2].data_ptr(), nuni, uh.data_ptr(), 1, True, stream)
+        g.count_device(sq[0].data_ptr(), sq[1].data_ptr(), sq[2].data_ptr(), n_user, sh.data_ptr(), 1, True, stream)
+        check(lib.gtars_lola_contingency_device(sh.data_ptr(), uh.data_ptr(), n_sets, n_user, nuni,
+                                                *[c.data_ptr() for c in cells], stream))
+
+    run()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    a, b, c, d = [x.cpu().numpy() for x in cells]
+    ok = bool(((a + b) == uh.cpu().numpy()).all() and ((a + c) == n_user).all() and ((a + b + c + d) == nuni).all())
+    del g
+    torch.cuda.empty_cache()
+    return {"sets": n_sets, "db_intervals": n_sets * per_set, "universe": nuni, "user": n_user, "build_s": round(tb, 2),
+            "counts_ms": round(dt * 1e3, 3), "identities_hold": ok, "support_sum": int(a.sum())}
 
 
 def main():
@@ -130,8 +277,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--queries", type=int, default=1_000_000, help="query regions per step per GPU")
     ap.add_argument("--universe", type=int, default=100_000)
+    ap.add_argument("--batches", type=int, default=32, help="distinct device-resident batches the steps rotate through")
+    ap.add_argument("--min-seconds", type=float, default=0.6, help="GPU time to spend in timed repetitions (at least 11 repetitions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sweep", type=str, default="", help="comma-separated extra batch sizes to report")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / igd_config3 / lola_config4 / host path")
+    ap.add_argument("--large", type=str, default="64000000,256000000,1000000000", help="batch sizes of roofline_large")
     args = ap.parse_args()
 
     import torch
@@ -164,21 +314,40 @@ def main():
             dist_mod.init_process_group(backend=backend)
         dist = dist_mod
 
-    # ---- synthetic workload (per rank: its own slice of the global batch) ----
+    # ---- synthetic workload: NB distinct batches per rank (its slices of the global stream of batches) ----
+    nb = max(1, args.batches)
+    nq = args.queries
     u = synth.make_universe(args.universe, seed=3)
-    q = synth.make_queries(u, args.queries, seed=4 + 100 * rank)
-    nu, nq = len(u["chrom"]), len(q["chrom"])
+    nu = len(u["chrom"])
     ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
-    qc, qs, qe = (torch.from_numpy(q[k].view(np.int32)).to(dev) for k in ("chrom", "start", "end"))
-    offsets = torch.empty(nq + 1, dtype=torch.int64, device=dev)
-    ids = torch.empty(2 * nq + 1024, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    q0 = None
+    batches = []
+    for b in range(nb):
+        qb = synth.make_queries(u, nq, seed=4 + 100 * rank + 7919 * b)
+        if b == 0:
+            q0 = qb
+        qc, qs, qe = (_dev(qb[k], dev) for k in ("chrom", "start", "end"))
+        offsets = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        batches.append([qc, qs, qe, offsets, None, 0])
+    for bt in batches:  # size the id buffers: one offsets-only pass per batch
+        qc, qs, qe, offsets = bt[:4]
+        h = ix.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, offsets.data_ptr(), 0, 0, stream, sync=True)
+        bt[4] = torch.empty(h + 1024, dtype=torch.int32, device=dev)
+        bt[5] = h
+    resident_bytes = sum(sum(t.numel() * t.element_size() for t in bt[:5]) for bt in batches)
+    h_mean = sum(bt[5] for bt in batches) / nb
+
+    counter = [0]
 
     def step(sync=False):
+        qc, qs, qe, offsets, ids, _ = batches[counter[0] % nb]
+        counter[0] += 1
         return ix.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, offsets.data_ptr(),
                                   ids.data_ptr(), ids.numel(), stream, sync=sync)
 
-    h = step(sync=True)  # also validates capacity / scan status once
+    for bt in batches:  # validates capacity / scan status of every batch once
+        assert step(sync=True) == batches[(counter[0] - 1) % nb][5]
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,23 +355,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- timed repetitions: K steps each, barrier + synchronize on both sides, MAX over ranks; median reported ----
+    ts = torch.cuda.current_stream()
+    rep_wall, rep_kernel_ms = [], []
+    gpu_s, reps_min, reps_max = 0.0, 11, 20000
+    while len(rep_wall) < reps_min or (gpu_s < args.min_seconds and len(rep_wall) < reps_max):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record(ts)
+        for _ in range(args.steps):
+            step()
+        e1.record(ts)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        rep_wall.append(dt)
+        rep_kernel_ms.append(e0.elapsed_time(e1) / args.steps)
+        gpu_s += dt
+    elapsed = statistics.median(rep_wall)
+    avg_ms = statistics.median(rep_kernel_ms)
 
-    # ---- dominant-kernel duration with HIP events on the launch stream ----
-    # One step is exactly one k_tok_lds launch (the chained-scan workspace is epoch-tagged, so there is
-    # no memset kernel); K launches are bracketed by ONE pair of HIP events recorded on the stream the
-    # kernel is launched on, so the average includes the ~1 us inter-launch gap but no event overhead.
+    # ---- the dominant kernel: its name from the library's profiling hooks, its duration from the events above ----
     roofline = None
     if rank == 0:
         _lib.lib.gtars_prof_reset()
@@ -212,23 +394,15 @@ def main():
         names = list(_lib.prof_read())
         _lib.lib.gtars_prof_enable(0)
         name = names[0] if len(names) == 1 else "+".join(names)
-        prof_steps = max(args.steps, 50)
-        ts = torch.cuda.current_stream()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(ts)
-        for _ in range(prof_steps):
-            step()
-        e1.record(ts)
-        torch.cuda.synchronize()
-        avg_ms = e0.elapsed_time(e1) / prof_steps
-        bytes_per_launch = algorithmic_bytes(nq, h, nu)
+        bytes_per_launch = algorithmic_bytes(nq, round(h_mean), nu)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_tokenize_1M.json")
+        traffic, traffic_source = None, "not measured in this run (needs rocprofv3 --pmc passes)"
+        tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_tokenize_1M.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj["workload"]["queries_per_step"] == nq and tj["workload"]["universe_regions"] == args.universe:
-                traffic = tj["traffic_bytes_per_launch"]  # rocprofv3 PMC passes, see that file for the recipe
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_source = f"replayed from profiles/{PROFILE_ROUND}/traffic_tokenize_1M.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         roofline = {
             "bound": "hbm",
             "kernel": name,
@@ -237,36 +411,31 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "avg_kernel_ms": avg_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "bytes_per_query": bytes_per_launch / nq,
+            "frac_of_measured_copy_6.29TBps": achieved / 6290.0,
         }
 
-    sweep = []
-    if rank == 0 and args.sweep:
-        for tok in args.sweep.split(","):
-            n2 = int(tok)
-            rep = max(n2 // nq, 1)
-            big = {k: torch.from_numpy(np.tile(q[k], rep).view(np.int32)).to(dev) for k in ("chrom", "start", "end")}
-            n2 = nq * rep
-            off2 = torch.empty(n2 + 1, dtype=torch.int64, device=dev)
-            ids2 = torch.empty(h * rep + 1024, dtype=torch.int32, device=dev)
-            run = lambda s=False: ix.tokenize_device(big["chrom"].data_ptr(), big["start"].data_ptr(),
-                                                     big["end"].data_ptr(), n2, off2.data_ptr(), ids2.data_ptr(),
-                                                     ids2.numel(), stream, sync=s)
-            h2 = run(True)
-            for _ in range(3):
-                run()
-            torch.cuda.synchronize()
-            k = max(2, min(50, int(2e9 // n2)))
-            t1 = time.perf_counter()
-            for _ in range(k):
-                run()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / k
-            sweep.append({"queries": n2, "ms_per_step": dt * 1e3, "qps": n2 / dt,
-                          "hbm_frac": algorithmic_bytes(n2, h2, nu) / dt / 1e9 / HBM_PEAK_GBS})
-            del big, off2, ids2
+    # ---- N > 1: the same steps when one consumer needs the whole batch (all-gatherv of the CSR over RCCL) ----
+    with_allgather = None
+    if dist is not None and backend == "nccl":
+        from gtars_amd import sharding
+
+        qc, qs, qe, offsets, ids, h = batches[0]
+        sharding.all_gather_csr_device(offsets, ids, h)  # warm-up (communicator setup)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            qc, qs, qe, offsets, ids, h = batches[i % nb]
+            ix.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(),
+                               ids.numel(), stream, sync=False)
+            sharding.all_gather_csr_device(offsets, ids, h)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        with_allgather = {"value": nq * n_gpus * args.steps / dt, "unit": "query intervals/s", "ms_per_step": dt / args.steps * 1e3,
+                          "note": "tokenize + all-gatherv of offsets (u64) and ids (u32) so that every rank holds the global CSR"}
 
     if rank == 0:
         total_q = nq * n_gpus * args.steps
@@ -288,26 +457,36 @@ def main():
                             "(Bits order, CSR u64 offsets + u32 token ids), inputs resident in HBM",
                 "queries_per_step_per_gpu": nq,
                 "universe_regions": nu,
-                "hits_per_step_per_gpu": h,
+                "hits_per_step_per_gpu": round(h_mean),
+                "distinct_batches": nb,
+                "resident_bytes_rotated": resident_bytes,
                 "sharding": "independent query ranges per rank, universe index replicated, no collective",
             },
+            "timing": {"repetitions": len(rep_wall), "statistic": "median over repetitions of K back-to-back steps",
+                       "timed_seconds": sum(rep_wall), "min_ms_per_step": min(rep_wall) / args.steps * 1e3,
+                       "max_ms_per_step": max(rep_wall) / args.steps * 1e3},
             "roofline": roofline,
         }
-        if sweep:
-            out["batch_sweep"] = sweep
-        if world == 1:
+        if with_allgather:
+            out["with_allgather"] = with_allgather
+        if world == 1 and not args.no_extras:
+            sizes = [int(t) for t in args.large.split(",") if t]
+            out["roofline_large"] = bench_large(ix, q0, nu, sizes, dev, stream)
             # PCIe-inclusive rate through the host-pointer entry point (gtars_tokenize: H2D, kernel, D2H of
             # offsets + ids).  Reported for context only; it is never `value`.
-            ix.tokenize(q["chrom"], q["start"], q["end"])
+            ix.tokenize(q0["chrom"], q0["start"], q0["end"])
             t1 = time.perf_counter()
             for _ in range(5):
-                ix.tokenize(q["chrom"], q["start"], q["end"])
+                ix.tokenize(q0["chrom"], q0["start"], q0["end"])
             out["host_buffers_end_to_end"] = {"value": 5 * nq / (time.perf_counter() - t1), "unit": "query intervals/s",
-                                              "note": "pageable numpy buffers in and out, one call per batch"}
-            out["roofline"]["frac_of_measured_copy_6.29TBps"] = roofline["achieved"] / 6290.0
+                                              "note": "pageable numpy buffers in and out, one call per 1M-query batch"}
+            del batches[:]
+            torch.cuda.empty_cache()
+            out["igd_config3"] = bench_igd_config3(dev, stream)
+            out["lola_config4"] = bench_lola_config4(dev, stream)
         if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(u, q)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(u, q)
+            out["cpu_baseline"] = cpu_baseline(u, q0)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(u, q0)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

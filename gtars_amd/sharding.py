@@ -1,19 +1,33 @@
-"""Multi-GPU sharding of the hot path (one process per GPU, torch.distributed; "nccl" is RCCL on ROCm).
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed ("nccl" is RCCL on ROCm).
 
-* Tokenize / count / find: every query is independent and the universe index is ~1 MB, so the index is
-  REPLICATED and the query batch is cut into ``world`` contiguous index ranges.  Rank r's output is exactly
-  the slice of the global CSR that belongs to its range, so concatenation in rank order reproduces the
-  single-GPU result; no collective is needed unless one consumer wants the whole batch -- then
-  ``all_gather_csr`` (C2: all-gather of lengths, then of padded payloads).
-* IGD / LOLA counts: per-file hit vectors are sums over queries, so ranks count their query range against a
-  replicated database and ``all_reduce_hits`` (C1: one SUM all-reduce of F u64 values, ~16 KB at F = 2,000)
-  gives the global vector on every rank.
+What shards how (BASELINE.json north_star):
+
+* **IGD / LOLA counts** (many-vs-many): the reference database AND the query sets shard by *chromosome bucket*.
+  ``chrom_buckets`` assigns chromosomes to ranks by LPT (longest processing time first) over the per-chromosome
+  weight ``Ndb_c + Nq_c``; rank r indexes only the database intervals of its chromosomes and counts only the
+  queries that fall on them, so the database is cut, not replicated (5e7 intervals -> 6e6 per GPU at N = 8).
+  Per-file hit vectors are sums over queries, hence one RCCL all-reduce(SUM) of F int64 values (16 KB at
+  F = 2000) yields the global vector on every rank -- exactly what the contingency cells of LOLA need
+  (support ``a`` per user set x DB set and the universe's pooled support, gtars-lola/src/enrichment.rs:198-221).
+  ``mode="range"`` (database replicated, queries cut into contiguous ranges) is kept as the cross-check: both
+  must equal the single-process result.
+* **Tokenize / count / find**: every query is independent and the universe index is ~1.6 MB, so the index is
+  replicated and the batch is cut into ``world`` contiguous ranges (``shard_range``).  Rank r's CSR is the slice
+  of the global CSR of its range; nothing is exchanged unless one consumer needs the whole batch -- then
+  ``all_gather_csr_device``: all-gatherv of per-query counts (u32) and ids (u32) over RCCL, offsets rebuilt by a
+  device-side cumulative sum.  Payloads stay on the device and stay 32 bits wide.
+
+The drivers take an *engine* (the thing that builds an index and counts on one device).  ``HipEngine`` is the
+product path (libgtars_amd.so on ``cuda:<local rank>``); the gloo test on CPU plugs a stand-in behind the same four
+methods, so that the sharding logic and the collectives that run there are the ones that run on the GPUs.
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+
+UNKNOWN_CHROM = 0xFFFFFFFF
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -25,42 +39,258 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_reduce_hits(hits: np.ndarray, group=None, device=None) -> np.ndarray:
-    """C1: element-wise SUM of per-file hit vectors over ranks (u64 carried as int64: counts < 2^63)."""
-    import torch
+def chrom_weights(n_chrom: int, *chrom_arrays: np.ndarray) -> np.ndarray:
+    """Per-chromosome weight = number of intervals (database + queries) on it; unknown chromosomes are ignored."""
+    w = np.zeros(n_chrom, dtype=np.int64)
+    for c in chrom_arrays:
+        c = np.asarray(c)
+        c = c[c < n_chrom]
+        w += np.bincount(c, minlength=n_chrom)[:n_chrom]
+    return w
+
+
+def chrom_buckets(weights: Sequence[int], world: int) -> np.ndarray:
+    """LPT assignment of chromosomes to ranks: heaviest chromosome first, each to the least-loaded rank (ties: lowest
+    rank; equal weights: lowest chromosome id first, so every rank computes the same map).  Returns owner[c]."""
+    w = np.asarray(weights, dtype=np.int64)
+    owner = np.zeros(len(w), dtype=np.int32)
+    load = np.zeros(max(world, 1), dtype=np.int64)
+    for c in sorted(range(len(w)), key=lambda i: (-int(w[i]), i)):
+        r = int(np.argmin(load))
+        owner[c] = r
+        load[r] += int(w[c])
+    return owner
+
+
+def _select_owned(owner: np.ndarray, rank: int, chrom: np.ndarray) -> np.ndarray:
+    c = np.asarray(chrom)
+    known = c < len(owner)
+    sel = np.zeros(len(c), dtype=bool)
+    sel[known] = owner[c[known]] == rank
+    return sel
+
+
+# --------------------------------------------------------------------------- collectives on device tensors
+
+def _backend(group=None) -> str:
     import torch.distributed as dist
 
-    t = torch.from_numpy(np.ascontiguousarray(hits).astype(np.int64))
-    if device is not None:
-        t = t.to(device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t.cpu().numpy().astype(np.uint64)
+    return dist.get_backend(group)
 
 
-def all_gather_csr(offsets: np.ndarray, ids: np.ndarray, group=None, device=None) -> Tuple[np.ndarray, np.ndarray]:
-    """C2: assemble the global CSR (offsets u64[N+1], ids u32[H]) from per-rank CSRs of consecutive query ranges."""
+def all_reduce_hits_(hits, group=None):
+    """C1: in-place element-wise SUM of per-file hit vectors (int64 tensor on the engine's device) over ranks.
+    RCCL reduces the device buffer directly; under gloo (CPU test, or several ranks sharing one GPU) the tensor is
+    staged through the host."""
+    import torch.distributed as dist
+
+    if _backend(group) == "gloo" and hits.is_cuda:
+        t = hits.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        hits.copy_(t)
+    else:
+        dist.all_reduce(hits, op=dist.ReduceOp.SUM, group=group)
+    return hits
+
+
+def all_gather_csr_device(offsets, ids, n_hits: int, group=None):
+    """C2: the global CSR from per-rank CSRs of consecutive query ranges, on the device.
+
+    offsets: int64[nq_r + 1] (the u64 offsets of the C ABI), ids: int32[>= n_hits] (u32 token ids, bit-identical).
+    Returns (global offsets int64[sum nq_r + 1], global ids int32[sum H_r]).  Wire format: one all-gather of
+    (nq_r, H_r), one of the per-query counts as int32, one of the ids as int32 -- all-gatherv emulated by padding to
+    the largest rank (ranks are balanced to +-1 query, ids to a few per cent)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    counts = np.diff(offsets.astype(np.int64))
-    meta = torch.tensor([len(counts), len(ids)], dtype=torch.int64, device=device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    nq = [int(m[0]) for m in metas]
-    nh = [int(m[1]) for m in metas]
+    stage = _backend(group) == "gloo" and offsets.is_cuda
+    dev = offsets.device
+    cdev = torch.device("cpu") if stage else dev
+    nq = offsets.numel() - 1
+    meta = torch.tensor([nq, n_hits], dtype=torch.int64, device=cdev)
+    metas = torch.empty(2 * world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.cpu().view(world, 2)
+    nqs, nhs = [int(x) for x in metas[:, 0]], [int(x) for x in metas[:, 1]]
 
-    def gather(arr: np.ndarray, lens: List[int], dtype) -> np.ndarray:
+    def gatherv(x, lens):
         pad = max(max(lens), 1)
-        buf = torch.zeros(pad, dtype=dtype, device=device)
-        if len(arr):
-            buf[: len(arr)] = torch.from_numpy(arr.astype(np.int64)).to(dtype).to(buf.device)
-        bufs = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(bufs, buf, group=group)
-        return np.concatenate([b[:l].cpu().numpy() for b, l in zip(bufs, lens)]) if sum(lens) else np.zeros(0, np.int64)
+        buf = torch.zeros(pad, dtype=torch.int32, device=cdev)
+        buf[: x.numel()] = x.to(cdev)
+        out = torch.empty(pad * world, dtype=torch.int32, device=cdev)
+        dist.all_gather_into_tensor(out, buf, group=group)
+        out = out.view(world, pad)
+        return torch.cat([out[r, : lens[r]] for r in range(world)]).to(dev)
 
-    all_counts = gather(counts, nq, torch.int64)
-    all_ids = gather(ids.astype(np.int64), nh, torch.int64)
-    goff = np.zeros(len(all_counts) + 1, dtype=np.uint64)
-    np.cumsum(all_counts, out=goff[1:])
-    return goff, all_ids.astype(np.uint32)
+    counts = (offsets[1:] - offsets[:-1]).to(torch.int32)  # hits per query < 2^32
+    g_counts = gatherv(counts, nqs)
+    g_ids = gatherv(ids[:n_hits], nhs)
+    g_off = torch.zeros(sum(nqs) + 1, dtype=torch.int64, device=dev)
+    # counts are u32 carried in int32: widen through the unsigned value before summing
+    torch.cumsum(g_counts.to(torch.int64) & 0xFFFFFFFF, dim=0, out=g_off[1:])
+    return g_off, g_ids
+
+
+# --------------------------------------------------------------------------- the product engine
+
+class HipEngine:
+    """One MI355X through libgtars_amd.so.  Inputs are host numpy columns; results are tensors on ``device``."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        import torch
+
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+
+    def _dev(self, a):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(self.device)
+
+    def igd(self, chrom, start, end, file_idx, n_chrom: int, n_files: int):
+        from .engine import IgdIndex
+
+        return IgdIndex(chrom, start, end, file_idx, n_chrom=n_chrom, n_files=n_files)
+
+    def upload(self, qc, qs, qe):
+        """queries resident on the device: what igd_count_resident takes"""
+        return [self._dev(x) for x in (qc, qs, qe)]
+
+    def igd_count_resident(self, g, d, min_overlap: int, binary: bool, hits=None, sync: bool = True):
+        import torch
+
+        if hits is None:
+            hits = torch.zeros(g.n_files, dtype=torch.int64, device=self.device)
+        n = d[0].numel()
+        if n:
+            g.count_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), n, hits.data_ptr(), min_overlap, binary,
+                           torch.cuda.current_stream().cuda_stream)
+        else:
+            hits.zero_()
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        return hits
+
+    def igd_count(self, g, qc, qs, qe, min_overlap: int, binary: bool):
+        return self.igd_count_resident(g, self.upload(qc, qs, qe), min_overlap, binary)
+
+    def index(self, chrom, start, end, n_chrom: int):
+        from .engine import OverlapIndex
+
+        return OverlapIndex(chrom, start, end, n_chrom=n_chrom)
+
+    def tokenize(self, ix, qc, qs, qe):
+        import torch
+
+        n = len(qc)
+        d = [self._dev(x) for x in (qc, qs, qe)]
+        offsets = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        st = torch.cuda.current_stream().cuda_stream
+        h = ix.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), n, offsets.data_ptr(), 0, 0, st, sync=True)
+        ids = torch.empty(max(h, 1), dtype=torch.int32, device=self.device)
+        ix.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), n, offsets.data_ptr(), ids.data_ptr(), ids.numel(),
+                           st, sync=True)
+        return offsets, ids[:h]
+
+
+# --------------------------------------------------------------------------- drivers
+
+def _rank_world(group=None) -> Tuple[int, int]:
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+class ShardedIgd:
+    """An IGD database spread over the ranks of a process group.
+
+    mode "bucket": rank r holds the intervals of the chromosomes ``owner == r`` (LPT over Ndb_c + Nq_c when query
+    chromosome columns are passed as ``balance_with``); mode "range": every rank holds the whole database."""
+
+    def __init__(self, engine, db: Dict[str, np.ndarray], n_chrom: int, n_files: int, mode: str = "bucket",
+                 balance_with: Sequence[np.ndarray] = (), group=None):
+        if mode not in ("bucket", "range"):
+            raise ValueError("mode must be 'bucket' or 'range'")
+        self.engine, self.mode, self.group = engine, mode, group
+        self.n_chrom, self.n_files = n_chrom, n_files
+        self.rank, self.world = _rank_world(group)
+        self.owner: Optional[np.ndarray] = None
+        if mode == "bucket" and self.world > 1:
+            self.owner = chrom_buckets(chrom_weights(n_chrom, db["chrom"], *balance_with), self.world)
+            keep = _select_owned(self.owner, self.rank, db["chrom"])
+            db = {k: np.ascontiguousarray(v[keep]) for k, v in db.items()}
+        self.local_intervals = len(db["chrom"])
+        self.g = engine.igd(db["chrom"], db["start"], db["end"], db["file"], n_chrom, n_files)
+
+    def local_queries(self, q: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+        """this rank's share of a query set (bucket: its chromosomes; range: its contiguous slice)"""
+        if self.world == 1:
+            return q
+        if self.mode == "bucket":
+            sel = _select_owned(self.owner, self.rank, q["chrom"])
+            return {k: np.ascontiguousarray(q[k][sel]) for k in ("chrom", "start", "end")}
+        lo, hi = shard_range(len(q["chrom"]), self.rank, self.world)
+        return {k: q[k][lo:hi] for k in ("chrom", "start", "end")}
+
+    def count_local(self, q, min_overlap: int = 1, binary: bool = False):
+        lq = self.local_queries(q)
+        return self.engine.igd_count(self.g, lq["chrom"], lq["start"], lq["end"], min_overlap, binary)
+
+    def upload_local(self, q):
+        """this rank's share of ``q``, resident on the engine's device (for repeated counts: ``count_resident``)"""
+        lq = self.local_queries(q)
+        return self.engine.upload(lq["chrom"], lq["start"], lq["end"])
+
+    def count_resident(self, handle, min_overlap: int = 1, binary: bool = False, hits=None):
+        """count + all-reduce on queries uploaded with ``upload_local``; nothing but the F-long vector leaves the device"""
+        hits = self.engine.igd_count_resident(self.g, handle, min_overlap, binary, hits, sync=False)
+        if self.world > 1:
+            all_reduce_hits_(hits, self.group)
+        return hits
+
+    def count(self, q, min_overlap: int = 1, binary: bool = False):
+        """global per-file hit vector (int64 tensor on the engine's device), identical on every rank"""
+        hits = self.count_local(q, min_overlap, binary)
+        if self.world > 1:
+            all_reduce_hits_(hits, self.group)
+        return hits
+
+
+def lola_counts_sharded(sdb: ShardedIgd, user_sets: Sequence[Dict[str, np.ndarray]], universe: Dict[str, np.ndarray],
+                        min_overlap: int = 1):
+    """Support vectors of LOLA (enrichment.rs:176-221) with the database sharded: ``a[u][f]`` = regions of user set u
+    that hit DB set f, ``pooled[f]`` the same for the universe.  All (1 + U) local vectors are reduced by ONE all-reduce
+    of (1 + U) * F int64 values.  Returns (support [U, F], pooled [F]) as int64 tensors on the engine's device."""
+    import torch
+
+    vecs = [sdb.count_local(universe, min_overlap, True)] + [sdb.count_local(us, min_overlap, True) for us in user_sets]
+    stacked = torch.stack(vecs)
+    if sdb.world > 1:
+        all_reduce_hits_(stacked, sdb.group)
+    return stacked[1:], stacked[0]
+
+
+def contingency(support, pooled, user_sizes: Sequence[int], universe_size: int):
+    """a, b, c, d of enrichment.rs:198-221 for every (user set, DB set), int64 (d may go negative as in the reference)."""
+    import torch
+
+    a = support
+    b = pooled.unsqueeze(0) - a
+    sizes = torch.tensor(list(user_sizes), dtype=torch.int64, device=a.device).unsqueeze(1)
+    c = sizes - a
+    d = universe_size - a - b - c
+    return a, b, c, d
+
+
+def tokenize_sharded(engine, ix, q: Dict[str, np.ndarray], gather: bool = True, group=None):
+    """Range-sharded tokenization: this rank's CSR of its query range; with ``gather`` the global CSR on every rank."""
+    rank, world = _rank_world(group)
+    lo, hi = shard_range(len(q["chrom"]), rank, world)
+    offsets, ids = engine.tokenize(ix, q["chrom"][lo:hi], q["start"][lo:hi], q["end"][lo:hi])
+    if world > 1 and gather:
+        return all_gather_csr_device(offsets, ids, int(ids.numel()), group)
+    return offsets, ids

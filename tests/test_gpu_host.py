@@ -477,3 +477,81 @@ def test_bench_line_contract():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 1e9 and abs(d["value"] - d["config"]["queries_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+
+
+# ------------------------------------------------------------ two ranks on one GPU: the sharded drivers on the HIP path
+
+
+def _hip_rank(rank, world, port, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from gtars_amd import sharding
+    from test_sharding_gloo import sharded_checks
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, sharded_checks(sharding.HipEngine("cuda:0"), rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_sharded_drivers():
+    """world size 2 on ONE MI355X (gloo carries the collectives; under RCCL the same tensors are reduced in place):
+    chromosome-bucket == range == single-process for the IGD / LOLA vectors, and the gathered CSR == the unsharded one.
+    Same assertions as the CPU gloo test, with HipEngine behind the drivers."""
+    import sys
+
+    import torch.multiprocessing as mp
+
+    from test_sharding_gloo import _free_port
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, checks in res.items():
+        assert checks and all(checks.values()), (rank, checks)
+    assert res[0]["bucket_db_is_cut"]
+
+
+def test_bench_tools_run_with_two_ranks_on_one_gpu():
+    """tools/igd_bench.py and tools/lola_bench.py --gpus 2 under torch.distributed.run (gloo: both ranks on this GPU) give the
+    same totals as their single-GPU runs (small sizes)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GTARS_BENCH_BACKEND="gloo", NDB="300000", NQ="100000", F="50", PER="1000", NUNI="20000", NUSER="3000")
+
+    def run(tool, n):
+        cmd = [sys.executable]
+        if n > 1:
+            from test_sharding_gloo import _free_port
+
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port())]
+        cmd += [os.path.join(root, "tools", tool), "--gpus", str(n)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-2000:])
+        return json.loads(lines[-1])
+
+    i1, i2 = run("igd_bench.py", 1), run("igd_bench.py", 2)
+    for k in ("pairwise", "binary", "pairwise_sorted_input", "binary_sorted_input"):
+        assert i1[k]["total_hits"] == i2[k]["total_hits"], k
+    assert i2["n_gpus"] == 2 and i2["local_db_intervals"] < i1["local_db_intervals"]
+    l1, l2 = run("lola_bench.py", 1), run("lola_bench.py", 2)
+    assert l1["identities_hold"] and l2["identities_hold"] and l1["support_sum"] == l2["support_sum"]

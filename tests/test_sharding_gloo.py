@@ -1,6 +1,9 @@
-"""N > 1 path on CPU: two gloo ranks shard the query batch, compute their slice with the oracle (the
-stand-in checker -- there is no GPU here), and the collectives of gtars_amd.sharding must reproduce the
-single-process result exactly."""
+"""N > 1 path on CPU: two gloo ranks run the DRIVERS of gtars_amd.sharding (chromosome-bucket and range sharding of an IGD
+database, LOLA support vectors, range-sharded tokenization with the CSR all-gather) and must reproduce the
+single-process result exactly.  There is no GPU here, so the engine behind the drivers is a stand-in with the same four
+methods as sharding.HipEngine, computing on the CPU oracle; everything else -- LPT buckets, query routing, the
+collectives -- is the code that runs on the GPUs.  (tests/test_gpu_host.py runs the same drivers with HipEngine, two
+ranks sharing one GPU.)"""
 import os
 import socket
 
@@ -16,36 +19,102 @@ def _free_port():
     return p
 
 
+class OracleEngine:
+    """CPU stand-in for sharding.HipEngine (test infrastructure: the product never imports oracle/)."""
+
+    name = "oracle"
+
+    def igd(self, chrom, start, end, file_idx, n_chrom, n_files):
+        import oracle
+
+        g = oracle.Igd()
+        g.add_arrays(chrom, start, end, np.zeros(len(chrom), dtype=int), file_idx)
+        g.n_files = n_files
+        g.finalize()
+        return g
+
+    def igd_count(self, g, qc, qs, qe, min_overlap, binary):
+        import torch
+
+        f = g.count_region_hits if binary else g.count_set_overlaps
+        return torch.from_numpy(f(qc, qs, qe, min_overlap, n_files=g.n_files).astype(np.int64))
+
+    def upload(self, qc, qs, qe):
+        return [np.ascontiguousarray(x) for x in (qc, qs, qe)]
+
+    def igd_count_resident(self, g, d, min_overlap, binary, hits=None, sync=True):
+        r = self.igd_count(g, d[0], d[1], d[2], min_overlap, binary)
+        if hits is not None:
+            hits.copy_(r)
+            return hits
+        return r
+
+    def index(self, chrom, start, end, n_chrom):
+        import oracle
+
+        return oracle.Index(chrom, start, end, None, n_chrom=n_chrom)
+
+    def tokenize(self, ix, qc, qs, qe):
+        import torch
+
+        off, ids = ix.tokenize(qc, qs, qe)
+        return torch.from_numpy(off.astype(np.int64)), torch.from_numpy(ids.view(np.int32).copy())
+
+
+def sharded_checks(engine, rank, world):
+    """The assertions shared by the CPU (gloo + oracle engine) and the GPU (HipEngine) multi-rank tests.
+    Returns a dict of booleans; the single-process expectation is computed with the same engine, unsharded."""
+    import torch
+
+    from gtars_amd import sharding, synth
+
+    out = {}
+    n_chrom, F = synth.N_CHROM, 37
+    db = synth.make_igd_db(20_000, F)
+    bq = synth.make_background_queries(6_001)
+    bq["chrom"][::97] = 0xFFFFFFFF  # unknown chromosomes hit nothing and belong to no bucket
+    whole = engine.igd(db["chrom"], db["start"], db["end"], db["file"], n_chrom, F)
+    for binary in (False, True):
+        exp = engine.igd_count(whole, bq["chrom"], bq["start"], bq["end"], 1, binary).cpu()
+        for mode in ("bucket", "range"):
+            sdb = sharding.ShardedIgd(engine, db, n_chrom, F, mode=mode, balance_with=[bq["chrom"]])
+            got = sdb.count(bq, 1, binary).cpu()
+            got2 = sdb.count_resident(sdb.upload_local(bq), 1, binary).cpu()
+            out[f"igd_{mode}_{'binary' if binary else 'pairwise'}"] = bool(torch.equal(got, exp) and torch.equal(got2, exp))
+            if mode == "bucket" and world > 1:
+                out["bucket_db_is_cut"] = sdb.local_intervals < len(db["chrom"])
+    # LOLA support vectors + contingency cells: two user sets, one all-reduce
+    uni = synth.make_universe(30_000, seed=3)
+    rng = np.random.default_rng(5)
+    users = []
+    for n_user in (2_000, 777):
+        sel = np.sort(rng.choice(len(uni["chrom"]), n_user, replace=False))
+        users.append({k: uni[k][sel] for k in ("chrom", "start", "end")})
+    exp_pooled = engine.igd_count(whole, uni["chrom"], uni["start"], uni["end"], 1, True).cpu()
+    exp_sup = torch.stack([engine.igd_count(whole, us["chrom"], us["start"], us["end"], 1, True).cpu() for us in users])
+    sdb = sharding.ShardedIgd(engine, db, n_chrom, F, mode="bucket", balance_with=[uni["chrom"]])
+    sup, pooled = sharding.lola_counts_sharded(sdb, users, uni)
+    out["lola_support"] = bool(torch.equal(sup.cpu(), exp_sup) and torch.equal(pooled.cpu(), exp_pooled))
+    a, b, c, d = sharding.contingency(sup, pooled, [len(us["chrom"]) for us in users], len(uni["chrom"]))
+    out["lola_cells"] = bool(torch.equal((a + b).cpu(), exp_pooled.expand_as(a)) and int((a + b + c + d - len(uni["chrom"])).abs().sum()) == 0)
+    # tokenization: replicated universe index, contiguous query ranges, all-gatherv of the CSR
+    u = synth.make_universe(5_000)
+    q = synth.make_queries(u, 40_001)
+    ix = engine.index(u["chrom"], u["start"], u["end"], n_chrom)
+    exp_off, exp_ids = engine.tokenize(ix, q["chrom"], q["start"], q["end"])
+    g_off, g_ids = sharding.tokenize_sharded(engine, ix, q, gather=True)
+    out["tokenize_gather"] = bool(torch.equal(g_off.cpu(), exp_off.cpu()) and torch.equal(g_ids.cpu(), exp_ids.cpu()))
+    return out
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
-
-    import oracle
-    from gtars_amd import sharding, synth
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        u = synth.make_universe(5_000)
-        qs = synth.make_queries(u, 40_001)
-        ix = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM)
-        lo, hi = sharding.shard_range(len(qs["chrom"]), rank, world)
-        off, ids = ix.tokenize(qs["chrom"][lo:hi], qs["start"][lo:hi], qs["end"][lo:hi])
-        goff, gids = sharding.all_gather_csr(off, ids)
-        full_off, full_ids = ix.tokenize(qs["chrom"], qs["start"], qs["end"])
-        ok_tok = np.array_equal(goff, full_off) and np.array_equal(gids, full_ids)
-        # IGD support vectors: replicated DB, sharded queries, one all-reduce
-        db = synth.make_igd_db(20_000, 37)
-        g = oracle.Igd()
-        g.add_arrays(db["chrom"], db["start"], db["end"], np.zeros(len(db["chrom"]), dtype=int), db["file"])
-        g.n_files = 37
-        g.finalize()
-        bq = synth.make_background_queries(6_001)
-        lo, hi = sharding.shard_range(len(bq["chrom"]), rank, world)
-        part = g.count_region_hits(bq["chrom"][lo:hi], bq["start"][lo:hi], bq["end"][lo:hi], 1, n_files=37)
-        total = sharding.all_reduce_hits(part)
-        ok_igd = np.array_equal(total, g.count_region_hits(bq["chrom"], bq["start"], bq["end"], 1, n_files=37))
-        q.put((rank, bool(ok_tok), bool(ok_igd)))
+        q.put((rank, sharded_checks(OracleEngine(), rank, world)))
     finally:
         dist.destroy_process_group()
 
@@ -61,6 +130,25 @@ def test_shard_range_tiles_the_batch():
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
 
 
+def test_chrom_buckets_lpt():
+    """hg38-shaped weights over 8 ranks: every chromosome has exactly one owner, the heaviest rank stays within
+    4/3 - 1/(3m) of the optimum (Graham's bound) -- in fact within a few per cent here -- and the map is deterministic."""
+    from gtars_amd import synth
+    from gtars_amd.sharding import chrom_buckets, chrom_weights
+
+    w = synth.CHROM_SIZES // 1000
+    for world in (1, 2, 4, 8):
+        owner = chrom_buckets(w, world)
+        assert owner.shape == (synth.N_CHROM,) and owner.min() >= 0 and owner.max() < world
+        load = np.bincount(owner, weights=w, minlength=world)
+        assert load.sum() == w.sum()
+        assert load.max() <= max(w.sum() / world * 1.08, w.max())
+        assert np.array_equal(owner, chrom_buckets(w, world))
+    assert chrom_buckets([5, 5, 5], 2).tolist() == [0, 1, 0]  # ties: lowest chromosome first, lowest rank first
+    cw = chrom_weights(3, np.array([0, 0, 2, 0xFFFFFFFF], dtype=np.uint32), np.array([1], dtype=np.uint32))
+    assert cw.tolist() == [2, 1, 1]
+
+
 def test_two_rank_gloo_matches_single_process():
     import torch.multiprocessing as mp
 
@@ -70,7 +158,15 @@ def test_two_rank_gloo_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = dict(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True, True), (1, True, True)]
+    assert sorted(res) == [0, 1]
+    for rank, checks in res.items():
+        assert checks and all(checks.values()), (rank, checks)
+    assert res[0]["bucket_db_is_cut"]
+
+
+def test_single_process_drivers_need_no_process_group():
+    checks = sharded_checks(OracleEngine(), 0, 1)
+    assert all(checks.values()), checks
