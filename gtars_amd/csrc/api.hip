@@ -277,7 +277,58 @@ struct gtars_igd {
     // per tile: the largest end among the chromosome's records BEFORE the tile (0: none) -- the carry-in of the
     // prefix maximum the sweep builds in LDS
     DevBuf<i32> tile_carry;
+    // ownership bound of every tile and the tiles of every chromosome (IgdTiles, common.h)
+    DevBuf<u32> tile_bnd, chrom_tile_off;
+    // IgdTiles::pme_file, built on the first binary count with min_overlap == 1
+    mutable std::mutex pme_mu;
+    mutable DevBuf<i32> pme_file;
+    mutable bool pme_ready = false;
+    gtars_status ensure_pme() const {
+        std::lock_guard<std::mutex> lk(pme_mu);
+        if (pme_ready || n == 0) return GTARS_OK;
+        ScopedDev ws;
+        const size_t wsb = igd_pme_ws_bytes((u32)n);
+        gtars_status st = ws.alloc(wsb);
+        if (st) return st;
+        i32 *p = nullptr;
+        GT_HIP(hipMalloc((void **)&p, (size_t)n * 4));
+        st = igd_build_pme_file(view(), p, ws.p, wsb, nullptr);
+        hipError_t e = hipDeviceSynchronize();
+        if (st || e != hipSuccess) {
+            (void)hipFree(p);
+            return st ? st : fail(GTARS_ERR_HIP, "pme_file build failed");
+        }
+        pme_file.p = p;
+        pme_file.n = n;
+        pme_ready = true;
+        return GTARS_OK;
+    }
     u32 n_tiles = 0;
+    IgdTiles tiles() const {
+        IgdTiles t;
+        t.first = tile_first.p;
+        t.cnt = tile_cnt.p;
+        t.chrom = tile_chrom.p;
+        t.carry = tile_carry.p;
+        t.bnd = tile_bnd.p;
+        t.chrom_tile_off = chrom_tile_off.p;
+        t.pme_file = pme_ready && !getenv("GTARS_IGD_NO_PME") ? pme_file.p : nullptr;
+        t.n_tiles = n_tiles;
+        return t;
+    }
+    // after tile_first / tile_cnt / tile_chrom, starts and chrom_maxlen are on the device
+    gtars_status finish_tiles(const std::vector<u32> &tch) {
+        std::vector<u32> cto(n_chrom + 1, 0);
+        for (u32 c : tch) cto[c + 1]++;
+        for (u32 c = 0; c < n_chrom; ++c) cto[c + 1] += cto[c];
+        gtars_status st = chrom_tile_off.upload(cto);
+        if (st) return st;
+        std::vector<u32> zero(std::max<u32>(n_tiles, 1), 0);
+        if ((st = tile_bnd.upload(zero))) return st;
+        if ((st = launch_igd_tile_bounds(view(), tile_first.p, tile_cnt.p, tile_chrom.p, n_tiles, tile_bnd.p, nullptr))) return st;
+        GT_HIP(hipDeviceSynchronize());
+        return GTARS_OK;
+    }
     IgdView view() const {
         IgdView v;
         v.starts = starts.p;
@@ -1165,6 +1216,7 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
             }
             if ((st = g->tile_carry.upload(carry))) return bail(st);
         }
+        if ((st = g->finish_tiles(tch))) return bail(st);
         *out = g;
         return GTARS_OK;
     }
@@ -1229,6 +1281,7 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const 
     if (!st) st = g->files.upload(hf);
     if (!st) st = g->chrom_off.upload(hoff);
     if (!st) st = g->chrom_maxlen.upload(hml);
+    if (!st) st = g->finish_tiles(tch);
     if (st) {
         gtars_igd_free(g);
         return st;
@@ -1249,6 +1302,9 @@ void gtars_igd_free(gtars_igd_t *g) {
     g->tile_cnt.release();
     g->tile_chrom.release();
     g->tile_carry.release();
+    g->tile_bnd.release();
+    g->chrom_tile_off.release();
+    g->pme_file.release();
     delete g;
 }
 
@@ -1294,12 +1350,14 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
     if (min_overlap < 1) return fail(GTARS_ERR_INVALID_ARG, "IGD queries are defined for min_overlap >= 1");
     if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
     if (igd_sweep_supported(g->view(), nq)) {
-        // large batch: sort the queries once, stream the database once (igd_sweep.hip)
+        // large batch: group the queries by owner tile once, stream the database once (igd_sweep.hip)
+        const bool no_pme = getenv("GTARS_IGD_NO_PME") != nullptr;  // tests / A-B runs: the credited-file list instead
+        if (binary && min_overlap == 1 && !no_pme && (st = g->ensure_pme())) return st;
         Workspace &ws = tls_workspace(2, (hipStream_t)stream);
         st = ws.reserve(igd_sweep_ws_bytes(nq, g->n_tiles, g->n_chrom));
         if (st) return st;
-        return launch_igd_sweep(g->view(), g->tile_first.p, g->tile_cnt.p, g->tile_chrom.p, g->tile_carry.p, g->n_tiles, d_qc, d_qs,
-                                d_qe, nq, min_overlap, binary, d_hits, ws.ptr, ws.bytes, (hipStream_t)stream);
+        return launch_igd_sweep(g->view(), g->tiles(), d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, ws.ptr, ws.bytes,
+                                (hipStream_t)stream);
     }
     return launch_igd_count(g->view(), d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
 }

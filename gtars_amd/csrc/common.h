@@ -206,6 +206,13 @@ gtars_status launch_lola_contingency(const u64 *user_hits, const u64 *universe_h
 gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, u32 *new_counts,
                                          hipStream_t st);
 
+// K1 (sort.hip): one-pass partition of (a, b) pairs by a small key (< n_bins <= MS_MAX_BINS), not stable: bin_off[n_bins + 1]
+// receives the bin boundaries; elements whose key is `drop_bin` are left out (their bin must be the last one)
+constexpr u32 MS_MAX_BINS = 36864;  // 144 KB of LDS counters
+size_t multisplit_ws_bytes(u32 n_bins);
+gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, u32 *out_a, u32 *out_b,
+                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st);
+
 // K1 (sort.hip): permutation that orders rows by (chrom, k1, [k2], input order); device columns in/out
 gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
                               hipStream_t st);
@@ -213,14 +220,29 @@ gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_
 size_t device_sort_perm_ws_bytes(u32 n);
 gtars_status device_sort_perm_ws(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
                                  void *scratch, size_t scratch_bytes, hipStream_t st);
-// IGD batch sweep (igd_sweep.hip)
+// IGD batch sweep (igd_sweep.hip): the database cut into tiles of IGD_TILE_RECORDS consecutive records of one chromosome
+struct IgdTiles {
+    const u32 *first, *cnt, *chrom;  // [n_tiles] first record, record count, chromosome
+    const i32 *carry;                // [n_tiles] largest end among the chromosome's records before the tile (0: none)
+    const u32 *bnd;                  // [n_tiles] ownership bound: last start + max_len + 1 (saturating); a query
+                                     //   (c, s) is owned by the first tile of chromosome c with bnd > s
+    const u32 *chrom_tile_off;       // [n_chrom + 1] tiles of each chromosome
+    const i32 *pme_file;             // [n] largest end among the EARLIER records of the same file and chromosome (0: none),
+                                     //   or null: not built yet
+    u32 n_tiles;
+};
 bool igd_sweep_supported(const IgdView &v, u64 nq);
 size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom);
+size_t igd_pme_ws_bytes(u32 n);
+gtars_status igd_build_pme_file(const IgdView &v, i32 *pme, void *ws, size_t ws_bytes, hipStream_t st);
+size_t radix_sort_ws_bytes(u32 n);
+gtars_status radix_sort_pairs(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u32 n, int begin_bit, int end_bit, void *ws, size_t ws_bytes,
+                              int *result_in, hipStream_t st);
+gtars_status launch_igd_tile_bounds(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom, u32 n_tiles,
+                                    u32 *bnd, hipStream_t st);
 gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, const u32 *tile_cnt, u32 n_tiles, i32 *tile_max,
                                      hipStream_t st);
-gtars_status launch_igd_sweep(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
-                              const i32 *tile_carry,
-                              u32 n_tiles, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, i32 min_overlap,
+gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, i32 min_overlap,
                               int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st);
 constexpr u32 IGD_TILE_RECORDS = 2048;
 gtars_status device_gather_u32(const u32 *src, const u32 *idx, u32 n, u32 *dst, hipStream_t st);

@@ -530,9 +530,26 @@ def test_igd_sweep_matches_oracle(ga, monkeypatch, seed, n, nq, F, span, wmax):
     for mo in (1, 7):
         assert g.count_set_overlaps(qc, qs, qe, mo).tolist() == o.count_set_overlaps(qc, qs, qe, mo, n_files=F).tolist()
         assert g.count_region_hits(qc, qs, qe, mo).tolist() == o.count_region_hits(qc, qs, qe, mo, n_files=F).tolist()
-    # and the per-query kernel gives the same vectors
+    # a shuffled batch is grouped by owner tile in one partition pass (no radix sort), binary counts with
+    # min_overlap == 1 go through the per-record pme_file instead of a list of credited files
+    _lib = ga._lib
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    exp_b = o.count_region_hits(qc, qs, qe, 1, n_files=F).tolist()
+    assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
+    names = set(_lib.prof_read())
+    _lib.lib.gtars_prof_enable(0)
+    assert "k_ms_scatter" in names and "k_radix_scatter" not in names, names
+    # ... and the alternatives agree: full radix sort of the batch, credited-file list, per-query kernel
+    monkeypatch.setenv("GTARS_IGD_FULL_SORT", "1")
+    assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
+    assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == o.count_set_overlaps(qc, qs, qe, 1, n_files=F).tolist()
+    monkeypatch.delenv("GTARS_IGD_FULL_SORT")
+    monkeypatch.setenv("GTARS_IGD_NO_PME", "1")
+    assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
+    monkeypatch.delenv("GTARS_IGD_NO_PME")
     monkeypatch.setenv("GTARS_NO_IGD_SWEEP", "1")
-    assert g.count_region_hits(qc, qs, qe, 1).tolist() == o.count_region_hits(qc, qs, qe, 1, n_files=F).tolist()
+    assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
 
 
 def test_igd_sweep_presorted_batch_skips_the_sort(ga, monkeypatch):
@@ -563,7 +580,8 @@ def test_igd_sweep_presorted_batch_skips_the_sort(ga, monkeypatch):
     assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
     names = set(_lib.prof_read())
     _lib.lib.gtars_prof_enable(0)
-    assert any(k.startswith("k_igd_sweep") for k in names) and "k_radix_scatter" not in names, names
+    # (k_radix_* may appear: the first binary count builds the database's pme_file with the radix sort)
+    assert any(k.startswith("k_igd_sweep") for k in names) and not names & {"k_ms_scatter", "k_gather2_u32"}, names
     monkeypatch.setenv("GTARS_IGD_ALWAYS_SORT", "1")
     assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == exp_p
     assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
