@@ -206,11 +206,12 @@ gtars_status launch_lola_contingency(const u64 *user_hits, const u64 *universe_h
 gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, u32 *new_counts,
                                          hipStream_t st);
 
-// K1 (sort.hip): one-pass partition of (a, b) pairs by a small key (< n_bins <= MS_MAX_BINS), not stable: bin_off[n_bins + 1]
-// receives the bin boundaries; elements whose key is `drop_bin` are left out (their bin must be the last one)
+// K1 (sort.hip): one-pass partition of (a, b) pairs by a small key (< n_bins <= MS_MAX_BINS), not stable: out_ab receives
+// the pairs interleaved, bin_off[n_bins + 1] the bin boundaries; elements whose key is `drop_bin` are left out (their bin
+// must be the last one)
 constexpr u32 MS_MAX_BINS = 36864;  // 144 KB of LDS counters
 size_t multisplit_ws_bytes(u32 n_bins);
-gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, u32 *out_a, u32 *out_b,
+gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
                               u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st);
 
 // K1 (sort.hip): permutation that orders rows by (chrom, k1, [k2], input order); device columns in/out

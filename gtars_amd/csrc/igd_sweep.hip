@@ -191,7 +191,7 @@ template <int MODE>
 __global__ void __launch_bounds__(SW_TPB)
 k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
             const u32 *__restrict__ tile_chrom, const i32 *__restrict__ tile_carry, u32 n_tiles,
-            const u32 *__restrict__ sqs, const u32 *__restrict__ sqe,
+            const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap,
             unsigned long long *__restrict__ hits) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
@@ -307,7 +307,16 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
         auto r_file = [&](u32 i) -> u32 { return i < n_lds ? t_f[i] : v.files[p0 + i]; };
         const u32 q_lo = ql[tile], q_hi = qh[tile];
         for (u32 qi = q_lo + threadIdx.x; qi < q_hi; qi += SW_TPB) {
-            const i32 s = (i32)sqs[qi], e = (i32)sqe[qi];
+            // (start, end) pairs as the partition leaves them, or two sorted columns
+            i32 s, e;
+            if (interleaved) {
+                const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
+                s = (i32)se2.x;
+                e = (i32)se2.y;
+            } else {
+                s = (i32)sqs[qi];
+                e = (i32)sqe[qi];
+            }
             u32 lo = 0, hi;
             if (min_overlap >= 1) {
                 // an overlap of >= 1 bp needs end > q_start: start at the first staged record whose prefix-max
@@ -649,10 +658,13 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         GT_HIP(hipStreamSynchronize(st));
     }
     const u32 *t_ql = ql, *t_qh = qh;
+    int interleaved = 0;
     if (h_unsorted && bucket) {
         // K1 (multisplit): (start, end) pairs grouped by owner tile; bin_off[t], bin_off[t + 1] bound tile t's queries
-        gtars_status s1 = multisplit_pairs(perm, ks, ke, nq, n_tiles + 1, n_tiles, ss, se, bin_off, scratch, scratch_bytes, st);
+        gtars_status s1 = multisplit_pairs(perm, ks, ke, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off, scratch,
+                                           scratch_bytes, st);  // ss and se are adjacent: 2 * nq words
         if (s1) return s1;
+        interleaved = 1;
         t_ql = bin_off;
         t_qh = bin_off + 1;
     } else {
@@ -684,7 +696,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     {
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.first, tl.cnt, tl.chrom, tl.carry, n_tiles, ss, se,
-                           t_ql, t_qh, min_overlap, (unsigned long long *)hits);
+                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;

@@ -183,8 +183,7 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off)
 
 __global__ void __launch_bounds__(MS_TPB)
 k_ms_scatter(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n, u32 n_bins, u32 chunk,
-             const u32 *__restrict__ table, const u32 *__restrict__ bin_off, u32 drop_bin, u32 *__restrict__ out_a,
-             u32 *__restrict__ out_b) {
+             const u32 *__restrict__ table, const u32 *__restrict__ bin_off, u32 drop_bin, uint2 *__restrict__ out_ab) {
     extern __shared__ u32 ms_bins[];
     const u32 *row = table + (size_t)blockIdx.x * n_bins;
     for (u32 k = threadIdx.x; k < n_bins; k += MS_TPB) ms_bins[k] = bin_off[k] + row[k];
@@ -207,10 +206,7 @@ k_ms_scatter(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *
         for (int j = 0; j < U; ++j) pos[j] = k[j] != drop_bin ? atomicAdd(&ms_bins[k[j]], 1u) : 0u;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            if (k[j] != drop_bin) {
-                out_a[pos[j]] = va[j];
-                out_b[pos[j]] = vb[j];
-            }
+            if (k[j] != drop_bin) out_ab[pos[j]] = make_uint2(va[j], vb[j]);  // one scattered 8-byte store per element
         }
     }
 }
@@ -222,7 +218,7 @@ static u32 ms_workgroups(u32 n) {
 }
 size_t multisplit_ws_bytes(u32 n_bins) { return ((size_t)256 * n_bins + n_bins + 64) * 4; }
 
-gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, u32 *out_a, u32 *out_b,
+gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
                               u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st) {
     if (n_bins == 0 || n_bins > MS_MAX_BINS) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
     if (ws_bytes < multisplit_ws_bytes(n_bins)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
@@ -254,7 +250,7 @@ gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n,
     {
         ProfScope p("k_ms_scatter", st);
         hipLaunchKernelGGL(k_ms_scatter, dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off, drop_bin,
-                           out_a, out_b);
+                           out_ab);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;
