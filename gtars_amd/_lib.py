@@ -76,6 +76,7 @@ _SIG = {
     "gtars_tokenize_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64, vp]),
     "gtars_fill_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, vp]),
     "gtars_tokenize": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
+    "gtars_tokenize_into": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64]),
     "gtars_count_overlaps_device": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, vp]),
     "gtars_count_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp]),
     "gtars_bits_count_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp]),

@@ -5,7 +5,11 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <numeric>
+#include <thread>
 #include <tuple>
 
 #include "common.h"
@@ -69,13 +73,54 @@ Workspace::~Workspace() {
 
 // One grow-only workspace per (host thread, device, stream, purpose): calls issued by one thread on DIFFERENT
 // streams may overlap on the device, so they must not share scratch memory; calls on the same stream are
-// ordered by the stream.
+// ordered by the stream.  The workspaces of a thread that exits go back to a process-wide pool (device memory
+// is never returned to the runtime from a thread-exit handler), from which new threads take theirs: a program
+// that keeps creating short-lived threads holds as many workspaces as it has threads alive, not as it ever had.
+namespace {
+struct WorkspacePool {
+    std::mutex mu;
+    std::vector<Workspace> idle;
+};
+WorkspacePool &workspace_pool() {
+    static WorkspacePool *p = new WorkspacePool();  // never destroyed: thread-exit handlers may run late
+    return *p;
+}
+struct TlsWorkspaces {
+    std::map<std::tuple<int, hipStream_t, int>, Workspace> ws;
+    ~TlsWorkspaces() {
+        WorkspacePool &pool = workspace_pool();
+        std::lock_guard<std::mutex> g(pool.mu);
+        for (auto &kv : ws)
+            if (kv.second.ptr) {
+                pool.idle.push_back(kv.second);
+                kv.second.ptr = nullptr;
+            }
+    }
+};
+}  // namespace
+
 Workspace &tls_workspace(int slot, hipStream_t stream) {
     // the default stream (NULL) exists on every device: the current device is part of the key
-    static thread_local std::map<std::tuple<int, hipStream_t, int>, Workspace> ws;
+    static thread_local TlsWorkspaces tls;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    return ws[std::make_tuple(dev, stream, slot)];
+    const auto key = std::make_tuple(dev, stream, slot);
+    auto it = tls.ws.find(key);
+    if (it != tls.ws.end()) return it->second;
+    Workspace w;
+    {
+        WorkspacePool &pool = workspace_pool();
+        std::lock_guard<std::mutex> g(pool.mu);
+        for (size_t i = 0; i < pool.idle.size(); ++i)
+            if (pool.idle[i].device == dev) {
+                w = pool.idle[i];
+                w.ep = ScanEpoch();  // whoever used it last may have left anything in it
+                pool.idle[i] = pool.idle.back();
+                pool.idle.pop_back();
+                break;
+            }
+    }
+    return tls.ws.emplace(key, w).first->second;
 }
 
 // ---------------------------------------------------------------- profiling
@@ -922,7 +967,244 @@ static gtars_status enumerate_to_host(const gtars_index_t *ix, const u32 *qc, co
     return GTARS_OK;
 }
 
+// ---------------------------------------------------------------- host pipeline
+// The host-pointer tokenizer as a stream: per calling thread (and device) one set of device buffers, two streams and a
+// helper thread, all kept across calls.  A batch is cut into chunks; the calling thread copies chunk k+1 to the device
+// while the kernel of chunk k runs and the helper thread copies the results of chunk k-1 back (copies from and to
+// pageable memory block the thread that issues them, hence two threads for the two directions of the link).
+// Chunks chain on the device: chunk k starts its offsets at the running total chunk k-1 left in d_chain[k].
+namespace {
+class HelperThread {
+public:
+    ~HelperThread() { stop(); }
+    void post(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!started_) {
+                started_ = true;
+                th_ = std::thread([this] { run(); });
+            }
+            jobs_.push_back(std::move(job));
+            ++pending_;
+        }
+        cv_.notify_one();
+    }
+    void wait_idle() {
+        std::unique_lock<std::mutex> g(mu_);
+        idle_.wait(g, [this] { return pending_ == 0; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!started_ || quit_) return;
+            quit_ = true;
+        }
+        cv_.notify_one();
+        if (th_.joinable()) th_.join();
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return quit_ || !jobs_.empty(); });
+                if (jobs_.empty()) return;
+                job = std::move(jobs_.front());
+                jobs_.pop_front();
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                --pending_;
+            }
+            idle_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, idle_;
+    std::deque<std::function<void()>> jobs_;
+    std::thread th_;
+    size_t pending_ = 0;
+    bool started_ = false, quit_ = false;
+};
+
+constexpr int PIPE_MAX_CHUNKS = 16;
+struct HostPipe {
+    int device = -1;
+    void *d_buf = nullptr;
+    size_t d_bytes = 0;
+    hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[PIPE_MAX_CHUNKS] = {}, ev_done[PIPE_MAX_CHUNKS] = {};
+    u64 *d_chain = nullptr;  // [PIPE_MAX_CHUNKS + 1] running totals
+    u64 *h_chain = nullptr;  // pinned mirror
+    HelperThread helper;
+    gtars_status init() {
+        int dev = 0;
+        GT_HIP(hipGetDevice(&dev));
+        if (device == dev) return GTARS_OK;
+        if (device != -1) return fail(GTARS_ERR_INTERNAL, "host pipeline: the calling thread changed its device");
+        GT_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+        GT_HIP(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
+        GT_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+        for (int k = 0; k < PIPE_MAX_CHUNKS; ++k) {
+            GT_HIP(hipEventCreateWithFlags(&ev_in[k], hipEventDisableTiming));
+            GT_HIP(hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming));
+        }
+        GT_HIP(hipMalloc((void **)&d_chain, sizeof(u64) * (PIPE_MAX_CHUNKS + 1)));
+        GT_HIP(hipHostMalloc((void **)&h_chain, sizeof(u64) * (PIPE_MAX_CHUNKS + 1), hipHostMallocDefault));
+        device = dev;
+        return GTARS_OK;
+    }
+    gtars_status reserve(size_t need) {
+        if (d_bytes >= need) return GTARS_OK;
+        if (d_buf) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(d_buf);
+            d_buf = nullptr;
+            d_bytes = 0;
+        }
+        const size_t want = (need + (need >> 2) + (1 << 20)) & ~(size_t)((1 << 20) - 1);
+        GT_HIP(hipMalloc(&d_buf, want));
+        d_bytes = want;
+        return GTARS_OK;
+    }
+};
+HostPipe &tls_host_pipe() {
+    static thread_local HostPipe p;  // device buffers stay until process exit (see Workspace)
+    return p;
+}
+}  // namespace
+
+// offsets[nq + 1] and up to ids_capacity ids into caller memory; *out_n = hits.  ids may be null (offsets only).
+static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, u64 *offsets,
+                                      u32 *ids, u64 ids_capacity, u64 *out_n) {
+    HostPipe &hp = tls_host_pipe();
+    gtars_status st = hp.init();
+    if (st) return st;
+    if (nq == 0) {
+        if (offsets) offsets[0] = 0;
+        *out_n = 0;
+        return GTARS_OK;
+    }
+    // chunks: multiples of the kernel's tile, at least 256k queries each; chained launches need the LDS kernel
+    const bool chain = use_lds_path(ix);
+    int n_chunks = 1;
+    // (a chunk costs ~25 us of fixed copy / launch / hand-over overhead per direction: 1M queries in one chunk 512 us,
+    // in 2 / 4 / 8 chunks 564 / 745 / 1231 us -- chunks pay from ~4M queries each)
+    if (chain) n_chunks = (int)std::min<u64>(PIPE_MAX_CHUNKS, std::max<u64>(1, nq / (4u << 20)));
+    if (const char *e = getenv("GTARS_PIPE_CHUNKS")) n_chunks = std::max(1, std::min(chain ? PIPE_MAX_CHUNKS : 1, atoi(e)));
+    const u64 chunk = ((nq + n_chunks - 1) / n_chunks + 4095) / 4096 * 4096;
+    n_chunks = (int)((nq + chunk - 1) / chunk);
+    // device layout: qc | qs | qe | offsets | ids (capacity: what the caller can take, at least a typical batch's hits)
+    const u64 cap_dev = ids ? std::max<u64>(ids_capacity, 1) : 0;
+    const size_t qpad = ((size_t)nq * 4 + 255) & ~(size_t)255;
+    const size_t opad = ((size_t)(nq + 1) * 8 + 255) & ~(size_t)255;
+    st = hp.reserve(3 * qpad + opad + (size_t)cap_dev * 4 + 256);
+    if (st) return st;
+    u32 *d_qc = (u32 *)hp.d_buf, *d_qs = (u32 *)((char *)hp.d_buf + qpad), *d_qe = (u32 *)((char *)hp.d_buf + 2 * qpad);
+    u64 *d_off = (u64 *)((char *)hp.d_buf + 3 * qpad);
+    u32 *d_ids = ids ? (u32 *)((char *)hp.d_buf + 3 * qpad + opad) : nullptr;
+    Workspace &ws = tls_workspace(0, hp.s_comp);
+    st = ws.reserve(fused_ws_bytes(ix, chunk));
+    if (st) return st;
+    if (n_chunks == 1) {
+        // one chunk: everything in order on one stream from the calling thread; the batch's total is the last offset
+        GT_HIP(hipMemcpyAsync(d_qc, qc, nq * 4, hipMemcpyHostToDevice, hp.s_comp));
+        GT_HIP(hipMemcpyAsync(d_qs, qs, nq * 4, hipMemcpyHostToDevice, hp.s_comp));
+        GT_HIP(hipMemcpyAsync(d_qe, qe, nq * 4, hipMemcpyHostToDevice, hp.s_comp));
+        EnumOut out{d_off, d_ids, nullptr, nullptr, cap_dev};
+        st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp);
+        if (st) {
+            ws.ep = ScanEpoch();
+            return st;
+        }
+        u64 total = 0;
+        if (offsets) {
+            GT_HIP(hipMemcpyAsync(offsets, d_off, (nq + 1) * 8, hipMemcpyDeviceToHost, hp.s_comp));
+            GT_HIP(hipStreamSynchronize(hp.s_comp));
+            total = offsets[nq];
+        } else {
+            GT_HIP(hipMemcpyAsync(&total, d_off + nq, 8, hipMemcpyDeviceToHost, hp.s_comp));
+            GT_HIP(hipStreamSynchronize(hp.s_comp));
+        }
+        *out_n = total;
+        if (ids && total) {
+            GT_HIP(hipMemcpyAsync(ids, d_ids, std::min<u64>(total, ids_capacity) * 4, hipMemcpyDeviceToHost, hp.s_comp));
+            GT_HIP(hipStreamSynchronize(hp.s_comp));
+        }
+        if (ids && total > ids_capacity) return fail(GTARS_ERR_CAPACITY, "ids buffer too small: need " + std::to_string(total));
+        return GTARS_OK;
+    }
+    GT_HIP(hipMemsetAsync(hp.d_chain, 0, sizeof(u64), hp.s_comp));
+    hp.h_chain[0] = 0;
+    gtars_status job_status[PIPE_MAX_CHUNKS];
+    for (int k = 0; k < n_chunks; ++k) job_status[k] = GTARS_OK;
+    for (int k = 0; k < n_chunks; ++k) {
+        const u64 q0 = (u64)k * chunk, n_k = std::min<u64>(chunk, nq - q0);
+        GT_HIP(hipMemcpyAsync(d_qc + q0, qc + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in));
+        GT_HIP(hipMemcpyAsync(d_qs + q0, qs + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in));
+        GT_HIP(hipMemcpyAsync(d_qe + q0, qe + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in));
+        GT_HIP(hipEventRecord(hp.ev_in[k], hp.s_in));
+        GT_HIP(hipStreamWaitEvent(hp.s_comp, hp.ev_in[k], 0));
+        EnumOut out{d_off + q0, d_ids, nullptr, nullptr, cap_dev};
+        if (chain)
+            st = launch_tokenize_lds(ix->accel(), d_qc + q0, d_qs + q0, d_qe + q0, n_k, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp,
+                                     hp.d_chain + k, hp.d_chain + k + 1);
+        else
+            st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp);
+        if (st) break;
+        if (chain)
+            GT_HIP(hipMemcpyAsync(hp.h_chain + k + 1, hp.d_chain + k + 1, sizeof(u64), hipMemcpyDeviceToHost, hp.s_comp));
+        else
+            GT_HIP(hipMemcpyAsync(hp.h_chain + 1, &((ScanHead *)ws.ptr)->total, sizeof(u64), hipMemcpyDeviceToHost, hp.s_comp));
+        GT_HIP(hipEventRecord(hp.ev_done[k], hp.s_comp));
+        const bool last = k + 1 == n_chunks;
+        const int dev = hp.device;
+        HostPipe *php = &hp;
+        gtars_status *js = &job_status[k];
+        hp.helper.post([=]() {
+            // results of chunk k: its offsets (the batch's last offset comes with the last chunk) and its ids
+            if (hipSetDevice(dev) != hipSuccess || hipEventSynchronize(php->ev_done[k]) != hipSuccess) {
+                *js = GTARS_ERR_HIP;
+                return;
+            }
+            const u64 lo = php->h_chain[k], hi = php->h_chain[k + 1];
+            hipError_t e = hipSuccess;
+            if (offsets) e = hipMemcpyAsync(offsets + q0, d_off + q0, (n_k + (last ? 1 : 0)) * 8, hipMemcpyDeviceToHost, php->s_out);
+            if (e == hipSuccess && ids && hi > lo && lo < ids_capacity)
+                e = hipMemcpyAsync(ids + lo, d_ids + lo, (std::min<u64>(hi, ids_capacity) - lo) * 4, hipMemcpyDeviceToHost, php->s_out);
+            if (e == hipSuccess) e = hipStreamSynchronize(php->s_out);
+            if (e != hipSuccess) *js = GTARS_ERR_HIP;
+        });
+    }
+    hp.helper.wait_idle();
+    if (st) {
+        (void)hipStreamSynchronize(hp.s_comp);
+        ws.ep = ScanEpoch();
+        return st;
+    }
+    for (int k = 0; k < n_chunks; ++k)
+        if (job_status[k]) return fail(GTARS_ERR_HIP, "host pipeline: device-to-host copy failed");
+    const u64 total = hp.h_chain[chain ? n_chunks : 1];
+    *out_n = total;
+    if (ids && total > ids_capacity) return fail(GTARS_ERR_CAPACITY, "ids buffer too small: need " + std::to_string(total));
+    return GTARS_OK;
+}
+
 extern "C" {
+
+gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+                                 uint64_t nq, uint64_t *offsets, uint32_t *ids, uint64_t ids_capacity, uint64_t *out_n) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (!offsets || !out_n || (ids_capacity && !ids)) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
+    *out_n = 0;
+    st = require_device();
+    if (st) return st;
+    return tokenize_pipeline(ix, qc, qs, qe, nq, offsets, ids_capacity ? ids : nullptr, ids_capacity, out_n);
+}
 
 gtars_status gtars_tokenize(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
                             const uint32_t *qe, uint64_t nq, uint64_t *offsets, uint32_t **out_ids,
@@ -932,35 +1214,31 @@ gtars_status gtars_tokenize(const gtars_index_t *ix, const uint32_t *qc, const u
     if (!out_ids || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
     *out_ids = nullptr;
     *out_n = 0;
-    // single fused pass with a guessed capacity; second pass only on overflow
     st = require_device();
     if (st) return st;
-    DevQueries q;
-    st = q.upload(qc, qs, qe, nq);
-    if (st) return st;
-    ScopedDev d_off, d_ids;
-    st = d_off.alloc((nq + 1) * 8);
-    if (st) return st;
-    u64 cap = nq * 2 + 1024;
-    st = d_ids.alloc(cap * 4);
-    if (st) return st;
-    u64 total = 0;
-    st = gtars_tokenize_device(ix, q.c, q.s, q.e, nq, d_off.as<u64>(), d_ids.as<u32>(), cap, &total, nullptr);
+    // the streaming pipeline with a guessed capacity; a second (ids only) pass on overflow
+    u64 cap = nq * 2 + 1024, total = 0;
+    u32 *ids = host_alloc<u32>(cap);
+    if (!ids) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    std::vector<u64> tmp_off;
+    u64 *off = offsets;
+    if (!off) {
+        tmp_off.resize(nq + 1);
+        off = tmp_off.data();
+    }
+    st = tokenize_pipeline(ix, qc, qs, qe, nq, off, ids, cap, &total);
     if (st == GTARS_ERR_CAPACITY) {
-        ScopedDev big;
-        st = big.alloc(total * 4);
-        if (st) return st;
-        st = gtars_fill_device(ix, q.c, q.s, q.e, nq, d_off.as<u64>(), big.as<u32>(), nullptr);
-        if (st) return st;
-        GT_HIP(hipDeviceSynchronize());
-        std::swap(d_ids.p, big.p);
-    } else if (st) {
+        free(ids);
+        cap = total;
+        ids = host_alloc<u32>(cap);
+        if (!ids) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+        st = tokenize_pipeline(ix, qc, qs, qe, nq, off, ids, cap, &total);
+    }
+    if (st) {
+        free(ids);
         return st;
     }
-    if (offsets) GT_HIP(hipMemcpy(offsets, d_off.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
-    *out_ids = host_alloc<u32>(total);
-    if (!*out_ids) return fail(GTARS_ERR_INTERNAL, "out of host memory");
-    if (total) GT_HIP(hipMemcpy(*out_ids, d_ids.p, total * 4, hipMemcpyDeviceToHost));
+    *out_ids = ids;
     *out_n = total;
     return GTARS_OK;
 }

@@ -171,9 +171,12 @@ gtars_status launch_enumerate_fused(const IndexView &v, int kind, const u32 *qc,
 size_t enumerate_fused_ws_bytes(u64 nq);
 
 // LDS-tiled fused tokenizer (tokenize_lds.hip), Bits order only
+// d_base (may be null): device word holding what precedes this launch's first offset (chained launches of one batch);
+// d_total_out (may be null): receives base + this launch's hits
 gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  int has_min, i32 min_overlap, const EnumOut &out, void *scan_ws,
-                                 size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st);
+                                 size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st, const u64 *d_base = nullptr,
+                                 u64 *d_total_out = nullptr);
 size_t tokenize_lds_ws_bytes(u64 nq);
 bool tokenize_lds_supported(const AccelView &a);
 

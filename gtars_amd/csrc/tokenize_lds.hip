@@ -414,9 +414,9 @@ __device__ __forceinline__ u64 help_count_tile(const AccelView &a, const SearchL
 // predecessor granules per round trip; help(t) returns tile t's hit count.  Publishes the inclusive prefix.
 template <class Help>
 __device__ __forceinline__ u64 resolve_prefix_helping(u64 *state, u32 tile, u64 agg, int lane, u32 epoch, u32 spin_limit,
-                                                      Help &&help) {
+                                                      u64 base, Help &&help) {
     const u64 ep = (u64)epoch << EP_SHIFT;
-    u64 excl = 0;
+    u64 excl = tile == 0 ? base : 0ull;  // `base`: what precedes tile 0 (chained launches); later tiles get it through tile 0's prefix
     i64 pred = (i64)tile - 1;
     u32 spins = 0;
     while (pred >= 0) {
@@ -434,7 +434,7 @@ __device__ __forceinline__ u64 resolve_prefix_helping(u64 *state, u32 tile, u64 
         if (b_inv & need) {
             if (++spins > spin_limit) {
                 const i64 t = pred - (__ffsll((long long)(b_inv & need)) - 1);  // nearest unpublished predecessor
-                const u64 h = help((u32)t);
+                const u64 h = help((u32)t) + (t == 0 ? base : 0ull);
                 if (lane == 0) st_state(&state[t], (t == 0 ? ST_INC : ST_AGG) | ep | h);
                 spins = 0;
             } else {
@@ -454,7 +454,8 @@ template <int TPB, int QPT, bool FILTER, bool IMPL>
 __global__ void __launch_bounds__(TPB, TPB / 256)
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
-          u32 epoch, u32 ticket_base, u32 stage_cap, u32 spin_limit) {
+          u32 epoch, u32 ticket_base, u32 stage_cap, u32 spin_limit, const u64 *__restrict__ d_base,
+          u64 *__restrict__ d_total_out) {
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
     __shared__ u32 s_tile;
     __shared__ u64 s_prefix;
@@ -469,6 +470,10 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     const bool off_vec_ok = (((uintptr_t)offsets) & 15u) == 0;
     const SearchLds L = search_lds_view(a, smem);
     u32 *stage = smem + tok_lds_bytes(a) / 4 + (size_t)wave * stage_cap;
+    // Chained launches (the host pipeline feeds a batch in chunks): every offset of this launch starts at *d_base, the
+    // running hit count of the chunks before.  It enters through tile 0 -- its inclusive prefix carries the base, and
+    // with it every later look-back sum.
+    const u64 base = d_base ? *d_base : 0ull;
 
     u32 c[QPT], s[QPT], e[QPT];
     // the first tile's queries come from HBM: issue their loads before the LDS fill so that both overlap
@@ -510,16 +515,17 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             cur.q.wtotal = __builtin_amdgcn_readlane(v, wave);
             cur.q.excl = inc - tsum;
             cur.tile = tile;
-            if (threadIdx.x == 0) publish_aggregate(ws->state, tile, (u64)cur.total, epoch);
+            if (threadIdx.x == 0) publish_aggregate(ws->state, tile, (u64)cur.total + (tile == 0 ? base : 0ull), epoch);
         }
         // resolve + write the PREVIOUS tile
         if (have_prev && wave == 0) {
-            const u64 excl = resolve_prefix_helping(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, help);
+            const u64 excl = resolve_prefix_helping(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help);
             if (lane == 0) {
                 s_prefix = excl;
                 if (prev.tile == num_tiles - 1) {
                     offsets[nq] = excl + (u64)prev.total;
                     ws->total = excl + (u64)prev.total;
+                    if (d_total_out) *d_total_out = excl + (u64)prev.total;
                 }
             }
         }
@@ -697,7 +703,8 @@ static u32 stage_words(const AccelView &a, int tpb, int per_cu) {
 
 template <int TPB, int QPT, bool FILTER, bool IMPL>
 static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
-                                 i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, hipStream_t st) {
+                                 i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, const u64 *d_base, u64 *d_total_out,
+                                 hipStream_t st) {
     static KernelSetup setup;
     int dev = 0, cus = 256;
     gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, FILTER, IMPL>), dev, cus);
@@ -712,7 +719,7 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     if (grid > tiles) grid = tiles;
     const u64 cap = out.vals ? out.capacity : 0;
     hipLaunchKernelGGL((k_tok_lds<TPB, QPT, FILTER, IMPL>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
-                       min_bp, out.offsets, out.vals, cap, ws, ep.epoch, ep.ticket_base, stage, spin_limit);
+                       min_bp, out.offsets, out.vals, cap, ws, ep.epoch, ep.ticket_base, stage, spin_limit, d_base, d_total_out);
     GT_HIP(hipGetLastError());
     // tickets drawn by this launch: one per tile beyond the first `grid`, plus one failing draw per workgroup
     if (tiles > grid) ep.ticket_base += (u32)tiles;
@@ -721,11 +728,18 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
 
 gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  int has_min, i32 min_overlap, const EnumOut &out, void *scan_ws,
-                                 size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st) {
+                                 size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st, const u64 *d_base, u64 *d_total_out) {
     if (out.starts || out.ends) return fail(GTARS_ERR_INTERNAL, "the LDS tokenizer writes vals only");
     if (nq == 0) {
-        GT_HIP(hipMemsetAsync(out.offsets, 0, sizeof(u64), st));
-        GT_HIP(hipMemsetAsync(&((ScanHead *)scan_ws)->total, 0, sizeof(u64), st));
+        if (d_base) {
+            GT_HIP(hipMemcpyAsync(out.offsets, d_base, sizeof(u64), hipMemcpyDeviceToDevice, st));
+            GT_HIP(hipMemcpyAsync(&((ScanHead *)scan_ws)->total, d_base, sizeof(u64), hipMemcpyDeviceToDevice, st));
+            if (d_total_out) GT_HIP(hipMemcpyAsync(d_total_out, d_base, sizeof(u64), hipMemcpyDeviceToDevice, st));
+        } else {
+            GT_HIP(hipMemsetAsync(out.offsets, 0, sizeof(u64), st));
+            GT_HIP(hipMemsetAsync(&((ScanHead *)scan_ws)->total, 0, sizeof(u64), st));
+            if (d_total_out) GT_HIP(hipMemsetAsync(d_total_out, 0, sizeof(u64), st));
+        }
         return GTARS_OK;
     }
     constexpr int TPB = 1024;
@@ -752,10 +766,10 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     ProfScope p("k_tok_lds", st);
 #define GT_TOK_CASE(Q)                                                                                         \
     if (qpt == Q) {                                                                                            \
-        if (impl) return filter ? launch_tok_t<TPB, Q, true, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st)     \
-                                : launch_tok_t<TPB, Q, false, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st);   \
-        return filter ? launch_tok_t<TPB, Q, true, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st)              \
-                      : launch_tok_t<TPB, Q, false, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, st);            \
+        if (impl) return filter ? launch_tok_t<TPB, Q, true, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)     \
+                                : launch_tok_t<TPB, Q, false, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);   \
+        return filter ? launch_tok_t<TPB, Q, true, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)              \
+                      : launch_tok_t<TPB, Q, false, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);            \
     }
     GT_TOK_CASE(4)
     GT_TOK_CASE(2)

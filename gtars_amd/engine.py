@@ -78,14 +78,31 @@ class OverlapIndex:
         return [int(x) for x in out]
 
     # -- host-array queries ----------------------------------------------------
-    def tokenize(self, qc, qs, qe) -> Tuple[np.ndarray, np.ndarray]:
-        """-> (offsets u64[nq+1], ids u32[H]) in reference order; no batch-level unk."""
+    def tokenize(self, qc, qs, qe, out: Optional[Tuple[np.ndarray, np.ndarray]] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (offsets u64[nq+1], ids u32[H]) in reference order; no batch-level unk.
+
+        ``out=(offsets, ids)``: caller-provided uint64[>= nq+1] / uint32 arrays that are REUSED across calls (the
+        streaming form, ``gtars_tokenize_into``: nothing is allocated, freshly mapped pages never have to be
+        faulted in during the device-to-host copy); the returned arrays are views of them.  When ``ids`` is too
+        small a larger array is allocated for this call."""
         qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
         nq = len(qc)
-        offsets = np.zeros(nq + 1, dtype=np.uint64)
-        p, n = C.c_void_p(), C.c_uint64()
-        check(lib.gtars_tokenize(self._h, ptr(qc), ptr(qs), ptr(qe), nq, ptr(offsets), C.byref(p), C.byref(n)))
-        return offsets, take_u32(p, n.value)
+        if out is None:
+            offsets = np.empty(nq + 1, dtype=np.uint64)
+            p, n = C.c_void_p(), C.c_uint64()
+            check(lib.gtars_tokenize(self._h, ptr(qc), ptr(qs), ptr(qe), nq, ptr(offsets), C.byref(p), C.byref(n)))
+            return offsets, take_u32(p, n.value)
+        offsets, ids = out
+        if offsets.dtype != np.uint64 or ids.dtype != np.uint32 or len(offsets) < nq + 1 or not (
+                offsets.flags.c_contiguous and ids.flags.c_contiguous):
+            raise ValueError("out must be (uint64[>= nq+1], uint32[...]) C-contiguous arrays")
+        n = C.c_uint64()
+        rc = lib.gtars_tokenize_into(self._h, ptr(qc), ptr(qs), ptr(qe), nq, ptr(offsets), ptr(ids), len(ids), C.byref(n))
+        if rc == _lib.ERR_CAPACITY:
+            ids = np.empty(int(n.value), dtype=np.uint32)
+            rc = lib.gtars_tokenize_into(self._h, ptr(qc), ptr(qs), ptr(qe), nq, ptr(offsets), ptr(ids), len(ids), C.byref(n))
+        check(rc)
+        return offsets[: nq + 1], ids[: int(n.value)]
 
     def count_overlaps(self, qc, qs, qe, min_overlap: Optional[int] = None) -> np.ndarray:
         qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)

@@ -131,6 +131,17 @@ gtars_status gtars_tokenize(const gtars_index_t *ix, const uint32_t *qchrom,
                             const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
                             uint64_t *offsets, uint32_t **out_ids, uint64_t *out_n);
 
+/* Host pointers, caller-provided outputs: offsets[nq + 1], ids[ids_capacity].  The streaming form of
+ * gtars_tokenize: device buffers and streams are cached per calling thread, the batch is fed in chunks
+ * (host-to-device copy of chunk k+1 || kernel of chunk k || device-to-host copy of chunk k-1), nothing is
+ * allocated on the way.  *out_n = number of ids; GTARS_ERR_CAPACITY (with *out_n set, offsets complete)
+ * when ids_capacity is too small.  Reuse the output buffers across calls: freshly mapped pages cost more
+ * than the transfer. */
+gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qchrom,
+                                 const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
+                                 uint64_t *offsets, uint32_t *ids, uint64_t ids_capacity,
+                                 uint64_t *out_n);
+
 /* ------------------------------------------------------------------------
  * Counts / any / find with the optional min-overlap filter.
  * Replaces MultiChromOverlapper::count_overlaps / any_overlaps /

@@ -555,3 +555,63 @@ def test_bench_tools_run_with_two_ranks_on_one_gpu():
     assert i2["n_gpus"] == 2 and i2["local_db_intervals"] < i1["local_db_intervals"]
     l1, l2 = run("lola_bench.py", 1), run("lola_bench.py", 2)
     assert l1["identities_hold"] and l2["identities_hold"] and l1["support_sum"] == l2["support_sum"]
+
+
+# ------------------------------------------------------------ the host pipeline (gtars_tokenize_into)
+
+
+def test_tokenize_into_streaming_pipeline_matches_oracle(monkeypatch):
+    """gtars_tokenize_into: chunked H2D / kernel / D2H pipeline with chained launches (every chunk starts its offsets at
+    the running total of the chunks before).  Bit-exact offsets and ids for 1..16 chunks, reused output buffers, a too
+    small ids buffer, an AIList-order index (generic kernel: one chunk) and calls from several host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import gtars_amd
+    from gtars_amd import synth
+
+    u = synth.make_universe(40_000)
+    q = synth.make_queries(u, 1_300_001)
+    ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    ref = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM)
+    off_o, ids_o = ref.tokenize(q["chrom"], q["start"], q["end"])
+    out = (np.empty(len(q["chrom"]) + 1, dtype=np.uint64), np.empty(len(ids_o) + 100, dtype=np.uint32))
+    for chunks in ("", "1", "3", "16"):
+        if chunks:
+            monkeypatch.setenv("GTARS_PIPE_CHUNKS", chunks)
+        out[0][:] = 0xFFFFFFFF
+        out[1][:] = 0xFFFFFFFF
+        off, ids = ix.tokenize(q["chrom"], q["start"], q["end"], out=out)
+        assert np.array_equal(off, off_o) and np.array_equal(ids, ids_o), chunks
+        assert ids.base is out[1] or ids is out[1]  # a view of the caller's buffer
+    monkeypatch.delenv("GTARS_PIPE_CHUNKS")
+    # ids buffer too small: the binding retries with the size the library reports; a prefix of the batch needs less
+    small = (out[0], np.empty(10, dtype=np.uint32))
+    off, ids = ix.tokenize(q["chrom"], q["start"], q["end"], out=small)
+    assert np.array_equal(off, off_o) and np.array_equal(ids, ids_o)
+    n = 70_000
+    off_p, ids_p = ref.tokenize(q["chrom"][:n], q["start"][:n], q["end"][:n])
+    off, ids = ix.tokenize(q["chrom"][:n], q["start"][:n], q["end"][:n], out=out)
+    assert np.array_equal(off, off_p) and np.array_equal(ids, ids_p)
+    off, ids = ix.tokenize(q["chrom"][:0], q["start"][:0], q["end"][:0], out=out)
+    assert off.tolist() == [0] and len(ids) == 0
+    # the allocating form runs on the same pipeline
+    off, ids = ix.tokenize(q["chrom"], q["start"], q["end"])
+    assert np.array_equal(off, off_o) and np.array_equal(ids, ids_o)
+    # AIList order: generic kernel, single chunk
+    ia = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM, kind=oracle.KIND_AILIST)
+    ra = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM, kind=oracle.KIND_AILIST)
+    off_a, ids_a = ra.tokenize(q["chrom"][:n], q["start"][:n], q["end"][:n])
+    off, ids = ia.tokenize(q["chrom"][:n], q["start"][:n], q["end"][:n], out=out)
+    assert np.array_equal(off, off_a) and np.array_equal(ids, ids_a)
+
+    # every host thread has its own pipeline (device buffers, streams, helper thread)
+    def work(t):
+        lo = t * 100_000
+        sl = slice(lo, lo + 300_000)
+        mine = (np.empty(300_001, dtype=np.uint64), np.empty(400_000, dtype=np.uint32))
+        o1, i1 = ix.tokenize(q["chrom"][sl], q["start"][sl], q["end"][sl], out=mine)
+        o2, i2 = ref.tokenize(q["chrom"][sl], q["start"][sl], q["end"][sl])
+        return bool(np.array_equal(o1, o2) and np.array_equal(i1, i2))
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        assert all(ex.map(work, range(8)))
