@@ -546,7 +546,15 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
     // kernels anyway: more units than the LDS budget holds even at the coarsest unit size (thousands of
     // non-empty contigs: every one needs at least one unit), or more blocks than a query's state word
     // addresses.  Decided BEFORE anything is allocated: padded block counts are computed in 64 bits.
-    bool build_accel = kind == GTARS_KIND_BITS && n > 0;
+    // AIList kind: a chromosome with ONE sub-list is its intervals in start order with max_ends as prefix maximum --
+    // exactly what the blocked structure is built over; AIList::find then yields the same hits in DESCENDING stored
+    // order (ailist.rs:238-263), which the LDS kernel emits by reversing each query's hits.  Indexes with a second
+    // sub-list anywhere (intervals that contain >= 10 of their next 20 neighbours, ailist.rs:198-223) keep the generic kernel.
+    bool single_sublist = kind == GTARS_KIND_AILIST;
+    if (kind == GTARS_KIND_AILIST)
+        for (u32 c = 0; c < n_chrom; ++c)
+            if (ix->h_chrom_sub[c + 1] - ix->h_chrom_sub[c] > 2) single_sublist = false;  // boundaries incl. terminator
+    bool build_accel = (kind == GTARS_KIND_BITS || single_sublist) && n > 0;
     u32 shift = 0;
     if (build_accel) {
         // LDS budget of the tokenizer kernels: one 1024-thread workgroup per CU with its copy of the unit keys
@@ -789,7 +797,8 @@ static size_t fused_ws_bytes(const gtars_index *ix, u64 nq) {
 }
 static bool use_lds_path(const gtars_index *ix) {
     static const bool disabled = getenv("GTARS_NO_LDS_PATH") != nullptr;
-    return !disabled && ix->kind == GTARS_KIND_BITS && ix->has_accel && tokenize_lds_supported(ix->accel());
+    // has_accel: a Bits-kind index, or an AIList-kind one whose chromosomes all have a single sub-list
+    return !disabled && ix->has_accel && tokenize_lds_supported(ix->accel());
 }
 
 // K2 dispatch: Bits-kind indexes with the blocked structure count through k_count_lds, everything else
@@ -803,7 +812,8 @@ static gtars_status run_fused(const gtars_index *ix, const u32 *qc, const u32 *q
                               int has_min, i32 min_overlap, const EnumOut &out, void *ws, size_t ws_bytes,
                               ScanEpoch &ep, hipStream_t s) {
     if (use_lds_path(ix) && !out.starts && !out.ends)
-        return launch_tokenize_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s);
+        return launch_tokenize_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s, nullptr, nullptr,
+                                   ix->kind == GTARS_KIND_AILIST);
     ep = ScanEpoch();  // the generic kernel clears the workspace itself
     return launch_enumerate_fused(ix->view(), ix->kind, qc, qs, qe, nq, has_min, min_overlap, out, ws,
                                   ws_bytes, s);
@@ -1151,7 +1161,7 @@ static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, co
         EnumOut out{d_off + q0, d_ids, nullptr, nullptr, cap_dev};
         if (chain)
             st = launch_tokenize_lds(ix->accel(), d_qc + q0, d_qs + q0, d_qe + q0, n_k, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp,
-                                     hp.d_chain + k, hp.d_chain + k + 1);
+                                     hp.d_chain + k, hp.d_chain + k + 1, ix->kind == GTARS_KIND_AILIST);
         else
             st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp);
         if (st) break;

@@ -172,11 +172,12 @@ size_t enumerate_fused_ws_bytes(u64 nq);
 
 // LDS-tiled fused tokenizer (tokenize_lds.hip), Bits order only
 // d_base (may be null): device word holding what precedes this launch's first offset (chained launches of one batch);
-// d_total_out (may be null): receives base + this launch's hits
+// d_total_out (may be null): receives base + this launch's hits; reverse: every query's hits in descending stored
+// order (AIList::find order of a single-sub-list index)
 gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  int has_min, i32 min_overlap, const EnumOut &out, void *scan_ws,
                                  size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st, const u64 *d_base = nullptr,
-                                 u64 *d_total_out = nullptr);
+                                 u64 *d_total_out = nullptr, bool reverse = false);
 size_t tokenize_lds_ws_bytes(u64 nq);
 bool tokenize_lds_supported(const AccelView &a);
 

@@ -257,7 +257,8 @@ __device__ __forceinline__ void load_queries(const u32 *__restrict__ qc, const u
 }
 
 // count phase of QPT consecutive queries of one lane: search, record burst, hit masks.  Returns the lane's hits.
-template <int QPT, bool FILTER, bool IMPL>
+// REV: the ids kept for the write phase are those of the LAST two hits (they are emitted first)
+template <int QPT, bool FILTER, bool IMPL, bool REV>
 __device__ __forceinline__ u32 count_queries(const AccelView &a, const SearchLds &L, const u32 (&c)[QPT], const u32 (&s)[QPT],
                                              const u32 (&e)[QPT], i32 min_bp, TileQ<QPT, IMPL> &t) {
     constexpr u32 STRIDE = IMPL ? 2 : 4;
@@ -289,9 +290,15 @@ __device__ __forceinline__ u32 count_queries(const AccelView &a, const SearchLds
         if constexpr (IMPL) {
             t.aux[j] = (u32)ACC_OWN * b0[j] + L.idc[act[j] ? c[j] : 0u];
         } else {
-            t.aux[2 * j] = (m & 1u) ? V[j].x : (m & 2u) ? V[j].y : (m & 4u) ? V[j].z : V[j].w;
-            const u32 m2 = m & (m - 1u);
-            t.aux[2 * j + 1] = (m2 & 2u) ? V[j].y : (m2 & 4u) ? V[j].z : V[j].w;
+            if (REV) {
+                t.aux[2 * j] = (m & 8u) ? V[j].w : (m & 4u) ? V[j].z : (m & 2u) ? V[j].y : V[j].x;
+                const u32 m2 = m ? m & ~(0x80000000u >> __clz(m)) : 0u;  // without its highest bit
+                t.aux[2 * j + 1] = (m2 & 4u) ? V[j].z : (m2 & 2u) ? V[j].y : V[j].x;
+            } else {
+                t.aux[2 * j] = (m & 1u) ? V[j].x : (m & 2u) ? V[j].y : (m & 4u) ? V[j].z : V[j].w;
+                const u32 m2 = m & (m - 1u);
+                t.aux[2 * j + 1] = (m2 & 2u) ? V[j].y : (m2 & 4u) ? V[j].z : V[j].w;
+            }
         }
     }
     return tsum;
@@ -300,7 +307,9 @@ __device__ __forceinline__ u32 count_queries(const AccelView &a, const SearchLds
 // write phase: CSR offsets and token ids of the lane's QPT queries (first query q0).  wave_base = global offset
 // of the wave's first id.  When the wave's ids fit the wave's LDS buffer (`stage`, stage_cap words) they are
 // compacted there and leave as contiguous stores; otherwise (and beyond the caller's capacity) one by one.
-template <int QPT, bool FILTER, bool IMPL>
+// REV: a query's hits leave in DESCENDING stored order (AIList::find, ailist.rs:238-263): the i-th hit of the forward
+// scan goes to slot n - 1 - i of the query's n.
+template <int QPT, bool FILTER, bool IMPL, bool REV>
 __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                               const u32 *__restrict__ qs, const u32 *__restrict__ qe, u64 nq, i32 min_bp,
                                               const TileQ<QPT, IMPL> &t, u64 q0, u64 wave_base, u64 *__restrict__ offsets,
@@ -324,38 +333,61 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
         o4[j] = run;
         const u32 b0 = t.st[j] & B0_MASK;
         u32 m = t.st[j] >> B0_BITS;
-        u64 o = run;
+        const bool more = (t.more_bits & (1u << j)) != 0;
+        u32 cq = 0, sq = 0, eq = 0, be = 0;
+        u32 n_all = __popc(m);  // the query's hits
+        if (more) {
+            cq = qc[q0 + j];
+            sq = qs[q0 + j];
+            eq = qe[q0 + j];
+            be = L.ctab[cq].w;
+            if (REV || !cap) n_all += walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [](u32, int) {});
+        }
+        // slot of the i-th hit of the forward scan
+        auto slot = [&](u32 i) -> u64 { return REV ? run + (n_all - 1u - i) : run + i; };
+        u32 i = 0;
         if (cap) {
             if constexpr (IMPL) {
                 while (m) {
                     const int k = __ffs((int)m) - 1;
                     m &= m - 1;
-                    put(o++, t.aux[j] + (u32)k);
+                    put(slot(i++), t.aux[j] + (u32)k);
                 }
+            } else if (REV) {
+                // aux holds the ids of the record's LAST two hits; earlier ones (3rd and 4th from the end) are rare loads
+                const u32 pm = __popc(m);
+                u32 r = 0;  // rank from the end
+                while (m) {
+                    const int k = 31 - __clz(m);
+                    m &= ~(1u << k);
+                    const u32 id = r == 0 ? t.aux[2 * j] : r == 1 ? t.aux[2 * j + 1] : recw[b0 * 16u + 8u + (u32)k];
+                    put(slot(pm - 1u - r), id);
+                    ++r;
+                }
+                i = pm;
             } else {
-                if (m) put(o++, t.aux[2 * j]);
+                if (m) put(slot(i++), t.aux[2 * j]);
                 m &= m - 1;
-                if (m) put(o++, t.aux[2 * j + 1]);
+                if (m) put(slot(i++), t.aux[2 * j + 1]);
                 m &= m - 1;
                 while (m) {  // 3rd and 4th hit of a record: rare, a dependent load
                     const int k = __ffs((int)m) - 1;
                     m &= m - 1;
-                    put(o++, recw[b0 * 16u + 8u + (u32)k]);
+                    put(slot(i++), recw[b0 * 16u + 8u + (u32)k]);
                 }
             }
         } else {
-            o += __popc(m);
+            i = __popc(m);
         }
-        if (t.more_bits & (1u << j)) {
-            const u32 cq = qc[q0 + j], sq = qs[q0 + j], eq = qe[q0 + j];
-            const u32 be = L.ctab[cq].w;
-            u64 ot = o;
-            o += walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
-                if (cap) put(ot, IMPL ? t.aux[IMPL ? j : 0] + (u32)ACC_OWN * (b - b0) + (u32)k : recw[b * 16u + 8u + (u32)k]);
-                ++ot;
-            });
+        if (more && (cap || !REV)) {
+            if (cap) {
+                const u32 n_tail = walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
+                    put(slot(i++), IMPL ? t.aux[IMPL ? j : 0] + (u32)ACC_OWN * (b - b0) + (u32)k : recw[b * 16u + 8u + (u32)k]);
+                });
+                if (!REV) n_all += n_tail;
+            }
         }
-        run = o;
+        run += n_all;
     }
     if (staged) {
         // the wave's ids, contiguous: 256 bytes per store instruction (LDS operations of a wave execute in order)
@@ -450,7 +482,7 @@ __device__ __forceinline__ u64 resolve_prefix_helping(u64 *state, u32 tile, u64 
     return excl;
 }
 
-template <int TPB, int QPT, bool FILTER, bool IMPL>
+template <int TPB, int QPT, bool FILTER, bool IMPL, bool REV>
 __global__ void __launch_bounds__(TPB, TPB / 256)
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
@@ -503,7 +535,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             if (draw && threadIdx.x == 0) ticket = atomicAdd(&ws->ticket, 1u);
             if (!loaded) load_queries<QPT>(qc, qs, qe, nq, (u64)tile * TILE + (u64)threadIdx.x * QPT, vec_ok, c, s, e);
             loaded = false;
-            const u32 tsum = count_queries<QPT, FILTER, IMPL>(a, L, c, s, e, min_bp, cur.q);
+            const u32 tsum = count_queries<QPT, FILTER, IMPL, REV>(a, L, c, s, e, min_bp, cur.q);
             const u32 inc = wave_inclusive_scan_u32(tsum, lane);
             if (lane == 63) s_scan[wave] = inc;
             if (draw && threadIdx.x == 0) s_tile = gridDim.x + (ticket - ticket_base);
@@ -531,7 +563,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         }
         if (have_prev) {
             lds_barrier();
-            write_queries<QPT, FILTER, IMPL>(a, L, qc, qs, qe, nq, min_bp, prev.q, (u64)prev.tile * TILE + (u64)threadIdx.x * QPT,
+            write_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, nq, min_bp, prev.q, (u64)prev.tile * TILE + (u64)threadIdx.x * QPT,
                                              s_prefix + prev.wbase, offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
         }
         lds_barrier();  // s_tile / s_prefix / s_scan reuse
@@ -678,11 +710,10 @@ gtars_status launch_count_lds(const AccelView &a, const u32 *qc, const u32 *qs, 
 
 static u64 tok_tile_queries(int tpb, int qpt) { return (u64)tpb * (u64)qpt; }
 
-// queries per lane and tile: 4 (one burst of eight 16-byte loads per lane); 2 is kept for experiments
+// queries per lane and tile: 4 (one burst of eight 16-byte loads per lane; 2 was slower at every batch size)
 static int choose_qpt(u64 nq) {
     (void)nq;
-    const int f_q = env_int("GTARS_TOK_QPT", 0);
-    return f_q == 2 ? 2 : 4;
+    return 4;
 }
 
 size_t tokenize_lds_ws_bytes(u64 nq) {
@@ -701,13 +732,13 @@ static u32 stage_words(const AccelView &a, int tpb, int per_cu) {
     return w >= 128 ? (u32)w : 0u;
 }
 
-template <int TPB, int QPT, bool FILTER, bool IMPL>
+template <int TPB, int QPT, bool FILTER, bool IMPL, bool REV>
 static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, const u64 *d_base, u64 *d_total_out,
                                  hipStream_t st) {
     static KernelSetup setup;
     int dev = 0, cus = 256;
-    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, FILTER, IMPL>), dev, cus);
+    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, FILTER, IMPL, REV>), dev, cus);
     if (s0) return s0;
     // one 1024-thread workgroup per CU: one LDS copy of the search keys, 16 waves -- what 128 VGPRs admit
     const u32 stage = stage_words(a, TPB, 1);
@@ -718,7 +749,7 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     u64 grid = (u64)cus;
     if (grid > tiles) grid = tiles;
     const u64 cap = out.vals ? out.capacity : 0;
-    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, FILTER, IMPL>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
+    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, FILTER, IMPL, REV>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
                        min_bp, out.offsets, out.vals, cap, ws, ep.epoch, ep.ticket_base, stage, spin_limit, d_base, d_total_out);
     GT_HIP(hipGetLastError());
     // tickets drawn by this launch: one per tile beyond the first `grid`, plus one failing draw per workgroup
@@ -728,7 +759,7 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
 
 gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  int has_min, i32 min_overlap, const EnumOut &out, void *scan_ws,
-                                 size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st, const u64 *d_base, u64 *d_total_out) {
+                                 size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st, const u64 *d_base, u64 *d_total_out, bool reverse) {
     if (out.starts || out.ends) return fail(GTARS_ERR_INTERNAL, "the LDS tokenizer writes vals only");
     if (nq == 0) {
         if (d_base) {
@@ -764,15 +795,15 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     const bool impl = a.ids_affine != 0;
     if (!impl && !a.rec4) return fail(GTARS_ERR_INTERNAL, "index has no id records");
     ProfScope p("k_tok_lds", st);
-#define GT_TOK_CASE(Q)                                                                                         \
-    if (qpt == Q) {                                                                                            \
-        if (impl) return filter ? launch_tok_t<TPB, Q, true, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)     \
-                                : launch_tok_t<TPB, Q, false, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);   \
-        return filter ? launch_tok_t<TPB, Q, true, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)              \
-                      : launch_tok_t<TPB, Q, false, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);            \
+#define GT_TOK_CASE(Q, R)                                                                                                   \
+    if (qpt == Q && reverse == R) {                                                                                         \
+        if (impl) return filter ? launch_tok_t<TPB, Q, true, true, R>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)     \
+                                : launch_tok_t<TPB, Q, false, true, R>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);   \
+        return filter ? launch_tok_t<TPB, Q, true, false, R>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)              \
+                      : launch_tok_t<TPB, Q, false, false, R>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);            \
     }
-    GT_TOK_CASE(4)
-    GT_TOK_CASE(2)
+    GT_TOK_CASE(4, false)
+    GT_TOK_CASE(4, true)
 #undef GT_TOK_CASE
     return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");
 }
