@@ -1,6 +1,6 @@
 """Fold a rocprofv3 run directory (gpurun_out/prof_*) into the tracked profiles/<round>/ summaries.
 
-usage: python tools/collect_profiles.py gpurun_out/prof_r1b profiles/r01
+usage: python tools/collect_profiles.py gpurun_out/prof_r02 profiles/r02      (after sh tools/profile_r02.sh on the GPU box)
 Expects <src>/trace (kernel-trace --stats), <src>/fetch and <src>/write (separate --pmc passes of
 bench.py) and optionally <src>/igd (kernel-trace --stats of tools/igd_bench.py).
 """
@@ -42,7 +42,8 @@ def main(src, dst):
                      "universe_regions": bench["config"]["universe_regions"]},
         "kernel": kernel,
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 20 "
-                   "--warmup 5 --no-cpu-baseline (two separate passes)",
+                   "--warmup 5 --no-cpu-baseline --no-extras --min-seconds 0.05 (two separate passes; steps rotate "
+                   "through 32 distinct batches)",
         "fetch_size_kb_raw": out["FETCH_SIZE"],
         "write_size_kb_raw": out["WRITE_SIZE"],
         "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B for wide coalesced reads; "
@@ -51,10 +52,10 @@ def main(src, dst):
         "write_bytes_per_launch": write,
         "traffic_bytes_per_launch": fetch + write,
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-        "note": "fetch = 12.0 MB query stream + 8 x 2.2 MB index (2.13 MB of 64-B block records + 75 KB of LDS search "
-                "keys, pulled once into each of the 8 non-coherent XCD L2s; FETCH_SIZE counts L2->fabric requests, so the "
-                "7 repeat copies are most likely served by the 256 MB Infinity Cache rather than HBM); writes match "
-                "8*(Nq+1)+4*H exactly",
+        "note": "fetch = 12.0 MB query stream + the index pulled into each of the 8 non-coherent XCD L2s (1.6 MB of "
+                "32-byte block records + 0.1 MB of LDS search keys per XCD; FETCH_SIZE counts L2->fabric requests, so the "
+                "repeat copies are most likely served by the 256 MB Infinity Cache rather than HBM); writes = "
+                "8*(Nq+1)+4*H",
     }
     json.dump(doc, open(f"{dst}/traffic_tokenize_1M.json", "w"), indent=1)
     igd = glob.glob(f"{src}/igd/**/*kernel_stats.csv", recursive=True)
