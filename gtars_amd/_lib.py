@@ -150,6 +150,14 @@ _HOST_SIG = {
     "gtars_tokenizer_encode_ids": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
     "gtars_tokenizer_tokenize_fragment_file": (C.c_int, [vp, cstr, C.POINTER(C.POINTER(FragmentTokens))]),
     "gtars_fragment_tokens_free": (None, [C.POINTER(FragmentTokens)]),
+    "gtars_barcode_map_from_file": (C.c_int, [cstr, pp]),
+    "gtars_barcode_map_free": (None, [vp]),
+    "gtars_barcode_map_len": (u64, [vp]),
+    "gtars_barcode_map_n_clusters": (u32, [vp]),
+    "gtars_barcode_map_cluster_label": (C.c_char_p, [vp, u32]),
+    "gtars_barcode_map_lookup": (C.c_char_p, [vp, cstr]),
+    "gtars_fragsplit": (C.c_int, [cstr, vp, cstr, pu64, pu64]),
+    "gtars_fragsplit_tokenize": (C.c_int, [vp, cstr, vp, C.POINTER(C.POINTER(C.POINTER(FragmentTokens))), pu64]),
     "gtars_gtok_write": (C.c_int, [cstr, vp, u64]),
     "gtars_gtok_read": (C.c_int, [cstr, pp, pu64]),
     "gtars_fragments_read": (C.c_int, [cstr, pp]),

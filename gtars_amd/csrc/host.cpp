@@ -20,6 +20,7 @@
 #include <map>
 #include <memory>
 #include <numeric>
+#include <set>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -1709,6 +1710,373 @@ gtars_status gtars_igddb_count_regionset(const gtars_igddb_t *db, const gtars_re
     const std::vector<uint32_t> qc = translate_chroms(rs, db->chroms);
     return gtars_igd_count(db->igd, qc.data(), rs->starts.data(), rs->ends.data(), rs->size(), min_overlap, binary,
                            hits);
+}
+
+}  // extern "C"
+
+// ===================================================================== gtars-fragsplit
+namespace {
+
+// remove_all_extensions (gtars-core/src/utils.rs:372-387): the file name without ANY extension
+std::string remove_all_extensions(const std::string &path) {
+    std::string stem = file_stem(path);
+    for (;;) {
+        const size_t dot = stem.find_last_of('.');
+        if (dot == std::string::npos || dot == 0) return stem;  // Path::extension() is None
+        stem = stem.substr(0, dot);
+    }
+}
+
+struct SvHash {
+    size_t operator()(const std::string &s) const noexcept {
+        uint64_t h = 1469598103934665603ull;  // FNV-1a
+        for (unsigned char ch : s) h = (h ^ ch) * 1099511628211ull;
+        return (size_t)h;
+    }
+};
+
+gtars_status list_regular_files(const std::string &dir, std::vector<std::string> &out) {
+    DIR *d = opendir(dir.c_str());
+    if (!d) return fail(GTARS_ERR_IO, "There was an error reading the specifed fragment file directory: \"" + dir + "\"");
+    while (struct dirent *e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name == "." || name == "..") continue;
+        const std::string p = dir + "/" + name;
+        if (is_regular_file(p)) out.push_back(p);
+    }
+    closedir(d);
+    std::sort(out.begin(), out.end());
+    return GTARS_OK;
+}
+
+}  // namespace
+
+struct gtars_barcode_map {
+    std::unordered_map<std::string, uint32_t, SvHash> map;  // "stem+barcode" -> cluster index (into labels)
+    std::vector<std::string> labels;                        // byte order
+};
+
+extern "C" {
+
+gtars_status gtars_barcode_map_from_file(const char *path, gtars_barcode_map_t **out) {
+    if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    FILE *probe = fopen(path, "rb");
+    if (!probe) return fail(GTARS_ERR_IO, std::string("Couldn't open file: \"") + path + "\"");
+    fclose(probe);
+    std::string data, err;
+    {
+        // BufReader::new(File::open(..)): never gunzipped, whatever the extension
+        FILE *f = fopen(path, "rb");
+        std::vector<char> buf(1 << 20);
+        size_t n;
+        while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) data.append(buf.data(), n);
+        fclose(f);
+    }
+    std::vector<std::pair<std::string, std::string>> rows;
+    const char *p = data.data(), *end = p + data.size();
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *next = nl ? nl + 1 : end;
+        if (nl && le > p && le[-1] == '\r') --le;
+        const char *q = p;
+        std::string f[2];
+        int nf = 0;
+        while (q < le && nf < 2) {
+            while (q < le && is_ws(*q)) ++q;
+            const char *st = q;
+            while (q < le && !is_ws(*q)) ++q;
+            if (q > st) f[nf++].assign(st, (size_t)(q - st));
+        }
+        if (nf < 2)
+            return fail(GTARS_ERR_PARSE, "Invalid line format: Expected two tab-separated values, found: \"" +
+                                             std::string(p, (size_t)(le - p)) + "\"");
+        rows.emplace_back(std::move(f[0]), std::move(f[1]));
+        p = next;
+    }
+    std::unique_ptr<gtars_barcode_map> m(new gtars_barcode_map());
+    std::set<std::string> labels;
+    for (auto &r : rows) labels.insert(r.second);
+    m->labels.assign(labels.begin(), labels.end());
+    std::unordered_map<std::string, uint32_t> lid;
+    for (uint32_t i = 0; i < m->labels.size(); ++i) lid[m->labels[i]] = i;
+    m->map.reserve(rows.size() * 2);
+    for (auto &r : rows) m->map[r.first] = lid[r.second];  // HashMap::insert: the later line wins
+    *out = m.release();
+    return GTARS_OK;
+}
+void gtars_barcode_map_free(gtars_barcode_map_t *m) { delete m; }
+uint64_t gtars_barcode_map_len(const gtars_barcode_map_t *m) { return m ? m->map.size() : 0; }
+uint32_t gtars_barcode_map_n_clusters(const gtars_barcode_map_t *m) { return m ? (uint32_t)m->labels.size() : 0; }
+const char *gtars_barcode_map_cluster_label(const gtars_barcode_map_t *m, uint32_t i) {
+    return m && i < m->labels.size() ? m->labels[i].c_str() : nullptr;
+}
+const char *gtars_barcode_map_lookup(const gtars_barcode_map_t *m, const char *key) {
+    if (!m || !key) return nullptr;
+    auto it = m->map.find(key);
+    return it == m->map.end() ? nullptr : m->labels[it->second].c_str();
+}
+
+}  // extern "C"
+
+namespace {
+
+// One input file routed by cluster.  TEXT: the output lines per cluster; COLS: the routed lines as fragment columns
+// (chromosome / barcode names as views into `data`, which stays alive with the result).
+struct SplitFile {
+    std::string data;
+    std::vector<std::string> text;                           // [n_clusters]
+    struct Row { const char *chr; uint32_t chr_n; const char *bc; uint32_t bc_n; uint32_t s, e; };
+    std::vector<std::vector<Row>> rows;                      // [n_clusters]
+    uint64_t n_reads = 0, n_written = 0;
+    gtars_status st = GTARS_OK;
+    std::string err;
+};
+
+void split_one_file(const std::string &path, const gtars_barcode_map &m, bool want_text, SplitFile &out) {
+    std::string err;
+    if (!read_all(path, out.data, err)) {
+        out.st = GTARS_ERR_IO;
+        out.err = err;
+        return;
+    }
+    const size_t nc = m.labels.size();
+    if (want_text) out.text.resize(nc); else out.rows.resize(nc);
+    const std::string stem = remove_all_extensions(path);
+    std::string key = stem + "+";
+    const size_t key0 = key.size();
+    const char *p = out.data.data(), *end = p + out.data.size();
+    size_t index = 0;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *next = nl ? nl + 1 : end;
+        if (nl && le > p && le[-1] == '\r') --le;
+        const char *f[5];
+        size_t fl[5];
+        int nf = 0;
+        const char *q = p;
+        while (q < le && nf < 5) {
+            while (q < le && is_ws(*q)) ++q;
+            const char *st = q;
+            while (q < le && !is_ws(*q)) ++q;
+            if (q > st) { f[nf] = st; fl[nf] = (size_t)(q - st); ++nf; }
+        }
+        if (nf < 5) {
+            out.st = GTARS_ERR_PARSE;
+            out.err = "Failed to parse fragments file at line " + std::to_string(index) + ": " + std::string(p, (size_t)(le - p));
+            return;
+        }
+        key.resize(key0);
+        key.append(f[3], fl[3]);
+        auto it = m.map.find(key);
+        if (it != m.map.end()) {  // else: most likely a cell dropped in QC
+            const uint32_t cl = it->second;
+            if (want_text) {
+                std::string &t = out.text[cl];
+                for (int k = 0; k < 5; ++k) {
+                    t.append(f[k], fl[k]);
+                    t.push_back(k == 4 ? '\n' : '\t');
+                }
+            } else if (f[0][0] != '#') {  // tokenize_fragment_file skips '#' lines of the cluster file
+                SplitFile::Row r;
+                if (!parse_u32_view(f[1], fl[1], r.s) || !parse_u32_view(f[2], fl[2], r.e)) {
+                    out.st = GTARS_ERR_PARSE;
+                    out.err = std::string("Failed to parse ") + (parse_u32_view(f[1], fl[1], r.s) ? "end" : "start") +
+                              " position of a routed fragment (" + path + " line " + std::to_string(index) + ")";
+                    return;
+                }
+                r.chr = f[0]; r.chr_n = (uint32_t)fl[0]; r.bc = f[3]; r.bc_n = (uint32_t)fl[3];
+                out.rows[cl].push_back(r);
+            }
+            ++out.n_written;
+        }
+        ++out.n_reads;
+        ++index;
+        p = next;
+    }
+}
+
+// files in waves of `wave` (parsed in parallel), handed to `sink(first_file_index, wave_results)` in file order
+template <class Sink>
+gtars_status for_each_split_wave(const std::vector<std::string> &files, const gtars_barcode_map &m, bool want_text, Sink &&sink) {
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_thread_budget(64), files.size()));
+    const size_t wave = (size_t)nt * 2;
+    for (size_t base = 0; base < files.size(); base += wave) {
+        const size_t n = std::min(wave, files.size() - base);
+        std::vector<SplitFile> res(n);
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) split_one_file(files[base + i], m, want_text, res[i]);
+        };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        for (size_t i = 0; i < n; ++i)
+            if (res[i].st) return fail(res[i].st, res[i].err);
+        gtars_status st = sink(base, res);
+        if (st) return st;
+    }
+    return GTARS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+gtars_status gtars_fragsplit(const char *files_dir, const gtars_barcode_map_t *m, const char *out_dir, uint64_t *n_reads,
+                             uint64_t *n_written) {
+    if (!files_dir || !m || !out_dir) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    std::vector<std::string> files;
+    gtars_status st = list_regular_files(files_dir, files);
+    if (st) return st;
+    {
+        // fs::create_dir_all
+        std::string acc;
+        const std::string od = out_dir;
+        for (size_t i = 0; i <= od.size(); ++i) {
+            if (i == od.size() || od[i] == '/') {
+                if (!acc.empty() && mkdir(acc.c_str(), 0777) != 0 && errno != EEXIST)
+                    return fail(GTARS_ERR_IO, "There was an error creating the output directory: \"" + od + "\"");
+            }
+            if (i < od.size()) acc.push_back(od[i]);
+        }
+    }
+    const size_t nc = m->labels.size();
+    std::vector<gzFile> outs(nc, nullptr);
+    auto close_all = [&] {
+        for (gzFile f : outs)
+            if (f) gzclose(f);
+    };
+    for (size_t c = 0; c < nc; ++c) {
+        const std::string p = std::string(out_dir) + "/cluster_" + m->labels[c] + ".bed.gz";
+        outs[c] = gzopen(p.c_str(), "wb6");  // flate2 Compression::default()
+        if (!outs[c]) {
+            close_all();
+            return fail(GTARS_ERR_IO, "cannot create " + p);
+        }
+        gzbuffer(outs[c], 1 << 18);
+    }
+    uint64_t reads = 0, written = 0;
+    st = for_each_split_wave(files, *m, true, [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
+        // every cluster's stream is compressed by one thread per wave, the wave's files in order
+        std::atomic<size_t> next{0};
+        std::atomic<int> bad{0};
+        auto work = [&] {
+            for (size_t c = next.fetch_add(1); c < nc; c = next.fetch_add(1))
+                for (SplitFile &f : res)
+                    if (!f.text[c].empty() && gzwrite(outs[c], f.text[c].data(), (unsigned)f.text[c].size()) <= 0) bad = 1;
+        };
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_thread_budget(64), nc));
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        for (SplitFile &f : res) {
+            reads += f.n_reads;
+            written += f.n_written;
+        }
+        return bad ? fail(GTARS_ERR_IO, "write to a cluster file failed") : GTARS_OK;
+    });
+    close_all();
+    if (st) return st;
+    if (n_reads) *n_reads = reads;
+    if (n_written) *n_written = written;
+    return GTARS_OK;
+}
+
+gtars_status gtars_fragsplit_tokenize(const gtars_tokenizer_t *t, const char *files_dir, const gtars_barcode_map_t *m,
+                                      gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
+    if (!t || !files_dir || !m || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    std::vector<std::string> files;
+    gtars_status st = list_regular_files(files_dir, files);
+    if (st) return st;
+    const size_t nc = m->labels.size();
+    // per cluster: fragment columns in the order the cluster file would have them (files in order, lines in order),
+    // chromosome ids of the TOKENIZER's dictionary, barcode ids in first-seen order
+    struct Cluster {
+        std::vector<uint32_t> c, s, e, b;
+        ViewDict barcodes;
+    };
+    std::vector<Cluster> cl(nc);
+    uint64_t reads = 0;
+    st = for_each_split_wave(files, *m, false, [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t c = next.fetch_add(1); c < nc; c = next.fetch_add(1)) {
+                Cluster &k = cl[c];
+                const char *lc = nullptr;
+                size_t lcn = 0;
+                uint32_t lcid = 0;
+                for (SplitFile &f : res)
+                    for (const SplitFile::Row &r : f.rows[c]) {
+                        if (!(lc && lcn == r.chr_n && memcmp(lc, r.chr, lcn) == 0)) {
+                            const int64_t cid = t->chroms.find(std::string(r.chr, r.chr_n));
+                            lcid = cid < 0 ? GTARS_UNKNOWN_CHROM : (uint32_t)cid;
+                            lc = r.chr;
+                            lcn = r.chr_n;
+                        }
+                        k.c.push_back(lcid);
+                        k.s.push_back(r.s);
+                        k.e.push_back(r.e);
+                        k.b.push_back(k.barcodes.get_or_add(r.bc, r.bc_n));
+                    }
+            }
+        };
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_thread_budget(64), nc));
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
+        work();
+        for (auto &tt : th) tt.join();
+        for (SplitFile &f : res) reads += f.n_reads;
+        return GTARS_OK;
+    });
+    if (st) return st;
+    auto **arr = (gtars_fragment_tokens_t **)calloc(nc ? nc : 1, sizeof(gtars_fragment_tokens_t *));
+    auto bail = [&](gtars_status e) {
+        for (size_t c = 0; c < nc; ++c) gtars_fragment_tokens_free(arr[c]);
+        free(arr);
+        return e;
+    };
+    for (size_t c = 0; c < nc; ++c) {
+        Cluster &k = cl[c];
+        const uint64_t n = k.c.size();
+        std::vector<uint64_t> off(n + 1, 0);
+        uint32_t *ids = nullptr;
+        uint64_t h = 0;
+        st = gtars_tokenize(t->index, k.c.data(), k.s.data(), k.e.data(), n, off.data(), &ids, &h);
+        if (st) return bail(st);
+        const uint64_t nb = k.barcodes.names.size();
+        std::vector<uint64_t> cnt(nb + 1, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t hits = off[i + 1] - off[i];
+            cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
+        }
+        for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
+        auto *ft = (gtars_fragment_tokens_t *)calloc(1, sizeof(gtars_fragment_tokens_t));
+        ft->n_barcodes = nb;
+        ft->barcodes = (char **)calloc(nb ? nb : 1, sizeof(char *));
+        ft->offsets = (uint64_t *)malloc((nb + 1) * sizeof(uint64_t));
+        ft->ids = (uint32_t *)malloc((cnt[nb] ? cnt[nb] : 1) * sizeof(uint32_t));
+        memcpy(ft->offsets, cnt.data(), (nb + 1) * sizeof(uint64_t));
+        for (uint64_t b = 0; b < nb; ++b) ft->barcodes[b] = dup_cstr(k.barcodes.names[b]);
+        std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
+        for (uint64_t i = 0; i < n; ++i) {
+            uint64_t &w = fill[k.b[i]];
+            if (off[i + 1] == off[i])
+                ft->ids[w++] = t->unk_id;
+            else
+                for (uint64_t x = off[i]; x < off[i + 1]; ++x) ft->ids[w++] = ids[x];
+        }
+        gtars_free(ids);
+        arr[c] = ft;
+    }
+    *out = arr;
+    if (n_reads) *n_reads = reads;
+    return GTARS_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,99 @@
+"""gtars-fragsplit: pseudobulking of scATAC fragment files by a barcode -> cluster map, and the
+"fragsplit -> tokenizer" pipeline of BASELINE config 5.
+
+Mirrors ``gtars_fragsplit::map::BarcodeToClusterMap`` (gtars-fragsplit/src/map.rs:8-81) and
+``gtars_fragsplit::split::pseudobulk_fragment_files`` (split.rs:36-151) over the C ABI of ``include/gtars_amd_host.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Set
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+
+def _check(st: int):
+    if st != 0:
+        raise RuntimeError(_lib.last_error())
+
+
+class BarcodeToClusterMap:
+    """``<file stem>+<barcode>`` -> cluster label, read from a two-column whitespace-separated file."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_file(cls, path: str) -> "BarcodeToClusterMap":
+        h = C.c_void_p()
+        _check(lib.gtars_barcode_map_from_file(os.fspath(path).encode(), C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.gtars_barcode_map_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(lib.gtars_barcode_map_len(self._h))
+
+    def n_clusters(self) -> int:
+        return int(lib.gtars_barcode_map_n_clusters(self._h))
+
+    def cluster_labels(self) -> List[str]:
+        """labels in byte order (the order of the results of ``fragsplit_tokenize``)"""
+        return [lib.gtars_barcode_map_cluster_label(self._h, i).decode() for i in range(self.n_clusters())]
+
+    def get_cluster_labels(self) -> Set[str]:
+        return set(self.cluster_labels())
+
+    def get_cluster_from_barcode(self, barcode: str) -> Optional[str]:
+        r = lib.gtars_barcode_map_lookup(self._h, barcode.encode())
+        return r.decode() if r is not None else None
+
+
+def pseudobulk_fragment_files(files: str, mapping: BarcodeToClusterMap, output: str) -> Dict[str, int]:
+    """Split every fragment file of the folder ``files`` into ``output``/cluster_<id>.bed.gz according to ``mapping``.
+    Returns {"reads": lines read, "written": lines routed to a cluster}."""
+    n_reads, n_written = C.c_uint64(), C.c_uint64()
+    _check(lib.gtars_fragsplit(os.fspath(files).encode(), mapping._h, os.fspath(output).encode(), C.byref(n_reads),
+                               C.byref(n_written)))
+    return {"reads": int(n_reads.value), "written": int(n_written.value)}
+
+
+def fragsplit_tokenize(files: str, mapping: BarcodeToClusterMap, tokenizer, as_arrays: bool = False):
+    """The fragsplit -> tokenizer pipeline without the intermediate files: {cluster label: {barcode: [ids]}}, for every
+    cluster exactly what ``tokenize_fragment_file(output/cluster_<id>.bed.gz, tokenizer)`` would return.
+    ``as_arrays``: {cluster: (barcodes, offsets uint64[nb+1], ids uint32[...])} instead (no per-id Python objects)."""
+    out = C.POINTER(C.POINTER(_lib.FragmentTokens))()
+    n_reads = C.c_uint64()
+    _check(lib.gtars_fragsplit_tokenize(tokenizer._h, os.fspath(files).encode(), mapping._h, C.byref(out), C.byref(n_reads)))
+    labels = mapping.cluster_labels()
+    res = {}
+    try:
+        for c, label in enumerate(labels):
+            ft = out[c].contents
+            nb = int(ft.n_barcodes)
+            offs = np.ctypeslib.as_array(ft.offsets, shape=(nb + 1,)).copy()
+            total = int(offs[nb])
+            ids = np.ctypeslib.as_array(ft.ids, shape=(max(total, 1),))[:total].copy()
+            names = [ft.barcodes[b].decode() for b in range(nb)]
+            if as_arrays:
+                res[label] = (names, offs, ids)
+            else:
+                res[label] = {names[b]: [int(v) for v in ids[int(offs[b]):int(offs[b + 1])]] for b in range(nb)}
+    finally:
+        for c in range(len(labels)):
+            lib.gtars_fragment_tokens_free(out[c])
+        lib.gtars_free(C.cast(out, C.c_void_p))
+    return res

@@ -145,6 +145,40 @@ gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, 
 void gtars_fragment_tokens_free(gtars_fragment_tokens_t *ft);
 
 /* ------------------------------------------------------------------------
+ * gtars-fragsplit: pseudobulking of fragment files by a barcode -> cluster map.
+ *   gtars_barcode_map_from_file   BarcodeToClusterMap::from_file (gtars-fragsplit/src/map.rs:34-81): one
+ *                                 `<file stem>+<barcode> <cluster>` pair per line, split on whitespace, later lines win;
+ *                                 a line with fewer than two fields -> GTARS_ERR_PARSE ("Invalid line format ...")
+ *   gtars_fragsplit               pseudobulk_fragment_files (split.rs:36-151): every regular file of `files_dir`
+ *                                 (.gz by extension), lines split on whitespace into chr start end barcode
+ *                                 read_support (fewer than five fields -> GTARS_ERR_PARSE "Failed to parse fragments
+ *                                 file at line {0-based index}: {line}"), looked up as "{stem}+{barcode}" with the stem
+ *                                 stripped of ALL extensions (utils.rs remove_all_extensions), and written as
+ *                                 "chr\tstart\tend\tbarcode\tread_support\n" to <out_dir>/cluster_<id>.bed.gz (one
+ *                                 file per cluster label, also when empty; gzip level 6).  The reference visits the
+ *                                 files in read_dir order (unspecified); here they are visited in byte order of their
+ *                                 names, so the output is deterministic.  Files are parsed by all host threads.
+ *   gtars_fragsplit_tokenize      the "gtars-fragsplit -> tokenizer" pipeline without the intermediate files: for every
+ *                                 cluster (labels in byte order) exactly what tokenize_fragment_file returns for
+ *                                 cluster_<id>.bed.gz -- the routed lines are parsed like fragment-file lines ('#'
+ *                                 lines skipped, start / end must parse as u32), one batched GPU tokenization per cluster.
+ * ---------------------------------------------------------------------- */
+typedef struct gtars_barcode_map gtars_barcode_map_t;
+gtars_status gtars_barcode_map_from_file(const char *path, gtars_barcode_map_t **out);
+void gtars_barcode_map_free(gtars_barcode_map_t *m);
+uint64_t gtars_barcode_map_len(const gtars_barcode_map_t *m);
+uint32_t gtars_barcode_map_n_clusters(const gtars_barcode_map_t *m);
+/* i-th cluster label in byte order */
+const char *gtars_barcode_map_cluster_label(const gtars_barcode_map_t *m, uint32_t i);
+/* cluster label of a "stem+barcode" key, NULL when it is not in the map */
+const char *gtars_barcode_map_lookup(const gtars_barcode_map_t *m, const char *key);
+gtars_status gtars_fragsplit(const char *files_dir, const gtars_barcode_map_t *m, const char *out_dir,
+                             uint64_t *n_reads, uint64_t *n_written);
+/* *out: array of n_clusters results (gtars_fragment_tokens_free each, gtars_free the array) */
+gtars_status gtars_fragsplit_tokenize(const gtars_tokenizer_t *t, const char *files_dir, const gtars_barcode_map_t *m,
+                                      gtars_fragment_tokens_t ***out, uint64_t *n_reads);
+
+/* ------------------------------------------------------------------------
  * .gtok  (gtars-io/src/gtok.rs:125-210, consts.rs:1-3)
  * ---------------------------------------------------------------------- */
 gtars_status gtars_gtok_write(const char *path, const uint32_t *tokens, uint64_t n);

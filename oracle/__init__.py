@@ -699,3 +699,59 @@ def read_tokens_from_gtok(filename: str) -> List[int]:
         n = len(body) // 4
         return list(struct.unpack(f"<{n}I", body[: 4 * n]))
     raise ValueError("Invalid data format flag found in gtok file")
+
+
+# ----------------------------------------------------------------------------- gtars-fragsplit
+def remove_all_extensions(path: str) -> str:
+    """gtars-core/src/utils.rs:372-387."""
+    stem = os.path.basename(path)
+
+    def ext(name):  # Path::extension
+        i = name.rfind(".")
+        return None if i <= 0 else name[i + 1:]
+
+    if ext(stem) is not None:  # Path::file_stem
+        stem = stem[: stem.rfind(".")]
+    while ext(stem) is not None:
+        stem = stem[: stem.rfind(".")]
+    return stem
+
+
+class OracleBarcodeMap:
+    """BarcodeToClusterMap::from_file (gtars-fragsplit/src/map.rs:34-81)."""
+
+    def __init__(self, path: str):
+        self.map: Dict[str, str] = {}
+        self.cluster_labels = set()
+        with open(path, "r") as f:
+            for line in _rust_lines(f):
+                parts = line.split()
+                if len(parts) < 2:
+                    raise ValueError(f"Invalid line format: Expected two tab-separated values, found: {line!r}")
+                self.map[parts[0]] = parts[1]
+                self.cluster_labels.add(parts[1])
+
+    def get_cluster_from_barcode(self, key: str) -> Optional[str]:
+        return self.map.get(key)
+
+
+def fragsplit(files_dir: str, mapping: OracleBarcodeMap, file_order: Optional[Sequence[str]] = None) -> Dict[str, List[str]]:
+    """pseudobulk_fragment_files (gtars-fragsplit/src/split.rs:36-151) with the cluster files kept in memory:
+    {cluster label: [output lines]}.  The reference visits the files in read_dir order (unspecified); the product
+    visits them in byte order of their names, which is the default here too."""
+    out: Dict[str, List[str]] = {c: [] for c in mapping.cluster_labels}
+    names = list(file_order) if file_order is not None else sorted(
+        n for n in os.listdir(files_dir) if os.path.isfile(os.path.join(files_dir, n)))
+    for name in names:
+        path = os.path.join(files_dir, name)
+        stem = remove_all_extensions(path)
+        with _open_text(path) as f:
+            for index, line in enumerate(_rust_lines(f)):
+                parts = line.split()
+                if len(parts) < 5:
+                    raise ValueError(f"Failed to parse fragments file at line {index}: {line}")
+                chr_, start, end, barcode, support = parts[:5]
+                cluster = mapping.get_cluster_from_barcode(f"{stem}+{barcode}")
+                if cluster is not None:
+                    out[cluster].append(f"{chr_}\t{start}\t{end}\t{barcode}\t{support}\n")
+    return out

@@ -19,6 +19,7 @@ cp "$REF/tests/hg38.chrom.sizes" "$HERE/"
 cp "$D/consensus/consensus1.bed" "$HERE/consensus/"
 cp "$D"/fragments/region_scoring/*.bed.gz "$HERE/fragments/region_scoring/"
 cp "$D"/fragments/fragsplit/*.bed.gz "$HERE/fragments/fragsplit/"
+cp "$D/barcode_cluster_map.tsv" "$HERE/"
 cp -r "$D/igd_file_list_01" "$D/igd_file_list_02" "$D/igd_query_files" "$D/lola_multi_db" "$HERE/"
 cp "$D/out/peaks.gtok" "$D/out/tokens.gtok" "$HERE/out/"
 cp "$D/regionset/dummy.bed" "$D/regionset/dummy_b.bed" "$D/regionset/dummy_headers.bed" \

@@ -232,3 +232,99 @@ def test_regionset_multichunk_bed_matches_oracle(tmp_path, monkeypatch, threads)
     with pytest.raises(RuntimeError) as ei:
         RegionSet(str(bad))
     assert "Error in parsing end position" in str(ei.value) and "boom" in str(ei.value)
+
+
+# ------------------------------------------------------------ gtars-fragsplit (host only: no GPU involved)
+
+
+def _cluster_text(out_dir, label):
+    import gzip
+
+    with gzip.open(os.path.join(out_dir, f"cluster_{label}.bed.gz"), "rt") as f:
+        return f.read()
+
+
+def test_fragsplit_reference_fixtures(golden_dir, tmp_path):
+    """pseudobulk_fragment_files on the reference's own fixtures (split.rs tests: fragments/fragsplit + barcode_cluster_map.tsv)
+    against the oracle restatement; map.rs KATs: 3 cluster labels, a QC-dropped barcode maps to nothing."""
+    from gtars_amd.fragsplit import BarcodeToClusterMap, pseudobulk_fragment_files
+
+    mp = os.path.join(golden_dir, "barcode_cluster_map.tsv")
+    fd = os.path.join(golden_dir, "fragments", "fragsplit")
+    m, om = BarcodeToClusterMap.from_file(mp), oracle.OracleBarcodeMap(mp)
+    assert m.n_clusters() == 3 == len(om.cluster_labels) and m.get_cluster_labels() == om.cluster_labels
+    assert len(m) == len(om.map)
+    assert m.get_cluster_from_barcode("AAACGCAAGCAAAGGATCGGCT") is None
+    for k, v in om.map.items():
+        assert m.get_cluster_from_barcode(k) == v
+    stats = pseudobulk_fragment_files(fd, m, str(tmp_path / "out" / "nested"))
+    exp = oracle.fragsplit(fd, om)
+    assert stats["written"] == sum(len(v) for v in exp.values()) and stats["reads"] == 30
+    for label in m.cluster_labels():
+        assert _cluster_text(tmp_path / "out" / "nested", label) == "".join(exp[label])
+
+
+def test_fragsplit_randomized_and_errors(tmp_path):
+    """many files (plain and .gz, CRLF, no trailing newline, extra columns, multi-dot names), duplicate map keys (the later
+    line wins), clusters without reads (their file exists and is empty), and the reference's error messages."""
+    import gzip
+
+    from gtars_amd.fragsplit import BarcodeToClusterMap, pseudobulk_fragment_files
+
+    rng = np.random.default_rng(11)
+    fd = tmp_path / "frags"
+    fd.mkdir()
+    barcodes = ["".join(rng.choice(list("ACGT"), 12)) for _ in range(40)]
+    map_lines = []
+    for fi in range(23):
+        name = f"sample{fi}.v2.bed" + (".gz" if fi % 2 else "")
+        rows = []
+        for _ in range(int(rng.integers(0, 400))):
+            b = barcodes[int(rng.integers(0, len(barcodes)))]
+            s = int(rng.integers(0, 1_000_000))
+            sep = "\t" if rng.random() < 0.8 else "  "
+            extra = f"{sep}extra" if rng.random() < 0.1 else ""
+            rows.append(sep.join([f"chr{int(rng.integers(1, 5))}", str(s), str(s + 50), b, str(int(rng.integers(1, 4)))]) + extra)
+        text = ("\r\n" if fi % 5 == 0 else "\n").join(rows) + ("" if fi % 3 == 0 else "\n")
+        if name.endswith(".gz"):
+            with gzip.open(fd / name, "wt", newline="") as f:
+                f.write(text)
+        else:
+            with open(fd / name, "w", newline="") as f:
+                f.write(text)
+        for b in barcodes[: 25 + fi % 7]:
+            map_lines.append(f"sample{fi}+{b}\t{'c' + str(hash((fi, b)) % 6)}")
+    map_lines.append(f"sample0+{barcodes[0]} override")   # later line wins, new label
+    map_lines.append("nobody+AAAA lonely")                  # a cluster that receives nothing
+    mp = tmp_path / "map.tsv"
+    mp.write_text("\n".join(map_lines))                     # no trailing newline
+    m, om = BarcodeToClusterMap.from_file(str(mp)), oracle.OracleBarcodeMap(str(mp))
+    assert m.get_cluster_from_barcode(f"sample0+{barcodes[0]}") == "override"
+    assert m.get_cluster_labels() == om.cluster_labels and "lonely" in om.cluster_labels
+    out = tmp_path / "out"
+    stats = pseudobulk_fragment_files(str(fd), m, str(out))
+    exp = oracle.fragsplit(str(fd), om)
+    assert stats["written"] == sum(len(v) for v in exp.values()) > 1000
+    for label in m.cluster_labels():
+        assert _cluster_text(out, label) == "".join(exp[label]), label
+    assert _cluster_text(out, "lonely") == ""
+    # errors: a short line (0-based index, the line itself), a bad map line, a missing directory
+    (fd / "zzz_bad.bed").write_text("chr1\t1\t2\tAAAA\t1\nchr1\t5\t6\tAAAA\n")
+    with pytest.raises(RuntimeError, match=r"Failed to parse fragments file at line 1: chr1\t5\t6\tAAAA"):
+        pseudobulk_fragment_files(str(fd), m, str(tmp_path / "out2"))
+    with pytest.raises(ValueError, match="line 1"):
+        oracle.fragsplit(str(fd), om)
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("a+b 1\nonlyone\n")
+    with pytest.raises(RuntimeError, match="Invalid line format"):
+        BarcodeToClusterMap.from_file(str(bad))
+    with pytest.raises(RuntimeError, match="error reading the specifed fragment file directory"):
+        pseudobulk_fragment_files(str(tmp_path / "nope"), m, str(tmp_path / "out3"))
+
+
+def test_remove_all_extensions_matches_reference_rule():
+    # gtars-core/src/utils.rs:372-387 through the product's lookup key: "<stem>+<barcode>"
+    assert oracle.remove_all_extensions("/x/y/fragments1.bed.gz") == "fragments1"
+    assert oracle.remove_all_extensions("a.b.c.d") == "a"
+    assert oracle.remove_all_extensions(".hidden") == ".hidden"
+    assert oracle.remove_all_extensions("plain") == "plain"
