@@ -34,7 +34,13 @@ class NoDeviceError(GtarsError):
 
 
 class CapacityError(GtarsError):
-    pass
+    @property
+    def needed(self) -> int:
+        """the element count the library asked for ("... need N")"""
+        import re
+
+        m = re.search(r"need (\d+)", self.message)
+        return int(m.group(1)) if m else 0
 
 
 if not os.path.exists(LIB_PATH):
@@ -75,6 +81,7 @@ _SIG = {
     "gtars_index_sublist_offsets": (C.c_int, [vp, u32, vp]),
     "gtars_tokenize_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64, vp]),
     "gtars_fill_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, vp]),
+    "gtars_histogram_u32_device": (C.c_int, [vp, u64, u32, vp, vp]),
     "gtars_tokenize": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
     "gtars_tokenize_into": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64]),
     "gtars_count_overlaps_device": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, vp]),
@@ -161,6 +168,7 @@ _HOST_SIG = {
     "gtars_gtok_write": (C.c_int, [cstr, vp, u64]),
     "gtars_gtok_read": (C.c_int, [cstr, pp, pu64]),
     "gtars_fragments_read": (C.c_int, [cstr, pp]),
+    "gtars_fragments_read_strict": (C.c_int, [cstr, pp]),
     "gtars_fragments_free": (None, [vp]),
     "gtars_fragments_len": (u64, [vp]),
     "gtars_fragments_n_chrom": (u32, [vp]),

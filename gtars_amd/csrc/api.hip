@@ -348,6 +348,39 @@ struct gtars_igd {
         pme_ready = true;
         return GTARS_OK;
     }
+    // are the records' values all distinct?  (then the per-query "first occurrence of a value" rule keeps every hit);
+    // decided on the first per-query call by sorting a copy of the values
+    mutable std::mutex uniq_mu;
+    mutable int values_unique = -1;
+    gtars_status ensure_values_unique(bool *out) const {
+        std::lock_guard<std::mutex> lk(uniq_mu);
+        if (values_unique < 0) {
+            if (n < 2) {
+                values_unique = 1;
+            } else {
+                const u32 n32 = (u32)n;
+                ScopedDev buf;
+                const size_t wsb = radix_sort_ws_bytes(n32);
+                gtars_status st = buf.alloc((size_t)n32 * 16 + wsb + 64);
+                if (st) return st;
+                u32 *k0 = buf.as<u32>(), *v0 = k0 + n32, *k1 = v0 + n32, *v1 = k1 + n32;
+                void *ws = (void *)(v1 + n32);
+                u32 *d_dup = (u32 *)((char *)ws + wsb);
+                GT_HIP(hipMemcpy(k0, values.p, (size_t)n32 * 4, hipMemcpyDeviceToDevice));
+                GT_HIP(hipMemset(d_dup, 0, 4));
+                int res = 0;
+                st = radix_sort_pairs(k0, v0, k1, v1, n32, 0, 32, ws, wsb, &res, nullptr);
+                if (st) return st;
+                st = launch_has_adjacent_equal(res ? k1 : k0, n32, d_dup, nullptr);
+                if (st) return st;
+                u32 h = 1;
+                GT_HIP(hipMemcpy(&h, d_dup, 4, hipMemcpyDeviceToHost));
+                values_unique = h ? 0 : 1;
+            }
+        }
+        *out = values_unique == 1;
+        return GTARS_OK;
+    }
     u32 n_tiles = 0;
     IgdTiles tiles() const {
         IgdTiles t;
@@ -876,6 +909,13 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
             return fail(GTARS_ERR_CAPACITY, "ids buffer too small: need " + std::to_string(*total_hits));
     }
     return GTARS_OK;
+}
+
+gtars_status gtars_histogram_u32_device(const uint32_t *d_ids, uint64_t n, uint32_t n_bins, uint32_t *d_bins, void *stream) {
+    if ((n && !d_ids) || (n_bins && !d_bins)) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    gtars_status st = require_device();
+    if (st) return st;
+    return launch_hist_u32(d_ids, n, n_bins, d_bins, (hipStream_t)stream);
 }
 
 gtars_status gtars_fill_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
@@ -1647,7 +1687,9 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
         return launch_igd_sweep(g->view(), g->tiles(), d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, ws.ptr, ws.bytes,
                                 (hipStream_t)stream);
     }
-    return launch_igd_count(g->view(), d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
+    // small batch: one thread per query (kernels.hip); binary counts with min_overlap == 1 through pme_file as well
+    if (binary && min_overlap == 1 && !getenv("GTARS_IGD_NO_PME") && (st = g->ensure_pme())) return st;
+    return launch_igd_count(g->view(), g->tiles().pme_file, d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
 }
 
 gtars_status gtars_igd_count(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
@@ -1684,7 +1726,9 @@ gtars_status gtars_igd_count_per_query(const gtars_igd_t *g, const uint32_t *qc,
     ScopedDev d;
     st = d.alloc(nq * 4);
     if (st) return st;
-    st = launch_igd_count_per_query(g->view(), q.c, q.s, q.e, nq, min_overlap, d.as<u32>(), nullptr);
+    bool uniq = false;
+    if ((st = g->ensure_values_unique(&uniq))) return st;
+    st = launch_igd_count_per_query(g->view(), q.c, q.s, q.e, nq, min_overlap, d.as<u32>(), uniq, nullptr);
     if (st) return st;
     GT_HIP(hipMemcpy(counts, d.p, nq * 4, hipMemcpyDeviceToHost));
     return GTARS_OK;
@@ -1709,7 +1753,9 @@ gtars_status gtars_igd_find_pairs(const gtars_igd_t *g, const uint32_t *qc, cons
     if ((st = d_off.alloc((nq + 1) * 8))) return st;
     const size_t wsb = scan_ws_bytes(nq);
     if ((st = d_ws.alloc(wsb))) return st;
-    st = launch_igd_count_per_query(g->view(), q.c, q.s, q.e, nq, min_overlap, d_cnt.as<u32>(), nullptr);
+    bool uniq = false;
+    if ((st = g->ensure_values_unique(&uniq))) return st;
+    st = launch_igd_count_per_query(g->view(), q.c, q.s, q.e, nq, min_overlap, d_cnt.as<u32>(), uniq, nullptr);
     if (st) return st;
     st = launch_scan_u32_to_u64(d_cnt.as<u32>(), nq, d_off.as<u64>(), d_ws.p, wsb, nullptr);
     if (st) return st;
@@ -1719,7 +1765,7 @@ gtars_status gtars_igd_find_pairs(const gtars_igd_t *g, const uint32_t *qc, cons
     if ((st = d_q.alloc(h * 4))) return st;
     if ((st = d_s.alloc(h * 4))) return st;
     st = launch_igd_fill_pairs(g->view(), q.c, q.s, q.e, nq, min_overlap, d_off.as<u64>(), d_q.as<u32>(),
-                               d_s.as<u32>(), nullptr);
+                               d_s.as<u32>(), uniq, nullptr);
     if (st) return st;
     *out_q = host_alloc<u32>(h);
     *out_s = host_alloc<u32>(h);

@@ -197,13 +197,16 @@ gtars_status launch_scan_u32_to_u64(const u32 *counts, u64 n, u64 *offsets, void
                                     hipStream_t st);
 size_t scan_ws_bytes(u64 n);
 
-gtars_status launch_igd_count(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
+// pme_file (may be null): IgdTiles::pme_file, used for binary counts with min_overlap == 1
+gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               i32 min_overlap, int binary, u64 *hits, hipStream_t st);
+gtars_status launch_hist_u32(const u32 *ids, u64 n, u32 n_bins, u32 *bins, hipStream_t st);
+gtars_status launch_has_adjacent_equal(const u32 *a, u64 n, u32 *dup, hipStream_t st);
 gtars_status launch_igd_count_per_query(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe,
-                                        u64 nq, i32 min_overlap, u32 *counts, hipStream_t st);
+                                        u64 nq, i32 min_overlap, u32 *counts, bool unique_values, hipStream_t st);
 gtars_status launch_igd_fill_pairs(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                    i32 min_overlap, const u64 *offsets, u32 *out_q, u32 *out_s,
-                                   hipStream_t st);
+                                   bool unique_values, hipStream_t st);
 gtars_status launch_lola_contingency(const u64 *user_hits, const u64 *universe_hits, u64 n_files,
                                      i64 user_size, i64 universe_size, i64 *a, i64 *b, i64 *c, i64 *d,
                                      hipStream_t st);

@@ -1227,11 +1227,11 @@ struct FragChunk {
     std::vector<uint32_t> c, s, e, b;
     ViewDict chroms, barcodes;
     size_t n_lines = 0;           // every line of the chunk, comments included (for error line numbers)
-    int err = 0;                  // 0 ok, 1 < 5 fields, 2 bad start, 3 bad end
+    int err = 0;                  // 0 ok, 1 < 5 fields, 2 bad start, 3 bad end, 4 bad read support (strict mode)
     size_t err_line = 0;          // line index inside the chunk
 };
 
-void parse_fragment_chunk(const char *p, const char *end, FragChunk &out) {
+void parse_fragment_chunk(const char *p, const char *end, FragChunk &out, bool check_support = false) {
     const size_t guess = (size_t)(end - p) / 30 + 16;
     out.c.reserve(guess); out.s.reserve(guess); out.e.reserve(guess); out.b.reserve(guess);
     uint32_t last_c = 0, last_b = 0;
@@ -1256,6 +1256,10 @@ void parse_fragment_chunk(const char *p, const char *end, FragChunk &out) {
         if (nf < 5) { out.err = 1; out.err_line = ln; return; }
         if (!parse_u32_view(f[1], fl[1], sv)) { out.err = 2; out.err_line = ln; return; }
         if (!parse_u32_view(f[2], fl[2], ev)) { out.err = 3; out.err_line = ln; return; }
+        if (check_support) {  // Fragment::from_str also parses the read support (gtars-core/src/models/fragments.rs:31-33)
+            uint32_t sup;
+            if (!parse_u32_view(f[4], fl[4], sup)) { out.err = 4; out.err_line = ln; return; }
+        }
         // fragment files are sorted by chromosome and barcodes repeat: try the previous line's ids first
         if (!(last_c_p && last_c_n == fl[0] && memcmp(last_c_p, f[0], fl[0]) == 0)) {
             last_c = out.chroms.get_or_add(f[0], fl[0]); last_c_p = f[0]; last_c_n = fl[0];
@@ -1273,7 +1277,7 @@ struct FragTable {
     std::vector<std::string> chroms, barcodes;
 };
 
-gtars_status read_fragment_table(const char *path, FragTable &ft) {
+gtars_status read_fragment_table(const char *path, FragTable &ft, bool check_support = false) {
     std::string data, err;
     if (!read_all(path, data, err)) return fail(GTARS_ERR_IO, err);
     unsigned nt = host_thread_budget(32);
@@ -1290,8 +1294,8 @@ gtars_status read_fragment_table(const char *path, FragTable &ft) {
     {
         std::vector<std::thread> th;
         for (unsigned i = 1; i < nt; ++i)
-            th.emplace_back([&, i] { parse_fragment_chunk(data.data() + cut[i], data.data() + cut[i + 1], chunks[i]); });
-        parse_fragment_chunk(data.data() + cut[0], data.data() + cut[1], chunks[0]);
+            th.emplace_back([&, i] { parse_fragment_chunk(data.data() + cut[i], data.data() + cut[i + 1], chunks[i], check_support); });
+        parse_fragment_chunk(data.data() + cut[0], data.data() + cut[1], chunks[0], check_support);
         for (auto &t : th) t.join();
     }
     size_t line0 = 0, total = 0;
@@ -1299,6 +1303,7 @@ gtars_status read_fragment_table(const char *path, FragTable &ft) {
         if (chunks[i].err) {
             const std::string ln = std::to_string(line0 + chunks[i].err_line);
             if (chunks[i].err == 1) return fail(GTARS_ERR_PARSE, "Invalid fragment file detected at line: " + ln);
+            if (chunks[i].err == 4) return fail(GTARS_ERR_PARSE, "invalid digit found in string (read support, line " + ln + ")");
             return fail(GTARS_ERR_PARSE, std::string("Failed to parse ") + (chunks[i].err == 2 ? "start" : "end") +
                                              " position at line " + ln);
         }
@@ -1350,6 +1355,15 @@ gtars_status gtars_fragments_read(const char *path, gtars_fragments_t **out) {
     *out = nullptr;
     std::unique_ptr<gtars_fragments> f(new gtars_fragments());
     gtars_status st = read_fragment_table(path, f->t);
+    if (st) return st;
+    *out = f.release();
+    return GTARS_OK;
+}
+gtars_status gtars_fragments_read_strict(const char *path, gtars_fragments_t **out) {
+    if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    std::unique_ptr<gtars_fragments> f(new gtars_fragments());
+    gtars_status st = read_fragment_table(path, f->t, true);
     if (st) return st;
     *out = f.release();
     return GTARS_OK;

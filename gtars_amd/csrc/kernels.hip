@@ -495,8 +495,9 @@ gtars_status launch_fill(const IndexView &v, int kind, const u32 *qc, const u32 
 
 // ------------------------------------------------ per-segment sort + unique
 // IndexedRegionSet::find_overlaps sorts and de-duplicates each query's source
-// indices (indexed_region_set.rs:258-260).  Segments are short (hits of one
-// query), so one thread insertion-sorts its own segment in place.
+// indices (indexed_region_set.rs:258-260).  One thread sorts its own segment in
+// place: insertion sort for the usual handful of hits, heap sort (n log n, no
+// scratch memory) for the long segments of dense databases.
 __global__ void __launch_bounds__(256)
 k_sort_unique_segments(u32 *__restrict__ vals, const u64 *__restrict__ offsets, u64 nq,
                        u32 *__restrict__ new_counts) {
@@ -505,14 +506,36 @@ k_sort_unique_segments(u32 *__restrict__ vals, const u64 *__restrict__ offsets, 
         const u64 lo = offsets[q], hi = offsets[q + 1];
         u32 *a = vals + lo;
         const u64 n = hi - lo;
-        for (u64 i = 1; i < n; ++i) {
-            const u32 x = a[i];
-            u64 j = i;
-            while (j > 0 && a[j - 1] > x) {
-                a[j] = a[j - 1];
-                --j;
+        if (n <= 24) {
+            for (u64 i = 1; i < n; ++i) {
+                const u32 x = a[i];
+                u64 j = i;
+                while (j > 0 && a[j - 1] > x) {
+                    a[j] = a[j - 1];
+                    --j;
+                }
+                a[j] = x;
             }
-            a[j] = x;
+        } else {
+            auto sift = [&](u64 root, u64 end) {  // max-heap on a[0, end)
+                const u32 x = a[root];
+                for (;;) {
+                    u64 ch = 2 * root + 1;
+                    if (ch >= end) break;
+                    if (ch + 1 < end && a[ch + 1] > a[ch]) ++ch;
+                    if (a[ch] <= x) break;
+                    a[root] = a[ch];
+                    root = ch;
+                }
+                a[root] = x;
+            };
+            for (u64 i = n / 2; i > 0; --i) sift(i - 1, n);
+            for (u64 end = n - 1; end > 0; --end) {
+                const u32 t = a[0];
+                a[0] = a[end];
+                a[end] = t;
+                sift(0, end);
+            }
         }
         u64 k = 0;
         for (u64 i = 0; i < n; ++i)
@@ -561,10 +584,12 @@ __device__ __forceinline__ void igd_walk(const IgdView &v, u32 c, i32 qs, i32 qe
 
 constexpr int IGD_LDS_FILES = 8192;  // 32 KiB of u32 bins per workgroup
 
+// BINARY with pme_file (min_overlap == 1): a hit is its file's first for the query iff no earlier record of the file
+// ends after the query's start (see k_igd_sweep, igd_sweep.hip) -- no look at the scanned prefix at all.
 template <bool BINARY, bool USE_LDS>
 __global__ void __launch_bounds__(256)
-k_igd_count(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
-            u64 nq, i32 min_overlap, unsigned long long *__restrict__ hits) {
+k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
+            const u32 *__restrict__ qe, u64 nq, i32 min_overlap, unsigned long long *__restrict__ hits) {
     __shared__ u32 bins[USE_LDS ? IGD_LDS_FILES : 1];
     if (USE_LDS) {
         for (u32 i = threadIdx.x; i < v.n_files; i += blockDim.x) bins[i] = 0;
@@ -578,6 +603,15 @@ k_igd_count(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         const u32 c = qc[q];
         if (!BINARY) {
             igd_walk(v, c, s, e, min_overlap, [&](u32 i) {
+                const u32 f = v.files[i];
+                if (USE_LDS)
+                    atomicAdd(&bins[f], 1u);
+                else
+                    atomicAdd(&hits[f], 1ull);
+            });
+        } else if (pme_file) {
+            igd_walk(v, c, s, e, min_overlap, [&](u32 i) {
+                if (pme_file[i] > s) return;
                 const u32 f = v.files[i];
                 if (USE_LDS)
                     atomicAdd(&bins[f], 1u);
@@ -629,8 +663,9 @@ k_igd_count(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     }
 }
 
-gtars_status launch_igd_count(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
+gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               i32 min_overlap, int binary, u64 *hits, hipStream_t st) {
+    if (!binary || min_overlap != 1) pme_file = nullptr;
     GT_HIP(hipMemsetAsync(hits, 0, sizeof(u64) * (v.n_files ? v.n_files : 1), st));
     if (nq == 0 || v.n == 0) return GTARS_OK;
     // u32 LDS bins cannot overflow: a workgroup adds at most (its queries x hits);
@@ -642,14 +677,14 @@ gtars_status launch_igd_count(const IgdView &v, const u32 *qc, const u32 *qs, co
     ProfScope p(binary ? "k_igd_count<binary>" : "k_igd_count<pairwise>", st);
     if (binary) {
         if (lds)
-            hipLaunchKernelGGL((k_igd_count<true, true>), dim3(grid), dim3(256), 0, st, v, qc, qs, qe, nq, min_overlap, h);
+            hipLaunchKernelGGL((k_igd_count<true, true>), dim3(grid), dim3(256), 0, st, v, pme_file, qc, qs, qe, nq, min_overlap, h);
         else
-            hipLaunchKernelGGL((k_igd_count<true, false>), dim3(grid), dim3(256), 0, st, v, qc, qs, qe, nq, min_overlap, h);
+            hipLaunchKernelGGL((k_igd_count<true, false>), dim3(grid), dim3(256), 0, st, v, pme_file, qc, qs, qe, nq, min_overlap, h);
     } else {
         if (lds)
-            hipLaunchKernelGGL((k_igd_count<false, true>), dim3(grid), dim3(256), 0, st, v, qc, qs, qe, nq, min_overlap, h);
+            hipLaunchKernelGGL((k_igd_count<false, true>), dim3(grid), dim3(256), 0, st, v, pme_file, qc, qs, qe, nq, min_overlap, h);
         else
-            hipLaunchKernelGGL((k_igd_count<false, false>), dim3(grid), dim3(256), 0, st, v, qc, qs, qe, nq, min_overlap, h);
+            hipLaunchKernelGGL((k_igd_count<false, false>), dim3(grid), dim3(256), 0, st, v, pme_file, qc, qs, qe, nq, min_overlap, h);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;
@@ -705,10 +740,16 @@ __device__ __forceinline__ void igd_walk_ref_order(const IgdView &v, u32 c, i32 
     }
 }
 
-// de-duplicated walk: f(i) only for the first record (walk order) of each value
-template <class F>
+// de-duplicated walk: f(i) only for the first record (walk order) of each value.  UNIQUE: the database's values
+// are all distinct (Igd::from_single_region_set: value = source index, the documented precondition of these
+// queries, igd.rs:640-641), so every hit is a first occurrence; otherwise every hit re-walks the hits before it.
+template <bool UNIQUE, class F>
 __device__ __forceinline__ void igd_walk_unique(const IgdView &v, u32 c, i32 qs, i32 qe, i32 min_overlap,
                                                 F &&f) {
+    if (UNIQUE) {
+        igd_walk_ref_order(v, c, qs, qe, min_overlap, f);
+        return;
+    }
     u32 ord = 0;
     igd_walk_ref_order(v, c, qs, qe, min_overlap, [&](u32 i) {
         const i32 val = v.values[i];
@@ -723,17 +764,19 @@ __device__ __forceinline__ void igd_walk_unique(const IgdView &v, u32 c, i32 qs,
     });
 }
 
+template <bool UNIQUE>
 __global__ void __launch_bounds__(256)
 k_igd_count_per_query(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
                       const u32 *__restrict__ qe, u64 nq, i32 min_overlap, u32 *__restrict__ counts) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
         u32 n = 0;
-        igd_walk_unique(v, qc[q], (i32)qs[q], (i32)qe[q], min_overlap, [&](u32) { ++n; });
+        igd_walk_unique<UNIQUE>(v, qc[q], (i32)qs[q], (i32)qe[q], min_overlap, [&](u32) { ++n; });
         counts[q] = n;
     }
 }
 
+template <bool UNIQUE>
 __global__ void __launch_bounds__(256)
 k_igd_fill_pairs(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
                  const u32 *__restrict__ qe, u64 nq, i32 min_overlap, const u64 *__restrict__ offsets,
@@ -741,7 +784,7 @@ k_igd_fill_pairs(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ 
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
         u64 o = offsets[q];
-        igd_walk_unique(v, qc[q], (i32)qs[q], (i32)qe[q], min_overlap, [&](u32 i) {
+        igd_walk_unique<UNIQUE>(v, qc[q], (i32)qs[q], (i32)qe[q], min_overlap, [&](u32 i) {
             out_q[o] = (u32)q;
             out_s[o] = (u32)v.values[i];
             ++o;
@@ -750,22 +793,62 @@ k_igd_fill_pairs(IgdView v, const u32 *__restrict__ qc, const u32 *__restrict__ 
 }
 
 gtars_status launch_igd_count_per_query(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe,
-                                        u64 nq, i32 min_overlap, u32 *counts, hipStream_t st) {
+                                        u64 nq, i32 min_overlap, u32 *counts, bool unique_values, hipStream_t st) {
     if (nq == 0) return GTARS_OK;
     ProfScope p("k_igd_count_per_query", st);
-    hipLaunchKernelGGL(k_igd_count_per_query, dim3(stream_grid(nq, 256)), dim3(256), 0, st, v, qc, qs, qe,
-                       nq, min_overlap, counts);
+    if (unique_values)
+        hipLaunchKernelGGL(k_igd_count_per_query<true>, dim3(stream_grid(nq, 256)), dim3(256), 0, st, v, qc, qs, qe, nq, min_overlap, counts);
+    else
+        hipLaunchKernelGGL(k_igd_count_per_query<false>, dim3(stream_grid(nq, 256)), dim3(256), 0, st, v, qc, qs, qe, nq, min_overlap, counts);
     GT_HIP(hipGetLastError());
     return GTARS_OK;
 }
 
 gtars_status launch_igd_fill_pairs(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                    i32 min_overlap, const u64 *offsets, u32 *out_q, u32 *out_s,
-                                   hipStream_t st) {
+                                   bool unique_values, hipStream_t st) {
     if (nq == 0) return GTARS_OK;
     ProfScope p("k_igd_fill_pairs", st);
-    hipLaunchKernelGGL(k_igd_fill_pairs, dim3(stream_grid(nq, 256)), dim3(256), 0, st, v, qc, qs, qe, nq,
-                       min_overlap, offsets, out_q, out_s);
+    if (unique_values)
+        hipLaunchKernelGGL(k_igd_fill_pairs<true>, dim3(stream_grid(nq, 256)), dim3(256), 0, st, v, qc, qs, qe, nq, min_overlap, offsets, out_q, out_s);
+    else
+        hipLaunchKernelGGL(k_igd_fill_pairs<false>, dim3(stream_grid(nq, 256)), dim3(256), 0, st, v, qc, qs, qe, nq, min_overlap, offsets, out_q, out_s);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
+// ---------------------------------------------------------------- id histogram
+// bins[id] += 1 for every id < n_bins: the scatter-add of gtars-scoring's count matrices (fragment_scoring.rs:88-105,
+// CountMatrix::increment) -- one row of the matrix per call, the ids being the peaks hit by one file's probes.
+__global__ void __launch_bounds__(256)
+k_hist_u32(const u32 *__restrict__ ids, u64 n, u32 n_bins, u32 *__restrict__ bins) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u32 k = ids[i];
+        if (k < n_bins) atomicAdd(&bins[k], 1u);
+    }
+}
+
+gtars_status launch_hist_u32(const u32 *ids, u64 n, u32 n_bins, u32 *bins, hipStream_t st) {
+    if (n == 0 || n_bins == 0) return GTARS_OK;
+    ProfScope p("k_hist_u32", st);
+    hipLaunchKernelGGL(k_hist_u32, dim3(stream_grid(n, 256)), dim3(256), 0, st, ids, n, n_bins, bins);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
+// *dup = 1 if two neighbours of a SORTED array are equal
+__global__ void __launch_bounds__(256)
+k_has_adjacent_equal(const u32 *__restrict__ a, u64 n, u32 *__restrict__ dup) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride) bad |= a[i] == a[i - 1];
+    if (__any(bad) && (threadIdx.x & 63) == 0) *dup = 1u;
+}
+
+gtars_status launch_has_adjacent_equal(const u32 *a, u64 n, u32 *dup, hipStream_t st) {
+    if (n < 2) return GTARS_OK;
+    hipLaunchKernelGGL(k_has_adjacent_equal, dim3(stream_grid(n, 256)), dim3(256), 0, st, a, n, dup);
     GT_HIP(hipGetLastError());
     return GTARS_OK;
 }

@@ -38,7 +38,8 @@ class Igd:
         self.nbp = nbp
         self.file_info: List[FileInfo] = []
         self._chrom_ids: Dict[str, int] = {}
-        self._rec: List[Tuple[int, int, int, int, int]] = []
+        self._rec: List[Tuple[int, int, int, int, int]] = []   # records added one by one, not yet in a chunk
+        self._chunks: List[np.ndarray] = []                     # int64 [n, 5] blocks in insertion order
         self._engine: Optional[IgdIndex] = None
         self._db = None  # gtars_igddb_t* when built by the C++ host from BED files
 
@@ -51,12 +52,46 @@ class Igd:
         cid = self._chrom_ids.setdefault(chrom, len(self._chrom_ids))
         self._rec.append((cid, start, end, value, file_idx))
 
+    def _flush(self) -> None:
+        if self._rec:
+            self._chunks.append(np.asarray(self._rec, dtype=np.int64))
+            self._rec = []
+
+    def _add_columns(self, chrom_names: Sequence[str], chrom_ids: np.ndarray, starts: np.ndarray, ends: np.ndarray,
+                     values: np.ndarray, file_idx: int) -> Tuple[int, int]:
+        """``add`` for whole columns (i32 coordinates, the reference's ``as i32`` casts): keeps start >= 0, end >= 0,
+        start < end (igd.rs:114-116), returns (records kept, their total width)."""
+        if self._engine is not None:
+            raise AssertionError("Cannot add intervals after finalization")
+        s = np.asarray(starts).astype(np.uint32).view(np.int32).astype(np.int64)
+        e = np.asarray(ends).astype(np.uint32).view(np.int32).astype(np.int64)
+        keep = (s >= 0) & (e >= 0) & (s < e)
+        if not keep.any():
+            return 0, 0
+        self._flush()
+        # dictionary ids in first-seen order of the KEPT records, like add() would assign them
+        ids = np.asarray(chrom_ids)[keep]
+        first = np.unique(ids, return_index=True)
+        lut = np.zeros(len(chrom_names) if len(chrom_names) else 1, dtype=np.int64)
+        for cid in first[0][np.argsort(first[1])]:
+            lut[cid] = self._chrom_ids.setdefault(chrom_names[int(cid)], len(self._chrom_ids))
+        blk = np.empty((int(keep.sum()), 5), dtype=np.int64)
+        blk[:, 0] = lut[ids]
+        blk[:, 1] = s[keep]
+        blk[:, 2] = e[keep]
+        blk[:, 3] = np.asarray(values)[keep] if np.ndim(values) else values
+        blk[:, 4] = file_idx
+        self._chunks.append(blk)
+        return len(blk), int((blk[:, 2] - blk[:, 1]).sum())
+
     def finalize(self) -> None:
         if self._engine is not None:
             return
         n_files = len(self.file_info)
-        if self._rec:
-            a = np.asarray(self._rec, dtype=np.int64)
+        self._flush()
+        if self._chunks:
+            a = np.concatenate(self._chunks) if len(self._chunks) > 1 else self._chunks[0]
+            self._chunks = []
             n_files = max(n_files, int(a[:, 4].max()) + 1)
             self._engine = IgdIndex(a[:, 0], a[:, 1], a[:, 2], a[:, 4], a[:, 3], n_chrom=len(self._chrom_ids), n_files=n_files)
         else:
@@ -113,15 +148,14 @@ class Igd:
         """igd.rs:284-317"""
         self = cls()
         for file_idx, (filename, rs) in enumerate(sets):
-            names, ids, st, en = rs.chrom_names, rs.chrom_ids, rs.starts, rs.ends
-            count, total = 0, 0
-            for i in range(len(rs)):
-                if st[i] < en[i]:
-                    s, e = int(np.int32(st[i])), int(np.int32(en[i]))  # `as i32`
-                    self.add(names[int(ids[i])], s, e, 0, file_idx)
-                    count += 1
-                    total += e - s
-            self.file_info.append(FileInfo(filename, count, total / count if count else 0.0))
+            st, en = rs.starts, rs.ends
+            ok = st < en  # u32 comparison first (igd.rs:296), then `as i32` and Igd::add's own rule
+            count, total = self._add_columns(rs.chrom_names, rs.chrom_ids[ok], st[ok], en[ok], 0, file_idx)
+            # count / width are taken over the regions with start < end (igd.rs:297-306), i32-cast widths
+            s32 = st[ok].view(np.int32).astype(np.int64)
+            e32 = en[ok].view(np.int32).astype(np.int64)
+            n_ok = int(ok.sum())
+            self.file_info.append(FileInfo(filename, n_ok, float((e32 - s32).sum()) / n_ok if n_ok else 0.0))
         self.finalize()
         return self
 
@@ -132,9 +166,7 @@ class Igd:
         n = len(rs)
         st, en = rs.starts.astype(np.int64), rs.ends.astype(np.int64)
         self.file_info = [FileInfo("", n, float((en - st).mean()) if n else 0.0)]
-        names, ids = rs.chrom_names, rs.chrom_ids
-        for i in range(n):
-            self.add(names[int(ids[i])], int(np.int32(rs.starts[i])), int(np.int32(rs.ends[i])), i, 0)
+        self._add_columns(rs.chrom_names, rs.chrom_ids, rs.starts, rs.ends, np.arange(n, dtype=np.int64), 0)
         self.finalize()
         return self
 

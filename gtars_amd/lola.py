@@ -184,6 +184,11 @@ def fisher_pvalue(a: int, b: int, c: int, d: int, enrichment: bool = True) -> fl
     return float(hypergeom.cdf(a, n_pop, k_success, n_draws))
 
 
+def p_value_log(a: int, b: int, c: int, d: int, enrichment: bool = True) -> float:
+    """ContingencyTable::p_value_log (enrichment.rs:166-169): -log10(p + 1e-322)."""
+    return -math.log10(fisher_pvalue(a, b, c, d, enrichment) + 1e-322)
+
+
 def _brent(f, a: float, b: float, tol: float, max_iter: int) -> float:
     """enrichment.rs:400-486, statement for statement."""
     fa, fb = f(a), f(b)
@@ -334,12 +339,13 @@ def _apply_fdr(rows: List[dict]) -> None:
 # --------------------------------------------------------------------------- run_lola
 
 
-def _as_regions(x) -> List[Tuple[str, int, int]]:
+def _as_regions(x):
+    """What Igd.count_region_hits takes: a RegionSet goes through as columns (no per-region Python objects: a 1e6-region
+    universe is three numpy arrays), a {"chr", "start", "end"} dict becomes a RegionSet, anything else a list of tuples."""
     if isinstance(x, RegionSet):
-        names, ids, s, e = x.chrom_names, x.chrom_ids, x.starts, x.ends
-        return [(names[int(ids[i])], int(s[i]), int(e[i])) for i in range(len(x))]
+        return x
     if isinstance(x, dict):
-        return list(zip(x["chr"], x["start"], x["end"]))
+        return RegionSet.from_vectors(list(x["chr"]), list(x["start"]), list(x["end"]))
     return [(r[0], int(r[1]), int(r[2])) for r in x]
 
 
@@ -394,7 +400,7 @@ def run_lola(user_sets, universe, region_db: RegionDB, min_overlap: int = 1, dir
             if bv < 0 or cv < 0 or dv < 0:
                 pv_log, orr = 0.0, float("nan")
             else:
-                pv_log = -math.log10(fisher_pvalue(av, bv, cv, dv, enrichment) + 1e-322)
+                pv_log = p_value_log(av, bv, cv, dv, enrichment)
                 orr = odds_ratio(av, bv, cv, dv)
             rows.append({"userSet": us_idx, "dbSet": f, "pValueLog": pv_log, "oddsRatio": orr, "support": av,
                          "b": bv, "c": cv, "d": dv, "qValue": None,
@@ -416,3 +422,40 @@ def run_lola(user_sets, universe, region_db: RegionDB, min_overlap: int = 1, dir
             "meanRnk", "b", "c", "d", "description", "cellType", "tissue", "antibody", "treatment", "dataSource",
             "filename", "qValue", "size"]
     return {c: [r.get(c) for r in rows_all] for c in cols}
+
+
+def _rust_exp6(x: float) -> str:
+    """format!("{:.6e}", x): mantissa with six decimals, exponent without sign padding (1.000000e-5, 3.000000e0)."""
+    m, e = f"{x:.6e}".split("e")
+    return f"{m}e{int(e)}"
+
+
+def write_results_tsv(out, results: Dict[str, list]) -> None:
+    """write_results_tsv (gtars-lola/src/output.rs:191-244): R LOLA's writeCombinedEnrichment layout, 1-based set indices,
+    pValueLog / oddsRatio with 4 decimals, meanRnk with 2, qValue as %.6e or NA.  ``out``: a path or a text file object."""
+    own = isinstance(out, (str, os.PathLike))
+    f = open(out, "w", newline="") if own else out
+    try:
+        f.write("userSet\tdbSet\tcollection\tpValueLog\toddsRatio\tsupport\trnkPV\trnkOR\trnkSup\tmaxRnk\tmeanRnk\tb\tc\td\t"
+                "description\tcellType\ttissue\tantibody\ttreatment\tdataSource\tfilename\tqValue\tsize\n")
+        n = len(results["userSet"])
+
+        def txt(col, i):
+            v = results[col][i]
+            return "" if v is None else str(v)
+
+        def f4(v):
+            return "NaN" if math.isnan(v) else ("inf" if v == math.inf else ("-inf" if v == -math.inf else f"{v:.4f}"))
+
+        for i in range(n):
+            q = results["qValue"][i]
+            f.write("\t".join([
+                str(results["userSet"][i] + 1), str(results["dbSet"][i] + 1), txt("collection", i), f4(results["pValueLog"][i]),
+                f4(results["oddsRatio"][i]), str(results["support"][i]), str(results["rnkPV"][i]), str(results["rnkOR"][i]),
+                str(results["rnkSup"][i]), str(results["maxRnk"][i]), f"{results['meanRnk'][i]:.2f}", str(results["b"][i]),
+                str(results["c"][i]), str(results["d"][i]), txt("description", i), txt("cellType", i), txt("tissue", i),
+                txt("antibody", i), txt("treatment", i), txt("dataSource", i), txt("filename", i),
+                "NA" if q is None else _rust_exp6(q), str(results["size"][i])]) + "\n")
+    finally:
+        if own:
+            f.close()

@@ -6,18 +6,19 @@ RegionSet, peak id = first-seen rank of the (chr,start,end,rest) region, one Bit
 ATAC mode probes the cut sites  [start+4, start+5)  and the INVERTED interval  [end-5, end-6)
 (fragment_scoring.rs:58-84) -- the overlap test is applied to it unchanged, as in the reference
 (Interval::overlap, gtars-core/src/models/interval.rs:47-50); ChIP mode probes the fragment itself.
-All probes of all files go through ONE batched tokenization on the device; the scatter-add into the
-matrix is a bincount over (file, peak) pairs.
+Fragment files are read by the C++ in-place parser; every file's probes go through one batched tokenization on
+the device and their token ids are scatter-added into the file's row of a device-resident matrix.
 """
 from __future__ import annotations
 
+import ctypes as C
 import glob as _glob
-import gzip
 from typing import Dict, List, Sequence, Union
 
 import numpy as np
 
-from ._lib import UNKNOWN_CHROM
+from . import _lib
+from ._lib import UNKNOWN_CHROM, check, lib
 from .engine import OverlapIndex
 from .models import RegionSet
 
@@ -48,30 +49,35 @@ class ConsensusSet:
 
 
 def _read_fragments(path: str, cons: ConsensusSet):
-    """Fragment::from_str (gtars-core/src/models/fragments.rs:16-41): whitespace split, u32 start/end/support."""
-    opener = gzip.open if path.endswith(".gz") else open
-    chrom, start, end, barcodes = [], [], [], []
-    with opener(path, "rt") as f:
-        for line in f:
-            line = line.rstrip("\n")
-            if line.startswith("#"):
-                continue
-            p = line.split()
-            s, e = int(p[1]), int(p[2])
-            int(p[4])  # read_support must parse
-            if not (0 <= s <= 0xFFFFFFFF and 0 <= e <= 0xFFFFFFFF):
-                raise ValueError(f"bad fragment coordinates: {line}")
-            chrom.append(cons.chrom_id(p[0]))
-            start.append(s)
-            end.append(e)
-            barcodes.append(p[3])
-    return (np.asarray(chrom, dtype=np.uint32), np.asarray(start, dtype=np.int64), np.asarray(end, dtype=np.int64), barcodes)
+    """Fragment::from_str over a whole file (gtars-core/src/models/fragments.rs:16-41: whitespace split, u32 start / end /
+    read support, '#' lines skipped) through the C++ in-place parser; chromosome ids translated to the consensus set's.
+    -> (chrom u32, start u32, end u32, barcode ids u32, barcode names)."""
+    h = C.c_void_p()
+    if lib.gtars_fragments_read_strict(str(path).encode(), C.byref(h)) != 0:
+        raise ValueError(_lib.last_error())
+    try:
+        n = int(lib.gtars_fragments_len(h))
+
+        def col(fn):
+            p = fn(h)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+
+        fc, fs, fe, fb = (col(f) for f in (lib.gtars_fragments_chrom_ids, lib.gtars_fragments_starts, lib.gtars_fragments_ends,
+                                           lib.gtars_fragments_barcode_ids))
+        names = [lib.gtars_fragments_chrom_name(h, i).decode() for i in range(int(lib.gtars_fragments_n_chrom(h)))]
+        barcodes = [lib.gtars_fragments_barcode_name(h, i).decode() for i in range(int(lib.gtars_fragments_n_barcodes(h)))]
+    finally:
+        lib.gtars_fragments_free(h)
+    lut = np.asarray([cons.chrom_id(nm) for nm in names] or [UNKNOWN_CHROM], dtype=np.uint32)
+    return (lut[fc] if n else fc), fs, fe, fb, barcodes
 
 
 def _probes(start: np.ndarray, end: np.ndarray, mode: str):
+    """u32 wrapping arithmetic of the reference (fragment_scoring.rs:58-84); returns probes per fragment too."""
     if mode == "atac":
-        ns = (start + START_SHIFT) & 0xFFFFFFFF
-        ne = (end - END_SHIFT) & 0xFFFFFFFF
+        s64, e64 = start.astype(np.int64), end.astype(np.int64)
+        ns = (s64 + START_SHIFT) & 0xFFFFFFFF
+        ne = (e64 - END_SHIFT) & 0xFFFFFFFF
         qs = np.stack([ns, ne], axis=1).reshape(-1)
         qe = np.stack([(ns + 1) & 0xFFFFFFFF, (ne - 1) & 0xFFFFFFFF], axis=1).reshape(-1)
         return qs.astype(np.uint32), qe.astype(np.uint32), 2
@@ -82,41 +88,55 @@ def _probes(start: np.ndarray, end: np.ndarray, mode: str):
 
 def region_scoring_from_fragments(fragments: Union[str, Sequence[str]], consensus: Union[str, ConsensusSet],
                                   scoring_mode: str = "atac") -> np.ndarray:
-    """-> u32 count matrix [n_files, n_peaks] (rows in sorted glob / given order)."""
+    """-> u32 count matrix [n_files, n_peaks] (rows in sorted glob / given order).
+
+    Per file: the C++ parser yields the fragment columns, the probes are tokenized on the device
+    (``gtars_tokenize_device``) and the token ids are scatter-added into the file's row of the DEVICE-resident matrix
+    (``gtars_histogram_u32_device``); the matrix comes back to the host once, at the end."""
+    import torch
+
     files = sorted(_glob.glob(fragments)) if isinstance(fragments, str) else list(fragments)
     cons = consensus if isinstance(consensus, ConsensusSet) else ConsensusSet(consensus)
     mode = scoring_mode.lower()
     if mode not in ("atac", "chip"):
         raise ValueError(f"Invalid scoring mode: {scoring_mode}")
-    qc, qs, qe, row = [], [], [], []
+    n_peaks = len(cons)
+    if not files or n_peaks == 0:
+        return np.zeros((len(files), n_peaks), dtype=np.uint32)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+    mat = torch.zeros((len(files), n_peaks), dtype=torch.int32, device=dev)  # u32 counts, bit-identical
     for i, path in enumerate(files):
-        c, s, e, _ = _read_fragments(path, cons)
+        c, s, e, _, _ = _read_fragments(path, cons)
+        if len(c) == 0:
+            continue
         ps, pe, k = _probes(s, e, mode)
-        qc.append(np.repeat(c, k))
-        qs.append(ps)
-        qe.append(pe)
-        row.append(np.full(len(ps), i, dtype=np.int64))
-    mat = np.zeros((len(files), len(cons)), dtype=np.uint32)
-    if not files or not sum(len(x) for x in qc):
-        return mat
-    qc, qs, qe, row = (np.concatenate(x) for x in (qc, qs, qe, row))
-    offsets, ids = cons.index.tokenize(qc, qs, qe)
-    per_query = np.diff(offsets.astype(np.int64))
-    flat = np.repeat(row, per_query) * len(cons) + ids.astype(np.int64)
-    mat += np.bincount(flat, minlength=mat.size).reshape(mat.shape).astype(np.uint32)
-    return mat
+        d = [torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev) for x in (np.repeat(c, k), ps, pe)]
+        nq = d[0].numel()
+        offsets = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        ids = torch.empty(2 * nq + 1024, dtype=torch.int32, device=dev)
+        try:
+            h = cons.index.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(),
+                                           ids.numel(), stream, sync=True)
+        except _lib.CapacityError as err:  # more than two hits per probe on average: once more with the exact size
+            ids = torch.empty(err.needed, dtype=torch.int32, device=dev)
+            h = cons.index.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(),
+                                           ids.numel(), stream, sync=True)
+        check(lib.gtars_histogram_u32_device(ids.data_ptr(), h, n_peaks, mat[i].data_ptr(), stream))
+    return mat.cpu().numpy().view(np.uint32)
 
 
 def barcode_scoring_from_fragments(fragment_file: str, consensus: Union[str, ConsensusSet]) -> Dict[str, Dict[int, int]]:
     """fragment_scoring.rs:125-155: barcode -> {peak index -> count} (fragment itself as the probe)."""
     cons = consensus if isinstance(consensus, ConsensusSet) else ConsensusSet(consensus)
-    c, s, e, barcodes = _read_fragments(fragment_file, cons)
-    offsets, ids = cons.index.tokenize(c, s.astype(np.uint32), e.astype(np.uint32))
+    c, s, e, b, barcodes = _read_fragments(fragment_file, cons)
+    offsets, ids = cons.index.tokenize(c, s, e)
+    per_query = np.diff(offsets.astype(np.int64))
+    # (barcode, peak) pairs of all hits, counted by one sort
+    pair = np.repeat(b.astype(np.int64), per_query) * max(len(cons), 1) + ids.astype(np.int64)
+    uniq, cnt = np.unique(pair, return_counts=True)
     out: Dict[str, Dict[int, int]] = {}
-    for i, bc in enumerate(barcodes):
-        lo, hi = int(offsets[i]), int(offsets[i + 1])
-        if hi > lo:
-            d = out.setdefault(bc, {})
-            for v in ids[lo:hi]:
-                d[int(v)] = d.get(int(v), 0) + 1
+    n_peaks = max(len(cons), 1)
+    for u, k in zip(uniq.tolist(), cnt.tolist()):
+        out.setdefault(barcodes[u // n_peaks], {})[u % n_peaks] = k
     return out

@@ -142,6 +142,12 @@ gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qchrom
                                  uint64_t *offsets, uint32_t *ids, uint64_t ids_capacity,
                                  uint64_t *out_n);
 
+/* bins[id] += 1 for every id < n_bins (device pointers): the scatter-add of gtars-scoring's count matrices
+ * (CountMatrix::increment, gtars-scoring/src/fragment_scoring.rs:88-105) -- one matrix row per call, the ids being
+ * the token ids of one fragment file's probes (gtars_tokenize_device). */
+gtars_status gtars_histogram_u32_device(const uint32_t *d_ids, uint64_t n, uint32_t n_bins, uint32_t *d_bins,
+                                        void *stream);
+
 /* ------------------------------------------------------------------------
  * Counts / any / find with the optional min-overlap filter.
  * Replaces MultiChromOverlapper::count_overlaps / any_overlaps /

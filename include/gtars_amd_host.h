@@ -119,6 +119,9 @@ gtars_status gtars_tokenizer_encode_ids(const gtars_tokenizer_t *t, const uint32
  * ---------------------------------------------------------------------- */
 typedef struct gtars_fragments gtars_fragments_t;
 gtars_status gtars_fragments_read(const char *path, gtars_fragments_t **out);
+/* the same with the fifth field (read support) required to parse as u32, as Fragment::from_str does
+ * (gtars-core/src/models/fragments.rs:16-41: the parser behind gtars-scoring) */
+gtars_status gtars_fragments_read_strict(const char *path, gtars_fragments_t **out);
 void gtars_fragments_free(gtars_fragments_t *f);
 uint64_t gtars_fragments_len(const gtars_fragments_t *f);
 uint32_t gtars_fragments_n_chrom(const gtars_fragments_t *f);

@@ -755,3 +755,56 @@ def fragsplit(files_dir: str, mapping: OracleBarcodeMap, file_order: Optional[Se
                 if cluster is not None:
                     out[cluster].append(f"{chr_}\t{start}\t{end}\t{barcode}\t{support}\n")
     return out
+
+
+# ----------------------------------------------------------------------------- LOLA statistics (independent restatement)
+# gtars-lola computes its p-values with statrs 0.18 (Hypergeometric::sf / cdf), a third-party crate that is not part of
+# the reference checkout.  The product uses scipy.stats.hypergeom; this is a THIRD, independent evaluation of the same
+# published definition (sum of the hypergeometric pmf over the tail, every term from lgamma), so that the product's
+# p-values are checked against something other than themselves.  Parity with statrs itself stays unpinned: the reference
+# holds no numeric p-value literal, only the inequalities ported in tests/test_lola_stats_cpu.py.
+def _log_choose(n: int, k: int) -> float:
+    import math
+
+    return math.lgamma(n + 1) - math.lgamma(k + 1) - math.lgamma(n - k + 1)
+
+
+def hypergeom_log_pmf(k: int, n_pop: int, k_success: int, n_draws: int) -> float:
+    return _log_choose(k_success, k) + _log_choose(n_pop - k_success, n_draws - k) - _log_choose(n_pop, n_draws)
+
+
+def fisher_pvalue(a: int, b: int, c: int, d: int, enrichment: bool = True) -> float:
+    """ContingencyTable::fisher_pvalue (gtars-lola/src/enrichment.rs:19-53): P(X >= a) or P(X <= a), X hypergeometric."""
+    import math
+
+    n_pop, k_success, n_draws = a + b + c + d, a + b, a + c
+    if n_pop == 0 or k_success == 0 or n_draws == 0 or k_success > n_pop or n_draws > n_pop:
+        return 1.0
+    lo, hi = max(0, n_draws - (n_pop - k_success)), min(k_success, n_draws)
+    if enrichment:
+        if a == 0:
+            return 1.0
+        ks = range(max(a, lo), hi + 1)
+    else:
+        ks = range(lo, min(a, hi) + 1)
+    logs = [hypergeom_log_pmf(k, n_pop, k_success, n_draws) for k in ks]
+    if not logs:
+        return 0.0
+    m = max(logs)
+    return min(1.0, math.exp(m) * math.fsum(math.exp(v - m) for v in logs))
+
+
+def bh_qvalues(p_value_logs: Sequence[float]) -> List[float]:
+    """apply_fdr_correction for ONE user set (gtars-lola/src/output.rs:35-113), results in input order."""
+    n = len(p_value_logs)
+    order = sorted(range(n), key=lambda i: -p_value_logs[i])  # stable, like sort_by
+    p = [0.0 if p_value_logs[i] == float("inf") else 10.0 ** (-p_value_logs[i]) for i in order]
+    q = [0.0] * n
+    if n:
+        q[n - 1] = min(p[n - 1] * n / n, 1.0)
+        for i in range(n - 2, -1, -1):
+            q[i] = min(min(p[i] * n / (i + 1), q[i + 1]), 1.0)
+    out = [0.0] * n
+    for j, i in enumerate(order):
+        out[i] = q[j]
+    return out

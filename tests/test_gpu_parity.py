@@ -824,3 +824,43 @@ def test_key_space_wider_than_32_bits(ga):
     assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
     assert names & {"k_tok_lds", "k_tok_wave"}, names
     assert np.array_equal(g.count_overlaps(qc, qs, qe), o.count_overlaps(qc, qs, qe))
+
+
+def test_dense_database_hundreds_of_hits_per_query(ga):
+    """A ChIP-like dense database: 500+ hits per query.  The paths that used to be quadratic in the hits of a query --
+    per-segment sort + unique (IndexedRegionSet::find_overlaps), the per-query binary IGD count, the "first occurrence
+    of a value" walk of find_overlaps_regionset / count_overlaps_per_query -- stay exact: heap sort beyond 24 hits,
+    pme_file for min_overlap == 1 (the scanned-prefix look-up for min_overlap > 1), values known to be distinct
+    (from_single_region_set) or not (a database whose values repeat)."""
+    rng = np.random.default_rng(2024)
+    n, span = 40_000, 60_000
+    c = np.zeros(n, dtype=np.int64)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 2_000, n)
+    qn = 300
+    qc = np.zeros(qn, dtype=np.int64)
+    qs = rng.integers(0, span, qn)
+    qe = qs + rng.integers(100, 1_500, qn)
+    # IndexedRegionSet: sorted unique source indices per query
+    for kind in BOTH:
+        g, o = _pair(ga, c, s, e, n_chrom=1, kind=kind)
+        og, ig = g.find_overlap_indices(qc, qs, qe)
+        oo, io = o.irs_find_overlaps(c, s, e, qc, qs, qe)
+        assert og.tolist() == oo.tolist() and ig.tolist() == io.tolist()
+        assert np.diff(og.astype(np.int64)).max() >= 500
+    # IGD, distinct values (value = source index): pairs in the reference's walk order, per-query counts
+    f = rng.integers(0, 7, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=1, n_files=7)
+    for mo in (1, 40):
+        gq, gs = g.find_overlaps_regionset(qc, qs, qe, mo)
+        oq, os_ = o.find_overlaps_regionset(qc, qs, qe, mo)
+        assert gq.tolist() == oq.tolist() and gs.tolist() == os_.tolist()
+        assert g.count_overlaps_per_query(qc, qs, qe, mo).tolist() == o.count_overlaps_per_query(qc, qs, qe, mo).tolist()
+        assert g.count_region_hits(qc, qs, qe, mo).tolist() == o.count_region_hits(qc, qs, qe, mo, n_files=7).tolist()
+        assert g.count_set_overlaps(qc, qs, qe, mo).tolist() == o.count_set_overlaps(qc, qs, qe, mo, n_files=7).tolist()
+    # values that repeat: the de-duplicating walk
+    g2, o2 = _igd_pair(ga, c, s, e, f, rng.integers(0, 5_000, n), n_chrom=1, n_files=7)
+    gq, gs = g2.find_overlaps_regionset(qc[:60], qs[:60], qe[:60], 1)
+    oq, os_ = o2.find_overlaps_regionset(qc[:60], qs[:60], qe[:60], 1)
+    assert gq.tolist() == oq.tolist() and gs.tolist() == os_.tolist()
+    assert g2.count_overlaps_per_query(qc[:60], qs[:60], qe[:60], 1).tolist() == o2.count_overlaps_per_query(qc[:60], qs[:60], qe[:60], 1).tolist()

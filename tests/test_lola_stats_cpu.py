@@ -1,0 +1,200 @@
+"""The statistics tail of LOLA (host f64): every known-answer / property test the reference holds for it, ported:
+gtars-lola/src/output.rs:245-531 (BH-FDR, TSV writer, column pivot) and gtars-lola/src/enrichment.rs:490-710 (odds ratio,
+Fisher p-values, ranking), plus an independent evaluation of the p-values (oracle.fisher_pvalue: pmf tail sums from
+lgamma) against the product's (scipy.stats.hypergeom).  statrs 0.18 -- what the reference calls -- is absent, so parity
+of pValueLog with the reference itself stays unpinned beyond these tests; the integer cells and everything derived from
+them by exact rules (ranks, q-values given p-values) are pinned."""
+import io
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from gtars_amd import lola
+
+
+def _rows(pvls, user_sets=None):
+    user_sets = user_sets or [0] * len(pvls)
+    return [{"userSet": u, "dbSet": i, "pValueLog": p, "oddsRatio": 1.0, "support": 10, "qValue": None}
+            for i, (u, p) in enumerate(zip(user_sets, pvls))]
+
+
+# ---- output.rs:271-305 test_fdr_basic
+def test_fdr_basic():
+    rows = _rows([3.0, 2.0, 1.0])
+    lola._apply_fdr(rows)
+    q = [r["qValue"] for r in rows]
+    assert all(v is not None for v in q)
+    for r in rows:
+        assert r["qValue"] >= 10.0 ** (-r["pValueLog"]) - 1e-10
+    assert q[0] <= q[1] + 1e-10 and q[1] <= q[2] + 1e-10
+    # the exact BH values: p = (1e-3, 1e-2, 1e-1), n = 3 -> q = (min(3e-3, ...), min(1.5e-2, ...), 1e-1)
+    assert q == pytest.approx([0.003, 0.015, 0.1], rel=1e-12)
+    assert q == oracle.bh_qvalues([3.0, 2.0, 1.0])
+
+
+# ---- output.rs:307-323 test_fdr_multiple_user_sets: corrected per user set
+def test_fdr_multiple_user_sets():
+    rows = _rows([5.0, 2.0, 3.0, 1.0], [0, 0, 1, 1])
+    lola._apply_fdr(rows)
+    assert all(r["qValue"] is not None for r in rows)
+    assert [rows[0]["qValue"], rows[1]["qValue"]] == oracle.bh_qvalues([5.0, 2.0])
+    assert [rows[2]["qValue"], rows[3]["qValue"]] == oracle.bh_qvalues([3.0, 1.0])
+    assert rows[0]["qValue"] == pytest.approx(2e-5) and rows[3]["qValue"] == pytest.approx(0.1)
+
+
+# ---- output.rs:325-333 test_fdr_single_result
+def test_fdr_single_result():
+    rows = _rows([5.0])
+    lola._apply_fdr(rows)
+    assert abs(rows[0]["qValue"] - 1e-5) < 1e-10
+
+
+# ---- output.rs:335-339 test_fdr_empty
+def test_fdr_empty():
+    lola._apply_fdr([])
+
+
+# ---- output.rs:341-366 test_fdr_identical_pvalues
+def test_fdr_identical_pvalues():
+    rows = _rows([3.0] * 4)
+    lola._apply_fdr(rows)
+    for r in rows:
+        assert r["qValue"] is not None and 1e-3 - 1e-10 <= r["qValue"] <= 1.0
+    assert [r["qValue"] for r in rows] == pytest.approx([1e-3] * 4, rel=1e-12)  # p * n / rank capped by the last: p
+
+
+# ---- output.rs:368-407 test_fdr_preserves_order
+def test_fdr_preserves_order():
+    rows = _rows([10.0, 7.0, 5.0, 3.0, 2.0, 1.0, 0.5, 0.1])
+    lola._apply_fdr(rows)
+    srt = sorted(rows, key=lambda r: -r["pValueLog"])
+    for a, b in zip(srt, srt[1:]):
+        assert b["qValue"] >= a["qValue"] - 1e-10
+    assert [r["qValue"] for r in rows] == oracle.bh_qvalues([r["pValueLog"] for r in rows])
+
+
+# ---- output.rs:409-443 test_fdr_single_very_significant
+def test_fdr_single_very_significant():
+    rows = _rows([20.0, 0.1, 0.05, 0.01, 0.0])
+    lola._apply_fdr(rows)
+    assert rows[0]["qValue"] < 0.05
+    for r in rows[1:]:
+        assert r["qValue"] >= 10.0 ** (-r["pValueLog"]) - 1e-10
+    assert rows[4]["qValue"] == 1.0  # p = 1
+
+
+def test_fdr_infinite_pvalue_log_is_p_zero():
+    rows = _rows([float("inf"), 1.0])  # output.rs:74-78: underflowed p-value
+    lola._apply_fdr(rows)
+    assert rows[0]["qValue"] == 0.0 and rows[1]["qValue"] == pytest.approx(0.1)
+
+
+def _columns(rows):
+    cols = ["userSet", "dbSet", "collection", "pValueLog", "oddsRatio", "support", "rnkPV", "rnkOR", "rnkSup", "maxRnk", "meanRnk",
+            "b", "c", "d", "description", "cellType", "tissue", "antibody", "treatment", "dataSource", "filename", "qValue", "size"]
+    return {c: [r.get(c) for r in rows] for c in cols}
+
+
+def _full_rows(pvls):
+    rows = _rows(pvls)
+    for r in rows:
+        r.update({"rnkPV": 1, "rnkOR": 1, "rnkSup": 1, "maxRnk": 1, "meanRnk": 1.0, "b": 5, "c": 5, "d": 100,
+                  "filename": f"file{r['dbSet']}.bed", "size": 0})
+    return rows
+
+
+# ---- output.rs:445-465 test_write_tsv, :467-475 test_write_tsv_no_qvalue
+def test_write_tsv():
+    rows = _full_rows([5.0, 2.0])
+    lola._apply_fdr(rows)
+    buf = io.StringIO()
+    lola.write_results_tsv(buf, _columns(rows))
+    out = buf.getvalue()
+    assert out.startswith("userSet\tdbSet\tcollection\tpValueLog\t")
+    lines = out.splitlines()
+    assert len(lines) == 3
+    assert lines[1].startswith("1\t1\t") and lines[2].startswith("1\t2\t")  # 1-based indices
+    f = lines[1].split("\t")
+    assert f[3] == "5.0000" and f[4] == "1.0000" and f[10] == "1.00" and f[20] == "file0.bed"
+    assert f[21] == "2.000000e-5"  # {:.6e}: Rust writes the exponent without padding (q = 1e-5 * 2 / 1)
+    assert lines[2].split("\t")[21] == "1.000000e-2"
+    rows = _full_rows([5.0])
+    buf = io.StringIO()
+    lola.write_results_tsv(buf, _columns(rows))
+    assert "NA" in buf.getvalue()
+
+
+# ---- enrichment.rs:498-537: odds ratio (CMLE as R's fisher.test) and its boundaries
+def test_odds_ratio_kats():
+    assert abs(lola.odds_ratio(10, 20, 30, 40) - 0.6693434) < 1e-3  # R: fisher.test(matrix(c(10,30,20,40), nrow=2))$estimate
+    assert lola.odds_ratio(10, 0, 5, 100) == float("inf")
+    assert lola.odds_ratio(0, 5, 10, 100) == 0.0
+
+
+# ---- enrichment.rs:538-598: Fisher's exact test, one-sided
+def test_fisher_enrichment_significant():
+    assert lola.fisher_pvalue(50, 10, 5, 1000, True) < 0.001
+
+
+def test_fisher_enrichment_not_significant():
+    assert lola.fisher_pvalue(1, 100, 100, 1000, True) > 0.05
+
+
+def test_fisher_depletion():
+    assert lola.fisher_pvalue(1, 100, 100, 10, False) < 0.05
+
+
+def test_fisher_edge_cases():
+    assert lola.fisher_pvalue(0, 0, 0, 0, True) == 1.0
+    assert lola.fisher_pvalue(0, 50, 50, 100, True) == 1.0
+
+
+# ---- enrichment.rs:600-636: p_value_log
+def test_p_value_log():
+    pvl = lola.p_value_log(5, 15, 10, 100, True)
+    assert pvl > 0.0
+    assert abs(pvl - -math.log10(lola.fisher_pvalue(5, 15, 10, 100, True))) < 1e-10
+
+
+def test_p_value_log_extreme():
+    pvl = lola.p_value_log(50, 10, 5, 1000, True)
+    assert pvl > 30.0 and math.isfinite(pvl)
+
+
+def test_fisher_pvalues_against_an_independent_evaluation():
+    """product (scipy.stats.hypergeom) vs oracle (pmf tail sums from lgamma): relative 1e-9 over a grid of tables,
+    both directions, down to p ~ 1e-60."""
+    rng = np.random.default_rng(5)
+    tables = [(5, 15, 10, 100), (50, 10, 5, 1000), (1, 100, 100, 1000), (1, 100, 100, 10), (0, 5, 5, 100), (3, 0, 0, 7),
+              (200, 50, 30, 5000), (1, 1, 2, 6)]
+    tables += [tuple(int(v) for v in rng.integers(0, 400, 4)) for _ in range(200)]
+    for a, b, c, d in tables:
+        for enr in (True, False):
+            got, exp = lola.fisher_pvalue(a, b, c, d, enr), oracle.fisher_pvalue(a, b, c, d, enr)
+            assert got == pytest.approx(exp, rel=1e-9, abs=1e-300), (a, b, c, d, enr)
+
+
+# ---- enrichment.rs:642-708 test_ranking
+def test_ranking():
+    rows = [{"userSet": 0, "dbSet": 0, "pValueLog": 5.0, "oddsRatio": 2.0, "support": 100},
+            {"userSet": 0, "dbSet": 1, "pValueLog": 10.0, "oddsRatio": 1.0, "support": 200},
+            {"userSet": 0, "dbSet": 2, "pValueLog": 3.0, "oddsRatio": 5.0, "support": 50}]
+    lola._rank_results(rows)
+    assert [r["rnkPV"] for r in rows] == [2, 1, 3]
+    assert [r["rnkOR"] for r in rows] == [2, 3, 1]
+    assert [r["rnkSup"] for r in rows] == [2, 1, 3]
+    assert [r["maxRnk"] for r in rows] == [2, 3, 3]
+    assert rows[0]["meanRnk"] == pytest.approx(2.0) and rows[1]["meanRnk"] == pytest.approx(5.0 / 3.0)
+    assert rows[2]["meanRnk"] == pytest.approx(7.0 / 3.0)
+
+
+def test_ranking_ties_and_nan():
+    # ties.method = "min" (enrichment.rs:310-351), NaN odds ratios rank last and tie with each other (f64_tied)
+    rows = [{"userSet": 0, "dbSet": i, "pValueLog": p, "oddsRatio": o, "support": s} for i, (p, o, s) in
+            enumerate([(5.0, 2.0, 10), (5.0, float("nan"), 10), (1.0, 3.0, 20), (0.5, float("nan"), 10)])]
+    lola._rank_results(rows)
+    assert [r["rnkPV"] for r in rows] == [1, 1, 3, 4]
+    assert [r["rnkOR"] for r in rows] == [2, 3, 1, 3]
+    assert [r["rnkSup"] for r in rows] == [2, 2, 1, 2]
