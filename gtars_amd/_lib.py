@@ -191,6 +191,9 @@ _HOST_SIG = {
     "gtars_igddb_chrom_name": (cstr, [vp, u32]),
     "gtars_igddb_engine": (vp, [vp]),
     "gtars_igddb_count_regionset": (C.c_int, [vp, vp, i32, C.c_int, vp]),
+    "gtars_igddb_from_arrays": (C.c_int, [vp, u32, vp, vp, vp, vp, vp, u64, vp, vp, vp, u32, pp]),
+    "gtars_igddb_save": (C.c_int, [vp, cstr, i32]),
+    "gtars_igddb_load": (C.c_int, [cstr, pp, C.POINTER(C.c_int32)]),
 }
 
 # every symbol the headers declare must resolve -- fail loudly otherwise

@@ -1728,6 +1728,214 @@ gtars_status gtars_igddb_count_regionset(const gtars_igddb_t *db, const gtars_re
 
 }  // extern "C"
 
+// ===================================================================== .igd files
+extern "C" {
+
+gtars_status gtars_igddb_from_arrays(const char *const *chrom_names, uint32_t n_chrom, const uint32_t *chrom,
+                                     const int32_t *start, const int32_t *end, const int32_t *value,
+                                     const uint32_t *file_idx, uint64_t n, const char *const *file_names,
+                                     const uint32_t *num_regions, const double *avg_width, uint32_t n_files,
+                                     gtars_igddb_t **out) {
+    if (!out || (n_chrom && !chrom_names) || (n && (!chrom || !start || !end || !file_idx)))
+        return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    std::unique_ptr<gtars_igddb> db(new gtars_igddb());
+    for (uint32_t c = 0; c < n_chrom; ++c)
+        if (db->chroms.get_or_add(chrom_names[c] ? chrom_names[c] : "") != c)
+            return fail(GTARS_ERR_INVALID_ARG, "duplicate chromosome name");
+    uint32_t nf = n_files;
+    for (uint64_t i = 0; i < n; ++i) nf = std::max(nf, file_idx[i] + 1);
+    for (uint32_t f = 0; f < n_files; ++f)
+        db->files.push_back({file_names && file_names[f] ? file_names[f] : "", num_regions ? num_regions[f] : 0u,
+                             avg_width ? avg_width[f] : 0.0});
+    gtars_status st = gtars_igd_build(chrom, start, end, value, file_idx, n, n_chrom, nf, &db->igd);
+    if (st) return st;
+    *out = db.release();
+    return GTARS_OK;
+}
+
+gtars_status gtars_igddb_save(const gtars_igddb_t *db, const char *path, int32_t nbp) {
+    if (!db || !path) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    if (nbp <= 0) nbp = 16384;
+    const uint64_t n = gtars_igd_len(db->igd);
+    std::vector<uint32_t> c(n), f(n);
+    std::vector<int32_t> s(n), e(n), v(n);
+    gtars_status st = gtars_igd_export(db->igd, c.data(), s.data(), e.data(), v.data(), f.data());
+    if (st) return st;
+    const uint32_t n_ctg = (uint32_t)db->chroms.names.size();
+    // tiles per contig = highest tile any record touches + 1 (Igd::add grows the tile vector, igd.rs:135-150)
+    std::vector<int32_t> n_tiles(n_ctg, 0);
+    for (uint64_t i = 0; i < n; ++i) n_tiles[c[i]] = std::max(n_tiles[c[i]], (e[i] - 1) / nbp + 1);
+    std::vector<uint64_t> toff(n_ctg + 1, 0);
+    for (uint32_t k = 0; k < n_ctg; ++k) toff[k + 1] = toff[k] + (uint64_t)n_tiles[k];
+    // the stored order is (contig, start, insertion); a tile's records are those that touch it, in that order
+    std::vector<int32_t> counts(toff[n_ctg], 0);
+    for (uint64_t i = 0; i < n; ++i)
+        for (int32_t t = s[i] / nbp; t <= (e[i] - 1) / nbp; ++t) counts[toff[c[i]] + (uint64_t)t]++;
+    std::vector<uint64_t> pos(counts.size() + 1, 0);
+    for (size_t t = 0; t < counts.size(); ++t) pos[t + 1] = pos[t] + (uint64_t)counts[t];
+    std::vector<int32_t> rec(pos.back() * 4);
+    {
+        std::vector<uint64_t> fill(pos.begin(), pos.end() - 1);
+        for (uint64_t i = 0; i < n; ++i)
+            for (int32_t t = s[i] / nbp; t <= (e[i] - 1) / nbp; ++t) {
+                int32_t *r = &rec[fill[toff[c[i]] + (uint64_t)t]++ * 4];
+                r[0] = (int32_t)f[i];
+                r[1] = s[i];
+                r[2] = e[i];
+                r[3] = v[i];
+            }
+    }
+    const std::string p = path;
+    {
+        const std::string parent = parent_dir(p);
+        std::string acc;
+        for (size_t i = 0; i <= parent.size(); ++i) {
+            if ((i == parent.size() || parent[i] == '/') && !acc.empty()) (void)mkdir(acc.c_str(), 0777);
+            if (i < parent.size()) acc.push_back(parent[i]);
+        }
+    }
+    FILE *fh = fopen(p.c_str(), "wb");
+    if (!fh) return fail(GTARS_ERR_IO, "cannot create " + p + ": " + strerror(errno));
+    const int32_t hdr[3] = {nbp, 1, (int32_t)n_ctg};
+    bool ok = fwrite(hdr, 4, 3, fh) == 3;
+    ok = ok && (n_ctg == 0 || fwrite(n_tiles.data(), 4, n_ctg, fh) == n_ctg);
+    ok = ok && (counts.empty() || fwrite(counts.data(), 4, counts.size(), fh) == counts.size());
+    for (uint32_t k = 0; ok && k < n_ctg; ++k) {
+        char name[40] = {0};
+        memcpy(name, db->chroms.names[k].data(), std::min<size_t>(40, db->chroms.names[k].size()));
+        ok = fwrite(name, 1, 40, fh) == 40;
+    }
+    ok = ok && (rec.empty() || fwrite(rec.data(), 4, rec.size(), fh) == rec.size());
+    ok = (fclose(fh) == 0) && ok;
+    if (!ok) return fail(GTARS_ERR_IO, "write to " + p + " failed");
+    // companion .tsv: Path::with_extension("tsv")
+    const std::string stem_path = (parent_dir(p).empty() ? "" : parent_dir(p) + "/") + file_stem(p);
+    FILE *th = fopen((stem_path + ".tsv").c_str(), "w");
+    if (!th) return fail(GTARS_ERR_IO, "cannot create " + stem_path + ".tsv");
+    fprintf(th, "Index\tFile\tNumber of Regions\tAvg size\n");
+    for (size_t i = 0; i < db->files.size(); ++i)
+        fprintf(th, "%zu\t%s\t%u\t%.2f\n", i, db->files[i].filename.c_str(), db->files[i].num_regions, db->files[i].avg_width);
+    fclose(th);
+    return GTARS_OK;
+}
+
+gtars_status gtars_igddb_load(const char *path, gtars_igddb_t **out, int32_t *nbp_out) {
+    if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    FILE *fh = fopen(path, "rb");
+    if (!fh) return fail(GTARS_ERR_IO, std::string("Failed to open file: \"") + path + "\": " + strerror(errno));
+    std::string data;
+    {
+        std::vector<char> buf(1 << 20);
+        size_t k;
+        while ((k = fread(buf.data(), 1, buf.size(), fh)) > 0) data.append(buf.data(), k);
+        fclose(fh);
+    }
+    auto need = [&](size_t pos, size_t bytes) { return pos + bytes <= data.size(); };
+    if (!need(0, 12)) return fail(GTARS_ERR_PARSE, "truncated .igd header");
+    int32_t hdr[3];
+    memcpy(hdr, data.data(), 12);
+    const int32_t nbp = hdr[0], g_type = hdr[1], n_ctg = hdr[2];
+    if (nbp <= 0 || n_ctg < 0 || (g_type != 0 && g_type != 1)) return fail(GTARS_ERR_PARSE, "bad .igd header");
+    size_t pos = 12;
+    if (!need(pos, (size_t)n_ctg * 4)) return fail(GTARS_ERR_PARSE, "truncated .igd (tile counts)");
+    std::vector<int32_t> n_tiles(n_ctg);
+    memcpy(n_tiles.data(), data.data() + pos, (size_t)n_ctg * 4);
+    pos += (size_t)n_ctg * 4;
+    uint64_t total_tiles = 0;
+    for (int32_t t : n_tiles) {
+        if (t < 0) return fail(GTARS_ERR_PARSE, "bad .igd tile count");
+        total_tiles += (uint64_t)t;
+    }
+    if (!need(pos, total_tiles * 4)) return fail(GTARS_ERR_PARSE, "truncated .igd (record counts)");
+    std::vector<int32_t> counts(total_tiles);
+    memcpy(counts.data(), data.data() + pos, total_tiles * 4);
+    pos += total_tiles * 4;
+    std::vector<std::string> names;
+    if (!need(pos, (size_t)n_ctg * 40)) return fail(GTARS_ERR_PARSE, "truncated .igd (contig names)");
+    for (int32_t k = 0; k < n_ctg; ++k) {
+        const char *nm = data.data() + pos + (size_t)k * 40;
+        names.emplace_back(nm, strnlen(nm, 40));
+    }
+    pos += (size_t)n_ctg * 40;
+    const size_t w = g_type == 0 ? 3 : 4;
+    uint64_t nrec = 0;
+    for (int32_t cnt : counts) {
+        if (cnt < 0) return fail(GTARS_ERR_PARSE, "bad .igd record count");
+        nrec += (uint64_t)cnt;
+    }
+    if (!need(pos, nrec * w * 4)) return fail(GTARS_ERR_PARSE, "truncated .igd (records)");
+    std::vector<uint32_t> c, f;
+    std::vector<int32_t> s, e, v;
+    {
+        const char *rp = data.data() + pos;
+        uint64_t tile = 0;
+        for (int32_t k = 0; k < n_ctg; ++k)
+            for (int32_t t = 0; t < n_tiles[k]; ++t, ++tile)
+                for (int32_t r = 0; r < counts[tile]; ++r, rp += w * 4) {
+                    int32_t rr[4] = {0, 0, 0, 0};
+                    memcpy(rr, rp, w * 4);
+                    if (rr[1] / nbp != t) continue;  // a replica: the record starts in an earlier tile
+                    c.push_back((uint32_t)k);
+                    f.push_back((uint32_t)rr[0]);
+                    s.push_back(rr[1]);
+                    e.push_back(rr[2]);
+                    v.push_back(rr[3]);
+                }
+    }
+    std::unique_ptr<gtars_igddb> db(new gtars_igddb());
+    for (const std::string &nm : names) db->chroms.get_or_add(nm);
+    // companion .tsv (igd.rs:386-410): Index, File, Number of Regions, Avg size; unparsable numbers read as 0
+    {
+        const std::string p = path;
+        const std::string tsv = (parent_dir(p).empty() ? "" : parent_dir(p) + "/") + file_stem(p) + ".tsv";
+        std::string text, err;
+        if (is_regular_file(tsv) && read_all(tsv + "", text, err)) {
+            size_t lp = 0, li = 0;
+            while (lp < text.size()) {
+                size_t nl = text.find('\n', lp);
+                if (nl == std::string::npos) nl = text.size();
+                std::string line = text.substr(lp, nl - lp);
+                lp = nl + 1;
+                if (li++ == 0) continue;
+                std::vector<std::string> fld;
+                size_t a = 0;
+                for (;;) {
+                    const size_t t = line.find('\t', a);
+                    fld.push_back(line.substr(a, t == std::string::npos ? std::string::npos : t - a));
+                    if (t == std::string::npos) break;
+                    a = t + 1;
+                }
+                if (fld.size() < 4) continue;
+                auto trim = [](std::string x) {
+                    size_t b = 0, e2 = x.size();
+                    while (b < e2 && is_ws(x[b])) ++b;
+                    while (e2 > b && is_ws(x[e2 - 1])) --e2;
+                    return x.substr(b, e2 - b);
+                };
+                uint32_t nr = 0;
+                const std::string nrs = trim(fld[2]);
+                if (!parse_u32_view(nrs.data(), nrs.size(), nr)) nr = 0;
+                char *endp = nullptr;
+                const std::string aws = trim(fld[3]);
+                double aw = strtod(aws.c_str(), &endp);
+                if (endp == aws.c_str() || *endp) aw = 0.0;
+                db->files.push_back({trim(fld[1]), nr, aw});
+            }
+        }
+    }
+    uint32_t nf = (uint32_t)db->files.size();
+    for (uint32_t x : f) nf = std::max(nf, x + 1);
+    gtars_status st = gtars_igd_build(c.data(), s.data(), e.data(), v.data(), f.data(), c.size(), (uint32_t)n_ctg, nf, &db->igd);
+    if (st) return st;
+    if (nbp_out) *nbp_out = nbp;
+    *out = db.release();
+    return GTARS_OK;
+}
+
+}  // extern "C"
+
 // ===================================================================== gtars-fragsplit
 namespace {
 

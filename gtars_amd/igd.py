@@ -85,19 +85,41 @@ class Igd:
         return len(blk), int((blk[:, 2] - blk[:, 1]).sum())
 
     def finalize(self) -> None:
+        """Igd::finalize (igd.rs:157-167): the records go to the device through ``gtars_igddb_from_arrays``; from here on
+        the database is the same C handle the BED / .igd loaders produce."""
         if self._engine is not None:
             return
-        n_files = len(self.file_info)
         self._flush()
         if self._chunks:
             a = np.concatenate(self._chunks) if len(self._chunks) > 1 else self._chunks[0]
             self._chunks = []
-            n_files = max(n_files, int(a[:, 4].max()) + 1)
-            self._engine = IgdIndex(a[:, 0], a[:, 1], a[:, 2], a[:, 4], a[:, 3], n_chrom=len(self._chrom_ids), n_files=n_files)
         else:
-            z = np.zeros(0, dtype=np.int64)
-            self._engine = IgdIndex(z, z, z, z, z, n_chrom=max(len(self._chrom_ids), 0), n_files=n_files)
-        self._n_files_engine = n_files
+            a = np.zeros((0, 5), dtype=np.int64)
+        names = [n for n, _ in sorted(self._chrom_ids.items(), key=lambda kv: kv[1])]
+        c = np.ascontiguousarray(a[:, 0], dtype=np.uint32)
+        st, en, va = (np.ascontiguousarray(a[:, k], dtype=np.int32) for k in (1, 2, 3))
+        fi = np.ascontiguousarray(a[:, 4], dtype=np.uint32)
+        narr, _k1 = cstr_array(names)
+        farr, _k2 = cstr_array([f.filename for f in self.file_info])
+        nreg = np.asarray([f.num_regions for f in self.file_info] or [0], dtype=np.uint32)
+        avgw = np.asarray([f.avg_region_width for f in self.file_info] or [0.0], dtype=np.float64)
+        h = C.c_void_p()
+        check(lib.gtars_igddb_from_arrays(C.cast(narr, C.c_void_p), len(names), ptr(c), ptr(st), ptr(en), ptr(va), ptr(fi), len(c),
+                                          C.cast(farr, C.c_void_p), ptr(nreg), ptr(avgw), len(self.file_info), C.byref(h)))
+        self._adopt(h)
+
+    def _adopt(self, h) -> None:
+        self._db = h
+        nf = int(lib.gtars_igddb_n_files(h))
+        self._engine = IgdIndex.__new__(IgdIndex)
+        self._engine._h = C.c_void_p(lib.gtars_igddb_engine(h))
+        self._engine.n_files = int(lib.gtars_igd_n_files(self._engine._h))
+        self._engine.n_chrom = int(lib.gtars_igddb_n_contigs(h))
+        self._engine.close = lambda: None  # borrowed from the db handle
+        self._n_files_engine = self._engine.n_files
+        if not self.file_info:
+            self.file_info = [FileInfo(dec(lib.gtars_igddb_file_name(h, i)), int(lib.gtars_igddb_file_num_regions(h, i)),
+                                       float(lib.gtars_igddb_file_avg_width(h, i))) for i in range(nf)]
 
     @classmethod
     def from_bed_files(cls, paths: Iterable[str]) -> "Igd":
@@ -114,18 +136,9 @@ class Igd:
         return cls._from_db(h)
 
     @classmethod
-    def _from_db(cls, h) -> "Igd":
-        self = cls()
-        self._db = h
-        nf = int(lib.gtars_igddb_n_files(h))
-        self.file_info = [FileInfo(dec(lib.gtars_igddb_file_name(h, i)), int(lib.gtars_igddb_file_num_regions(h, i)),
-                                   float(lib.gtars_igddb_file_avg_width(h, i))) for i in range(nf)]
-        self._engine = IgdIndex.__new__(IgdIndex)
-        self._engine._h = C.c_void_p(lib.gtars_igddb_engine(h))
-        self._engine.n_files = nf
-        self._engine.n_chrom = int(lib.gtars_igddb_n_contigs(h))
-        self._engine.close = lambda: None  # borrowed from the db handle
-        self._n_files_engine = nf
+    def _from_db(cls, h, nbp: int = 16384) -> "Igd":
+        self = cls(nbp)
+        self._adopt(h)
         return self
 
     @classmethod
@@ -185,104 +198,18 @@ class Igd:
         return c, s, e, v, f
 
     def save(self, path: str) -> None:
-        """Igd::save (igd.rs:425-486): LE i32 nbp, gType = 1, nCtg; tiles per contig; counts per tile;
-        40-byte NUL-padded names; 16-byte records {idx, start, end, value}; companion .tsv."""
+        """Igd::save (igd.rs:425-486) through ``gtars_igddb_save``: the .igd v1 file and its companion .tsv."""
         self._require()
-        c, s, e, v, f = self._export()
-        names = self._chrom_names()
-        nbp = self.nbp
-        n1 = s // nbp
-        n2 = (e - 1) // nbp
-        reps = (n2 - n1 + 1).astype(np.int64)
-        idx = np.repeat(np.arange(len(s)), reps)                      # record of every tile replica
-        first = np.cumsum(reps) - reps
-        tile = n1[idx] + (np.arange(len(idx)) - first[idx])           # tile of every replica
-        order = np.lexsort((idx, s[idx], tile, c[idx]))               # (contig, tile, start, insertion)
-        idx, tile = idx[order], tile[order]
-        n_ctg = len(names)
-        n_tiles = np.zeros(n_ctg, dtype=np.int32)
-        if len(s):
-            np.maximum.at(n_tiles, c, (n2 + 1).astype(np.int32))
-        buf = bytearray()
-        buf += np.asarray([nbp, 1, n_ctg], dtype="<i4").tobytes()
-        buf += n_tiles.astype("<i4").tobytes()
-        toff = np.concatenate([[0], np.cumsum(n_tiles.astype(np.int64))])
-        counts = np.zeros(int(toff[-1]), dtype=np.int32)
-        if len(idx):
-            np.add.at(counts, toff[c[idx]] + tile, 1)
-        buf += counts.astype("<i4").tobytes()
-        for nm in names:
-            b = nm.encode()[:40]
-            buf += b + b"\0" * (40 - len(b))
-        rec = np.empty((len(idx), 4), dtype="<i4")
-        rec[:, 0] = f[idx].astype(np.int32)
-        rec[:, 1] = s[idx]
-        rec[:, 2] = e[idx]
-        rec[:, 3] = v[idx]
-        buf += rec.tobytes()
-        parent = os.path.dirname(path)
-        if parent:
-            os.makedirs(parent, exist_ok=True)
-        with open(path, "wb") as fh:
-            fh.write(bytes(buf))
-        tsv = os.path.splitext(path)[0] + ".tsv"
-        with open(tsv, "wt") as fh:
-            fh.write("Index\tFile\tNumber of Regions\tAvg size\n")
-            for i, fi in enumerate(self.file_info):
-                fh.write(f"{i}\t{fi.filename}\t{fi.num_regions}\t{fi.avg_region_width:.2f}\n")
+        check(lib.gtars_igddb_save(self._db, os.fspath(path).encode(), int(self.nbp)))
 
     @classmethod
     def from_igd_file(cls, path: str) -> "Igd":
-        """Igd::from_igd_file (igd.rs:320-418).  Tile replicas are dropped on load: a record is kept from
-        the tile it starts in, so the device holds every stored interval once."""
-        with open(path, "rb") as fh:
-            data = fh.read()
-        hdr = np.frombuffer(data, dtype="<i4", count=3)
-        nbp, g_type, n_ctg = int(hdr[0]), int(hdr[1]), int(hdr[2])
-        pos = 12
-        n_tiles = np.frombuffer(data, dtype="<i4", count=n_ctg, offset=pos).astype(np.int64)
-        pos += 4 * n_ctg
-        total_tiles = int(n_tiles.sum())
-        counts = np.frombuffer(data, dtype="<i4", count=total_tiles, offset=pos).astype(np.int64)
-        pos += 4 * total_tiles
-        names = []
-        for _ in range(n_ctg):
-            names.append(data[pos:pos + 40].decode("utf-8", "replace").strip("\0"))
-            pos += 40
-        w = 3 if g_type == 0 else 4
-        nrec = int(counts.sum())
-        rec = np.frombuffer(data, dtype="<i4", count=nrec * w, offset=pos).reshape(nrec, w)
-        tile_of = np.repeat(np.arange(total_tiles), counts)
-        toff = np.concatenate([[0], np.cumsum(n_tiles)])
-        ctg_of = np.searchsorted(toff, tile_of, side="right") - 1
-        local_tile = tile_of - toff[ctg_of]
-        keep = (rec[:, 1] // nbp) == local_tile
-        self = cls(nbp)
-        self._chrom_ids = {n: i for i, n in enumerate(names)}
-        tsv = os.path.splitext(path)[0] + ".tsv"
-        if os.path.exists(tsv):
-            with open(tsv, "rt") as fh:
-                for i, line in enumerate(fh):
-                    if i == 0:
-                        continue
-                    fields = line.rstrip("\n").split("\t")
-                    if len(fields) < 4:
-                        continue
-                    try:
-                        nr = int(fields[2].strip())
-                    except ValueError:
-                        nr = 0
-                    try:
-                        aw = float(fields[3].strip())
-                    except ValueError:
-                        aw = 0.0
-                    self.file_info.append(FileInfo(fields[1].strip(), nr, aw))
-        k = rec[keep]
-        n_files = max(len(self.file_info), int(k[:, 0].max()) + 1 if len(k) else 0)
-        vals = k[:, 3] if w == 4 else np.zeros(len(k), dtype=np.int32)
-        self._engine = IgdIndex(ctg_of[keep], k[:, 1], k[:, 2], k[:, 0], vals, n_chrom=n_ctg, n_files=n_files)
-        self._n_files_engine = n_files
-        return self
+        """Igd::from_igd_file (igd.rs:320-418) through ``gtars_igddb_load``.  Tile replicas are dropped on load: a record
+        is kept from the tile it starts in, so the device holds every stored interval once."""
+        h = C.c_void_p()
+        nbp = C.c_int32()
+        check(lib.gtars_igddb_load(os.fspath(path).encode(), C.byref(h), C.byref(nbp)))
+        return cls._from_db(h, int(nbp.value))
 
     def __del__(self):
         try:

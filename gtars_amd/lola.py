@@ -459,3 +459,91 @@ def write_results_tsv(out, results: Dict[str, list]) -> None:
     finally:
         if own:
             f.close()
+
+
+# --------------------------------------------------------------------------- universe helpers (gtars-lola/src/universe.rs)
+
+
+def _to_region_set(x) -> RegionSet:
+    if isinstance(x, RegionSet):
+        return x
+    if isinstance(x, dict):
+        return RegionSet.from_vectors(list(x["chr"]), list(x["start"]), list(x["end"]))
+    x = list(x)
+    return RegionSet.from_vectors([r[0] for r in x], [int(r[1]) for r in x], [int(r[2]) for r in x])
+
+
+def check_universe(user_sets, universe) -> Dict[str, list]:
+    """check_universe_appropriateness (universe.rs:39-105) as py_check_universe returns it (gtars-python/src/lola/mod.rs:
+    279-320): per user set the number of regions, how many overlap the universe (count_overlaps_per_query against an IGD
+    of the universe, on the GPU), the coverage, the many-to-many count, and the reference's warning texts."""
+    uni = _to_region_set(universe)
+    igd = Igd.from_single_region_set(uni)
+    out = {"userSet": [], "totalRegions": [], "regionsInUniverse": [], "coverage": [], "manyToMany": [], "warnings": []}
+    for us_idx, us in enumerate(user_sets):
+        rs = _to_region_set(us)
+        total = len(rs)
+        counts = np.asarray(igd.count_overlaps_per_query(rs, 1), dtype=np.int64)
+        in_u, m2m = int((counts > 0).sum()), int((counts > 1).sum())
+        cov = in_u / total if total else 0.0
+        if cov < 0.5:
+            out["warnings"].append(f"User set {us_idx}: only {cov * 100.0:.1f}% of regions overlap the universe. "
+                                   "Consider using a more appropriate universe.")
+        elif cov < 0.9:
+            out["warnings"].append(f"User set {us_idx}: {cov * 100.0:.1f}% of regions overlap the universe. "
+                                   "Some regions may not be represented.")
+        if m2m > 0:
+            out["warnings"].append(f"User set {us_idx}: {m2m} regions overlap multiple universe regions (many-to-many). "
+                                   "Consider using redefine_user_sets() to eliminate artifacts.")
+        out["userSet"].append(us_idx)
+        out["totalRegions"].append(total)
+        out["regionsInUniverse"].append(in_u)
+        out["coverage"].append(cov)
+        out["manyToMany"].append(m2m)
+    return out
+
+
+def redefine_user_sets(user_sets, universe) -> List[List[Tuple[str, int, int]]]:
+    """redefine_user_sets (universe.rs:107-139): every user set replaced by the universe regions it overlaps
+    (find_overlaps_regionset on the GPU, de-duplicated, sorted by (chr, start))."""
+    uni = _to_region_set(universe)
+    igd = Igd.from_single_region_set(uni)
+    names, ids, st, en = uni.chrom_names, uni.chrom_ids, uni.starts, uni.ends
+    out = []
+    for us in user_sets:
+        pairs = igd.find_overlaps_regionset(_to_region_set(us), 1)
+        subj = list(dict.fromkeys(s for _, s in pairs))  # first occurrence wins, like the HashSet + push
+        regs = [(names[int(ids[i])], int(st[i]), int(en[i])) for i in subj]
+        regs.sort(key=lambda r: (r[0], r[1]))  # stable, like sort_by
+        out.append(regs)
+    return out
+
+
+def build_restricted_universe(user_sets) -> List[Tuple[str, int, int]]:
+    """build_restricted_universe (universe.rs:141-152): all user regions concatenated, then RegionSet::disjoin
+    (gtars-core/src/models/region_set.rs:1051-1090): cut at every boundary, keep the pieces some region covers, sorted
+    by (chr, start).  Host code: set algebra is outside the GPU path."""
+    by_chr: Dict[str, List[Tuple[int, int]]] = {}
+    for us in user_sets:
+        rs = _to_region_set(us)
+        names, ids, st, en = rs.chrom_names, rs.chrom_ids, rs.starts, rs.ends
+        for c in range(len(names)):
+            m = ids == c
+            if m.any():
+                by_chr.setdefault(names[c], []).extend(zip(st[m].tolist(), en[m].tolist()))
+    result: List[Tuple[str, int, int]] = []
+    for chrom, iv in by_chr.items():
+        a = np.asarray(iv, dtype=np.int64)
+        bounds = np.unique(a.reshape(-1))
+        if len(bounds) < 2:
+            continue
+        # piece [bounds[i], bounds[i+1]) is covered iff some interval has start <= bounds[i] and bounds[i+1] <= end
+        ok = a[:, 0] <= a[:, 1]  # an inverted interval contains no piece
+        cover = np.zeros(len(bounds) + 1, dtype=np.int64)
+        np.add.at(cover, np.searchsorted(bounds, a[ok, 0]), 1)
+        np.add.at(cover, np.searchsorted(bounds, a[ok, 1]), -1)
+        depth = np.cumsum(cover)[: len(bounds) - 1]
+        for i in np.nonzero(depth > 0)[0]:
+            result.append((chrom, int(bounds[i]), int(bounds[i + 1])))
+    result.sort(key=lambda r: (r[0], r[1]))
+    return result

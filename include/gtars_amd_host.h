@@ -212,6 +212,21 @@ const gtars_igd_t *gtars_igddb_engine(const gtars_igddb_t *db);        /* borrow
 gtars_status gtars_igddb_count_regionset(const gtars_igddb_t *db, const gtars_regionset_t *rs,
                                          int32_t min_overlap, int binary, uint64_t *hits);
 
+/* Igd::save / Igd::from_igd_file (gtars-igd/src/igd.rs:320-486): the .igd v1 file -- LE i32 header {nbp, gType = 1,
+ * nCtg}, tiles per contig, record counts per tile, 40-byte NUL-padded contig names, 16-byte records {file idx, start,
+ * end, value} tile by tile (a record is written once for every nbp-tile it touches) -- and its companion
+ * <stem>.tsv ("Index\tFile\tNumber of Regions\tAvg size").  On load a record is kept from the tile it starts in, so
+ * the device holds every stored interval once; gType 0 files (12-byte records) load with value 0.
+ * gtars_igddb_from_arrays builds a database handle from columns the caller has already parsed (chromosome ids index
+ * chrom_names; file i is described by file_names[i], num_regions[i], avg_width[i]). */
+gtars_status gtars_igddb_from_arrays(const char *const *chrom_names, uint32_t n_chrom, const uint32_t *chrom,
+                                     const int32_t *start, const int32_t *end, const int32_t *value,
+                                     const uint32_t *file_idx, uint64_t n, const char *const *file_names,
+                                     const uint32_t *num_regions, const double *avg_width, uint32_t n_files,
+                                     gtars_igddb_t **out);
+gtars_status gtars_igddb_save(const gtars_igddb_t *db, const char *path, int32_t nbp);
+gtars_status gtars_igddb_load(const char *path, gtars_igddb_t **out, int32_t *nbp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,3 +90,24 @@ def test_synth_generators_are_deterministic_and_shaped():
 
     r = oracle.SplitMix64(42)
     assert [int(x) for x in s] == [r.next() for _ in range(4)]
+
+
+def test_gtars_alias_namespace_resolves_to_the_hip_package():
+    """gtars-python/src/lib.rs:27-104 registers gtars.tokenizers / models / utils / lola in sys.modules; user code written
+    against the reference imports from there.  The alias package makes the same imports land in gtars_amd."""
+    import importlib
+
+    import gtars
+    import gtars_amd
+    from gtars.lola import RegionDB, build_restricted_universe, check_universe, redefine_user_sets, run_lola  # noqa: F401
+    from gtars.models import Region, RegionSet  # noqa: F401
+    from gtars.tokenizers import Tokenizer, tokenize_fragment_file  # noqa: F401
+    from gtars.utils import read_tokens_from_gtok, read_tokens_from_gtok_as_strings, write_tokens_to_gtok  # noqa: F401
+
+    assert importlib.import_module("gtars.tokenizers") is gtars_amd.tokenizers
+    assert Tokenizer is gtars_amd.tokenizers.Tokenizer and RegionSet is gtars_amd.models.RegionSet
+    assert gtars.__version__ == gtars_amd.__version__
+    import pytest
+
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("gtars.refget")

@@ -661,3 +661,27 @@ def test_fragsplit_tokenize_pipeline_equals_two_step(tk, golden_dir, tmp_path):
             assert fused[label] == two_step, label
             assert list(fused[label]) == list(two_step)  # barcodes in first-seen order
             assert two_step == otk.tokenize_fragment_file(path), label
+
+
+# ------------------------------------------------------------ LOLA universe helpers (gtars-lola/src/universe.rs:154-301)
+
+
+def test_lola_universe_helpers_kats():
+    from gtars_amd.lola import check_universe, redefine_user_sets
+
+    # test_check_universe_full_coverage
+    rep = check_universe([[("chr1", 100, 200), ("chr1", 2500, 2600)]], [("chr1", 0, 1000), ("chr1", 2000, 3000)])
+    assert rep["totalRegions"] == [2] and rep["regionsInUniverse"] == [2] and abs(rep["coverage"][0] - 1.0) < 1e-10
+    assert rep["manyToMany"] == [0] and rep["warnings"] == []
+    # test_check_universe_low_coverage
+    rep = check_universe([[("chr1", 50, 80), ("chr1", 500, 600), ("chr1", 700, 800)]], [("chr1", 0, 100)])
+    assert rep["regionsInUniverse"] == [1] and abs(rep["coverage"][0] - 1.0 / 3.0) < 0.01 and rep["warnings"]
+    assert "only 33.3% of regions overlap the universe" in rep["warnings"][0]
+    # test_check_universe_many_to_many
+    rep = check_universe([[("chr1", 120, 220)]], [("chr1", 100, 200), ("chr1", 150, 250)])
+    assert rep["manyToMany"] == [1] and any("many-to-many" in w for w in rep["warnings"])
+    # test_redefine_user_sets_basic / _dedup / _no_overlap
+    uni = [("chr1", 100, 200), ("chr1", 300, 400), ("chr1", 500, 600)]
+    assert redefine_user_sets([[("chr1", 150, 350)]], uni) == [[("chr1", 100, 200), ("chr1", 300, 400)]]
+    assert redefine_user_sets([[("chr1", 120, 150), ("chr1", 200, 250)]], [("chr1", 100, 300)]) == [[("chr1", 100, 300)]]
+    assert redefine_user_sets([[("chr1", 500, 600)]], [("chr1", 100, 200)]) == [[]]

@@ -198,3 +198,16 @@ def test_ranking_ties_and_nan():
     assert [r["rnkPV"] for r in rows] == [1, 1, 3, 4]
     assert [r["rnkOR"] for r in rows] == [2, 3, 1, 3]
     assert [r["rnkSup"] for r in rows] == [2, 2, 1, 2]
+
+
+# ---- gtars-lola/src/universe.rs:303-347: build_restricted_universe (host-only set algebra)
+def test_build_restricted_universe_kats():
+    user0 = [("chr1", 100, 200), ("chr1", 300, 400)]
+    user1 = [("chr1", 150, 250), ("chr2", 100, 200)]
+    got = lola.build_restricted_universe([user0, user1])
+    assert got == [("chr1", 100, 150), ("chr1", 150, 200), ("chr1", 200, 250), ("chr1", 300, 400), ("chr2", 100, 200)]
+    assert lola.build_restricted_universe([]) == []
+    assert len(lola.build_restricted_universe([[("chr1", 100, 200), ("chr1", 300, 400), ("chr1", 500, 600)]])) == 3
+    # gaps are never filled, touching intervals are cut at the shared boundary (GenomicRanges disjoin)
+    assert lola.build_restricted_universe([[("c", 0, 10), ("c", 10, 20), ("c", 5, 12)]]) == [
+        ("c", 0, 5), ("c", 5, 10), ("c", 10, 12), ("c", 12, 20)]
