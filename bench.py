@@ -420,7 +420,7 @@ def main():
 
     # ---- N > 1: the same steps when one consumer needs the whole batch (all-gatherv of the CSR over RCCL) ----
     with_allgather = None
-    if dist is not None and backend == "nccl":
+    if dist is not None:
         from gtars_amd import sharding
 
         qc, qs, qe, offsets, ids, h = batches[0]

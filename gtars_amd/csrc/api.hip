@@ -911,6 +911,13 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
     return GTARS_OK;
 }
 
+gtars_status gtars_debug_occupy_device(void *stream, uint32_t workgroups, uint32_t lds_bytes, uint32_t microseconds) {
+    gtars_status st = require_device();
+    if (st) return st;
+    if (lds_bytes > 160 * 1024) return fail(GTARS_ERR_INVALID_ARG, "lds_bytes > 160 KB");
+    return launch_occupy(workgroups, lds_bytes, microseconds, (hipStream_t)stream);
+}
+
 gtars_status gtars_histogram_u32_device(const uint32_t *d_ids, uint64_t n, uint32_t n_bins, uint32_t *d_bins, void *stream) {
     if ((n && !d_ids) || (n_bins && !d_bins)) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     gtars_status st = require_device();

@@ -200,6 +200,7 @@ size_t scan_ws_bytes(u64 n);
 // pme_file (may be null): IgdTiles::pme_file, used for binary counts with min_overlap == 1
 gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               i32 min_overlap, int binary, u64 *hits, hipStream_t st);
+gtars_status launch_occupy(u32 workgroups, u32 lds_bytes, u32 microseconds, hipStream_t st);
 gtars_status launch_hist_u32(const u32 *ids, u64 n, u32 n_bins, u32 *bins, hipStream_t st);
 gtars_status launch_has_adjacent_equal(const u32 *a, u64 n, u32 *dup, hipStream_t st);
 gtars_status launch_igd_count_per_query(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe,

@@ -817,6 +817,28 @@ gtars_status launch_igd_fill_pairs(const IgdView &v, const u32 *qc, const u32 *q
     return GTARS_OK;
 }
 
+// ---------------------------------------------------------------- CU hog (tests)
+__global__ void __launch_bounds__(1024) k_occupy(unsigned long long ticks_100mhz, u32 lds_words, u32 *sink) {
+    extern __shared__ u32 hog[];
+    for (u32 i = threadIdx.x; i < lds_words; i += blockDim.x) hog[i] = i;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(32);
+    if (lds_words && hog[threadIdx.x % lds_words] == 0xFFFFFFFFu) *sink = 1;
+}
+
+gtars_status launch_occupy(u32 workgroups, u32 lds_bytes, u32 microseconds, hipStream_t st) {
+    if (!workgroups) return GTARS_OK;
+    static u32 *d_sink = nullptr;
+    if (!d_sink) GT_HIP(hipMalloc((void **)&d_sink, 4));
+    if (lds_bytes > 48 * 1024)
+        GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_occupy, dim3(workgroups), dim3(1024), lds_bytes, st, (unsigned long long)microseconds * 100ull, lds_bytes / 4,
+                       d_sink);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
 // ---------------------------------------------------------------- id histogram
 // bins[id] += 1 for every id < n_bins: the scatter-add of gtars-scoring's count matrices (fragment_scoring.rs:88-105,
 // CountMatrix::increment) -- one row of the matrix per call, the ids being the peaks hit by one file's probes.

@@ -142,6 +142,11 @@ gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qchrom
                                  uint64_t *offsets, uint32_t *ids, uint64_t ids_capacity,
                                  uint64_t *out_n);
 
+/* Test / diagnostics hook: launches `workgroups` workgroups of 1024 threads that each hold `lds_bytes` of LDS and spin
+ * for `microseconds` on `stream` -- a stand-in for foreign work that occupies CUs while a tokenizer launch runs on
+ * another stream (tests/test_gpu_parity.py: the chained scan must complete with the right result whatever is resident). */
+gtars_status gtars_debug_occupy_device(void *stream, uint32_t workgroups, uint32_t lds_bytes, uint32_t microseconds);
+
 /* bins[id] += 1 for every id < n_bins (device pointers): the scatter-add of gtars-scoring's count matrices
  * (CountMatrix::increment, gtars-scoring/src/fragment_scoring.rs:88-105) -- one matrix row per call, the ids being
  * the token ids of one fragment file's probes (gtars_tokenize_device). */

@@ -685,3 +685,26 @@ def test_lola_universe_helpers_kats():
     assert redefine_user_sets([[("chr1", 150, 350)]], uni) == [[("chr1", 100, 200), ("chr1", 300, 400)]]
     assert redefine_user_sets([[("chr1", 120, 150), ("chr1", 200, 250)]], [("chr1", 100, 300)]) == [[("chr1", 100, 300)]]
     assert redefine_user_sets([[("chr1", 500, 600)]], [("chr1", 100, 200)]) == [[]]
+
+
+def test_bench_py_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 under torch.distributed.run with the gloo backend (both ranks on this GPU): one JSON line from
+    rank 0 with the whole-job value, the roofline object and the all-gatherv variant; small sizes."""
+    import json
+    import subprocess
+    import sys
+
+    from test_sharding_gloo import _free_port
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GTARS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--queries", "200000", "--batches", "3", "--min-seconds", "0.01", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["roofline"]["kernel"] == "k_tok_lds" and 0 < out["roofline"]["frac"] < 1
+    assert out["with_allgather"]["value"] > 0 and out["timing"]["repetitions"] >= 11

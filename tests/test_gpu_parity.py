@@ -864,3 +864,50 @@ def test_dense_database_hundreds_of_hits_per_query(ga):
     oq, os_ = o2.find_overlaps_regionset(qc[:60], qs[:60], qe[:60], 1)
     assert gq.tolist() == oq.tolist() and gs.tolist() == os_.tolist()
     assert g2.count_overlaps_per_query(qc[:60], qs[:60], qe[:60], 1).tolist() == o2.count_overlaps_per_query(qc[:60], qs[:60], qe[:60], 1).tolist()
+
+
+@pytest.mark.parametrize("hog_wgs,hog_lds", [(200, 100 * 1024), (512, 60 * 1024)])
+def test_tokenize_async_while_another_stream_holds_cus(ga, hog_wgs, hog_lds):
+    """An ASYNCHRONOUS gtars_tokenize_device(total_hits = NULL) launch that shares the GPU with foreign work: a kernel on a
+    second stream occupies most CUs (one 1024-thread workgroup with 100 KB of LDS per CU, or two with 60 KB) for several
+    milliseconds while tokenizer launches of 1..40 tiles per workgroup are queued on another stream.  Whatever part of the
+    tokenizer's grid is resident at a time, every launch must complete with the exact offsets and ids (tiles are handed
+    out by ticket, and a look-back that cannot see a predecessor counts that tile itself)."""
+    import torch
+    from gtars_amd import synth
+    from gtars_amd._lib import check, lib
+
+    u = synth.make_universe(50_000)
+    g, o = _pair(ga, u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    dev = torch.device("cuda:0")
+    s_tok, s_hog = torch.cuda.Stream(), torch.cuda.Stream()
+    cases = []
+    for nq in (300_000, 1_000_000, 9_000_000):
+        q = synth.make_queries(u, min(nq, 1_000_000), seed=nq)
+        rep = max(nq // len(q["chrom"]), 1)
+        qc, qs, qe = (torch.from_numpy(np.tile(q[k], rep).view(np.int32)).to(dev) for k in ("chrom", "start", "end"))
+        off_o, ids_o = o.tokenize(q["chrom"], q["start"], q["end"])
+        n = qc.numel()
+        offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ids = torch.zeros(len(ids_o) * rep + 8, dtype=torch.int32, device=dev)
+        cases.append((qc, qs, qe, n, offsets, ids, off_o, ids_o, rep))
+    torch.cuda.synchronize()
+    for round_ in range(3):
+        check(lib.gtars_debug_occupy_device(s_hog.cuda_stream, hog_wgs, hog_lds, 4000))
+        for qc, qs, qe, n, offsets, ids, off_o, ids_o, rep in cases:
+            offsets.zero_()
+            ids.zero_()
+            with torch.cuda.stream(s_tok):
+                g.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), n, offsets.data_ptr(), ids.data_ptr(), ids.numel(),
+                                  s_tok.cuda_stream, sync=False)
+        torch.cuda.synchronize()
+        for qc, qs, qe, n, offsets, ids, off_o, ids_o, rep in cases:
+            got_off = offsets.cpu().numpy().view(np.uint64)
+            h1 = len(ids_o)
+            assert int(got_off[-1]) == h1 * rep
+            nq1 = len(off_o) - 1
+            assert np.array_equal(got_off[: nq1 + 1], off_o)
+            assert np.array_equal(ids[:h1].cpu().numpy().view(np.uint32), ids_o)
+            if rep > 1:  # every repetition of the base batch: same counts, same ids
+                assert np.array_equal(np.diff(got_off.astype(np.int64)).reshape(rep, nq1), np.tile(np.diff(off_o.astype(np.int64)), (rep, 1)))
+                assert np.array_equal(ids[h1 * (rep - 1): h1 * rep].cpu().numpy().view(np.uint32), ids_o)
