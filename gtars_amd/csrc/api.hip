@@ -210,6 +210,18 @@ struct ScopedDev {
 
 using namespace gtars;
 
+// runs f(), turning C++ exceptions into a status (nothing may unwind through the extern "C" boundary)
+template <class F>
+static gtars_status guarded(F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(GTARS_ERR_INTERNAL, std::string("internal error: ") + e.what());
+    }
+}
+
 // K1 policy: large builds are ordered by the device radix sort, small ones by std::stable_sort
 // (identical results; GTARS_DEVICE_SORT=0/1 forces one path, used by the tests)
 static bool use_device_sort(u64 n) {
@@ -456,7 +468,7 @@ int gtars_prof_read(const char **names, double *total_ms, uint64_t *launches, in
 
 // ------------------------------------------------------------- index build
 
-gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, const uint32_t *end,
+static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t *start, const uint32_t *end,
                                const uint32_t *val, uint64_t n, uint32_t n_chrom, int kind,
                                gtars_index_t **out) {
     if (!out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
@@ -1252,7 +1264,7 @@ static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, co
 
 extern "C" {
 
-gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+static gtars_status gtars_tokenize_into_impl(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
                                  uint64_t nq, uint64_t *offsets, uint32_t *ids, uint64_t ids_capacity, uint64_t *out_n) {
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
     if (st) return st;
@@ -1263,7 +1275,7 @@ gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qc, co
     return tokenize_pipeline(ix, qc, qs, qe, nq, offsets, ids_capacity ? ids : nullptr, ids_capacity, out_n);
 }
 
-gtars_status gtars_tokenize(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
+static gtars_status gtars_tokenize_impl(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
                             const uint32_t *qe, uint64_t nq, uint64_t *offsets, uint32_t **out_ids,
                             uint64_t *out_n) {
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
@@ -1456,7 +1468,7 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
 
 // ---------------------------------------------------------------------- IGD
 
-gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const int32_t *end,
+static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *start, const int32_t *end,
                              const int32_t *value, const uint32_t *file_idx, uint64_t n, uint32_t n_chrom,
                              uint32_t n_files, gtars_igd_t **out) {
     if (!out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
@@ -1793,6 +1805,34 @@ gtars_status gtars_lola_contingency_device(const uint64_t *d_user_hits, const ui
         return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     return launch_lola_contingency(d_user_hits, d_universe_hits, n_files, user_size, universe_size, d_a, d_b,
                                    d_c, d_d, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- the C ABI never lets a C++ exception cross it (std::bad_alloc of a huge build, std::length_error ...)
+extern "C" {
+
+gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, const uint32_t *end,
+                               const uint32_t *val, uint64_t n, uint32_t n_chrom, int kind,
+                               gtars_index_t **out) {
+    return guarded([&]() -> gtars_status { return gtars_index_build_impl(chrom, start, end, val, n, n_chrom, kind, out); });
+}
+
+gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const int32_t *end,
+                             const int32_t *value, const uint32_t *file_idx, uint64_t n, uint32_t n_chrom,
+                             uint32_t n_files, gtars_igd_t **out) {
+    return guarded([&]() -> gtars_status { return gtars_igd_build_impl(chrom, start, end, value, file_idx, n, n_chrom, n_files, out); });
+}
+
+gtars_status gtars_tokenize(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
+                            const uint32_t *qe, uint64_t nq, uint64_t *offsets, uint32_t **out_ids,
+                            uint64_t *out_n) {
+    return guarded([&]() -> gtars_status { return gtars_tokenize_impl(ix, qc, qs, qe, nq, offsets, out_ids, out_n); });
+}
+
+gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+                                 uint64_t nq, uint64_t *offsets, uint32_t *ids, uint64_t ids_capacity, uint64_t *out_n) {
+    return guarded([&]() -> gtars_status { return gtars_tokenize_into_impl(ix, qc, qs, qe, nq, offsets, ids, ids_capacity, out_n); });
 }
 
 }  // extern "C"

@@ -30,6 +30,18 @@
 
 namespace gtars {
 gtars_status fail(gtars_status st, const std::string &msg);
+
+// runs f(), turning C++ exceptions into a status (nothing may unwind through the extern "C" boundary)
+template <class F>
+static gtars_status guarded(F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(GTARS_ERR_INTERNAL, std::string("internal error: ") + e.what());
+    }
+}
 }
 using gtars::fail;
 
@@ -370,7 +382,7 @@ std::vector<uint32_t> translate_chroms(const gtars_regionset *q, const Dict &d) 
 extern "C" {
 
 // RegionSet::try_from(&Path) -- gtars-core/src/models/region_set.rs:52-186
-gtars_status gtars_regionset_from_bed(const char *path, gtars_regionset_t **out) {
+static gtars_status gtars_regionset_from_bed_impl(const char *path, gtars_regionset_t **out) {
     if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
     const std::string p(path);
@@ -1350,7 +1362,7 @@ struct gtars_fragments {
     std::vector<const char *> chrom_ptrs, barcode_ptrs;
 };
 
-gtars_status gtars_fragments_read(const char *path, gtars_fragments_t **out) {
+static gtars_status gtars_fragments_read_impl(const char *path, gtars_fragments_t **out) {
     if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
     std::unique_ptr<gtars_fragments> f(new gtars_fragments());
@@ -1383,7 +1395,7 @@ const uint32_t *gtars_fragments_starts(const gtars_fragments_t *f) { return f ? 
 const uint32_t *gtars_fragments_ends(const gtars_fragments_t *f) { return f ? f->t.e.data() : nullptr; }
 const uint32_t *gtars_fragments_barcode_ids(const gtars_fragments_t *f) { return f ? f->t.b.data() : nullptr; }
 
-gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, const char *path,
+static gtars_status gtars_tokenizer_tokenize_fragment_file_impl(const gtars_tokenizer_t *t, const char *path,
                                                     gtars_fragment_tokens_t **out) {
     if (!t || !path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
@@ -1626,7 +1638,7 @@ extern "C" {
 
 // Igd::from_bed_files -- gtars-igd/src/igd.rs:191-242.  Files are independent: they are parsed by a pool
 // of host threads and merged in argument order (contigs and file indices come out as in a serial pass).
-gtars_status gtars_igddb_from_bed_files(const char *const *paths, uint64_t n_paths, gtars_igddb_t **out) {
+static gtars_status gtars_igddb_from_bed_files_impl(const char *const *paths, uint64_t n_paths, gtars_igddb_t **out) {
     if (!out || (n_paths && !paths)) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
     std::vector<IgdBedFile> parsed(n_paths);
@@ -1731,7 +1743,7 @@ gtars_status gtars_igddb_count_regionset(const gtars_igddb_t *db, const gtars_re
 // ===================================================================== .igd files
 extern "C" {
 
-gtars_status gtars_igddb_from_arrays(const char *const *chrom_names, uint32_t n_chrom, const uint32_t *chrom,
+static gtars_status gtars_igddb_from_arrays_impl(const char *const *chrom_names, uint32_t n_chrom, const uint32_t *chrom,
                                      const int32_t *start, const int32_t *end, const int32_t *value,
                                      const uint32_t *file_idx, uint64_t n, const char *const *file_names,
                                      const uint32_t *num_regions, const double *avg_width, uint32_t n_files,
@@ -1754,7 +1766,7 @@ gtars_status gtars_igddb_from_arrays(const char *const *chrom_names, uint32_t n_
     return GTARS_OK;
 }
 
-gtars_status gtars_igddb_save(const gtars_igddb_t *db, const char *path, int32_t nbp) {
+static gtars_status gtars_igddb_save_impl(const gtars_igddb_t *db, const char *path, int32_t nbp) {
     if (!db || !path) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     if (nbp <= 0) nbp = 16384;
     const uint64_t n = gtars_igd_len(db->igd);
@@ -1820,7 +1832,7 @@ gtars_status gtars_igddb_save(const gtars_igddb_t *db, const char *path, int32_t
     return GTARS_OK;
 }
 
-gtars_status gtars_igddb_load(const char *path, gtars_igddb_t **out, int32_t *nbp_out) {
+static gtars_status gtars_igddb_load_impl(const char *path, gtars_igddb_t **out, int32_t *nbp_out) {
     if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
     FILE *fh = fopen(path, "rb");
@@ -2148,7 +2160,7 @@ gtars_status for_each_split_wave(const std::vector<std::string> &files, const gt
 
 extern "C" {
 
-gtars_status gtars_fragsplit(const char *files_dir, const gtars_barcode_map_t *m, const char *out_dir, uint64_t *n_reads,
+static gtars_status gtars_fragsplit_impl(const char *files_dir, const gtars_barcode_map_t *m, const char *out_dir, uint64_t *n_reads,
                              uint64_t *n_written) {
     if (!files_dir || !m || !out_dir) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     std::vector<std::string> files;
@@ -2209,7 +2221,7 @@ gtars_status gtars_fragsplit(const char *files_dir, const gtars_barcode_map_t *m
     return GTARS_OK;
 }
 
-gtars_status gtars_fragsplit_tokenize(const gtars_tokenizer_t *t, const char *files_dir, const gtars_barcode_map_t *m,
+static gtars_status gtars_fragsplit_tokenize_impl(const gtars_tokenizer_t *t, const char *files_dir, const gtars_barcode_map_t *m,
                                       gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
     if (!t || !files_dir || !m || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
     *out = nullptr;
@@ -2299,6 +2311,54 @@ gtars_status gtars_fragsplit_tokenize(const gtars_tokenizer_t *t, const char *fi
     *out = arr;
     if (n_reads) *n_reads = reads;
     return GTARS_OK;
+}
+
+}  // extern "C"
+
+// ---- the C ABI never lets a C++ exception cross it (std::bad_alloc of a huge build, std::length_error ...)
+extern "C" {
+
+gtars_status gtars_regionset_from_bed(const char *path, gtars_regionset_t **out) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_regionset_from_bed_impl(path, out); });
+}
+
+gtars_status gtars_igddb_from_bed_files(const char *const *paths, uint64_t n_paths, gtars_igddb_t **out) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_igddb_from_bed_files_impl(paths, n_paths, out); });
+}
+
+gtars_status gtars_fragsplit(const char *files_dir, const gtars_barcode_map_t *m, const char *out_dir, uint64_t *n_reads,
+                             uint64_t *n_written) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_fragsplit_impl(files_dir, m, out_dir, n_reads, n_written); });
+}
+
+gtars_status gtars_fragsplit_tokenize(const gtars_tokenizer_t *t, const char *files_dir, const gtars_barcode_map_t *m,
+                                      gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_fragsplit_tokenize_impl(t, files_dir, m, out, n_reads); });
+}
+
+gtars_status gtars_igddb_load(const char *path, gtars_igddb_t **out, int32_t *nbp_out) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_igddb_load_impl(path, out, nbp_out); });
+}
+
+gtars_status gtars_igddb_save(const gtars_igddb_t *db, const char *path, int32_t nbp) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_igddb_save_impl(db, path, nbp); });
+}
+
+gtars_status gtars_igddb_from_arrays(const char *const *chrom_names, uint32_t n_chrom, const uint32_t *chrom,
+                                     const int32_t *start, const int32_t *end, const int32_t *value,
+                                     const uint32_t *file_idx, uint64_t n, const char *const *file_names,
+                                     const uint32_t *num_regions, const double *avg_width, uint32_t n_files,
+                                     gtars_igddb_t **out) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_igddb_from_arrays_impl(chrom_names, n_chrom, chrom, start, end, value, file_idx, n, file_names, num_regions, avg_width, n_files, out); });
+}
+
+gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, const char *path,
+                                                    gtars_fragment_tokens_t **out) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_tokenizer_tokenize_fragment_file_impl(t, path, out); });
+}
+
+gtars_status gtars_fragments_read(const char *path, gtars_fragments_t **out) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_fragments_read_impl(path, out); });
 }
 
 }  // extern "C"
