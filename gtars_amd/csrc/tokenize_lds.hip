@@ -36,6 +36,13 @@
 
 namespace gtars {
 
+// timing experiments only (tools/build_variant.sh; results are then WRONG by construction):
+//   1 no look-back (a made-up base)   2 no id stores   4 no offset stores   8 no record burst (made-up records)
+//   16 no LDS search (a made-up block)
+#ifndef GTARS_TOK_ABLATE
+#define GTARS_TOK_ABLATE 0
+#endif
+
 __device__ __forceinline__ i64 overlap_bp_tok(u32 as, u32 ae, u32 bs, u32 be) {
     u32 mn = ae < be ? ae : be;
     u32 mx = as > bs ? as : bs;
@@ -258,23 +265,38 @@ __device__ __forceinline__ void load_queries(const u32 *__restrict__ qc, const u
 
 // count phase of QPT consecutive queries of one lane: search, record burst, hit masks.  Returns the lane's hits.
 // REV: the ids kept for the write phase are those of the LAST two hits (they are emitted first)
-template <int QPT, bool FILTER, bool IMPL, bool REV>
+template <int QPT, bool FILTER, bool IMPL, bool REV, class After>
 __device__ __forceinline__ u32 count_queries(const AccelView &a, const SearchLds &L, const u32 (&c)[QPT], const u32 (&s)[QPT],
-                                             const u32 (&e)[QPT], i32 min_bp, TileQ<QPT, IMPL> &t) {
+                                             const u32 (&e)[QPT], i32 min_bp, TileQ<QPT, IMPL> &t, After &&after_issue) {
     constexpr u32 STRIDE = IMPL ? 2 : 4;
     const uint4 *__restrict__ recs = IMPL ? a.rec2 : a.rec4;
     u32 b0[QPT], be[QPT];
-    search_blocks<QPT>(a, L.lut, L.q, L.ctab, c, s, b0, be);
+    if (GTARS_TOK_ABLATE & 16) {
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            b0[j] = (s[j] * 2654435761u) % a.n_blocks;
+            be[j] = c[j] < a.n_chrom ? a.n_blocks : 0u;
+        }
+    } else {
+        search_blocks<QPT>(a, L.lut, L.q, L.ctab, c, s, b0, be);
+    }
     uint4 S[QPT], E[QPT], V[IMPL ? 1 : QPT];
     bool act[QPT];
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
         act[j] = b0[j] < be[j];
         const uint4 *rec = recs + (size_t)(act[j] ? b0[j] : 0u) * STRIDE;
-        S[j] = rec[0];
-        E[j] = rec[1];
-        if constexpr (!IMPL) V[j] = rec[2];
+        if (GTARS_TOK_ABLATE & 8) {
+            S[j] = make_uint4(s[j] ^ 8u, ~0u, ~0u, ~0u);
+            E[j] = make_uint4(e[j], 0, 0, 0);
+            if constexpr (!IMPL) V[j] = make_uint4((u32)j, 0, 0, 0);
+        } else {
+            S[j] = rec[0];
+            E[j] = rec[1];
+            if constexpr (!IMPL) V[j] = rec[2];
+        }
     }
+    after_issue();  // the record loads are in flight
     u32 tsum = 0;
     t.more_bits = 0;
 #pragma unroll
@@ -304,30 +326,23 @@ __device__ __forceinline__ u32 count_queries(const AccelView &a, const SearchLds
     return tsum;
 }
 
-// write phase: CSR offsets and token ids of the lane's QPT queries (first query q0).  wave_base = global offset
-// of the wave's first id.  When the wave's ids fit the wave's LDS buffer (`stage`, stage_cap words) they are
-// compacted there and leave as contiguous stores; otherwise (and beyond the caller's capacity) one by one.
+template <int QPT, bool FILTER, bool IMPL, bool REV>
+__device__ __forceinline__ u32 count_queries(const AccelView &a, const SearchLds &L, const u32 (&c)[QPT], const u32 (&s)[QPT],
+                                             const u32 (&e)[QPT], i32 min_bp, TileQ<QPT, IMPL> &t) {
+    return count_queries<QPT, FILTER, IMPL, REV>(a, L, c, s, e, min_bp, t, [] {});
+}
+
+// Emits the hits of the lane's QPT queries (first query q0) in result order: put(position, id) for every hit when
+// `want_ids`, o4[j] = position of query j's first hit; `run` = position of the lane's first hit.
 // REV: a query's hits leave in DESCENDING stored order (AIList::find, ailist.rs:238-263): the i-th hit of the forward
 // scan goes to slot n - 1 - i of the query's n.
-template <int QPT, bool FILTER, bool IMPL, bool REV>
-__device__ __forceinline__ void write_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
-                                              const u32 *__restrict__ qs, const u32 *__restrict__ qe, u64 nq, i32 min_bp,
-                                              const TileQ<QPT, IMPL> &t, u64 q0, u64 wave_base, u64 *__restrict__ offsets,
-                                              u32 *__restrict__ ovals, u64 cap, bool off_vec_ok, u32 *stage, u32 stage_cap,
-                                              int lane) {
+template <int QPT, bool FILTER, bool IMPL, bool REV, class Put>
+__device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
+                                             const u32 *__restrict__ qs, const u32 *__restrict__ qe, i32 min_bp,
+                                             const TileQ<QPT, IMPL> &t, u64 q0, u64 run, bool want_ids, u64 (&o4)[QPT], Put &&put) {
     constexpr u32 STRIDE = IMPL ? 2 : 4;
     const uint4 *__restrict__ recs = IMPL ? a.rec2 : a.rec4;
     const u32 *recw = reinterpret_cast<const u32 *>(a.rec4);
-    const bool staged = cap && t.wtotal <= stage_cap && wave_base + t.wtotal <= cap;
-    // ids go either to the wave's LDS buffer (index relative to wave_base) or straight to memory
-    auto put = [&](u64 pos, u32 id) {
-        if (staged)
-            stage[(u32)(pos - wave_base)] = id;
-        else if (pos < cap)
-            ovals[pos] = id;
-    };
-    u64 run = wave_base + t.excl;
-    u64 o4[QPT];
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
         o4[j] = run;
@@ -341,12 +356,12 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
             sq = qs[q0 + j];
             eq = qe[q0 + j];
             be = L.ctab[cq].w;
-            if (REV || !cap) n_all += walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [](u32, int) {});
+            if (REV || !want_ids) n_all += walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [](u32, int) {});
         }
         // slot of the i-th hit of the forward scan
         auto slot = [&](u32 i) -> u64 { return REV ? run + (n_all - 1u - i) : run + i; };
         u32 i = 0;
-        if (cap) {
+        if (want_ids) {
             if constexpr (IMPL) {
                 while (m) {
                     const int k = __ffs((int)m) - 1;
@@ -379,8 +394,8 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
         } else {
             i = __popc(m);
         }
-        if (more && (cap || !REV)) {
-            if (cap) {
+        if (more && (want_ids || !REV)) {
+            if (want_ids) {
                 const u32 n_tail = walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
                     put(slot(i++), IMPL ? t.aux[IMPL ? j : 0] + (u32)ACC_OWN * (b - b0) + (u32)k : recw[b * 16u + 8u + (u32)k]);
                 });
@@ -389,11 +404,34 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
         }
         run += n_all;
     }
-    if (staged) {
+}
+
+// write phase: CSR offsets and token ids of the lane's QPT queries.  wave_base = global offset
+// of the wave's first id.  When the wave's ids fit the wave's LDS buffer (`stage`, stage_cap words) they are
+// compacted there and leave as contiguous stores; otherwise (and beyond the caller's capacity) one by one.
+template <int QPT, bool FILTER, bool IMPL, bool REV>
+__device__ __forceinline__ void write_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
+                                              const u32 *__restrict__ qs, const u32 *__restrict__ qe, u64 nq, i32 min_bp,
+                                              const TileQ<QPT, IMPL> &t, u64 q0, u64 wave_base, u64 *__restrict__ offsets,
+                                              u32 *__restrict__ ovals, u64 cap, bool off_vec_ok, u32 *stage, u32 stage_cap,
+                                              int lane) {
+    const bool staged = cap && t.wtotal <= stage_cap && wave_base + t.wtotal <= cap;
+    u64 o4[QPT];
+    // ids go either to the wave's LDS buffer (index relative to wave_base) or straight to memory
+    emit_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, [&](u64 pos, u32 id) {
+        if (GTARS_TOK_ABLATE & 2) return;
+        if (staged)
+            stage[(u32)(pos - wave_base)] = id;
+        else if (pos < cap)
+            ovals[pos] = id;
+    });
+    if (staged && !(GTARS_TOK_ABLATE & 2)) {
         // the wave's ids, contiguous: 256 bytes per store instruction (LDS operations of a wave execute in order)
         for (u32 i = (u32)lane; i < t.wtotal; i += 64) __builtin_nontemporal_store(stage[i], &ovals[wave_base + i]);
     }
-    if (QPT >= 2 && off_vec_ok && q0 + QPT <= nq) {
+    if (GTARS_TOK_ABLATE & 4) {
+        if (o4[0] == 0xFFFFFFFFFFFFFFFFull) offsets[q0] = o4[QPT - 1];
+    } else if (QPT >= 2 && off_vec_ok && q0 + QPT <= nq) {
 #pragma unroll
         for (int h = 0; h < QPT / 2; ++h) st_stream2(offsets + q0 + 2 * h, o4[2 * h], o4[2 * h + 1]);
     } else {
@@ -482,7 +520,7 @@ __device__ __forceinline__ u64 resolve_prefix_helping(u64 *state, u32 tile, u64 
     return excl;
 }
 
-template <int TPB, int QPT, bool FILTER, bool IMPL, bool REV>
+template <int TPB, int QPT, int R, bool FILTER, bool IMPL, bool REV>
 __global__ void __launch_bounds__(TPB, TPB / 256)
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
@@ -492,8 +530,11 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     __shared__ u32 s_tile;
     __shared__ u64 s_prefix;
     constexpr int NW = TPB / 64;
-    __shared__ u32 s_scan[NW];
-    constexpr u32 TILE = TPB * QPT;
+    static_assert(NW * R <= 64, "one lane per wave part in the workgroup scan");
+    __shared__ u32 s_scan[NW * R];
+    // a tile is R rounds of TPB * QPT queries: round r of lane t holds queries tile * TILE + r * ROUND + t * QPT ...
+    constexpr u32 ROUND = TPB * QPT;
+    constexpr u32 TILE = ROUND * R;
 
     const u32 num_tiles = (u32)((nq + TILE - 1) / TILE);
     const int lane = threadIdx.x & 63;
@@ -507,10 +548,15 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     // with it every later look-back sum.
     const u64 base = d_base ? *d_base : 0ull;
 
-    u32 c[QPT], s[QPT], e[QPT];
+    u32 c[R][QPT], s[R][QPT], e[R][QPT];
+    auto load_tile = [&](u32 t) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            load_queries<QPT>(qc, qs, qe, nq, (u64)t * TILE + (u64)r * ROUND + (u64)threadIdx.x * QPT, vec_ok, c[r], s[r], e[r]);
+    };
     // the first tile's queries come from HBM: issue their loads before the LDS fill so that both overlap
     u32 tile = blockIdx.x;
-    load_queries<QPT>(qc, qs, qe, nq, (u64)tile * TILE + (u64)threadIdx.x * QPT, vec_ok, c, s, e);
+    load_tile(tile);
     fill_search_lds<TPB>(a, smem);
     __syncthreads();
 
@@ -520,8 +566,8 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     };
 
     struct Prev {
-        TileQ<QPT, IMPL> q;
-        u32 wbase, total, tile;
+        TileQ<QPT, IMPL> q[R];
+        u32 wbase[R], total, tile;
     } cur, prev;
     bool have_prev = false, loaded = true;
     const bool draw = num_tiles > gridDim.x;  // otherwise one tile per workgroup: nothing to draw
@@ -533,25 +579,34 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             // the scan's barrier: its latency is off the critical path and no barrier is spent on it
             u32 ticket = 0;
             if (draw && threadIdx.x == 0) ticket = atomicAdd(&ws->ticket, 1u);
-            if (!loaded) load_queries<QPT>(qc, qs, qe, nq, (u64)tile * TILE + (u64)threadIdx.x * QPT, vec_ok, c, s, e);
+            if (!loaded) load_tile(tile);
             loaded = false;
-            const u32 tsum = count_queries<QPT, FILTER, IMPL, REV>(a, L, c, s, e, min_bp, cur.q);
-            const u32 inc = wave_inclusive_scan_u32(tsum, lane);
-            if (lane == 63) s_scan[wave] = inc;
+            u32 tsum[R], inc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) tsum[r] = count_queries<QPT, FILTER, IMPL, REV>(a, L, c[r], s[r], e[r], min_bp, cur.q[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                inc[r] = wave_inclusive_scan_u32(tsum[r], lane);
+                if (lane == 63) s_scan[r * NW + wave] = inc[r];
+            }
             if (draw && threadIdx.x == 0) s_tile = gridDim.x + (ticket - ticket_base);
             lds_barrier();
             if (draw) next_tile = s_tile;
-            const u32 v = lane < NW ? s_scan[lane] : 0u;
+            const u32 v = lane < NW * R ? s_scan[lane] : 0u;
             cur.total = (u32)wave_reduce_sum_u64((u64)v);
-            cur.wbase = (u32)wave_reduce_sum_u64(lane < wave ? (u64)v : 0ull);
-            cur.q.wtotal = __builtin_amdgcn_readlane(v, wave);
-            cur.q.excl = inc - tsum;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                cur.wbase[r] = (u32)wave_reduce_sum_u64(lane < r * NW + wave ? (u64)v : 0ull);
+                cur.q[r].wtotal = __builtin_amdgcn_readlane(v, r * NW + wave);
+                cur.q[r].excl = inc[r] - tsum[r];
+            }
             cur.tile = tile;
             if (threadIdx.x == 0) publish_aggregate(ws->state, tile, (u64)cur.total + (tile == 0 ? base : 0ull), epoch);
         }
         // resolve + write the PREVIOUS tile
         if (have_prev && wave == 0) {
-            const u64 excl = resolve_prefix_helping(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help);
+            const u64 excl = (GTARS_TOK_ABLATE & 1) ? (u64)prev.tile * 2400u
+                                                    : resolve_prefix_helping(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help);
             if (lane == 0) {
                 s_prefix = excl;
                 if (prev.tile == num_tiles - 1) {
@@ -563,8 +618,11 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         }
         if (have_prev) {
             lds_barrier();
-            write_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, nq, min_bp, prev.q, (u64)prev.tile * TILE + (u64)threadIdx.x * QPT,
-                                             s_prefix + prev.wbase, offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                write_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, nq, min_bp, prev.q[r],
+                                                      (u64)prev.tile * TILE + (u64)r * ROUND + (u64)threadIdx.x * QPT,
+                                                      s_prefix + prev.wbase[r], offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
         }
         lds_barrier();  // s_tile / s_prefix / s_scan reuse
         if (!has_cur) break;
@@ -574,10 +632,6 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     }
 }
 
-// ---------------------------------------------------------------- K2 on the same structure
-// count_overlaps / any_overlaps (multi_chrom_overlapper.rs:483-517) for a Bits-kind index: the search and
-// the record burst without the scan -- counts do not depend on the result order, nor on the ids (always the
-// 32-byte records).
 // branch-free form of load_queries for 16-byte-aligned arrays: lanes past the end load element 0 and are
 // masked afterwards; a lane's 16 bytes never leave the array's last 16-byte chunk
 __device__ __forceinline__ void load_queries_bf4(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
@@ -590,6 +644,11 @@ __device__ __forceinline__ void load_queries_bf4(const u32 *__restrict__ qc, con
     e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
 }
 
+
+// ---------------------------------------------------------------- K2 on the same structure
+// count_overlaps / any_overlaps (multi_chrom_overlapper.rs:483-517) for a Bits-kind index: the search and
+// the record burst without the scan -- counts do not depend on the result order, nor on the ids (always the
+// 32-byte records).
 // PF (16-byte-aligned query arrays): the next tile's queries are loaded right behind the record burst (branch-free,
 // so that the wait for the records is a counted one that leaves them in flight): 570 -> 532 us per 64M queries.
 // (The same prefetch makes the tokenizer SLOWER -- 632 -> 772 us per 64M queries -- and is not used there.)
@@ -710,10 +769,14 @@ gtars_status launch_count_lds(const AccelView &a, const u32 *qc, const u32 *qs, 
 
 static u64 tok_tile_queries(int tpb, int qpt) { return (u64)tpb * (u64)qpt; }
 
-// queries per lane and tile: 4 (one burst of eight 16-byte loads per lane; 2 was slower at every batch size)
-static int choose_qpt(u64 nq) {
-    (void)nq;
-    return 4;
+// Queries per lane and round: 4 (one burst of eight 16-byte loads per lane; 2 was slower at every batch size).
+// Rounds per tile: 2 once every CU has several 8192-query tiles -- the query loads of both rounds are in flight
+// together and the per-tile costs (barriers, ticket, look-back) are paid half as often; small batches keep 4096-query
+// tiles so that every CU gets one.
+static int choose_rounds(u64 nq, int cus) {
+    const int forced = env_int("GTARS_TOK_ROUNDS", 0);
+    if (forced == 1 || forced == 2) return forced;
+    return nq >= (u64)cus * 8192ull * 4ull ? 2 : 1;
 }
 
 size_t tokenize_lds_ws_bytes(u64 nq) {
@@ -732,24 +795,24 @@ static u32 stage_words(const AccelView &a, int tpb, int per_cu) {
     return w >= 128 ? (u32)w : 0u;
 }
 
-template <int TPB, int QPT, bool FILTER, bool IMPL, bool REV>
+template <int TPB, int QPT, int R, bool FILTER, bool IMPL, bool REV>
 static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, const u64 *d_base, u64 *d_total_out,
                                  hipStream_t st) {
     static KernelSetup setup;
     int dev = 0, cus = 256;
-    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, FILTER, IMPL, REV>), dev, cus);
+    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, R, FILTER, IMPL, REV>), dev, cus);
     if (s0) return s0;
     // one 1024-thread workgroup per CU: one LDS copy of the search keys, 16 waves -- what 128 VGPRs admit
     const u32 stage = stage_words(a, TPB, 1);
     const size_t lds = tok_lds_bytes(a) + (size_t)stage * 4 * (TPB / 64);
     static const u32 spin_limit = (u32)env_int("GTARS_TOK_SPIN_LIMIT", 4096);
-    const u64 tile_q = tok_tile_queries(TPB, QPT);
+    const u64 tile_q = tok_tile_queries(TPB, QPT * R);
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     u64 grid = (u64)cus;
     if (grid > tiles) grid = tiles;
     const u64 cap = out.vals ? out.capacity : 0;
-    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, FILTER, IMPL, REV>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
+    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, R, FILTER, IMPL, REV>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
                        min_bp, out.offsets, out.vals, cap, ws, ep.epoch, ep.ticket_base, stage, spin_limit, d_base, d_total_out);
     GT_HIP(hipGetLastError());
     // tickets drawn by this launch: one per tile beyond the first `grid`, plus one failing draw per workgroup
@@ -774,8 +837,24 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
         return GTARS_OK;
     }
     constexpr int TPB = 1024;
-    const int qpt = choose_qpt(nq);
-    const u64 tile_q = tok_tile_queries(TPB, qpt);
+    int cus = 256;
+    {
+        int dev = 0;
+        GT_HIP(hipGetDevice(&dev));
+        static int cached[64] = {};
+        if (dev >= 0 && dev < 64) {
+            if (!cached[dev]) {
+                int c = 256;
+                GT_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+                cached[dev] = c;
+            }
+            cus = cached[dev];
+        }
+    }
+    const bool impl = a.ids_affine != 0;
+    // two rounds keep 8 queries' state per lane across the scan: with the id pairs of explicit-id records that spills
+    const int rounds = impl ? choose_rounds(nq, cus) : 1;
+    const u64 tile_q = tok_tile_queries(TPB, 4 * rounds);
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     if (tiles > 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "query batch too large for one launch");
     const size_t need = scan_ws_bytes_for_tiles(tiles);
@@ -792,18 +871,23 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     const bool filter = has_min && min_overlap > 1;
     const i32 min_bp = has_min ? min_overlap : 0;
     ScanWs *ws = (ScanWs *)scan_ws;
-    const bool impl = a.ids_affine != 0;
     if (!impl && !a.rec4) return fail(GTARS_ERR_INTERNAL, "index has no id records");
     ProfScope p("k_tok_lds", st);
-#define GT_TOK_CASE(Q, R)                                                                                                   \
-    if (qpt == Q && reverse == R) {                                                                                         \
-        if (impl) return filter ? launch_tok_t<TPB, Q, true, true, R>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)     \
-                                : launch_tok_t<TPB, Q, false, true, R>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);   \
-        return filter ? launch_tok_t<TPB, Q, true, false, R>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)              \
-                      : launch_tok_t<TPB, Q, false, false, R>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);            \
+#define GT_TOK_CASE(N, V)                                                                                                   \
+    if (rounds == N && reverse == V) {                                                                                      \
+        if (impl) return filter ? launch_tok_t<TPB, 4, N, true, true, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)     \
+                                : launch_tok_t<TPB, 4, N, false, true, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);   \
+        return filter ? launch_tok_t<TPB, 4, N, true, false, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)              \
+                      : launch_tok_t<TPB, 4, N, false, false, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);            \
     }
-    GT_TOK_CASE(4, false)
-    GT_TOK_CASE(4, true)
+    GT_TOK_CASE(1, false)
+    GT_TOK_CASE(1, true)
+    if (rounds == 2 && impl) {
+        if (reverse) return filter ? launch_tok_t<TPB, 4, 2, true, true, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)
+                                   : launch_tok_t<TPB, 4, 2, false, true, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
+        return filter ? launch_tok_t<TPB, 4, 2, true, true, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)
+                      : launch_tok_t<TPB, 4, 2, false, true, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
+    }
 #undef GT_TOK_CASE
     return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");
 }

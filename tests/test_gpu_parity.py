@@ -751,17 +751,74 @@ print("HELP_PARITY", ok)
 """
 
 
-@pytest.mark.parametrize("qpt", ["2", "4"])
-def test_lookback_helps_itself_instead_of_waiting(ga, qpt):
-    """k_tok_wave never depends on a predecessor tile being resident: a look-back that has polled an unpublished
+VARIANTS = {  # launch geometries of the fused tokenizer (tokenize_lds.hip): forced through the environment
+    "tile4096": {"GTARS_TOK_ROUNDS": "1"},
+    "tile8192": {"GTARS_TOK_ROUNDS": "2"},
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_lookback_helps_itself_instead_of_waiting(ga, variant):
+    """The tokenizer never depends on a predecessor tile being resident: a look-back that has polled an unpublished
     predecessor `spin_limit` times counts that tile itself.  With the limit forced to 0 EVERY wait takes that path
     (own subprocess: the limit is read once per process); results stay bit-exact."""
     import os, subprocess, sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GTARS_TOK_SPIN_LIMIT="0", GTARS_TOK_QPT=qpt)
+    env = dict(os.environ, GTARS_TOK_SPIN_LIMIT="0", **VARIANTS[variant])
     r = subprocess.run([sys.executable, "-c", _HELP_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
     assert "HELP_PARITY True" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_tokenizer_launch_geometries_agree_with_the_oracle(ga, monkeypatch, variant):
+    """Every launch geometry (4096- and 8192-query tiles) on: a sorted universe (ids from
+    the position), shuffled ids (explicit id records), a dense universe (tiles whose hits overflow the LDS stage take
+    the direct path), AIList order, a minimum-overlap filter, batch sizes around the tile sizes, and a caller
+    capacity smaller than the result."""
+    import torch
+    from gtars_amd import synth
+
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(77)
+    u = synth.make_universe(20_000)
+    shuffled = rng.permutation(len(u["chrom"])).astype(np.uint32)
+    cases = [(u["chrom"], u["start"], u["end"], None, KIND_BITS), (u["chrom"], u["start"], u["end"], shuffled, KIND_BITS),
+             (u["chrom"], u["start"], u["end"], shuffled, KIND_AILIST)]
+    dense_s = np.sort(rng.integers(0, 200_000, 30_000)).astype(np.uint32)
+    dense = (np.zeros(30_000, dtype=np.uint32), dense_s, dense_s + rng.integers(50, 400, 30_000).astype(np.uint32), None, KIND_BITS)
+    for c, s, e, val, kind in cases + [dense]:
+        n_chrom = int(c.max()) + 1
+        g, o = _pair(ga, c, s, e, val, n_chrom=n_chrom, kind=kind)
+        for nq in (1, 3839, 3841, 8193, 50_001):
+            if c is dense[0]:
+                qc = np.zeros(nq, dtype=np.uint32)
+                qs = rng.integers(0, 200_000, nq).astype(np.uint32)
+                qe = qs + rng.integers(1, 300, nq).astype(np.uint32)
+            else:
+                q = synth.make_queries(u, nq, seed=nq)
+                qc, qs, qe = q["chrom"].copy(), q["start"], q["end"]
+                qc[::53] = UNK
+            off_o, ids_o = o.tokenize(qc, qs, qe)
+            off_g, ids_g = g.tokenize(qc, qs, qe)
+            assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o), (variant, kind, nq)
+            fo = o.find_overlaps_regions(qc, qs, qe, 20)
+            fg = g.find_overlaps(qc, qs, qe, 20)
+            assert all(np.array_equal(a, b) for a, b in zip(fg, fo)), (variant, kind, nq, "min_overlap")
+        # capacity below the result: offsets complete, ids written up to the capacity, nothing beyond it
+        dev = torch.device("cuda:0")
+        d = [torch.from_numpy(x.view(np.int32)).to(dev) for x in (qc, qs, qe)]
+        h_all = len(ids_o)
+        capn = h_all // 2
+        offsets = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        ids = torch.full((h_all + 8,), -7, dtype=torch.int32, device=dev)
+        with pytest.raises(ga.CapacityError):
+            g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(), capn,
+                              torch.cuda.current_stream().cuda_stream, sync=True)
+        assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), off_o.astype(np.uint64))
+        assert np.array_equal(ids[:capn].cpu().numpy().view(np.uint32), ids_o[:capn])
+        assert bool((ids[capn:] == -7).all())
 
 
 def test_scan_epoch_wraps_after_16k_launches(ga):
