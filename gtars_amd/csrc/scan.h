@@ -14,13 +14,27 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Inclusive scan across the wave's 64 lanes on the VALU's data-parallel-primitive path: four shifts inside each row
+// of 16 lanes, then the row totals handed on with row_bcast:15 / row_bcast:31 -- six v_add_u32_dpp and no LDS
+// traffic (the __shfl_up form is six ds_bpermute round trips in a dependent chain).
 __device__ __forceinline__ u32 wave_inclusive_scan_u32(u32 x, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
+    (void)lane;
+    // lanes without a source (row_shr past the row start, rows masked out) read `old` = 0
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
     return x;
+}
+
+// Sum of one value < 2^48 per lane (the chained scan's granule payloads), every lane gets it: two 24-bit halves
+// summed by DPP scans (64 * 2^24 fits 32 bits), no LDS round trips in the look-back's critical path.
+__device__ __forceinline__ u64 wave_reduce_sum_u48(u64 x) {
+    const u32 lo = wave_inclusive_scan_u32((u32)x & 0xFFFFFFu, 0);
+    const u32 hi = wave_inclusive_scan_u32((u32)(x >> 24) & 0xFFFFFFu, 0);
+    return (u64)__builtin_amdgcn_readlane(lo, 63) + ((u64)__builtin_amdgcn_readlane(hi, 63) << 24);
 }
 
 __device__ __forceinline__ u64 wave_reduce_sum_u64(u64 x) {
@@ -141,7 +155,7 @@ __device__ __forceinline__ u64 resolve_prefix(u64 *state, u32 tile, u64 agg, int
             if (b_inv & need) continue;  // not ready: re-read from this window on
 #endif
             const u64 contrib = (lane <= first_inc) ? (val[w] & VAL_MASK) : 0ull;
-            excl += wave_reduce_sum_u64(contrib);
+            excl += wave_reduce_sum_u48(contrib);
             consumed = w + 1;
             if (first_inc < 64) done = true;
         }

@@ -512,7 +512,7 @@ __device__ __forceinline__ u64 resolve_prefix_helping(u64 *state, u32 tile, u64 
             }
             continue;
         }
-        excl += wave_reduce_sum_u64(lane <= first_inc ? (v & VAL_MASK) : 0ull);
+        excl += wave_reduce_sum_u48(lane <= first_inc ? (v & VAL_MASK) : 0ull);
         if (first_inc < 64) break;
         pred -= 64;
     }
@@ -520,25 +520,45 @@ __device__ __forceinline__ u64 resolve_prefix_helping(u64 *state, u32 tile, u64 
     return excl;
 }
 
-template <int TPB, int QPT, int R, bool FILTER, bool IMPL, bool REV>
+// G = 2: the workgroup's 16 waves form two GROUPS of 8 that take tiles independently of each other and
+// synchronize through LDS counters instead of s_barrier, so that one group's search, scan, look-back and LDS
+// compaction (no vector-memory traffic) run while the other group's record burst and stores keep the CU's
+// vector-memory path busy.  Both groups search the same LDS copy of the keys.
+__device__ __forceinline__ void group_barrier(u32 *ctr, u32 &phase, u32 members, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes have landed
+    phase += members;
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+        const u32 v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((i32)(v - phase) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV>
 __global__ void __launch_bounds__(TPB, TPB / 256)
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
           u32 epoch, u32 ticket_base, u32 stage_cap, u32 spin_limit, const u64 *__restrict__ d_base,
           u64 *__restrict__ d_total_out) {
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
-    __shared__ u32 s_tile;
-    __shared__ u64 s_prefix;
-    constexpr int NW = TPB / 64;
-    static_assert(NW * R <= 64, "one lane per wave part in the workgroup scan");
-    __shared__ u32 s_scan[NW * R];
-    // a tile is R rounds of TPB * QPT queries: round r of lane t holds queries tile * TILE + r * ROUND + t * QPT ...
-    constexpr u32 ROUND = TPB * QPT;
+    constexpr int NW = TPB / 64, GW = NW / G;  // waves per workgroup / per group
+    static_assert(GW * R <= 64, "one lane per wave part in the group's scan");
+    __shared__ u32 s_tile[G];
+    __shared__ u64 s_prefix[G];
+    __shared__ u32 s_scan[G][GW * R];
+    __shared__ u32 s_bar[G];
+    // a tile is R rounds of GW * 64 * QPT queries: round r of the group's lane t holds queries tile * TILE + r * ROUND + t * QPT ...
+    constexpr u32 ROUND = GW * 64 * QPT;
     constexpr u32 TILE = ROUND * R;
 
     const u32 num_tiles = (u32)((nq + TILE - 1) / TILE);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave / GW, gwave = wave % GW;   // group, wave within the group
+    const u32 gtid = threadIdx.x - (u32)grp * GW * 64;  // thread within the group
+    const u32 first_tiles = gridDim.x * G;            // tiles dealt by position; the others by ticket
     const bool vec_ok = ((((uintptr_t)qc) | ((uintptr_t)qs) | ((uintptr_t)qe)) & 15u) == 0;
     const bool off_vec_ok = (((uintptr_t)offsets) & 15u) == 0;
     const SearchLds L = search_lds_view(a, smem);
@@ -552,14 +572,22 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     auto load_tile = [&](u32 t) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            load_queries<QPT>(qc, qs, qe, nq, (u64)t * TILE + (u64)r * ROUND + (u64)threadIdx.x * QPT, vec_ok, c[r], s[r], e[r]);
+            load_queries<QPT>(qc, qs, qe, nq, (u64)t * TILE + (u64)r * ROUND + (u64)gtid * QPT, vec_ok, c[r], s[r], e[r]);
     };
     // the first tile's queries come from HBM: issue their loads before the LDS fill so that both overlap
-    u32 tile = blockIdx.x;
+    u32 tile = blockIdx.x * G + (u32)grp;
     load_tile(tile);
+    if (G > 1 && threadIdx.x < G) s_bar[threadIdx.x] = 0;
     fill_search_lds<TPB>(a, smem);
     __syncthreads();
 
+    u32 phase = 0;
+    auto bar = [&]() {
+        if constexpr (G == 1)
+            lds_barrier();
+        else
+            group_barrier(&s_bar[grp], phase, (u32)GW, lane);
+    };
     auto help = [&](u32 t) -> u64 {
         const u64 qb = (u64)t * TILE, qn = qb + TILE < nq ? qb + TILE : nq;
         return help_count_tile<FILTER>(a, L, qc, qs, qe, qb, qn, min_bp);
@@ -570,7 +598,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         u32 wbase[R], total, tile;
     } cur, prev;
     bool have_prev = false, loaded = true;
-    const bool draw = num_tiles > gridDim.x;  // otherwise one tile per workgroup: nothing to draw
+    const bool draw = num_tiles > first_tiles;  // otherwise one tile per group: nothing to draw
     for (;;) {
         const bool has_cur = tile < num_tiles;
         u32 next_tile = num_tiles;
@@ -578,7 +606,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             // the ticket of the NEXT tile is drawn (one lane) before this tile is counted and handed round through
             // the scan's barrier: its latency is off the critical path and no barrier is spent on it
             u32 ticket = 0;
-            if (draw && threadIdx.x == 0) ticket = atomicAdd(&ws->ticket, 1u);
+            if (draw && gtid == 0) ticket = atomicAdd(&ws->ticket, 1u);
             if (!loaded) load_tile(tile);
             loaded = false;
             u32 tsum[R], inc[R];
@@ -587,28 +615,30 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 inc[r] = wave_inclusive_scan_u32(tsum[r], lane);
-                if (lane == 63) s_scan[r * NW + wave] = inc[r];
+                if (lane == 63) s_scan[grp][r * GW + gwave] = inc[r];
             }
-            if (draw && threadIdx.x == 0) s_tile = gridDim.x + (ticket - ticket_base);
-            lds_barrier();
-            if (draw) next_tile = s_tile;
-            const u32 v = lane < NW * R ? s_scan[lane] : 0u;
-            cur.total = (u32)wave_reduce_sum_u64((u64)v);
+            if (draw && gtid == 0) s_tile[grp] = first_tiles + (ticket - ticket_base);
+            bar();
+            if (draw) next_tile = s_tile[grp];
+            // the group's wave parts, scanned by every wave for itself: one LDS read and six DPP adds
+            const u32 v = lane < GW * R ? s_scan[grp][lane] : 0u;
+            const u32 vinc = wave_inclusive_scan_u32(v, lane);
+            cur.total = __builtin_amdgcn_readlane(vinc, 63);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                cur.wbase[r] = (u32)wave_reduce_sum_u64(lane < r * NW + wave ? (u64)v : 0ull);
-                cur.q[r].wtotal = __builtin_amdgcn_readlane(v, r * NW + wave);
+                cur.q[r].wtotal = __builtin_amdgcn_readlane(v, r * GW + gwave);
+                cur.wbase[r] = __builtin_amdgcn_readlane(vinc, r * GW + gwave) - cur.q[r].wtotal;
                 cur.q[r].excl = inc[r] - tsum[r];
             }
             cur.tile = tile;
-            if (threadIdx.x == 0) publish_aggregate(ws->state, tile, (u64)cur.total + (tile == 0 ? base : 0ull), epoch);
+            if (gtid == 0) publish_aggregate(ws->state, tile, (u64)cur.total + (tile == 0 ? base : 0ull), epoch);
         }
         // resolve + write the PREVIOUS tile
-        if (have_prev && wave == 0) {
+        if (have_prev && gwave == 0) {
             const u64 excl = (GTARS_TOK_ABLATE & 1) ? (u64)prev.tile * 2400u
                                                     : resolve_prefix_helping(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help);
             if (lane == 0) {
-                s_prefix = excl;
+                s_prefix[grp] = excl;
                 if (prev.tile == num_tiles - 1) {
                     offsets[nq] = excl + (u64)prev.total;
                     ws->total = excl + (u64)prev.total;
@@ -617,14 +647,14 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             }
         }
         if (have_prev) {
-            lds_barrier();
+            bar();
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 write_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, nq, min_bp, prev.q[r],
-                                                      (u64)prev.tile * TILE + (u64)r * ROUND + (u64)threadIdx.x * QPT,
-                                                      s_prefix + prev.wbase[r], offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
+                                                      (u64)prev.tile * TILE + (u64)r * ROUND + (u64)gtid * QPT,
+                                                      s_prefix[grp] + prev.wbase[r], offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
         }
-        lds_barrier();  // s_tile / s_prefix / s_scan reuse
+        bar();  // s_tile / s_prefix / s_scan reuse
         if (!has_cur) break;
         prev = cur;
         have_prev = true;
@@ -778,6 +808,12 @@ static int choose_rounds(u64 nq, int cus) {
     if (forced == 1 || forced == 2) return forced;
     return nq >= (u64)cus * 8192ull * 4ull ? 2 : 1;
 }
+// wave groups per workgroup (k_tok_lds): 2 once every group has several tiles
+static int choose_groups(u64 nq, int cus) {
+    const int forced = env_int("GTARS_TOK_GROUPS", 0);
+    if (forced == 1 || forced == 2) return forced;
+    return nq >= (u64)cus * 8192ull * 4ull ? 2 : 1;
+}
 
 size_t tokenize_lds_ws_bytes(u64 nq) {
     // sized for the smallest tile (1024 threads x 2 queries)
@@ -795,28 +831,27 @@ static u32 stage_words(const AccelView &a, int tpb, int per_cu) {
     return w >= 128 ? (u32)w : 0u;
 }
 
-template <int TPB, int QPT, int R, bool FILTER, bool IMPL, bool REV>
+template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV>
 static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, const u64 *d_base, u64 *d_total_out,
                                  hipStream_t st) {
     static KernelSetup setup;
     int dev = 0, cus = 256;
-    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, R, FILTER, IMPL, REV>), dev, cus);
+    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV>), dev, cus);
     if (s0) return s0;
     // one 1024-thread workgroup per CU: one LDS copy of the search keys, 16 waves -- what 128 VGPRs admit
     const u32 stage = stage_words(a, TPB, 1);
     const size_t lds = tok_lds_bytes(a) + (size_t)stage * 4 * (TPB / 64);
     static const u32 spin_limit = (u32)env_int("GTARS_TOK_SPIN_LIMIT", 4096);
-    const u64 tile_q = tok_tile_queries(TPB, QPT * R);
+    const u64 tile_q = tok_tile_queries(TPB / G, QPT * R);
     const u64 tiles = (nq + tile_q - 1) / tile_q;
-    u64 grid = (u64)cus;
-    if (grid > tiles) grid = tiles;
+    const u64 grid = std::min<u64>((u64)cus, (tiles + G - 1) / G);
     const u64 cap = out.vals ? out.capacity : 0;
-    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, R, FILTER, IMPL, REV>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
+    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
                        min_bp, out.offsets, out.vals, cap, ws, ep.epoch, ep.ticket_base, stage, spin_limit, d_base, d_total_out);
     GT_HIP(hipGetLastError());
-    // tickets drawn by this launch: one per tile beyond the first `grid`, plus one failing draw per workgroup
-    if (tiles > grid) ep.ticket_base += (u32)tiles;
+    // tickets drawn by this launch: one per tile beyond the first `grid * G`, plus one failing draw per group
+    if (tiles > grid * G) ep.ticket_base += (u32)tiles;
     return GTARS_OK;
 }
 
@@ -854,7 +889,8 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     const bool impl = a.ids_affine != 0;
     // two rounds keep 8 queries' state per lane across the scan: with the id pairs of explicit-id records that spills
     const int rounds = impl ? choose_rounds(nq, cus) : 1;
-    const u64 tile_q = tok_tile_queries(TPB, 4 * rounds);
+    const int groups = choose_groups(nq, cus);
+    const u64 tile_q = tok_tile_queries(TPB / groups, 4 * rounds);
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     if (tiles > 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "query batch too large for one launch");
     const size_t need = scan_ws_bytes_for_tiles(tiles);
@@ -873,21 +909,21 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     ScanWs *ws = (ScanWs *)scan_ws;
     if (!impl && !a.rec4) return fail(GTARS_ERR_INTERNAL, "index has no id records");
     ProfScope p("k_tok_lds", st);
-#define GT_TOK_CASE(N, V)                                                                                                   \
-    if (rounds == N && reverse == V) {                                                                                      \
-        if (impl) return filter ? launch_tok_t<TPB, 4, N, true, true, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)     \
-                                : launch_tok_t<TPB, 4, N, false, true, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);   \
-        return filter ? launch_tok_t<TPB, 4, N, true, false, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)              \
-                      : launch_tok_t<TPB, 4, N, false, false, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);            \
-    }
-    GT_TOK_CASE(1, false)
-    GT_TOK_CASE(1, true)
-    if (rounds == 2 && impl) {
-        if (reverse) return filter ? launch_tok_t<TPB, 4, 2, true, true, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)
-                                   : launch_tok_t<TPB, 4, 2, false, true, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
-        return filter ? launch_tok_t<TPB, 4, 2, true, true, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st)
-                      : launch_tok_t<TPB, 4, 2, false, true, false>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
-    }
+#define GT_TOK_CASE(N, GG, F, I, V)                                                                                         \
+    if (rounds == N && groups == GG && filter == F && impl == I && reverse == V)                                            \
+        return launch_tok_t<TPB, 4, N, GG, F, I, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
+#define GT_TOK_GEOM(N, GG, I)                                                                                               \
+    GT_TOK_CASE(N, GG, false, I, false)                                                                                     \
+    GT_TOK_CASE(N, GG, true, I, false)                                                                                      \
+    GT_TOK_CASE(N, GG, false, I, true)                                                                                      \
+    GT_TOK_CASE(N, GG, true, I, true)
+    GT_TOK_GEOM(1, 1, true)
+    GT_TOK_GEOM(2, 1, true)
+    GT_TOK_GEOM(1, 2, true)
+    GT_TOK_GEOM(2, 2, true)
+    GT_TOK_GEOM(1, 1, false)
+    GT_TOK_GEOM(1, 2, false)
+#undef GT_TOK_GEOM
 #undef GT_TOK_CASE
     return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");
 }

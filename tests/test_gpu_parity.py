@@ -752,8 +752,10 @@ print("HELP_PARITY", ok)
 
 
 VARIANTS = {  # launch geometries of the fused tokenizer (tokenize_lds.hip): forced through the environment
-    "tile4096": {"GTARS_TOK_ROUNDS": "1"},
-    "tile8192": {"GTARS_TOK_ROUNDS": "2"},
+    "tile4096": {"GTARS_TOK_ROUNDS": "1", "GTARS_TOK_GROUPS": "1"},
+    "tile8192": {"GTARS_TOK_ROUNDS": "2", "GTARS_TOK_GROUPS": "1"},
+    "two_groups_tile2048": {"GTARS_TOK_ROUNDS": "1", "GTARS_TOK_GROUPS": "2"},
+    "two_groups_tile4096": {"GTARS_TOK_ROUNDS": "2", "GTARS_TOK_GROUPS": "2"},
 }
 
 
@@ -772,7 +774,7 @@ def test_lookback_helps_itself_instead_of_waiting(ga, variant):
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
 def test_tokenizer_launch_geometries_agree_with_the_oracle(ga, monkeypatch, variant):
-    """Every launch geometry (4096- and 8192-query tiles) on: a sorted universe (ids from
+    """Every launch geometry (one or two rounds per lane, one or two wave groups per workgroup) on: a sorted universe (ids from
     the position), shuffled ids (explicit id records), a dense universe (tiles whose hits overflow the LDS stage take
     the direct path), AIList order, a minimum-overlap filter, batch sizes around the tile sizes, and a caller
     capacity smaller than the result."""
