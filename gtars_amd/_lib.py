@@ -76,6 +76,8 @@ _SIG = {
     "gtars_index_kind": (C.c_int, [vp]),
     "gtars_index_chrom_len": (u64, [vp, u32]),
     "gtars_index_stored": (C.c_int, [vp, u32, vp, vp, vp]),
+    "gtars_index_insert": (C.c_int, [vp, u32, u32, u32, u32, vp]),
+    "gtars_index_seek": (C.c_int, [vp, u32, u32, u32, vp, vp, u64, vp]),
     "gtars_index_max_len": (u32, [vp, u32]),
     "gtars_index_n_sublists": (u64, [vp, u32]),
     "gtars_index_sublist_offsets": (C.c_int, [vp, u32, vp]),

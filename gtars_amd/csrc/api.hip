@@ -289,7 +289,14 @@ struct gtars_index {
         a.search_top = acc_search_top;
         a.top_shift = acc_top_shift;
         a.n_chrom = n_chrom;
+        a.max_chrom_n = max_chrom_n();
         return a;
+    }
+    // most intervals on one chromosome = the most hits one query can have
+    u32 max_chrom_n() const {
+        u32 m = 0;
+        for (size_t c = 0; c + 1 < h_chrom_off.size(); ++c) m = std::max(m, h_chrom_off[c + 1] - h_chrom_off[c]);
+        return m;
     }
     IndexView view() const {
         IndexView v;
@@ -856,6 +863,10 @@ static gtars_status count_dispatch(const gtars_index *ix, const u32 *qc, const u
 static gtars_status run_fused(const gtars_index *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               int has_min, i32 min_overlap, const EnumOut &out, void *ws, size_t ws_bytes,
                               ScanEpoch &ep, hipStream_t s) {
+    // hit counts are summed in 32 bits per tile: refuse a batch whose smallest tile could overflow them (every query
+    // of the tile overlapping every interval of the largest chromosome) instead of returning wrapped offsets
+    if ((u64)ix->max_chrom_n() * (u64)enumerate_fused_tile_queries() > 0xFFFFFFFFull)
+        return fail(GTARS_ERR_INVALID_ARG, "index too dense: a tile of queries could have more than 2^32 - 1 hits");
     if (use_lds_path(ix) && !out.starts && !out.ends)
         return launch_tokenize_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s, nullptr, nullptr,
                                    ix->kind == GTARS_KIND_AILIST);
@@ -1809,6 +1820,84 @@ gtars_status gtars_lola_contingency_device(const uint64_t *d_user_hits, const ui
 
 }  // extern "C"
 
+// ---- Bits::insert / Bits::seek (host side; SURVEY 8 a4': no caller on the hot path)
+// bits.rs:304-322 bsearch_seq_ref over the (start, end) order of one chromosome's stored intervals
+static u32 bits_insert_pos(const u32 *S, const u32 *E, u32 n, u32 start, u32 end) {
+    auto lt = [&](u32 i) { return S[i] < start || (S[i] == start && E[i] < end); };  // elems[i] < key (interval.rs:18-30)
+    if (n == 0 || !lt(0)) return 0;
+    if (lt(n - 1)) return n;
+    u32 cursor = 0, length = n;
+    while (length > 1) {
+        const u32 half = length >> 1;
+        length -= half;
+        cursor += lt(cursor + half - 1) ? half : 0u;
+    }
+    return cursor;
+}
+
+static gtars_status gtars_index_insert_impl(const gtars_index_t *ix, uint32_t chrom, uint32_t start, uint32_t end,
+                                            uint32_t val, gtars_index_t **out) {
+    if (!out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!ix) return fail(GTARS_ERR_INVALID_ARG, "NULL index");
+    if (ix->kind != GTARS_KIND_BITS) return fail(GTARS_ERR_INVALID_ARG, "insert is a Bits operation (bits.rs:209-222)");
+    if (chrom >= ix->n_chrom) return fail(GTARS_ERR_INVALID_ARG, "interval chromosome id >= n_chrom");
+    const u64 n = ix->n + 1;
+    std::vector<u32> c(n), s(n), e(n), v(n);
+    const u32 lo = ix->h_chrom_off[chrom], hi = ix->h_chrom_off[chrom + 1];
+    const u32 at = lo + bits_insert_pos(ix->h_starts.data() + lo, ix->h_ends.data() + lo, hi - lo, start, end);
+    u64 w = 0;
+    for (u32 k = 0; k < ix->n_chrom; ++k)
+        for (u32 p = ix->h_chrom_off[k]; p <= ix->h_chrom_off[k + 1]; ++p) {
+            if (k == chrom && p == at) {  // in front of equal (start, end) keys: the stable build keeps it there
+                c[w] = chrom, s[w] = start, e[w] = end, v[w] = val;
+                ++w;
+            }
+            if (p == ix->h_chrom_off[k + 1]) break;
+            c[w] = k, s[w] = ix->h_starts[p], e[w] = ix->h_ends[p], v[w] = ix->h_vals[p];
+            ++w;
+        }
+    return gtars_index_build_impl(c.data(), s.data(), e.data(), v.data(), n, ix->n_chrom, GTARS_KIND_BITS, out);
+}
+
+static gtars_status gtars_index_seek_impl(const gtars_index_t *ix, uint32_t chrom, uint32_t start, uint32_t stop,
+                                          uint64_t *cursor, uint32_t *out_vals, uint64_t capacity, uint64_t *n_hits) {
+    if (!ix || !cursor || !n_hits) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    if (ix->kind != GTARS_KIND_BITS) return fail(GTARS_ERR_INVALID_ARG, "seek is a Bits operation (bits.rs:364-386)");
+    *n_hits = 0;
+    if (chrom >= ix->n_chrom) return GTARS_OK;
+    const u32 lo = ix->h_chrom_off[chrom];
+    const u64 n = ix->h_chrom_off[chrom + 1] - lo;
+    const u32 *S = ix->h_starts.data() + lo, *E = ix->h_ends.data() + lo, *V = ix->h_vals.data() + lo;
+    const u32 max_len = ix->h_chrom_aux[chrom];
+    const u32 key = start >= max_len ? start - max_len : 0u;  // checked_sub(..).unwrap_or(0)
+    u64 cur = *cursor;
+    if (cur == 0 || (cur < n && S[cur] > start)) {
+        // Bits::lower_bound (bits.rs:250-264), same probe sequence
+        u64 size = n, low = 0;
+        while (size > 0) {
+            const u64 half = size / 2, other_half = size - half, probe = low + half, other_low = low + other_half;
+            size = half;
+            low = S[probe] < key ? other_low : low;
+        }
+        cur = low;
+    }
+    while (cur + 1 < n && S[cur + 1] < key) ++cur;
+    *cursor = cur;
+    u64 k = 0;
+    for (u64 off = cur; off < n; ++off) {  // IterFind::next, bits.rs:433-446
+        if (S[off] < stop && E[off] > start) {
+            if (out_vals && k < capacity) out_vals[k] = V[off];
+            ++k;
+        } else if (S[off] >= stop) {
+            break;
+        }
+    }
+    *n_hits = k;
+    if (out_vals && k > capacity) return fail(GTARS_ERR_CAPACITY, "seek: more hits than capacity");
+    return GTARS_OK;
+}
+
 // ---- the C ABI never lets a C++ exception cross it (std::bad_alloc of a huge build, std::length_error ...)
 extern "C" {
 
@@ -1816,6 +1905,16 @@ gtars_status gtars_index_build(const uint32_t *chrom, const uint32_t *start, con
                                const uint32_t *val, uint64_t n, uint32_t n_chrom, int kind,
                                gtars_index_t **out) {
     return guarded([&]() -> gtars_status { return gtars_index_build_impl(chrom, start, end, val, n, n_chrom, kind, out); });
+}
+
+gtars_status gtars_index_insert(const gtars_index_t *ix, uint32_t chrom, uint32_t start, uint32_t end, uint32_t val,
+                                gtars_index_t **out) {
+    return guarded([&]() -> gtars_status { return gtars_index_insert_impl(ix, chrom, start, end, val, out); });
+}
+
+gtars_status gtars_index_seek(const gtars_index_t *ix, uint32_t chrom, uint32_t start, uint32_t stop, uint64_t *cursor,
+                              uint32_t *out_vals, uint64_t capacity, uint64_t *n_hits) {
+    return guarded([&]() -> gtars_status { return gtars_index_seek_impl(ix, chrom, start, stop, cursor, out_vals, capacity, n_hits); });
 }
 
 gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start, const int32_t *end,

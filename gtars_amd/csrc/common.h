@@ -111,6 +111,7 @@ struct AccelView {
     u32 top_shift;
     u32 n_chrom;
     u32 ids_affine;
+    u32 max_chrom_n;  // most intervals on one chromosome: bounds a query's hits (tile totals are 32-bit)
 };
 
 // IGD database: all stored intervals (tile replicas are NOT materialised),
@@ -168,6 +169,7 @@ gtars_status launch_enumerate_fused(const IndexView &v, int kind, const u32 *qc,
                                     const u32 *qe, u64 nq, int has_min, i32 min_overlap,
                                     const EnumOut &out, void *scan_ws, size_t scan_ws_bytes,
                                     hipStream_t st);
+u32 enumerate_fused_tile_queries();
 size_t enumerate_fused_ws_bytes(u64 nq);
 
 // LDS-tiled fused tokenizer (tokenize_lds.hip), Bits order only

@@ -260,6 +260,7 @@ constexpr int ENUM_TPB = 256;
 constexpr int ENUM_QPT = 4;
 constexpr int ENUM_TILE = ENUM_TPB * ENUM_QPT;
 
+u32 enumerate_fused_tile_queries() { return ENUM_TILE; }
 size_t enumerate_fused_ws_bytes(u64 nq) {
     return scan_ws_bytes_for_tiles((nq + ENUM_TILE - 1) / ENUM_TILE);
 }

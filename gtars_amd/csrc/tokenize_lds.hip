@@ -750,7 +750,8 @@ static int env_int(const char *name, int dflt) {
 constexpr size_t TOK_LDS_MAX = 150 * 1024;    // search structure
 constexpr size_t TOK_LDS_TOTAL = 158 * 1024;  // search structure + id staging (static LDS comes on top)
 bool tokenize_lds_supported(const AccelView &a) {
-    return a.n_blocks > 0 && a.n_blocks <= ((1u << 22) - 1u) && a.n_units > 0 && tok_lds_bytes(a) <= TOK_LDS_MAX;
+    return a.n_blocks > 0 && a.n_blocks <= ((1u << 22) - 1u) && a.n_units > 0 && tok_lds_bytes(a) <= TOK_LDS_MAX &&
+           (u64)a.max_chrom_n * 2048ull <= 0xFFFFFFFFull;  // the smallest tile's 32-bit hit total
 }
 
 // The dynamic-LDS attribute belongs to the function (per device), not to the calling thread: it is raised once
@@ -888,8 +889,14 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     }
     const bool impl = a.ids_affine != 0;
     // two rounds keep 8 queries' state per lane across the scan: with the id pairs of explicit-id records that spills
-    const int rounds = impl ? choose_rounds(nq, cus) : 1;
-    const int groups = choose_groups(nq, cus);
+    int rounds = impl ? choose_rounds(nq, cus) : 1;
+    int groups = choose_groups(nq, cus);
+    // a tile's hits are summed in 32 bits: tile queries x (most intervals on one chromosome) must fit
+    const u64 dense = std::max<u64>(a.max_chrom_n, 1);
+    if (dense * tok_tile_queries(TPB / groups, 4 * rounds) > 0xFFFFFFFFull) rounds = 1;
+    if (dense * tok_tile_queries(TPB / groups, 4 * rounds) > 0xFFFFFFFFull) groups = 2;
+    if (dense * tok_tile_queries(TPB / groups, 4 * rounds) > 0xFFFFFFFFull)
+        return fail(GTARS_ERR_INVALID_ARG, "index too dense: a tile of queries could have more than 2^32 - 1 hits");
     const u64 tile_q = tok_tile_queries(TPB / groups, 4 * rounds);
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     if (tiles > 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "query batch too large for one launch");

@@ -77,6 +77,27 @@ class OverlapIndex:
         check(lib.gtars_index_sublist_offsets(self._h, c, ptr(out)))
         return [int(x) for x in out]
 
+    # -- Bits::insert / Bits::seek (bits.rs:209-222, 364-386) -----------------------
+    def insert(self, chrom: int, start: int, end: int, val: int) -> None:
+        """Bits::insert: the interval goes where ``bsearch_seq_ref`` puts it (in front of equal (start, end) keys).
+        The device structures are rebuilt (O(n), like the reference's Vec::insert)."""
+        h = C.c_void_p()
+        check(lib.gtars_index_insert(self._h, int(chrom), int(start), int(end), int(val), C.byref(h)))
+        old, self._h = self._h, h
+        lib.gtars_index_free(old)
+
+    def seek(self, chrom: int, start: int, stop: int, cursor: int = 0) -> Tuple[np.ndarray, int]:
+        """Bits::seek for sorted query sequences: -> (vals of the hits in stored order, updated cursor)."""
+        cur, n = C.c_uint64(int(cursor)), C.c_uint64()
+        out = np.empty(64, dtype=np.uint32)
+        rc = lib.gtars_index_seek(self._h, int(chrom), int(start), int(stop), C.byref(cur), ptr(out), len(out), C.byref(n))
+        if rc == _lib.ERR_CAPACITY:
+            out = np.empty(int(n.value), dtype=np.uint32)
+            cur = C.c_uint64(int(cursor))
+            rc = lib.gtars_index_seek(self._h, int(chrom), int(start), int(stop), C.byref(cur), ptr(out), len(out), C.byref(n))
+        check(rc)
+        return out[: int(n.value)].copy(), int(cur.value)
+
     # -- host-array queries ----------------------------------------------------
     def tokenize(self, qc, qs, qe, out: Optional[Tuple[np.ndarray, np.ndarray]] = None) -> Tuple[np.ndarray, np.ndarray]:
         """-> (offsets u64[nq+1], ids u32[H]) in reference order; no batch-level unk.

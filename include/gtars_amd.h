@@ -91,6 +91,18 @@ int gtars_index_kind(const gtars_index_t *ix);
 uint64_t gtars_index_chrom_len(const gtars_index_t *ix, uint32_t chrom);
 gtars_status gtars_index_stored(const gtars_index_t *ix, uint32_t chrom,
                                 uint32_t *start, uint32_t *end, uint32_t *val);
+/* Bits::insert (gtars-overlaprs/src/bits.rs:209-222).  The device structures are immutable: *out is a NEW index =
+ * `ix` plus the interval, stored where bsearch_seq_ref (bits.rs:304-322) puts it, i.e. in front of equal (start, end)
+ * keys, with max_len updated; the caller swaps handles and frees the old one.  O(n), like the reference's Vec::insert. */
+gtars_status gtars_index_insert(const gtars_index_t *ix, uint32_t chrom, uint32_t start, uint32_t end, uint32_t val,
+                                gtars_index_t **out);
+/* Bits::seek (bits.rs:364-386) + IterFind (bits.rs:433-446) on the host copy of one chromosome: *cursor is the
+ * caller's cursor into the chromosome's stored order (0 to begin), updated by the reference's rule; the vals of the
+ * hits from the cursor on are written to out_vals (may be NULL: count only).  More hits than `capacity`:
+ * GTARS_ERR_CAPACITY with *n_hits = the number needed.  Sequential API for completeness -- a batch of queries
+ * belongs in gtars_tokenize. */
+gtars_status gtars_index_seek(const gtars_index_t *ix, uint32_t chrom, uint32_t start, uint32_t stop, uint64_t *cursor,
+                              uint32_t *out_vals, uint64_t capacity, uint64_t *n_hits);
 /* Bits.max_len (bits.rs:110-119) / AIList.header_list (ailist.rs:127-141) */
 uint32_t gtars_index_max_len(const gtars_index_t *ix, uint32_t chrom);
 uint64_t gtars_index_n_sublists(const gtars_index_t *ix, uint32_t chrom);
