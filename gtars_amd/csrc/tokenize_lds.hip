@@ -457,11 +457,13 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
 // when other streams hold CUs.
 //
 // Measured and rejected on this structure (64M queries, 100k universe; profiles/r02/README.md): per-wave pipelines
-// without workgroup barriers (waves poll a control block in LDS: 855 us vs 619), prefetching the next tile's
-// queries behind the record burst (781 us: a wave's vector-memory operations retire in order, so whatever it
-// waits for next also waits for the prefetch and for the result stores in front of it), a dedicated scan wave
-// with prefetching workers (815 us), resolving a tile's base from the workgroup's own previous inclusive prefix plus
-// ONE round of 256 granule loads instead of chained 64-granule windows (658 us; 18.6 instead of 17.2 us per 1M).
+// without workgroup barriers (waves poll a control block in LDS: 855 us vs 619); prefetching the next tile's
+// queries, wherever the loads are issued -- behind the record burst (772-781 us) or a phase later, after the scan
+// barrier, as raw vectors unpacked at the next count (669 vs 620 us for the same build without the prefetch): with
+// the HBM stream in flight the tile's own look-back, tail and store traffic queues behind it in the CU's in-order
+// vector-memory pipe; a service wave that owns look-back and all stores while 15 waves only load (825 us); a dedicated
+// scan wave with prefetching workers (815 us); resolving a tile's base from the workgroup's own previous inclusive
+// prefix plus ONE round of 256 granule loads instead of chained 64-granule windows (658 us; 18.6 vs 17.2 us per 1M).
 // hits of queries [q_begin, q_end), counted by one wave (the look-back's self-service path: rare)
 template <bool FILTER>
 __device__ __forceinline__ u64 help_count_tile(const AccelView &a, const SearchLds &L, const u32 *qc, const u32 *qs,

@@ -808,3 +808,79 @@ def bh_qvalues(p_value_logs: Sequence[float]) -> List[float]:
     for j, i in enumerate(order):
         out[i] = q[j]
     return out
+
+
+class MutableBits:
+    """Bits with ``insert`` and ``seek`` -- a literal restatement on Python lists of gtars-overlaprs/src/bits.rs:
+    build 101-128, insert 209-222, lower_bound 250-264, bsearch_seq_ref 304-322, seek 364-386, IterFind 433-446.
+    Pure-Python loops: small cases only.  Intervals are (start, end, val) with u32 coordinates."""
+
+    def __init__(self, intervals: Sequence[Tuple[int, int, int]]):
+        self.intervals = sorted(((int(s), int(e), v) for s, e, v in intervals), key=lambda t: (t[0], t[1]))  # stable
+        self.starts = sorted(t[0] for t in self.intervals)
+        self.ends = sorted(t[1] for t in self.intervals)
+        self.max_len = max([e - s if e >= s else 0 for s, e, _ in self.intervals], default=0)  # checked_sub -> 0
+
+    def __len__(self) -> int:
+        return len(self.intervals)
+
+    @staticmethod
+    def _bsearch_seq_ref(lt, n: int) -> int:
+        """bits.rs:304-322 with ``lt(i)`` = elems[i] < key"""
+        if n == 0 or not lt(0):
+            return 0
+        if lt(n - 1):
+            return n
+        cursor, length = 0, n
+        while length > 1:
+            half = length >> 1
+            length -= half
+            cursor += half if lt(cursor + half - 1) else 0
+        return cursor
+
+    def insert(self, start: int, end: int, val) -> None:
+        si = self._bsearch_seq_ref(lambda i: self.starts[i] < start, len(self.starts))
+        ei = self._bsearch_seq_ref(lambda i: self.ends[i] < end, len(self.ends))
+        # Interval's Ord compares (start, end) (interval.rs:18-30)
+        ii = self._bsearch_seq_ref(lambda i: self.intervals[i][:2] < (start, end), len(self.intervals))
+        i_len = end - start if end >= start else 0
+        if i_len > self.max_len:
+            self.max_len = i_len
+        self.starts.insert(si, start)
+        self.ends.insert(ei, end)
+        self.intervals.insert(ii, (start, end, val))
+
+    def _lower_bound(self, start: int) -> int:
+        size, low = len(self.intervals), 0
+        while size > 0:
+            half = size // 2
+            other_half = size - half
+            probe, other_low = low + half, low + other_half
+            size = half
+            low = other_low if self.intervals[probe][0] < start else low
+        return low
+
+    def _iter_from(self, off: int, start: int, stop: int) -> List[Tuple[int, int, int]]:
+        out = []
+        while off < len(self.intervals):
+            s, e, v = self.intervals[off]
+            off += 1
+            if s < stop and e > start:
+                out.append((s, e, v))
+            elif s >= stop:
+                break
+        return out
+
+    def find(self, start: int, stop: int) -> List[Tuple[int, int, int]]:
+        key = start - self.max_len if start >= self.max_len else 0
+        return self._iter_from(self._lower_bound(key), start, stop)
+
+    def seek(self, start: int, stop: int, cursor: int) -> Tuple[List[Tuple[int, int, int]], int]:
+        """-> (hits, updated cursor)"""
+        n = len(self.intervals)
+        key = start - self.max_len if start >= self.max_len else 0
+        if cursor == 0 or (cursor < n and self.intervals[cursor][0] > start):
+            cursor = self._lower_bound(key)
+        while cursor + 1 < n and self.intervals[cursor + 1][0] < key:
+            cursor += 1
+        return self._iter_from(cursor, start, stop), cursor

@@ -970,3 +970,64 @@ def test_tokenize_async_while_another_stream_holds_cus(ga, hog_wgs, hog_lds):
             if rep > 1:  # every repetition of the base batch: same counts, same ids
                 assert np.array_equal(np.diff(got_off.astype(np.int64)).reshape(rep, nq1), np.tile(np.diff(off_o.astype(np.int64)), (rep, 1)))
                 assert np.array_equal(ids[h1 * (rep - 1): h1 * rep].cpu().numpy().view(np.uint32), ids_o)
+
+
+# ------------------------------------------------------------ Bits::insert / Bits::seek behind the C ABI
+
+
+def test_bits_insert_and_seek_match_the_reference_rules(ga):
+    """gtars_index_insert / gtars_index_seek vs the literal list restatement (oracle.MutableBits): the doc examples of
+    bits.rs:193-206 and 351-361, then random inserts (equal keys, wider-than-max_len intervals, two chromosomes) with
+    sorted and unsorted seek sequences carrying one cursor, and the device path (tokenize) on the index after inserts."""
+    g = ga.OverlapIndex(np.zeros(2, dtype=np.uint32), np.array([0, 6], dtype=np.uint32), np.array([5, 10], dtype=np.uint32),
+                        np.array([1, 2], dtype=np.uint32), n_chrom=1)
+    g.insert(0, 0, 20, 5)
+    assert len(g) == 3 and g.max_len(0) == 20
+    off, ids = g.tokenize(np.zeros(1, dtype=np.uint32), np.array([1], dtype=np.uint32), np.array([3], dtype=np.uint32))
+    assert ids.tolist() == [1, 5]  # {0,5,1} then {0,20,5}
+    xs = np.arange(0, 100, 5, dtype=np.uint32)
+    g = ga.OverlapIndex(np.zeros(len(xs), dtype=np.uint32), xs, xs + 2, n_chrom=1)
+    cur = 0
+    for x in xs.tolist():
+        vals, cur = g.seek(0, x, x + 2, cur)
+        assert len(vals) == 1
+    rng = np.random.default_rng(9)
+    n = 400
+    c = rng.integers(0, 2, n).astype(np.uint32)
+    s = rng.integers(0, 3000, n).astype(np.uint32)
+    e = (s + rng.integers(0, 100, n)).astype(np.uint32)
+    v = np.arange(n, dtype=np.uint32)
+    g = ga.OverlapIndex(c, s, e, v, n_chrom=2)
+    refs = [oracle.MutableBits([(int(s[i]), int(e[i]), int(v[i])) for i in range(n) if c[i] == ch]) for ch in (0, 1)]
+    for k in range(60):
+        ch = int(rng.integers(0, 2))
+        if k % 3 == 0:  # an equal (start, end) key: goes in front of the existing ones
+            a, b = refs[ch].intervals[int(rng.integers(0, len(refs[ch])))][:2]
+        else:
+            a = int(rng.integers(0, 3000))
+            b = a + int(rng.integers(0, 400))
+        g.insert(ch, a, b, 10_000 + k)
+        refs[ch].insert(a, b, 10_000 + k)
+    for ch in (0, 1):
+        st, en, va = g.stored(ch)
+        assert list(zip(st.tolist(), en.tolist(), va.tolist())) == refs[ch].intervals
+        assert g.max_len(ch) == refs[ch].max_len
+        for sorted_queries in (True, False):
+            qs = rng.integers(0, 3200, 300)
+            if sorted_queries:
+                qs = np.sort(qs)
+            cur_g = cur_o = 0
+            for q in qs.tolist():
+                w = int(rng.integers(0, 200))
+                vals, cur_g = g.seek(ch, q, q + w, cur_g)
+                hits, cur_o = refs[ch].seek(q, q + w, cur_o)
+                assert cur_g == cur_o and vals.tolist() == [t[2] for t in hits]
+    # the device structures were rebuilt: the kernel path sees the inserted intervals
+    qs = rng.integers(0, 3200, 500).astype(np.uint32)
+    qe = (qs + rng.integers(0, 200, 500)).astype(np.uint32)
+    qc = rng.integers(0, 2, 500).astype(np.uint32)
+    off, ids = g.tokenize(qc, qs, qe)
+    for i in range(500):
+        assert ids[off[i]:off[i + 1]].tolist() == [t[2] for t in refs[int(qc[i])].find(int(qs[i]), int(qe[i]))]
+    with pytest.raises(ValueError):  # GTARS_ERR_INVALID_ARG: insert is a Bits operation
+        ga.OverlapIndex(c, s, e, v, n_chrom=2, kind=KIND_AILIST).insert(0, 1, 2, 3)

@@ -496,3 +496,51 @@ def test_splitmix64_matches_c():
     py = oracle.SplitMix64(12345)
     for _ in range(5):
         assert oracle.lib().orc_splitmix64(ctypes.byref(st)) == py.next()
+
+
+# ------------------------------------------------------------ Bits::insert / Bits::seek (doc tests of bits.rs)
+
+
+def test_bits_insert_doc_example():
+    # bits.rs:193-206: insert {0,20,5} into [{0,5,1},{6,10,2}]; find_iter(1,3) -> {0,5,1}, {0,20,5}
+    b = oracle.MutableBits([(0, 5, 1), (6, 10, 2)])
+    b.insert(0, 20, 5)
+    assert len(b) == 3
+    assert b.find(1, 3) == [(0, 5, 1), (0, 20, 5)]
+    assert b.max_len == 20 and b.starts == [0, 0, 6] and b.ends == [5, 10, 20]
+
+
+def test_bits_seek_doc_example():
+    # bits.rs:351-361: intervals x..x+2 for x in 0,5,..,95; seeking each interval with one running cursor finds exactly it
+    b = oracle.MutableBits([(x, x + 2, True) for x in range(0, 100, 5)])
+    cursor = 0
+    for s, e, _ in list(b.intervals):
+        hits, cursor = b.seek(s, e, cursor)
+        assert len(hits) == 1
+    # bits.rs:44-58: sorted queries i..i+5
+    cursor = 0
+    for i in range(0, 100, 5):
+        hits, cursor = b.seek(i, i + 5, cursor)
+        assert hits == b.find(i, i + 5)
+
+
+def test_mutable_bits_agrees_with_the_c_restatement():
+    # find() of the list restatement == Index.find_overlaps_regions of oracle/gtars_oracle.c after rebuilding from the same order
+    rng = np.random.default_rng(3)
+    s = rng.integers(0, 2000, 300)
+    e = s + rng.integers(0, 120, 300)
+    b = oracle.MutableBits(list(zip(s.tolist(), e.tolist(), range(300))))
+    for k in range(40):
+        a = int(rng.integers(0, 2000))
+        b.insert(a, a + int(rng.integers(0, 200)), 1000 + k)
+    st = np.array([t[0] for t in b.intervals], dtype=np.uint32)
+    en = np.array([t[1] for t in b.intervals], dtype=np.uint32)
+    va = np.array([t[2] for t in b.intervals], dtype=np.uint32)
+    ix = oracle.Index(np.zeros(len(st), dtype=np.uint32), st, en, va, n_chrom=1)
+    assert ix.max_len(0) == b.max_len
+    assert ix.stored(0)[2].tolist() == va.tolist()  # the stable build keeps the inserted order
+    qs = rng.integers(0, 2100, 200).astype(np.uint32)
+    qe = (qs + rng.integers(0, 150, 200)).astype(np.uint32)
+    off, ids = ix.tokenize(np.zeros(200, dtype=np.uint32), qs, qe)
+    for i in range(200):
+        assert [t[2] for t in b.find(int(qs[i]), int(qe[i]))] == ids[off[i]:off[i + 1]].tolist()
