@@ -24,6 +24,9 @@
 
 namespace gtars {
 
+#ifndef GTARS_IGD_ABLATE
+#define GTARS_IGD_ABLATE 0  // timing experiments (results wrong): 1 one record per query, 2 no histogram atomics, 4 no prefix-max scan
+#endif
 constexpr int IGD_TILE = (int)IGD_TILE_RECORDS;
 constexpr int SW_TPB = 512;
 
@@ -203,6 +206,11 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
     i32 *t_pm = reinterpret_cast<i32 *>(t_f + CAP);  // prefix maximum of the ends (carry-in included)
     i32 *t_pf = t_pm + CAP;                           // MODE 2: pme_file of the staged records
     u32 *bins = reinterpret_cast<u32 *>(t_pf + (MODE == 2 ? CAP : 0));  // [n_files]
+    // MODE 0 / 2 (a hit is decided by the (query, record) pair alone): the queries of a chunk with their record
+    // ranges, so that the PAIRS can be dealt evenly to the threads
+    __shared__ i32 c_s[SW_TPB], c_e[SW_TPB];
+    __shared__ u32 c_lo[SW_TPB], c_off[SW_TPB + 1];
+    __shared__ u32 s_part[SW_TPB / 64];
     __shared__ i32 s_wmax[SW_TPB / 64];
     for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
 
@@ -306,6 +314,131 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
         auto r_end = [&](u32 i) -> i32 { return i < n_lds ? t_e[i] : v.ends[p0 + i]; };
         auto r_file = [&](u32 i) -> u32 { return i < n_lds ? t_f[i] : v.files[p0 + i]; };
         const u32 q_lo = ql[tile], q_hi = qh[tile];
+        if constexpr (MODE != 1) {
+            // Pair-balanced scan.  A query's candidates are the records [lo, hi): lo = first record that can overlap it
+            // (prefix-max end > q_start), hi = first record that starts at or after q_end (the reference's scan
+            // stops there, igd.rs:772-846).  Per chunk of SW_TPB queries: one thread per query finds (lo, hi), the
+            // lengths are scanned, and every thread then takes the same number of consecutive (query, record) pairs
+            // -- no lane waits for the longest scan of its wave (a thread-per-query loop runs 20 records on average
+            // and 45 for the slowest lane).  Records past the staged range (rare) are scanned by the query's own thread.
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            for (u32 cb = q_lo; cb < q_hi; cb += SW_TPB) {
+                const u32 qi = cb + threadIdx.x;
+                i32 s = 0, e = 0;
+                u32 lo = 0, len = 0;
+                if (qi < q_hi) {
+                    if (interleaved) {
+                        const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
+                        s = (i32)se2.x;
+                        e = (i32)se2.y;
+                    } else {
+                        s = (i32)sqs[qi];
+                        e = (i32)sqe[qi];
+                    }
+                    u32 hi;
+                    if (min_overlap >= 1) {
+                        hi = n_lds;
+                        while (lo < hi) {
+                            const u32 mid = lo + ((hi - lo) >> 1);
+                            if (t_pm[mid] <= s)
+                                lo = mid + 1;
+                            else
+                                hi = mid;
+                        }
+                    } else {
+                        const i32 key = s > max_len ? s - max_len : 0;
+                        hi = cnt;
+                        while (lo < hi) {
+                            const u32 mid = lo + ((hi - lo) >> 1);
+                            if (t_s[mid] < key)
+                                lo = mid + 1;
+                            else
+                                hi = mid;
+                        }
+                    }
+                    // first staged record at or after lo whose start is >= q_end
+                    u32 a = lo, b = n_lds;
+                    while (a < b) {
+                        const u32 mid = a + ((b - a) >> 1);
+                        if (t_s[mid] < e)
+                            a = mid + 1;
+                        else
+                            b = mid;
+                    }
+                    len = a - lo;
+                    if (a == n_lds && n_seg > n_lds) {
+                        // the scan runs past the staged records: the rest from global memory, by this thread
+                        for (u32 r = max(lo, n_lds); r < n_seg; ++r) {
+                            const i32 rs = v.starts[p0 + r], re = v.ends[p0 + r];
+                            if (rs >= e) break;
+                            const i32 ov = (re < e ? re : e) - (rs > s ? rs : s);
+                            if (ov < min_overlap) continue;
+                            if (MODE == 2 && pme_file[p0 + r] > s) continue;
+                            atomicAdd(&bins[v.files[p0 + r]], 1u);
+                        }
+                    }
+                }
+                c_s[threadIdx.x] = s;
+                c_e[threadIdx.x] = e;
+                c_lo[threadIdx.x] = lo;
+                // exclusive scan of the lengths over the chunk
+                const u32 inc = wave_inclusive_scan_u32(len, lane);
+                if (lane == 63) s_part[wave] = inc;
+                __syncthreads();
+                u32 wbase = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < SW_TPB / 64; ++w) {
+                    const u32 x = s_part[w];
+                    wbase += w < wave ? x : 0u;
+                    total += x;
+                }
+                c_off[threadIdx.x] = wbase + inc - len;
+                if (threadIdx.x == 0) c_off[SW_TPB] = total;
+                __syncthreads();
+                if (total) {
+                    const u32 ppt = (total + SW_TPB - 1) / SW_TPB;
+                    u32 p = threadIdx.x * ppt;
+                    const u32 p_end = min(p + ppt, total);
+                    if (p < p_end) {
+                        // the query that holds pair p: last j with c_off[j] <= p
+                        u32 j = 0, jh = SW_TPB;
+                        while (jh - j > 1) {
+                            const u32 mid = (j + jh) >> 1;
+                            if (c_off[mid] <= p)
+                                j = mid;
+                            else
+                                jh = mid;
+                        }
+                        u32 j_end = c_off[j + 1];
+                        u32 r = c_lo[j] + (p - c_off[j]);
+                        i32 qs_ = c_s[j], qe_ = c_e[j];
+                        for (; p < p_end; ++p, ++r) {
+                            if (p == j_end) {  // next query with a non-empty range
+                                do {
+                                    ++j;
+                                    j_end = c_off[j + 1];
+                                } while (j_end == p);
+                                r = c_lo[j];
+                                qs_ = c_s[j];
+                                qe_ = c_e[j];
+                            }
+                            const i32 rs = t_s[r], re = t_e[r];
+                            const i32 ov = (re < qe_ ? re : qe_) - (rs > qs_ ? rs : qs_);
+                            bool hit = ov >= min_overlap;
+                            if (MODE == 2) hit = hit && t_pf[r] <= qs_;  // no earlier record of this file reaches the query
+                            if (hit) {
+                                if (GTARS_IGD_ABLATE & 2) {
+                                    if (rs == 0x7FFFFFF0) bins[0] = 1;
+                                } else {
+                                    atomicAdd(&bins[t_f[r]], 1u);
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();  // c_* reused by the next chunk
+            }
+        } else
         for (u32 qi = q_lo + threadIdx.x; qi < q_hi; qi += SW_TPB) {
             // (start, end) pairs as the partition leaves them, or two sorted columns
             i32 s, e;
@@ -349,7 +482,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
             u32 sl[IGD_SEEN / 2];
 #pragma unroll
             for (int k = 0; k < IGD_SEEN / 2; ++k) sl[k] = 0xFFFFFFFFu;
-            for (u32 r = lo; r < n_seg; ++r) {
+            for (u32 r = lo; r < ((GTARS_IGD_ABLATE & 1) ? min(n_seg, lo + 1u) : n_seg); ++r) {
                 // the three fields of a record in one LDS round trip
                 i32 rs, re, pf = 0;
                 u32 f;
@@ -395,7 +528,11 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                     }
                     ++n_seen;
                 }
-                atomicAdd(&bins[f], 1u);
+                if (GTARS_IGD_ABLATE & 2) {
+                    if (f == 0xFFFFFFF0u) bins[0] = 1;
+                } else {
+                    atomicAdd(&bins[f], 1u);
+                }
             }
         }
         __syncthreads();  // every query of the current tile served: LDS may be overwritten

@@ -449,9 +449,10 @@ def test_fragment_files_in_parallel_host_threads(tmp_path):
     serial = [tokenize_fragment_file(f, tok) for f in files]
     for rep in range(3):
         assert tokenize_fragment_files(files, tok, workers=8) == serial
-    # and against the oracle for one of them
+    # and against the oracle, every file
     o = oracle.OracleTokenizer(str(ub))
-    assert serial[0] == o.tokenize_fragment_file(files[0])
+    for f, got in zip(files, serial):
+        assert got == o.tokenize_fragment_file(f), f
 
 
 def test_bench_line_contract():

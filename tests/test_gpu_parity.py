@@ -733,6 +733,39 @@ def test_config4_lola_counts_identities(ga):
     assert np.array_equal(sh[:8], exp.astype(np.int64))
 
 
+def test_config4_full_size_support_vectors(ga):
+    """BASELINE config 4 at its full single-GPU size: 2000 DB sets x 25k regions (5e7 records), universe 1e6, user set
+    1e5.  The support vectors (binary IGD counts) of the user set and of the universe equal the oracle's on 24 DB sets
+    spread over the whole file range (their records only: per-file counts are independent of the other files), the
+    pairwise counts too, and the contingency identities hold for all 2000 sets."""
+    from gtars_amd import synth
+
+    F, per = 2000, 25_000
+    db = synth.make_igd_db(F * per, F, seed=12)
+    uni = synth.make_universe(1_000_000, seed=4)
+    rng = np.random.default_rng(10)
+    sel = np.sort(rng.choice(len(uni["chrom"]), 100_000, replace=False))
+    user = {k: uni[k][sel] for k in ("chrom", "start", "end")}
+    g = ga.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=F)
+    uh = g.count_region_hits(uni["chrom"], uni["start"], uni["end"], 1).astype(np.int64)
+    sh = g.count_region_hits(user["chrom"], user["start"], user["end"], 1).astype(np.int64)
+    pw = g.count_set_overlaps(user["chrom"], user["start"], user["end"], 1).astype(np.int64)
+    a, b, c, d = oracle.lola_contingency(sh, uh, len(sel), len(uni["chrom"]))
+    assert np.array_equal(a + b, uh) and (a + c == len(sel)).all() and (a + b + c + d == len(uni["chrom"])).all()
+    assert (sh <= uh).all() and (sh <= pw).all() and int(sh.sum()) > 0
+    sample = np.unique(np.concatenate([[0, 1, F - 1, F - 2], rng.integers(0, F, 20)]))
+    remap = np.full(F, -1, dtype=np.int64)
+    remap[sample] = np.arange(len(sample))
+    keep = np.nonzero(remap[db["file"]] >= 0)[0]
+    o = oracle.Igd()
+    o.add_arrays(db["chrom"][keep], db["start"][keep], db["end"][keep], np.zeros(len(keep), dtype=int), remap[db["file"][keep]])
+    o.n_files = len(sample)
+    o.finalize()
+    assert np.array_equal(sh[sample], o.count_region_hits(user["chrom"], user["start"], user["end"], 1, n_files=len(sample)).astype(np.int64))
+    assert np.array_equal(pw[sample], o.count_set_overlaps(user["chrom"], user["start"], user["end"], 1, n_files=len(sample)).astype(np.int64))
+    assert np.array_equal(uh[sample], o.count_region_hits(uni["chrom"], uni["start"], uni["end"], 1, n_files=len(sample)).astype(np.int64))
+
+
 _HELP_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
