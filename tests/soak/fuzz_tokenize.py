@@ -30,13 +30,20 @@ def one(seed):
         k = rng.integers(0, n, 3)
         e[k] = np.maximum(s[k].astype(np.int64) - 5, 0)
     val = rng.permutation(n).astype(np.uint32)
+    if rng.random() < 0.5:                    # a sorted universe file: ids follow from the position (no id records)
+        order = np.lexsort((e, s, c))
+        c, s, e = c[order], s[order], e[order]
+        val = np.arange(n, dtype=np.uint32)
+    kind = gtars_amd.KIND_AILIST if rng.random() < 0.3 else gtars_amd.KIND_BITS
+    os.environ["GTARS_TOK_ROUNDS"] = str(rng.choice(["0", "1", "2"]))    # launch geometry of the fused tokenizer
+    os.environ["GTARS_TOK_GROUPS"] = str(rng.choice(["0", "1", "2"]))
     top_max = rng.choice(["", "64", "512"])
     if top_max:
         os.environ["GTARS_TOP_MAX"] = str(top_max)
     else:
         os.environ.pop("GTARS_TOP_MAX", None)
-    g = gtars_amd.OverlapIndex(c, s, e, val, n_chrom=n_chrom)
-    o = oracle.Index(c, s, e, val, n_chrom=n_chrom)
+    g = gtars_amd.OverlapIndex(c, s, e, val, n_chrom=n_chrom, kind=kind)
+    o = oracle.Index(c, s, e, val, n_chrom=n_chrom, kind=kind)
     nq = int(rng.choice([1, 5, 257, 4096, 4097, 70_001]))
     qc = rng.integers(0, n_chrom + 1, nq)
     qc = np.where(qc >= n_chrom, UNK, qc)
