@@ -441,6 +441,46 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
     }
 }
 
+// The write phase in two steps, for the round whose ids can be staged BEFORE the tile's global base is known: the ids
+// go to the wave's LDS buffer at wave-relative positions while wave 0 is still busy with the look-back (the other
+// waves would only wait for it), and once the base is there the buffer is flushed and the offsets are stored.
+// stage_queries returns false when the wave's ids do not fit the buffer (write_queries then serves the round).
+template <int QPT, bool FILTER, bool IMPL, bool REV>
+__device__ __forceinline__ bool stage_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
+                                              const u32 *__restrict__ qs, const u32 *__restrict__ qe, i32 min_bp,
+                                              const TileQ<QPT, IMPL> &t, u64 q0, u64 cap, u32 *stage, u32 stage_cap,
+                                              u32 (&orel)[QPT]) {
+    if (cap && t.wtotal > stage_cap) return false;
+    u64 o4[QPT];
+    emit_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, [&](u64 pos, u32 id) {
+        if (GTARS_TOK_ABLATE & 2) return;
+        stage[(u32)pos] = id;
+    });
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) orel[j] = (u32)o4[j];
+    return true;
+}
+template <int QPT>
+__device__ __forceinline__ void flush_queries(u64 nq, u32 wtotal, const u32 (&orel)[QPT], u64 q0, u64 wave_base,
+                                              u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, bool off_vec_ok,
+                                              const u32 *stage, int lane) {
+    if (cap && !(GTARS_TOK_ABLATE & 2)) {
+        // within the caller's capacity; 256 bytes per store instruction
+        const u32 n = wave_base >= cap ? 0u : (cap - wave_base < (u64)wtotal ? (u32)(cap - wave_base) : wtotal);
+        for (u32 i = (u32)lane; i < n; i += 64) __builtin_nontemporal_store(stage[i], &ovals[wave_base + i]);
+    }
+    if (GTARS_TOK_ABLATE & 4) {
+        if (orel[0] == 0xFFFFFFFFu) offsets[q0] = orel[QPT - 1];
+    } else if (QPT >= 2 && off_vec_ok && q0 + QPT <= nq) {
+#pragma unroll
+        for (int h = 0; h < QPT / 2; ++h) st_stream2(offsets + q0 + 2 * h, wave_base + orel[2 * h], wave_base + orel[2 * h + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < QPT; ++j)
+            if (q0 + j < nq) offsets[q0 + j] = wave_base + orel[j];
+    }
+}
+
 // ---------------------------------------------------------------- k_tok_lds
 // Persistent workgroups take tiles of TPB * QPT consecutive queries.  Per tile: count phase (search, record
 // burst, hit masks), workgroup scan of the hit counts, aggregate published; then -- one tile later, so that the
@@ -635,7 +675,13 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             cur.tile = tile;
             if (gtid == 0) publish_aggregate(ws->state, tile, (u64)cur.total + (tile == 0 ? base : 0ull), epoch);
         }
-        // resolve + write the PREVIOUS tile
+        // resolve + write the PREVIOUS tile.  Round 0's ids are staged in LDS before the base is known: by waves 1.. while
+        // wave 0 looks back, by wave 0 right after.
+        u32 orel0[QPT];
+        bool pre0 = false;
+        const u64 prev_q0 = (u64)prev.tile * TILE + (u64)gtid * QPT;
+        if (have_prev && gwave != 0)
+            pre0 = stage_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
         if (have_prev && gwave == 0) {
             const u64 excl = (GTARS_TOK_ABLATE & 1) ? (u64)prev.tile * 2400u
                                                     : resolve_prefix_helping(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help);
@@ -649,12 +695,19 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             }
         }
         if (have_prev) {
+            if (gwave == 0)
+                pre0 = stage_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
             bar();
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                write_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, nq, min_bp, prev.q[r],
-                                                      (u64)prev.tile * TILE + (u64)r * ROUND + (u64)gtid * QPT,
-                                                      s_prefix[grp] + prev.wbase[r], offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
+            for (int r = 0; r < R; ++r) {
+                const u64 q0 = (u64)prev.tile * TILE + (u64)r * ROUND + (u64)gtid * QPT;
+                if (r == 0 && pre0)
+                    flush_queries<QPT>(nq, prev.q[0].wtotal, orel0, q0, s_prefix[grp] + prev.wbase[0], offsets, ovals, cap, off_vec_ok,
+                                       stage, lane);
+                else
+                    write_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, nq, min_bp, prev.q[r], q0, s_prefix[grp] + prev.wbase[r],
+                                                          offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
+            }
         }
         bar();  // s_tile / s_prefix / s_scan reuse
         if (!has_cur) break;
