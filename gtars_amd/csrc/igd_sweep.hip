@@ -18,6 +18,7 @@
 //
 // Bound: HBM.  Algorithmic bytes 12*Nq + 16*Ndb + 8*F; no MFMA (integer compare/scan).
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 #include "scan.h"
@@ -720,7 +721,11 @@ gtars_status igd_build_pme_file(const IgdView &v, i32 *pme, void *ws, size_t ws_
 
 bool igd_sweep_supported(const IgdView &v, u64 nq) {
     if (getenv("GTARS_NO_IGD_SWEEP")) return false;
-    const u64 min_q = getenv("GTARS_IGD_SWEEP_MIN") ? (u64)atoll(getenv("GTARS_IGD_SWEEP_MIN")) : (1u << 16);
+    // The sweep reads the whole database once per batch (0.37 ms per 5e7 records) whatever the batch size; the per-query
+    // kernel costs ~1.2 ns per query at config-3/4 densities.  Crossover measured on config 4 (5e7 records): ~300k
+    // queries -- the 1e5-region user set goes per query (0.17 instead of 0.37 ms), the 1e6-region universe sweeps.
+    const u64 min_q = getenv("GTARS_IGD_SWEEP_MIN") ? (u64)atoll(getenv("GTARS_IGD_SWEEP_MIN"))
+                                                    : std::max<u64>(1u << 16, (u64)v.n / 256);
     // u32 LDS bins: a workgroup adds at most (its queries x hits) -- keep the batch below 2^31 queries
     return v.n > 0 && v.n_files > 0 && v.n_files <= 16384 && nq >= min_q && nq < (1ull << 31);
 }
@@ -824,8 +829,20 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
     const size_t lds = ((size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 5 : 4) + v.n_files) * 4;
     auto kern = mode == 2 ? k_igd_sweep<2> : mode == 1 ? k_igd_sweep<1> : k_igd_sweep<0>;
-    if (lds > 48 * 1024)
-        GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        // the dynamic-LDS limit belongs to the function, not to the calling thread: raised once per device to the largest
+        // size any launch can ask for (5 staged arrays + 16384 file bins) and never lowered
+        static std::mutex mu;
+        static bool done[3][64] = {};
+        int dev = 0;
+        GT_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev >= 0 && dev < 64 && !done[mode][dev]) {
+            GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(((size_t)(IGD_TILE + IGD_HALO) * 5 + 16384) * 4)));
+            done[mode][dev] = true;
+        }
+    }
     int per_cu = 1;
     GT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SW_TPB, lds));
     if (per_cu < 1) return fail(GTARS_ERR_INTERNAL, "k_igd_sweep does not fit on a CU");

@@ -263,6 +263,9 @@ class Igd:
         return int(h.sum())
 
     def count_set_overlaps(self, regions, min_overlap: int = 1) -> np.ndarray:
+        """igd.rs:544-561.  ``min_overlap`` must be >= 1 (``ValueError`` otherwise): for ``min_overlap <= 0`` the
+        reference's tile walk admits records that do not overlap the query, depending on the tile they fall in -- a
+        deliberate divergence, see INTEGRATION.md.  The same holds for every query method below."""
         self._require()
         return self._engine.count_set_overlaps(*self._encode(regions), min_overlap=min_overlap)[: self.num_files()]
 
