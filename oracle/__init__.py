@@ -884,3 +884,50 @@ class MutableBits:
         while cursor + 1 < n and self.intervals[cursor + 1][0] < key:
             cursor += 1
         return self._iter_from(cursor, start, stop), cursor
+
+
+# ------------------------------------------------------------------- CLI text front ends (gtars-cli)
+
+
+def overlaprs_text(universe: str, query: str, backend: str = "bits") -> str:
+    """gtars-cli/src/overlaprs/handlers.rs:21-157 restated: every line of both files is split on TAB, fields 2 and 3
+    parse as u32; per chromosome Bits / AIList over the universe's intervals (val = None); per query line, in file
+    order, one "chr\\tstart\\tend" line per hit in the backend's find order; unknown chromosomes are skipped."""
+    def read(path):
+        rows = []
+        with _open_text(path) as f:
+            for line in _rust_lines(f):
+                fields = line.split("\t")
+                if len(fields) < 3:
+                    raise ValueError("Missing field")
+                s, e = _parse_u32(fields[1]), _parse_u32(fields[2])
+                if s is None or e is None:
+                    raise ValueError("invalid digit found in string")
+                rows.append((fields[0], s, e))
+        return rows
+
+    uni, qry = read(universe), read(query)
+    names: Dict[str, int] = {}
+    cid = [names.setdefault(c, len(names)) for c, _, _ in uni]
+    kind = {"bits": KIND_BITS, "ailist": KIND_AILIST}[backend]
+    ix = Index(cid, [r[1] for r in uni], [r[2] for r in uni], None, n_chrom=len(names), kind=kind)
+    qc = [names.get(c, 0xFFFFFFFF) for c, _, _ in qry]
+    off, hs, he, _ = ix.find_overlaps_regions(qc, [r[1] for r in qry], [r[2] for r in qry])
+    out = []
+    for i, (c, _, _) in enumerate(qry):
+        for k in range(int(off[i]), int(off[i + 1])):
+            out.append(f"{c}\t{int(hs[k])}\t{int(he[k])}\n")
+    return "".join(out)
+
+
+def igd_search_text(bed_paths: Sequence[str], query: str) -> str:
+    """gtars-cli/src/igd/handlers.rs:74-98 restated over Igd::from_bed_files: the legacy TSV of the files with hits."""
+    db = OracleIgdDb(bed_paths)
+    regions = [(r[0], r[1], r[2]) for r in read_region_set(query)]  # RegionSet::try_from: parsed and sorted
+    hits = db.count_set_overlaps(regions, 1)
+    out = ["index\t number of regions\t number of hits\t File_name\n"]
+    for i, (name, n_regions, _) in enumerate(db.file_info):
+        if int(hits[i]) > 0:
+            out.append(f"{i}\t{n_regions}\t{int(hits[i])}\t{name}\n")
+    out.append(f"Total: {int(sum(int(h) for h in hits))}\n")
+    return "".join(out)

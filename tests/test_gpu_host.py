@@ -709,3 +709,70 @@ def test_bench_py_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
     assert out["roofline"]["kernel"] == "k_tok_lds" and 0 < out["roofline"]["frac"] < 1
     assert out["with_allgather"]["value"] > 0 and out["timing"]["repetitions"] >= 11
+
+
+# ------------------------------------------------------------ CLI text front ends (python -m gtars_amd overlaprs / igd)
+
+
+def test_cli_overlaprs_text_matches_the_reference_rules(golden_dir, tmp_path):
+    """gtars-cli/src/overlaprs/handlers.rs: same text, line for line, as the oracle restatement -- on the reference's
+    tokenizer fixtures and on a synthetic universe / query pair (.gz, 30k x 50k lines, unknown chromosomes), both backends."""
+    import gzip
+    import io
+    import subprocess
+    import sys
+
+    from gtars_amd import cli, synth
+
+    peaks = os.path.join(golden_dir, "tokenizers", "peaks.bed")
+    query = os.path.join(golden_dir, "to_tokenize.bed")
+    for backend in ("bits", "ailist"):
+        buf = io.StringIO()
+        n = cli.run_overlaprs(peaks, query, backend, buf)
+        exp = oracle.overlaprs_text(peaks, query, backend)
+        assert buf.getvalue() == exp and n == exp.count("\n") and n > 0
+    u = synth.make_universe(30_000, overlapping=True)
+    q = synth.make_queries(u, 50_000, seed=4)
+    up, qp = tmp_path / "u.bed.gz", tmp_path / "q.bed"
+    with gzip.open(up, "wt") as fh:
+        fh.write("".join(f"{synth.CHROM_NAMES[c]}\t{s}\t{e}\n" for c, s, e in zip(u["chrom"], u["start"], u["end"])))
+    qp.write_text("".join(f"{synth.CHROM_NAMES[c] if c < synth.N_CHROM else 'chrUn_1'}\t{s}\t{e}\tname\n"
+                          for c, s, e in zip(q["chrom"], q["start"], q["end"])))
+    for backend in ("bits", "ailist"):
+        buf = io.StringIO()
+        cli.run_overlaprs(str(up), str(qp), backend, buf)
+        assert buf.getvalue() == oracle.overlaprs_text(str(up), str(qp), backend)
+    # through the command line
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "gtars_amd", "overlaprs", "-u", peaks, "-q", query], cwd=root, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout == oracle.overlaprs_text(peaks, query, "bits")
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chr1\t1 \t2\n")
+    with pytest.raises(ValueError):
+        cli.run_overlaprs(str(bad), query, "bits", io.StringIO())
+    with pytest.raises(ValueError):
+        cli.run_overlaprs(peaks, query, "nclist", io.StringIO())
+
+
+def test_cli_igd_create_and_search(golden_dir, tmp_path):
+    """gtars-cli/src/igd/handlers.rs: create from a directory / a .txt list, search prints the legacy TSV."""
+    import io
+
+    from gtars_amd import cli
+
+    d = os.path.join(golden_dir, "igd_file_list_02")
+    beds = sorted(os.path.join(d, n) for n in os.listdir(d) if n.endswith((".bed", ".gz")))
+    assert cli.resolve_bed_paths(d) == beds
+    lst = tmp_path / "files.txt"
+    lst.write_text("\n".join(beds) + "\n\n")
+    assert cli.resolve_bed_paths(str(lst)) == beds
+    assert cli.resolve_bed_paths("-", io.StringIO("\n".join(beds))) == beds
+    db_path = cli.run_igd_create(str(tmp_path), d, "mydb")
+    assert db_path.endswith("mydb.igd") and os.path.exists(db_path)
+    for qn in ("query1.bed", "query2.bed"):
+        q = os.path.join(golden_dir, "igd_query_files", qn)
+        buf = io.StringIO()
+        total = cli.run_igd_search(db_path, q, buf)
+        exp = oracle.igd_search_text(beds, q)
+        assert buf.getvalue() == exp and f"Total: {total}\n" in exp

@@ -544,3 +544,32 @@ def test_mutable_bits_agrees_with_the_c_restatement():
     off, ids = ix.tokenize(np.zeros(200, dtype=np.uint32), qs, qe)
     for i in range(200):
         assert [t[2] for t in b.find(int(qs[i]), int(qe[i]))] == ids[off[i]:off[i + 1]].tolist()
+
+
+# ------------------------------------------------------------ CLI text front ends (gtars-cli overlaprs / igd search)
+
+
+def test_overlaprs_text_small(tmp_path):
+    # hand-derived: chr1 has (1,5) (3,9) (8,12), chr2 has (0,4); Bits lists hits in (start, end) order, AIList -- one
+    # sub-list here -- from the last start < q_end downwards; the chrX query is skipped; a line is "chr\tstart\tend"
+    u = tmp_path / "u.bed"
+    u.write_text("chr1\t3\t9\nchr2\t0\t4\nchr1\t1\t5\nchr1\t8\t12\textra\n")
+    q = tmp_path / "q.bed"
+    q.write_text("chr1\t4\t9\nchrX\t1\t2\nchr2\t3\t4\nchr1\t100\t200\n")
+    assert oracle.overlaprs_text(str(u), str(q), "bits") == "chr1\t1\t5\nchr1\t3\t9\nchr1\t8\t12\nchr2\t0\t4\n"
+    assert oracle.overlaprs_text(str(u), str(q), "ailist") == "chr1\t8\t12\nchr1\t3\t9\nchr1\t1\t5\nchr2\t0\t4\n"
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chr1\t 3\t9\n")
+    with pytest.raises(ValueError):
+        oracle.overlaprs_text(str(bad), str(q), "bits")
+
+
+def test_igd_search_text_small(tmp_path):
+    a = tmp_path / "a.bed"
+    a.write_text("chr1\t10\t20\nchr1\t15\t30\nchr2\t5\t6\n")
+    b = tmp_path / "b.bed"
+    b.write_text("chr3\t1\t2\n")
+    q = tmp_path / "q.bed"
+    q.write_text("chr1\t18\t19\nchr2\t0\t100\n")
+    assert oracle.igd_search_text([str(a), str(b)], str(q)) == (
+        "index\t number of regions\t number of hits\t File_name\n0\t3\t3\ta.bed\nTotal: 3\n")
