@@ -282,15 +282,9 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
             }
             // exclusive maximum over the threads before this one: wave shuffles, then one LDS word per wave
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            i32 inc = run;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const i32 y = __shfl_up(inc, d, 64);
-                if (lane >= d) inc = max(inc, y);
-            }
+            const i32 inc = wave_inclusive_max_nonneg(run);  // ends are > 0
             if (lane == 63) s_wmax[wave] = inc;
-            i32 excl = __shfl_up(inc, 1, 64);
-            if (lane == 0) excl = 0;
+            const i32 excl = __builtin_amdgcn_update_dpp(0, inc, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 gets 0
             __syncthreads();
             i32 before = cur.carry;
             for (int w = 0; w < wave; ++w) before = max(before, s_wmax[w]);

@@ -29,6 +29,17 @@ __device__ __forceinline__ u32 wave_inclusive_scan_u32(u32 x, int lane) {
     return x;
 }
 
+// Inclusive running maximum across the wave for values >= 0 (0 is the identity the DPP fills in), same DPP steps.
+__device__ __forceinline__ i32 wave_inclusive_max_nonneg(i32 x) {
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+
 // Sum of one value < 2^48 per lane (the chained scan's granule payloads), every lane gets it: two 24-bit halves
 // summed by DPP scans (64 * 2^24 fits 32 bits), no LDS round trips in the look-back's critical path.
 __device__ __forceinline__ u64 wave_reduce_sum_u48(u64 x) {
