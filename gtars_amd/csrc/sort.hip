@@ -118,11 +118,11 @@ k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 
 // per-workgroup cursors, and the second pass places every element with one more LDS atomic -- 10M queries into 24k
 // bins: ~0.3 ms instead of 1.25 ms for five 8-bit passes (profiles/r02).  Not stable (atomics decide the order inside a
 // bin); nothing downstream depends on it.
-// What bounds it (10M elements into 24k bins, GTARS ablations on the box): the scattered 8-byte stores -- 0.42 ms with them,
-// 0.09 ms with the same stores made contiguous, 0.05 ms without stores.  Random 8-byte accesses to an 80 MB region run at
-// ~3e10 per second chip-wide (one HBM burst each), reads and writes alike; a first pass into <= 256 coarse bins does not
-// help (0.51 ms for both passes): a wave's 64 stores still go to ~55 different lines.  The way down is a two-pass split
-// whose tiles are reordered by bin in LDS so that stores leave as runs (as k_radix_scatter does for its 8-bit digits).
+// What bounds it (10M elements into 24k bins: 0.215 ms by rocprofv3): the scattered 8-byte stores -- with the same stores
+// made contiguous the kernel takes a fifth of the time, without stores an eighth.  Random 8-byte accesses to an 80 MB region
+// run at ~5e10 per second chip-wide, reads and writes alike; a first pass into <= 256 coarse bins does not help (1.2x the
+// time for both passes): a wave's 64 stores still go to ~55 different lines.  The way down is a two-pass split whose tiles
+// are reordered by bin in LDS so that stores leave as runs (as k_radix_scatter does for its 8-bit digits).
 constexpr int MS_TPB = 1024;
 
 __global__ void __launch_bounds__(MS_TPB)

@@ -7,12 +7,19 @@ bench.py) and optionally <src>/igd (kernel-trace --stats of tools/igd_bench.py).
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same local directory: take the latest run's file"""
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=os.path.getmtime) if files else None
+
+
 def pmc(src, which, kernel):
-    f = glob.glob(f"{src}/{which}/**/*counter_collection.csv", recursive=True)[0]
+    f = newest(f"{src}/{which}/**/*counter_collection.csv")
     rows = [r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
     with open(f) as fh:
         head = fh.readline()
@@ -21,7 +28,7 @@ def pmc(src, which, kernel):
 
 def main(src, dst):
     kernel = "k_tok_lds"
-    ks = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)[0]
+    ks = newest(f"{src}/trace/**/*kernel_stats.csv")
     shutil.copy(ks, f"{dst}/kernel_stats_bench_1M.csv")
     shutil.copy(f"{src}/bench_trace.json", f"{dst}/bench_under_rocprof_trace.json")
     out = {}
@@ -58,9 +65,9 @@ def main(src, dst):
                 "8*(Nq+1)+4*H",
     }
     json.dump(doc, open(f"{dst}/traffic_tokenize_1M.json", "w"), indent=1)
-    igd = glob.glob(f"{src}/igd/**/*kernel_stats.csv", recursive=True)
+    igd = newest(f"{src}/igd/**/*kernel_stats.csv")
     if igd:
-        shutil.copy(igd[0], f"{dst}/kernel_stats_igd_config3.csv")
+        shutil.copy(igd, f"{dst}/kernel_stats_igd_config3.csv")
         shutil.copy(f"{src}/igd.json", f"{dst}/igd_config3.json")
     print(json.dumps(doc["fetch_size_kb_raw"]), doc["traffic_bytes_per_launch"])
 
