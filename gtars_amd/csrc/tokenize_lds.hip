@@ -263,73 +263,90 @@ __device__ __forceinline__ void load_queries(const u32 *__restrict__ qc, const u
     }
 }
 
-// count phase of QPT consecutive queries of one lane: search, record burst, hit masks.  Returns the lane's hits.
+// Count phase of a lane's R rounds of QPT = 4 consecutive queries: search, record burst, hit masks; tsum[r] = the lane's
+// hits in round r.  Software-pipelined over UNITS of two queries: unit u's LDS search runs while unit u-1's record loads
+// are in flight, and unit u-1's masks are taken while unit u's loads are (searching all four queries of a round first
+// and then waiting for all eight loads leaves the CU's vector-memory pipe idle during every search: 586 -> 555 us per 64M
+// queries for the two-unit split alone).
 // REV: the ids kept for the write phase are those of the LAST two hits (they are emitted first)
-template <int QPT, bool FILTER, bool IMPL, bool REV, class After>
-__device__ __forceinline__ u32 count_queries(const AccelView &a, const SearchLds &L, const u32 (&c)[QPT], const u32 (&s)[QPT],
-                                             const u32 (&e)[QPT], i32 min_bp, TileQ<QPT, IMPL> &t, After &&after_issue) {
+template <int R, int QPT, bool FILTER, bool IMPL, bool REV>
+__device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds &L, const u32 (&c)[R][QPT], const u32 (&s)[R][QPT],
+                                             const u32 (&e)[R][QPT], i32 min_bp, TileQ<QPT, IMPL> (&t)[R], u32 (&tsum)[R]) {
+    static_assert(QPT == 4, "two units of two queries per round");
     constexpr u32 STRIDE = IMPL ? 2 : 4;
+    constexpr int UQ = 2, NU = R * QPT / UQ;  // queries per unit, units
     const uint4 *__restrict__ recs = IMPL ? a.rec2 : a.rec4;
-    u32 b0[QPT], be[QPT];
-    if (GTARS_TOK_ABLATE & 16) {
+    u32 b0[2][UQ], be[2][UQ];
+    uint4 S[2][UQ], E[2][UQ], V[2][IMPL ? 1 : UQ];
+    bool act[2][UQ];
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-            b0[j] = (s[j] * 2654435761u) % a.n_blocks;
-            be[j] = c[j] < a.n_chrom ? a.n_blocks : 0u;
-        }
-    } else {
-        search_blocks<QPT>(a, L.lut, L.q, L.ctab, c, s, b0, be);
+    for (int r = 0; r < R; ++r) {
+        tsum[r] = 0;
+        t[r].more_bits = 0;
     }
-    uint4 S[QPT], E[QPT], V[IMPL ? 1 : QPT];
-    bool act[QPT];
+    auto issue = [&](int u) {  // search + record loads of unit u
+        const int r = u / 2, j0 = (u & 1) * UQ, p = u & 1;
+        if (GTARS_TOK_ABLATE & 16) {
 #pragma unroll
-    for (int j = 0; j < QPT; ++j) {
-        act[j] = b0[j] < be[j];
-        const uint4 *rec = recs + (size_t)(act[j] ? b0[j] : 0u) * STRIDE;
-        if (GTARS_TOK_ABLATE & 8) {
-            S[j] = make_uint4(s[j] ^ 8u, ~0u, ~0u, ~0u);
-            E[j] = make_uint4(e[j], 0, 0, 0);
-            if constexpr (!IMPL) V[j] = make_uint4((u32)j, 0, 0, 0);
+            for (int k = 0; k < UQ; ++k) {
+                b0[p][k] = (s[r][j0 + k] * 2654435761u) % a.n_blocks;
+                be[p][k] = c[r][j0 + k] < a.n_chrom ? a.n_blocks : 0u;
+            }
         } else {
-            S[j] = rec[0];
-            E[j] = rec[1];
-            if constexpr (!IMPL) V[j] = rec[2];
+            search_blocks<UQ>(a, L.lut, L.q, L.ctab, c[r] + j0, s[r] + j0, b0[p], be[p]);
         }
-    }
-    after_issue();  // the record loads are in flight
-    u32 tsum = 0;
-    t.more_bits = 0;
 #pragma unroll
-    for (int j = 0; j < QPT; ++j) {
-        u32 m = block_mask4<FILTER>(S[j], E[j], s[j], e[j], min_bp);
-        m = act[j] ? m : 0u;
-        const bool more = act[j] && (S[j].w < e[j]) && (b0[j] + 2 < be[j]);
-        u32 n = __popc(m);
-        if (more) n += walk_tail<FILTER, STRIDE>(recs, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
-        tsum += n;
-        t.st[j] = (b0[j] & B0_MASK) | (m << B0_BITS);
-        t.more_bits |= (more ? 1u : 0u) << j;
-        if constexpr (IMPL) {
-            t.aux[j] = (u32)ACC_OWN * b0[j] + L.idc[act[j] ? c[j] : 0u];
-        } else {
-            if (REV) {
-                t.aux[2 * j] = (m & 8u) ? V[j].w : (m & 4u) ? V[j].z : (m & 2u) ? V[j].y : V[j].x;
-                const u32 m2 = m ? m & ~(0x80000000u >> __clz(m)) : 0u;  // without its highest bit
-                t.aux[2 * j + 1] = (m2 & 4u) ? V[j].z : (m2 & 2u) ? V[j].y : V[j].x;
+        for (int k = 0; k < UQ; ++k) {
+            act[p][k] = b0[p][k] < be[p][k];
+            const uint4 *rec = recs + (size_t)(act[p][k] ? b0[p][k] : 0u) * STRIDE;
+            if (GTARS_TOK_ABLATE & 8) {
+                S[p][k] = make_uint4(s[r][j0 + k] ^ 8u, ~0u, ~0u, ~0u);
+                E[p][k] = make_uint4(e[r][j0 + k], 0, 0, 0);
+                if constexpr (!IMPL) V[p][k] = make_uint4((u32)k, 0, 0, 0);
             } else {
-                t.aux[2 * j] = (m & 1u) ? V[j].x : (m & 2u) ? V[j].y : (m & 4u) ? V[j].z : V[j].w;
-                const u32 m2 = m & (m - 1u);
-                t.aux[2 * j + 1] = (m2 & 2u) ? V[j].y : (m2 & 4u) ? V[j].z : V[j].w;
+                S[p][k] = rec[0];
+                E[p][k] = rec[1];
+                if constexpr (!IMPL) V[p][k] = rec[2];
             }
         }
+    };
+    auto finish = [&](int u) {  // masks, tails and write-phase state of unit u
+        const int r = u / 2, j0 = (u & 1) * UQ, p = u & 1;
+#pragma unroll
+        for (int k = 0; k < UQ; ++k) {
+            const int j = j0 + k;
+            const u32 qs_ = s[r][j], qe_ = e[r][j];
+            u32 m = block_mask4<FILTER>(S[p][k], E[p][k], qs_, qe_, min_bp);
+            m = act[p][k] ? m : 0u;
+            const bool more = act[p][k] && (S[p][k].w < qe_) && (b0[p][k] + 2 < be[p][k]);
+            u32 n = __popc(m);
+            if (more) n += walk_tail<FILTER, STRIDE>(recs, b0[p][k], be[p][k], qs_, qe_, min_bp, [](u32, int) {});
+            tsum[r] += n;
+            t[r].st[j] = (b0[p][k] & B0_MASK) | (m << B0_BITS);
+            t[r].more_bits |= (more ? 1u : 0u) << j;
+            if constexpr (IMPL) {
+                t[r].aux[j] = (u32)ACC_OWN * b0[p][k] + L.idc[act[p][k] ? c[r][j] : 0u];
+            } else {
+                const uint4 v = V[p][k];
+                if (REV) {
+                    t[r].aux[2 * j] = (m & 8u) ? v.w : (m & 4u) ? v.z : (m & 2u) ? v.y : v.x;
+                    const u32 m2 = m ? m & ~(0x80000000u >> __clz(m)) : 0u;  // without its highest bit
+                    t[r].aux[2 * j + 1] = (m2 & 4u) ? v.z : (m2 & 2u) ? v.y : v.x;
+                } else {
+                    t[r].aux[2 * j] = (m & 1u) ? v.x : (m & 2u) ? v.y : (m & 4u) ? v.z : v.w;
+                    const u32 m2 = m & (m - 1u);
+                    t[r].aux[2 * j + 1] = (m2 & 2u) ? v.y : (m2 & 4u) ? v.z : v.w;
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        issue(u);
+        __builtin_amdgcn_sched_barrier(0);  // keep the order: search and loads of u, THEN the wait for u - 1
+        if (u > 0) finish(u - 1);
     }
-    return tsum;
-}
-
-template <int QPT, bool FILTER, bool IMPL, bool REV>
-__device__ __forceinline__ u32 count_queries(const AccelView &a, const SearchLds &L, const u32 (&c)[QPT], const u32 (&s)[QPT],
-                                             const u32 (&e)[QPT], i32 min_bp, TileQ<QPT, IMPL> &t) {
-    return count_queries<QPT, FILTER, IMPL, REV>(a, L, c, s, e, min_bp, t, [] {});
+    finish(NU - 1);
 }
 
 // Emits the hits of the lane's QPT queries (first query q0) in result order: put(position, id) for every hit when
@@ -652,8 +669,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             if (!loaded) load_tile(tile);
             loaded = false;
             u32 tsum[R], inc[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) tsum[r] = count_queries<QPT, FILTER, IMPL, REV>(a, L, c[r], s[r], e[r], min_bp, cur.q[r]);
+            count_rounds<R, QPT, FILTER, IMPL, REV>(a, L, c, s, e, min_bp, cur.q, tsum);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 inc[r] = wave_inclusive_scan_u32(tsum[r], lane);
