@@ -770,15 +770,20 @@ k_count_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
         const u64 q0 = tile * TILE + (u64)threadIdx.x * QPT;
         if constexpr (!PF) load_queries<QPT>(qc, qs, qe, nq, q0, false, c, s, e);
         u32 b0[QPT], be[QPT];
-        search_blocks<QPT>(a, L.lut, L.q, L.ctab, c, s, b0, be);
         uint4 S[QPT], E[QPT];
         bool act[QPT];
+        // two units of two queries: the second unit's LDS search runs while the first unit's record loads are in flight
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-            act[j] = b0[j] < be[j];
-            const uint4 *rec = a.rec2 + (size_t)(act[j] ? b0[j] : 0u) * 2;
-            S[j] = rec[0];
-            E[j] = rec[1];
+        for (int h0 = 0; h0 < QPT; h0 += 2) {
+            search_blocks<2>(a, L.lut, L.q, L.ctab, c + h0, s + h0, b0 + h0, be + h0);
+#pragma unroll
+            for (int j = h0; j < h0 + 2; ++j) {
+                act[j] = b0[j] < be[j];
+                const uint4 *rec = a.rec2 + (size_t)(act[j] ? b0[j] : 0u) * 2;
+                S[j] = rec[0];
+                E[j] = rec[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         u32 c2[QPT], s2[QPT], e2[QPT];
         if constexpr (PF) {
