@@ -520,7 +520,10 @@ __device__ __forceinline__ void flush_queries(u64 nq, u32 wtotal, const u32 (&or
 // the HBM stream in flight the tile's own look-back, tail and store traffic queues behind it in the CU's in-order
 // vector-memory pipe; a service wave that owns look-back and all stores while 15 waves only load (825 us); a dedicated
 // scan wave with prefetching workers (815 us); resolving a tile's base from the workgroup's own previous inclusive
-// prefix plus ONE round of 256 granule loads instead of chained 64-granule windows (658 us; 18.6 vs 17.2 us per 1M).
+// prefix plus ONE round of 256 granule loads instead of chained 64-granule windows (658 us; 18.6 vs 17.2 us per 1M);
+// four wave groups (633 vs 560 us); for 1M-query launches two groups of 2048-query tiles with the second group's search
+// held back until the first group's record loads are in flight (20.1 vs 16.8 us: eight waves hide a burst's latency
+// worse than sixteen do, and the look-back chain doubles).
 // hits of queries [q_begin, q_end), counted by one wave (the look-back's self-service path: rare)
 template <bool FILTER>
 __device__ __forceinline__ u64 help_count_tile(const AccelView &a, const SearchLds &L, const u32 *qc, const u32 *qs,
