@@ -220,7 +220,7 @@ gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, 
 // the pairs interleaved, bin_off[n_bins + 1] the bin boundaries; elements whose key is `drop_bin` are left out (their bin
 // must be the last one)
 constexpr u32 MS_MAX_BINS = 36864;  // 144 KB of LDS counters
-size_t multisplit_ws_bytes(u32 n_bins);
+size_t multisplit_ws_bytes(u32 n_bins, u32 n);
 gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
                               u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st);
 

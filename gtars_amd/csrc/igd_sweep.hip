@@ -727,7 +727,7 @@ bool igd_sweep_supported(const IgdView &v, u64 nq) {
 size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom) {
     // kc ks ke | sorted qs qe chrom | perm (or owner tiles) | ql qh | cq_off | bin offsets | slack | partition / sort scratch
     return (size_t)nq * 4 * 7 + (size_t)n_tiles * 12 + ((size_t)n_chrom + 2) * 4 + 512 +
-           std::max(device_sort_perm_ws_bytes((u32)nq), multisplit_ws_bytes(n_tiles + 1));
+           std::max(device_sort_perm_ws_bytes((u32)nq), multisplit_ws_bytes(n_tiles + 1, (u32)nq));
 }
 
 // per-tile maximum end (index build: the carry-in of the sweep's prefix maximum is its running maximum)

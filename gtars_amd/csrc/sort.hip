@@ -118,11 +118,11 @@ k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 
 // per-workgroup cursors, and the second pass places every element with one more LDS atomic -- 10M queries into 24k
 // bins: ~0.3 ms instead of 1.25 ms for five 8-bit passes (profiles/r02).  Not stable (atomics decide the order inside a
 // bin); nothing downstream depends on it.
-// What bounds it (10M elements into 24k bins: 0.215 ms by rocprofv3): the scattered 8-byte stores -- with the same stores
-// made contiguous the kernel takes a fifth of the time, without stores an eighth.  Random 8-byte accesses to an 80 MB region
-// run at ~5e10 per second chip-wide, reads and writes alike; a first pass into <= 256 coarse bins does not help (1.2x the
-// time for both passes): a wave's 64 stores still go to ~55 different lines.  The way down is a two-pass split whose tiles
-// are reordered by bin in LDS so that stores leave as runs (as k_radix_scatter does for its 8-bit digits).
+// What bounds k_ms_scatter (10M elements into 24k bins: 0.215 ms by rocprofv3): the scattered 8-byte stores -- with the same
+// stores made contiguous the kernel takes a fifth of the time, without stores an eighth.  Random 8-byte accesses to an 80 MB
+// region run at ~5e10 per second chip-wide, reads and writes alike; a first pass into <= 256 coarse bins with the same
+// element-wise stores does not help (1.2x the time for both passes): a wave's 64 stores still go to ~55 different lines.
+// Large splits therefore go through k_split_pass below (tiles reordered by bin in LDS, stores leave as runs): 0.12 ms.
 constexpr int MS_TPB = 1024;
 
 __global__ void __launch_bounds__(MS_TPB)
@@ -221,26 +221,144 @@ static u32 ms_workgroups(u32 n) {
     const u32 by_size = (n + 16383) / 16384;
     return std::max<u32>(1, std::min<u32>(256, by_size));
 }
-size_t multisplit_ws_bytes(u32 n_bins) { return ((size_t)256 * n_bins + n_bins + 64) * 4; }
+
+// ---- two-level split with tiles reordered in LDS -------------------------------------------------------------
+// k_ms_scatter stores every element on its own: 64 lanes, ~55 different lines, and random 8-byte accesses to a large
+// region run at ~5e10 per second chip-wide.  Here a workgroup takes a tile of 8192 elements, ranks them by bin with LDS
+// atomics, reserves a run per bin with ONE global atomic on the bin's cursor, reorders the tile by bin in LDS and writes
+// it out slot by slot -- neighbouring lanes then store neighbouring elements of the same run.  Two passes keep the runs
+// long: pass A splits by coarse bin (key >> shift, <= 256 bins: runs of ~40 elements), pass B splits each coarse segment by
+// the full key -- a tile of pass A's output spans only a few coarse bins, i.e. <= SP_BINS neighbouring keys; an element
+// outside that window (tiny coarse segments) is placed with its own global atomic.  Not stable.
+constexpr int SP_TPB = 1024;
+constexpr int SP_ITEMS = 8;
+constexpr int SP_TILE = SP_TPB * SP_ITEMS;
+constexpr int SP_BINS = 1024;
+
+__global__ void k_split_init(const u32 *__restrict__ bin_off, u32 n_bins, u32 shift, u32 n_coarse, u32 *__restrict__ cur_a,
+                             u32 *__restrict__ cur_b) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_bins) cur_b[i] = bin_off[i];
+    if (i < n_coarse) cur_a[i] = bin_off[i << shift];
+}
+
+template <bool FINE>
+__global__ void __launch_bounds__(SP_TPB)
+k_split_pass(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
+             u32 shift, u32 drop_bin, u32 *__restrict__ cursor, u32 *__restrict__ out_key, uint2 *__restrict__ out_ab) {
+    extern __shared__ u32 sp_lds[];
+    u32 *s_k = sp_lds, *s_a = s_k + SP_TILE, *s_b = s_a + SP_TILE;
+    u32 *cnt = s_b + SP_TILE, *toff = cnt + SP_BINS, *gbase = toff + SP_BINS;
+    __shared__ u32 s_scan[SP_TPB / 64];
+    __shared__ u32 s_min;
+    const u32 n_tiles = (n + SP_TILE - 1) / SP_TILE;
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const u32 base = tile * SP_TILE;
+        cnt[threadIdx.x] = 0;  // SP_BINS == SP_TPB
+        if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
+        u32 k[SP_ITEMS], va[SP_ITEMS], vb[SP_ITEMS], lb[SP_ITEMS], rank[SP_ITEMS];
+        u32 kmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < SP_ITEMS; ++j) {
+            const u32 i = base + (u32)j * SP_TPB + threadIdx.x;
+            const bool ok = i < n;
+            k[j] = ok ? key[i] : 0xFFFFFFFFu;
+            if (FINE) {
+                const uint2 p = ok ? ab_in[i] : make_uint2(0u, 0u);
+                va[j] = p.x;
+                vb[j] = p.y;
+                if (k[j] == drop_bin) k[j] = 0xFFFFFFFFu;  // no owner: dropped here
+            } else {
+                va[j] = ok ? a[i] : 0u;
+                vb[j] = ok ? b[i] : 0u;
+            }
+            if (k[j] != 0xFFFFFFFFu) kmin = min(kmin, k[j]);
+        }
+        u32 bin0 = 0;
+        if (FINE) {
+            // the tile's window of keys starts at its smallest coarse bin
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) kmin = min(kmin, (u32)__shfl_xor((int)kmin, d, 64));
+            __syncthreads();  // s_min initialised
+            if ((threadIdx.x & 63) == 0 && kmin != 0xFFFFFFFFu) atomicMin(&s_min, kmin);
+            __syncthreads();
+            bin0 = s_min == 0xFFFFFFFFu ? 0u : (s_min >> shift) << shift;
+        } else {
+            __syncthreads();  // cnt zeroed
+        }
+#pragma unroll
+        for (int j = 0; j < SP_ITEMS; ++j) {
+            lb[j] = 0xFFFFFFFFu;
+            rank[j] = 0;
+            if (k[j] == 0xFFFFFFFFu) continue;
+            const u32 x = FINE ? k[j] - bin0 : k[j] >> shift;
+            if (x < (u32)SP_BINS) {
+                lb[j] = x;
+                rank[j] = atomicAdd(&cnt[x], 1u);
+            } else {
+                // outside the tile's window (FINE only): its own slot from the bin's cursor
+                out_ab[atomicAdd(&cursor[k[j]], 1u)] = make_uint2(va[j], vb[j]);
+            }
+        }
+        __syncthreads();
+        {
+            // tile-local layout + one reserved run per non-empty bin
+            const u32 c = cnt[threadIdx.x];
+            u32 total;
+            toff[threadIdx.x] = block_exclusive_scan<SP_TPB>(c, s_scan, total);
+            if (c) gbase[threadIdx.x] = atomicAdd(&cursor[FINE ? bin0 + threadIdx.x : threadIdx.x], c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SP_ITEMS; ++j) {
+            if (lb[j] == 0xFFFFFFFFu) continue;
+            const u32 slot = toff[lb[j]] + rank[j];
+            s_k[slot] = k[j];
+            s_a[slot] = va[j];
+            s_b[slot] = vb[j];
+        }
+        __syncthreads();
+        const u32 staged = toff[SP_BINS - 1] + cnt[SP_BINS - 1];
+        for (u32 j = threadIdx.x; j < staged; j += SP_TPB) {
+            const u32 kk = s_k[j];
+            const u32 x = FINE ? kk - bin0 : kk >> shift;
+            const u32 pos = gbase[x] + (j - toff[x]);
+            out_ab[pos] = make_uint2(s_a[j], s_b[j]);
+            if (!FINE) out_key[pos] = kk;
+        }
+        __syncthreads();  // LDS reused by the next tile
+    }
+}
+
+// table [256][n_bins] | tot [n_bins] | cursors (coarse [1024], fine [n_bins]) | first-level output: keys [n], pairs [n]
+size_t multisplit_ws_bytes(u32 n_bins, u32 n) {
+    return ((size_t)256 * n_bins + 2 * (size_t)n_bins + 1024 + 256) * 4 + (size_t)n * 12 + 256;
+}
 
 gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
                               u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st) {
     if (n_bins == 0 || n_bins > MS_MAX_BINS) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
-    if (ws_bytes < multisplit_ws_bytes(n_bins)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
+    if (ws_bytes < multisplit_ws_bytes(n_bins, n)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
     const u32 n_wg = ms_workgroups(n);
     const u32 chunk = (n + n_wg - 1) / n_wg;
     u32 *table = (u32 *)ws, *tot = table + (size_t)256 * n_bins;
+    u32 *cur_a = tot + n_bins, *cur_b = cur_a + 1024;
+    u32 *tmp_key = (u32 *)(((uintptr_t)(cur_b + n_bins) + 63) & ~(uintptr_t)63);
+    uint2 *tmp_ab = reinterpret_cast<uint2 *>(tmp_key + (((size_t)n + 15) & ~(size_t)15));
     const size_t lds = (size_t)n_bins * 4;
+    constexpr size_t sp_lds = ((size_t)SP_TILE * 3 + (size_t)SP_BINS * 3) * 4;
     static std::once_flag once[16];
     int dev = 0;
     GT_HIP(hipGetDevice(&dev));
     hipError_t attr_err = hipSuccess;
     std::call_once(once[dev & 15], [&]() {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ms_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(MS_MAX_BINS * 4));
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ms_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(MS_MAX_BINS * 4));
+        const void *fns[] = {reinterpret_cast<const void *>(k_ms_hist), reinterpret_cast<const void *>(k_ms_scatter)};
+        for (const void *fn : fns)
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MS_MAX_BINS * 4));
+        const void *sp[] = {reinterpret_cast<const void *>(k_split_pass<false>), reinterpret_cast<const void *>(k_split_pass<true>)};
+        for (const void *fn : sp)
+            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds);
     });
     GT_HIP(attr_err);
     {
@@ -252,7 +370,20 @@ gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n,
         hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot);
         hipLaunchKernelGGL(k_ms_binscan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off);
     }
-    {
+    static const bool one_level = getenv("GTARS_MS_ONE_LEVEL") != nullptr;  // A/B
+    if (n_bins > 1024 && n >= (1u << 20) && !one_level) {
+        u32 shift = 0;
+        while (((n_bins - 1) >> shift) >= 256u) ++shift;
+        const u32 n_coarse = ((n_bins - 1) >> shift) + 1;
+        const u32 tiles = (n + SP_TILE - 1) / SP_TILE;
+        const unsigned grid = std::min<u32>(256, tiles);
+        ProfScope p("k_split_pass", st);
+        hipLaunchKernelGGL(k_split_init, dim3((n_bins + 255) / 256), dim3(256), 0, st, bin_off, n_bins, shift, n_coarse, cur_a, cur_b);
+        hipLaunchKernelGGL(k_split_pass<false>, dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n, shift,
+                           drop_bin, cur_a, tmp_key, tmp_ab);
+        hipLaunchKernelGGL(k_split_pass<true>, dim3(grid), dim3(SP_TPB), sp_lds, st, tmp_key, (const u32 *)nullptr,
+                           (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (u32 *)nullptr, out_ab);
+    } else {
         ProfScope p("k_ms_scatter", st);
         hipLaunchKernelGGL(k_ms_scatter, dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off, drop_bin,
                            out_ab);
