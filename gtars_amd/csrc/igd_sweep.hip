@@ -202,15 +202,18 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
     constexpr int CAP = IGD_TILE + IGD_HALO;
     i32 *t_s = reinterpret_cast<i32 *>(sm);
     i32 *t_e = t_s + CAP;
-    u32 *t_f = reinterpret_cast<u32 *>(t_e + CAP);
+    // file ids as u16 (the LDS histogram limits a database to 16384 files): 4.5 KB less per workgroup -- with the chunk arrays
+    // below it decides between 2 and 3 workgroups per CU for the pme-binary form, and every workgroup less costs 20-75 %
+    unsigned short *t_f = reinterpret_cast<unsigned short *>(t_e + CAP);
     constexpr bool BINARY = MODE == 1;
-    i32 *t_pm = reinterpret_cast<i32 *>(t_f + CAP);  // prefix maximum of the ends (carry-in included)
+    i32 *t_pm = reinterpret_cast<i32 *>(t_f + CAP);  // prefix maximum of the ends (carry-in included); CAP is even
     i32 *t_pf = t_pm + CAP;                           // MODE 2: pme_file of the staged records
     u32 *bins = reinterpret_cast<u32 *>(t_pf + (MODE == 2 ? CAP : 0));  // [n_files]
     // MODE 0 / 2 (a hit is decided by the (query, record) pair alone): the queries of a chunk with their record
     // ranges, so that the PAIRS can be dealt evenly to the threads
     __shared__ i32 c_s[SW_TPB], c_e[SW_TPB];
-    __shared__ u32 c_lo[SW_TPB], c_off[SW_TPB + 1];
+    __shared__ unsigned short c_lo[SW_TPB];  // < CAP
+    __shared__ u32 c_off[SW_TPB + 1];
     __shared__ u32 s_part[SW_TPB / 64];
     __shared__ i32 s_wmax[SW_TPB / 64];
     for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
@@ -254,7 +257,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
             if (i < d.n_lds) {
                 t_s[i] = rg_s[k];
                 t_e[i] = rg_e[k];
-                t_f[i] = rg_f[k];
+                t_f[i] = (unsigned short)rg_f[k];
                 if (MODE == 2) t_pf[i] = rg_p[MODE == 2 ? k : 0];
             }
         }
@@ -375,7 +378,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                 }
                 c_s[threadIdx.x] = s;
                 c_e[threadIdx.x] = e;
-                c_lo[threadIdx.x] = lo;
+                c_lo[threadIdx.x] = (unsigned short)lo;
                 // exclusive scan of the lengths over the chunk
                 const u32 inc = wave_inclusive_scan_u32(len, lane);
                 if (lane == 63) s_part[wave] = inc;
@@ -821,7 +824,8 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
                            cq_off, ql, qh);
     }
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
-    const size_t lds = ((size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 5 : 4) + v.n_files) * 4;
+    // starts | ends | files (u16) | prefix-max ends | [pme_file] | bins
+    const size_t lds = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14) + (size_t)v.n_files * 4;
     auto kern = mode == 2 ? k_igd_sweep<2> : mode == 1 ? k_igd_sweep<1> : k_igd_sweep<0>;
     {
         // the dynamic-LDS limit belongs to the function, not to the calling thread: raised once per device to the largest
