@@ -222,7 +222,7 @@ gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, 
 constexpr u32 MS_MAX_BINS = 36864;  // 144 KB of LDS counters
 size_t multisplit_ws_bytes(u32 n_bins, u32 n);
 gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
-                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st);
+                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if = nullptr);
 
 // K1 (sort.hip): permutation that orders rows by (chrom, k1, [k2], input order); device columns in/out
 gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,

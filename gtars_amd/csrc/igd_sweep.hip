@@ -141,7 +141,8 @@ __device__ __forceinline__ u32 lb_u32(const u32 *__restrict__ a, u32 lo, u32 hi,
 // `perm` (may be NULL: the batch is already ordered) maps a sorted position to its row of `chrom_key`, so the
 // sorted chromosome column never has to be materialised for these n_chrom + 1 binary searches
 __global__ void k_igd_chrom_segments(const u32 *__restrict__ chrom_key, const u32 *__restrict__ perm, u32 nq, u32 n_chrom,
-                                     u32 *__restrict__ cq_off) {
+                                     u32 *__restrict__ cq_off, const u32 *__restrict__ skip_if) {
+    if (skip_if && *skip_if) return;  // the batch was partitioned instead (decided on the device)
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n_chrom) return;
     u32 lo = 0, hi = nq;
@@ -172,7 +173,9 @@ __global__ void k_gather2_u32(const u32 *__restrict__ a, const u32 *__restrict__
 // sorted queries:   last_start(previous tile) < key <= last_start(this tile).
 __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
                                   const u32 *__restrict__ tile_chrom, u32 n_tiles, const u32 *__restrict__ sorted_qs,
-                                  const u32 *__restrict__ cq_off, u32 *__restrict__ ql, u32 *__restrict__ qh) {
+                                  const u32 *__restrict__ cq_off, u32 *__restrict__ ql, u32 *__restrict__ qh,
+                                  const u32 *__restrict__ skip_if) {
+    if (skip_if && *skip_if) return;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const u32 c = tile_chrom[t], p0 = tile_first[t], cnt = tile_cnt[t];
@@ -197,8 +200,18 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
             const u32 *__restrict__ tile_chrom, const i32 *__restrict__ tile_carry, u32 n_tiles,
             const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap,
-            unsigned long long *__restrict__ hits) {
+            unsigned long long *__restrict__ hits, const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab,
+            const u32 *__restrict__ part_ql) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
+    // whether the batch had to be partitioned was decided on the device (k_igd_prep_queries): take the partition's
+    // interleaved (start, end) pairs and bin offsets, or the batch as it arrived with the tile ranges
+    if (part_flag && *part_flag) {
+        sqs = part_ab;
+        sqe = nullptr;
+        interleaved = 1;
+        ql = part_ql;
+        qh = part_ql + 1;
+    }
     constexpr int CAP = IGD_TILE + IGD_HALO;
     i32 *t_s = reinterpret_cast<i32 *>(sm);
     i32 *t_e = t_s + CAP;
@@ -771,7 +784,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     void *scratch = (void *)(((uintptr_t)(d_unsorted + 16) + 63) & ~(uintptr_t)63);
     const size_t scratch_bytes = ws_bytes - (size_t)((char *)scratch - (char *)ws);
     (void)sc;
-    GT_HIP(hipMemsetAsync(d_unsorted, 0, sizeof(u32), st));
+    // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the preparation kernel only ever raises the flag
+    GT_HIP(hipMemsetAsync(d_unsorted, getenv("GTARS_IGD_ALWAYS_SORT") ? 1 : 0, 1, st));
+    GT_HIP(hipMemsetAsync((char *)d_unsorted + 1, 0, 3, st));
     // queries grouped by owner tile in one partition pass, when the tile bounds fit in LDS (76M records); otherwise
     // (and for GTARS_IGD_FULL_SORT=1) the batch is fully sorted by (chromosome, start) with the radix sort
     const bool full_sort = getenv("GTARS_IGD_FULL_SORT") != nullptr;  // tests / A-B runs
@@ -791,22 +806,33 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(PREP_TPB), lds, st, qc, qs, qe, nq, v.n_chrom, tl.bnd, tl.chrom_tile_off, n_tiles,
                            chunk, kc, ks, ke, perm, d_unsorted);
     }
-    u32 h_unsorted = 1;
-    if (!getenv("GTARS_IGD_ALWAYS_SORT")) {
-        GT_HIP(hipMemcpyAsync(&h_unsorted, d_unsorted, sizeof(u32), hipMemcpyDeviceToHost, st));
-        GT_HIP(hipStreamSynchronize(st));
-    }
     const u32 *t_ql = ql, *t_qh = qh;
     int interleaved = 0;
-    if (h_unsorted && bucket) {
+    const u32 *part_flag = nullptr, *part_ab = nullptr, *part_ql = nullptr;
+    u32 h_unsorted = 1;
+    if (bucket) {
+        // No host round trip: both continuations are enqueued and the flag the preparation kernel leaves on the device
+        // picks one -- the partition kernels return at once for a batch that is already in owner order, the range
+        // kernels for one that is not, and the sweep takes its inputs accordingly.
         // K1 (multisplit): (start, end) pairs grouped by owner tile; bin_off[t], bin_off[t + 1] bound tile t's queries
         gtars_status s1 = multisplit_pairs(perm, ks, ke, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off, scratch,
-                                           scratch_bytes, st);  // ss and se are adjacent: 2 * nq words
+                                           scratch_bytes, st, d_unsorted);  // ss and se are adjacent: 2 * nq words
         if (s1) return s1;
-        interleaved = 1;
-        t_ql = bin_off;
-        t_qh = bin_off + 1;
+        part_flag = d_unsorted;
+        part_ab = ss;
+        part_ql = bin_off;
+        ss = ks;
+        se = ke;
+        ProfScope p("k_igd_tile_ranges", st);
+        hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, kc, (const u32 *)nullptr, nq,
+                           v.n_chrom, cq_off, d_unsorted);
+        hipLaunchKernelGGL(k_igd_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles, ss,
+                           cq_off, ql, qh, d_unsorted);
     } else {
+        if (!getenv("GTARS_IGD_ALWAYS_SORT")) {
+            GT_HIP(hipMemcpyAsync(&h_unsorted, d_unsorted, sizeof(u32), hipMemcpyDeviceToHost, st));
+            GT_HIP(hipStreamSynchronize(st));
+        }
         if (h_unsorted) {
             // K1 (radix sort): order the queries by (chromosome, start)
             gtars_status s1 = device_sort_perm_ws(kc, ks, nullptr, nq, v.n_chrom + 1, perm, scratch, scratch_bytes, st);
@@ -819,9 +845,10 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
             se = ke;
         }
         ProfScope p("k_igd_tile_ranges", st);
-        hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, kc, perm, nq, v.n_chrom, cq_off);
+        hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, kc, perm, nq, v.n_chrom, cq_off,
+                           (const u32 *)nullptr);
         hipLaunchKernelGGL(k_igd_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles, ss,
-                           cq_off, ql, qh);
+                           cq_off, ql, qh, (const u32 *)nullptr);
     }
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
     // starts | ends | files (u16) | prefix-max ends | [pme_file] | bins
@@ -848,7 +875,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     {
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.first, tl.cnt, tl.chrom, tl.carry, n_tiles, ss, se,
-                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits);
+                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;

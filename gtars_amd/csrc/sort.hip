@@ -126,7 +126,8 @@ k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 
 constexpr int MS_TPB = 1024;
 
 __global__ void __launch_bounds__(MS_TPB)
-k_ms_hist(const u32 *__restrict__ key, u32 n, u32 n_bins, u32 chunk, u32 *__restrict__ table) {
+k_ms_hist(const u32 *__restrict__ key, u32 n, u32 n_bins, u32 chunk, u32 *__restrict__ table, const u32 *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 ms_bins[];
     for (u32 b = threadIdx.x; b < n_bins; b += MS_TPB) ms_bins[b] = 0;
     __syncthreads();
@@ -148,7 +149,8 @@ k_ms_hist(const u32 *__restrict__ key, u32 n, u32 n_bins, u32 chunk, u32 *__rest
 }
 
 // per bin: exclusive prefix over the workgroups (in place) and the bin total; 16 independent loads per step
-__global__ void k_ms_colscan(u32 *__restrict__ table, u32 n_wg, u32 n_bins, u32 *__restrict__ tot) {
+__global__ void k_ms_colscan(u32 *__restrict__ table, u32 n_wg, u32 n_bins, u32 *__restrict__ tot, const u32 *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_bins) return;
     u32 run = 0;
@@ -167,7 +169,8 @@ __global__ void k_ms_colscan(u32 *__restrict__ table, u32 n_wg, u32 n_bins, u32 
 
 // bin_off[0 .. n_bins] = exclusive scan of tot (one workgroup)
 __global__ void __launch_bounds__(MS_TPB)
-k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off) {
+k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off, const u32 *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     __shared__ u32 s_scan[MS_TPB / 64];
     __shared__ u32 s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -188,7 +191,8 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off)
 
 __global__ void __launch_bounds__(MS_TPB)
 k_ms_scatter(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n, u32 n_bins, u32 chunk,
-             const u32 *__restrict__ table, const u32 *__restrict__ bin_off, u32 drop_bin, uint2 *__restrict__ out_ab) {
+             const u32 *__restrict__ table, const u32 *__restrict__ bin_off, u32 drop_bin, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 ms_bins[];
     const u32 *row = table + (size_t)blockIdx.x * n_bins;
     for (u32 k = threadIdx.x; k < n_bins; k += MS_TPB) ms_bins[k] = bin_off[k] + row[k];
@@ -236,7 +240,8 @@ constexpr int SP_TILE = SP_TPB * SP_ITEMS;
 constexpr int SP_BINS = 1024;
 
 __global__ void k_split_init(const u32 *__restrict__ bin_off, u32 n_bins, u32 shift, u32 n_coarse, u32 *__restrict__ cur_a,
-                             u32 *__restrict__ cur_b) {
+                             u32 *__restrict__ cur_b, const u32 *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_bins) cur_b[i] = bin_off[i];
     if (i < n_coarse) cur_a[i] = bin_off[i << shift];
@@ -245,7 +250,8 @@ __global__ void k_split_init(const u32 *__restrict__ bin_off, u32 n_bins, u32 sh
 template <bool FINE>
 __global__ void __launch_bounds__(SP_TPB)
 k_split_pass(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
-             u32 shift, u32 drop_bin, u32 *__restrict__ cursor, u32 *__restrict__ out_key, uint2 *__restrict__ out_ab) {
+             u32 shift, u32 drop_bin, u32 *__restrict__ cursor, u32 *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 sp_lds[];
     u32 *s_k = sp_lds, *s_a = s_k + SP_TILE, *s_b = s_a + SP_TILE;
     u32 *cnt = s_b + SP_TILE, *toff = cnt + SP_BINS, *gbase = toff + SP_BINS;
@@ -336,7 +342,7 @@ size_t multisplit_ws_bytes(u32 n_bins, u32 n) {
 }
 
 gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
-                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st) {
+                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if) {
     if (n_bins == 0 || n_bins > MS_MAX_BINS) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
     if (ws_bytes < multisplit_ws_bytes(n_bins, n)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
     const u32 n_wg = ms_workgroups(n);
@@ -363,12 +369,12 @@ gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n,
     GT_HIP(attr_err);
     {
         ProfScope p("k_ms_hist", st);
-        hipLaunchKernelGGL(k_ms_hist, dim3(n_wg), dim3(MS_TPB), lds, st, key, n, n_bins, chunk, table);
+        hipLaunchKernelGGL(k_ms_hist, dim3(n_wg), dim3(MS_TPB), lds, st, key, n, n_bins, chunk, table, run_if);
     }
     {
         ProfScope p("k_ms_scan", st);
-        hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot);
-        hipLaunchKernelGGL(k_ms_binscan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off);
+        hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot, run_if);
+        hipLaunchKernelGGL(k_ms_binscan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off, run_if);
     }
     static const bool one_level = getenv("GTARS_MS_ONE_LEVEL") != nullptr;  // A/B
     if (n_bins > 1024 && n >= (1u << 20) && !one_level) {
@@ -378,15 +384,15 @@ gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n,
         const u32 tiles = (n + SP_TILE - 1) / SP_TILE;
         const unsigned grid = std::min<u32>(256, tiles);
         ProfScope p("k_split_pass", st);
-        hipLaunchKernelGGL(k_split_init, dim3((n_bins + 255) / 256), dim3(256), 0, st, bin_off, n_bins, shift, n_coarse, cur_a, cur_b);
+        hipLaunchKernelGGL(k_split_init, dim3((n_bins + 255) / 256), dim3(256), 0, st, bin_off, n_bins, shift, n_coarse, cur_a, cur_b, run_if);
         hipLaunchKernelGGL(k_split_pass<false>, dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n, shift,
-                           drop_bin, cur_a, tmp_key, tmp_ab);
+                           drop_bin, cur_a, tmp_key, tmp_ab, run_if);
         hipLaunchKernelGGL(k_split_pass<true>, dim3(grid), dim3(SP_TPB), sp_lds, st, tmp_key, (const u32 *)nullptr,
-                           (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (u32 *)nullptr, out_ab);
+                           (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (u32 *)nullptr, out_ab, run_if);
     } else {
         ProfScope p("k_ms_scatter", st);
         hipLaunchKernelGGL(k_ms_scatter, dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off, drop_bin,
-                           out_ab);
+                           out_ab, run_if);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;

@@ -553,11 +553,12 @@ def test_igd_sweep_matches_oracle(ga, monkeypatch, seed, n, nq, F, span, wmax):
 
 
 def test_igd_sweep_presorted_batch_skips_the_sort(ga, monkeypatch):
-    """A batch already in (chromosome, start) order takes the sweep without the device sort; same vectors
-    as the oracle and as the forced-sort path."""
+    """A batch already in (chromosome, start) order takes the sweep without the partition; same vectors as the oracle
+    and as the forced-partition path.  The choice is made on the device (no host round trip): both continuations are
+    enqueued and the partition kernels return at once -- their profiled time collapses to launch overhead."""
     monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
     rng = np.random.default_rng(321)
-    n, nq, F, n_chrom, span = 40_000, 30_000, 64, 4, 500_000
+    n, nq, F, n_chrom, span = 40_000, 1_500_000, 64, 4, 500_000
     c = rng.integers(0, n_chrom, n)
     s = rng.integers(0, span, n)
     e = s + rng.integers(1, 2_000, n)
@@ -567,24 +568,35 @@ def test_igd_sweep_presorted_batch_skips_the_sort(ga, monkeypatch):
     qs = rng.integers(0, span, nq).astype(np.int64)
     order = np.lexsort((qs, qc))
     qc, qs = qc[order], qs[order]
-    qe = qs + rng.integers(1, 3_000, nq)
+    qe = qs + rng.integers(1, 300, nq)
     qc = np.concatenate([qc, np.full(50, UNK)])  # unknown chromosomes sort last
     qs = np.concatenate([qs, rng.integers(0, span, 50)])
     qe = np.concatenate([qe, qs[-50:] + 10])
     exp_p = o.count_set_overlaps(qc, qs, qe, 1, n_files=F).tolist()
     exp_b = o.count_region_hits(qc, qs, qe, 1, n_files=F).tolist()
     _lib = ga._lib
-    _lib.lib.gtars_prof_reset()
-    _lib.lib.gtars_prof_enable(1)
-    assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == exp_p
-    assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
-    names = set(_lib.prof_read())
-    _lib.lib.gtars_prof_enable(0)
-    # (k_radix_* may appear: the first binary count builds the database's pme_file with the radix sort)
-    assert any(k.startswith("k_igd_sweep") for k in names) and not names & {"k_ms_scatter", "k_gather2_u32"}, names
+
+    def profiled():
+        _lib.lib.gtars_prof_reset()
+        _lib.lib.gtars_prof_enable(1)
+        assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == exp_p
+        assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
+        prof = _lib.prof_read()
+        _lib.lib.gtars_prof_enable(0)
+        return prof
+
+    g.count_region_hits(qc[:1000], qs[:1000], qe[:1000], 1)  # builds the database's pme_file outside the profiled calls
+    in_order = profiled()
+    assert any(k.startswith("k_igd_sweep") for k in in_order) and "k_gather2_u32" not in in_order, in_order
     monkeypatch.setenv("GTARS_IGD_ALWAYS_SORT", "1")
-    assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == exp_p
-    assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
+    forced = profiled()
+    assert in_order["k_ms_scatter"]["total_ms"] < 0.5 * forced["k_ms_scatter"]["total_ms"], (in_order, forced)
+    # and a shuffled batch partitions by itself
+    monkeypatch.delenv("GTARS_IGD_ALWAYS_SORT")
+    sh = rng.permutation(len(qc))
+    qc, qs, qe = qc[sh], qs[sh], qe[sh]
+    shuffled = profiled()
+    assert shuffled["k_ms_scatter"]["total_ms"] > 0.5 * forced["k_ms_scatter"]["total_ms"], (shuffled, forced)
 
 
 def test_bits_count_matches_reference_formula(ga):
