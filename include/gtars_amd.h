@@ -238,7 +238,9 @@ gtars_status gtars_igd_export(const gtars_igd_t *g, uint32_t *chrom, int32_t *st
 /* binary = 0: Igd::count_set_overlaps (pairwise);
  * binary = 1: Igd::count_region_hits (at most 1 per query per file).
  * Query coordinates are u32 cast to i32 as the reference does (igd.rs:549-550).
- * d_hits: n_files u64, overwritten. */
+ * d_hits: n_files u64, overwritten.  Asynchronous on `stream`: the call only enqueues work (whether the batch has
+ * to be partitioned first is decided on the device); the first binary count of a database builds its per-record
+ * "largest earlier end of the same file" column once, synchronously. */
 gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qchrom,
                                     const uint32_t *d_qstart, const uint32_t *d_qend,
                                     uint64_t nq, int32_t min_overlap, int binary,
