@@ -1076,3 +1076,35 @@ def test_bits_insert_and_seek_match_the_reference_rules(ga):
         assert ids[off[i]:off[i + 1]].tolist() == [t[2] for t in refs[int(qc[i])].find(int(qs[i]), int(qe[i]))]
     with pytest.raises(ValueError):  # GTARS_ERR_INVALID_ARG: insert is a Bits operation
         ga.OverlapIndex(c, s, e, v, n_chrom=2, kind=KIND_AILIST).insert(0, 1, 2, 3)
+
+
+def test_igd_two_level_partition_with_a_sparse_tail(ga, monkeypatch):
+    """The two-level, LDS-reordered partition (k_split_pass) on a skewed batch: 1.2M queries, most of them inside one
+    100-kb window, 10k spread over the whole genome.  In the second pass a tile of the sparse tail spans far more than
+    the 1024-key window, so its elements take the direct-slot path.  Three independent routes must agree: the shuffled
+    batch (partitioned), the same batch in (chromosome, start) order (no partition at all) and the per-query kernel
+    (no sweep), for pairwise and binary counts."""
+    from gtars_amd import synth
+
+    F = 50
+    db = synth.make_igd_db(45_000_000, F, seed=21)
+    g = ga.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=F)
+    del db
+    rng = np.random.default_rng(8)
+    n_hot, n_tail = 1_190_000, 10_000
+    bg = synth.make_background_queries(n_tail, seed=5)
+    qc = np.concatenate([np.zeros(n_hot, dtype=np.uint32), bg["chrom"]])
+    hs = rng.integers(5_000_000, 5_100_000, n_hot)
+    qs = np.concatenate([hs, bg["start"]]).astype(np.uint32)
+    qe = np.concatenate([hs + rng.integers(1, 500, n_hot), bg["end"]]).astype(np.uint32)
+    sh = rng.permutation(len(qc))
+    qc, qs, qe = qc[sh], qs[sh], qe[sh]
+    order = np.lexsort((qs, qc))
+    for count in (g.count_set_overlaps, g.count_region_hits):
+        shuffled = count(qc, qs, qe, 1)
+        in_order = count(qc[order], qs[order], qe[order], 1)
+        monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "100000000")
+        per_query = count(qc, qs, qe, 1)
+        monkeypatch.delenv("GTARS_IGD_SWEEP_MIN")
+        assert int(shuffled.sum()) > n_hot  # the hot window is covered
+        assert np.array_equal(shuffled, in_order) and np.array_equal(shuffled, per_query)
