@@ -201,7 +201,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
             const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap,
             unsigned long long *__restrict__ hits, const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab,
-            const u32 *__restrict__ part_ql) {
+            const u32 *__restrict__ part_ql, u32 cq) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
     // whether the batch had to be partitioned was decided on the device (k_igd_prep_queries): take the partition's
     // interleaved (start, end) pairs and bin offsets, or the batch as it arrived with the tile ranges
@@ -224,9 +224,11 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
     u32 *bins = reinterpret_cast<u32 *>(t_pf + (MODE == 2 ? CAP : 0));  // [n_files]
     // MODE 0 / 2 (a hit is decided by the (query, record) pair alone): the queries of a chunk with their record
     // ranges, so that the PAIRS can be dealt evenly to the threads
-    __shared__ i32 c_s[SW_TPB], c_e[SW_TPB];
-    __shared__ unsigned short c_lo[SW_TPB];  // < CAP
-    __shared__ u32 c_off[SW_TPB + 1];
+    // chunk arrays (cq = 128 / 256 / 512 queries per chunk, chosen by the launcher from the batch's queries per tile: sparse
+    // batches -- a LOLA universe against a large database -- need few, and the LDS saved is a workgroup more per CU)
+    u32 *c_off = bins + ((v.n_files + 1u) & ~1u);                   // [cq + 1] (+1 pad)
+    i32 *c_s = reinterpret_cast<i32 *>(c_off + cq + 2), *c_e = c_s + cq;
+    unsigned short *c_lo = reinterpret_cast<unsigned short *>(c_e + cq);  // [cq], values < CAP
     __shared__ u32 s_part[SW_TPB / 64];
     __shared__ i32 s_wmax[SW_TPB / 64];
     for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
@@ -328,16 +330,16 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
         if constexpr (MODE != 1) {
             // Pair-balanced scan.  A query's candidates are the records [lo, hi): lo = first record that can overlap it
             // (prefix-max end > q_start), hi = first record that starts at or after q_end (the reference's scan
-            // stops there, igd.rs:772-846).  Per chunk of SW_TPB queries: one thread per query finds (lo, hi), the
+            // stops there, igd.rs:772-846).  Per chunk of cq queries: one thread per query finds (lo, hi), the
             // lengths are scanned, and every thread then takes the same number of consecutive (query, record) pairs
             // -- no lane waits for the longest scan of its wave (a thread-per-query loop runs 20 records on average
             // and 45 for the slowest lane).  Records past the staged range (rare) are scanned by the query's own thread.
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            for (u32 cb = q_lo; cb < q_hi; cb += SW_TPB) {
+            for (u32 cb = q_lo; cb < q_hi; cb += cq) {
                 const u32 qi = cb + threadIdx.x;
                 i32 s = 0, e = 0;
                 u32 lo = 0, len = 0;
-                if (qi < q_hi) {
+                if (threadIdx.x < cq && qi < q_hi) {
                     if (interleaved) {
                         const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
                         s = (i32)se2.x;
@@ -389,9 +391,11 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                         }
                     }
                 }
-                c_s[threadIdx.x] = s;
-                c_e[threadIdx.x] = e;
-                c_lo[threadIdx.x] = (unsigned short)lo;
+                if (threadIdx.x < cq) {
+                    c_s[threadIdx.x] = s;
+                    c_e[threadIdx.x] = e;
+                    c_lo[threadIdx.x] = (unsigned short)lo;
+                }
                 // exclusive scan of the lengths over the chunk
                 const u32 inc = wave_inclusive_scan_u32(len, lane);
                 if (lane == 63) s_part[wave] = inc;
@@ -403,8 +407,8 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                     wbase += w < wave ? x : 0u;
                     total += x;
                 }
-                c_off[threadIdx.x] = wbase + inc - len;
-                if (threadIdx.x == 0) c_off[SW_TPB] = total;
+                if (threadIdx.x < cq) c_off[threadIdx.x] = wbase + inc - len;
+                if (threadIdx.x == 0) c_off[cq] = total;
                 __syncthreads();
                 if (total) {
                     const u32 ppt = (total + SW_TPB - 1) / SW_TPB;
@@ -412,7 +416,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                     const u32 p_end = min(p + ppt, total);
                     if (p < p_end) {
                         // the query that holds pair p: last j with c_off[j] <= p
-                        u32 j = 0, jh = SW_TPB;
+                        u32 j = 0, jh = cq;
                         while (jh - j > 1) {
                             const u32 mid = (j + jh) >> 1;
                             if (c_off[mid] <= p)
@@ -852,7 +856,14 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     }
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
     // starts | ends | files (u16) | prefix-max ends | [pme_file] | bins
-    const size_t lds = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14) + (size_t)v.n_files * 4;
+    // + chunk arrays: offsets u32 [cq + 2] | starts, ends i32 [cq] | first records u16 [cq]
+    u32 cq = 512;
+    if (mode != 1) {
+        const u64 per_tile = n_tiles ? (u64)nq / n_tiles : nq;  // queries per tile on average
+        cq = per_tile <= 48 ? 128u : per_tile <= 110 ? 256u : 512u;
+    }
+    const size_t lds = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14) + (((size_t)v.n_files + 1) & ~(size_t)1) * 4 +
+                       (mode != 1 ? ((size_t)cq + 2) * 4 + (size_t)cq * 10 : 0);
     auto kern = mode == 2 ? k_igd_sweep<2> : mode == 1 ? k_igd_sweep<1> : k_igd_sweep<0>;
     {
         // the dynamic-LDS limit belongs to the function, not to the calling thread: raised once per device to the largest
@@ -864,7 +875,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         std::lock_guard<std::mutex> lock(mu);
         if (dev >= 0 && dev < 64 && !done[mode][dev]) {
             GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(((size_t)(IGD_TILE + IGD_HALO) * 5 + 16384) * 4)));
+                                       (int)(((size_t)(IGD_TILE + IGD_HALO) * 5 + 16384 + 2048) * 4)));
             done[mode][dev] = true;
         }
     }
@@ -875,7 +886,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     {
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.first, tl.cnt, tl.chrom, tl.carry, n_tiles, ss, se,
-                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql);
+                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql, cq);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;
