@@ -21,8 +21,11 @@ How the number is taken:
   * roofline.achieved = algorithmic bytes per launch / average kernel duration, the duration measured with
     HIP events on the launch stream around the K launches of the same repetitions (the events see only
     that stream; one step is exactly one k_tok_lds launch);
-  * roofline.traffic is NOT measured in this run (it needs rocprofv3 --pmc passes): it is replayed from the
-    committed PMC summary of this same command under profiles/, and `traffic_source` says so.
+  * roofline.traffic is measured in the run when rocprofv3 is on PATH: two child processes -- separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of a short invocation of this script (never
+    combined with a trace domain; the parent is idle meanwhile) -- give the mean bytes per k_tok_lds
+    dispatch (FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  If a pass fails the figure of the
+    committed PMC summary under profiles/ is replayed instead; `traffic_source` says which.
 
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  The tokenizer shards by
 independent query ranges with the universe index replicated, so there is no data-path collective (weak
@@ -223,6 +226,44 @@ def bench_igd_config3(dev, stream, ndb=50_000_000, nq=10_000_000, n_files=1000):
     return out
 
 
+def measure_traffic_with_rocprof(nq, universe):
+    """HBM-side bytes per k_tok_lds launch from two rocprofv3 --pmc passes (children of this process; nothing else
+    traced) over a short run of this script on the same workload.  -> (bytes, source) or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="gtars_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    means = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "20", "--warmup", "5", "--queries", str(nq), "--universe", str(universe), "--no-cpu-baseline",
+                   "--no-extras", "--no-pmc", "--min-seconds", "0.05"]
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240, env=dict(os.environ, TMPDIR=tmp))
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(max(files, key=os.path.getmtime)))
+                    if "k_tok_lds" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            if not vals:
+                return None
+            means[counter] = sum(vals) / len(vals) * 1024.0  # the counters are in KB
+        traffic = 2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]
+        return traffic, ("measured in this run: mean over k_tok_lds dispatches of two child rocprofv3 --pmc passes "
+                         "(FETCH_SIZE x2 for gfx950 + WRITE_SIZE) of a short invocation of this script")
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def bench_lola_config4(dev, stream, n_sets=2000, per_set=25_000, n_universe=1_000_000, n_user=100_000):
     """BASELINE config 4 on ONE GPU: support counts of one user set and of the universe against a 2000-set region DB
     (two binary IGD counts) + the contingency cells (enrichment.rs:198-221)."""
@@ -280,6 +321,7 @@ def main():
     ap.add_argument("--batches", type=int, default=32, help="distinct device-resident batches the steps rotate through")
     ap.add_argument("--min-seconds", type=float, default=0.6, help="GPU time to spend in timed repetitions (at least 11 repetitions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / igd_config3 / lola_config4 / host path")
     ap.add_argument("--large", type=str, default="64000000,256000000,1000000000", help="batch sizes of roofline_large")
     args = ap.parse_args()
@@ -398,7 +440,11 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_source = None, "not measured in this run (needs rocprofv3 --pmc passes)"
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_tokenize_1M.json")
-        if os.path.exists(tpath):
+        if world == 1 and not args.no_extras and not args.no_pmc:
+            live = measure_traffic_with_rocprof(nq, args.universe)
+            if live is not None:
+                traffic, traffic_source = live
+        if traffic is None and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj["workload"]["queries_per_step"] == nq and tj["workload"]["universe_regions"] == args.universe:
                 traffic = tj["traffic_bytes_per_launch"]

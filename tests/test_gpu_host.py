@@ -474,8 +474,11 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert k in r, k
+    # the two child `rocprofv3 --pmc` passes ran (or the committed summary was replayed): HBM-side bytes per launch,
+    # never below the 12 B per query the kernel must read
+    assert r["traffic"] is not None and r["traffic"] > 12.0 * d["config"]["queries_per_step_per_gpu"], r
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 1e9 and abs(d["value"] - d["config"]["queries_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
 
