@@ -238,6 +238,7 @@ constexpr int SP_TPB = 1024;
 constexpr int SP_ITEMS = 8;
 constexpr int SP_TILE = SP_TPB * SP_ITEMS;
 constexpr int SP_BINS = 1024;
+static_assert(SP_BINS == SP_TPB, "one thread per tile-local bin (counter reset, layout scan, run reservation)");
 
 __global__ void k_split_init(const u32 *__restrict__ bin_off, u32 n_bins, u32 shift, u32 n_coarse, u32 *__restrict__ cur_a,
                              u32 *__restrict__ cur_b, const u32 *__restrict__ run_if) {
