@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential soak: IGD batch counts (sweep and per-query kernels) vs the oracle's literal tile walk.
 
-Run on the GPU box:  python tests/soak/fuzz_igd.py [rounds]"""
+Run on the GPU box:  python tests/soak/fuzz_igd.py [rounds]      (small shapes, both kernels)
+                     python tests/soak/fuzz_igd.py big [rounds]  (2-3M records, 1M+ queries: the two-level partition)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -49,7 +50,51 @@ def one(seed):
     return nq
 
 
+def one_big(seed):
+    """Databases of more than 1024 tiles with batches of 1M+ queries: the two-level, LDS-reordered partition
+    (k_split_pass), its direct-slot path (skewed batches) and the device-side sorted / partition choice."""
+    rng = np.random.default_rng(seed)
+    n_chrom = int(rng.integers(1, 5))
+    n = int(rng.choice([2_200_000, 3_000_000]))
+    F = int(rng.choice([1, 40, 3000]))
+    span = int(rng.choice([40_000_000, 200_000_000]))
+    wmax = int(rng.choice([300, 20_000]))
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, wmax, n)
+    f = rng.integers(0, F, n)
+    g = gtars_amd.IgdIndex(c, s, e, f, np.arange(n), n_chrom=n_chrom, n_files=F)
+    o = oracle.Igd()
+    o.add_arrays(c, s, e, np.zeros(n, dtype=np.int64), f)
+    o.n_files = F
+    o.finalize()
+    nq = int(rng.choice([1_050_000, 1_600_000]))
+    shape = rng.choice(["uniform", "skewed", "sorted"])
+    qc = rng.integers(0, n_chrom + 1, nq)
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, span + wmax, nq).astype(np.int64)
+    if shape == "skewed":  # almost everything in one window, a thin tail everywhere else
+        hot = rng.random(nq) < 0.99
+        qc = np.where(hot, 0, qc)
+        qs = np.where(hot, rng.integers(span // 3, span // 3 + 50_000, nq), qs)
+    qe = qs + rng.integers(1, max(2, wmax // 4), nq)
+    if shape == "sorted":
+        order = np.lexsort((qs, np.where(qc == UNK, n_chrom, qc)))
+        qc, qs, qe = qc[order], qs[order], qe[order]
+    os.environ.pop("GTARS_IGD_SWEEP_MIN", None)
+    assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), o.count_set_overlaps(qc, qs, qe, 1, n_files=F)), ("big pair", seed, shape)
+    assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F)), ("big bin", seed, shape)
+    return nq
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "big":
+        t = time.time()
+        for seed in range(int(sys.argv[2])):
+            one_big(9000 + seed)
+            print(f"  big {seed + 1}, {time.time() - t:.0f} s", flush=True)
+        print(f"fuzz_igd: {sys.argv[2]} large configurations bit-exact vs the oracle ({time.time() - t:.0f} s)")
+        return
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     t = time.time()
     for seed in range(rounds):
