@@ -38,7 +38,7 @@ namespace gtars {
 
 // timing experiments only (tools/build_variant.sh; results are then WRONG by construction):
 //   1 no look-back (a made-up base)   2 no id stores   4 no offset stores   8 no record burst (made-up records)
-//   16 no LDS search (a made-up block)
+//   16 no LDS search (a made-up block)   32 no LDS fill (the search runs on whatever the LDS holds)
 #ifndef GTARS_TOK_ABLATE
 #define GTARS_TOK_ABLATE 0
 #endif
@@ -294,6 +294,13 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
             }
         } else {
             search_blocks<UQ>(a, L.lut, L.q, L.ctab, c[r] + j0, s[r] + j0, b0[p], be[p]);
+            if (GTARS_TOK_ABLATE & 32) {  // the LDS image was not filled: keep the made-up blocks inside the record array
+#pragma unroll
+                for (int k = 0; k < UQ; ++k) {
+                    b0[p][k] %= a.n_blocks;
+                    be[p][k] = a.n_blocks;
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < UQ; ++k) {
@@ -640,7 +647,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     u32 tile = blockIdx.x * G + (u32)grp;
     load_tile(tile);
     if (G > 1 && threadIdx.x < G) s_bar[threadIdx.x] = 0;
-    fill_search_lds<TPB>(a, smem);
+    if (!(GTARS_TOK_ABLATE & 32)) fill_search_lds<TPB>(a, smem);
     __syncthreads();
 
     u32 phase = 0;
