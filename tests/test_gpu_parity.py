@@ -558,7 +558,7 @@ def test_igd_sweep_presorted_batch_skips_the_sort(ga, monkeypatch):
     enqueued and the partition kernels return at once -- their profiled time collapses to launch overhead."""
     monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
     rng = np.random.default_rng(321)
-    n, nq, F, n_chrom, span = 40_000, 1_500_000, 64, 4, 500_000
+    n, nq, F, n_chrom, span = 40_000, 3_000_000, 64, 4, 500_000
     c = rng.integers(0, n_chrom, n)
     s = rng.integers(0, span, n)
     e = s + rng.integers(1, 2_000, n)
