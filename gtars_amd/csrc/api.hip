@@ -260,7 +260,7 @@ struct gtars_index {
     std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
     // blocked acceleration structure (Bits kind), see AccelView in common.h
-    DevBuf<u32> acc_rec2, acc_rec4, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab, acc_idc;
+    DevBuf<u32> acc_rec2, acc_rec4, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab, acc_idc, acc_idc_pos;
     bool acc_ids_affine = false;
     u32 acc_n_blocks = 0, acc_n_units = 0, acc_n_buckets = 0, acc_lut_words = 0, acc_q_words = 0;
     u32 acc_lut_shift = 0, acc_q_shift = 0, acc_search_top = 0, acc_top_shift = 0;
@@ -290,6 +290,15 @@ struct gtars_index {
         a.top_shift = acc_top_shift;
         a.n_chrom = n_chrom;
         a.max_chrom_n = max_chrom_n();
+        return a;
+    }
+    // The same structure with ids that are the STORED POSITIONS of the hits (position of (block b, slot k) =
+    // ACC_OWN * b + k + idc_pos[chrom]): what the region-returning calls gather starts / ends / values by.
+    AccelView accel_pos() const {
+        AccelView a = accel();
+        a.idc = acc_idc_pos.p;
+        a.ids_affine = 1u;
+        a.rec4 = nullptr;
         return a;
     }
     // most intervals on one chromosome = the most hits one query can have
@@ -759,6 +768,11 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
     if (!st && ix->has_accel) st = ix->acc_rec2.upload(h_rec2);
     if (!st && ix->has_accel && !ix->acc_ids_affine) st = ix->acc_rec4.upload(h_rec4);
     if (!st && ix->has_accel) st = ix->acc_idc.upload(h_idc);
+    if (!st && ix->has_accel) {
+        std::vector<u32> h_idc_pos(n_chrom, 0);
+        for (u32 c = 0; c < n_chrom; ++c) h_idc_pos[c] = off[c] - (u32)ACC_OWN * h_cblk[c];  // mod 2^32
+        st = ix->acc_idc_pos.upload(h_idc_pos);
+    }
     if (!st && ix->has_accel) st = ix->acc_blk_first.upload(h_blk_first);
     if (!st && ix->has_accel) st = ix->acc_lut.upload(h_lut);
     if (!st && ix->has_accel) st = ix->acc_qkeys.upload(h_q);
@@ -791,6 +805,7 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->acc_rec2.release();
     ix->acc_rec4.release();
     ix->acc_idc.release();
+    ix->acc_idc_pos.release();
     ix->acc_blk_first.release();
     ix->acc_lut.release();
     ix->ends_sorted.release();
@@ -1029,10 +1044,24 @@ static gtars_status enumerate_to_host(const gtars_index_t *ix, const u32 *qc, co
         u32 *dv = out_val ? (u32 *)d_out.p : nullptr;
         u32 *ds = out_start ? (u32 *)((char *)d_out.p + pad) : nullptr;
         u32 *de = out_end ? (u32 *)((char *)d_out.p + 2 * pad) : nullptr;
-        st = launch_fill(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d_off.as<u64>(), dv, ds,
-                         de, nullptr);
-        if (st) return st;
-        GT_HIP(hipDeviceSynchronize());
+        if (use_lds_path(ix)) {
+            // the fused tokenizer once more, this time emitting the hits' stored positions (reference order, Bits or
+            // AIList), and one gather of the payload columns by position -- instead of the generic per-query fill pass
+            ScopedDev d_pos;
+            if ((st = d_pos.alloc(pad))) return st;
+            EnumOut o2{d_off.as<u64>(), d_pos.as<u32>(), nullptr, nullptr, h};
+            st = launch_tokenize_lds(ix->accel_pos(), q.c, q.s, q.e, nq, has_min, min_overlap, o2, d_ws.p, wsb, ep, nullptr, nullptr,
+                                     nullptr, ix->kind == GTARS_KIND_AILIST);
+            if (st) return st;
+            st = launch_gather_hits(ix->view(), d_pos.as<u32>(), h, dv, ds, de, nullptr);
+            if (st) return st;
+            GT_HIP(hipDeviceSynchronize());
+        } else {
+            st = launch_fill(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d_off.as<u64>(), dv, ds,
+                             de, nullptr);
+            if (st) return st;
+            GT_HIP(hipDeviceSynchronize());
+        }
         auto fetch = [&](u32 **dst, u32 *src) -> gtars_status {
             if (!dst) return GTARS_OK;
             *dst = host_alloc<u32>(h);

@@ -194,6 +194,8 @@ gtars_status launch_count(const IndexView &v, int kind, const u32 *qc, const u32
 gtars_status launch_fill(const IndexView &v, int kind, const u32 *qc, const u32 *qs, const u32 *qe,
                          u64 nq, int has_min, i32 min_overlap, const u64 *offsets, u32 *vals,
                          u32 *starts, u32 *ends, hipStream_t st);
+// payload columns of hits given by stored position (any of vals / starts / ends may be null)
+gtars_status launch_gather_hits(const IndexView &v, const u32 *pos, u64 n, u32 *vals, u32 *starts, u32 *ends, hipStream_t st);
 // exclusive scan u32 counts -> u64 offsets[n+1]
 gtars_status launch_scan_u32_to_u64(const u32 *counts, u64 n, u64 *offsets, void *ws, size_t ws_bytes,
                                     hipStream_t st);

@@ -260,6 +260,26 @@ constexpr int ENUM_TPB = 256;
 constexpr int ENUM_QPT = 4;
 constexpr int ENUM_TILE = ENUM_TPB * ENUM_QPT;
 
+__global__ void k_gather_hits(const u32 *__restrict__ sv, const u32 *__restrict__ ss, const u32 *__restrict__ se,
+                              const u32 *__restrict__ pos, u64 n, u32 *__restrict__ vals, u32 *__restrict__ starts,
+                              u32 *__restrict__ ends) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 p = pos[i];
+    if (vals) vals[i] = sv[p];
+    if (starts) starts[i] = ss[p];
+    if (ends) ends[i] = se[p];
+}
+
+gtars_status launch_gather_hits(const IndexView &v, const u32 *pos, u64 n, u32 *vals, u32 *starts, u32 *ends, hipStream_t st) {
+    if (n == 0) return GTARS_OK;
+    ProfScope p("k_gather_hits", st);
+    hipLaunchKernelGGL(k_gather_hits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v.vals, v.starts, v.ends, pos, n, vals,
+                       starts, ends);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
 u32 enumerate_fused_tile_queries() { return ENUM_TILE; }
 size_t enumerate_fused_ws_bytes(u64 nq) {
     return scan_ws_bytes_for_tiles((nq + ENUM_TILE - 1) / ENUM_TILE);
