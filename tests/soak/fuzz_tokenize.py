@@ -60,6 +60,9 @@ def one(seed):
     assert np.array_equal(ids_g, ids_o), ("ids", seed)
     for mo in (None, 1, 3):
         assert np.array_equal(g.count_overlaps(qc, qs, qe, mo), o.count_overlaps(qc, qs, qe, mo)), ("count", seed, mo)
+    mo = [None, 2, 7][seed % 3]  # regions with payload: positions from the fused kernel + gather
+    for a, b in zip(g.find_overlaps(qc, qs, qe, mo), o.find_overlaps_regions(qc, qs, qe, mo)):
+        assert np.array_equal(a, b), ("find", seed, mo)
     return n, nq, len(ids_o)
 
 
