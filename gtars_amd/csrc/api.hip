@@ -1479,8 +1479,14 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
     if (st) return st;
     ScopedDev d_val;
     if ((st = d_val.alloc(h * 4))) return st;
-    st = launch_fill(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d_off.as<u64>(),
-                     d_val.as<u32>(), nullptr, nullptr, nullptr);
+    if (use_lds_path(ix)) {  // the fused tokenizer writes the source indices itself (the order inside a query does not matter here)
+        EnumOut o2{d_off.as<u64>(), d_val.as<u32>(), nullptr, nullptr, h};
+        st = launch_tokenize_lds(ix->accel(), q.c, q.s, q.e, nq, has_min, min_overlap, o2, d_ws.p, wsb, ep, nullptr, nullptr, nullptr,
+                                 ix->kind == GTARS_KIND_AILIST);
+    } else {
+        st = launch_fill(ix->view(), ix->kind, q.c, q.s, q.e, nq, has_min, min_overlap, d_off.as<u64>(),
+                         d_val.as<u32>(), nullptr, nullptr, nullptr);
+    }
     if (st) return st;
     st = launch_sort_unique_segments(d_val.as<u32>(), d_off.as<u64>(), nq, d_cnt.as<u32>(), nullptr);
     if (st) return st;
