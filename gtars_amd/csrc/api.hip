@@ -173,6 +173,19 @@ static void prof_drain() {
     g_prof_pending.clear();
 }
 
+// Deterministic observation of a choice a kernel made on the device (tests assert on this, never on kernel times):
+// with profiling enabled, reads the device word behind the work queued so far and counts one "launch" of the entry
+// named after its state.  Synchronises the stream -- profiling mode only.
+void prof_note_device_flag(const char *if_set, const char *if_clear, const u32 *d_flag, hipStream_t st) {
+    if (!g_prof_on) return;
+    u32 h = 0;
+    if (hipMemcpyAsync(&h, d_flag, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    g_prof_entries[prof_entry(h ? if_set : if_clear)].launches += 1;
+}
+
 // -------------------------------------------------------------- device bufs
 template <class T>
 struct DevBuf {

@@ -269,5 +269,7 @@ struct ProfScope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool on = false;
 };
+// profiling mode only: counts one launch of entry `if_set` / `if_clear` by the state of a device word (synchronises `st`)
+void prof_note_device_flag(const char *if_set, const char *if_clear, const u32 *d_flag, hipStream_t st);
 
 }  // namespace gtars

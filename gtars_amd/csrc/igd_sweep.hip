@@ -889,6 +889,8 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
                            interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql, cq);
     }
     GT_HIP(hipGetLastError());
+    // which continuation the device took (profiling mode: a deterministic fact for the tests, not a timing)
+    if (bucket) prof_note_device_flag("igd_batch_partitioned", "igd_batch_in_owner_order", d_unsorted, st);
     return GTARS_OK;
 }
 
