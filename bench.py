@@ -27,14 +27,22 @@ How the number is taken:
     dispatch (FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  If a pass fails the figure of the
     committed PMC summary under profiles/ is replayed instead; `traffic_source` says which.
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  The tokenizer shards by
-independent query ranges with the universe index replicated, so there is no data-path collective (weak
-scaling: every rank tokenizes its own Q-query batches); `with_allgather` additionally reports the rate when
-every rank must end up with the whole batch's CSR (RCCL all-gatherv of offsets and ids, gtars_amd/sharding.py).
+N > 1: one rank per GPU over RCCL (`torch.distributed`, backend "nccl").  Under an external launcher
+(`python -m torch.distributed.run ... bench.py --gpus N`: RANK / WORLD_SIZE set) this process IS a rank.  Started
+plainly (`python bench.py --gpus N`), the parent -- before it touches any GPU -- starts the N ranks itself as a CHILD
+`torch.distributed.run` (never an exec) and exits with its code; it exits non-zero when fewer than N devices are visible.
+The tokenizer shards by independent query ranges with the universe index replicated, so there is no data-path collective
+(weak scaling: every rank tokenizes its own Q-query batches); `with_allgather` additionally reports the rate when every
+rank must end up with the whole batch's CSR (RCCL all-gatherv of offsets and ids, gtars_amd/sharding.py).  What
+`north_star` shards by chromosome bucket -- the IGD database + its query batch (config 3) and the LOLA region DB with the
+universe and user set (config 4) -- is measured at N > 1 in `igd_config3_sharded` / `lola_config4_sharded`: every rank
+ingests only its chromosomes, counts, and ONE all-reduce of the per-file vector(s) yields the global counts
+(what must be reduced: gtars-lola/src/enrichment.rs:198-221).  `ranks` lists what every rank saw (device, backend).
 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries: larger batches (`roofline_large`), BASELINE config 3
-(`igd_config3`) and config 4 on one GPU (`lola_config4`), the PCIe-inclusive host-buffer rate and the CPU
-baselines (the oracle on the GPU box's host cores).
+(`igd_config3`) and config 4 on one GPU (`lola_config4`), each with a sampled CPU baseline and a parity check of the
+sample against the oracle, config 5 at a reduced file count (`fragsplit_config5`), the PCIe-inclusive host-buffer rate
+and the CPU baselines (the oracle on the GPU box's host cores).  Every timed output is checked in the run (`verified`).
 """
 from __future__ import annotations
 
@@ -52,7 +60,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def algorithmic_bytes(nq: int, h: int, nu: int) -> int:
@@ -145,11 +153,33 @@ def _dev(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
 
 
-def bench_large(ix, q, nu, sizes, dev, stream):
-    """The same kernel on larger batches (the 1M-query base batch tiled on the device): queries/s and fraction of
-    the HBM peak, median of 5 single-launch timings each (HIP events on the launch stream)."""
+def verify_tokenization(u, q, offsets_t, ids_t, h, where):
+    """A timed launch's output against the oracle, bit for bit (offsets u64 and ids u32 of the whole batch)."""
+    import oracle
+    from gtars_amd import synth
+
+    ref = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM)
+    off_o, ids_o = ref.tokenize(q["chrom"], q["start"], q["end"])
+    ok = (h == len(ids_o) and np.array_equal(offsets_t.cpu().numpy().view(np.uint64), off_o)
+          and np.array_equal(ids_t[:h].cpu().numpy().view(np.uint32), ids_o))
+    if not ok:
+        raise SystemExit(f"bench.py: {where} differs from the oracle")
+    return True
+
+
+def bench_large(ix, u, q, nu, sizes, dev, stream):
+    """The same kernel on larger batches: queries/s and fraction of the HBM peak, median of 5 single-launch timings each
+    (HIP events on the launch stream).  The batch is the 1M-query base batch TILED on the device (query values repeat with
+    period 1M; the batch stays shuffled).  Checked in the run: the first and the last period's ids equal the oracle's
+    tokenization of the base batch, offsets ascend and end at the hit count."""
     import torch
 
+    import oracle
+    from gtars_amd import synth
+
+    ref = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM)
+    off_o, ids_o = ref.tokenize(q["chrom"], q["start"], q["end"])
+    ids_o_t = torch.from_numpy(ids_o.view(np.int32)).to(dev)
     out = []
     base = {k: _dev(q[k], dev) for k in ("chrom", "start", "end")}
     nq0 = base["chrom"].numel()
@@ -174,18 +204,103 @@ def bench_large(ix, q, nu, sizes, dev, stream):
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) * 1e-3)
         dt = statistics.median(times)
+        h0 = len(ids_o)
+        ok = (h2 == h0 * rep and int(off[-1]) == h2 and bool((off[1:] >= off[:-1]).all())
+              and torch.equal(ids[:h0], ids_o_t) and torch.equal(ids[h2 - h0:h2], ids_o_t))
+        if not ok:
+            raise SystemExit(f"bench.py: the {n2}-query launch differs from the oracle")
         byts = algorithmic_bytes(n2, h2, nu)
         out.append({"queries": n2, "hits": h2, "ms": dt * 1e3, "qps": n2 / dt, "achieved_GBps": byts / dt / 1e9,
-                    "frac": byts / dt / 1e9 / HBM_PEAK_GBS})
+                    "frac": byts / dt / 1e9 / HBM_PEAK_GBS, "verified": True,
+                    "batch": f"the 1M-query base batch tiled {rep}x on the device (values repeat with period {nq0}; still shuffled)"})
         del big, off, ids
         torch.cuda.empty_cache()
     return out
 
 
-def bench_igd_config3(dev, stream, ndb=50_000_000, nq=10_000_000, n_files=1000):
+def _profiler_attached() -> bool:
+    env = os.environ
+    return ("rocprofiler" in env.get("LD_PRELOAD", "").lower() or "rocprof" in env.get("LD_PRELOAD", "").lower()
+            or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in env))
+
+
+def _child_env(tmp):
+    """environment of a child rocprofv3: nothing of a profiler that may be attached to THIS process is inherited"""
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_"))}
+    env["TMPDIR"] = tmp
+    return env
+
+
+def measure_traffic_with_rocprof(child_args):
+    """HBM-side bytes per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE; children of this process,
+    never combined with a trace domain) over a short invocation of this script.
+    -> {kernel name: {"fetch": bytes summed over its dispatches (FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md),
+    "write": bytes, "dispatches": n}} or None.  Not attempted when a profiler is already attached to this process
+    (bench.py under rocprofv3 needs --no-pmc: a child profiler started from a process the tool library has initialised
+    would be the forbidden exec-after-GPU-init hop)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None or _profiler_attached():
+        return None
+    tmp = tempfile.mkdtemp(prefix="gtars_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    res = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__)] + child_args
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300, env=_child_env(tmp))
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            key = "fetch" if counter == "FETCH_SIZE" else "write"
+            scale = 2048.0 if counter == "FETCH_SIZE" else 1024.0  # the counters are in KB
+            for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("gtars::", "").strip()
+                e = res.setdefault(name, {"fetch": 0.0, "write": 0.0, "dispatches": 0})
+                e[key] += float(row["Counter_Value"]) * scale
+                if counter == "FETCH_SIZE":
+                    e["dispatches"] += 1
+        return res or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+IGD3 = dict(ndb=50_000_000, nq=10_000_000, n_files=1000)
+# total hits of config 3 at its seeds (pairwise, binary): what one GPU returns (BENCH_r02.json, checked there against the
+# oracle by tests/test_gpu_parity.py::test_config3_igd_full_size_properties) -- any sharding must reproduce them
+IGD3_TOTALS = (149452392, 148309462)
+IGD_PMC_CALLS = 6
+IGD_COUNT_KERNELS = ("k_igd_prep", "k_igd_route", "k_ms_", "k_split_", "k_igd_chrom_segments", "k_igd_tile_ranges", "k_igd_sweep")
+LOLA4 = dict(n_sets=2000, per_set=25_000, n_universe=1_000_000, n_user=100_000)
+LOLA4_SUPPORT_SUM = 1793489
+
+
+def _oracle_igd(db, n_files):
+    import oracle
+
+    t = time.perf_counter()
+    g = oracle.Igd()
+    g.add_arrays(db["chrom"], db["start"], db["end"], np.arange(len(db["chrom"]), dtype=np.int32), db["file"])
+    g.finalize()
+    g.n_files = n_files
+    return g, time.perf_counter() - t
+
+
+def bench_igd_config3(dev, stream, ndb=IGD3["ndb"], nq=IGD3["nq"], n_files=IGD3["n_files"], cpu=True, pmc=True):
     """BASELINE config 3: 10M shuffled synthetic intervals vs a 50M-interval, 1000-file IGD database on one GPU.
     Bytes = 12*Nq + 16*Ndb + 8*F.  The headline is the batch AS SPECIFIED (shuffled); the same batch in
-    (chromosome, start) order -- what a sorted BED file delivers -- is reported next to it."""
+    (chromosome, start) order -- what a sorted BED file delivers -- is reported next to it.  `cpu_baseline`: the oracle's
+    Igd (B1, one thread) on the full database and a SAMPLE of the batch; the GPU's counts of the same sample must equal it."""
     import torch
 
     import gtars_amd
@@ -198,7 +313,6 @@ def bench_igd_config3(dev, stream, ndb=50_000_000, nq=10_000_000, n_files=1000):
     t = time.time()
     g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=n_files)
     tbuild = time.time() - t
-    del db
     hits = torch.zeros(n_files, dtype=torch.int64, device=dev)
     byts = 12 * nq + 16 * ndb + 8 * n_files
     out = {"db_intervals": ndb, "queries": nq, "files": n_files, "gen_s": round(tgen, 2), "build_s": round(tbuild, 2),
@@ -211,60 +325,99 @@ def bench_igd_config3(dev, stream, ndb=50_000_000, nq=10_000_000, n_files=1000):
             f()
             torch.cuda.synchronize()
             times = []
-            for _ in range(5):
+            for _ in range(7):
                 t0 = time.perf_counter()
                 f()
                 torch.cuda.synchronize()
                 times.append(time.perf_counter() - t0)
             dt = statistics.median(times)
-            out[("binary" if binary else "pairwise") + "_" + label] = {
-                "ms": round(dt * 1e3, 3), "qps": round(nq / dt), "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 5),
-                "total_hits": int(hits.sum())}
+            tot = int(hits.sum())
+            key = ("binary" if binary else "pairwise") + "_" + label
+            out[key] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt), "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 5),
+                        "total_hits": tot}
+            if (ndb, nq, n_files) == (IGD3["ndb"], IGD3["nq"], IGD3["n_files"]):
+                if tot != IGD3_TOTALS[1 if binary else 0]:
+                    raise SystemExit(f"bench.py: igd_config3 {key}: {tot} hits, expected {IGD3_TOTALS[1 if binary else 0]}")
+                out[key]["verified"] = "total hits == the config's known total; sample == oracle (cpu_baseline)"
         del qc, qs, qe
+    if cpu:
+        # B1 on a sample: the oracle indexes the WHOLE database (build time stated, not part of the rate), then counts the
+        # first `ns` queries of the shuffled batch; the GPU counts the same sample and must return the same vectors
+        og, t_ob = _oracle_igd(db, n_files)
+        ns = min(nq, 6_000_000)
+        sq = {k: np.ascontiguousarray(q[k][:ns]) for k in ("chrom", "start", "end")}
+        t0 = time.perf_counter()
+        hp = og.count_set_overlaps(sq["chrom"], sq["start"], sq["end"], 1, n_files=n_files)
+        t_p = time.perf_counter() - t0
+        nb = ns // 2
+        t0 = time.perf_counter()
+        hb = og.count_region_hits(sq["chrom"][:nb], sq["start"][:nb], sq["end"][:nb], 1, n_files=n_files)
+        t_b = time.perf_counter() - t0
+        d = [_dev(sq[k], dev) for k in ("chrom", "start", "end")]
+        g.count_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), ns, hits.data_ptr(), 1, False, stream)
+        torch.cuda.synchronize()
+        same = np.array_equal(hits.cpu().numpy().astype(np.uint64), hp.astype(np.uint64))
+        g.count_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nb, hits.data_ptr(), 1, True, stream)
+        torch.cuda.synchronize()
+        same = same and np.array_equal(hits.cpu().numpy().astype(np.uint64), hb.astype(np.uint64))
+        if not same:
+            raise SystemExit("bench.py: igd_config3: the GPU's per-file counts of the sample differ from the oracle's")
+        out["cpu_baseline"] = {
+            "value": ns / t_p, "unit": "queries/s", "cores": 1, "kind": "port", "binary_value": nb / t_b,
+            "sample": f"oracle Igd (oracle/gtars_oracle.c, one thread) over the full {ndb}-record database (built in {t_ob:.1f} s, not "
+                      f"counted): count_set_overlaps of the first {ns} queries of the shuffled batch in {t_p:.1f} s, count_region_hits "
+                      f"of the first {nb} in {t_b:.1f} s; the GPU's vectors for the same samples are identical",
+        }
+        del og, d
+    del db
+    if pmc:
+        live = measure_traffic_with_rocprof(["--igd-pmc-child"])
+        tr = None
+        if live is not None:
+            # every kernel of the count path (prep, partition, tile ranges, sweep), summed over the child's IGD_PMC_CALLS calls
+            path = {k: v for k, v in live.items() if k.startswith(IGD_COUNT_KERNELS)}
+            per_call = sum(v["fetch"] + v["write"] for v in path.values()) / IGD_PMC_CALLS
+            if path:
+                tr = {"bytes_per_call": per_call, "vs_algorithmic": per_call / byts,
+                      "by_kernel_per_call": {k: round((v["fetch"] + v["write"]) / IGD_PMC_CALLS) for k, v in sorted(path.items())},
+                      "source": f"measured in this run: child rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py "
+                                f"--igd-pmc-child` ({IGD_PMC_CALLS} shuffled-batch calls, pairwise and binary alternating; FETCH_SIZE x2)"}
+        if tr is None:
+            tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_igd_config3.json")
+            if os.path.exists(tpath):
+                tr = json.load(open(tpath))
+                tr["source"] = f"replayed from profiles/{PROFILE_ROUND}/traffic_igd_config3.json"
+        out["traffic"] = tr
     del g
     torch.cuda.empty_cache()
     return out
 
 
-def measure_traffic_with_rocprof(nq, universe):
-    """HBM-side bytes per k_tok_lds launch from two rocprofv3 --pmc passes (children of this process; nothing else
-    traced) over a short run of this script on the same workload.  -> (bytes, source) or None."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
+def igd_pmc_child():
+    """`bench.py --igd-pmc-child` (under rocprofv3 --pmc): a few config-3 calls, nothing else."""
+    import torch
 
-    exe = shutil.which("rocprofv3")
-    if exe is None:
-        return None
-    tmp = tempfile.mkdtemp(prefix="gtars_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    means = {}
-    try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "20", "--warmup", "5", "--queries", str(nq), "--universe", str(universe), "--no-cpu-baseline",
-                   "--no-extras", "--no-pmc", "--min-seconds", "0.05"]
-            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240, env=dict(os.environ, TMPDIR=tmp))
-            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None
-            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(max(files, key=os.path.getmtime)))
-                    if "k_tok_lds" in row["Kernel_Name"] and row["Counter_Name"] == counter]
-            if not vals:
-                return None
-            means[counter] = sum(vals) / len(vals) * 1024.0  # the counters are in KB
-        traffic = 2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]
-        return traffic, ("measured in this run: mean over k_tok_lds dispatches of two child rocprofv3 --pmc passes "
-                         "(FETCH_SIZE x2 for gfx950 + WRITE_SIZE) of a short invocation of this script")
-    except Exception:
-        return None
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+    import gtars_amd
+    from gtars_amd import synth
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    db = synth.make_igd_db(IGD3["ndb"], IGD3["n_files"])
+    q = synth.make_background_queries(IGD3["nq"])
+    g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=IGD3["n_files"])
+    del db
+    qc, qs, qe = (_dev(q[k], dev) for k in ("chrom", "start", "end"))
+    hits = torch.zeros(IGD3["n_files"], dtype=torch.int64, device=dev)
+    g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), 1000, hits.data_ptr(), 1, True, stream)  # builds pme_file (per-query path)
+    torch.cuda.synchronize()
+    for i in range(IGD_PMC_CALLS):
+        g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), IGD3["nq"], hits.data_ptr(), 1, bool(i & 1), stream)
+    torch.cuda.synchronize()
 
 
-def bench_lola_config4(dev, stream, n_sets=2000, per_set=25_000, n_universe=1_000_000, n_user=100_000):
+def bench_lola_config4(dev, stream, n_sets=LOLA4["n_sets"], per_set=LOLA4["per_set"], n_universe=LOLA4["n_universe"],
+                       n_user=LOLA4["n_user"], cpu=True):
     """BASELINE config 4 on ONE GPU: support counts of one user set and of the universe against a 2000-set region DB
     (two binary IGD counts) + the contingency cells (enrichment.rs:198-221)."""
     import torch
@@ -280,7 +433,6 @@ def bench_lola_config4(dev, stream, n_sets=2000, per_set=25_000, n_universe=1_00
     t = time.time()
     g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=n_sets)
     tb = time.time() - t
-    del db
     uq = [_dev(uni[k], dev) for k in ("chrom", "start", "end")]
     sq = [_dev(uni[k][sel], dev) for k in ("chrom", "start", "end")]
     uh = torch.zeros(n_sets, dtype=torch.int64, device=dev)
@@ -297,18 +449,229 @@ def bench_lola_config4(dev, stream, n_sets=2000, per_set=25_000, n_universe=1_00
     run()
     torch.cuda.synchronize()
     times = []
-    for _ in range(5):
+    for _ in range(7):
         t0 = time.perf_counter()
         run()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     dt = statistics.median(times)
     a, b, c, d = [x.cpu().numpy() for x in cells]
-    ok = bool(((a + b) == uh.cpu().numpy()).all() and ((a + c) == n_user).all() and ((a + b + c + d) == nuni).all())
-    del g
+    uh_h, sh_h = uh.cpu().numpy(), sh.cpu().numpy()
+    ok = bool(((a + b) == uh_h).all() and ((a + c) == n_user).all() and ((a + b + c + d) == nuni).all())
+    byts = 12 * (nuni + n_user) + 16 * n_sets * per_set + 8 * 2 * n_sets
+    out = {"sets": n_sets, "db_intervals": n_sets * per_set, "universe": nuni, "user": n_user, "build_s": round(tb, 2),
+           "counts_ms": round(dt * 1e3, 3), "algorithmic_bytes": byts, "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 5),
+           "identities_hold": ok, "support_sum": int(a.sum())}
+    if not ok:
+        raise SystemExit("bench.py: lola_config4: the contingency identities do not hold")
+    if cpu:
+        # B1: the oracle's Igd over the whole region DB; the user set's support vector in full (the GPU's must equal it) and
+        # the first `ns` universe regions as the timing sample of the pooled-support count
+        og, t_ob = _oracle_igd(db, n_sets)
+        user = {k: np.ascontiguousarray(uni[k][sel]) for k in ("chrom", "start", "end")}
+        t0 = time.perf_counter()
+        su = og.count_region_hits(user["chrom"], user["start"], user["end"], 1, n_files=n_sets)
+        ns = nuni
+        og.count_region_hits(uni["chrom"][:ns], uni["start"][:ns], uni["end"][:ns], 1, n_files=n_sets)
+        t_c = time.perf_counter() - t0
+        if not np.array_equal(su.astype(np.int64), sh_h):
+            raise SystemExit("bench.py: lola_config4: the user set's support vector differs from the oracle's")
+        out["verified"] = "a,b,c,d identities; the user set's support vector == oracle"
+        out["cpu_baseline"] = {
+            "value": (n_user + ns) / t_c, "unit": "regions/s (binary support counts)", "cores": 1, "kind": "port",
+            "est_counts_ms": round((n_user + nuni) / ((n_user + ns) / t_c) * 1e3, 1),
+            "sample": f"oracle Igd over the full {n_sets * per_set}-record region DB (built in {t_ob:.1f} s, not counted): "
+                      f"count_region_hits of the whole {n_user}-region user set + the first {ns} universe regions in {t_c:.1f} s "
+                      f"(one thread); est_counts_ms extrapolates to user set + universe",
+        }
+        del og
+    del db, g
     torch.cuda.empty_cache()
-    return {"sets": n_sets, "db_intervals": n_sets * per_set, "universe": nuni, "user": n_user, "build_s": round(tb, 2),
-            "counts_ms": round(dt * 1e3, 3), "identities_hold": ok, "support_sum": int(a.sum())}
+    return out
+
+
+def bench_fragsplit_config5(files=300, frags=10_000, clusters=20, cpu_files=60):
+    """BASELINE config 5 at a reduced file count (the config names 10k fragment files on 8 GPUs; per-file cost is what
+    scales): gzip'd fragment files -> barcode routing -> per-cluster tokenization, end to end from the .gz files."""
+    import shutil
+    import tempfile
+
+    import oracle
+    from gtars_amd import synth, utils
+    from gtars_amd.fragsplit import BarcodeToClusterMap, fragsplit_tokenize, pseudobulk_fragment_files
+    from gtars_amd.tokenizers import Tokenizer, tokenize_fragment_files
+
+    tmp = tempfile.mkdtemp(prefix="gtars_c5_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        u = synth.make_universe(100_000)
+        t = time.time()
+        ub, fd, mp, gz_bytes = synth.write_config5_inputs(tmp, u, files, frags, clusters)
+        t_gen = time.time() - t
+        tok = Tokenizer.from_bed(ub)
+        m = BarcodeToClusterMap.from_file(mp)
+        paths = sorted(os.path.join(fd, f) for f in os.listdir(fd))
+        t = time.perf_counter()
+        n_parsed = 0
+        for pth in paths:  # host share: gunzip + parse only, file by file (the pipelines below read the files on several host threads)
+            n_parsed += len(utils.read_fragments(pth)["start"])
+        t_parse = time.perf_counter() - t
+        od = os.path.join(tmp, "out")
+        t = time.perf_counter(); st = pseudobulk_fragment_files(fd, m, od); t_split = time.perf_counter() - t
+        cluster_files = [os.path.join(od, f"cluster_{l}.bed.gz") for l in m.cluster_labels()]
+        t = time.perf_counter(); res2 = tokenize_fragment_files(cluster_files, tok, workers=16); t_tok = time.perf_counter() - t
+        fragsplit_tokenize(fd, m, tok, as_arrays=True)  # warm-up (device buffers)
+        t = time.perf_counter(); fused = fragsplit_tokenize(fd, m, tok, as_arrays=True); t_fused = time.perf_counter() - t
+        ids_two = sum(sum(len(v) for v in d.values()) for d in res2)
+        ids_fused = sum(int(v[1][-1]) for v in fused.values())
+        n = files * frags
+        out = {"files": files, "fragments_per_file": frags, "fragments": n, "clusters": m.n_clusters(),
+               "input_gz_MB": round(gz_bytes / 1e6, 1), "gen_s": round(t_gen, 1), "host_threads": os.cpu_count(),
+               "scale_note": f"{files} of the config's 10,000 files (1/{10000 // files}); one GPU",
+               "routed_fragments": st["written"], "token_ids": ids_fused,
+               "host_gunzip_parse": {"s": round(t_parse, 3), "fragments_per_s": round(n_parsed / t_parse), "note": "gtars_fragments_read, one file at a time"},
+               "two_step": {"fragsplit_s": round(t_split, 3), "tokenize_cluster_files_s": round(t_tok, 3),
+                            "fragments_per_s": round(n / (t_split + t_tok))},
+               "fused": {"s": round(t_fused, 3), "fragments_per_s": round(n / t_fused)},
+               "value": n / t_fused, "unit": "fragments/s end to end (fused route + tokenize)"}
+        if ids_two != ids_fused:
+            raise SystemExit("bench.py: fragsplit_config5: fused and two-step pipelines disagree")
+        # B1 on a sample of the files: the oracle's fragsplit (split.rs:36-151 restated) + OracleTokenizer per cluster file
+        sd = os.path.join(tmp, "sample")
+        os.mkdir(sd)
+        for pth in paths[:cpu_files]:
+            os.symlink(pth, os.path.join(sd, os.path.basename(pth)))
+        t = time.perf_counter()
+        om = oracle.OracleBarcodeMap(mp)
+        routed = oracle.fragsplit(sd, om)
+        otok = oracle.OracleTokenizer(ub)
+        n_ids = 0
+        for label, lines in routed.items():
+            regs = [ln.split("\t")[:3] for ln in lines]
+            n_ids += len(otok.encode_regions([(r[0], int(r[1]), int(r[2])) for r in regs]))
+        t_cpu = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": cpu_files * frags / t_cpu, "unit": "fragments/s", "cores": 1, "kind": "port",
+                               "sample": f"{cpu_files} of the {files} files through oracle.fragsplit + OracleTokenizer (pure-Python "
+                                         f"restatement of split.rs / tokenizer.rs, one thread, {t_cpu:.1f} s): a port, far slower than "
+                                         f"compiled Rust would be -- reported for completeness, not as a fair CPU figure"}
+        out["verified"] = "fused == two-step id counts (every file is compared with the oracle by tests/test_gpu_host.py)"
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------ N > 1
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` started plainly: start the N ranks as a child torch.distributed.run (this process has
+    not touched a GPU: torch.cuda.device_count() does not initialise one on this image) and return its exit code."""
+    import socket
+    import subprocess
+
+    import torch
+
+    backend = os.environ.get("GTARS_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (backend == "nccl" and ndev < n):
+        print(f"bench.py: --gpus {n} needs {n} visible devices under the nccl backend, found {ndev} "
+              f"(GTARS_BENCH_BACKEND=gloo lets ranks share a device: a plumbing test, not a measurement)", file=sys.stderr)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GTARS_BENCH_SPAWNED="1")).returncode
+
+
+def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scale=1):
+    """What north_star shards by chromosome bucket, at N > 1: config 3 (IGD database + query batch) and config 4 (LOLA region
+    DB, universe and user set).  Strong scaling: the configs' sizes are fixed, every rank ingests and counts only its
+    chromosomes (LPT buckets over database + query weights), one all-reduce of the per-file vector(s) per call."""
+    import torch
+
+    from gtars_amd import sharding, synth
+
+    eng = sharding.HipEngine(dev)
+    out = {}
+    # ---- config 3 ----
+    ndb, nq, F = IGD3["ndb"] // scale, IGD3["nq"] // scale, IGD3["n_files"]
+    q = synth.make_background_queries(nq)
+    t = time.time()
+    sdb = sharding.ShardedIgd(eng, synth.igd_db_chunks(ndb, F), synth.N_CHROM, F, mode="bucket", balance_with=[q["chrom"]])
+    t_ingest = time.time() - t
+    h = sdb.upload_local(q)
+    local_q = int(h[0].numel())
+    byts = 12 * nq + 16 * ndb + 8 * F
+    o3 = {"db_intervals": ndb, "queries": nq, "files": F, "algorithmic_bytes": byts, "scaling": "strong",
+          "sharding": "chromosome buckets (LPT over database + query weights); every rank ingests only its chromosomes' rows",
+          "collective": f"one all-reduce(SUM) of {F} int64 per call ({backend})",
+          "ingest_s_rank0": round(t_ingest, 2)}
+    locals_ = [None] * world
+    dist.all_gather_object(locals_, {"db_intervals": sdb.local_intervals, "queries": local_q})
+    o3["per_rank"] = locals_
+    for binary in (False, True):
+        hits = torch.zeros(F, dtype=torch.int64, device=dev)
+        sdb.count_resident(h, 1, binary, hits)
+        times = []
+        for _ in range(7):
+            barrier()
+            t0 = time.perf_counter()
+            sdb.count_resident(h, 1, binary, hits)
+            barrier()
+            times.append(max_over_ranks(time.perf_counter() - t0))
+        dt = statistics.median(times)
+        tot = int(hits.sum())
+        if scale == 1 and tot != IGD3_TOTALS[1 if binary else 0]:
+            raise SystemExit(f"bench.py: igd_config3_sharded: {tot} hits, expected {IGD3_TOTALS[1 if binary else 0]}")
+        o3["binary" if binary else "pairwise"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt), "total_hits": tot,
+                                                  "frac_of_all_gpus": round(byts / dt / 1e9 / HBM_PEAK_GBS / world, 5),
+                                                  "verified": "total hits == the single-GPU total" if scale == 1 else None}
+    out["igd_config3_sharded"] = o3
+    del sdb, h, q
+    torch.cuda.empty_cache()
+    # ---- config 4 ----
+    n_sets, per_set = LOLA4["n_sets"], LOLA4["per_set"] // scale
+    uni = synth.make_universe(LOLA4["n_universe"] // scale, seed=3)
+    sel = np.sort(np.random.default_rng(9).choice(len(uni["chrom"]), LOLA4["n_user"] // scale, replace=False))
+    user = {k: uni[k][sel] for k in ("chrom", "start", "end")}
+    nuni, n_user = len(uni["chrom"]), len(sel)
+    sdb = sharding.ShardedIgd(eng, synth.igd_db_chunks(n_sets * per_set, n_sets, seed=6), synth.N_CHROM, n_sets, mode="bucket",
+                              balance_with=[uni["chrom"]])
+    hu, hs = sdb.upload_local(uni), sdb.upload_local(user)
+    stacked = torch.zeros(2, n_sets, dtype=torch.int64, device=dev)
+
+    def run():
+        eng.igd_count_resident(sdb.g, hu, 1, True, stacked[0], sync=False)
+        eng.igd_count_resident(sdb.g, hs, 1, True, stacked[1], sync=False)
+        sharding.all_reduce_hits_(stacked)
+        return sharding.contingency(stacked[1:], stacked[0], [n_user], nuni)
+
+    run()
+    times = []
+    for _ in range(7):
+        barrier()
+        t0 = time.perf_counter()
+        cells = run()
+        barrier()
+        times.append(max_over_ranks(time.perf_counter() - t0))
+    dt = statistics.median(times)
+    a, b, c, d = [x[0].cpu().numpy() for x in cells]
+    uh = stacked[0].cpu().numpy()
+    ok = bool(((a + b) == uh).all() and ((a + c) == n_user).all() and ((a + b + c + d) == nuni).all()
+              and (scale != 1 or int(a.sum()) == LOLA4_SUPPORT_SUM))
+    if not ok:
+        raise SystemExit("bench.py: lola_config4_sharded: identities / support sum differ from the single-GPU result")
+    out["lola_config4_sharded"] = {"sets": n_sets, "db_intervals": n_sets * per_set, "universe": nuni, "user": n_user,
+                                   "scaling": "strong", "counts_ms": round(dt * 1e3, 3), "support_sum": int(a.sum()),
+                                   "collective": f"one all-reduce(SUM) of 2 x {n_sets} int64 per call ({backend}): the user set's "
+                                                 f"and the universe's support vectors (enrichment.rs:198-221)",
+                                   "local_db_intervals_rank0": sdb.local_intervals,
+                                   "verified": "a,b,c,d identities; support sum == the single-GPU value"}
+    del sdb, hu, hs
+    torch.cuda.empty_cache()
+    if scale != 1:
+        out["configs_scaled_down_by"] = scale
+    return out
 
 
 def main():
@@ -324,15 +687,24 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / igd_config3 / lola_config4 / host path")
     ap.add_argument("--large", type=str, default="64000000,256000000,1000000000", help="batch sizes of roofline_large")
+    ap.add_argument("--c5-files", type=int, default=300, help="fragment files of fragsplit_config5 (the config names 10,000)")
+    ap.add_argument("--scale-configs", type=int, default=1, help="tests only: divide the sizes of configs 3 / 4 (sharded objects) by this")
+    ap.add_argument("--igd-pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.igd_pmc_child:
+        return igd_pmc_child()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: this process becomes the launcher of the N ranks (no GPU call has been made here)
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: the launcher's world size is what runs", file=sys.stderr)
     n_gpus = max(world, 1)
 
     import gtars_amd
@@ -342,6 +714,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: gtars_amd has no CPU fallback")
     # one rank per GPU; GTARS_BENCH_BACKEND=gloo lets several ranks share a GPU (plumbing test on a 1-GPU box)
     backend = os.environ.get("GTARS_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks under nccl need {world} devices, {torch.cuda.device_count()} visible")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -425,6 +799,16 @@ def main():
         gpu_s += dt
     elapsed = statistics.median(rep_wall)
     avg_ms = statistics.median(rep_kernel_ms)
+    # the outputs the timed launches left behind, against the oracle (bit-exact): batch 0 on every rank
+    verified = verify_tokenization(u, q0, batches[0][3], batches[0][4], batches[0][5], f"rank {rank}: the timed output of batch 0")
+    # what every rank saw (device, backend): "did RCCL see N ranks" is answerable from the line
+    me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index),
+          "pci_bus_id": getattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id", None),
+          "visible_devices": torch.cuda.device_count(), "backend": backend, "pid": os.getpid()}
+    ranks = [me]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
 
     # ---- the dominant kernel: its name from the library's profiling hooks, its duration from the events above ----
     roofline = None
@@ -441,9 +825,13 @@ def main():
         traffic, traffic_source = None, "not measured in this run (needs rocprofv3 --pmc passes)"
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_tokenize_1M.json")
         if world == 1 and not args.no_extras and not args.no_pmc:
-            live = measure_traffic_with_rocprof(nq, args.universe)
-            if live is not None:
-                traffic, traffic_source = live
+            live = measure_traffic_with_rocprof(["--steps", "20", "--warmup", "5", "--queries", str(nq), "--universe", str(args.universe),
+                                                 "--no-cpu-baseline", "--no-extras", "--no-pmc", "--min-seconds", "0.05"])
+            tok = [v for k, v in (live or {}).items() if "k_tok_lds" in k]
+            if tok:
+                traffic = sum(v["fetch"] + v["write"] for v in tok) / sum(v["dispatches"] for v in tok)
+                traffic_source = ("measured in this run: mean over k_tok_lds dispatches of two child rocprofv3 --pmc passes "
+                                  "(FETCH_SIZE x2 for gfx950 + WRITE_SIZE) of a short invocation of this script")
         if traffic is None and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj["workload"]["queries_per_step"] == nq and tj["workload"]["universe_regions"] == args.universe:
@@ -457,6 +845,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_vs_algorithmic": (traffic / bytes_per_launch) if traffic else None,
             "traffic_source": traffic_source,
             "avg_kernel_ms": avg_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -483,6 +872,12 @@ def main():
         with_allgather = {"value": nq * n_gpus * args.steps / dt, "unit": "query intervals/s", "ms_per_step": dt / args.steps * 1e3,
                           "note": "tokenize + all-gatherv of offsets (u64) and ids (u32) so that every rank holds the global CSR"}
 
+    sharded = None
+    if dist is not None and not args.no_extras:
+        del batches[:]
+        torch.cuda.empty_cache()
+        sharded = bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, max(1, args.scale_configs))
+
     if rank == 0:
         total_q = nq * n_gpus * args.steps
         out = {
@@ -490,6 +885,10 @@ def main():
             "value": total_q / elapsed,
             "unit": "query intervals/s",
             "n_gpus": n_gpus,
+            "world_size": world,
+            "backend": backend if world > 1 else None,
+            "ranks": ranks,
+            "verified": "every rank: offsets + ids of timed batch 0 == oracle (bit-exact)" if verified else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -515,9 +914,11 @@ def main():
         }
         if with_allgather:
             out["with_allgather"] = with_allgather
+        if sharded:
+            out.update(sharded)
         if world == 1 and not args.no_extras:
             sizes = [int(t) for t in args.large.split(",") if t]
-            out["roofline_large"] = bench_large(ix, q0, nu, sizes, dev, stream)
+            out["roofline_large"] = bench_large(ix, u, q0, nu, sizes, dev, stream)
             # PCIe-inclusive rates through the host-pointer entry points (H2D of the queries, kernel, D2H of offsets +
             # ids).  Reported for context only; never `value`.  `streaming`: gtars_tokenize_into with
             # output arrays the caller reuses (chunked copy / kernel / copy-back pipeline, nothing allocated);
@@ -536,8 +937,10 @@ def main():
             out["host_buffers_end_to_end"] = hb
             del batches[:]
             torch.cuda.empty_cache()
-            out["igd_config3"] = bench_igd_config3(dev, stream)
-            out["lola_config4"] = bench_lola_config4(dev, stream)
+            cpu = not args.no_cpu_baseline
+            out["igd_config3"] = bench_igd_config3(dev, stream, cpu=cpu, pmc=not args.no_pmc)
+            out["lola_config4"] = bench_lola_config4(dev, stream, cpu=cpu)
+            out["fragsplit_config5"] = bench_fragsplit_config5(files=args.c5_files)
         if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(u, q0)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(u, q0)

@@ -94,6 +94,9 @@ _SIG = {
     "gtars_any_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp]),
     "gtars_find_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, pp, pp, pp, pu64]),
     "gtars_find_overlap_indices": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, pp, pu64]),
+    "gtars_subset_by_overlaps": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, pp, pp, pp, pu64]),
+    "gtars_subset_source_indices": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, pp, pu64]),
+    "gtars_mark_overlapped_device": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, vp]),
     "gtars_igd_build": (C.c_int, [vp, vp, vp, vp, vp, u64, u32, u32, pp]),
     "gtars_igd_free": (None, [vp]),
     "gtars_igd_len": (u64, [vp]),

@@ -877,6 +877,7 @@ static size_t fused_ws_bytes(const gtars_index *ix, u64 nq) {
 }
 static bool use_lds_path(const gtars_index *ix) {
     static const bool disabled = getenv("GTARS_NO_LDS_PATH") != nullptr;
+    if (getenv("GTARS_NO_LDS_PATH_FOR_TEST")) return false;  // tests: read on every call, so one process can compare both paths
     // has_accel: a Bits-kind index, or an AIList-kind one whose chromosomes all have a single sub-list
     return !disabled && ix->has_accel && tokenize_lds_supported(ix->accel());
 }
@@ -1166,7 +1167,6 @@ struct HostPipe {
         int dev = 0;
         GT_HIP(hipGetDevice(&dev));
         if (device == dev) return GTARS_OK;
-        if (device != -1) return fail(GTARS_ERR_INTERNAL, "host pipeline: the calling thread changed its device");
         GT_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
         GT_HIP(hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking));
         GT_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
@@ -1193,11 +1193,27 @@ struct HostPipe {
         return GTARS_OK;
     }
 };
+// one pipe per (calling thread, device): a thread that switches devices between calls gets that device's pipe
 HostPipe &tls_host_pipe() {
-    static thread_local HostPipe p;  // device buffers stay until process exit (see Workspace)
-    return p;
+    static thread_local std::map<int, HostPipe> pipes;  // streams / helper threads stay until the thread exits
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return pipes[dev];
+}
+// A batch that needed more than this keeps only this much device memory afterwards (a 1e9-query batch is 22 GB of
+// staging; the next 1M-query call should not find a thread holding on to it).  GTARS_PIPE_KEEP_MB overrides.
+size_t pipe_keep_bytes() {
+    static const size_t keep = [] {
+        const char *e = getenv("GTARS_PIPE_KEEP_MB");
+        return (size_t)(e && *e ? atoll(e) : 1024) << 20;
+    }();
+    return keep;
 }
 }  // namespace
+
+static gtars_status hip_try(hipError_t e, const char *what) {
+    return e == hipSuccess ? GTARS_OK : hip_fail(e, what, __FILE__, __LINE__);
+}
 
 // offsets[nq + 1] and up to ids_capacity ids into caller memory; *out_n = hits.  ids may be null (offsets only).
 static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, u64 *offsets,
@@ -1225,6 +1241,18 @@ static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, co
     const size_t opad = ((size_t)(nq + 1) * 8 + 255) & ~(size_t)255;
     st = hp.reserve(3 * qpad + opad + (size_t)cap_dev * 4 + 256);
     if (st) return st;
+    struct Trim {  // on every way out: an unusually large batch does not leave its staging memory with the thread
+        HostPipe &hp;
+        ~Trim() {
+            if (hp.d_bytes <= pipe_keep_bytes()) return;
+            (void)hipStreamSynchronize(hp.s_in);
+            (void)hipStreamSynchronize(hp.s_comp);
+            (void)hipStreamSynchronize(hp.s_out);
+            (void)hipFree(hp.d_buf);
+            hp.d_buf = nullptr;
+            hp.d_bytes = 0;
+        }
+    } trim{hp};
     u32 *d_qc = (u32 *)hp.d_buf, *d_qs = (u32 *)((char *)hp.d_buf + qpad), *d_qe = (u32 *)((char *)hp.d_buf + 2 * qpad);
     u64 *d_off = (u64 *)((char *)hp.d_buf + 3 * qpad);
     u32 *d_ids = ids ? (u32 *)((char *)hp.d_buf + 3 * qpad + opad) : nullptr;
@@ -1237,7 +1265,14 @@ static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, co
         GT_HIP(hipMemcpyAsync(d_qs, qs, nq * 4, hipMemcpyHostToDevice, hp.s_comp));
         GT_HIP(hipMemcpyAsync(d_qe, qe, nq * 4, hipMemcpyHostToDevice, hp.s_comp));
         EnumOut out{d_off, d_ids, nullptr, nullptr, cap_dev};
-        st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp);
+        // The LDS tokenizer cannot time out (its look-back counts a missing tile itself).  The generic kernel can: its
+        // ScanHead.err is read back before offsets[nq] is trusted, and a timed-out batch is redone (run_fused_sync).
+        if (chain) {
+            st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp);
+        } else {
+            u64 scan_total = 0;
+            st = run_fused_sync(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp, &scan_total);
+        }
         if (st) {
             ws.ep = ScanEpoch();
             return st;
@@ -1265,11 +1300,14 @@ static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, co
     for (int k = 0; k < n_chunks; ++k) job_status[k] = GTARS_OK;
     for (int k = 0; k < n_chunks; ++k) {
         const u64 q0 = (u64)k * chunk, n_k = std::min<u64>(chunk, nq - q0);
-        GT_HIP(hipMemcpyAsync(d_qc + q0, qc + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in));
-        GT_HIP(hipMemcpyAsync(d_qs + q0, qs + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in));
-        GT_HIP(hipMemcpyAsync(d_qe + q0, qe + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in));
-        GT_HIP(hipEventRecord(hp.ev_in[k], hp.s_in));
-        GT_HIP(hipStreamWaitEvent(hp.s_comp, hp.ev_in[k], 0));
+        // no early return inside this loop: the helper's jobs hold pointers into this frame (job_status) and into the
+        // caller's arrays, so every exit goes through wait_idle() below
+        if ((st = hip_try(hipMemcpyAsync(d_qc + q0, qc + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in), "H2D chrom")) ||
+            (st = hip_try(hipMemcpyAsync(d_qs + q0, qs + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in), "H2D start")) ||
+            (st = hip_try(hipMemcpyAsync(d_qe + q0, qe + q0, n_k * 4, hipMemcpyHostToDevice, hp.s_in), "H2D end")) ||
+            (st = hip_try(hipEventRecord(hp.ev_in[k], hp.s_in), "record H2D event")) ||
+            (st = hip_try(hipStreamWaitEvent(hp.s_comp, hp.ev_in[k], 0), "wait H2D event")))
+            break;
         EnumOut out{d_off + q0, d_ids, nullptr, nullptr, cap_dev};
         if (chain)
             st = launch_tokenize_lds(ix->accel(), d_qc + q0, d_qs + q0, d_qe + q0, n_k, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp,
@@ -1278,10 +1316,11 @@ static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, co
             st = run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, hp.s_comp);
         if (st) break;
         if (chain)
-            GT_HIP(hipMemcpyAsync(hp.h_chain + k + 1, hp.d_chain + k + 1, sizeof(u64), hipMemcpyDeviceToHost, hp.s_comp));
+            st = hip_try(hipMemcpyAsync(hp.h_chain + k + 1, hp.d_chain + k + 1, sizeof(u64), hipMemcpyDeviceToHost, hp.s_comp), "D2H total");
         else
-            GT_HIP(hipMemcpyAsync(hp.h_chain + 1, &((ScanHead *)ws.ptr)->total, sizeof(u64), hipMemcpyDeviceToHost, hp.s_comp));
-        GT_HIP(hipEventRecord(hp.ev_done[k], hp.s_comp));
+            st = hip_try(hipMemcpyAsync(hp.h_chain + 1, &((ScanHead *)ws.ptr)->total, sizeof(u64), hipMemcpyDeviceToHost, hp.s_comp),
+                         "D2H total");
+        if (st || (st = hip_try(hipEventRecord(hp.ev_done[k], hp.s_comp), "record done event"))) break;
         const bool last = k + 1 == n_chunks;
         const int dev = hp.device;
         HostPipe *php = &hp;
@@ -1523,6 +1562,163 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
     *out_idx = res;
     *out_n = h2;
     return GTARS_OK;
+}
+
+// ---- index-side subset (multi_chrom_overlapper.rs:449-478, indexed_region_set.rs:201-230) ----------------------
+
+gtars_status gtars_mark_overlapped_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
+                                          const uint32_t *d_qe, uint64_t nq, int has_min, int32_t min_overlap,
+                                          uint32_t *d_mark, void *stream) {
+    gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
+    if (st) return st;
+    if (!d_mark && ix->n) return fail(GTARS_ERR_INVALID_ARG, "d_mark is NULL");
+    if ((st = require_device())) return st;
+    if (!use_lds_path(ix)) return fail(GTARS_ERR_INVALID_ARG, "index has no blocked structure: use gtars_subset_by_overlaps");
+    hipStream_t s = (hipStream_t)stream;
+    GT_HIP(hipMemsetAsync(d_mark, 0, ((size_t)ix->n + 31) / 32 * 4, s));
+    return launch_mark_lds(ix->accel_pos(), d_qc, d_qs, d_qe, nq, has_min, min_overlap, d_mark, s);
+}
+
+}  // extern "C"
+
+// ascending stored positions hit by any query (blocked structure), or -- generic kernels -- the hits themselves
+static gtars_status subset_positions(const gtars_index_t *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min,
+                                     i32 min_overlap, std::vector<u32> &pos) {
+    pos.clear();
+    if (!nq || !ix->n) return GTARS_OK;
+    DevQueries q;
+    gtars_status st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    const size_t words = ((size_t)ix->n + 31) / 32;
+    ScopedDev d_mark;
+    if ((st = d_mark.alloc(words * 4))) return st;
+    st = gtars_mark_overlapped_device(ix, q.c, q.s, q.e, nq, has_min, min_overlap, d_mark.as<u32>(), nullptr);
+    if (st) return st;
+    std::vector<u32> mark(words);
+    GT_HIP(hipMemcpy(mark.data(), d_mark.p, words * 4, hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < words; ++w) {
+        u32 m = mark[w];
+        while (m) {
+            pos.push_back((u32)(w * 32) + (u32)__builtin_ctz(m));
+            m &= m - 1;
+        }
+    }
+    return GTARS_OK;
+}
+
+extern "C" {
+
+static gtars_status gtars_subset_by_overlaps_impl(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+                                                  uint64_t nq, int has_min, int32_t min_overlap, uint32_t **out_chrom,
+                                                  uint32_t **out_start, uint32_t **out_end, uint64_t *out_n) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (!out_chrom || !out_start || !out_end || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
+    *out_chrom = *out_start = *out_end = nullptr;
+    *out_n = 0;
+    if ((st = require_device())) return st;
+    struct Trip {
+        u32 c, s, e;
+        bool operator<(const Trip &o) const { return std::tie(c, s, e) < std::tie(o.c, o.s, o.e); }
+        bool operator==(const Trip &o) const { return c == o.c && s == o.s && e == o.e; }
+    };
+    std::vector<Trip> hits;
+    if (use_lds_path(ix)) {
+        std::vector<u32> pos;
+        if ((st = subset_positions(ix, qc, qs, qe, nq, has_min, min_overlap, pos))) return st;
+        hits.reserve(pos.size());
+        u32 c = 0;
+        for (u32 p : pos) {  // positions ascend: so do their chromosomes
+            while (c + 1 < ix->h_chrom_off.size() && p >= ix->h_chrom_off[c + 1]) ++c;
+            hits.push_back(Trip{c, ix->h_starts[p], ix->h_ends[p]});
+        }
+    } else {
+        // generic kernels: the hits' coordinates per query (find_overlaps_regions), the set is formed here
+        std::vector<u64> off(nq + 1);
+        u32 *hs = nullptr, *he = nullptr;
+        u64 h = 0;
+        st = enumerate_to_host(ix, qc, qs, qe, nq, has_min, min_overlap, off.data(), nullptr, &hs, &he, &h);
+        if (st) {
+            free(hs);
+            free(he);
+            return st;
+        }
+        hits.reserve(h);
+        for (u64 qi = 0; qi < nq; ++qi)
+            for (u64 k = off[qi]; k < off[qi + 1]; ++k) hits.push_back(Trip{qc[qi], hs[k], he[k]});
+        free(hs);
+        free(he);
+    }
+    // BTreeSet<(chr, start, end)>: sorted, de-duplicated (Bits positions are already in this order; AIList's are not)
+    if (!std::is_sorted(hits.begin(), hits.end())) std::sort(hits.begin(), hits.end());
+    hits.erase(std::unique(hits.begin(), hits.end()), hits.end());
+    const u64 n = hits.size();
+    u32 *oc = host_alloc<u32>(n), *os = host_alloc<u32>(n), *oe = host_alloc<u32>(n);
+    if (!oc || !os || !oe) {
+        free(oc);
+        free(os);
+        free(oe);
+        return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    }
+    for (u64 i = 0; i < n; ++i) {
+        oc[i] = hits[i].c;
+        os[i] = hits[i].s;
+        oe[i] = hits[i].e;
+    }
+    *out_chrom = oc;
+    *out_start = os;
+    *out_end = oe;
+    *out_n = n;
+    return GTARS_OK;
+}
+
+gtars_status gtars_subset_by_overlaps(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe, uint64_t nq,
+                                      int has_min, int32_t min_overlap, uint32_t **out_chrom, uint32_t **out_start,
+                                      uint32_t **out_end, uint64_t *out_n) {
+    return guarded([&] { return gtars_subset_by_overlaps_impl(ix, qc, qs, qe, nq, has_min, min_overlap, out_chrom, out_start, out_end, out_n); });
+}
+
+static gtars_status gtars_subset_source_indices_impl(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
+                                                     const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
+                                                     uint32_t **out_idx, uint64_t *out_n) {
+    gtars_status st = check_query_args(ix, qc, qs, qe, nq);
+    if (st) return st;
+    if (!out_idx || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
+    *out_idx = nullptr;
+    *out_n = 0;
+    if ((st = require_device())) return st;
+    std::vector<u32> vals;
+    if (use_lds_path(ix)) {
+        std::vector<u32> pos;
+        if ((st = subset_positions(ix, qc, qs, qe, nq, has_min, min_overlap, pos))) return st;
+        vals.reserve(pos.size());
+        for (u32 p : pos) vals.push_back(ix->h_vals[p]);
+    } else {
+        std::vector<u64> off(nq + 1);
+        u32 *hv = nullptr;
+        u64 h = 0;
+        st = enumerate_to_host(ix, qc, qs, qe, nq, has_min, min_overlap, off.data(), &hv, nullptr, nullptr, &h);
+        if (st) {
+            free(hv);
+            return st;
+        }
+        vals.assign(hv, hv + h);
+        free(hv);
+    }
+    // BTreeSet<usize>: ascending, unique
+    std::sort(vals.begin(), vals.end());
+    vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+    u32 *res = host_alloc<u32>(vals.size());
+    if (!res) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    if (!vals.empty()) memcpy(res, vals.data(), vals.size() * 4);
+    *out_idx = res;
+    *out_n = vals.size();
+    return GTARS_OK;
+}
+
+gtars_status gtars_subset_source_indices(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+                                         uint64_t nq, int has_min, int32_t min_overlap, uint32_t **out_idx, uint64_t *out_n) {
+    return guarded([&] { return gtars_subset_source_indices_impl(ix, qc, qs, qe, nq, has_min, min_overlap, out_idx, out_n); });
 }
 
 // ---------------------------------------------------------------------- IGD

@@ -185,6 +185,8 @@ bool tokenize_lds_supported(const AccelView &a);
 
 gtars_status launch_count_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min,
                               i32 min_overlap, u32 *counts, u8 *any, hipStream_t st);
+gtars_status launch_mark_lds(const AccelView &a_pos, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min, i32 min_overlap,
+                             u32 *mark, hipStream_t st);
 gtars_status launch_bits_count(const IndexView &v, const u32 *ends_sorted, const u32 *qc, const u32 *qs, const u32 *qe,
                                u64 nq, u64 *out, hipStream_t st);
 gtars_status launch_count(const IndexView &v, int kind, const u32 *qc, const u32 *qs, const u32 *qe,

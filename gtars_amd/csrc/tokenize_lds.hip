@@ -763,10 +763,14 @@ __device__ __forceinline__ void load_queries_bf4(const u32 *__restrict__ qc, con
 // PF (16-byte-aligned query arrays): the next tile's queries are loaded right behind the record burst (branch-free,
 // so that the wait for the records is a counted one that leaves them in flight): 570 -> 532 us per 64M queries.
 // (The same prefetch makes the tokenizer SLOWER -- 632 -> 772 us per 64M queries -- and is not used there.)
-template <int TPB, bool FILTER, bool PF>
+// MARK (index-side subset, multi_chrom_overlapper.rs:454-478 / indexed_region_set.rs:201-230): instead of counting, every hit
+// sets the bit of its STORED POSITION in `mark` (launched on the position view of the structure, AccelView::idc = idc_pos:
+// position of (block b, slot k) = ACC_OWN * b + k + idc[chrom]).  A bit already seen set is not set again (a stale read only
+// costs a redundant atomic), so a dense batch does not hammer the same words.
+template <int TPB, bool FILTER, bool PF, bool MARK = false>
 __global__ void __launch_bounds__(TPB, 4)
 k_count_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u64 nq,
-            i32 min_bp, u32 *__restrict__ counts, u8 *__restrict__ any) {
+            i32 min_bp, u32 *__restrict__ counts, u8 *__restrict__ any, u32 *mark = nullptr) {
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
     constexpr int QPT = 4;
     constexpr u64 TILE = (u64)TPB * QPT;
@@ -802,17 +806,36 @@ k_count_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
             __builtin_amdgcn_sched_barrier(0);
         }
         u32 n[QPT];
+        if constexpr (MARK) {
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-            n[j] = act[j] ? __popc(block_mask4<FILTER>(S[j], E[j], s[j], e[j], min_bp)) : 0u;
-            if (act[j] && S[j].w < e[j] && b0[j] + 2 < be[j])
-                n[j] += walk_tail<FILTER, 2>(a.rec2, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
-        }
+            for (int j = 0; j < QPT; ++j) {
+                if (!act[j]) continue;  // also every query past the end of the batch (unknown chromosome)
+                const u32 pbase = L.idc[c[j]];
+                auto set_bit = [&](u32 b, int k) {
+                    const u32 pos = (u32)ACC_OWN * b + (u32)k + pbase, w = pos >> 5, bit = 1u << (pos & 31u);
+                    if (!(mark[w] & bit)) atomicOr(&mark[w], bit);
+                };
+                u32 m = block_mask4<FILTER>(S[j], E[j], s[j], e[j], min_bp);
+                while (m) {
+                    const int k = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    set_bit(b0[j], k);
+                }
+                if (S[j].w < e[j] && b0[j] + 2 < be[j]) walk_tail<FILTER, 2>(a.rec2, b0[j], be[j], s[j], e[j], min_bp, set_bit);
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-            if (q0 + j < nq) {
-                if (counts) counts[q0 + j] = n[j];
-                if (any) any[q0 + j] = n[j] ? 1 : 0;
+            for (int j = 0; j < QPT; ++j) {
+                n[j] = act[j] ? __popc(block_mask4<FILTER>(S[j], E[j], s[j], e[j], min_bp)) : 0u;
+                if (act[j] && S[j].w < e[j] && b0[j] + 2 < be[j])
+                    n[j] += walk_tail<FILTER, 2>(a.rec2, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
+            }
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                if (q0 + j < nq) {
+                    if (counts) counts[q0 + j] = n[j];
+                    if (any) any[q0 + j] = n[j] ? 1 : 0;
+                }
             }
         }
         if constexpr (PF) {
@@ -879,7 +902,29 @@ gtars_status launch_count_lds(const AccelView &a, const u32 *qc, const u32 *qs, 
     const u64 tiles = (nq + (u64)TPB * 4 - 1) / ((u64)TPB * 4);
     const unsigned grid = (unsigned)std::min<u64>(tiles, (u64)cus);
     ProfScope p("k_count_lds", st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, st, a, qc, qs, qe, nq, min_bp, counts, any);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, st, a, qc, qs, qe, nq, min_bp, counts, any, (u32 *)nullptr);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
+// index-side subset: bit p of `mark` (zeroed by the caller, ceil(n / 32) words) = stored position p is hit by some query.
+// `a` must be the POSITION view of the structure (gtars_index::accel_pos()).
+gtars_status launch_mark_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min, i32 min_overlap,
+                             u32 *mark, hipStream_t st) {
+    if (nq == 0) return GTARS_OK;
+    constexpr int TPB = 1024;
+    const size_t lds = tok_lds_bytes(a);
+    const bool filter = has_min && min_overlap > 1;
+    const i32 min_bp = has_min ? min_overlap : 0;
+    auto kern = filter ? k_count_lds<TPB, true, false, true> : k_count_lds<TPB, false, false, true>;
+    static KernelSetup setup[2];
+    int dev = 0, cus = 256;
+    gtars_status s0 = setup[filter ? 1 : 0].get(reinterpret_cast<const void *>(kern), dev, cus);
+    if (s0) return s0;
+    const u64 tiles = (nq + (u64)TPB * 4 - 1) / ((u64)TPB * 4);
+    const unsigned grid = (unsigned)std::min<u64>(tiles, (u64)cus);
+    ProfScope p("k_mark_lds", st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, st, a, qc, qs, qe, nq, min_bp, (u32 *)nullptr, (u8 *)nullptr, mark);
     GT_HIP(hipGetLastError());
     return GTARS_OK;
 }

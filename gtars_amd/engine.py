@@ -168,7 +168,32 @@ class OverlapIndex:
                                              C.byref(p), C.byref(n)))
         return offsets, take_u32(p, n.value)
 
+    def subset_by_overlaps(self, qc, qs, qe, min_overlap: Optional[int] = None):
+        """MultiChromOverlapper::subset_by_overlaps (multi_chrom_overlapper.rs:454-478): the index's intervals hit by any query
+        -> (chrom ids, starts, ends), de-duplicated, sorted by (chrom id, start, end)."""
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        pc, ps, pe, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        hm, mo = _minargs(min_overlap)
+        check(lib.gtars_subset_by_overlaps(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), hm, mo, C.byref(pc), C.byref(ps),
+                                           C.byref(pe), C.byref(n)))
+        return take_u32(pc, n.value), take_u32(ps, n.value), take_u32(pe, n.value)
+
+    def subset_source_indices(self, qc, qs, qe, min_overlap: Optional[int] = None) -> np.ndarray:
+        """IndexedRegionSet::subset_by_overlaps / intersect_all (indexed_region_set.rs:201-230): the source rows (vals) hit
+        by any query, ascending and unique."""
+        qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
+        p, n = C.c_void_p(), C.c_uint64()
+        hm, mo = _minargs(min_overlap)
+        check(lib.gtars_subset_source_indices(self._h, ptr(qc), ptr(qs), ptr(qe), len(qc), hm, mo, C.byref(p), C.byref(n)))
+        return take_u32(p, n.value)
+
     # -- device-pointer queries --------------------------------------------------
+    def mark_overlapped_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_mark: int, min_overlap: Optional[int] = None,
+                               stream: int = 0):
+        """bit p of d_mark (ceil(len / 32) u32 words) = the interval at stored position p is hit by some query"""
+        hm, mo = _minargs(min_overlap)
+        check(lib.gtars_mark_overlapped_device(self._h, d_qc, d_qs, d_qe, nq, hm, mo, d_mark, stream))
+
     def tokenize_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_offsets: int, d_ids: int,
                         ids_capacity: int, stream: int = 0, sync: bool = True) -> Optional[int]:
         """Single fused pass on device buffers.  Returns H when ``sync`` (else None)."""

@@ -211,15 +211,33 @@ class ShardedIgd:
     mode "bucket": rank r holds the intervals of the chromosomes ``owner == r`` (LPT over Ndb_c + Nq_c when query
     chromosome columns are passed as ``balance_with``); mode "range": every rank holds the whole database."""
 
-    def __init__(self, engine, db: Dict[str, np.ndarray], n_chrom: int, n_files: int, mode: str = "bucket",
+    def __init__(self, engine, db, n_chrom: int, n_files: int, mode: str = "bucket",
                  balance_with: Sequence[np.ndarray] = (), group=None):
+        """``db``: the database columns (dict of chrom / start / end / file arrays), or a callable returning a fresh
+        iterator over row CHUNKS of it (dicts of the same columns; e.g. one chunk per BED file of a LOLA folder, or
+        ``synth.igd_db_chunks``).  With chunks a bucket-mode rank keeps only the rows of the chromosomes it owns: it never
+        materialises the others' (two passes over the source: chromosome weights, then its rows)."""
         if mode not in ("bucket", "range"):
             raise ValueError("mode must be 'bucket' or 'range'")
         self.engine, self.mode, self.group = engine, mode, group
         self.n_chrom, self.n_files = n_chrom, n_files
         self.rank, self.world = _rank_world(group)
         self.owner: Optional[np.ndarray] = None
-        if mode == "bucket" and self.world > 1:
+        cols = ("chrom", "start", "end", "file")
+        bucket = mode == "bucket" and self.world > 1
+        if callable(db):
+            if bucket:
+                w = chrom_weights(n_chrom, *balance_with)
+                for ch in db():
+                    w += chrom_weights(n_chrom, ch["chrom"])
+                self.owner = chrom_buckets(w, self.world)
+            parts = {k: [] for k in cols}
+            for ch in db():
+                keep = _select_owned(self.owner, self.rank, ch["chrom"]) if bucket else slice(None)
+                for k in cols:
+                    parts[k].append(np.ascontiguousarray(ch[k][keep]))
+            db = {k: (np.concatenate(v) if v else np.zeros(0, dtype=np.uint32)) for k, v in parts.items()}
+        elif bucket:
             self.owner = chrom_buckets(chrom_weights(n_chrom, db["chrom"], *balance_with), self.world)
             keep = _select_owned(self.owner, self.rank, db["chrom"])
             db = {k: np.ascontiguousarray(v[keep]) for k, v in db.items()}

@@ -120,20 +120,30 @@ def make_queries(universe: Dict[str, np.ndarray], n_queries: int = 1_000_000, se
     }
 
 
-def make_igd_db(n_intervals: int, n_files: int, seed: int = 6) -> Dict[str, np.ndarray]:
-    """C3 database: ChIP-like widths 200+U[0,800), hg38-shaped, file uniform."""
+def make_igd_db(n_intervals: int, n_files: int, seed: int = 6, offset: int = 0) -> Dict[str, np.ndarray]:
+    """C3 database: ChIP-like widths 200+U[0,800), hg38-shaped, file uniform.  ``offset``: rows offset .. offset+n-1 of
+    the same database (the streams are counter-based, so a database can be produced in pieces)."""
     total = int(CHROM_SIZES.sum())
-    g = _uniform(seed, n_intervals, total)
+    g = _uniform(seed, n_intervals, total, offset)
     cum = np.cumsum(CHROM_SIZES)
     chrom = np.searchsorted(cum, g, side="right")
     start = g - (cum[chrom] - CHROM_SIZES[chrom])
-    width = 200 + _uniform(seed + 1, n_intervals, 800)
+    width = 200 + _uniform(seed + 1, n_intervals, 800, offset)
     return {
         "chrom": chrom.astype(np.uint32),
         "start": start.astype(np.int32),
         "end": (start + width).astype(np.int32),
-        "file": _uniform(seed + 2, n_intervals, n_files).astype(np.uint32),
+        "file": _uniform(seed + 2, n_intervals, n_files, offset).astype(np.uint32),
     }
+
+
+def igd_db_chunks(n_intervals: int, n_files: int, seed: int = 6, chunk: int = 4_000_000):
+    """make_igd_db(n_intervals, ...) as a sequence of row chunks (concatenated: the same database, same order): what a
+    rank that owns a few chromosomes ingests without ever holding the other chromosomes' rows (sharding.ShardedIgd)."""
+    def chunks():
+        for lo in range(0, n_intervals, chunk):
+            yield make_igd_db(min(chunk, n_intervals - lo), n_files, seed, lo)
+    return chunks
 
 
 def make_background_queries(n_queries: int, seed: int = 7) -> Dict[str, np.ndarray]:
@@ -152,3 +162,37 @@ def make_single_chrom(n: int, seed: int) -> Tuple[np.ndarray, np.ndarray, np.nda
     s = _uniform(seed, n, 1_000_000)
     w = 50 + _uniform(seed + 1, n, 451)
     return np.zeros(n, dtype=np.uint32), s.astype(np.uint32), (s + w).astype(np.uint32)
+
+
+def write_config5_inputs(tmp: str, universe: Dict[str, np.ndarray], files: int, frags: int, clusters: int = 20):
+    """BASELINE config 5 inputs under ``tmp``: ``universe.bed``, ``frags/sample<k>.bed.gz`` (``frags`` position-sorted
+    fragments and 200 barcodes each, gzip level 1) and ``map.tsv`` (80 % of the barcodes mapped to ``clusters`` clusters:
+    the rest stands for cells dropped in QC).  -> (universe path, fragment dir, map path, compressed bytes)."""
+    import gzip
+    import os
+
+    names = CHROM_NAMES
+    ub = os.path.join(tmp, "universe.bed")
+    with open(ub, "w") as fh:
+        fh.write("".join(f"{names[c]}\t{s}\t{e}\n" for c, s, e in zip(universe["chrom"], universe["start"], universe["end"])))
+    fd = os.path.join(tmp, "frags")
+    os.mkdir(fd)
+    name_arr = np.array(names + ["chrUn_synthetic"])
+    map_lines, total_bytes = [], 0
+    for k in range(files):
+        q = make_queries(universe, frags, seed=5000 + k)
+        order = np.lexsort((q["start"], q["chrom"]))
+        bc = np.random.default_rng(k).integers(0, 200, frags)
+        c = np.minimum(q["chrom"][order], len(names))
+        cols = [name_arr[c], q["start"][order].astype(str), q["end"][order].astype(str),
+                np.char.add("BC", np.char.zfill(bc.astype(str), 5)), np.full(frags, "1")]
+        text = "\n".join("\t".join(r) for r in zip(*cols)) + "\n"
+        data = gzip.compress(text.encode(), compresslevel=1)
+        total_bytes += len(data)
+        with open(os.path.join(fd, f"sample{k:05d}.bed.gz"), "wb") as fh:
+            fh.write(data)
+        map_lines += [f"sample{k:05d}+BC{b:05d}\tcl{(k + b) % clusters}" for b in range(160)]
+    mp = os.path.join(tmp, "map.tsv")
+    with open(mp, "w") as fh:
+        fh.write("\n".join(map_lines) + "\n")
+    return ub, fd, mp, total_bytes

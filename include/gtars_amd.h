@@ -208,6 +208,34 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
                                         uint64_t *offsets, uint32_t **out_idx,
                                         uint64_t *out_n);
 
+/* Index-side subset (the index's own intervals that are hit by ANY query):
+ *   MultiChromOverlapper::subset_by / subset_by_overlaps / intersect_all
+ *       gtars-overlaprs/src/multi_chrom_overlapper.rs:449-478, 554-556
+ *   IndexedRegionSet::intersect_all / subset_by_overlaps
+ *       gtars-overlaprs/src/indexed_region_set.rs:201-230
+ * One pass over the batch marks the hit stored positions in a bitmap (no hit list is materialised), the bitmap is
+ * compacted.  min_overlap filters only when has_min && min_overlap > 1, as in the reference.
+ *
+ * gtars_subset_by_overlaps: the de-duplicated (chrom id, start, end) triples, sorted by (chrom id, start, end) -- the
+ * reference's BTreeSet<(String, u32, u32)> orders chromosomes by NAME: a caller whose ids are not in name order
+ * permutes the chromosome runs (the Python layer does).
+ * gtars_subset_source_indices: the vals of the hit intervals, ascending and unique -- for an index built with
+ * val == NULL these are the source rows, i.e. IndexedRegionSet's result in source order. */
+gtars_status gtars_subset_by_overlaps(const gtars_index_t *ix, const uint32_t *qchrom, const uint32_t *qstart,
+                                      const uint32_t *qend, uint64_t nq, int has_min, int32_t min_overlap,
+                                      uint32_t **out_chrom, uint32_t **out_start, uint32_t **out_end,
+                                      uint64_t *out_n);
+gtars_status gtars_subset_source_indices(const gtars_index_t *ix, const uint32_t *qchrom, const uint32_t *qstart,
+                                         const uint32_t *qend, uint64_t nq, int has_min, int32_t min_overlap,
+                                         uint32_t **out_idx, uint64_t *out_n);
+/* Device form of the marking pass: bit p of d_mark (ceil(gtars_index_len / 32) u32 words, zeroed by this call on
+ * `stream`) is set iff the interval at STORED position p (gtars_index_stored order, chromosomes concatenated) is hit
+ * by some query.  Asynchronous.  GTARS_ERR_INVALID_ARG for an index without the blocked structure (nested AIList
+ * sub-lists, > 4M blocks): use the host-pointer forms above, which fall back to the generic kernels. */
+gtars_status gtars_mark_overlapped_device(const gtars_index_t *ix, const uint32_t *d_qchrom, const uint32_t *d_qstart,
+                                          const uint32_t *d_qend, uint64_t nq, int has_min, int32_t min_overlap,
+                                          uint32_t *d_mark, void *stream);
+
 /* ------------------------------------------------------------------------
  * IGD: multi-file interval database, per-file hit counting.
  * Replaces gtars-igd/src/igd.rs: Igd::add (:109-153), finalize (:157-167),

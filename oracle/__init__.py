@@ -54,6 +54,7 @@ def build(force: bool = False) -> str:
 _lib = None
 
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
@@ -93,6 +94,7 @@ def lib():
     L.orc_igd_new.argtypes = [i32]
     L.orc_igd_free.argtypes = [vp]
     L.orc_igd_add.argtypes = [vp, u32, i32, i32, i32, u32]
+    L.orc_igd_add_arrays.argtypes = [vp, _u32p, _i32p, _i32p, _i32p, _u32p, u64]
     L.orc_igd_finalize.argtypes = [vp]
     L.orc_igd_total_records.restype = u64
     L.orc_igd_total_records.argtypes = [vp]
@@ -228,6 +230,29 @@ class Index:
         return offsets, out[:h]
 
 
+def mco_subset_by_overlaps(ix: "Index", qc, qs, qe, min_overlap: Optional[int] = None):
+    """MultiChromOverlapper::subset_by_overlaps (gtars-overlaprs/src/multi_chrom_overlapper.rs:454-478): every hit of every
+    query region (find_overlaps_for_region, filtered only when min_bp > 1) goes into a BTreeSet of (chr, start, end); the set
+    comes back sorted and de-duplicated.  Chromosomes are integer ids here, so "sorted by chr" is by id (the string order of
+    the reference is a relabelling the host layer applies).  -> (chrom, start, end) u32 arrays."""
+    qc = _u32(qc)
+    off, s, e, _ = ix.find_overlaps_regions(qc, qs, qe, min_overlap)
+    counts = np.diff(off.astype(np.int64))
+    c = np.repeat(qc, counts)
+    if len(c) == 0:
+        z = np.zeros(0, dtype=np.uint32)
+        return z, z.copy(), z.copy()
+    rows = np.unique(np.stack([c.astype(np.uint64), s.astype(np.uint64), e.astype(np.uint64)], axis=1), axis=0)
+    return rows[:, 0].astype(np.uint32), rows[:, 1].astype(np.uint32), rows[:, 2].astype(np.uint32)
+
+
+def irs_subset_by_overlaps(ix: "Index", src_chrom, src_start, src_end, qc, qs, qe, min_overlap: Optional[int] = None) -> np.ndarray:
+    """IndexedRegionSet::subset_by_overlaps / intersect_all (gtars-overlaprs/src/indexed_region_set.rs:201-230): the union of
+    find_overlaps' per-query source indices in a BTreeSet<usize> -> ascending unique source rows."""
+    _, idx = ix.irs_find_overlaps(src_chrom, src_start, src_end, qc, qs, qe, min_overlap)
+    return np.unique(np.asarray(idx, dtype=np.uint64)).astype(np.uint32)
+
+
 class Igd:
     """Igd over integer chromosome ids (gtars-igd/src/igd.rs)."""
 
@@ -248,11 +273,13 @@ class Igd:
         self.n_files = max(self.n_files, file_idx + 1)
 
     def add_arrays(self, chrom, start, end, value, file_idx):
-        L = lib()
-        for c, s, e, v, f in zip(chrom, start, end, value, file_idx):
-            L.orc_igd_add(self._h, int(c), int(s), int(e), int(v), int(f))
-        if len(file_idx):
-            self.n_files = max(self.n_files, int(max(file_idx)) + 1)
+        """Igd::add for every row, in array order (one C loop over orc_igd_add)"""
+        n = len(chrom)
+        c, f = _u32(chrom), _u32(file_idx)
+        s, e, v = (np.ascontiguousarray(np.asarray(x).astype(np.int32, copy=False)) for x in (start, end, value))
+        lib().orc_igd_add_arrays(self._h, c, s, e, v, f, n)
+        if n:
+            self.n_files = max(self.n_files, int(f.max()) + 1)
 
     def finalize(self):
         lib().orc_igd_finalize(self._h)

@@ -680,6 +680,12 @@ void orc_igd_add(orc_igd *g, uint32_t chrom, int32_t start, int32_t end,
     }
 }
 
+/* n calls of orc_igd_add in array order (batch form for the Python binding: same insertion order, same rules) */
+void orc_igd_add_arrays(orc_igd *g, const uint32_t *chrom, const int32_t *start, const int32_t *end,
+                        const int32_t *value, const uint32_t *file_idx, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) orc_igd_add(g, chrom[i], start[i], end[i], value[i], file_idx[i]);
+}
+
 static void rec_msort(rec_t *a, rec_t *tmp, size_t n) {
     if (n < 2) return;
     size_t h = n / 2;

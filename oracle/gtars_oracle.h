@@ -106,6 +106,10 @@ void orc_igd_free(orc_igd *g);
 /* Igd::add (igd.rs:109-153) */
 void orc_igd_add(orc_igd *g, uint32_t chrom, int32_t start, int32_t end,
                  int32_t value, uint32_t file_idx);
+/* n x orc_igd_add, in array order */
+void orc_igd_add_arrays(orc_igd *g, const uint32_t *chrom, const int32_t *start,
+                        const int32_t *end, const int32_t *value,
+                        const uint32_t *file_idx, uint64_t n);
 /* Igd::finalize (igd.rs:157-167) */
 void orc_igd_finalize(orc_igd *g);
 uint64_t orc_igd_total_records(const orc_igd *g); /* igd.rs:736-742 */

@@ -714,6 +714,60 @@ def test_bench_py_two_ranks_on_one_gpu():
     assert out["with_allgather"]["value"] > 0 and out["timing"]["repetitions"] >= 11
 
 
+def test_bench_py_launches_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (how the driver starts --gpus 1; no launcher, no WORLD_SIZE): the parent starts the two
+    ranks itself.  gloo backend so that both ranks may share this box's one GPU; the chromosome-bucket objects run at 1/100 of
+    the configs' sizes and their totals are checked against the oracle here."""
+    import json
+    import subprocess
+    import sys
+
+    import oracle
+    from gtars_amd import synth
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GTARS_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--queries", "200000",
+           "--batches", "3", "--min-seconds", "0.01", "--no-cpu-baseline", "--scale-configs", "100"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["backend"] == "gloo"
+    assert sorted(x["rank"] for x in out["ranks"]) == [0, 1] and len({x["pid"] for x in out["ranks"]}) == 2
+    assert out["verified"]
+    # config 3 at 1/100: the sharded totals against the oracle on the same synthetic data
+    ndb, nq, F = 500_000, 100_000, 1000
+    db, q = synth.make_igd_db(ndb, F), synth.make_background_queries(nq)
+    og = oracle.Igd()
+    og.add_arrays(db["chrom"], db["start"], db["end"], np.arange(ndb, dtype=np.int32), db["file"])
+    og.finalize()
+    s3 = out["igd_config3_sharded"]
+    assert s3["db_intervals"] == ndb and s3["queries"] == nq and sum(x["db_intervals"] for x in s3["per_rank"]) == ndb
+    assert all(0 < x["db_intervals"] < ndb for x in s3["per_rank"])  # the database is cut, not replicated
+    assert s3["pairwise"]["total_hits"] == int(og.count_set_overlaps(q["chrom"], q["start"], q["end"], 1, n_files=F).sum())
+    assert s3["binary"]["total_hits"] == int(og.count_region_hits(q["chrom"], q["start"], q["end"], 1, n_files=F).sum())
+    # config 4 at 1/100: support sum against the oracle
+    s4 = out["lola_config4_sharded"]
+    n_sets, per = 2000, 250
+    db = synth.make_igd_db(n_sets * per, n_sets, seed=6)
+    uni = synth.make_universe(10_000, seed=3)
+    sel = np.sort(np.random.default_rng(9).choice(len(uni["chrom"]), 1000, replace=False))
+    og = oracle.Igd()
+    og.add_arrays(db["chrom"], db["start"], db["end"], np.arange(n_sets * per, dtype=np.int32), db["file"])
+    og.finalize()
+    sup = og.count_region_hits(uni["chrom"][sel], uni["start"][sel], uni["end"][sel], 1, n_files=n_sets)
+    assert s4["support_sum"] == int(sup.sum()) and s4["user"] == 1000
+    # fewer devices than ranks under nccl: refused before anything runs
+    env["GTARS_BENCH_BACKEND"] = "nccl"
+    import torch
+
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible devices" in r.stderr
+
+
 # ------------------------------------------------------------ CLI text front ends (python -m gtars_amd overlaprs / igd)
 
 

@@ -223,6 +223,54 @@ def test_irs_find_overlap_indices_random(ga, kind):
         assert ig.tolist() == io.tolist()
 
 
+@pytest.mark.parametrize("kind", BOTH)
+def test_index_side_subset_kats_and_random(ga, kind, monkeypatch):
+    """MultiChromOverlapper::subset_by_overlaps / intersect_all (multi_chrom_overlapper.rs:454-478, KAT :1044-1066) and
+    IndexedRegionSet::intersect_all / subset_by_overlaps (indexed_region_set.rs:201-230, KAT :395-414) behind the C ABI:
+    one bitmap-marking pass over the batch + compaction, against the oracle's BTreeSet restatement."""
+    g, o = _pair(ga, [0, 0, 1], [100, 300, 500], [200, 400, 600], n_chrom=2, kind=kind)
+    q = ([0, 1], [150, 550], [250, 650])
+    assert [x.tolist() for x in g.subset_by_overlaps(*q)] == [[0, 1], [100, 500], [200, 600]]
+    assert g.subset_source_indices(*q).tolist() == [0, 2]
+    assert [len(x) for x in g.subset_by_overlaps([], [], [])] == [0, 0, 0] and len(g.subset_source_indices([], [], [])) == 0
+    e0 = ga.OverlapIndex([], [], [], None, n_chrom=1, kind=kind)
+    assert len(e0.subset_by_overlaps([0], [100], [200])[0]) == 0 and len(e0.subset_source_indices([0], [100], [200])) == 0
+    rng = np.random.default_rng(77)
+    for n, nq, span, dup in ((3000, 4000, 8000, 0.3), (40_000, 30_000, 3_000_000, 0.0), (500, 200_000, 2_000_000, 0.1)):
+        c, s, e, qc, qs, qe = _random_case(rng, n, nq, 4, span, 300, dup_frac=dup)
+        g = ga.OverlapIndex(c, s, e, None, n_chrom=4, kind=kind)
+        o = oracle.Index(c, s, e, None, n_chrom=4, kind=kind)
+        for forced_generic in (False, True):
+            if forced_generic:
+                monkeypatch.setenv("GTARS_NO_LDS_PATH_FOR_TEST", "1")
+            for mo in (None, 1, 4, 40):
+                got = g.subset_by_overlaps(qc, qs, qe, mo)
+                exp = oracle.mco_subset_by_overlaps(o, qc, qs, qe, mo)
+                assert all(a.tolist() == b.tolist() for a, b in zip(got, exp)), (n, mo)
+                assert g.subset_source_indices(qc, qs, qe, mo).tolist() == oracle.irs_subset_by_overlaps(o, c, s, e, qc, qs, qe, mo).tolist()
+        monkeypatch.delenv("GTARS_NO_LDS_PATH_FOR_TEST")
+    # the device form: bit p <=> stored position p is hit
+    import torch
+
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint32).view(np.int32)).to(dev) for x in (qc, qs, qe)]
+    if kind == KIND_BITS:
+        mark = torch.full(((len(c) + 31) // 32,), -1, dtype=torch.int32, device=dev)  # the call zeroes it
+        g.mark_overlapped_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(qc), mark.data_ptr(), None,
+                                 torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        bits = np.unpackbits(mark.cpu().numpy().view(np.uint8), bitorder="little")[: len(c)].astype(bool)
+        got = []
+        base = 0
+        for ch in range(4):
+            ss, ee, _ = g.stored(ch)
+            sel = bits[base : base + len(ss)]
+            got += [(ch, int(a), int(b)) for a, b in zip(ss[sel], ee[sel])]
+            base += len(ss)
+        exp = oracle.mco_subset_by_overlaps(o, qc, qs, qe)
+        assert sorted(set(got)) == list(zip(*[x.tolist() for x in exp]))
+
+
 def test_config1_1k_by_1k(ga):
     # BASELINE config 1: 1k x 1k single chromosome (SURVEY 8d C1)
     from gtars_amd import synth

@@ -218,6 +218,35 @@ def test_irs_duplicate_coordinates_return_all_rows():
     assert _split(off, idx) == [[0, 1, 3]]
 
 
+def test_index_side_subset_kats():
+    """multi_chrom_overlapper.rs:1044-1066 (test_intersect_all, both overlapper types), :1131-1157 (empty query / index),
+    indexed_region_set.rs:395-414 (test_intersect_all -> source rows 0 and 2) and :497-517."""
+    src = [(0, 100, 200), (0, 300, 400), (1, 500, 600)]
+    q = ([0, 1], [150, 550], [250, 650])
+    for kind in (oracle.KIND_BITS, oracle.KIND_AILIST):
+        c, s, e = zip(*src)
+        ix = oracle.Index(c, s, e, None, n_chrom=2, kind=kind)
+        oc, os_, oe = oracle.mco_subset_by_overlaps(ix, *q)
+        assert list(zip(oc.tolist(), os_.tolist(), oe.tolist())) == [(0, 100, 200), (1, 500, 600)]
+        assert oracle.irs_subset_by_overlaps(ix, c, s, e, *q).tolist() == [0, 2]
+        assert len(oracle.mco_subset_by_overlaps(ix, [], [], [])[0]) == 0
+        assert len(oracle.irs_subset_by_overlaps(ix, c, s, e, [], [], [])) == 0
+    empty = oracle.Index([], [], [], None, n_chrom=1)
+    assert len(oracle.mco_subset_by_overlaps(empty, [0], [100], [200])[0]) == 0
+    # de-duplication (BTreeSet): the same interval hit by two queries, and two source rows with the same coordinates
+    src = [(0, 100, 200), (0, 100, 200), (0, 150, 400)]
+    c, s, e = zip(*src)
+    ix = oracle.Index(c, s, e, None, n_chrom=1)
+    oc, os_, oe = oracle.mco_subset_by_overlaps(ix, [0, 0], [120, 160], [130, 170])
+    assert list(zip(os_.tolist(), oe.tolist())) == [(100, 200), (150, 400)]
+    assert oracle.irs_subset_by_overlaps(ix, c, s, e, [0, 0], [120, 160], [130, 170]).tolist() == [0, 1, 2]
+    # min_overlap filters only when > 1 (multi_chrom_overlapper.rs:461-465)
+    oc, os_, oe = oracle.mco_subset_by_overlaps(ix, [0], [190], [260], 20)
+    assert list(zip(os_.tolist(), oe.tolist())) == [(150, 400)]
+    oc, os_, oe = oracle.mco_subset_by_overlaps(ix, [0], [190], [260], 1)
+    assert list(zip(os_.tolist(), oe.tolist())) == [(100, 200), (150, 400)]
+
+
 # ------------------------------------------------------------------- Tokenizer
 
 

@@ -19,35 +19,11 @@ from gtars_amd.tokenizers import Tokenizer, tokenize_fragment_files
 
 def main():
     K = int(os.environ.get("FILES", "1000")); n = int(os.environ.get("FRAGS", "10000")); ncl = int(os.environ.get("CLUSTERS", "20"))
-    names = synth.CHROM_NAMES
     tmp = tempfile.mkdtemp(prefix="gtars_fragsplit_")
     try:
         u = synth.make_universe(100_000)
-        ub = os.path.join(tmp, "universe.bed")
-        with open(ub, "w") as fh:
-            fh.write("".join(f"{names[c]}\t{s}\t{e}\n" for c, s, e in zip(u["chrom"], u["start"], u["end"])))
-        fd = os.path.join(tmp, "frags")
-        os.mkdir(fd)
         t = time.time()
-        map_lines = []
-        name_arr = np.array(names + ["chrUn_synthetic"])
-        total_bytes = 0
-        for k in range(K):
-            q = synth.make_queries(u, n, seed=5000 + k)
-            order = np.lexsort((q["start"], q["chrom"]))
-            rng = np.random.default_rng(k)
-            bc = rng.integers(0, 200, n)
-            c = np.minimum(q["chrom"][order], len(names))
-            cols = [name_arr[c], q["start"][order].astype(str), q["end"][order].astype(str), np.char.add("BC", np.char.zfill(bc.astype(str), 5)),
-                    np.full(n, "1")]
-            text = "\n".join("\t".join(r) for r in zip(*cols)) + "\n"
-            data = gzip.compress(text.encode(), compresslevel=1)
-            total_bytes += len(data)
-            with open(os.path.join(fd, f"sample{k:05d}.bed.gz"), "wb") as fh:
-                fh.write(data)
-            map_lines += [f"sample{k:05d}+BC{b:05d}\tcl{(k + b) % ncl}" for b in range(160)]
-        mp = os.path.join(tmp, "map.tsv")
-        open(mp, "w").write("\n".join(map_lines) + "\n")
+        ub, fd, mp, total_bytes = synth.write_config5_inputs(tmp, u, K, n, ncl)
         t_gen = time.time() - t
         tok = Tokenizer.from_bed(ub)
         m = BarcodeToClusterMap.from_file(mp)
