@@ -26,12 +26,55 @@
 namespace gtars {
 
 #ifndef GTARS_IGD_ABLATE
-#define GTARS_IGD_ABLATE 0  // timing experiments (results wrong): 1 one record per query, 2 no histogram atomics, 4 no prefix-max scan
+#define GTARS_IGD_ABLATE 0  // timing experiments (results wrong): 1 one record per query, 2 no histogram atomics, 4 no prefix-max scan, 8 no queries, 16 no searches
 #endif
 constexpr int IGD_TILE = (int)IGD_TILE_RECORDS;
 constexpr int SW_TPB = 512;
 
 constexpr int IGD_HALO = 256;
+#ifndef IGD_STAMPS
+#define IGD_STAMPS 0  // diagnostic build: per-phase shader-clock totals of wave 0 of every workgroup (tools/r03_sweep_stamps.py)
+#endif
+#if IGD_STAMPS
+__device__ unsigned long long g_sweep_stamps[8];
+#define STAMP(k)                                                  \
+    do {                                                          \
+        const u64 _t = __builtin_amdgcn_s_memtime();              \
+        st_acc[k] += _t - st_last;                                \
+        st_last = _t;                                             \
+    } while (0)
+#else
+#define STAMP(k) \
+    do {         \
+    } while (0)
+#endif
+constexpr int LUT_NB = 512;  // buckets of the per-tile search tables
+// smallest shift with (span >> shift) < LUT_NB
+__device__ __forceinline__ u32 lut_shift(u32 span) {
+    const int bits = 32 - __clz((int)(span | 1u));  // significant bits of span
+    return bits > 9 ? (u32)(bits - 9) : 0u;
+}
+// first index i in [0, n) with key[i] >= x, through the table: the answer lies in [lut[b], lut[b + 1]] for b = bucket(x)
+__device__ __forceinline__ void lut_range(const unsigned short *lut, i32 x, i32 k0, i32 k1, u32 sh, u32 n, u32 &l, u32 &h) {
+    if (x <= k0) {
+        l = h = 0;
+    } else if (x > k1) {
+        l = h = n;
+    } else {
+        const u32 b = (u32)(x - k0) >> sh;
+        l = lut[b];
+        h = lut[b + 1];
+    }
+}
+#ifndef IGD_PAIR_UNROLL
+#define IGD_PAIR_UNROLL 1  // queries of a lane group whose candidate reads are in flight together
+#endif
+#ifndef IGD_PREFETCH
+#define IGD_PREFETCH 1  // next tile's records loaded into registers before the current tile's queries are served
+#endif
+#ifndef IGD_GROUP_LANES
+#define IGD_GROUP_LANES 8  // lanes that walk one query's candidate records together (pair loop of the sweep)
+#endif
 constexpr int IGD_SEEN = 32;   // per-thread list of credited files (binary counting)  // records after the tile kept in LDS too (a query's scan may run past its tile)
 
 // ---- query preparation: validity rules of Igd::count_overlaps (igd.rs:514-517) ------------------
@@ -194,14 +237,28 @@ __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first,
 // "ends after q.start" is all that is left of the overlap test, and the largest such end is a per-record constant of
 // the database (IgdTiles::pme_file).  Binary counting then costs what pairwise counting costs (2.3 -> 0.5 ms for
 // config 3) instead of a 32-entry membership test per hit.
-template <int MODE>
-__global__ void __launch_bounds__(SW_TPB)
+// Query k of a block of SW_TPB goes to wave k % NWV, group (k / NWV) % NG, slot k / (NWV * NG): the first 64 queries of a tile
+// land on 64 different (wave, group) pairs, so a sparse batch (a LOLA universe: ~40 queries per tile) still spreads over every
+// wave, and a dense one gives every group the same number of queries.
+__device__ __forceinline__ u32 sweep_query_slot(int lane, int wave) {
+    constexpr int GL = IGD_GROUP_LANES, NG = 64 / GL, NWV = SW_TPB / 64;
+#ifdef IGD_MAP_COALESCED
+    return (u32)wave * 64u + (u32)lane;
+#else
+    return ((u32)(lane % GL) * NG + (u32)(lane / GL)) * NWV + (u32)wave;
+#endif
+}
+
+// register budget = what the LDS footprint admits anyway: 4 workgroups per CU (8 waves per SIMD, 64 VGPRs) for the pairwise
+// form, 3 (80 VGPRs) with the staged pme_file column; the credited-file-list form keeps its 16 list registers
+template <int MODE, bool MO1>
+__global__ void __launch_bounds__(SW_TPB, MODE == 0 ? 8 : MODE == 2 ? 6 : 4)
 k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
             const u32 *__restrict__ tile_chrom, const i32 *__restrict__ tile_carry, u32 n_tiles,
             const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap,
             unsigned long long *__restrict__ hits, const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab,
-            const u32 *__restrict__ part_ql, u32 cq) {
+            const u32 *__restrict__ part_ql) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
     // whether the batch had to be partitioned was decided on the device (k_igd_prep_queries): take the partition's
     // interleaved (start, end) pairs and bin offsets, or the batch as it arrived with the tile ranges
@@ -222,15 +279,9 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
     i32 *t_pm = reinterpret_cast<i32 *>(t_f + CAP);  // prefix maximum of the ends (carry-in included); CAP is even
     i32 *t_pf = t_pm + CAP;                           // MODE 2: pme_file of the staged records
     u32 *bins = reinterpret_cast<u32 *>(t_pf + (MODE == 2 ? CAP : 0));  // [n_files]
-    // MODE 0 / 2 (a hit is decided by the (query, record) pair alone): the queries of a chunk with their record
-    // ranges, so that the PAIRS can be dealt evenly to the threads
-    // chunk arrays (cq = 128 / 256 / 512 queries per chunk, chosen by the launcher from the batch's queries per tile: sparse
-    // batches -- a LOLA universe against a large database -- need few, and the LDS saved is a workgroup more per CU)
-    u32 *c_off = bins + ((v.n_files + 1u) & ~1u);                   // [cq + 1] (+1 pad)
-    i32 *c_s = reinterpret_cast<i32 *>(c_off + cq + 2), *c_e = c_s + cq;
-    unsigned short *c_lo = reinterpret_cast<unsigned short *>(c_e + cq);  // [cq], values < CAP
-    __shared__ u32 s_part[SW_TPB / 64];
     __shared__ i32 s_wmax[SW_TPB / 64];
+    __shared__ unsigned short lut_s[LUT_NB + 2], lut_p[LUT_NB + 2];
+    __shared__ i32 s_lutdesc[6];
     for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
 
     // Software pipeline over the workgroup's tiles: the NEXT tile's records are loaded into registers
@@ -284,8 +335,29 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
         __syncthreads();  // bins zeroed
         commit(cur);
     }
+#if IGD_STAMPS
+    u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // the tile's first SW_TPB queries: loaded now, used after the scan and the table build (MODE 0 / 2)
+        const u32 q_lo = ql[tile], q_hi = (GTARS_IGD_ABLATE & 8) ? q_lo : qh[tile];
+        i32 pf_s = 0, pf_e = 0;
+        if constexpr (MODE != 1) {
+            const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+            const u32 qi = q_lo + sweep_query_slot(lane_, wave_);
+            if (qi < q_hi) {
+                if (interleaved) {
+                    const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
+                    pf_s = (i32)se2.x;
+                    pf_e = (i32)se2.y;
+                } else {
+                    pf_s = (i32)sqs[qi];
+                    pf_e = (i32)sqe[qi];
+                }
+            }
+        }
         __syncthreads();  // the current tile is in LDS
+        STAMP(0);
         {
             // t_pm[i] = max(carry, ends[0..i]): ascending, so "first record that can overlap a query" is a
             // binary search for t_pm > q_start.  Blocked layout: thread t owns records [t*RPT, (t+1)*RPT).
@@ -304,21 +376,69 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
             if (lane == 63) s_wmax[wave] = inc;
             const i32 excl = __builtin_amdgcn_update_dpp(0, inc, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 gets 0
             __syncthreads();
-            i32 before = cur.carry;
-            for (int w = 0; w < wave; ++w) before = max(before, s_wmax[w]);
+            i32 before = cur.carry, all_max = cur.carry;
+#pragma unroll
+            for (int w = 0; w < SW_TPB / 64; ++w) {
+                const i32 x = s_wmax[w];
+                before = max(before, w < wave ? x : 0);
+                all_max = max(all_max, x);
+            }
             before = max(before, excl);
+            // Direct-mapped tables over the tile's two ascending key arrays (starts, prefix-max ends): lut[b] = first record
+            // whose key falls in bucket >= b, bucket(x) = (x - first key) >> shift with shift chosen so that the last key lands
+            // in a bucket < LUT_NB.  A query's two binary searches then start from a range of a handful of records instead of
+            // the whole tile: 2 + ~3 dependent LDS round trips instead of 12 (the searches were 0.19 of the sweep's 0.41 ms).
+            const u32 n = cur.n_lds;
+            const i32 S0 = __builtin_amdgcn_readfirstlane(t_s[0]), S1 = __builtin_amdgcn_readfirstlane(t_s[n - 1]);
+            const i32 P0 = __builtin_amdgcn_readfirstlane(max(cur.carry, t_e[0])), P1 = __builtin_amdgcn_readfirstlane(all_max);
+            const u32 sh_s = lut_shift((u32)(S1 - S0)), sh_p = lut_shift((u32)(P1 - P0));
+            if (threadIdx.x == 0) {
+                s_lutdesc[0] = S0;
+                s_lutdesc[1] = S1;
+                s_lutdesc[2] = (i32)sh_s;
+                s_lutdesc[3] = P0;
+                s_lutdesc[4] = P1;
+                s_lutdesc[5] = (i32)sh_p;
+            }
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const u32 i = base + k;
-                if (i < cur.n_lds) t_pm[i] = max(before, loc[k]);
+                if (i < n) t_pm[i] = max(before, loc[k]);
+            }
+            __syncthreads();
+            STAMP(1);
+            // table build, one record per thread and step: buckets (bucket of the previous key, bucket of this key] start at
+            // record i; record 0 opens bucket 0; the buckets behind the last key mean "no such record"
+            {
+                // the buckets behind the last key, by all threads (disjoint from the buckets the loop below writes)
+                const u32 last_s = (u32)(S1 - S0) >> sh_s, last_p = (u32)(P1 - P0) >> sh_p;
+                for (u32 b = threadIdx.x; b <= (u32)LUT_NB; b += SW_TPB) {
+                    if (b > last_s) lut_s[b] = (unsigned short)n;
+                    if (b > last_p) lut_p[b] = (unsigned short)n;
+                }
+            }
+#pragma unroll 1
+            for (u32 i = threadIdx.x; i < n; i += SW_TPB) {
+                const i32 st = t_s[i], pm = t_pm[i];
+                const u32 bs1 = (u32)(st - S0) >> sh_s, bp1 = (u32)(pm - P0) >> sh_p;
+                u32 bs0 = 0, bp0 = 0;
+                if (i) {
+                    bs0 = ((u32)(t_s[i - 1] - S0) >> sh_s) + 1u;
+                    bp0 = ((u32)(t_pm[i - 1] - P0) >> sh_p) + 1u;
+                }
+                for (; bs0 <= bs1; ++bs0) lut_s[bs0] = (unsigned short)i;
+                for (; bp0 <= bp1; ++bp0) lut_p[bp0] = (unsigned short)i;
             }
             __syncthreads();
         }
+        STAMP(2);
         const u32 next = tile + gridDim.x;
+#if IGD_PREFETCH
         if (next < n_tiles) {
             nxt = describe(next);
             issue(nxt);
         }
+#endif
         const u32 p0 = cur.p0, cnt = cur.cnt, c = cur.c, seg_hi = cur.seg_hi, n_lds = cur.n_lds;
         const i32 max_len = v.chrom_maxlen[c];
         const u32 n_seg = seg_hi - p0;  // records from the tile start to the end of the chromosome
@@ -326,21 +446,38 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
         auto r_start = [&](u32 i) -> i32 { return i < n_lds ? t_s[i] : v.starts[p0 + i]; };
         auto r_end = [&](u32 i) -> i32 { return i < n_lds ? t_e[i] : v.ends[p0 + i]; };
         auto r_file = [&](u32 i) -> u32 { return i < n_lds ? t_f[i] : v.files[p0 + i]; };
-        const u32 q_lo = ql[tile], q_hi = qh[tile];
         if constexpr (MODE != 1) {
-            // Pair-balanced scan.  A query's candidates are the records [lo, hi): lo = first record that can overlap it
-            // (prefix-max end > q_start), hi = first record that starts at or after q_end (the reference's scan
-            // stops there, igd.rs:772-846).  Per chunk of cq queries: one thread per query finds (lo, hi), the
-            // lengths are scanned, and every thread then takes the same number of consecutive (query, record) pairs
-            // -- no lane waits for the longest scan of its wave (a thread-per-query loop runs 20 records on average
-            // and 45 for the slowest lane).  Records past the staged range (rare) are scanned by the query's own thread.
+            // A hit is decided by the (query, record) PAIR alone.  A query's candidates are the records [lo, hi): lo = first
+            // record that can overlap it (prefix-max end > q_start), hi = first record that starts at or after q_end (the
+            // reference's scan stops there, igd.rs:772-846).  Waves work on their own, 64 queries at a time, no workgroup
+            // barrier inside a tile: (1) one lane per query finds (lo, hi) with two LDS binary searches; (2) the pairs are
+            // walked by GROUPS of GL lanes -- group g takes the queries of its own GL lanes one after the other, its lanes
+            // read CONSECUTIVE records (conflict-free LDS reads; the thread-per-pair-run loop before read three random words
+            // per pair and spent 45 VALU instructions per pair slot: LDS 60 % busy, half of it bank conflicts).
+            // For min_overlap == 1 (MO1) a candidate record is a hit iff its end is > q_start: its start is < q_end by
+            // construction of hi, so the start is not even read.  Records past the staged range (rare) are scanned by the
+            // query's own lane from global memory.
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            for (u32 cb = q_lo; cb < q_hi; cb += cq) {
-                const u32 qi = cb + threadIdx.x;
+            constexpr int GL = IGD_GROUP_LANES, NG = 64 / GL, NWV = SW_TPB / 64;
+            const int grp = lane / GL, sub = lane % GL;
+            static_assert(GL * NG == 64, "groups tile the wave");
+            // Query k of a block of SW_TPB goes to wave k % NWV, group (k / NWV) % NG, slot k / (NWV * NG): the first 64 queries
+            // of a tile land on 64 different (wave, group) pairs, so a sparse batch (a LOLA universe: ~40 queries per tile)
+            // still spreads over every wave, and a dense one gives every group the same number of queries.
+            const u32 kq = sweep_query_slot(lane, wave);
+            // the same for every lane: kept in scalar registers
+            const i32 S0 = __builtin_amdgcn_readfirstlane(s_lutdesc[0]), S1 = __builtin_amdgcn_readfirstlane(s_lutdesc[1]);
+            const i32 P0 = __builtin_amdgcn_readfirstlane(s_lutdesc[3]), P1 = __builtin_amdgcn_readfirstlane(s_lutdesc[4]);
+            const u32 sh_s = (u32)__builtin_amdgcn_readfirstlane(s_lutdesc[2]), sh_p = (u32)__builtin_amdgcn_readfirstlane(s_lutdesc[5]);
+            for (u32 qb = q_lo; qb < q_hi; qb += SW_TPB) {
+                const u32 qi = qb + kq;
                 i32 s = 0, e = 0;
                 u32 lo = 0, len = 0;
-                if (threadIdx.x < cq && qi < q_hi) {
-                    if (interleaved) {
+                if (qi < q_hi) {
+                    if (qb == q_lo) {  // loaded at the top of the tile
+                        s = pf_s;
+                        e = pf_e;
+                    } else if (interleaved) {
                         const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
                         s = (i32)se2.x;
                         e = (i32)se2.y;
@@ -349,14 +486,32 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                         e = (i32)sqe[qi];
                     }
                     u32 hi;
-                    if (min_overlap >= 1) {
-                        hi = n_lds;
-                        while (lo < hi) {
-                            const u32 mid = lo + ((hi - lo) >> 1);
-                            if (t_pm[mid] <= s)
-                                lo = mid + 1;
-                            else
-                                hi = mid;
+                    u32 a, b = n_lds;
+                    if (GTARS_IGD_ABLATE & 16) {
+                        lo = ((u32)s * 2654435761u) % (n_lds > 40 ? n_lds - 40 : 1u);
+                        a = lo + 20;
+                        b = a;
+                    } else if (min_overlap >= 1) {
+                        // lo = first record with prefix-max end > s (>= s + 1), a = first record with start >= e: both through
+                        // their tables, the two searches advance together (their LDS reads overlap)
+                        lut_range(lut_p, s + 1, P0, P1, sh_p, n_lds, lo, hi);
+                        lut_range(lut_s, e, S0, S1, sh_s, n_lds, a, b);
+                        while (lo < hi || a < b) {
+                            const u32 m1 = lo + ((hi - lo) >> 1), m2 = a + ((b - a) >> 1);
+                            const bool go1 = lo < hi, go2 = a < b;
+                            const i32 v1 = go1 ? t_pm[m1] : 0, v2 = go2 ? t_s[m2] : 0;
+                            if (go1) {
+                                if (v1 <= s)
+                                    lo = m1 + 1;
+                                else
+                                    hi = m1;
+                            }
+                            if (go2) {
+                                if (v2 < e)
+                                    a = m2 + 1;
+                                else
+                                    b = m2;
+                            }
                         }
                     } else {
                         const i32 key = s > max_len ? s - max_len : 0;
@@ -368,19 +523,18 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                             else
                                 hi = mid;
                         }
-                    }
-                    // first staged record at or after lo whose start is >= q_end
-                    u32 a = lo, b = n_lds;
-                    while (a < b) {
-                        const u32 mid = a + ((b - a) >> 1);
-                        if (t_s[mid] < e)
-                            a = mid + 1;
-                        else
-                            b = mid;
+                        a = lo;
+                        while (a < b) {
+                            const u32 mid = a + ((b - a) >> 1);
+                            if (t_s[mid] < e)
+                                a = mid + 1;
+                            else
+                                b = mid;
+                        }
                     }
                     len = a - lo;
-                    if (a == n_lds && n_seg > n_lds) {
-                        // the scan runs past the staged records: the rest from global memory, by this thread
+                    if (!(GTARS_IGD_ABLATE & 16) && a == n_lds && n_seg > n_lds) {
+                        // the scan runs past the staged records: the rest from global memory, by this lane
                         for (u32 r = max(lo, n_lds); r < n_seg; ++r) {
                             const i32 rs = v.starts[p0 + r], re = v.ends[p0 + r];
                             if (rs >= e) break;
@@ -391,67 +545,57 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                         }
                     }
                 }
-                if (threadIdx.x < cq) {
-                    c_s[threadIdx.x] = s;
-                    c_e[threadIdx.x] = e;
-                    c_lo[threadIdx.x] = (unsigned short)lo;
-                }
-                // exclusive scan of the lengths over the chunk
-                const u32 inc = wave_inclusive_scan_u32(len, lane);
-                if (lane == 63) s_part[wave] = inc;
-                __syncthreads();
-                u32 wbase = 0, total = 0;
+                if (GTARS_IGD_ABLATE & 1) len = min(len, 1u);
+                STAMP(3);
+                // the group's GL queries, IGD_PAIR_UNROLL at a time: their candidate reads (end, file id, [start, pme_file])
+                // are issued together, so that one LDS round trip serves every query of the step
+                constexpr int U = IGD_PAIR_UNROLL;
+                static_assert(GL % U == 0, "slots per step divide the group");
+#pragma unroll 1
+                for (int i0 = 0; i0 < GL; i0 += U) {
+                    i32 qs_[U], qe_[U];
+                    u32 lo_[U], len_[U], mx = 0;
 #pragma unroll
-                for (int w = 0; w < SW_TPB / 64; ++w) {
-                    const u32 x = s_part[w];
-                    wbase += w < wave ? x : 0u;
-                    total += x;
-                }
-                if (threadIdx.x < cq) c_off[threadIdx.x] = wbase + inc - len;
-                if (threadIdx.x == 0) c_off[cq] = total;
-                __syncthreads();
-                if (total) {
-                    const u32 ppt = (total + SW_TPB - 1) / SW_TPB;
-                    u32 p = threadIdx.x * ppt;
-                    const u32 p_end = min(p + ppt, total);
-                    if (p < p_end) {
-                        // the query that holds pair p: last j with c_off[j] <= p
-                        u32 j = 0, jh = cq;
-                        while (jh - j > 1) {
-                            const u32 mid = (j + jh) >> 1;
-                            if (c_off[mid] <= p)
-                                j = mid;
-                            else
-                                jh = mid;
+                    for (int u = 0; u < U; ++u) {
+                        const int src = grp * GL + i0 + u;  // this group's (i0 + u)-th query
+                        qs_[u] = __shfl(s, src, 64);
+                        lo_[u] = (u32)__shfl((int)lo, src, 64);
+                        len_[u] = (u32)__shfl((int)len, src, 64);
+                        qe_[u] = MO1 ? 0 : __shfl(e, src, 64);
+                        mx = max(mx, len_[u]);
+                    }
+                    for (u32 k = (u32)sub; k < mx; k += GL) {
+                        i32 re[U], rs[U], pf[U];
+                        u32 f[U];
+                        bool on[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            on[u] = k < len_[u];
+                            const u32 r = on[u] ? lo_[u] + k : 0u;
+                            re[u] = t_e[r];
+                            f[u] = t_f[r];
+                            rs[u] = MO1 ? 0 : t_s[r];
+                            pf[u] = MODE == 2 ? t_pf[r] : 0;
                         }
-                        u32 j_end = c_off[j + 1];
-                        u32 r = c_lo[j] + (p - c_off[j]);
-                        i32 qs_ = c_s[j], qe_ = c_e[j];
-                        for (; p < p_end; ++p, ++r) {
-                            if (p == j_end) {  // next query with a non-empty range
-                                do {
-                                    ++j;
-                                    j_end = c_off[j + 1];
-                                } while (j_end == p);
-                                r = c_lo[j];
-                                qs_ = c_s[j];
-                                qe_ = c_e[j];
-                            }
-                            const i32 rs = t_s[r], re = t_e[r];
-                            const i32 ov = (re < qe_ ? re : qe_) - (rs > qs_ ? rs : qs_);
-                            bool hit = ov >= min_overlap;
-                            if (MODE == 2) hit = hit && t_pf[r] <= qs_;  // no earlier record of this file reaches the query
-                            if (hit) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            bool hit;
+                            if (MO1)
+                                hit = re[u] > qs_[u];
+                            else
+                                hit = (re[u] < qe_[u] ? re[u] : qe_[u]) - (rs[u] > qs_[u] ? rs[u] : qs_[u]) >= min_overlap;
+                            if (MODE == 2) hit = hit && pf[u] <= qs_[u];  // no earlier record of this file reaches the query
+                            if (hit && on[u]) {
                                 if (GTARS_IGD_ABLATE & 2) {
-                                    if (rs == 0x7FFFFFF0) bins[0] = 1;
+                                    if (re[u] == 0x7FFFFFF0) bins[0] = 1;
                                 } else {
-                                    atomicAdd(&bins[t_f[r]], 1u);
+                                    atomicAdd(&bins[f[u]], 1u);
                                 }
                             }
                         }
                     }
                 }
-                __syncthreads();  // c_* reused by the next chunk
+                STAMP(4);
             }
         } else
         for (u32 qi = q_lo + threadIdx.x; qi < q_hi; qi += SW_TPB) {
@@ -550,12 +694,25 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                 }
             }
         }
+        STAMP(3);
         __syncthreads();  // every query of the current tile served: LDS may be overwritten
+        STAMP(5);
         if (next < n_tiles) {
+#if !IGD_PREFETCH
+            nxt = describe(next);
+            issue(nxt);
+#endif
             commit(nxt);
             cur = nxt;
         }
+        STAMP(6);
     }
+#if IGD_STAMPS
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_sweep_stamps[k], st_acc[k]);
+        atomicAdd(&g_sweep_stamps[7], 1ull);
+    }
+#endif
     __syncthreads();
     for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) {
         const u32 b = bins[i];
@@ -856,27 +1013,22 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     }
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
     // starts | ends | files (u16) | prefix-max ends | [pme_file] | bins
-    // + chunk arrays: offsets u32 [cq + 2] | starts, ends i32 [cq] | first records u16 [cq]
-    u32 cq = 512;
-    if (mode != 1) {
-        const u64 per_tile = n_tiles ? (u64)nq / n_tiles : nq;  // queries per tile on average
-        cq = per_tile <= 48 ? 128u : per_tile <= 110 ? 256u : 512u;
-    }
-    const size_t lds = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14) + (((size_t)v.n_files + 1) & ~(size_t)1) * 4 +
-                       (mode != 1 ? ((size_t)cq + 2) * 4 + (size_t)cq * 10 : 0);
-    auto kern = mode == 2 ? k_igd_sweep<2> : mode == 1 ? k_igd_sweep<1> : k_igd_sweep<0>;
+    const size_t lds = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14) + (((size_t)v.n_files + 1) & ~(size_t)1) * 4;
+    const bool mo1 = min_overlap == 1;
+    auto kern = mode == 2 ? k_igd_sweep<2, true> : mode == 1 ? k_igd_sweep<1, false> : mo1 ? k_igd_sweep<0, true> : k_igd_sweep<0, false>;
     {
         // the dynamic-LDS limit belongs to the function, not to the calling thread: raised once per device to the largest
         // size any launch can ask for (5 staged arrays + 16384 file bins) and never lowered
         static std::mutex mu;
-        static bool done[3][64] = {};
+        static bool done[4][64] = {};
         int dev = 0;
         GT_HIP(hipGetDevice(&dev));
+        const int slot = mode == 0 && !mo1 ? 3 : mode;
         std::lock_guard<std::mutex> lock(mu);
-        if (dev >= 0 && dev < 64 && !done[mode][dev]) {
+        if (dev >= 0 && dev < 64 && !done[slot][dev]) {
             GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(((size_t)(IGD_TILE + IGD_HALO) * 5 + 16384 + 2048) * 4)));
-            done[mode][dev] = true;
+            done[slot][dev] = true;
         }
     }
     int per_cu = 1;
@@ -886,7 +1038,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     {
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.first, tl.cnt, tl.chrom, tl.carry, n_tiles, ss, se,
-                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql, cq);
+                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql);
     }
     GT_HIP(hipGetLastError());
     // which continuation the device took (profiling mode: a deterministic fact for the tests, not a timing)
@@ -895,3 +1047,14 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
 }
 
 }  // namespace gtars
+
+#if IGD_STAMPS
+extern "C" int gtars_debug_sweep_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gtars::g_sweep_stamps), 64) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gtars::g_sweep_stamps), z, 64) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
