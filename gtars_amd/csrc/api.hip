@@ -365,6 +365,13 @@ struct gtars_igd {
     DevBuf<i32> tile_carry;
     // ownership bound of every tile and the tiles of every chromosome (IgdTiles, common.h)
     DevBuf<u32> tile_bnd, chrom_tile_off;
+    // static tables of the sweep (IgdTiles::pm / files16 / tab): built once in finish_tiles
+    DevBuf<i32> tile_pm;
+    DevBuf<unsigned short> tile_files16;
+    DevBuf<u32> tile_tab;
+    // static routing table (IgdTiles::route_*)
+    DevBuf<u32> route_lut, route_base, route_len;
+    u32 route_n = 0, route_shift = 0;
     // IgdTiles::pme_file, built on the first binary count with min_overlap == 1
     mutable std::mutex pme_mu;
     mutable DevBuf<i32> pme_file;
@@ -432,6 +439,14 @@ struct gtars_igd {
         t.bnd = tile_bnd.p;
         t.chrom_tile_off = chrom_tile_off.p;
         t.pme_file = pme_ready && !getenv("GTARS_IGD_NO_PME") ? pme_file.p : nullptr;
+        t.pm = tile_pm.p;
+        t.files16 = tile_files16.p;
+        t.tab = tile_tab.p;
+        t.route_lut = route_n ? route_lut.p : nullptr;
+        t.route_base = route_base.p;
+        t.route_len = route_len.p;
+        t.route_n = route_n;
+        t.route_shift = route_shift;
         t.n_tiles = n_tiles;
         return t;
     }
@@ -445,7 +460,54 @@ struct gtars_igd {
         std::vector<u32> zero(std::max<u32>(n_tiles, 1), 0);
         if ((st = tile_bnd.upload(zero))) return st;
         if ((st = launch_igd_tile_bounds(view(), tile_first.p, tile_cnt.p, tile_chrom.p, n_tiles, tile_bnd.p, nullptr))) return st;
+        if (n_tiles && n_files <= 65535) {
+            // one pass over the database: prefix maxima, u16 file ids, search tables (what the sweep streams with the records)
+            GT_HIP(hipMalloc((void **)&tile_pm.p, (size_t)n * 4));
+            tile_pm.n = n;
+            GT_HIP(hipMalloc((void **)&tile_files16.p, ((size_t)n + 1) / 2 * 4));
+            tile_files16.n = n;
+            GT_HIP(hipMalloc((void **)&tile_tab.p, (size_t)n_tiles * IGD_TILE_TAB_WORDS * 4));
+            tile_tab.n = (size_t)n_tiles * IGD_TILE_TAB_WORDS;
+            if ((st = launch_igd_tile_tables(view(), tile_first.p, tile_cnt.p, tile_chrom.p, tile_carry.p, n_tiles, tile_pm.p, tile_files16.p,
+                                             tile_tab.p, nullptr)))
+                return st;
+        }
         GT_HIP(hipDeviceSynchronize());
+        if (n_tiles && n_tiles < 65535) {
+            // routing table over (chromosome, start >> shift), from the tile bounds the device has just computed
+            std::vector<u32> hb(n_tiles);
+            GT_HIP(hipMemcpy(hb.data(), tile_bnd.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+            std::vector<u32> len(n_chrom, 0), base(n_chrom + 1, 0);
+            for (u32 c = 0; c < n_chrom; ++c)
+                if (cto[c + 1] > cto[c]) len[c] = hb[cto[c + 1] - 1];
+            constexpr u64 ROUTE_MAX = 4096;
+            u32 sh = 0;
+            for (;; ++sh) {
+                u64 tot = 0;
+                for (u32 c = 0; c < n_chrom; ++c) tot += ((u64)len[c] >> sh) + 2;
+                if (tot <= ROUTE_MAX || sh == 31) break;
+            }
+            for (u32 c = 0; c < n_chrom; ++c) base[c + 1] = base[c] + (len[c] >> sh) + 2;
+            if (base[n_chrom] <= ROUTE_MAX) {
+                std::vector<unsigned short> lut(((size_t)base[n_chrom] + 2) & ~(size_t)1, 0);
+                for (u32 c = 0; c < n_chrom; ++c) {
+                    u32 t = cto[c];
+                    const u32 t1 = cto[c + 1], nj = (len[c] >> sh) + 2;
+                    for (u32 j = 0; j < nj; ++j) {
+                        const u64 x = (u64)j << sh;
+                        while (t < t1 && (u64)hb[t] <= x) ++t;  // first tile with bound > x
+                        lut[base[c] + j] = (unsigned short)t;
+                    }
+                }
+                std::vector<u32> packed(lut.size() / 2);
+                for (size_t w = 0; w < packed.size(); ++w) packed[w] = (u32)lut[2 * w] | ((u32)lut[2 * w + 1] << 16);
+                if ((st = route_lut.upload(packed))) return st;
+                if ((st = route_base.upload(base))) return st;
+                if ((st = route_len.upload(len))) return st;
+                route_n = base[n_chrom];
+                route_shift = sh;
+            }
+        }
         return GTARS_OK;
     }
     IgdView view() const {
@@ -1906,6 +1968,12 @@ void gtars_igd_free(gtars_igd_t *g) {
     g->tile_carry.release();
     g->tile_bnd.release();
     g->chrom_tile_off.release();
+    g->tile_pm.release();
+    g->tile_files16.release();
+    g->tile_tab.release();
+    g->route_lut.release();
+    g->route_base.release();
+    g->route_len.release();
     g->pme_file.release();
     delete g;
 }

@@ -225,8 +225,17 @@ gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, 
 // must be the last one)
 constexpr u32 MS_MAX_BINS = 36864;  // 144 KB of LDS counters
 size_t multisplit_ws_bytes(u32 n_bins, u32 n);
-gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
-                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if = nullptr);
+// key: u32 keys, or unsigned short keys when key16 (n_bins <= 65535); clamp_a: a = max((i32)a, 0) on the way (raw IGD query
+// starts); table_ready: the caller has already counted the keys into multisplit_table(ws) -- one row of n_bins counters per
+// workgroup of a multisplit_workgroups(n)-workgroup grid over contiguous chunks of ceil(n / workgroups) elements
+gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
+                              uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if = nullptr,
+                              bool table_ready = false);
+u32 multisplit_workgroups(u32 n);
+u32 multisplit_chunk(u32 n);  // elements per workgroup of that grid (a multiple of 4)
+u32 *multisplit_table(void *ws);
+// table_ready callers of a two-level split (large n, many bins) leave only the bin totals here (zeroed first); null: one-level
+u32 *multisplit_totals(void *ws, u32 n_bins, u32 n);
 
 // K1 (sort.hip): permutation that orders rows by (chrom, k1, [k2], input order); device columns in/out
 gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,
@@ -244,8 +253,20 @@ struct IgdTiles {
     const u32 *chrom_tile_off;       // [n_chrom + 1] tiles of each chromosome
     const i32 *pme_file;             // [n] largest end among the EARLIER records of the same file and chromosome (0: none),
                                      //   or null: not built yet
+    // static per-tile tables of the sweep (igd_sweep.hip, launch_igd_tile_tables), built with the index:
+    const i32 *pm;                   // [n] prefix maximum of the ends over the chromosome's records up to each record
+    const unsigned short *files16;   // [n] file ids as u16 (null when n_files > 65535: such a database is never swept)
+    const u32 *tab;                  // [n_tiles * IGD_TILE_TAB_WORDS] descriptor + two search tables per tile
+    // static routing table (owner tile of a query): entry route_base[c] + j (u16, packed two per word) = first tile of
+    // chromosome c whose ownership bound is > (j << route_shift); route_len[c] = the chromosome's last bound (0: no tiles);
+    // null when the database has more than 65535 tiles
+    const u32 *route_lut, *route_base, *route_len;
+    u32 route_n, route_shift;
     u32 n_tiles;
 };
+constexpr u32 IGD_TILE_TAB_WORDS = 528;
+gtars_status launch_igd_tile_tables(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
+                                    const i32 *tile_carry, u32 n_tiles, i32 *pm, unsigned short *files16, u32 *tile_tab, hipStream_t st);
 bool igd_sweep_supported(const IgdView &v, u64 nq);
 size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom);
 size_t igd_pme_ws_bytes(u32 n);

@@ -37,6 +37,7 @@ constexpr int IGD_HALO = 256;
 #endif
 #if IGD_STAMPS
 __device__ unsigned long long g_sweep_stamps[8];
+__device__ unsigned long long g_route_stamps[8];
 #define STAMP(k)                                                  \
     do {                                                          \
         const u64 _t = __builtin_amdgcn_s_memtime();              \
@@ -152,6 +153,194 @@ k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const
     if (__any(bad) && lane == 0) *unsorted = 1u;
 }
 
+// ---- routing: owner tile of every query + the partition's histogram, in ONE pass over the raw batch ------------------------
+// Round 2 prepared the batch in one kernel (four columns written: clamped chromosome / start / end and the owner tile, 160 MB
+// for config 3) and counted the owner tiles in a second one.  Here the raw columns are read once, the owner tile leaves as a
+// u16 key (2 bytes per query) and the per-workgroup histogram the partition needs is counted in the same pass (16-bit
+// counters packed two per LDS word: a workgroup's chunk is at most 65535 queries); the start clamp (igd.rs:517) is applied
+// later, where the columns are read anyway (multisplit_pairs clamp_a, the sweep's own loads).  The owner search goes through a
+// static table over (chromosome, start >> shift) built with the index (IgdTiles::route_*): 2 + ~3 LDS round trips instead of
+// a 10-step binary search of the chromosome's tile bounds.
+constexpr int RT_TPB = 1024;
+constexpr int RT_U = 4;  // queries per thread and step (their loads and searches overlap)
+size_t igd_route_lds_bytes(u32 n_tiles, u32 n_chrom, u32 n_lut) {
+    return ((size_t)n_tiles + 3 * (size_t)n_chrom + 2 + ((size_t)n_lut + 1) / 2 + ((size_t)n_tiles + 2) / 2) * 4;
+}
+template <bool VEC>
+__global__ void __launch_bounds__(RT_TPB)
+k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
+            const u32 *__restrict__ bnd, const u32 *__restrict__ chrom_tile_off, const u32 *__restrict__ route_base,
+            const u32 *__restrict__ route_len, const u32 *__restrict__ route_lut, u32 n_lut, u32 route_shift, u32 n_tiles, u32 chunk,
+            unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, u32 *__restrict__ unsorted) {
+    extern __shared__ u32 rt_lds[];
+    u32 *s_bnd = rt_lds, *s_cto = s_bnd + n_tiles, *s_base = s_cto + n_chrom + 1, *s_len = s_base + n_chrom + 1;
+    u32 *s_lutw = s_len + n_chrom;
+    u32 *bins = s_lutw + (n_lut + 1) / 2;  // (n_tiles + 2) / 2 words: bin b in half (b & 1) of word b >> 1
+    const unsigned short *s_lut = reinterpret_cast<const unsigned short *>(s_lutw);
+#if IGD_STAMPS
+    u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+    {
+        // the tile bounds: 16-byte loads, four in flight per thread (a dword-per-step copy loop is a chain of L2 round trips)
+        const u32 n4 = n_tiles >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(bnd);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_bnd);
+        for (u32 i0 = threadIdx.x; i0 < n4; i0 += RT_TPB * 4) {
+            uint4 x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = i0 + (u32)k * RT_TPB < n4 ? src[i0 + (u32)k * RT_TPB] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + (u32)k * RT_TPB < n4) dst[i0 + (u32)k * RT_TPB] = x[k];
+        }
+        for (u32 t = (n4 << 2) + threadIdx.x; t < n_tiles; t += RT_TPB) s_bnd[t] = bnd[t];
+    }
+    for (u32 c = threadIdx.x; c <= n_chrom; c += RT_TPB) {
+        s_cto[c] = chrom_tile_off[c];
+        s_base[c] = route_base[c];
+        if (c < n_chrom) s_len[c] = route_len[c];
+    }
+    for (u32 w = threadIdx.x; w < (n_lut + 1) / 2; w += RT_TPB) s_lutw[w] = route_lut[w];
+    for (u32 w = threadIdx.x; w < (n_tiles + 2) / 2; w += RT_TPB) bins[w] = 0;
+    __syncthreads();
+    STAMP(0);
+    const u32 lo_q = blockIdx.x * chunk, hi_q = min(nq, lo_q + chunk);
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    // A lane takes RT_U = 4 CONSECUTIVE queries per step.  VEC (16-byte aligned columns, chunk a multiple of 4): three 16-byte
+    // loads and one 8-byte key store per step instead of twelve loads and four stores, the order check runs inside the lane
+    // for three of the four and needs ONE neighbour value per step (the loop was instruction-bound: 17.8k cycles per step by
+    // the in-kernel stamps, ~500 VALU instructions per wave and step).  The raw columns of the NEXT step are loaded while the
+    // current one is searched (one workgroup per CU: nothing else covers the HBM latency); lane 0 also fetches the element
+    // in front of its wave's 256, so that the order check never waits for a dependent load.
+    u32 nc[RT_U], ns[RT_U], ne[RT_U], pc0 = 0, ps0 = 0, pe0 = 0;
+    auto fetch = [&](u32 base) {
+        const u32 i0 = base + threadIdx.x * RT_U;
+        if (VEC && i0 + RT_U <= hi_q) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(qc + i0), b = *reinterpret_cast<const uint4 *>(qs + i0),
+                        d = *reinterpret_cast<const uint4 *>(qe + i0);
+            nc[0] = a.x, nc[1] = a.y, nc[2] = a.z, nc[3] = a.w;
+            ns[0] = b.x, ns[1] = b.y, ns[2] = b.z, ns[3] = b.w;
+            ne[0] = d.x, ne[1] = d.y, ne[2] = d.z, ne[3] = d.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) {
+                const bool in = i0 + u < hi_q;
+                nc[u] = in ? qc[i0 + u] : GTARS_UNKNOWN_CHROM;
+                ns[u] = in ? qs[i0 + u] : 0u;
+                ne[u] = in ? qe[i0 + u] : 0u;
+            }
+        }
+        const bool edge = lane == 0 && i0 > 0 && i0 < hi_q;
+        pc0 = edge ? qc[i0 - 1] : 0u;
+        ps0 = edge ? qs[i0 - 1] : 0u;
+        pe0 = edge ? qe[i0 - 1] : 0u;
+    };
+    fetch(lo_q);
+    for (u32 base = lo_q; base < hi_q; base += RT_TPB * RT_U) {
+        const u32 i0 = base + threadIdx.x * RT_U;
+        u32 c[RT_U], l[RT_U], h[RT_U];
+        i32 s[RT_U], e[RT_U];
+        bool ok[RT_U], owned[RT_U];
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u) {
+            ok[u] = i0 + u < hi_q;
+            c[u] = n_chrom;
+            s[u] = e[u] = 0;
+            if (ok[u]) igd_prep_one(nc[u], ns[u], ne[u], n_chrom, c[u], s[u], e[u]);
+        }
+        u32 ec;
+        i32 es, ee;
+        igd_prep_one(pc0, ps0, pe0, n_chrom, ec, es, ee);  // lane 0: the element before this wave's
+        if (base + RT_TPB * RT_U < hi_q) fetch(base + RT_TPB * RT_U);
+        {
+            // already in (chromosome, start) order?  then the sweep can skip the partition (BED inputs usually are)
+            u32 pc = __shfl_up(c[RT_U - 1], 1, 64);
+            u32 ps = __shfl_up((u32)s[RT_U - 1], 1, 64);
+            if (lane == 0) {
+                pc = ec;
+                ps = (u32)es;
+            }
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) {
+                if (ok[u] && i0 + u > 0 && (pc > c[u] || (pc == c[u] && ps > (u32)s[u]))) bad = true;
+                pc = c[u];
+                ps = (u32)s[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u) {
+            // the owner: first tile of the chromosome whose bound is > start, bracketed by the static table
+            l[u] = h[u] = 0;
+            owned[u] = c[u] < n_chrom && (u32)s[u] < s_len[c[u]];  // otherwise: invalid, unknown chromosome or past every bound
+            if (owned[u]) {
+                const u32 j = s_base[c[u]] + ((u32)s[u] >> route_shift);
+                l[u] = s_lut[j];
+                h[u] = s_lut[j + 1];
+            }
+        }
+        bool more = true;
+        while (more) {
+            more = false;
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) {
+                if (l[u] < h[u]) {
+                    const u32 mid = l[u] + ((h[u] - l[u]) >> 1);
+                    if (s_bnd[mid] <= (u32)s[u])
+                        l[u] = mid + 1;
+                    else
+                        h[u] = mid;
+                    more = more || l[u] < h[u];
+                }
+            }
+        }
+        u32 tt[RT_U];
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u) {
+            tt[u] = owned[u] ? l[u] : n_tiles;
+            if (ok[u]) atomicAdd(&bins[tt[u] >> 1], 1u << ((tt[u] & 1u) * 16u));
+        }
+        if (VEC && i0 + RT_U <= hi_q) {
+            *reinterpret_cast<uint2 *>(key + i0) = make_uint2(tt[0] | (tt[1] << 16), tt[2] | (tt[3] << 16));
+        } else {
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u)
+                if (ok[u]) key[i0 + u] = (unsigned short)tt[u];
+        }
+    }
+    if (__any(bad) && lane == 0) *unsorted = 1u;
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+    if (tot) {
+        // the two-level split only needs the bin totals (its passes reserve runs with atomics on the bins' cursors)
+        for (u32 b = threadIdx.x; b <= n_tiles; b += RT_TPB) {
+            const u32 x = (bins[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
+            if (x) atomicAdd(&tot[b], x);
+        }
+    } else {
+        u32 *row = table + (size_t)blockIdx.x * (n_tiles + 1);
+        for (u32 b = threadIdx.x; b <= n_tiles; b += RT_TPB) row[b] = (bins[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
+    }
+    STAMP(3);
+#if IGD_STAMPS
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_route_stamps[k], st_acc[k]);
+        atomicAdd(&g_route_stamps[7], 1ull);
+    }
+#endif
+}
+
+// start of a batch call: the result vector, the "arrived out of owner order" flag and (fused routing) the bin totals -- one
+// launch instead of four memsets
+__global__ void k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict__ flag, u32 flag_value,
+                                u32 *__restrict__ tot, u32 n_tot) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_files) hits[i] = 0ull;
+    if (i < n_tot) tot[i] = 0u;
+    if (i == 0) *flag = flag_value;
+}
+
 __global__ void k_igd_tile_bounds(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
                                   const u32 *__restrict__ tile_chrom, u32 n_tiles, u32 *__restrict__ bnd) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,11 +357,13 @@ gtars_status launch_igd_tile_bounds(const IgdView &v, const u32 *tile_first, con
     return GTARS_OK;
 }
 
-// first index in [lo, hi) with a[i] >= key
+// first index in [lo, hi) with a[i] >= key; CLAMP: a holds raw i32 starts, negative ones count as 0 (igd.rs:517)
+template <bool CLAMP>
 __device__ __forceinline__ u32 lb_u32(const u32 *__restrict__ a, u32 lo, u32 hi, u64 key) {
     while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
-        if ((u64)a[mid] < key)
+        const u32 x = a[mid];
+        if ((u64)(CLAMP && (i32)x < 0 ? 0u : x) < key)
             lo = mid + 1;
         else
             hi = mid;
@@ -182,16 +373,26 @@ __device__ __forceinline__ u32 lb_u32(const u32 *__restrict__ a, u32 lo, u32 hi,
 
 // per-chromosome segments of the sorted queries
 // `perm` (may be NULL: the batch is already ordered) maps a sorted position to its row of `chrom_key`, so the
-// sorted chromosome column never has to be materialised for these n_chrom + 1 binary searches
-__global__ void k_igd_chrom_segments(const u32 *__restrict__ chrom_key, const u32 *__restrict__ perm, u32 nq, u32 n_chrom,
-                                     u32 *__restrict__ cq_off, const u32 *__restrict__ skip_if) {
+// sorted chromosome column never has to be materialised for these n_chrom + 1 binary searches.
+// RAW: chrom_key / raw_s / raw_e are the caller's columns as they came; the validity rules are applied on the way (an
+// in-order batch has its invalid queries at the end: they map to chromosome n_chrom).
+template <bool RAW>
+__global__ void k_igd_chrom_segments(const u32 *__restrict__ chrom_key, const u32 *__restrict__ raw_s, const u32 *__restrict__ raw_e,
+                                     const u32 *__restrict__ perm, u32 nq, u32 n_chrom, u32 *__restrict__ cq_off,
+                                     const u32 *__restrict__ skip_if) {
     if (skip_if && *skip_if) return;  // the batch was partitioned instead (decided on the device)
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n_chrom) return;
     u32 lo = 0, hi = nq;
     while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
-        if (chrom_key[perm ? perm[mid] : mid] < c)
+        const u32 row = perm ? perm[mid] : mid;
+        u32 cc = chrom_key[row];
+        if (RAW) {
+            i32 s1, e1;
+            igd_prep_one(cc, raw_s[row], raw_e[row], n_chrom, cc, s1, e1);
+        }
+        if (cc < c)
             lo = mid + 1;
         else
             hi = mid;
@@ -214,6 +415,7 @@ __global__ void k_gather2_u32(const u32 *__restrict__ a, const u32 *__restrict__
 // p = first record of the chromosome with start >= key, key = max(q.start - max_len, 0).
 // key is monotone in q.start, so the owned queries of a tile are a contiguous range [ql, qh) of the
 // sorted queries:   last_start(previous tile) < key <= last_start(this tile).
+template <bool CLAMP>
 __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
                                   const u32 *__restrict__ tile_chrom, u32 n_tiles, const u32 *__restrict__ sorted_qs,
                                   const u32 *__restrict__ cq_off, u32 *__restrict__ ql, u32 *__restrict__ qh,
@@ -226,8 +428,8 @@ __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first,
     const u32 lo = cq_off[c], hi = cq_off[c + 1];
     const bool first_of_chrom = p0 == v.chrom_off[c];
     // key > prev_last  <=>  q.start >= prev_last + max_len + 1   (keys clamped to 0 belong to the first tile)
-    ql[t] = first_of_chrom ? lo : lb_u32(sorted_qs, lo, hi, (u64)v.starts[p0 - 1] + max_len + 1);
-    qh[t] = lb_u32(sorted_qs, lo, hi, (u64)v.starts[p0 + cnt - 1] + max_len + 1);
+    ql[t] = first_of_chrom ? lo : lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 - 1] + max_len + 1);
+    qh[t] = lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 + cnt - 1] + max_len + 1);
 }
 
 // ---- the sweep ---------------------------------------------------------------------------------
@@ -237,30 +439,153 @@ __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first,
 // "ends after q.start" is all that is left of the overlap test, and the largest such end is a per-record constant of
 // the database (IgdTiles::pme_file).  Binary counting then costs what pairwise counting costs (2.3 -> 0.5 ms for
 // config 3) instead of a 32-entry membership test per hit.
+// ---- static per-tile tables (built once per database, launch_igd_tile_tables) -------------------------------------------
+// Everything a tile's queries need that depends on the DATABASE only is computed at index build and streamed with the records:
+//   pm[r]      prefix maximum of the ends over the chromosome's records up to r: ascending, so "first record that can overlap
+//              a query" is the first one with pm > q_start;
+//   files16[r] the file ids as u16 (the LDS histogram limits a swept database to 16384 files);
+//   tile_tab   per tile TAB_WORDS words: a descriptor and two direct-mapped search tables over the staged range (the tile + its
+//              halo): lut[b] = first staged record whose key falls in bucket >= b, bucket(x) = (x - first key) >> shift, for the
+//              starts and for pm.  A query's two binary searches then start from a handful of records instead of 2304
+//              (2 + ~3 dependent LDS round trips instead of 24).
+// In round 2 the sweep scanned the prefix maximum in LDS for every tile of every call (2.4k cycles per tile by the in-kernel
+// stamps) and searched without tables (the searches were 0.19 of the sweep's 0.41 ms).
+constexpr int TAB_DESC = 12;  // p0, cnt, chrom, n_lds, S0, S1, shift_s, P0, P1, shift_p, n_seg, -
+constexpr int TAB_LUT_WORDS = (LUT_NB + 2) / 2;
+constexpr int TAB_WORDS = (TAB_DESC + 2 * TAB_LUT_WORDS + 3) / 4 * 4;
+static_assert(TAB_WORDS == (int)IGD_TILE_TAB_WORDS, "common.h states the table size");
+
+__global__ void __launch_bounds__(SW_TPB)
+k_igd_tile_tables(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt, const u32 *__restrict__ tile_chrom,
+                  const i32 *__restrict__ tile_carry, u32 n_tiles, i32 *__restrict__ pm_out, unsigned short *__restrict__ files16,
+                  u32 *__restrict__ tile_tab) {
+    constexpr int CAP = IGD_TILE + IGD_HALO;
+    constexpr int RPT = (CAP + SW_TPB - 1) / SW_TPB;
+    __shared__ i32 t_s[CAP], t_e[CAP], t_pm[CAP];
+    __shared__ unsigned short lut_s[LUT_NB + 2], lut_p[LUT_NB + 2];
+    __shared__ i32 s_wmax[SW_TPB / 64];
+    const u32 t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const u32 p0 = tile_first[t], cnt = tile_cnt[t], c = tile_chrom[t];
+    const u32 seg_hi = v.chrom_off[c + 1];
+    const u32 n = min((u32)CAP, seg_hi - p0);  // tile + halo, never past the chromosome
+    const i32 carry = tile_carry[t];
+    for (u32 i = threadIdx.x; i < n; i += SW_TPB) {
+        t_s[i] = v.starts[p0 + i];
+        t_e[i] = v.ends[p0 + i];
+        if (i < cnt && files16) files16[p0 + i] = (unsigned short)v.files[p0 + i];
+    }
+    __syncthreads();
+    // t_pm[i] = max(carry, ends[0..i]); blocked layout: thread k owns records [k * RPT, (k + 1) * RPT)
+    const u32 base = threadIdx.x * RPT;
+    i32 loc[RPT], run = 0;  // ends are > 0 (Igd::add drop rule)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const u32 i = base + k;
+        run = max(run, i < n ? t_e[i] : 0);
+        loc[k] = run;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i32 inc = wave_inclusive_max_nonneg(run);
+    if (lane == 63) s_wmax[wave] = inc;
+    const i32 excl = __builtin_amdgcn_update_dpp(0, inc, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 gets 0
+    __syncthreads();
+    i32 before = carry, all_max = carry;
+    for (int w = 0; w < SW_TPB / 64; ++w) {
+        const i32 x = s_wmax[w];
+        before = max(before, w < wave ? x : 0);
+        all_max = max(all_max, x);
+    }
+    before = max(before, excl);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const u32 i = base + k;
+        if (i < n) {
+            const i32 pmv = max(before, loc[k]);
+            t_pm[i] = pmv;
+            if (i < cnt) pm_out[p0 + i] = pmv;  // own records: the chromosome-wide prefix maximum, the same for every tile
+        }
+    }
+    const i32 S0 = t_s[0], S1 = t_s[n - 1], P0 = max(carry, t_e[0]), P1 = all_max;
+    const u32 sh_s = lut_shift((u32)(S1 - S0)), sh_p = lut_shift((u32)(P1 - P0));
+    {
+        // the buckets behind the last key ("no such record"), disjoint from the buckets the loop below writes
+        const u32 last_s = (u32)(S1 - S0) >> sh_s, last_p = (u32)(P1 - P0) >> sh_p;
+        for (u32 b = threadIdx.x; b < (u32)LUT_NB + 2; b += SW_TPB) {
+            if (b > last_s) lut_s[b] = (unsigned short)n;
+            if (b > last_p) lut_p[b] = (unsigned short)n;
+        }
+    }
+    __syncthreads();
+    // buckets (bucket of the previous key, bucket of this key] start at record i; record 0 opens bucket 0
+    for (u32 i = threadIdx.x; i < n; i += SW_TPB) {
+        const i32 st = t_s[i], pmv = t_pm[i];
+        const u32 bs1 = (u32)(st - S0) >> sh_s, bp1 = (u32)(pmv - P0) >> sh_p;
+        u32 bs0 = 0, bp0 = 0;
+        if (i) {
+            bs0 = ((u32)(t_s[i - 1] - S0) >> sh_s) + 1u;
+            bp0 = ((u32)(t_pm[i - 1] - P0) >> sh_p) + 1u;
+        }
+        for (; bs0 <= bs1; ++bs0) lut_s[bs0] = (unsigned short)i;
+        for (; bp0 <= bp1; ++bp0) lut_p[bp0] = (unsigned short)i;
+    }
+    __syncthreads();
+    u32 *tab = tile_tab + (size_t)t * TAB_WORDS;
+    if (threadIdx.x == 0) {
+        tab[0] = p0;
+        tab[1] = cnt;
+        tab[2] = c;
+        tab[3] = n;
+        tab[4] = (u32)S0;
+        tab[5] = (u32)S1;
+        tab[6] = sh_s;
+        tab[7] = (u32)P0;
+        tab[8] = (u32)P1;
+        tab[9] = sh_p;
+        tab[10] = seg_hi - p0;
+        tab[11] = 0;
+    }
+    for (u32 w = threadIdx.x; w < 2u * TAB_LUT_WORDS; w += SW_TPB) {
+        const unsigned short *src = w < (u32)TAB_LUT_WORDS ? lut_s : lut_p;
+        const u32 k = w < (u32)TAB_LUT_WORDS ? w : w - TAB_LUT_WORDS;
+        tab[TAB_DESC + w] = (u32)src[2 * k] | ((u32)src[2 * k + 1] << 16);
+    }
+}
+
+gtars_status launch_igd_tile_tables(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
+                                    const i32 *tile_carry, u32 n_tiles, i32 *pm, unsigned short *files16, u32 *tile_tab, hipStream_t st) {
+    if (!n_tiles) return GTARS_OK;
+    hipLaunchKernelGGL(k_igd_tile_tables, dim3(n_tiles), dim3(SW_TPB), 0, st, v, tile_first, tile_cnt, tile_chrom, tile_carry, n_tiles, pm,
+                       files16, tile_tab);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
+// ---- the sweep -------------------------------------------------------------------------------------------------------
 // Query k of a block of SW_TPB goes to wave k % NWV, group (k / NWV) % NG, slot k / (NWV * NG): the first 64 queries of a tile
 // land on 64 different (wave, group) pairs, so a sparse batch (a LOLA universe: ~40 queries per tile) still spreads over every
 // wave, and a dense one gives every group the same number of queries.
 __device__ __forceinline__ u32 sweep_query_slot(int lane, int wave) {
     constexpr int GL = IGD_GROUP_LANES, NG = 64 / GL, NWV = SW_TPB / 64;
-#ifdef IGD_MAP_COALESCED
-    return (u32)wave * 64u + (u32)lane;
-#else
     return ((u32)(lane % GL) * NG + (u32)(lane / GL)) * NWV + (u32)wave;
-#endif
 }
 
-// register budget = what the LDS footprint admits anyway: 4 workgroups per CU (8 waves per SIMD, 64 VGPRs) for the pairwise
-// form, 3 (80 VGPRs) with the staged pme_file column; the credited-file-list form keeps its 16 list registers
+// MODE 0: pairwise counts (count_set_overlaps); 1: binary counts (count_region_hits) with a per-query list of credited
+// files; 2: binary counts for min_overlap == 1 through pme_file -- a record is the FIRST hit of its file for a query iff
+// no earlier record of that file (and chromosome) ends after the query's start: earlier records start no later, so
+// "ends after q.start" is all that is left of the overlap test, and the largest such end is a per-record constant of
+// the database (IgdTiles::pme_file).  Binary counting then costs what pairwise counting costs.
+// MO1: min_overlap == 1 (a candidate record is a hit iff its end is > q_start; its start is not read).
+// Register budget = what the LDS footprint admits: 4 workgroups per CU (8 waves per SIMD, 64 VGPRs) for the pairwise form,
+// 3 (80 VGPRs) with the staged pme_file column; the credited-file-list form keeps its 16 list registers.
 template <int MODE, bool MO1>
 __global__ void __launch_bounds__(SW_TPB, MODE == 0 ? 8 : MODE == 2 ? 6 : 4)
-k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
-            const u32 *__restrict__ tile_chrom, const i32 *__restrict__ tile_carry, u32 n_tiles,
-            const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
-            const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap,
-            unsigned long long *__restrict__ hits, const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab,
-            const u32 *__restrict__ part_ql) {
+k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__ pm, const unsigned short *__restrict__ files16,
+            const u32 *__restrict__ tile_tab, u32 n_tiles, const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
+            const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap, unsigned long long *__restrict__ hits,
+            const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab, const u32 *__restrict__ part_ql) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
-    // whether the batch had to be partitioned was decided on the device (k_igd_prep_queries): take the partition's
+    // whether the batch had to be partitioned was decided on the device (the routing kernel): take the partition's
     // interleaved (start, end) pairs and bin offsets, or the batch as it arrived with the tile ranges
     if (part_flag && *part_flag) {
         sqs = part_ab;
@@ -272,176 +597,84 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
     constexpr int CAP = IGD_TILE + IGD_HALO;
     i32 *t_s = reinterpret_cast<i32 *>(sm);
     i32 *t_e = t_s + CAP;
-    // file ids as u16 (the LDS histogram limits a database to 16384 files): 4.5 KB less per workgroup -- with the chunk arrays
-    // below it decides between 2 and 3 workgroups per CU for the pme-binary form, and every workgroup less costs 20-75 %
-    unsigned short *t_f = reinterpret_cast<unsigned short *>(t_e + CAP);
+    i32 *t_pm = t_e + CAP;                             // prefix maximum of the ends (IgdTiles::pm)
+    i32 *t_pf = t_pm + CAP;                            // MODE 2: pme_file of the staged records
+    unsigned short *t_f = reinterpret_cast<unsigned short *>(t_pf + (MODE == 2 ? CAP : 0));  // file ids, u16; CAP is even
+    u32 *bins = reinterpret_cast<u32 *>(t_f + CAP);    // [n_files]
+    __shared__ u32 s_lutw[2 * TAB_LUT_WORDS];
+    const unsigned short *lut_s = reinterpret_cast<const unsigned short *>(s_lutw);
+    const unsigned short *lut_p = reinterpret_cast<const unsigned short *>(s_lutw + TAB_LUT_WORDS);
     constexpr bool BINARY = MODE == 1;
-    i32 *t_pm = reinterpret_cast<i32 *>(t_f + CAP);  // prefix maximum of the ends (carry-in included); CAP is even
-    i32 *t_pf = t_pm + CAP;                           // MODE 2: pme_file of the staged records
-    u32 *bins = reinterpret_cast<u32 *>(t_pf + (MODE == 2 ? CAP : 0));  // [n_files]
-    __shared__ i32 s_wmax[SW_TPB / 64];
-    __shared__ unsigned short lut_s[LUT_NB + 2], lut_p[LUT_NB + 2];
-    __shared__ i32 s_lutdesc[6];
     for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
-
-    // Software pipeline over the workgroup's tiles: the NEXT tile's records are loaded into registers
-    // before the current tile's queries are served and committed to LDS afterwards, so their HBM latency
-    // hides behind the LDS-bound query loop.
     constexpr int RPT = (CAP + SW_TPB - 1) / SW_TPB;
-    i32 rg_s[RPT], rg_e[RPT], rg_p[MODE == 2 ? RPT : 1];
-    u32 rg_f[RPT];
-    struct TileDesc {
-        u32 p0, cnt, c, seg_hi, n_lds;
-        i32 carry;
-    };
-    auto describe = [&](u32 t) {
-        TileDesc d;
-        d.p0 = tile_first[t];
-        d.cnt = tile_cnt[t];
-        d.c = tile_chrom[t];
-        d.seg_hi = v.chrom_off[d.c + 1];
-        d.n_lds = min((u32)CAP, d.seg_hi - d.p0);  // tile + halo, never past the chromosome
-        d.carry = tile_carry[t];
-        return d;
-    };
-    auto issue = [&](const TileDesc &d) {
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const u32 i = threadIdx.x + (u32)k * SW_TPB;
-            if (i < d.n_lds) {
-                rg_s[k] = v.starts[d.p0 + i];
-                rg_e[k] = v.ends[d.p0 + i];
-                rg_f[k] = v.files[d.p0 + i];
-                if (MODE == 2) rg_p[MODE == 2 ? k : 0] = pme_file[d.p0 + i];
-            }
-        }
-    };
-    auto commit = [&](const TileDesc &d) {
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const u32 i = threadIdx.x + (u32)k * SW_TPB;
-            if (i < d.n_lds) {
-                t_s[i] = rg_s[k];
-                t_e[i] = rg_e[k];
-                t_f[i] = (unsigned short)rg_f[k];
-                if (MODE == 2) t_pf[i] = rg_p[MODE == 2 ? k : 0];
-            }
-        }
-    };
-    TileDesc cur{}, nxt{};
-    if (blockIdx.x < n_tiles) {
-        cur = describe(blockIdx.x);
-        issue(cur);
-        __syncthreads();  // bins zeroed
-        commit(cur);
-    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #if IGD_STAMPS
     u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        // the tile's first SW_TPB queries: loaded now, used after the scan and the table build (MODE 0 / 2)
+        const u32 *__restrict__ tab = tile_tab + (size_t)tile * TAB_WORDS;  // uniform: the descriptor comes by scalar loads
+        const u32 p0 = tab[0], cnt = tab[1], n_lds = tab[3], n_seg = tab[10];
+        const i32 S0 = (i32)tab[4], S1 = (i32)tab[5], P0 = (i32)tab[7], P1 = (i32)tab[8];
+        const u32 sh_s = tab[6], sh_p = tab[9];
+        (void)cnt;
         const u32 q_lo = ql[tile], q_hi = (GTARS_IGD_ABLATE & 8) ? q_lo : qh[tile];
+        // the tile's first SW_TPB queries: loaded now, used once the tile is staged (MODE 0 / 2)
         i32 pf_s = 0, pf_e = 0;
         if constexpr (MODE != 1) {
-            const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-            const u32 qi = q_lo + sweep_query_slot(lane_, wave_);
+            const u32 qi = q_lo + sweep_query_slot(lane, wave);
             if (qi < q_hi) {
                 if (interleaved) {
                     const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
                     pf_s = (i32)se2.x;
                     pf_e = (i32)se2.y;
                 } else {
-                    pf_s = (i32)sqs[qi];
+                    pf_s = max((i32)sqs[qi], 0);  // raw column of an in-order batch: the start clamp (igd.rs:517) here
                     pf_e = (i32)sqe[qi];
                 }
             }
         }
-        __syncthreads();  // the current tile is in LDS
-        STAMP(0);
+        // stage the tile: records + the search tables.  No register prefetch across the query phase: with 3 - 4 workgroups per
+        // CU the other workgroups' query phases cover this one's loads (measured: prefetching one tile ahead bought nothing and
+        // cost 15 registers).
         {
-            // t_pm[i] = max(carry, ends[0..i]): ascending, so "first record that can overlap a query" is a
-            // binary search for t_pm > q_start.  Blocked layout: thread t owns records [t*RPT, (t+1)*RPT).
-            const u32 base = threadIdx.x * RPT;
-            i32 loc[RPT];
-            i32 run = 0;  // ends are > 0 (Igd::add drop rule)
+            i32 rs[RPT], re[RPT], rp[RPT], rq[MODE == 2 ? RPT : 1];
+            unsigned short rf[RPT];
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                const u32 i = base + k;
-                run = max(run, i < cur.n_lds ? t_e[i] : 0);
-                loc[k] = run;
+                const u32 i = threadIdx.x + (u32)k * SW_TPB;
+                if (i < n_lds) {
+                    rs[k] = v.starts[p0 + i];
+                    re[k] = v.ends[p0 + i];
+                    rp[k] = pm[p0 + i];
+                    rf[k] = files16[p0 + i];
+                    if (MODE == 2) rq[MODE == 2 ? k : 0] = pme_file[p0 + i];
+                }
             }
-            // exclusive maximum over the threads before this one: wave shuffles, then one LDS word per wave
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            const i32 inc = wave_inclusive_max_nonneg(run);  // ends are > 0
-            if (lane == 63) s_wmax[wave] = inc;
-            const i32 excl = __builtin_amdgcn_update_dpp(0, inc, 0x138, 0xf, 0xf, false);  // wave_shr:1; lane 0 gets 0
-            __syncthreads();
-            i32 before = cur.carry, all_max = cur.carry;
+            u32 lw[2];
 #pragma unroll
-            for (int w = 0; w < SW_TPB / 64; ++w) {
-                const i32 x = s_wmax[w];
-                before = max(before, w < wave ? x : 0);
-                all_max = max(all_max, x);
-            }
-            before = max(before, excl);
-            // Direct-mapped tables over the tile's two ascending key arrays (starts, prefix-max ends): lut[b] = first record
-            // whose key falls in bucket >= b, bucket(x) = (x - first key) >> shift with shift chosen so that the last key lands
-            // in a bucket < LUT_NB.  A query's two binary searches then start from a range of a handful of records instead of
-            // the whole tile: 2 + ~3 dependent LDS round trips instead of 12 (the searches were 0.19 of the sweep's 0.41 ms).
-            const u32 n = cur.n_lds;
-            const i32 S0 = __builtin_amdgcn_readfirstlane(t_s[0]), S1 = __builtin_amdgcn_readfirstlane(t_s[n - 1]);
-            const i32 P0 = __builtin_amdgcn_readfirstlane(max(cur.carry, t_e[0])), P1 = __builtin_amdgcn_readfirstlane(all_max);
-            const u32 sh_s = lut_shift((u32)(S1 - S0)), sh_p = lut_shift((u32)(P1 - P0));
-            if (threadIdx.x == 0) {
-                s_lutdesc[0] = S0;
-                s_lutdesc[1] = S1;
-                s_lutdesc[2] = (i32)sh_s;
-                s_lutdesc[3] = P0;
-                s_lutdesc[4] = P1;
-                s_lutdesc[5] = (i32)sh_p;
+            for (int k = 0; k < 2; ++k) {
+                const u32 w = threadIdx.x + (u32)k * SW_TPB;
+                lw[k] = w < 2u * TAB_LUT_WORDS ? tab[TAB_DESC + w] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                const u32 i = base + k;
-                if (i < n) t_pm[i] = max(before, loc[k]);
-            }
-            __syncthreads();
-            STAMP(1);
-            // table build, one record per thread and step: buckets (bucket of the previous key, bucket of this key] start at
-            // record i; record 0 opens bucket 0; the buckets behind the last key mean "no such record"
-            {
-                // the buckets behind the last key, by all threads (disjoint from the buckets the loop below writes)
-                const u32 last_s = (u32)(S1 - S0) >> sh_s, last_p = (u32)(P1 - P0) >> sh_p;
-                for (u32 b = threadIdx.x; b <= (u32)LUT_NB; b += SW_TPB) {
-                    if (b > last_s) lut_s[b] = (unsigned short)n;
-                    if (b > last_p) lut_p[b] = (unsigned short)n;
+                const u32 i = threadIdx.x + (u32)k * SW_TPB;
+                if (i < n_lds) {
+                    t_s[i] = rs[k];
+                    t_e[i] = re[k];
+                    t_pm[i] = rp[k];
+                    t_f[i] = rf[k];
+                    if (MODE == 2) t_pf[i] = rq[MODE == 2 ? k : 0];
                 }
             }
-#pragma unroll 1
-            for (u32 i = threadIdx.x; i < n; i += SW_TPB) {
-                const i32 st = t_s[i], pm = t_pm[i];
-                const u32 bs1 = (u32)(st - S0) >> sh_s, bp1 = (u32)(pm - P0) >> sh_p;
-                u32 bs0 = 0, bp0 = 0;
-                if (i) {
-                    bs0 = ((u32)(t_s[i - 1] - S0) >> sh_s) + 1u;
-                    bp0 = ((u32)(t_pm[i - 1] - P0) >> sh_p) + 1u;
-                }
-                for (; bs0 <= bs1; ++bs0) lut_s[bs0] = (unsigned short)i;
-                for (; bp0 <= bp1; ++bp0) lut_p[bp0] = (unsigned short)i;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const u32 w = threadIdx.x + (u32)k * SW_TPB;
+                if (w < 2u * TAB_LUT_WORDS) s_lutw[w] = lw[k];
             }
-            __syncthreads();
         }
-        STAMP(2);
-        const u32 next = tile + gridDim.x;
-#if IGD_PREFETCH
-        if (next < n_tiles) {
-            nxt = describe(next);
-            issue(nxt);
-        }
-#endif
-        const u32 p0 = cur.p0, cnt = cur.cnt, c = cur.c, seg_hi = cur.seg_hi, n_lds = cur.n_lds;
-        const i32 max_len = v.chrom_maxlen[c];
-        const u32 n_seg = seg_hi - p0;  // records from the tile start to the end of the chromosome
+        __syncthreads();  // the tile is in LDS (and, first tile, the bins are zeroed)
+        STAMP(0);
         // record i (relative to p0): LDS if staged, global otherwise (rare: scans longer than the halo)
         auto r_start = [&](u32 i) -> i32 { return i < n_lds ? t_s[i] : v.starts[p0 + i]; };
         auto r_end = [&](u32 i) -> i32 { return i < n_lds ? t_e[i] : v.ends[p0 + i]; };
@@ -449,26 +682,14 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
         if constexpr (MODE != 1) {
             // A hit is decided by the (query, record) PAIR alone.  A query's candidates are the records [lo, hi): lo = first
             // record that can overlap it (prefix-max end > q_start), hi = first record that starts at or after q_end (the
-            // reference's scan stops there, igd.rs:772-846).  Waves work on their own, 64 queries at a time, no workgroup
-            // barrier inside a tile: (1) one lane per query finds (lo, hi) with two LDS binary searches; (2) the pairs are
-            // walked by GROUPS of GL lanes -- group g takes the queries of its own GL lanes one after the other, its lanes
-            // read CONSECUTIVE records (conflict-free LDS reads; the thread-per-pair-run loop before read three random words
-            // per pair and spent 45 VALU instructions per pair slot: LDS 60 % busy, half of it bank conflicts).
-            // For min_overlap == 1 (MO1) a candidate record is a hit iff its end is > q_start: its start is < q_end by
-            // construction of hi, so the start is not even read.  Records past the staged range (rare) are scanned by the
-            // query's own lane from global memory.
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            constexpr int GL = IGD_GROUP_LANES, NG = 64 / GL, NWV = SW_TPB / 64;
+            // reference's scan stops there, igd.rs:772-846).  Waves work on their own, no workgroup barrier inside a tile:
+            // (1) one lane per query finds (lo, hi) through the tile's search tables, the two searches advancing together;
+            // (2) the pairs are walked by GROUPS of GL lanes -- group g takes the queries of its own GL lanes one after the
+            // other, its lanes read CONSECUTIVE records.  Records past the staged range (rare) are scanned by the query's own
+            // lane from global memory.
+            constexpr int GL = IGD_GROUP_LANES;
             const int grp = lane / GL, sub = lane % GL;
-            static_assert(GL * NG == 64, "groups tile the wave");
-            // Query k of a block of SW_TPB goes to wave k % NWV, group (k / NWV) % NG, slot k / (NWV * NG): the first 64 queries
-            // of a tile land on 64 different (wave, group) pairs, so a sparse batch (a LOLA universe: ~40 queries per tile)
-            // still spreads over every wave, and a dense one gives every group the same number of queries.
             const u32 kq = sweep_query_slot(lane, wave);
-            // the same for every lane: kept in scalar registers
-            const i32 S0 = __builtin_amdgcn_readfirstlane(s_lutdesc[0]), S1 = __builtin_amdgcn_readfirstlane(s_lutdesc[1]);
-            const i32 P0 = __builtin_amdgcn_readfirstlane(s_lutdesc[3]), P1 = __builtin_amdgcn_readfirstlane(s_lutdesc[4]);
-            const u32 sh_s = (u32)__builtin_amdgcn_readfirstlane(s_lutdesc[2]), sh_p = (u32)__builtin_amdgcn_readfirstlane(s_lutdesc[5]);
             for (u32 qb = q_lo; qb < q_hi; qb += SW_TPB) {
                 const u32 qi = qb + kq;
                 i32 s = 0, e = 0;
@@ -482,18 +703,15 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                         s = (i32)se2.x;
                         e = (i32)se2.y;
                     } else {
-                        s = (i32)sqs[qi];
+                        s = max((i32)sqs[qi], 0);
                         e = (i32)sqe[qi];
                     }
-                    u32 hi;
-                    u32 a, b = n_lds;
+                    u32 hi, a, b;
                     if (GTARS_IGD_ABLATE & 16) {
                         lo = ((u32)s * 2654435761u) % (n_lds > 40 ? n_lds - 40 : 1u);
                         a = lo + 20;
-                        b = a;
-                    } else if (min_overlap >= 1) {
-                        // lo = first record with prefix-max end > s (>= s + 1), a = first record with start >= e: both through
-                        // their tables, the two searches advance together (their LDS reads overlap)
+                    } else {
+                        // lo = first record with prefix-max end > s (>= s + 1), a = first record with start >= e
                         lut_range(lut_p, s + 1, P0, P1, sh_p, n_lds, lo, hi);
                         lut_range(lut_s, e, S0, S1, sh_s, n_lds, a, b);
                         while (lo < hi || a < b) {
@@ -513,26 +731,8 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                                     b = m2;
                             }
                         }
-                    } else {
-                        const i32 key = s > max_len ? s - max_len : 0;
-                        hi = cnt;
-                        while (lo < hi) {
-                            const u32 mid = lo + ((hi - lo) >> 1);
-                            if (t_s[mid] < key)
-                                lo = mid + 1;
-                            else
-                                hi = mid;
-                        }
-                        a = lo;
-                        while (a < b) {
-                            const u32 mid = a + ((b - a) >> 1);
-                            if (t_s[mid] < e)
-                                a = mid + 1;
-                            else
-                                b = mid;
-                        }
                     }
-                    len = a - lo;
+                    len = a - lo;  // a >= lo: every record before lo ends at or before s, hence starts before e
                     if (!(GTARS_IGD_ABLATE & 16) && a == n_lds && n_seg > n_lds) {
                         // the scan runs past the staged records: the rest from global memory, by this lane
                         for (u32 r = max(lo, n_lds); r < n_seg; ++r) {
@@ -547,8 +747,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                 }
                 if (GTARS_IGD_ABLATE & 1) len = min(len, 1u);
                 STAMP(3);
-                // the group's GL queries, IGD_PAIR_UNROLL at a time: their candidate reads (end, file id, [start, pme_file])
-                // are issued together, so that one LDS round trip serves every query of the step
+                // the group's GL queries, IGD_PAIR_UNROLL at a time (their candidate reads issued together)
                 constexpr int U = IGD_PAIR_UNROLL;
                 static_assert(GL % U == 0, "slots per step divide the group");
 #pragma unroll 1
@@ -606,34 +805,21 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                 s = (i32)se2.x;
                 e = (i32)se2.y;
             } else {
-                s = (i32)sqs[qi];
+                s = max((i32)sqs[qi], 0);
                 e = (i32)sqe[qi];
             }
-            u32 lo = 0, hi;
-            if (min_overlap >= 1) {
-                // an overlap of >= 1 bp needs end > q_start: start at the first staged record whose prefix-max
-                // end is > q_start.  It is never before lower_bound(q_start - max_len) (everything in between
-                // ends at or before q_start), so ownership by this tile still holds; if no staged record
-                // qualifies the scan goes on in global memory from the end of the staged range.
-                hi = n_lds;
-                while (lo < hi) {
-                    const u32 mid = lo + ((hi - lo) >> 1);
-                    if (t_pm[mid] <= s)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-            } else {
-                const i32 key = s > max_len ? s - max_len : 0;
-                // lower_bound of key: inside the tile by ownership
-                hi = cnt;
-                while (lo < hi) {
-                    const u32 mid = lo + ((hi - lo) >> 1);
-                    if (t_s[mid] < key)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
+            // an overlap of >= 1 bp needs end > q_start: start at the first staged record whose prefix-max
+            // end is > q_start.  It is never before lower_bound(q_start - max_len) (everything in between
+            // ends at or before q_start), so ownership by this tile still holds; if no staged record
+            // qualifies the scan goes on in global memory from the end of the staged range.
+            u32 lo, hi;
+            lut_range(lut_p, s + 1, P0, P1, sh_p, n_lds, lo, hi);
+            while (lo < hi) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (t_pm[mid] <= s)
+                    lo = mid + 1;
+                else
+                    hi = mid;
             }
             // binary counting: the files already credited to this query, as packed u16 pairs in
             // registers (no memory latency in the membership test); 0xFFFF = empty (n_files <= 16384)
@@ -642,24 +828,20 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
 #pragma unroll
             for (int k = 0; k < IGD_SEEN / 2; ++k) sl[k] = 0xFFFFFFFFu;
             for (u32 r = lo; r < ((GTARS_IGD_ABLATE & 1) ? min(n_seg, lo + 1u) : n_seg); ++r) {
-                // the three fields of a record in one LDS round trip
-                i32 rs, re, pf = 0;
+                i32 rs, re;
                 u32 f;
                 if (r < n_lds) {
                     rs = t_s[r];
                     re = t_e[r];
                     f = t_f[r];
-                    if (MODE == 2) pf = t_pf[r];
                 } else {
                     rs = v.starts[p0 + r];
                     re = v.ends[p0 + r];
                     f = v.files[p0 + r];
-                    if (MODE == 2) pf = pme_file[p0 + r];
                 }
                 if (rs >= e) break;
                 const i32 ov = (re < e ? re : e) - (rs > s ? rs : s);
                 if (ov < min_overlap) continue;
-                if (MODE == 2 && pf > s) continue;  // an earlier record of this file already hit the query
                 if (BINARY) {
                     // credit (query, file) only at its first hit in database order (igd.rs:563-590):
                     // compare with the files already credited to this query
@@ -697,15 +879,6 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
         STAMP(3);
         __syncthreads();  // every query of the current tile served: LDS may be overwritten
         STAMP(5);
-        if (next < n_tiles) {
-#if !IGD_PREFETCH
-            nxt = describe(next);
-            issue(nxt);
-#endif
-            commit(nxt);
-            cur = nxt;
-        }
-        STAMP(6);
     }
 #if IGD_STAMPS
     if (threadIdx.x == 0) {
@@ -936,7 +1109,6 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     const u32 nq = (u32)nq64;
     const u32 n_tiles = tl.n_tiles;
     if (ws_bytes < igd_sweep_ws_bytes(nq, n_tiles, v.n_chrom)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
-    GT_HIP(hipMemsetAsync(hits, 0, sizeof(u64) * v.n_files, st));
     u32 *kc = (u32 *)ws, *ks = kc + nq, *ke = ks + nq;
     u32 *sc = ke + nq, *ss = sc + nq, *se = ss + nq, *perm = se + nq;  // perm doubles as the owner-tile column
     u32 *ql = perm + nq, *qh = ql + n_tiles, *cq_off = qh + n_tiles;
@@ -945,25 +1117,60 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     void *scratch = (void *)(((uintptr_t)(d_unsorted + 16) + 63) & ~(uintptr_t)63);
     const size_t scratch_bytes = ws_bytes - (size_t)((char *)scratch - (char *)ws);
     (void)sc;
-    // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the preparation kernel only ever raises the flag
-    GT_HIP(hipMemsetAsync(d_unsorted, getenv("GTARS_IGD_ALWAYS_SORT") ? 1 : 0, 1, st));
-    GT_HIP(hipMemsetAsync((char *)d_unsorted + 1, 0, 3, st));
-    // queries grouped by owner tile in one partition pass, when the tile bounds fit in LDS (76M records); otherwise
+    // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the routing kernel only ever raises the flag
+    const u32 flag0 = getenv("GTARS_IGD_ALWAYS_SORT") ? 1u : 0u;
+    // queries grouped by owner tile in one partition, when the tile bounds fit in LDS (76M records); otherwise
     // (and for GTARS_IGD_FULL_SORT=1) the batch is fully sorted by (chromosome, start) with the radix sort
     const bool full_sort = getenv("GTARS_IGD_FULL_SORT") != nullptr;  // tests / A-B runs
-    const bool bucket = !full_sort && tl.bnd && n_tiles + 1 <= MS_MAX_BINS;
+    const size_t prep_lds = ((size_t)n_tiles + v.n_chrom + 1) * 4;
+    const bool bucket = !full_sort && tl.bnd && n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024;
+    // routing and histogram fused (no prepared columns at all): when the routing kernel's LDS image fits and a workgroup's
+    // chunk fits its 16-bit counters
+    const u32 rt_wg = multisplit_workgroups(nq);
+    const u32 rt_chunk = multisplit_chunk(nq);  // a multiple of the 4 queries a lane takes per step
+    const size_t rt_lds = igd_route_lds_bytes(n_tiles, v.n_chrom, tl.route_n);
+    const bool fused = bucket && tl.route_lut && rt_lds <= 160 * 1024 - 64 && rt_chunk <= 65535u && !getenv("GTARS_IGD_NO_FUSED_ROUTE");
     int dev = 0, cus = 256;
     GT_HIP(hipGetDevice(&dev));
     GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    static std::mutex attr_mu;
     {
+        u32 *d_tot0 = fused ? multisplit_totals(scratch, n_tiles + 1, nq) : nullptr;
+        const u32 n_tot0 = d_tot0 ? n_tiles + 1 : 0u, n_init = std::max<u32>(std::max<u32>(v.n_files, n_tot0), 1u);
+        hipLaunchKernelGGL(k_igd_call_init, dim3((n_init + 255) / 256), dim3(256), 0, st, (unsigned long long *)hits, v.n_files, d_unsorted,
+                           flag0, d_tot0, n_tot0);
+    }
+    if (fused) {
+        if (scratch_bytes < multisplit_ws_bytes(n_tiles + 1, nq)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
+        {
+            static bool done[64] = {};
+            std::lock_guard<std::mutex> lock(attr_mu);
+            if (dev >= 0 && dev < 64 && !done[dev]) {
+                GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_igd_route<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_igd_route<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                done[dev] = true;
+            }
+        }
+        u32 *d_tot = multisplit_totals(scratch, n_tiles + 1, nq);  // null: the one-level split wants the per-workgroup table
+        const bool vec = ((((uintptr_t)qc) | ((uintptr_t)qs) | ((uintptr_t)qe)) & 15u) == 0 && (((uintptr_t)perm) & 7u) == 0;
+        ProfScope p("k_igd_route", st);
+        hipLaunchKernelGGL(vec ? k_igd_route<true> : k_igd_route<false>, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom,
+                           tl.bnd, tl.chrom_tile_off, tl.route_base, tl.route_len, tl.route_lut, tl.route_n, tl.route_shift, n_tiles,
+                           rt_chunk, reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted);
+    } else {
         ProfScope p("k_igd_prep_queries", st);
         const u32 n_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
         const u32 chunk = ((nq + n_wg - 1) / n_wg + PREP_TPB - 1) / PREP_TPB * PREP_TPB;
-        const size_t lds = bucket ? ((size_t)n_tiles + v.n_chrom + 1) * 4 : 0;
+        const size_t lds = bucket ? prep_lds : 0;
         auto kern = bucket ? k_igd_prep_queries<true> : k_igd_prep_queries<false>;
-        if (lds > 48 * 1024)
-            GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((MS_MAX_BINS + 4096) * 4)));
+        if (lds > 48 * 1024) {
+            static bool done[64] = {};
+            std::lock_guard<std::mutex> lock(attr_mu);
+            if (dev >= 0 && dev < 64 && !done[dev]) {
+                GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                done[dev] = true;
+            }
+        }
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(PREP_TPB), lds, st, qc, qs, qe, nq, v.n_chrom, tl.bnd, tl.chrom_tile_off, n_tiles,
                            chunk, kc, ks, ke, perm, d_unsorted);
     }
@@ -972,23 +1179,35 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     const u32 *part_flag = nullptr, *part_ab = nullptr, *part_ql = nullptr;
     u32 h_unsorted = 1;
     if (bucket) {
-        // No host round trip: both continuations are enqueued and the flag the preparation kernel leaves on the device
+        // No host round trip: both continuations are enqueued and the flag the routing kernel leaves on the device
         // picks one -- the partition kernels return at once for a batch that is already in owner order, the range
         // kernels for one that is not, and the sweep takes its inputs accordingly.
         // K1 (multisplit): (start, end) pairs grouped by owner tile; bin_off[t], bin_off[t + 1] bound tile t's queries
-        gtars_status s1 = multisplit_pairs(perm, ks, ke, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off, scratch,
-                                           scratch_bytes, st, d_unsorted);  // ss and se are adjacent: 2 * nq words
+        gtars_status s1 = fused ? multisplit_pairs(perm, true, qs, qe, true, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
+                                                   scratch, scratch_bytes, st, d_unsorted, true)
+                                : multisplit_pairs(perm, false, ks, ke, false, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
+                                                   scratch, scratch_bytes, st, d_unsorted, false);  // ss and se are adjacent: 2 * nq words
         if (s1) return s1;
         part_flag = d_unsorted;
         part_ab = ss;
         part_ql = bin_off;
-        ss = ks;
-        se = ke;
+        // the in-order continuation reads the batch where it lies: the caller's raw columns (fused; clamped on the way) or
+        // the prepared ones
+        const u32 *oc = fused ? qc : kc;
+        ss = const_cast<u32 *>(fused ? qs : ks);
+        se = const_cast<u32 *>(fused ? qe : ke);
         ProfScope p("k_igd_tile_ranges", st);
-        hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, kc, (const u32 *)nullptr, nq,
-                           v.n_chrom, cq_off, d_unsorted);
-        hipLaunchKernelGGL(k_igd_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles, ss,
-                           cq_off, ql, qh, d_unsorted);
+        if (fused) {
+            hipLaunchKernelGGL(k_igd_chrom_segments<true>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, oc, qs, qe, (const u32 *)nullptr,
+                               nq, v.n_chrom, cq_off, d_unsorted);
+            hipLaunchKernelGGL(k_igd_tile_ranges<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles,
+                               ss, cq_off, ql, qh, d_unsorted);
+        } else {
+            hipLaunchKernelGGL(k_igd_chrom_segments<false>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, oc, (const u32 *)nullptr,
+                               (const u32 *)nullptr, (const u32 *)nullptr, nq, v.n_chrom, cq_off, d_unsorted);
+            hipLaunchKernelGGL(k_igd_tile_ranges<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles,
+                               ss, cq_off, ql, qh, d_unsorted);
+        }
     } else {
         if (!getenv("GTARS_IGD_ALWAYS_SORT")) {
             GT_HIP(hipMemcpyAsync(&h_unsorted, d_unsorted, sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -1006,13 +1225,14 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
             se = ke;
         }
         ProfScope p("k_igd_tile_ranges", st);
-        hipLaunchKernelGGL(k_igd_chrom_segments, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, kc, perm, nq, v.n_chrom, cq_off,
-                           (const u32 *)nullptr);
-        hipLaunchKernelGGL(k_igd_tile_ranges, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles, ss,
+        hipLaunchKernelGGL(k_igd_chrom_segments<false>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, kc, (const u32 *)nullptr,
+                           (const u32 *)nullptr, perm, nq, v.n_chrom, cq_off, (const u32 *)nullptr);
+        hipLaunchKernelGGL(k_igd_tile_ranges<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles, ss,
                            cq_off, ql, qh, (const u32 *)nullptr);
     }
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
-    // starts | ends | files (u16) | prefix-max ends | [pme_file] | bins
+    if (!tl.pm || !tl.files16 || !tl.tab) return fail(GTARS_ERR_INTERNAL, "IGD sweep: the per-tile tables were not built");
+    // starts | ends | prefix-max ends | [pme_file] | files (u16) | bins
     const size_t lds = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14) + (((size_t)v.n_files + 1) & ~(size_t)1) * 4;
     const bool mo1 = min_overlap == 1;
     auto kern = mode == 2 ? k_igd_sweep<2, true> : mode == 1 ? k_igd_sweep<1, false> : mo1 ? k_igd_sweep<0, true> : k_igd_sweep<0, false>;
@@ -1037,7 +1257,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     const unsigned grid = (unsigned)std::min<u64>((u64)cus * per_cu, n_tiles);
     {
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.first, tl.cnt, tl.chrom, tl.carry, n_tiles, ss, se,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.pm, tl.files16, tl.tab, n_tiles, ss, se,
                            interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql);
     }
     GT_HIP(hipGetLastError());
@@ -1049,6 +1269,14 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
 }  // namespace gtars
 
 #if IGD_STAMPS
+extern "C" int gtars_debug_route_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gtars::g_route_stamps), 64) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gtars::g_route_stamps), z, 64) != hipSuccess) return 1;
+    }
+    return 0;
+}
 extern "C" int gtars_debug_sweep_stamps(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gtars::g_sweep_stamps), 64) != hipSuccess) return 1;
     if (reset) {

@@ -125,8 +125,9 @@ k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 
 // Large splits therefore go through k_split_pass below (tiles reordered by bin in LDS, stores leave as runs): 0.12 ms.
 constexpr int MS_TPB = 1024;
 
+template <class KeyT>
 __global__ void __launch_bounds__(MS_TPB)
-k_ms_hist(const u32 *__restrict__ key, u32 n, u32 n_bins, u32 chunk, u32 *__restrict__ table, const u32 *__restrict__ run_if) {
+k_ms_hist(const KeyT *__restrict__ key, u32 n, u32 n_bins, u32 chunk, u32 *__restrict__ table, const u32 *__restrict__ run_if) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 ms_bins[];
     for (u32 b = threadIdx.x; b < n_bins; b += MS_TPB) ms_bins[b] = 0;
@@ -137,7 +138,7 @@ k_ms_hist(const u32 *__restrict__ key, u32 n, u32 n_bins, u32 chunk, u32 *__rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const u32 i = base + (u32)j * MS_TPB + threadIdx.x;
-            k[j] = i < hi ? key[i] : 0xFFFFFFFFu;
+            k[j] = i < hi ? (u32)key[i] : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -167,9 +168,11 @@ __global__ void k_ms_colscan(u32 *__restrict__ table, u32 n_wg, u32 n_bins, u32 
     tot[b] = run;
 }
 
-// bin_off[0 .. n_bins] = exclusive scan of tot (one workgroup)
+// bin_off[0 .. n_bins] = exclusive scan of tot (one workgroup); for the two-level split (cur_a != null) also the cursors its
+// passes reserve runs from: cur_b[i] = bin_off[i], cur_a[j] = bin_off[j << shift] (was a launch of its own)
 __global__ void __launch_bounds__(MS_TPB)
-k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off, const u32 *__restrict__ run_if) {
+k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off, u32 shift, u32 *__restrict__ cur_a,
+             u32 *__restrict__ cur_b, const u32 *__restrict__ run_if) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     __shared__ u32 s_scan[MS_TPB / 64];
     __shared__ u32 s_carry;
@@ -181,7 +184,13 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off,
         u32 total;
         const u32 ex = block_exclusive_scan<MS_TPB>(v, s_scan, total);
         const u32 carry = s_carry;
-        if (b < n_bins) bin_off[b] = carry + ex;
+        if (b < n_bins) {
+            bin_off[b] = carry + ex;
+            if (cur_a) {
+                cur_b[b] = carry + ex;
+                if ((b & ((1u << shift) - 1u)) == 0) cur_a[b >> shift] = carry + ex;
+            }
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_carry = carry + total;
         __syncthreads();
@@ -189,8 +198,9 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off,
     if (threadIdx.x == 0) bin_off[n_bins] = s_carry;
 }
 
+template <class KeyT, bool CLAMP>
 __global__ void __launch_bounds__(MS_TPB)
-k_ms_scatter(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n, u32 n_bins, u32 chunk,
+k_ms_scatter(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n, u32 n_bins, u32 chunk,
              const u32 *__restrict__ table, const u32 *__restrict__ bin_off, u32 drop_bin, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 ms_bins[];
@@ -207,9 +217,10 @@ k_ms_scatter(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *
         for (int j = 0; j < U; ++j) {
             const u32 i = base + (u32)j * MS_TPB + threadIdx.x;
             const bool ok = i < hi;
-            k[j] = ok ? key[i] : drop_bin;
+            k[j] = ok ? (u32)key[i] : drop_bin;
             va[j] = ok ? a[i] : 0u;
             vb[j] = ok ? b[i] : 0u;
+            if (CLAMP) va[j] = (i32)va[j] < 0 ? 0u : va[j];
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) pos[j] = k[j] != drop_bin ? atomicAdd(&ms_bins[k[j]], 1u) : 0u;
@@ -220,7 +231,7 @@ k_ms_scatter(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *
     }
 }
 
-static u32 ms_workgroups(u32 n) {
+u32 multisplit_workgroups(u32 n) {
     // one persistent-sized grid: chunks of at least 16k elements, at most 256 workgroups
     const u32 by_size = (n + 16383) / 16384;
     return std::max<u32>(1, std::min<u32>(256, by_size));
@@ -240,18 +251,13 @@ constexpr int SP_TILE = SP_TPB * SP_ITEMS;
 constexpr int SP_BINS = 1024;
 static_assert(SP_BINS == SP_TPB, "one thread per tile-local bin (counter reset, layout scan, run reservation)");
 
-__global__ void k_split_init(const u32 *__restrict__ bin_off, u32 n_bins, u32 shift, u32 n_coarse, u32 *__restrict__ cur_a,
-                             u32 *__restrict__ cur_b, const u32 *__restrict__ run_if) {
-    if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_bins) cur_b[i] = bin_off[i];
-    if (i < n_coarse) cur_a[i] = bin_off[i << shift];
-}
-
-template <bool FINE>
+// KeyT: u32, or unsigned short when every bin fits 16 bits (2 bytes per element less to read and write in both passes).
+// CLAMP (first pass on raw query columns): a = max((i32)a, 0) -- the start clamp of Igd::count_overlaps (igd.rs:517) applied
+// on the way, so that no prepared copy of the columns is ever written.
+template <bool FINE, class KeyT, bool CLAMP>
 __global__ void __launch_bounds__(SP_TPB)
-k_split_pass(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
-             u32 shift, u32 drop_bin, u32 *__restrict__ cursor, u32 *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if) {
+k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
+             u32 shift, u32 drop_bin, u32 *__restrict__ cursor, KeyT *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 sp_lds[];
     u32 *s_k = sp_lds, *s_a = s_k + SP_TILE, *s_b = s_a + SP_TILE;
@@ -269,15 +275,16 @@ k_split_pass(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *
         for (int j = 0; j < SP_ITEMS; ++j) {
             const u32 i = base + (u32)j * SP_TPB + threadIdx.x;
             const bool ok = i < n;
-            k[j] = ok ? key[i] : 0xFFFFFFFFu;
+            k[j] = ok ? (u32)key[i] : 0xFFFFFFFFu;
+            if (k[j] == drop_bin) k[j] = 0xFFFFFFFFu;  // no owner: dropped here
             if (FINE) {
                 const uint2 p = ok ? ab_in[i] : make_uint2(0u, 0u);
                 va[j] = p.x;
                 vb[j] = p.y;
-                if (k[j] == drop_bin) k[j] = 0xFFFFFFFFu;  // no owner: dropped here
             } else {
                 va[j] = ok ? a[i] : 0u;
                 vb[j] = ok ? b[i] : 0u;
+                if (CLAMP) va[j] = (i32)va[j] < 0 ? 0u : va[j];
             }
             if (k[j] != 0xFFFFFFFFu) kmin = min(kmin, k[j]);
         }
@@ -331,7 +338,7 @@ k_split_pass(const u32 *__restrict__ key, const u32 *__restrict__ a, const u32 *
             const u32 x = FINE ? kk - bin0 : kk >> shift;
             const u32 pos = gbase[x] + (j - toff[x]);
             out_ab[pos] = make_uint2(s_a[j], s_b[j]);
-            if (!FINE) out_key[pos] = kk;
+            if (!FINE) out_key[pos] = (KeyT)kk;
         }
         __syncthreads();  // LDS reused by the next tile
     }
@@ -342,61 +349,99 @@ size_t multisplit_ws_bytes(u32 n_bins, u32 n) {
     return ((size_t)256 * n_bins + 2 * (size_t)n_bins + 1024 + 256) * 4 + (size_t)n * 12 + 256;
 }
 
-gtars_status multisplit_pairs(const u32 *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
-                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if) {
+// elements per workgroup of the counting / scatter grid: a multiple of 4 (callers that count the keys themselves take four
+// consecutive elements per lane)
+u32 multisplit_chunk(u32 n) {
+    const u32 n_wg = multisplit_workgroups(n);
+    return ((n + n_wg - 1) / n_wg + 3u) & ~3u;
+}
+u32 *multisplit_table(void *ws) { return (u32 *)ws; }
+static bool multisplit_two_level(u32 n_bins, u32 n) {
+    static const bool one_level = getenv("GTARS_MS_ONE_LEVEL") != nullptr;  // A/B
+    return n_bins > 1024 && n >= (1u << 20) && !one_level;
+}
+// where a table_ready caller of the two-level split leaves the bin TOTALS (zeroed by the caller, filled with atomics) instead of
+// per-workgroup rows; null when the split of (n_bins, n) is one-level and wants the table
+u32 *multisplit_totals(void *ws, u32 n_bins, u32 n) { return multisplit_two_level(n_bins, n) ? (u32 *)ws + (size_t)256 * n_bins : nullptr; }
+
+// KeyT / CLAMP: see k_split_pass.  table_ready: the caller's own kernel has already counted the keys into the table
+// (multisplit_table(ws), one row of n_bins counters per workgroup of a multisplit_workgroups(n) x MS_TPB grid whose workgroup w
+// covers elements [w * chunk, (w + 1) * chunk), chunk = ceil(n / workgroups)) -- the IGD routing kernel does, in the pass
+// that computes the keys.
+template <class KeyT, bool CLAMP>
+static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
+                                       u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready) {
     if (n_bins == 0 || n_bins > MS_MAX_BINS) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
     if (ws_bytes < multisplit_ws_bytes(n_bins, n)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
-    const u32 n_wg = ms_workgroups(n);
-    const u32 chunk = (n + n_wg - 1) / n_wg;
+    const u32 n_wg = multisplit_workgroups(n);
+    const u32 chunk = multisplit_chunk(n);
     u32 *table = (u32 *)ws, *tot = table + (size_t)256 * n_bins;
     u32 *cur_a = tot + n_bins, *cur_b = cur_a + 1024;
-    u32 *tmp_key = (u32 *)(((uintptr_t)(cur_b + n_bins) + 63) & ~(uintptr_t)63);
-    uint2 *tmp_ab = reinterpret_cast<uint2 *>(tmp_key + (((size_t)n + 15) & ~(size_t)15));
+    KeyT *tmp_key = (KeyT *)(((uintptr_t)(cur_b + n_bins) + 63) & ~(uintptr_t)63);
+    uint2 *tmp_ab = reinterpret_cast<uint2 *>(reinterpret_cast<u32 *>(tmp_key) + (((size_t)n + 15) & ~(size_t)15));
     const size_t lds = (size_t)n_bins * 4;
     constexpr size_t sp_lds = ((size_t)SP_TILE * 3 + (size_t)SP_BINS * 3) * 4;
-    static std::once_flag once[16];
+    // the dynamic-LDS limits belong to the functions (per device); a failed attempt is retried by the next call
+    static std::mutex mu;
+    static bool done[16] = {};
     int dev = 0;
     GT_HIP(hipGetDevice(&dev));
-    hipError_t attr_err = hipSuccess;
-    std::call_once(once[dev & 15], [&]() {
-        const void *fns[] = {reinterpret_cast<const void *>(k_ms_hist), reinterpret_cast<const void *>(k_ms_scatter)};
-        for (const void *fn : fns)
-            if (attr_err == hipSuccess)
-                attr_err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MS_MAX_BINS * 4));
-        const void *sp[] = {reinterpret_cast<const void *>(k_split_pass<false>), reinterpret_cast<const void *>(k_split_pass<true>)};
-        for (const void *fn : sp)
-            if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds);
-    });
-    GT_HIP(attr_err);
     {
-        ProfScope p("k_ms_hist", st);
-        hipLaunchKernelGGL(k_ms_hist, dim3(n_wg), dim3(MS_TPB), lds, st, key, n, n_bins, chunk, table, run_if);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done[dev & 15]) {
+            const void *fns[] = {reinterpret_cast<const void *>(k_ms_hist<KeyT>), reinterpret_cast<const void *>(k_ms_scatter<KeyT, CLAMP>)};
+            for (const void *fn : fns) GT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MS_MAX_BINS * 4)));
+            const void *sp[] = {reinterpret_cast<const void *>(k_split_pass<false, KeyT, CLAMP>),
+                                reinterpret_cast<const void *>(k_split_pass<true, KeyT, false>)};
+            for (const void *fn : sp) GT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds));
+            done[dev & 15] = true;
+        }
     }
+    if (!table_ready) {
+        ProfScope p("k_ms_hist", st);
+        hipLaunchKernelGGL(k_ms_hist<KeyT>, dim3(n_wg), dim3(MS_TPB), lds, st, key, n, n_bins, chunk, table, run_if);
+    }
+    const bool two_level = multisplit_two_level(n_bins, n);
     {
         ProfScope p("k_ms_scan", st);
-        hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot, run_if);
-        hipLaunchKernelGGL(k_ms_binscan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off, run_if);
-    }
-    static const bool one_level = getenv("GTARS_MS_ONE_LEVEL") != nullptr;  // A/B
-    if (n_bins > 1024 && n >= (1u << 20) && !one_level) {
+        if (!(table_ready && two_level))  // otherwise the caller has left the totals themselves (multisplit_totals)
+            hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot, run_if);
         u32 shift = 0;
         while (((n_bins - 1) >> shift) >= 256u) ++shift;
-        const u32 n_coarse = ((n_bins - 1) >> shift) + 1;
+        hipLaunchKernelGGL(k_ms_binscan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off, shift, two_level ? cur_a : (u32 *)nullptr, cur_b,
+                           run_if);
+    }
+    if (two_level) {
+        u32 shift = 0;
+        while (((n_bins - 1) >> shift) >= 256u) ++shift;
         const u32 tiles = (n + SP_TILE - 1) / SP_TILE;
         const unsigned grid = std::min<u32>(256, tiles);
         ProfScope p("k_split_pass", st);
-        hipLaunchKernelGGL(k_split_init, dim3((n_bins + 255) / 256), dim3(256), 0, st, bin_off, n_bins, shift, n_coarse, cur_a, cur_b, run_if);
-        hipLaunchKernelGGL(k_split_pass<false>, dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n, shift,
-                           drop_bin, cur_a, tmp_key, tmp_ab, run_if);
-        hipLaunchKernelGGL(k_split_pass<true>, dim3(grid), dim3(SP_TPB), sp_lds, st, tmp_key, (const u32 *)nullptr,
-                           (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (u32 *)nullptr, out_ab, run_if);
+        hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n,
+                           shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if);
+        hipLaunchKernelGGL((k_split_pass<true, KeyT, false>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
+                           (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if);
     } else {
         ProfScope p("k_ms_scatter", st);
-        hipLaunchKernelGGL(k_ms_scatter, dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off, drop_bin,
-                           out_ab, run_if);
+        hipLaunchKernelGGL((k_ms_scatter<KeyT, CLAMP>), dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off,
+                           drop_bin, out_ab, run_if);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;
+}
+
+gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
+                              uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready) {
+    if (key16 && n_bins > 65535u) return fail(GTARS_ERR_INTERNAL, "multisplit: 16-bit keys need <= 65535 bins");
+    if (key16)
+        return clamp_a ? multisplit_pairs_t<unsigned short, true>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
+                                                                  ws_bytes, st, run_if, table_ready)
+                       : multisplit_pairs_t<unsigned short, false>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
+                                                                   ws_bytes, st, run_if, table_ready);
+    return clamp_a ? multisplit_pairs_t<u32, true>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
+                                                   table_ready)
+                   : multisplit_pairs_t<u32, false>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
+                                                    table_ready);
 }
 
 __global__ void k_iota(u32 *__restrict__ p, u32 n) {

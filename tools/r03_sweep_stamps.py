@@ -9,7 +9,7 @@ import numpy as np, torch
 import gtars_amd
 from gtars_amd import synth, _lib
 
-NAMES = ["wait tile in LDS", "prefix-max scan", "table build", "search (+loop head)", "pair loop", "barrier wait", "commit next tile"]
+NAMES = ["stage tile (loads + LDS writes + barrier)", "-", "-", "search (+loop head)", "pair loop", "barrier wait", "-"]
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 F = int(os.environ.get("F", "1000"))
@@ -18,7 +18,9 @@ g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=
 del db
 hits = torch.zeros(F, dtype=torch.int64, device=dev)
 fn = _lib.lib.gtars_debug_sweep_stamps
+fr = _lib.lib.gtars_debug_route_stamps
 buf = (C.c_ulonglong * 8)()
+RNAMES = ["LDS fill", "routing loop", "barrier", "flush counters"]
 def run(q, binary, label):
     d = [torch.from_numpy(np.ascontiguousarray(q[k]).view(np.int32)).to(dev) for k in ("chrom", "start", "end")]
     n = d[0].numel()
@@ -26,8 +28,16 @@ def run(q, binary, label):
         g.count_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), n, hits.data_ptr(), 1, binary, st)
     torch.cuda.synchronize()
     fn(buf, 1)
+    fr(buf, 1)
     g.count_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), n, hits.data_ptr(), 1, binary, st)
     torch.cuda.synchronize()
+    fr(buf, 0)
+    v = list(buf)
+    if v[7]:
+        tot = sum(v[:4])
+        print(f"== {label}: k_igd_route, {v[7]} workgroups, {tot / v[7]:.0f} cycles per workgroup")
+        for nme, x in zip(RNAMES, v[:4]):
+            print(f"   {nme:22s} {x / v[7]:10.0f}  {100 * x / tot:5.1f} %")
     fn(buf, 0)
     v = list(buf)
     wg = max(v[7], 1)
