@@ -720,7 +720,6 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
         if ((nb64 >> shift) > unit_max || nb64 > (u64)((1u << 22) - 1u)) build_accel = false;
     }
     if (build_accel) {
-        constexpr u32 kBucketMax = 4096;
         const u64 g = 1ull << shift;
         h_cblk.assign(n_chrom + 1, 0);
         for (u32 c = 0; c < n_chrom; ++c) {
@@ -787,6 +786,19 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
         std::vector<u64> uk(n_units);
         u64 total = 0;
         for (u32 c = 0; c < n_chrom; ++c) total += chrom_span[c] + 1;
+        // The bucket table is as fine as the LDS budget allows: what the unit keys (2 B each), the chromosome tables and
+        // 16 KB of id staging (256 words per wave) leave of the kernels' 158 KB, up to 16384 buckets -- the in-bucket search
+        // reads the bucket's first 8 keys at once, so the fewer units a bucket holds the better (100k-region universe:
+        // 50k units, 16384 buckets, 3 units per bucket on average).  GTARS_TOK_BUCKETS overrides (A/B runs).
+        u32 kBucketMax = 4096;
+        {
+            const long left = 158l * 1024 - 16l * 1024 - 2l * (long)(n_units + 16) - 20l * (long)n_chrom - 64;
+            while (kBucketMax < 16384 && 2l * (2 * (long)kBucketMax + 16) <= left) kBucketMax *= 2;
+            if (const char *e = getenv("GTARS_TOK_BUCKETS")) {
+                const long v = atol(e);
+                if (v >= 64 && v <= 65536) kBucketMax = (u32)v;
+            }
+        }
         // bucket width 2^lsh: the smallest that needs <= kBucketMax buckets (padding between chromosomes included)
         u32 lsh = 4, qsh = 0;
         for (;; ++lsh) {
@@ -807,7 +819,7 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
             gbase += span + (1ull << qsh);
         }
         const u32 n_buckets = (u32)std::min<u64>((gbase >> lsh) + 1, 1u << 20);
-        std::vector<uint16_t> lut16(((size_t)n_buckets + 1 + 7) & ~(size_t)7, 0), q16(((size_t)n_units + 7) & ~(size_t)7, 0xFFFFu);
+        std::vector<uint16_t> lut16(((size_t)n_buckets + 1 + 7) & ~(size_t)7, 0), q16(((size_t)n_units + 8 + 7) & ~(size_t)7, 0xFFFFu);  // + 8: the in-bucket search reads 8 keys from any unit on
         u32 max_occ = 0;
         {
             u32 u = 0;

@@ -61,6 +61,28 @@ __device__ __forceinline__ void st_stream2(u64 *p, u64 a, u64 b) {
     __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(p));
 }
 
+// diagnostic build (tools/build_variant.sh tokstamps "-DGTARS_TOK_STAMPS=1", tools/r03_tok_stamps.py): shader-clock totals per
+// phase of the tile loop, for wave 0 (the look-back wave) and wave 1 of every workgroup, and the look-back's round counts
+#ifndef GTARS_TOK_SEARCH8
+#define GTARS_TOK_SEARCH8 1  // in-bucket search by one 16-byte read of 8 keys instead of halving steps
+#endif
+#ifndef GTARS_TOK_STAMPS
+#define GTARS_TOK_STAMPS 0
+#endif
+#if GTARS_TOK_STAMPS
+__device__ unsigned long long g_tok_stamps[2][12];
+#define TSTAMP(k)                                         \
+    do {                                                  \
+        const u64 _t = __builtin_amdgcn_s_memtime();      \
+        ts_acc[k] += _t - ts_last;                        \
+        ts_last = _t;                                     \
+    } while (0)
+#else
+#define TSTAMP(k) \
+    do {          \
+    } while (0)
+#endif
+
 template <bool FILTER>
 __device__ __forceinline__ bool hit_test(u32 s, u32 e, u32 qs, u32 qe, i32 min_bp) {
     bool hit = (s < qe) & (e > qs);  // Interval::overlap, interval.rs:47-50
@@ -136,6 +158,36 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
         pos[j] = qb + (lo << 1) - 2u;                  // &q[lo - 1]
         last[j] = qb + (hi << 1) - 2u;                 // &q[hi - 1]
     }
+#if GTARS_TOK_SEARCH8
+    // The bucket's keys ascend, so "first key >= target" = number of leading keys below it.  A bucket holds a handful of
+    // units (the table is as fine as the LDS budget allows: ~3 units per bucket for the 100k universe): ONE 16-byte LDS read
+    // of the 8 keys at its start and a chain of eight compares replace the stepwise search (6 dependent LDS round trips
+    // before).  Larger buckets are first narrowed by halving steps.  Keys past the bucket's end belong to the next bucket and
+    // restart low, so only the LEADING run counts: c_i = c_(i-1) & (key_i < target), and the sum is clamped to the bucket.
+    (void)last;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+        u32 lo_b = pos[j] + 2u, n = (last[j] - pos[j]) >> 1;  // byte address of the bucket's first key, keys in the bucket
+        while (n > 8u) {
+            const u32 half = n >> 1, mid = lo_b + (half << 1);
+            const bool below = (u32) * (lds_cu16)(uintptr_t)mid < tq[j];
+            lo_b = below ? mid + 2u : lo_b;
+            n = below ? n - half - 1u : half;
+        }
+        typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+        typedef us8 us8_a2 __attribute__((aligned(2)));  // any key may start a bucket: a 2-byte-aligned 16-byte LDS read
+        typedef const __attribute__((address_space(3))) us8_a2 *lds_k8;
+        const us8 kk = *(lds_k8)(uintptr_t)lo_b;  // (the key array is padded by 8 entries)
+        u32 cnt = 0;
+        bool run = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            run = run && (u32)kk[i] < tq[j];
+            cnt += run ? 1u : 0u;
+        }
+        pos[j] = lo_b - 2u + (min(cnt, n) << 1);  // &q[first key >= target] - 2, what the stepwise search leaves
+    }
+#else
     for (u32 step = a.search_top << 1; step >= 2; step >>= 1) {  // byte steps
 #pragma unroll
         for (int j = 0; j < SUB; ++j) {
@@ -144,6 +196,7 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
             pos[j] = v < tq[j] ? cand : pos[j];
         }
     }
+#endif
 #pragma unroll
     for (int j = 0; j < SUB; ++j) {
         u32 b = ((pos[j] + 2u - qb) >> 1) << shift;  // first block of the first unit with key >= target
@@ -559,6 +612,9 @@ __device__ __forceinline__ u64 resolve_prefix_helping(u64 *state, u32 tile, u64 
     i64 pred = (i64)tile - 1;
     u32 spins = 0;
     while (pred >= 0) {
+#if GTARS_TOK_STAMPS
+        if (lane == 0) atomicAdd(&g_tok_stamps[1][spins ? 9 : 8], 1ull);  // rounds: first tries / retries
+#endif
         const i64 idx = pred - lane;
         u64 v = ST_INC;  // before tile 0: inclusive 0
         if (idx >= 0) {
@@ -668,6 +724,9 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
     } cur, prev;
     bool have_prev = false, loaded = true;
     const bool draw = num_tiles > first_tiles;  // otherwise one tile per group: nothing to draw
+#if GTARS_TOK_STAMPS
+    u64 ts_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_last = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         const bool has_cur = tile < num_tiles;
         u32 next_tile = num_tiles;
@@ -678,8 +737,13 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             if (draw && gtid == 0) ticket = atomicAdd(&ws->ticket, 1u);
             if (!loaded) load_tile(tile);
             loaded = false;
+#if GTARS_TOK_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (diagnostic build only: separates the query-load wait)
+#endif
+            TSTAMP(0);
             u32 tsum[R], inc[R];
             count_rounds<R, QPT, FILTER, IMPL, REV>(a, L, c, s, e, min_bp, cur.q, tsum);
+            TSTAMP(1);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 inc[r] = wave_inclusive_scan_u32(tsum[r], lane);
@@ -687,6 +751,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             }
             if (draw && gtid == 0) s_tile[grp] = first_tiles + (ticket - ticket_base);
             bar();
+            TSTAMP(2);
             if (draw) next_tile = s_tile[grp];
             // the group's wave parts, scanned by every wave for itself: one LDS read and six DPP adds
             const u32 v = lane < GW * R ? s_scan[grp][lane] : 0u;
@@ -720,10 +785,13 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                 }
             }
         }
+        TSTAMP(7);
         if (have_prev) {
             if (gwave == 0)
                 pre0 = stage_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
+            TSTAMP(3);
             bar();
+            TSTAMP(4);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const u64 q0 = (u64)prev.tile * TILE + (u64)r * ROUND + (u64)gtid * QPT;
@@ -735,12 +803,20 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                                                           offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
             }
         }
+        TSTAMP(5);
         bar();  // s_tile / s_prefix / s_scan reuse
+        TSTAMP(6);
         if (!has_cur) break;
         prev = cur;
         have_prev = true;
         tile = next_tile;
     }
+#if GTARS_TOK_STAMPS
+    if (lane == 0 && wave < 2) {
+        for (int k = 0; k < 11; ++k) atomicAdd(&g_tok_stamps[wave][k], ts_acc[k]);
+        atomicAdd(&g_tok_stamps[wave][11], 1ull);
+    }
+#endif
 }
 
 // branch-free form of load_queries for 16-byte-aligned arrays: lanes past the end load element 0 and are
@@ -1067,3 +1143,14 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
 }
 
 }  // namespace gtars
+
+#if GTARS_TOK_STAMPS
+extern "C" int gtars_debug_tok_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gtars::g_tok_stamps), 192) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[24] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gtars::g_tok_stamps), z, 192) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
