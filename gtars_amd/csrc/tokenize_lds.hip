@@ -63,6 +63,9 @@ __device__ __forceinline__ void st_stream2(u64 *p, u64 a, u64 b) {
 
 // diagnostic build (tools/build_variant.sh tokstamps "-DGTARS_TOK_STAMPS=1", tools/r03_tok_stamps.py): shader-clock totals per
 // phase of the tile loop, for wave 0 (the look-back wave) and wave 1 of every workgroup, and the look-back's round counts
+#ifndef GTARS_TOK_LB_W1
+#define GTARS_TOK_LB_W1 1  // look-back windows per round in one-tile-per-group launches (see resolve_prefix_helping)
+#endif
 #ifndef GTARS_TOK_SEARCH8
 #define GTARS_TOK_SEARCH8 1  // in-bucket search by one 16-byte read of 8 keys instead of halving steps
 #endif
@@ -602,45 +605,71 @@ __device__ __forceinline__ u64 help_count_tile(const AccelView &a, const SearchL
     return wave_reduce_sum_u64(n);
 }
 
-// resolve_prefix (scan.h) that never gives up: the tile's exclusive prefix by chained look-back, one window of 64
-// predecessor granules per round trip; help(t) returns tile t's hit count.  Publishes the inclusive prefix.
-template <class Help>
+// resolve_prefix (scan.h) that never gives up: the tile's exclusive prefix by chained look-back; help(t) returns tile t's
+// hit count.  Publishes the inclusive prefix.  W windows of 64 predecessor granules are read per round (independent loads:
+// one memory round trip) and consumed nearest first; the lanes' contributions are summed once, at the end.
+// W = 1 everywhere: wider rounds measured SLOWER both for launches whose groups take many tiles (558 / 600 / 615 / 672 us per
+// 64M queries for W = 1 / 2 / 4 / 8) and for one-tile-per-workgroup launches, where all <= 256 tiles publish at about the same
+// time (16.5 / 17.3 / 18.4 us per 1M queries for W = 1 / 2 / 4 when every round re-reads all W windows, 16.5 / 16.6 / 17.3 when only
+// the incomplete window is polled again): the look-back of a 1M-query launch is the wait for the slowest predecessor
+// workgroup, not a chain of round trips (profiles/r03/README.md).
+template <int W, class Help>
 __device__ __forceinline__ u64 resolve_prefix_helping(u64 *state, u32 tile, u64 agg, int lane, u32 epoch, u32 spin_limit,
                                                       u64 base, Help &&help) {
     const u64 ep = (u64)epoch << EP_SHIFT;
-    u64 excl = tile == 0 ? base : 0ull;  // `base`: what precedes tile 0 (chained launches); later tiles get it through tile 0's prefix
+    u64 part = 0;  // this lane's share of the exclusive prefix
     i64 pred = (i64)tile - 1;
     u32 spins = 0;
-    while (pred >= 0) {
-#if GTARS_TOK_STAMPS
-        if (lane == 0) atomicAdd(&g_tok_stamps[1][spins ? 9 : 8], 1ull);  // rounds: first tries / retries
-#endif
-        const i64 idx = pred - lane;
+    bool done = pred < 0;
+    auto load_window = [&](i64 first) -> u64 {
+        const i64 idx = first - lane;
         u64 v = ST_INC;  // before tile 0: inclusive 0
         if (idx >= 0) {
             v = ld_state(&state[idx]);
             if ((u32)((v >> EP_SHIFT) & EP_MAX) != epoch) v = 0;  // left over from an earlier launch
         }
-        const u64 status = v & ST_MASK;
-        const unsigned long long b_inc = __ballot(status == ST_INC);
-        const unsigned long long b_inv = __ballot(status == 0);
-        const int first_inc = b_inc ? __ffsll((long long)b_inc) - 1 : 64;
-        const unsigned long long need = first_inc >= 63 ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);
-        if (b_inv & need) {
-            if (++spins > spin_limit) {
-                const i64 t = pred - (__ffsll((long long)(b_inv & need)) - 1);  // nearest unpublished predecessor
-                const u64 h = help((u32)t) + (t == 0 ? base : 0ull);
-                if (lane == 0) st_state(&state[t], (t == 0 ? ST_INC : ST_AGG) | ep | h);
-                spins = 0;
-            } else {
-                __builtin_amdgcn_s_sleep(1);
+        return v;
+    };
+    while (!done) {
+#if GTARS_TOK_STAMPS
+        if (lane == 0) atomicAdd(&g_tok_stamps[1][spins ? 9 : 8], 1ull);  // rounds: first tries / retries
+#endif
+        // W windows in one round trip; a window that is not complete yet is polled ON ITS OWN afterwards (the snapshots of the
+        // windows behind it stay valid: a granule only ever goes from aggregate to inclusive prefix, both usable)
+        u64 v[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) v[w] = load_window(pred - 64 * w);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            if (done) continue;
+            for (;;) {
+                const u64 status = v[w] & ST_MASK;
+                const unsigned long long b_inc = __ballot(status == ST_INC);
+                const unsigned long long b_inv = __ballot(status == 0);
+                const int first_inc = b_inc ? __ffsll((long long)b_inc) - 1 : 64;
+                const unsigned long long need = first_inc >= 63 ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);
+                if (!(b_inv & need)) {
+                    part += lane <= first_inc ? (v[w] & VAL_MASK) : 0ull;
+                    if (first_inc < 64) done = true;
+                    break;
+                }
+                // an unpublished predecessor in front of the nearest inclusive prefix: wait for it (or count it ourselves)
+                if (++spins > spin_limit) {
+                    const i64 missing = pred - 64 * w - (__ffsll((long long)(b_inv & need)) - 1);
+                    const u64 h = help((u32)missing) + (missing == 0 ? base : 0ull);
+                    if (lane == 0) st_state(&state[missing], (missing == 0 ? ST_INC : ST_AGG) | ep | h);
+                    spins = 0;
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                v[w] = load_window(pred - 64 * w);
             }
-            continue;
         }
-        excl += wave_reduce_sum_u48(lane <= first_inc ? (v & VAL_MASK) : 0ull);
-        if (first_inc < 64) break;
-        pred -= 64;
+        pred -= 64 * W;
+        if (pred < 0) done = true;
     }
+    // `base`: what precedes tile 0 (chained launches); later tiles get it through tile 0's inclusive prefix
+    const u64 excl = wave_reduce_sum_u48(part) + (tile == 0 ? base : 0ull);
     if (lane == 0) st_state(&state[tile], ST_INC | ep | (excl + agg));
     return excl;
 }
@@ -775,7 +804,9 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             pre0 = stage_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
         if (have_prev && gwave == 0) {
             const u64 excl = (GTARS_TOK_ABLATE & 1) ? (u64)prev.tile * 2400u
-                                                    : resolve_prefix_helping(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help);
+                                                    : (draw ? resolve_prefix_helping<1>(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help)
+                                                            : resolve_prefix_helping<GTARS_TOK_LB_W1>(ws->state, prev.tile, (u64)prev.total, lane, epoch,
+                                                                                                      spin_limit, base, help));
             if (lane == 0) {
                 s_prefix[grp] = excl;
                 if (prev.tile == num_tiles - 1) {
