@@ -2,11 +2,10 @@
 // (gtars-tokenizers/src/tokenizer.rs:140-171 -> Bits::find, bits.rs:141-156,
 // 433-446) and of count_overlaps / any_overlaps for a Bits-kind index.
 //
-// Data layout (AccelView, common.h): the sorted index is cut into 3-interval
-// blocks; a block's record holds its starts and ends plus a copy of the next
-// block's first interval (the look-ahead), 32 bytes when token ids follow from
-// the position (sorted universes), 48 bytes of a 64-byte slot otherwise.  One
-// u16 search key per block and a bucket table over the key space live in LDS.
+// Data layout (AccelView, common.h): the sorted index is cut into blocks of 2 intervals; a block's record holds its
+// own 2 intervals plus copies of the NEXT block's 2 (the look-ahead): starts | ends, 32 bytes, when token ids follow
+// from the position (sorted universes); a 64-byte slot with an id quad otherwise.  One u16 search key per block (or
+// per unit of 2^shift blocks) and a bucket table over the key space live in LDS.
 //
 // Per query:
 //   1. LDS search for the first block that can hold a hit: the first whose key --
@@ -15,8 +14,8 @@
 //      bits.rs:144-147; every interval between that point and ours has
 //      end <= q_start, so the hit set and its order are the same.)
 //   2. ONE burst of two (three) 16-byte loads from the block's record; the overlap
-//      test runs in registers -> 4-bit hit mask.  Only a query that reaches past the
-//      look-ahead interval (iv.start >= stop ends the reference scan,
+//      test runs in registers -> 4-bit hit mask.  Only a query that reaches past BOTH
+//      look-ahead intervals (iv.start >= stop ends the reference scan,
 //      bits.rs:441-443) walks into the following blocks.
 //   3. hit counts are scanned inside the wave, across the waves of a workgroup and
 //      across workgroups (chained scan, scan.h);

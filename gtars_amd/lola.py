@@ -26,7 +26,6 @@ import numpy as np
 from .igd import Igd
 from .models import RegionSet
 
-_EPS = np.finfo(np.float64).eps
 
 
 # --------------------------------------------------------------------------- RegionDB
@@ -189,64 +188,16 @@ def p_value_log(a: int, b: int, c: int, d: int, enrichment: bool = True) -> floa
     return -math.log10(fisher_pvalue(a, b, c, d, enrichment) + 1e-322)
 
 
-def _brent(f, a: float, b: float, tol: float, max_iter: int) -> float:
-    """enrichment.rs:400-486, statement for statement."""
-    fa, fb = f(a), f(b)
-    if abs(fa) < tol:
-        return a
-    if abs(fb) < tol:
-        return b
-    if fa * fb > 0.0:
-        return (a + b) / 2.0
-    c, fc = a, fa
-    d = b - a
-    e = d
-    for _ in range(max_iter):
-        if fb * fc > 0.0:
-            c, fc = a, fa
-            d = b - a
-            e = d
-        if abs(fc) < abs(fb):
-            a, b, c = b, c, b
-            fa, fb, fc = fb, fc, fb
-        tol1 = 2.0 * _EPS * abs(b) + 0.5 * tol
-        m = 0.5 * (c - b)
-        if abs(m) <= tol1 or fb == 0.0:
-            return b
-        if abs(e) >= tol1 and abs(fa) > abs(fb):
-            s = fb / fa
-            if abs(a - c) < _EPS:
-                p = 2.0 * m * s
-                q = 1.0 - s
-            else:
-                qv = fa / fc
-                r = fb / fc
-                p = s * (2.0 * m * qv * (qv - r) - (b - a) * (r - 1.0))
-                q = (qv - 1.0) * (r - 1.0) * (s - 1.0)
-            if p > 0.0:
-                q = -q
-            else:
-                p = -p
-            if 2.0 * p < min(3.0 * m * q - abs(tol1 * q), e * q):
-                e = d
-                d = p / q
-            else:
-                d = m
-                e = m
-        else:
-            d = m
-            e = m
-        a, fa = b, fb
-        if abs(d) > tol1:
-            b += d
-        else:
-            b += tol1 if m > 0.0 else -tol1
-        fb = f(b)
-    return b
-
-
 def odds_ratio(a: int, b: int, c: int, d: int) -> float:
-    """ContingencyTable::odds_ratio -- CMLE as R's fisher.test (enrichment.rs:62-160)."""
+    """ContingencyTable::odds_ratio (enrichment.rs:62-160): the conditional maximum-likelihood estimate of the odds ratio,
+    as R's fisher.test reports it -- the omega for which the noncentral hypergeometric distribution of the table's margins
+    has mean a.  Same definition and the same edge values (NaN for a one-point support, 0 / inf at the ends) as the
+    reference; the numerics are this module's own: the support's log-weights come from lgamma, the equation is solved in
+    theta = log(omega), where the mean is strictly increasing with the variance as its derivative, by Newton steps kept
+    inside a sign-change bracket.  (The reference finds the root of the same equation in omega with Brent's method, to an
+    absolute 1e-8 in omega; its own tests pin the value to 1e-3.)"""
+    from scipy.special import gammaln, logsumexp
+
     m, n, k, x = a + c, b + d, a + b, a
     lo = k - n if k > n else 0
     hi = min(k, m)
@@ -256,30 +207,45 @@ def odds_ratio(a: int, b: int, c: int, d: int) -> float:
         return 0.0
     if x == hi:
         return float("inf")
-    size = hi - lo + 1
-    logdc = np.zeros(size, dtype=np.float64)
-    for i in range(1, size):
-        y = lo + i - 1
-        logdc[i] = logdc[i - 1] + (math.log(m - y) + math.log(k - y) - math.log(y + 1) - math.log(n - k + y + 1))
-    ys = lo + np.arange(size, dtype=np.float64)
+    ys = np.arange(lo, hi + 1, dtype=np.float64)
+    # log of C(m, y) * C(n, k - y) up to a constant
+    lw = -(gammaln(ys + 1) + gammaln(m - ys + 1) + gammaln(k - ys + 1) + gammaln(n - k + ys + 1))
 
-    def mean_nhyper(omega: float) -> float:
-        if omega == 0.0:
-            return float(lo)
-        if math.isinf(omega):
-            return float(hi)
-        lv = logdc + ys * math.log(omega)
-        w = np.exp(lv - lv.max())
-        return math.fsum(ys * w) / math.fsum(w)
+    def moments(theta: float):
+        lv = lw + theta * ys
+        p = np.exp(lv - logsumexp(lv))
+        mu = float(np.dot(p, ys))
+        return mu, float(np.dot(p, (ys - mu) ** 2))
 
-    xf = float(x)
-    mu1 = mean_nhyper(1.0)
-    if abs(mu1 - xf) < 1e-12:
+    target = float(x)
+    mu0, _ = moments(0.0)
+    if abs(mu0 - target) < 1e-12:
         return 1.0
-    if mu1 > xf:
-        return _brent(lambda t: mean_nhyper(t) - xf, 0.0, 1.0, 1e-8, 100)
-    t = _brent(lambda t: mean_nhyper(1.0 / t) - xf, _EPS, 1.0, 1e-8, 100)
-    return 1.0 / t
+    # bracket the root: the mean runs from lo to hi as theta goes from -inf to +inf, and lo < x < hi here
+    step = 1.0
+    if mu0 < target:
+        t_lo, t_hi = 0.0, step
+        while moments(t_hi)[0] < target:
+            t_lo, t_hi, step = t_hi, t_hi + 2.0 * step, 2.0 * step
+    else:
+        t_lo, t_hi = -step, 0.0
+        while moments(t_lo)[0] > target:
+            t_lo, t_hi, step = t_lo - 2.0 * step, t_lo, 2.0 * step
+    theta = 0.5 * (t_lo + t_hi)
+    for _ in range(200):
+        mu, var = moments(theta)
+        if mu < target:
+            t_lo = theta
+        else:
+            t_hi = theta
+        nxt = theta - (mu - target) / var if var > 0.0 else float("nan")
+        if not (t_lo < nxt < t_hi):  # Newton left the bracket (flat tail of the mean): bisect
+            nxt = 0.5 * (t_lo + t_hi)
+        if abs(nxt - theta) <= 1e-13 * max(1.0, abs(theta)) or t_hi - t_lo <= 1e-14 * max(1.0, abs(theta)):
+            theta = nxt
+            break
+        theta = nxt
+    return math.exp(theta)
 
 
 def _min_ranks(order: List[int], key) -> Dict[int, int]:
