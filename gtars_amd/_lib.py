@@ -131,6 +131,7 @@ _HOST_SIG = {
     "gtars_regionset_from_bed": (C.c_int, [cstr, pp]),
     "gtars_regionset_from_arrays": (C.c_int, [vp, vp, vp, vp, u64, pp]),
     "gtars_regionset_free": (None, [vp]),
+    "gtars_regionset_dense_ids": (C.c_int, [vp, pp, vp]),
     "gtars_regionset_len": (u64, [vp]),
     "gtars_regionset_header": (cstr, [vp]),
     "gtars_regionset_n_chrom": (u32, [vp]),
@@ -175,6 +176,8 @@ _HOST_SIG = {
     "gtars_gtok_read": (C.c_int, [cstr, pp, pu64]),
     "gtars_fragments_read": (C.c_int, [cstr, pp]),
     "gtars_fragments_read_strict": (C.c_int, [cstr, pp]),
+    "gtars_bed3_lines_read": (C.c_int, [cstr, pp]),
+    "gtars_format_hit_lines": (C.c_int, [vp, vp, vp, vp, u64, pp, pu64]),
     "gtars_fragments_free": (None, [vp]),
     "gtars_fragments_len": (u64, [vp]),
     "gtars_fragments_n_chrom": (u32, [vp]),

@@ -15,66 +15,69 @@ signs are not), every line counts (no header skipping in overlaprs).  The whole 
 from __future__ import annotations
 
 import argparse
-import gzip
 import os
-import re
 import sys
-from typing import Dict, List, Sequence, TextIO, Tuple
+from typing import List, Sequence, TextIO, Tuple
 
 import numpy as np
 
 from ._lib import KIND_AILIST, KIND_BITS, UNKNOWN_CHROM
 
-_U32 = re.compile(r"\+?[0-9]+\Z")
 
+def read_bed3_lines(path: str) -> Tuple[List[str], np.ndarray, np.ndarray, np.ndarray]:
+    """chr / start / end of EVERY line, in file order (handlers.rs:64-92, 123-139), through the C++ chunked reader
+    (gtars_bed3_lines_read): -> (chromosome names in first-seen order, chromosome id per line, starts, ends)."""
+    import ctypes as C
 
-def _open_text(path: str):
-    return gzip.open(path, "rt") if str(path).endswith(".gz") else open(path, "rt")
+    from . import _lib
 
+    h = C.c_void_p()
+    if _lib.lib.gtars_bed3_lines_read(str(path).encode(), C.byref(h)) != 0:
+        raise ValueError(_lib.last_error())
+    try:
+        n = int(_lib.lib.gtars_fragments_len(h))
 
-def _parse_u32(text: str, path: str, line_no: int) -> int:
-    if not _U32.match(text) or int(text) > 0xFFFFFFFF:  # str::parse::<u32>
-        raise ValueError(f"{path}:{line_no}: invalid digit found in string: {text!r}")
-    return int(text)
+        def col(fn):
+            if not n:
+                return np.zeros(0, dtype=np.uint32)
+            return np.ctypeslib.as_array(C.cast(fn(h), C.POINTER(C.c_uint32)), shape=(n,)).copy()
 
-
-def read_bed3_lines(path: str) -> Tuple[List[str], np.ndarray, np.ndarray]:
-    """chr / start / end of EVERY line, in file order (handlers.rs:64-92, 123-139)."""
-    chrs: List[str] = []
-    starts: List[int] = []
-    ends: List[int] = []
-    with _open_text(path) as fh:
-        for no, line in enumerate(fh, 1):
-            line = line.rstrip("\n")
-            if line.endswith("\r"):  # BufRead::lines strips "\r\n"
-                line = line[:-1]
-            f = line.split("\t")
-            if len(f) < 3:
-                raise ValueError(f"{path}:{no}: Missing {'start' if len(f) == 1 else 'end'} field")
-            chrs.append(f[0])
-            starts.append(_parse_u32(f[1], path, no))
-            ends.append(_parse_u32(f[2], path, no))
-    return chrs, np.asarray(starts, dtype=np.uint32), np.asarray(ends, dtype=np.uint32)
+        names = [_lib.lib.gtars_fragments_chrom_name(h, i).decode() for i in range(_lib.lib.gtars_fragments_n_chrom(h))]
+        return names, col(_lib.lib.gtars_fragments_chrom_ids), col(_lib.lib.gtars_fragments_starts), col(_lib.lib.gtars_fragments_ends)
+    finally:
+        _lib.lib.gtars_fragments_free(h)
 
 
 def run_overlaprs(universe: str, query: str, backend: str = "bits", out: TextIO = sys.stdout) -> int:
-    """-> number of hit lines written."""
+    """-> number of hit lines written.  Text in and out go through the C++ host layer (chunked in-place parse, one
+    formatted buffer); the whole query file is one device batch in between."""
+    import ctypes as C
+
+    from . import _lib
     from .engine import OverlapIndex
 
     if backend not in ("bits", "ailist"):
         raise ValueError(f"Invalid backend type: {backend}. Valid options are 'bits' or 'ailist'")
-    uc, us, ue = read_bed3_lines(universe)
-    names: Dict[str, int] = {}
-    cid = np.fromiter((names.setdefault(c, len(names)) for c in uc), dtype=np.uint32, count=len(uc))
+    names, cid, us, ue = read_bed3_lines(universe)
     ix = OverlapIndex(cid, us, ue, None, n_chrom=len(names), kind=KIND_AILIST if backend == "ailist" else KIND_BITS)
-    qc_names, qs, qe = read_bed3_lines(query)
-    qc = np.fromiter((names.get(c, UNKNOWN_CHROM) for c in qc_names), dtype=np.uint32, count=len(qc_names))
+    q_names, q_cid, qs, qe = read_bed3_lines(query)
+    # the query file's chromosome ids -> the universe's (chromosomes the universe does not have are skipped)
+    uid = {nme: i for i, nme in enumerate(names)}
+    relabel = np.fromiter((uid.get(nme, UNKNOWN_CHROM) for nme in q_names), dtype=np.uint32, count=len(q_names))
+    qc = relabel[q_cid] if len(q_cid) else np.zeros(0, dtype=np.uint32)
     offsets, hs, he, _ = ix.find_overlaps(qc, qs, qe)
-    per_query = np.diff(offsets.astype(np.int64))
-    if len(hs):
-        chrom_of_hit = np.repeat(np.asarray(qc_names, dtype=object), per_query)
-        out.write("".join(f"{c}\t{s}\t{e}\n" for c, s, e in zip(chrom_of_hit, hs.tolist(), he.tolist())))
-    return int(len(hs))
+    n = int(len(hs))
+    if n:
+        hit_chrom = np.ascontiguousarray(np.repeat(qc, np.diff(offsets.astype(np.int64))), dtype=np.uint32)
+        arr = (C.c_char_p * len(names))(*[nme.encode() for nme in names])
+        text, ln = C.c_void_p(), C.c_uint64()
+        _lib.check(_lib.lib.gtars_format_hit_lines(C.cast(arr, C.c_void_p), _lib.ptr(hit_chrom), _lib.ptr(np.ascontiguousarray(hs)),
+                                                   _lib.ptr(np.ascontiguousarray(he)), n, C.byref(text), C.byref(ln)))
+        try:
+            out.write(C.string_at(text, ln.value).decode())
+        finally:
+            _lib.lib.gtars_free(text)
+    return n
 
 
 def resolve_bed_paths(filelist: str, stdin: TextIO = sys.stdin) -> List[str]:

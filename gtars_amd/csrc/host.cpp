@@ -22,6 +22,7 @@
 #include <numeric>
 #include <set>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -575,6 +576,41 @@ const uint32_t *gtars_regionset_starts(const gtars_regionset_t *rs) { return rs 
 const uint32_t *gtars_regionset_ends(const gtars_regionset_t *rs) { return rs ? rs->ends.data() : nullptr; }
 const char *gtars_regionset_rest(const gtars_regionset_t *rs, uint64_t i) {
     return rs && i < rs->size() && rs->has_rest[i] ? rs->rest_arena.data() + rs->rest_off[i] : nullptr;
+}
+
+// generate_region_to_id_map (gtars-core/src/utils.rs:202-214): dense ids in first-seen order over the whole Region
+// (chr, start, end, rest) -- what gtars-scoring's ConsensusSet stores as the interval payload (files.rs:60-83)
+gtars_status gtars_regionset_dense_ids(const gtars_regionset_t *rs, uint32_t **out_ids, uint32_t *out_n_ids) {
+    return gtars::guarded([&]() -> gtars_status {
+        if (!rs || !out_ids) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+        *out_ids = nullptr;
+        const size_t n = rs->size();
+        uint32_t *ids = (uint32_t *)malloc(std::max<size_t>(n, 1) * sizeof(uint32_t));
+        if (!ids) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+        struct Key {
+            uint32_t c, s, e;
+            bool has;
+            std::string_view rest;
+            bool operator==(const Key &o) const { return c == o.c && s == o.s && e == o.e && has == o.has && rest == o.rest; }
+        };
+        struct Hash {
+            size_t operator()(const Key &k) const {
+                uint64_t h = ((uint64_t)k.c * 0x9E3779B97F4A7C15ull) ^ (((uint64_t)k.s << 32) | k.e);
+                h ^= std::hash<std::string_view>()(k.rest) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2) + (k.has ? 1 : 0);
+                return (size_t)h;
+            }
+        };
+        std::unordered_map<Key, uint32_t, Hash> seen;
+        seen.reserve(n * 2 + 16);
+        for (size_t i = 0; i < n; ++i) {
+            Key k{rs->chrom_ids[i], rs->starts[i], rs->ends[i], rs->has_rest[i] != 0,
+                  rs->has_rest[i] ? std::string_view(rs->rest_arena.data() + rs->rest_off[i]) : std::string_view()};
+            ids[i] = seen.emplace(k, (uint32_t)seen.size()).first->second;
+        }
+        *out_ids = ids;
+        if (out_n_ids) *out_n_ids = (uint32_t)seen.size();
+        return GTARS_OK;
+    });
 }
 
 }  // extern "C"
@@ -1361,6 +1397,93 @@ struct gtars_fragments {
     FragTable t;
     std::vector<const char *> chrom_ptrs, barcode_ptrs;
 };
+
+// ------------------------------------------------------------ BED3 text mode of the overlaprs front end
+// gtars-cli/src/overlaprs/handlers.rs:64-92, 123-139: EVERY line is a record (no header or comment skipping), fields are
+// split on TAB only, the first three are chr / start / end with start and end through str::parse::<u32>; what follows is
+// ignored.  Same chunked in-place scan as the fragment reader; the columns come back in a gtars_fragments_t without barcodes.
+namespace {
+void parse_bed3_chunk(const char *p, const char *end, FragChunk &out) {
+    const size_t guess = (size_t)(end - p) / 20 + 16;
+    out.c.reserve(guess); out.s.reserve(guess); out.e.reserve(guess);
+    uint32_t last_c = 0;
+    const char *last_c_p = nullptr;
+    size_t last_c_n = 0;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *next = nl ? nl + 1 : end;
+        if (nl && le > p && le[-1] == '\r') --le;  // BufRead::lines strips "\r\n"
+        const size_t ln = out.n_lines++;
+        const char *t1 = (const char *)memchr(p, '\t', (size_t)(le - p));
+        if (!t1) { out.err = 1; out.err_line = ln; return; }            // Missing start field
+        const char *t2 = (const char *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1));
+        if (!t2) { out.err = 2; out.err_line = ln; return; }            // Missing end field
+        const char *t3 = (const char *)memchr(t2 + 1, '\t', (size_t)(le - t2 - 1));
+        const char *e_end = t3 ? t3 : le;
+        uint32_t sv, ev;
+        if (!parse_u32_view(t1 + 1, (size_t)(t2 - t1 - 1), sv)) { out.err = 3; out.err_line = ln; return; }
+        if (!parse_u32_view(t2 + 1, (size_t)(e_end - t2 - 1), ev)) { out.err = 4; out.err_line = ln; return; }
+        const size_t cl = (size_t)(t1 - p);
+        if (!(last_c_p && last_c_n == cl && memcmp(last_c_p, p, cl) == 0)) {
+            last_c = out.chroms.get_or_add(p, cl); last_c_p = p; last_c_n = cl;
+        }
+        out.c.push_back(last_c); out.s.push_back(sv); out.e.push_back(ev);
+        p = next;
+    }
+}
+
+gtars_status read_bed3_lines(const char *path, FragTable &ft) {
+    std::string data, err;
+    if (!read_all(path, data, err)) return fail(GTARS_ERR_IO, err);
+    unsigned nt = host_thread_budget(32);
+    nt = (unsigned)std::min<size_t>(nt, data.size() / (1u << 20) + 1);
+    std::vector<size_t> cut(nt + 1, data.size());
+    cut[0] = 0;
+    for (unsigned i = 1; i < nt; ++i) {
+        const size_t nl = data.find('\n', data.size() / nt * i);
+        cut[i] = nl == std::string::npos ? data.size() : nl + 1;
+    }
+    for (unsigned i = 1; i <= nt; ++i) cut[i] = std::max(cut[i], cut[i - 1]);
+    std::vector<FragChunk> chunks(nt);
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; ++i)
+            th.emplace_back([&, i] { parse_bed3_chunk(data.data() + cut[i], data.data() + cut[i + 1], chunks[i]); });
+        parse_bed3_chunk(data.data() + cut[0], data.data() + cut[1], chunks[0]);
+        for (auto &t : th) t.join();
+    }
+    size_t line0 = 0, total = 0;
+    for (unsigned i = 0; i < nt; ++i) {
+        if (chunks[i].err) {
+            const std::string where = std::string(path) + ":" + std::to_string(line0 + chunks[i].err_line + 1) + ": ";
+            if (chunks[i].err <= 2) return fail(GTARS_ERR_PARSE, where + (chunks[i].err == 1 ? "Missing start field" : "Missing end field"));
+            return fail(GTARS_ERR_PARSE, where + "invalid digit found in string (" + (chunks[i].err == 3 ? "start" : "end") + ")");
+        }
+        line0 += chunks[i].n_lines;
+        total += chunks[i].c.size();
+    }
+    ViewDict gc;
+    std::vector<std::vector<uint32_t>> mapc(nt);
+    for (unsigned i = 0; i < nt; ++i)
+        for (const std::string &n : chunks[i].chroms.names) mapc[i].push_back(gc.get_or_add(n.data(), n.size()));
+    ft.c.resize(total); ft.s.resize(total); ft.e.resize(total); ft.b.assign(total, 0);
+    size_t o = 0;
+    for (unsigned i = 0; i < nt; ++i) {
+        const FragChunk &ck = chunks[i];
+        const size_t m = ck.c.size();
+        for (size_t k = 0; k < m; ++k) ft.c[o + k] = mapc[i][ck.c[k]];
+        if (m) {
+            memcpy(&ft.s[o], ck.s.data(), m * sizeof(uint32_t));
+            memcpy(&ft.e[o], ck.e.data(), m * sizeof(uint32_t));
+        }
+        o += m;
+    }
+    ft.chroms.assign(gc.names.begin(), gc.names.end());
+    ft.barcodes.clear();
+    return GTARS_OK;
+}
+}  // namespace
 
 static gtars_status gtars_fragments_read_impl(const char *path, gtars_fragments_t **out) {
     if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
@@ -2359,6 +2482,51 @@ gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, 
 
 gtars_status gtars_fragments_read(const char *path, gtars_fragments_t **out) {
     return gtars::guarded([&]() -> gtars_status { return gtars_fragments_read_impl(path, out); });
+}
+
+gtars_status gtars_bed3_lines_read(const char *path, gtars_fragments_t **out) {
+    return gtars::guarded([&]() -> gtars_status {
+        if (!path || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+        *out = nullptr;
+        auto f = std::make_unique<gtars_fragments>();
+        gtars_status st = read_bed3_lines(path, f->t);
+        if (st) return st;
+        for (const std::string &n : f->t.chroms) f->chrom_ptrs.push_back(n.c_str());
+        *out = f.release();
+        return GTARS_OK;
+    });
+}
+
+// one line  chr<TAB>start<TAB>end  per hit (handlers.rs:141-150), `n` hits, into a malloc'ed buffer (gtars_free)
+gtars_status gtars_format_hit_lines(const char *const *chrom_names, const uint32_t *hit_chrom, const uint32_t *hit_start,
+                                    const uint32_t *hit_end, uint64_t n, char **out_text, uint64_t *out_len) {
+    return gtars::guarded([&]() -> gtars_status {
+        if (!out_text || !out_len || (n && (!chrom_names || !hit_chrom || !hit_start || !hit_end)))
+            return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+        std::string text;
+        text.reserve((size_t)n * 24);
+        char buf[16];
+        auto put_u32 = [&](uint32_t v) {
+            int k = 0;
+            do { buf[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+            while (k) text.push_back(buf[--k]);
+        };
+        for (uint64_t i = 0; i < n; ++i) {
+            text += chrom_names[hit_chrom[i]];
+            text.push_back('\t');
+            put_u32(hit_start[i]);
+            text.push_back('\t');
+            put_u32(hit_end[i]);
+            text.push_back('\n');
+        }
+        char *p = (char *)malloc(text.size() + 1);
+        if (!p) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+        memcpy(p, text.data(), text.size());
+        p[text.size()] = 0;
+        *out_text = p;
+        *out_len = text.size();
+        return GTARS_OK;
+    });
 }
 
 }  // extern "C"

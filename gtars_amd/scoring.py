@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import glob as _glob
-from typing import Dict, List, Sequence, Union
+from typing import Dict, Sequence, Union
 
 import numpy as np
 
@@ -31,12 +31,11 @@ class ConsensusSet:
 
     def __init__(self, path: str):
         rs = RegionSet(path)
-        regs = rs.regions
-        ids: Dict[tuple, int] = {}
-        vals = np.empty(len(regs), dtype=np.uint32)
-        for i, r in enumerate(regs):  # generate_region_to_id_map: first-seen dense ids (gtars-core utils.rs:202-214)
-            vals[i] = ids.setdefault((r.chr, r.start, r.end, r.rest), len(ids))
-        self._len = len(regs)
+        # generate_region_to_id_map: first-seen dense ids over (chr, start, end, rest) (gtars-core utils.rs:202-214), in C++
+        p = C.c_void_p()
+        check(lib.gtars_regionset_dense_ids(rs._h, C.byref(p), None))
+        vals = _lib.take_u32(p, len(rs))
+        self._len = len(rs)
         self.chrom_names = rs.chrom_names
         self._chrom_ids = {n: i for i, n in enumerate(self.chrom_names)}
         self.index = OverlapIndex(rs.chrom_ids, rs.starts, rs.ends, vals, n_chrom=len(self.chrom_names))

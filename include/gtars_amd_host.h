@@ -44,6 +44,10 @@ const uint32_t *gtars_regionset_chrom_ids(const gtars_regionset_t *rs);
 const uint32_t *gtars_regionset_starts(const gtars_regionset_t *rs);
 const uint32_t *gtars_regionset_ends(const gtars_regionset_t *rs);
 const char *gtars_regionset_rest(const gtars_regionset_t *rs, uint64_t i); /* NULL if None */
+/* generate_region_to_id_map (gtars-core/src/utils.rs:202-214): dense ids in first-seen order over the whole Region
+ * (chr, start, end, rest): what gtars-scoring's ConsensusSet stores as interval payload (files.rs:60-83).
+ * *out_ids: gtars_regionset_len ids (gtars_free); *out_n_ids (may be NULL): number of distinct regions */
+gtars_status gtars_regionset_dense_ids(const gtars_regionset_t *rs, uint32_t **out_ids, uint32_t *out_n_ids);
 
 /* IndexedRegionSet::new(other) then count / any / find_overlaps(self)
  * (gtars-overlaprs/src/indexed_region_set.rs:111-113, 234-263) -- the
@@ -122,6 +126,15 @@ gtars_status gtars_fragments_read(const char *path, gtars_fragments_t **out);
 /* the same with the fifth field (read support) required to parse as u32, as Fragment::from_str does
  * (gtars-core/src/models/fragments.rs:16-41: the parser behind gtars-scoring) */
 gtars_status gtars_fragments_read_strict(const char *path, gtars_fragments_t **out);
+/* BED3 text mode of the `gtars overlaprs` front end (gtars-cli/src/overlaprs/handlers.rs:64-92, 123-139): EVERY line is a
+ * record (no header / comment skipping), fields split on TAB only, start and end through str::parse::<u32>; errors name
+ * the file and the 1-based line ("Missing start field", "Missing end field", "invalid digit found in string").  The
+ * columns come back in a gtars_fragments_t without barcodes (file order, chromosome ids in first-seen order). */
+gtars_status gtars_bed3_lines_read(const char *path, gtars_fragments_t **out);
+/* the front end's output (handlers.rs:141-150): one line chr<TAB>start<TAB>end per hit, in the order given; *out_text is
+ * malloc'ed (gtars_free), NUL-terminated, *out_len bytes long */
+gtars_status gtars_format_hit_lines(const char *const *chrom_names, const uint32_t *hit_chrom, const uint32_t *hit_start,
+                                    const uint32_t *hit_end, uint64_t n, char **out_text, uint64_t *out_len);
 void gtars_fragments_free(gtars_fragments_t *f);
 uint64_t gtars_fragments_len(const gtars_fragments_t *f);
 uint32_t gtars_fragments_n_chrom(const gtars_fragments_t *f);

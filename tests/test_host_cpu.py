@@ -328,3 +328,60 @@ def test_remove_all_extensions_matches_reference_rule():
     assert oracle.remove_all_extensions("a.b.c.d") == "a"
     assert oracle.remove_all_extensions(".hidden") == ".hidden"
     assert oracle.remove_all_extensions("plain") == "plain"
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+def test_cli_bed3_text_mode_reader(tmp_path, monkeypatch, threads):
+    """gtars_bed3_lines_read (the overlaprs front end's rules, gtars-cli/src/overlaprs/handlers.rs:64-92): every line counts,
+    TAB-only split, str::parse::<u32> -- against a plain Python statement of those rules, multi-chunk, with the errors."""
+    from gtars_amd import cli
+
+    monkeypatch.setenv("GTARS_HOST_THREADS", str(threads))
+    rng = np.random.default_rng(5)
+    n = 120_000
+    chroms = [f"chr{rng.integers(1, 30)}" if i % 997 else "#odd name" for i in range(n)]
+    starts, ends = rng.integers(0, 2**32, n), rng.integers(0, 2**32, n)
+    lines = [f"{c}\t{'+' if i % 13 == 0 else ''}{s}\t{e}" + ("\trest\tmore" if i % 3 == 0 else "") + ("\r" if i % 7 == 0 else "")
+             for i, (c, s, e) in enumerate(zip(chroms, starts, ends))]
+    p = tmp_path / "q.bed"
+    p.write_text("\n".join(lines))  # no trailing newline: the last line still counts
+    names, cid, s, e = cli.read_bed3_lines(str(p))
+    assert [names[k] for k in cid] == chroms and s.tolist() == starts.tolist() and e.tolist() == ends.tolist()
+    first_seen = list(dict.fromkeys(chroms))
+    assert names == first_seen
+    for bad, msg in (("chr1\t5", "Missing end field"), ("chr1", "Missing start field"), ("", "Missing start field"),
+                     ("chr1\t-1\t5", "invalid digit"), ("chr1\t1\t5 ", "invalid digit"), ("chr1\t1\t4294967296", "invalid digit"),
+                     ("chr1 1 5", "Missing start field")):
+        q = tmp_path / "bad.bed"
+        q.write_text("\n".join(lines[:70_000] + [bad] + lines[70_000:]))
+        with pytest.raises(ValueError, match=f"bad.bed:70001: {msg}"):
+            cli.read_bed3_lines(str(q))
+
+
+def test_dense_region_ids_and_hit_lines(tmp_path):
+    """gtars_regionset_dense_ids = generate_region_to_id_map (gtars-core/src/utils.rs:202-214: first-seen ids over the whole
+    Region incl. rest); gtars_format_hit_lines = the overlaprs output lines."""
+    import ctypes as C
+
+    from gtars_amd import _lib
+    from gtars_amd.models import RegionSet
+
+    p = tmp_path / "c.bed"
+    p.write_text("chr1\t10\t20\ta\nchr1\t10\t20\tb\nchr1\t10\t20\ta\nchr2\t5\t9\nchr2\t5\t9\nchr1\t1\t2\n")
+    rs = RegionSet(str(p))
+    regs = [(r.chr, r.start, r.end, r.rest) for r in rs]
+    exp, seen = [], {}
+    for r in regs:
+        exp.append(seen.setdefault(r, len(seen)))
+    h, n_ids = C.c_void_p(), C.c_uint32()
+    _lib.check(_lib.lib.gtars_regionset_dense_ids(rs._h, C.byref(h), C.byref(n_ids)))
+    assert _lib.take_u32(h, len(rs)).tolist() == exp and n_ids.value == len(seen) == 4
+    names = [b"chrA", b"chr10"]
+    arr = (C.c_char_p * 2)(*names)
+    hc, hs, he = (np.asarray(x, dtype=np.uint32) for x in ([1, 0, 1], [0, 4294967295, 12], [7, 5, 4000000000]))
+    text, ln = C.c_void_p(), C.c_uint64()
+    _lib.check(_lib.lib.gtars_format_hit_lines(C.cast(arr, C.c_void_p), _lib.ptr(hc), _lib.ptr(hs), _lib.ptr(he), 3, C.byref(text), C.byref(ln)))
+    try:
+        assert C.string_at(text, ln.value) == b"chr10\t0\t7\nchrA\t4294967295\t5\nchr10\t12\t4000000000\n"
+    finally:
+        _lib.lib.gtars_free(text)
