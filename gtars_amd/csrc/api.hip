@@ -369,6 +369,27 @@ struct gtars_igd {
     DevBuf<i32> tile_pm;
     DevBuf<unsigned short> tile_files16;
     DevBuf<u32> tile_tab;
+    // per chromosome, the reference contig's tile count at nbp = 16384 (min_overlap <= 0 counts), built on first use
+    mutable std::mutex ntiles_mu;
+    mutable DevBuf<i32> chrom_ntiles;
+    mutable bool ntiles_ready = false;
+    gtars_status ensure_ntiles() const {
+        std::lock_guard<std::mutex> lk(ntiles_mu);
+        if (ntiles_ready) return GTARS_OK;
+        gtars_status st = ensure_mirror();
+        if (st) return st;
+        std::vector<u32> off(n_chrom + 1, 0);
+        if (n_chrom) GT_HIP(hipMemcpy(off.data(), chrom_off.p, ((size_t)n_chrom + 1) * 4, hipMemcpyDeviceToHost));
+        std::vector<i32> nt(std::max<u32>(n_chrom, 1), 0);
+        for (u32 c = 0; c < n_chrom; ++c) {
+            i32 mx = 0;
+            for (u32 p = off[c]; p < off[c + 1]; ++p) mx = std::max(mx, h_ends[p]);
+            nt[c] = off[c + 1] > off[c] ? (mx - 1) / 16384 + 1 : 0;
+        }
+        if ((st = chrom_ntiles.upload(nt))) return st;
+        ntiles_ready = true;
+        return GTARS_OK;
+    }
     // static routing table (IgdTiles::route_*)
     DevBuf<u32> route_lut, route_base, route_len;
     u32 route_n = 0, route_shift = 0;
@@ -518,6 +539,7 @@ struct gtars_igd {
         v.values = values.p;
         v.chrom_off = chrom_off.p;
         v.chrom_maxlen = chrom_maxlen.p;
+        v.chrom_ntiles = ntiles_ready ? chrom_ntiles.p : nullptr;
         v.n_chrom = n_chrom;
         v.n = (u32)n;
         v.n_files = n_files;
@@ -1983,6 +2005,7 @@ void gtars_igd_free(gtars_igd_t *g) {
     g->tile_pm.release();
     g->tile_files16.release();
     g->tile_tab.release();
+    g->chrom_ntiles.release();
     g->route_lut.release();
     g->route_base.release();
     g->route_len.release();
@@ -2029,8 +2052,13 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
                                     uint64_t *d_hits, void *stream) {
     gtars_status st = check_query_args(g, d_qc, d_qs, d_qe, nq);
     if (st) return st;
-    if (min_overlap < 1) return fail(GTARS_ERR_INVALID_ARG, "IGD queries are defined for min_overlap >= 1");
     if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
+    if (min_overlap < 1) {
+        // The reference's tile walk also admits non-overlapping records then, depending on the 16384-bp tile they fall in
+        // (igd.rs:772-846): reproduced by the per-query kernel with the walk's tile test (kernels.hip, IgdQual).
+        if ((st = g->ensure_ntiles())) return st;
+        return launch_igd_count(g->view(), nullptr, d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
+    }
     if (igd_sweep_supported(g->view(), nq)) {
         // large batch: group the queries by owner tile once, stream the database once (igd_sweep.hip)
         const bool no_pme = getenv("GTARS_IGD_NO_PME") != nullptr;  // tests / A-B runs: the credited-file list instead
@@ -2070,10 +2098,10 @@ gtars_status gtars_igd_count_per_query(const gtars_igd_t *g, const uint32_t *qc,
                                        uint32_t *counts) {
     gtars_status st = check_query_args(g, qc, qs, qe, nq);
     if (st) return st;
-    if (min_overlap < 1) return fail(GTARS_ERR_INVALID_ARG, "IGD queries are defined for min_overlap >= 1");
     st = require_device();
     if (st) return st;
     if (!nq) return GTARS_OK;
+    if (min_overlap < 1 && (st = g->ensure_ntiles())) return st;  // the walk's tile test (kernels.hip, IgdQual)
     DevQueries q;
     st = q.upload(qc, qs, qe, nq);
     if (st) return st;
@@ -2096,9 +2124,9 @@ gtars_status gtars_igd_find_pairs(const gtars_igd_t *g, const uint32_t *qc, cons
     if (!out_q || !out_s || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
     *out_q = *out_s = nullptr;
     *out_n = 0;
-    if (min_overlap < 1) return fail(GTARS_ERR_INVALID_ARG, "IGD queries are defined for min_overlap >= 1");
     st = require_device();
     if (st) return st;
+    if (min_overlap < 1 && (st = g->ensure_ntiles())) return st;  // the walk's tile test (kernels.hip, IgdQual)
     DevQueries q;
     st = q.upload(qc, qs, qe, nq);
     if (st) return st;

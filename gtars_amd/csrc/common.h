@@ -123,6 +123,9 @@ struct IgdView {
     const i32 *values;
     const u32 *chrom_off;  // [n_chrom + 1]
     const i32 *chrom_maxlen;  // [n_chrom] max(end-start)
+    // [n_chrom] tiles of the reference's contig at nbp = 16384, (largest end - 1) / 16384 + 1 -- what the walk of
+    // igd.rs:772-846 needs to reproduce min_overlap <= 0; null until such a query is made (gtars_igd::ensure_ntiles)
+    const i32 *chrom_ntiles;
     u32 n_chrom;
     u32 n;
     u32 n_files;
@@ -204,6 +207,7 @@ gtars_status launch_scan_u32_to_u64(const u32 *counts, u64 n, u64 *offsets, void
 size_t scan_ws_bytes(u64 n);
 
 // pme_file (may be null): IgdTiles::pme_file, used for binary counts with min_overlap == 1
+// (min_overlap < 1 needs v.chrom_ntiles)
 gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               i32 min_overlap, int binary, u64 *hits, hipStream_t st);
 gtars_status launch_occupy(u32 workgroups, u32 lds_bytes, u32 microseconds, hipStream_t st);

@@ -586,20 +586,57 @@ gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, 
 // [lower_bound(qs - max_len), lower_bound(qe)).
 // Query validation follows Igd::count_overlaps (igd.rs:514-517).
 
+// min_overlap <= 0 (igd.rs accepts it): the walk then also admits records that do not overlap the query, and which ones
+// depends on the tiling -- the first tile n1 = qs / nbp scans every record PRESENT in it (start / nbp <= n1 <= (end - 1) / nbp),
+// a later tile j <= n2 = (qe - 1) / nbp only the records that START in it (igd.rs:772-846), each once, all with start < qe
+// and min(end, qe) - max(start, qs) >= min_overlap.  For min_overlap >= 1 every overlapping record passes that tile test,
+// which is why the flat formula suffices there.  nbp = 16384 (Igd::new, igd.rs:80-83).
+constexpr i32 IGD_NBP_COUNT = 16384;
+struct IgdQual {
+    i32 qs, qe, mo, n1, n2;
+    bool tiled;
+    __device__ __forceinline__ bool operator()(i32 s, i32 e) const {
+        const i32 ov = (e < qe ? e : qe) - (s > qs ? s : qs);
+        if (ov < mo) return false;
+        if (!tiled) return true;
+        const i32 ts = s / IGD_NBP_COUNT;
+        return ts <= n1 ? (e - 1) / IGD_NBP_COUNT >= n1 : ts <= n2;
+    }
+};
+// -> false: no record can qualify (unknown / empty chromosome, or -- tiled -- the query starts past the contig's last tile);
+// lo = where the scan starts
+__device__ __forceinline__ bool igd_walk_setup(const IgdView &v, u32 c, i32 qs, i32 qe, i32 min_overlap, IgdQual &q, u32 &lo,
+                                               u32 &seg_hi) {
+    if (c >= v.n_chrom) return false;
+    const u32 seg_lo = v.chrom_off[c];
+    seg_hi = v.chrom_off[c + 1];
+    if (seg_lo == seg_hi) return false;
+    q.qs = qs;
+    q.qe = qe;
+    q.mo = min_overlap;
+    q.tiled = min_overlap < 1;
+    q.n1 = q.n2 = 0;
+    i64 key = (i64)qs - (i64)v.chrom_maxlen[c];
+    if (q.tiled) {
+        const i32 nt = v.chrom_ntiles[c];
+        q.n1 = qs / IGD_NBP_COUNT;
+        if (q.n1 >= nt) return false;
+        q.n2 = min((qe - 1) / IGD_NBP_COUNT, nt - 1);
+        key += (i64)min_overlap;  // a record left of the query may end up to -min_overlap before it
+    }
+    lo = lower_bound_i32(v.starts, seg_lo, seg_hi, key > 0 ? (i32)key : 0);  // starts are >= 0
+    return true;
+}
+
 template <class F>
 __device__ __forceinline__ void igd_walk(const IgdView &v, u32 c, i32 qs, i32 qe, i32 min_overlap, F &&f) {
-    if (c >= v.n_chrom) return;
-    const u32 seg_lo = v.chrom_off[c], seg_hi = v.chrom_off[c + 1];
-    if (seg_lo == seg_hi) return;
-    const i32 max_len = v.chrom_maxlen[c];
-    const i32 key = qs > max_len ? qs - max_len : 0;  // starts are >= 0
-    u32 i = lower_bound_i32(v.starts, seg_lo, seg_hi, key);
+    IgdQual q;
+    u32 i, seg_hi;
+    if (!igd_walk_setup(v, c, qs, qe, min_overlap, q, i, seg_hi)) return;
     for (; i < seg_hi; ++i) {
         const i32 s = v.starts[i];
         if (s >= qe) break;
-        const i32 e = v.ends[i];
-        const i32 ov = (e < qe ? e : qe) - (s > qs ? s : qs);
-        if (ov >= min_overlap) f(i);
+        if (q(s, v.ends[i])) f(i);
     }
 }
 
@@ -643,10 +680,9 @@ k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
             // count file f once per query: only at the first hit (in scan order) that belongs to f.
             // "Is there an earlier hit of the same file" looks at the file ids of the (short) scanned
             // prefix first and tests the overlap only for records of the same file.
-            const u32 seg_lo = c < v.n_chrom ? v.chrom_off[c] : 0u;
-            const i32 max_len = c < v.n_chrom ? v.chrom_maxlen[c] : 0;
-            const i32 key = s > max_len ? s - max_len : 0;
-            const u32 lo = c < v.n_chrom ? lower_bound_i32(v.starts, seg_lo, v.chrom_off[c + 1], key) : 0u;
+            IgdQual qual;
+            u32 lo = 0, seg_hi0 = 0;
+            if (!igd_walk_setup(v, c, s, e, min_overlap, qual, lo, seg_hi0)) continue;
             unsigned long long seen0 = 0, seen1 = 0;  // 128-bit filter of files already credited
             igd_walk(v, c, s, e, min_overlap, [&](u32 i) {
                 const u32 f = v.files[i];
@@ -657,13 +693,9 @@ k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                 word |= bit;
                 bool first = true;
                 for (u32 k = lo; maybe_dup && k < i; ++k) {
-                    if (v.files[k] == f) {
-                        const i32 ks = v.starts[k], ke = v.ends[k];
-                        const i32 ov = (ke < e ? ke : e) - (ks > s ? ks : s);
-                        if (ov >= min_overlap) {
-                            first = false;
-                            break;
-                        }
+                    if (v.files[k] == f && qual(v.starts[k], v.ends[k])) {
+                        first = false;
+                        break;
                     }
                 }
                 if (first) {
@@ -687,6 +719,7 @@ k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
 gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               i32 min_overlap, int binary, u64 *hits, hipStream_t st) {
     if (!binary || min_overlap != 1) pme_file = nullptr;
+    if (min_overlap < 1 && !v.chrom_ntiles) return fail(GTARS_ERR_INTERNAL, "IGD count with min_overlap < 1 needs the contigs' tile counts");
     GT_HIP(hipMemsetAsync(hits, 0, sizeof(u64) * (v.n_files ? v.n_files : 1), st));
     if (nq == 0 || v.n == 0) return GTARS_OK;
     // u32 LDS bins cannot overflow: a workgroup adds at most (its queries x hits);
@@ -726,15 +759,17 @@ __device__ __forceinline__ void igd_walk_ref_order(const IgdView &v, u32 c, i32 
     const u32 seg_lo = v.chrom_off[c], seg_hi = v.chrom_off[c + 1];
     if (seg_lo == seg_hi) return;
     if (qs < 0) return;  // the reference indexes tiles[n1] with n1 < 0 -> panic; no result defined
-    const i32 max_len = v.chrom_maxlen[c];
-    const i32 key = qs > max_len ? qs - max_len : 0;
-    const u32 lo = lower_bound_i32(v.starts, seg_lo, seg_hi, key);
+    const i32 n1 = qs / IGD_NBP;
+    const bool tiled = min_overlap < 1;  // see IgdQual: the first tile then only serves the records PRESENT in it
+    if (tiled && n1 >= v.chrom_ntiles[c]) return;
+    i64 key = (i64)qs - (i64)v.chrom_maxlen[c] + (tiled ? (i64)min_overlap : 0);
+    const u32 lo = lower_bound_i32(v.starts, seg_lo, seg_hi, key > 0 ? (i32)key : 0);
     const u32 hi = lower_bound_i32(v.starts, lo, seg_hi, qe);
     if (lo >= hi) return;
-    const i32 n1 = qs / IGD_NBP;
     // group boundaries: first group = starts < (n1+1)*nbp
     u32 g_lo = lo;
     i64 bd = (i64)IGD_NBP * ((i64)n1 + 1);
+    bool first_group = true;
     while (g_lo < hi) {
         u32 g_hi = g_lo;
         // end of this group: first position with start >= bd
@@ -750,9 +785,10 @@ __device__ __forceinline__ void igd_walk_ref_order(const IgdView &v, u32 c, i32 
             --i;
             const i32 s = v.starts[i], e = v.ends[i];
             const i32 ov = (e < qe ? e : qe) - (s > qs ? s : qs);
-            if (ov >= min_overlap) f(i);
+            if (ov >= min_overlap && !(tiled && first_group && (e - 1) / IGD_NBP < n1)) f(i);
         }
         g_lo = g_hi;
+        first_group = false;
         if (g_lo < hi) {
             // jump to the tile that holds the next record
             const i64 t = (i64)v.starts[g_lo] / IGD_NBP;

@@ -263,9 +263,9 @@ class Igd:
         return int(h.sum())
 
     def count_set_overlaps(self, regions, min_overlap: int = 1) -> np.ndarray:
-        """igd.rs:544-561.  ``min_overlap`` must be >= 1 (``ValueError`` otherwise): for ``min_overlap <= 0`` the
-        reference's tile walk admits records that do not overlap the query, depending on the tile they fall in -- a
-        deliberate divergence, see INTEGRATION.md.  The same holds for every query method below."""
+        """igd.rs:544-561.  ``min_overlap <= 0`` is accepted like in the reference: its tile walk then also admits records
+        that do not overlap the query, depending on the 16384-bp tile they fall in (igd.rs:772-846) -- reproduced here
+        by the per-query kernels with the walk's tile test.  The same holds for every query method below."""
         self._require()
         return self._engine.count_set_overlaps(*self._encode(regions), min_overlap=min_overlap)[: self.num_files()]
 

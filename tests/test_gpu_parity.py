@@ -600,6 +600,38 @@ def test_igd_sweep_matches_oracle(ga, monkeypatch, seed, n, nq, F, span, wmax):
     assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
 
 
+def test_igd_non_positive_min_overlap_follows_the_tile_walk(ga):
+    """igd.rs:772-846 with min_overlap <= 0: the walk also admits records that do NOT overlap the query, depending on the
+    16384-bp tile they fall in.  Every IGD query against the oracle's literal tile walk, incl. records that straddle tile
+    borders, queries spanning several tiles, queries past the contig's last tile and database values that repeat."""
+    rng = np.random.default_rng(2024)
+    n, nq, F, n_chrom = 30_000, 20_000, 40, 3
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, 400_000, n)
+    s[: n // 4] = (rng.integers(1, 24, n // 4) * 16384 - rng.integers(0, 300, n // 4)).clip(0)  # right before tile borders
+    e = s + rng.integers(1, 2_000, n)
+    e[:200] = s[:200] + rng.integers(16_000, 70_000, 200)  # records that span several tiles
+    f = rng.integers(0, F, n)
+    for values in (np.arange(n), rng.integers(0, n // 3, n)):
+        g, o = _igd_pair(ga, c, s, e, f, values, n_chrom=n_chrom, n_files=F)
+        qc = rng.integers(0, n_chrom + 1, nq)
+        qc[qc == n_chrom] = UNK
+        qs = rng.integers(0, 430_000, nq).astype(np.int64)
+        qs[: nq // 5] = (rng.integers(1, 26, nq // 5) * 16384 + rng.integers(-200, 200, nq // 5)).clip(0)
+        qe = qs + rng.integers(1, 600, nq)
+        qe[:300] = qs[:300] + rng.integers(16_384, 60_000, 300)  # queries over several tiles
+        for mo in (0, -1, -50, -1000, -40_000):
+            assert g.count_set_overlaps(qc, qs, qe, mo).tolist() == o.count_set_overlaps(qc, qs, qe, mo, n_files=F).tolist(), mo
+            assert g.count_region_hits(qc, qs, qe, mo).tolist() == o.count_region_hits(qc, qs, qe, mo, n_files=F).tolist(), mo
+        for mo in (0, -50, -1000):
+            sub = slice(0, 4000)
+            assert g.count_overlaps_per_query(qc[sub], qs[sub], qe[sub], mo).tolist() == \
+                o.count_overlaps_per_query(qc[sub], qs[sub], qe[sub], mo).tolist(), mo
+            gq, gs_ = g.find_overlaps_regionset(qc[sub], qs[sub], qe[sub], mo)
+            oq, os_ = o.find_overlaps_regionset(qc[sub], qs[sub], qe[sub], mo)
+            assert gq.tolist() == oq.tolist() and gs_.tolist() == os_.tolist(), mo
+
+
 def test_igd_sweep_presorted_batch_skips_the_sort(ga, monkeypatch):
     """A batch already in (chromosome, start) order takes the sweep without the partition; same vectors as the oracle
     and as the forced-partition path.  The choice is made on the device (no host round trip); what the tests observe
