@@ -49,7 +49,7 @@ def main(src, dst):
                      "universe_regions": bench["config"]["universe_regions"]},
         "kernel": kernel,
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 20 "
-                   "--warmup 5 --no-cpu-baseline --no-extras --min-seconds 0.05 (two separate passes; steps rotate "
+                   "--warmup 5 --no-cpu-baseline --no-extras --no-pmc --min-seconds 0.05 (two separate passes; steps rotate "
                    "through 32 distinct batches)",
         "fetch_size_kb_raw": out["FETCH_SIZE"],
         "write_size_kb_raw": out["WRITE_SIZE"],
@@ -60,7 +60,7 @@ def main(src, dst):
         "traffic_bytes_per_launch": fetch + write,
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
         "note": "fetch = 12.0 MB query stream + the index pulled into each of the 8 non-coherent XCD L2s (1.6 MB of "
-                "32-byte block records + 0.1 MB of LDS search keys per XCD; FETCH_SIZE counts L2->fabric requests, so the "
+                "32-byte block records + 0.13 MB of LDS search keys per XCD; FETCH_SIZE counts L2->fabric requests, so the "
                 "repeat copies are most likely served by the 256 MB Infinity Cache rather than HBM); writes = "
                 "8*(Nq+1)+4*H",
     }
@@ -69,6 +69,8 @@ def main(src, dst):
     if igd:
         shutil.copy(igd, f"{dst}/kernel_stats_igd_config3.csv")
         shutil.copy(f"{src}/igd.json", f"{dst}/igd_config3.json")
+    if os.path.exists(f"{src}/traffic_igd_config3.json"):
+        shutil.copy(f"{src}/traffic_igd_config3.json", f"{dst}/traffic_igd_config3.json")
     print(json.dumps(doc["fetch_size_kb_raw"]), doc["traffic_bytes_per_launch"])
 
 
