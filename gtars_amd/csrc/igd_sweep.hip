@@ -74,7 +74,7 @@ __device__ __forceinline__ void lut_range(const unsigned short *lut, i32 x, i32 
 #define IGD_PREFETCH 1  // next tile's records loaded into registers before the current tile's queries are served
 #endif
 #ifndef IGD_GROUP_LANES
-#define IGD_GROUP_LANES 8  // lanes that walk one query's candidate records together (pair loop of the sweep)
+#define IGD_GROUP_LANES 4  // lanes that walk one query's candidate records together (pair loop of the sweep; 4 / 8 / 16: 0.263 / 0.278 / 0.318 ms)
 #endif
 constexpr int IGD_SEEN = 32;   // per-thread list of credited files (binary counting)  // records after the tile kept in LDS too (a query's scan may run past its tile)
 
