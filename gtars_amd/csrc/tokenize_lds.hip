@@ -62,6 +62,12 @@ __device__ __forceinline__ void st_stream2(u64 *p, u64 a, u64 b) {
 
 // diagnostic build (tools/build_variant.sh tokstamps "-DGTARS_TOK_STAMPS=1", tools/r03_tok_stamps.py): shader-clock totals per
 // phase of the tile loop, for wave 0 (the look-back wave) and wave 1 of every workgroup, and the look-back's round counts
+#ifndef GTARS_TOK_FILL_U
+#define GTARS_TOK_FILL_U 4  // unroll factor of the copy of the search structure into LDS (16-byte loads in flight per thread)
+#endif
+#ifndef GTARS_TOK_PRIO
+#define GTARS_TOK_PRIO 0  // 1: s_setprio 1 during the count phase, 2: during the write phase (A/B)
+#endif
 #ifndef GTARS_TOK_LB_W1
 #define GTARS_TOK_LB_W1 1  // look-back windows per round in one-tile-per-group launches (see resolve_prefix_helping)
 #endif
@@ -255,14 +261,16 @@ __host__ __device__ __forceinline__ size_t tok_lds_bytes(const AccelView &a) {
 
 template <int TPB>
 __device__ __forceinline__ void fill_search_lds(const AccelView &a, u32 *smem) {
-    // 16-byte loads, 4 in flight.  Every workgroup copies the same arrays: start each one at a
+    // 16-byte loads, GTARS_TOK_FILL_U in flight.  Every workgroup copies the same arrays: start each one at a
     // different place so that they do not all queue on the same L2 channel at the same time.
+    // (A hand-batched form with the loads of a whole batch held in a register array went to scratch -- 176 bytes per lane --
+    // and cost 6-10 us per launch; the compiler's own unrolling of this loop keeps them in registers.)
     const u32 n4a = a.lut_words >> 2, n4 = n4a + (a.q_words >> 2);
     const uint4 *src_a = reinterpret_cast<const uint4 *>(a.lut);
     const uint4 *src_b = reinterpret_cast<const uint4 *>(a.qkeys);
     uint4 *dst = reinterpret_cast<uint4 *>(smem);
     const u32 rot = (u32)(((u64)blockIdx.x * 2654435761ull) % n4);
-#pragma unroll 4
+#pragma unroll GTARS_TOK_FILL_U
     for (u32 i = threadIdx.x; i < n4; i += TPB) {
         u32 k = i + rot;
         k = k >= n4 ? k - n4 : k;
@@ -770,7 +778,13 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
 #endif
             TSTAMP(0);
             u32 tsum[R], inc[R];
+#if GTARS_TOK_PRIO & 1
+            __builtin_amdgcn_s_setprio(1);  // the group that feeds the vector-memory path goes first
+#endif
             count_rounds<R, QPT, FILTER, IMPL, REV>(a, L, c, s, e, min_bp, cur.q, tsum);
+#if GTARS_TOK_PRIO & 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
             TSTAMP(1);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -822,6 +836,9 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
             TSTAMP(3);
             bar();
             TSTAMP(4);
+#if GTARS_TOK_PRIO & 2
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const u64 q0 = (u64)prev.tile * TILE + (u64)r * ROUND + (u64)gtid * QPT;
@@ -833,6 +850,9 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                                                           offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
             }
         }
+#if GTARS_TOK_PRIO & 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         TSTAMP(5);
         bar();  // s_tile / s_prefix / s_scan reuse
         TSTAMP(6);
