@@ -297,11 +297,13 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             const u32 i = base + (u32)j * SP_TPB + threadIdx.x;
             const bool ok = i < n;
             k[j] = ok ? (u32)key[i] : 0xFFFFFFFFu;
-            if (k[j] == drop_bin) k[j] = 0xFFFFFFFFu;  // no owner: dropped here
             if (FINE) {
                 const uint2 p = ok ? ab_in[i] : make_uint2(0u, 0u);
                 va[j] = p.x;
                 vb[j] = p.y;
+                // no owner: dropped HERE, not in the first pass -- that pass must fill all n slots of its output (the drop
+                // bin's coarse segment included), or this one would read whatever an earlier call left behind the kept ones
+                if (k[j] == drop_bin) k[j] = 0xFFFFFFFFu;
             } else {
                 va[j] = ok ? a[i] : 0u;
                 vb[j] = ok ? b[i] : 0u;

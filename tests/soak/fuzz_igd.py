@@ -44,9 +44,14 @@ def one(seed):
         os.environ["GTARS_IGD_SWEEP_MIN"] = "1"
     else:
         os.environ.pop("GTARS_IGD_SWEEP_MIN", None)
-    for mo in (1, int(rng.integers(2, 40))):
+    # min_overlap <= 0: the reference's tile walk also admits non-overlapping records (per-query kernels with the tile test)
+    for mo in (1, int(rng.integers(2, 40)), int(rng.choice([0, -1, -30, -20_000]))):
         assert np.array_equal(g.count_set_overlaps(qc, qs, qe, mo), o.count_set_overlaps(qc, qs, qe, mo, n_files=F)), ("pair", seed, mo)
         assert np.array_equal(g.count_region_hits(qc, qs, qe, mo), o.count_region_hits(qc, qs, qe, mo, n_files=F)), ("bin", seed, mo)
+    if nq <= 5000 and n <= 3000:
+        ok = (qs < 2**31) & (qe < 2**31)  # count_overlaps_per_query / find_overlaps_regionset take the query as it is
+        mo = int(rng.choice([1, 5, 0, -30]))
+        assert np.array_equal(g.count_overlaps_per_query(qc[ok], qs[ok], qe[ok], mo), o.count_overlaps_per_query(qc[ok], qs[ok], qe[ok], mo)), ("perq", seed, mo)
     return nq
 
 

@@ -42,6 +42,11 @@ def one(seed):
         os.environ["GTARS_TOP_MAX"] = str(top_max)
     else:
         os.environ.pop("GTARS_TOP_MAX", None)
+    buckets = rng.choice(["", "64", "4096", "16384"])  # bucket-table size of the LDS search (read at index build)
+    if buckets:
+        os.environ["GTARS_TOK_BUCKETS"] = str(buckets)
+    else:
+        os.environ.pop("GTARS_TOK_BUCKETS", None)
     g = gtars_amd.OverlapIndex(c, s, e, val, n_chrom=n_chrom, kind=kind)
     o = oracle.Index(c, s, e, val, n_chrom=n_chrom, kind=kind)
     nq = int(rng.choice([1, 5, 257, 4096, 4097, 70_001]))
@@ -63,6 +68,10 @@ def one(seed):
     mo = [None, 2, 7][seed % 3]  # regions with payload: positions from the fused kernel + gather
     for a, b in zip(g.find_overlaps(qc, qs, qe, mo), o.find_overlaps_regions(qc, qs, qe, mo)):
         assert np.array_equal(a, b), ("find", seed, mo)
+    if seed % 4 == 0:  # index-side subset: the bitmap-marking pass against the oracle's BTreeSet restatement
+        mo = [None, 3][seed % 8 == 0]
+        for a, b in zip(g.subset_by_overlaps(qc, qs, qe, mo), oracle.mco_subset_by_overlaps(o, qc, qs, qe, mo)):
+            assert np.array_equal(a, b), ("subset", seed, mo)
     return n, nq, len(ids_o)
 
 

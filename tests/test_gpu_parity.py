@@ -1166,9 +1166,12 @@ def test_bits_insert_and_seek_match_the_reference_rules(ga):
 def test_igd_two_level_partition_with_a_sparse_tail(ga, monkeypatch):
     """The two-level, LDS-reordered partition (k_split_pass) on a skewed batch: 1.2M queries, most of them inside one
     100-kb window, 10k spread over the whole genome.  In the second pass a tile of the sparse tail spans far more than
-    the 1024-key window, so its elements take the direct-slot path.  Three independent routes must agree: the shuffled
-    batch (partitioned), the same batch in (chromosome, start) order (no partition at all) and the per-query kernel
-    (no sweep), for pairwise and binary counts."""
+    the 1024-key window, so its elements take the direct-slot path.  6000 queries have NO owner tile (unknown chromosome,
+    start past every record of the chromosome, start >= end): the partition drops them in its second pass, and the first
+    pass has to carry them (a first pass that drops them leaves the tail of its output to whatever an earlier call wrote
+    there: round 3's soak found exactly that).  Three independent routes must agree: the shuffled batch (partitioned), the
+    same batch in (chromosome, start) order (no partition at all) and the per-query kernel (no sweep), for pairwise and
+    binary counts; the partitioned call runs twice with a different batch in between, so stale workspace would show."""
     from gtars_amd import synth
 
     F = 50
@@ -1178,15 +1181,22 @@ def test_igd_two_level_partition_with_a_sparse_tail(ga, monkeypatch):
     rng = np.random.default_rng(8)
     n_hot, n_tail = 1_190_000, 10_000
     bg = synth.make_background_queries(n_tail, seed=5)
-    qc = np.concatenate([np.zeros(n_hot, dtype=np.uint32), bg["chrom"]])
+    n_lost = 2000
+    lost_c = np.concatenate([np.full(n_lost, 0xFFFFFFFF, dtype=np.uint32), np.zeros(2 * n_lost, dtype=np.uint32)])
+    lost_s = np.concatenate([rng.integers(0, 10**8, n_lost), rng.integers(3 * 10**8, 4 * 10**8, n_lost), rng.integers(10**6, 10**8, n_lost)])
+    lost_e = np.concatenate([lost_s[:2 * n_lost] + 300, lost_s[2 * n_lost:] - rng.integers(0, 50, n_lost)])
+    qc = np.concatenate([np.zeros(n_hot, dtype=np.uint32), bg["chrom"], lost_c])
     hs = rng.integers(5_000_000, 5_100_000, n_hot)
-    qs = np.concatenate([hs, bg["start"]]).astype(np.uint32)
-    qe = np.concatenate([hs + rng.integers(1, 500, n_hot), bg["end"]]).astype(np.uint32)
+    qs = np.concatenate([hs, bg["start"], lost_s]).astype(np.uint32)
+    qe = np.concatenate([hs + rng.integers(1, 500, n_hot), bg["end"], lost_e]).astype(np.uint32)
     sh = rng.permutation(len(qc))
     qc, qs, qe = qc[sh], qs[sh], qe[sh]
-    order = np.lexsort((qs, qc))
+    order = np.lexsort((qs, np.where(qs >= qe, 0xFFFFFFFF, qc)))  # rejected queries last: the batch stays in owner order
+    other = synth.make_background_queries(1_100_000, seed=6)
     for count in (g.count_set_overlaps, g.count_region_hits):
         shuffled = count(qc, qs, qe, 1)
+        count(other["chrom"], other["start"], other["end"], 1)  # leaves its own intermediate data in the workspace
+        assert np.array_equal(count(qc, qs, qe, 1), shuffled)
         in_order = count(qc[order], qs[order], qe[order], 1)
         monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "100000000")
         per_query = count(qc, qs, qe, 1)
