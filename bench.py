@@ -444,34 +444,52 @@ def bench_lola_config4(dev, stream, n_sets=LOLA4["n_sets"], per_set=LOLA4["per_s
     t = time.time()
     g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=n_sets)
     tb = time.time() - t
-    uq = [_dev(uni[k], dev) for k in ("chrom", "start", "end")]
-    sq = [_dev(uni[k][sel], dev) for k in ("chrom", "start", "end")]
-    uh = torch.zeros(n_sets, dtype=torch.int64, device=dev)
-    sh = torch.zeros(n_sets, dtype=torch.int64, device=dev)
-    cells = [torch.empty(n_sets, dtype=torch.int64, device=dev) for _ in range(4)]
+    # the universe and the user set as ONE resident batch of two sets: both support vectors come out of one pass over the
+    # region DB (gtars_igd_count_sets_device; the reference walks the database once per set, enrichment.rs:198-215)
+    both = [_dev(np.concatenate([uni[k], uni[k][sel]]), dev) for k in ("chrom", "start", "end")]
     nuni = len(uni["chrom"])
+    set_off = [0, nuni, nuni + n_user]
+    support = torch.zeros(2, n_sets, dtype=torch.int64, device=dev)
+    uh, sh = support[0], support[1]
+    cells = [torch.empty(n_sets, dtype=torch.int64, device=dev) for _ in range(4)]
 
     def run():
-        g.count_device(uq[0].data_ptr(), uq[1].data_ptr(), uq[2].data_ptr(), nuni, uh.data_ptr(), 1, True, stream)
-        g.count_device(sq[0].data_ptr(), sq[1].data_ptr(), sq[2].data_ptr(), n_user, sh.data_ptr(), 1, True, stream)
+        g.count_sets_device(both[0].data_ptr(), both[1].data_ptr(), both[2].data_ptr(), set_off, support.data_ptr(), 1, True, stream)
         check(lib.gtars_lola_contingency_device(sh.data_ptr(), uh.data_ptr(), n_sets, n_user, nuni,
                                                 *[c.data_ptr() for c in cells], stream))
 
-    run()
-    torch.cuda.synchronize()
-    times = []
-    for _ in range(7):
-        t0 = time.perf_counter()
-        run()
+    def run_set_by_set():  # what the shared pass replaces: one count per set (round 2's form of this object)
+        g.count_device(both[0].data_ptr(), both[1].data_ptr(), both[2].data_ptr(), nuni, uh.data_ptr(), 1, True, stream)
+        g.count_device(both[0][nuni:].data_ptr(), both[1][nuni:].data_ptr(), both[2][nuni:].data_ptr(), n_user, sh.data_ptr(), 1,
+                       True, stream)
+        check(lib.gtars_lola_contingency_device(sh.data_ptr(), uh.data_ptr(), n_sets, n_user, nuni,
+                                                *[c.data_ptr() for c in cells], stream))
+
+    def timed(fn):
+        fn()
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    dt = statistics.median(times)
+        times = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        return statistics.median(times)
+
+    dt_sets = timed(run_set_by_set)
+    by_set = support.cpu().numpy().copy()
+    dt = timed(run)
+    if not np.array_equal(by_set, support.cpu().numpy()):
+        raise SystemExit("bench.py: lola_config4: the shared pass and the set-by-set counts differ")
     a, b, c, d = [x.cpu().numpy() for x in cells]
     uh_h, sh_h = uh.cpu().numpy(), sh.cpu().numpy()
     ok = bool(((a + b) == uh_h).all() and ((a + c) == n_user).all() and ((a + b + c + d) == nuni).all())
     byts = 12 * (nuni + n_user) + 16 * n_sets * per_set + 8 * 2 * n_sets
     out = {"sets": n_sets, "db_intervals": n_sets * per_set, "universe": nuni, "user": n_user, "build_s": round(tb, 2),
            "counts_ms": round(dt * 1e3, 3), "algorithmic_bytes": byts, "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 5),
+           "counts_ms_set_by_set": round(dt_sets * 1e3, 3),
+           "how": "universe + user set as two sets of one batch: ONE pass over the region DB (gtars_igd_count_sets_device); "
+                  "counts_ms_set_by_set = one count per set (same vectors, checked)",
            "identities_hold": ok, "support_sum": int(a.sum())}
     if not ok:
         raise SystemExit("bench.py: lola_config4: the contingency identities do not hold")
@@ -648,13 +666,11 @@ def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scal
     nuni, n_user = len(uni["chrom"]), len(sel)
     sdb = sharding.ShardedIgd(eng, synth.igd_db_chunks(n_sets * per_set, n_sets, seed=6), synth.N_CHROM, n_sets, mode="bucket",
                               balance_with=[uni["chrom"]])
-    hu, hs = sdb.upload_local(uni), sdb.upload_local(user)
+    hboth = sdb.upload_local_sets([uni, user])  # this rank's share of both sets, one resident batch
     stacked = torch.zeros(2, n_sets, dtype=torch.int64, device=dev)
 
     def run():
-        eng.igd_count_resident(sdb.g, hu, 1, True, stacked[0], sync=False)
-        eng.igd_count_resident(sdb.g, hs, 1, True, stacked[1], sync=False)
-        sharding.all_reduce_hits_(stacked)
+        sdb.count_sets_resident(hboth, 1, True, stacked)  # one pass over the local region DB + the one all-reduce
         return sharding.contingency(stacked[1:], stacked[0], [n_user], nuni)
 
     run()
@@ -678,7 +694,7 @@ def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scal
                                                  f"and the universe's support vectors (enrichment.rs:198-221)",
                                    "local_db_intervals_rank0": sdb.local_intervals,
                                    "verified": "a,b,c,d identities; support sum == the single-GPU value"}
-    del sdb, hu, hs
+    del sdb, hboth
     torch.cuda.empty_cache()
     if scale != 1:
         out["configs_scaled_down_by"] = scale

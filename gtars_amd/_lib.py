@@ -105,6 +105,8 @@ _SIG = {
     "gtars_igd_export": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "gtars_igd_count_device": (C.c_int, [vp, vp, vp, vp, u64, i32, C.c_int, vp, vp]),
     "gtars_igd_count": (C.c_int, [vp, vp, vp, vp, u64, i32, C.c_int, vp]),
+    "gtars_igd_count_sets_device": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint32, i32, C.c_int, vp, vp]),
+    "gtars_igd_count_sets": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint32, i32, C.c_int, vp]),
     "gtars_igd_count_per_query": (C.c_int, [vp, vp, vp, vp, u64, i32, vp]),
     "gtars_igd_find_pairs": (C.c_int, [vp, vp, vp, vp, u64, i32, pp, pp, pu64]),
     "gtars_lola_contingency_device": (C.c_int, [vp, vp, u64, i64, i64, vp, vp, vp, vp, vp]),
@@ -205,9 +207,13 @@ _HOST_SIG = {
     "gtars_igddb_load": (C.c_int, [cstr, pp, C.POINTER(C.c_int32)]),
 }
 
-# every symbol the headers declare must resolve -- fail loudly otherwise
+# every symbol the headers declare must resolve -- fail loudly otherwise (GTARS_AMD_LIB_OLDER=1, A/B tooling only: an older
+# build loaded through GTARS_AMD_LIB may lack the newest entry points; calling one of those then fails at the call)
+_older = bool(os.environ.get("GTARS_AMD_LIB")) and os.environ.get("GTARS_AMD_LIB_OLDER") == "1"
 for _table in (_SIG, _HOST_SIG):
     for _name, (_res, _args) in _table.items():
+        if _older and not hasattr(lib, _name):
+            continue
         _fn = getattr(lib, _name)
         _fn.restype = _res
         _fn.argtypes = _args

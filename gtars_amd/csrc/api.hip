@@ -2074,6 +2074,77 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
     return launch_igd_count(g->view(), g->tiles().pme_file, d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
 }
 
+// Several query sets against one database (LOLA: the universe and the user sets, enrichment.rs:198-221 -- the reference calls
+// count_region_hits once per set).  Up to 4 sets share ONE pass over the database: the partition tags every (start, end) pair with
+// its set and the sweep keeps one row of LDS counters per set; sets that cannot share a pass (more than 4, too many files for the
+// counters, batches below the sweep's crossover, min_overlap < 1) are counted one call per set -- same vectors either way.
+gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d_qc, const uint32_t *d_qs, const uint32_t *d_qe,
+                                         const uint64_t *set_off, uint32_t n_sets, int32_t min_overlap, int binary,
+                                         uint64_t *d_hits, void *stream) {
+    if (!g) return fail(GTARS_ERR_INVALID_ARG, "NULL handle");
+    if (!set_off || n_sets == 0) return fail(GTARS_ERR_INVALID_ARG, "set_off is NULL or n_sets is 0");
+    if (set_off[0] != 0) return fail(GTARS_ERR_INVALID_ARG, "set_off[0] must be 0");
+    for (u32 k = 0; k < n_sets; ++k)
+        if (set_off[k + 1] < set_off[k]) return fail(GTARS_ERR_INVALID_ARG, "set_off must not decrease");
+    const u64 nq = set_off[n_sets];
+    gtars_status st = check_query_args(g, d_qc, d_qs, d_qe, nq);
+    if (st) return st;
+    if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
+    const size_t F = g->n_files;
+    static const bool no_shared = getenv("GTARS_IGD_NO_SHARED_PASS") != nullptr;  // tests / A-B runs
+    for (u32 k0 = 0; k0 < n_sets;) {
+        // the longest run of <= 4 consecutive sets that can share a pass
+        u32 k1 = k0 + 1;
+        if (min_overlap >= 1 && !no_shared) {
+            u32 best = k0 + 1;
+            for (u32 k = k0 + 2; k <= std::min<u32>(n_sets, k0 + 4); ++k)
+                if (igd_sweep_sets_supported(g->view(), g->tiles(), set_off[k] - set_off[k0], k - k0)) best = k;
+            k1 = best;
+        }
+        const u64 lo = set_off[k0], n = set_off[k1] - lo;
+        if (k1 - k0 == 1) {
+            st = gtars_igd_count_device(g, d_qc + lo, d_qs + lo, d_qe + lo, n, min_overlap, binary, d_hits + (size_t)k0 * F, stream);
+            if (st) return st;
+        } else {
+            const bool no_pme = getenv("GTARS_IGD_NO_PME") != nullptr;
+            if (binary && min_overlap == 1 && !no_pme && (st = g->ensure_pme())) return st;
+            Workspace &ws = tls_workspace(2, (hipStream_t)stream);
+            st = ws.reserve(igd_sweep_ws_bytes(n, g->n_tiles, g->n_chrom));
+            if (st) return st;
+            u32 bounds[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            for (u32 k = k0 + 1; k < k1; ++k) bounds[k - k0 - 1] = (u32)(set_off[k] - lo);
+            st = launch_igd_sweep(g->view(), g->tiles(), d_qc + lo, d_qs + lo, d_qe + lo, n, min_overlap, binary, d_hits + (size_t)k0 * F,
+                                  ws.ptr, ws.bytes, (hipStream_t)stream, k1 - k0, bounds);
+            if (st) return st;
+            if (g_prof_on) g_prof_entries[prof_entry("igd_sets_shared_pass")].launches += 1;  // (a fact for the tests, not a time)
+        }
+        k0 = k1;
+    }
+    return GTARS_OK;
+}
+
+gtars_status gtars_igd_count_sets(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
+                                  const uint64_t *set_off, uint32_t n_sets, int32_t min_overlap, int binary, uint64_t *hits) {
+    if (!set_off || n_sets == 0) return fail(GTARS_ERR_INVALID_ARG, "set_off is NULL or n_sets is 0");
+    const u64 nq = set_off[n_sets];
+    gtars_status st = check_query_args(g, qc, qs, qe, nq);
+    if (st) return st;
+    if (!hits && g->n_files) return fail(GTARS_ERR_INVALID_ARG, "hits is NULL");
+    st = require_device();
+    if (st) return st;
+    DevQueries q;
+    st = q.upload(qc, qs, qe, nq);
+    if (st) return st;
+    ScopedDev d;
+    const size_t cells = (size_t)std::max<u32>(g->n_files, 1) * n_sets;
+    st = d.alloc(cells * 8);
+    if (st) return st;
+    st = gtars_igd_count_sets_device(g, q.c, q.s, q.e, set_off, n_sets, min_overlap, binary, d.as<u64>(), nullptr);
+    if (st) return st;
+    if (g->n_files) GT_HIP(hipMemcpy(hits, d.p, (size_t)g->n_files * n_sets * 8, hipMemcpyDeviceToHost));
+    return GTARS_OK;
+}
+
 gtars_status gtars_igd_count(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
                              uint64_t nq, int32_t min_overlap, int binary, uint64_t *hits) {
     gtars_status st = check_query_args(g, qc, qs, qe, nq);

@@ -234,7 +234,9 @@ size_t multisplit_ws_bytes(u32 n_bins, u32 n);
 // workgroup of a multisplit_workgroups(n)-workgroup grid over contiguous chunks of ceil(n / workgroups) elements
 gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
                               uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if = nullptr,
-                              bool table_ready = false);
+                              bool table_ready = false, const u32 *set_bounds = nullptr);
+// set_bounds (host, 3 values; null: one set): the input holds up to 4 row ranges ("sets") -- first row of set 1, 2, 3, 0xFFFFFFFF
+// for a set that does not exist; the set of a row leaves in bit 31 of its pair (b: set & 1, a: set >> 1; see SetTags, sort.hip)
 u32 multisplit_workgroups(u32 n);
 u32 multisplit_chunk(u32 n);  // elements per workgroup of that grid (a multiple of 4)
 u32 *multisplit_table(void *ws);
@@ -282,8 +284,12 @@ gtars_status launch_igd_tile_bounds(const IgdView &v, const u32 *tile_first, con
                                     u32 *bnd, hipStream_t st);
 gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, const u32 *tile_cnt, u32 n_tiles, i32 *tile_max,
                                      hipStream_t st);
+// n_sets > 1: the batch is the concatenation of n_sets <= 4 query sets (set_bounds as for multisplit_pairs), hits is
+// u64[n_sets][n_files]; needs igd_sweep_sets_supported
 gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, i32 min_overlap,
-                              int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st);
+                              int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st, u32 n_sets = 1,
+                              const u32 *set_bounds = nullptr);
+bool igd_sweep_sets_supported(const IgdView &v, const IgdTiles &tl, u64 nq, u32 n_sets);
 constexpr u32 IGD_TILE_RECORDS = 2048;
 gtars_status device_gather_u32(const u32 *src, const u32 *idx, u32 n, u32 *dst, hipStream_t st);
 

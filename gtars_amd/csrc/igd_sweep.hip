@@ -578,12 +578,12 @@ __device__ __forceinline__ u32 sweep_query_slot(int lane, int wave) {
 // MO1: min_overlap == 1 (a candidate record is a hit iff its end is > q_start; its start is not read).
 // Register budget = what the LDS footprint admits: 4 workgroups per CU (8 waves per SIMD, 64 VGPRs) for the pairwise form,
 // 3 (80 VGPRs) with the staged pme_file column; the credited-file-list form keeps its 16 list registers.
-template <int MODE, bool MO1>
+template <int MODE, bool MO1, bool B16 = false>
 __global__ void __launch_bounds__(SW_TPB, MODE == 0 ? 8 : MODE == 2 ? 6 : 4)
 k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__ pm, const unsigned short *__restrict__ files16,
             const u32 *__restrict__ tile_tab, u32 n_tiles, const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap, unsigned long long *__restrict__ hits,
-            const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab, const u32 *__restrict__ part_ql) {
+            const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab, const u32 *__restrict__ part_ql, u32 n_bins) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
     // whether the batch had to be partitioned was decided on the device (the routing kernel): take the partition's
     // interleaved (start, end) pairs and bin offsets, or the batch as it arrived with the tile ranges
@@ -600,12 +600,48 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
     i32 *t_pm = t_e + CAP;                             // prefix maximum of the ends (IgdTiles::pm)
     i32 *t_pf = t_pm + CAP;                            // MODE 2: pme_file of the staged records
     unsigned short *t_f = reinterpret_cast<unsigned short *>(t_pf + (MODE == 2 ? CAP : 0));  // file ids, u16; CAP is even
-    u32 *bins = reinterpret_cast<u32 *>(t_f + CAP);    // [n_files]
+    // [n_bins]: n_files counters per query SET.  A partitioned batch may hold up to 4 sets (gtars_igd_count_sets_device): the set
+    // of a query travels in bit 31 of its (start, end) pair (SetTags, sort.hip) and selects the row of counters its hits go to
+    u32 *bins = reinterpret_cast<u32 *>(t_f + CAP);
+    auto untag = [&](i32 &s, i32 &e) -> u32 {  // -> the query's first counter
+        const u32 set = (((u32)s >> 31) << 1) | ((u32)e >> 31);
+        s &= 0x7FFFFFFF;
+        e &= 0x7FFFFFFF;
+        return __umul24(set, v.n_files);  // < 16384 (the launcher's bound on sets x files)
+    };
+    static_assert(IGD_TILE + IGD_HALO < 4096, "a candidate count and a counter offset share one shuffled word: 12 + 14 bits");
     __shared__ u32 s_lutw[2 * TAB_LUT_WORDS];
     const unsigned short *lut_s = reinterpret_cast<const unsigned short *>(s_lutw);
     const unsigned short *lut_p = reinterpret_cast<const unsigned short *>(s_lutw + TAB_LUT_WORDS);
     constexpr bool BINARY = MODE == 1;
-    for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) bins[i] = 0;
+    // B16 (MODE 2 only): 16-bit counters, two per LDS word.  A query credits a (set, file) at most once, so a counter is bounded
+    // by the number of queries the workgroup has served since its counters were last flushed -- flushed every <= 65535 queries.
+    // Half the LDS for the counters; the launcher takes this form only when that admits one more workgroup per CU (two sets x
+    // 2000 files, config 4: 3 instead of 2) -- the packed increment costs three more instructions per hit (config 3's dense
+    // binary batch: 0.32 -> 0.355 ms with it, for no gain in residency).
+    static_assert(!B16 || MODE == 2, "16-bit counters need the one-credit-per-query bound of the pme_file form");
+    const u32 n_words = B16 ? (n_bins + 1) / 2 : n_bins;
+    auto bump = [&](u32 b) {
+        if (B16)
+            atomicAdd(&bins[b >> 1], 1u << ((b & 1u) * 16u));
+        else
+            atomicAdd(&bins[b], 1u);
+    };
+    auto flush = [&]() {  // (workgroup-uniform; the caller has synchronised)
+        for (u32 i = threadIdx.x; i < n_words; i += SW_TPB) {
+            const u32 b = bins[i];
+            if (!b) continue;
+            if (B16) {
+                if (b & 0xFFFFu) atomicAdd(&hits[2 * i], (unsigned long long)(b & 0xFFFFu));
+                if (b >> 16) atomicAdd(&hits[2 * i + 1], (unsigned long long)(b >> 16));
+                bins[i] = 0;
+            } else {
+                atomicAdd(&hits[i], (unsigned long long)b);
+            }
+        }
+    };
+    u32 since = 0;  // queries served since the last flush (B16)
+    for (u32 i = threadIdx.x; i < n_words; i += SW_TPB) bins[i] = 0;
     constexpr int RPT = (CAP + SW_TPB - 1) / SW_TPB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #if IGD_STAMPS
@@ -691,9 +727,18 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
             const int grp = lane / GL, sub = lane % GL;
             const u32 kq = sweep_query_slot(lane, wave);
             for (u32 qb = q_lo; qb < q_hi; qb += SW_TPB) {
+                if (B16) {
+                    if (since + SW_TPB > 65535u) {  // (uniform) the 16-bit counters could wrap: hand them over first
+                        __syncthreads();
+                        flush();
+                        __syncthreads();
+                        since = 0;
+                    }
+                    since += SW_TPB;
+                }
                 const u32 qi = qb + kq;
                 i32 s = 0, e = 0;
-                u32 lo = 0, len = 0;
+                u32 lo = 0, len = 0, boff = 0;
                 if (qi < q_hi) {
                     if (qb == q_lo) {  // loaded at the top of the tile
                         s = pf_s;
@@ -706,6 +751,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                         s = max((i32)sqs[qi], 0);
                         e = (i32)sqe[qi];
                     }
+                    if (interleaved) boff = untag(s, e);
                     u32 hi, a, b;
                     if (GTARS_IGD_ABLATE & 16) {
                         lo = ((u32)s * 2654435761u) % (n_lds > 40 ? n_lds - 40 : 1u);
@@ -741,7 +787,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                             const i32 ov = (re < e ? re : e) - (rs > s ? rs : s);
                             if (ov < min_overlap) continue;
                             if (MODE == 2 && pme_file[p0 + r] > s) continue;
-                            atomicAdd(&bins[v.files[p0 + r]], 1u);
+                            bump(boff + v.files[p0 + r]);
                         }
                     }
                 }
@@ -753,13 +799,16 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
 #pragma unroll 1
                 for (int i0 = 0; i0 < GL; i0 += U) {
                     i32 qs_[U], qe_[U];
-                    u32 lo_[U], len_[U], mx = 0;
+                    u32 lo_[U], len_[U], bo_[U], mx = 0;
+                    const u32 len_bo = len | (boff << 12);  // one shuffle for both (a shuffle is an LDS instruction)
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int src = grp * GL + i0 + u;  // this group's (i0 + u)-th query
                         qs_[u] = __shfl(s, src, 64);
                         lo_[u] = (u32)__shfl((int)lo, src, 64);
-                        len_[u] = (u32)__shfl((int)len, src, 64);
+                        const u32 lb = (u32)__shfl((int)len_bo, src, 64);
+                        len_[u] = lb & 0xFFFu;
+                        bo_[u] = lb >> 12;
                         qe_[u] = MO1 ? 0 : __shfl(e, src, 64);
                         mx = max(mx, len_[u]);
                     }
@@ -788,7 +837,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                                 if (GTARS_IGD_ABLATE & 2) {
                                     if (re[u] == 0x7FFFFFF0) bins[0] = 1;
                                 } else {
-                                    atomicAdd(&bins[f[u]], 1u);
+                                    bump(bo_[u] + f[u]);
                                 }
                             }
                         }
@@ -800,10 +849,12 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
         for (u32 qi = q_lo + threadIdx.x; qi < q_hi; qi += SW_TPB) {
             // (start, end) pairs as the partition leaves them, or two sorted columns
             i32 s, e;
+            u32 boff = 0;
             if (interleaved) {
                 const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
                 s = (i32)se2.x;
                 e = (i32)se2.y;
+                boff = untag(s, e);
             } else {
                 s = max((i32)sqs[qi], 0);
                 e = (i32)sqe[qi];
@@ -872,7 +923,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                 if (GTARS_IGD_ABLATE & 2) {
                     if (f == 0xFFFFFFF0u) bins[0] = 1;
                 } else {
-                    atomicAdd(&bins[f], 1u);
+                    atomicAdd(&bins[boff + f], 1u);
                 }
             }
         }
@@ -887,10 +938,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
     }
 #endif
     __syncthreads();
-    for (u32 i = threadIdx.x; i < v.n_files; i += SW_TPB) {
-        const u32 b = bins[i];
-        if (b) atomicAdd(&hits[i], (unsigned long long)b);
-    }
+    flush();
 }
 
 
@@ -1104,10 +1152,28 @@ gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, con
     return GTARS_OK;
 }
 
+static bool igd_bucket_path(const IgdView &v, const IgdTiles &tl) {
+    // queries grouped by owner tile in one partition, when the tile bounds fit in LDS (76M records); otherwise
+    // (and for GTARS_IGD_FULL_SORT=1: tests / A-B runs) the batch is fully sorted by (chromosome, start) with the radix sort
+    const size_t prep_lds = ((size_t)tl.n_tiles + v.n_chrom + 1) * 4;
+    return !getenv("GTARS_IGD_FULL_SORT") && tl.bnd && tl.n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024;
+}
+
+// several query sets in one sweep: only through the partition (the set of a query travels with its pair), at most 4 sets (two
+// tag bits), one row of LDS counters per set
+bool igd_sweep_sets_supported(const IgdView &v, const IgdTiles &tl, u64 nq, u32 n_sets) {
+    return n_sets >= 1 && n_sets <= 4 && (u64)n_sets * v.n_files <= 16384 && igd_sweep_supported(v, nq) && igd_bucket_path(v, tl);
+}
+
 gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq64,
-                              i32 min_overlap, int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st) {
+                              i32 min_overlap, int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st, u32 n_sets,
+                              const u32 *set_bounds) {
     const u32 nq = (u32)nq64;
     const u32 n_tiles = tl.n_tiles;
+    if (n_sets > 1 && (!set_bounds || !igd_sweep_sets_supported(v, tl, nq64, n_sets)))
+        return fail(GTARS_ERR_INTERNAL, "IGD sweep: this batch of query sets needs the per-set path");
+    if (n_sets <= 1) set_bounds = nullptr;
+    const u32 n_bins = v.n_files * std::max<u32>(n_sets, 1);
     if (ws_bytes < igd_sweep_ws_bytes(nq, n_tiles, v.n_chrom)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
     u32 *kc = (u32 *)ws, *ks = kc + nq, *ke = ks + nq;
     u32 *sc = ke + nq, *ss = sc + nq, *se = ss + nq, *perm = se + nq;  // perm doubles as the owner-tile column
@@ -1117,27 +1183,31 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     void *scratch = (void *)(((uintptr_t)(d_unsorted + 16) + 63) & ~(uintptr_t)63);
     const size_t scratch_bytes = ws_bytes - (size_t)((char *)scratch - (char *)ws);
     (void)sc;
-    // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the routing kernel only ever raises the flag
-    const u32 flag0 = getenv("GTARS_IGD_ALWAYS_SORT") ? 1u : 0u;
-    // queries grouped by owner tile in one partition, when the tile bounds fit in LDS (76M records); otherwise
-    // (and for GTARS_IGD_FULL_SORT=1) the batch is fully sorted by (chromosome, start) with the radix sort
-    const bool full_sort = getenv("GTARS_IGD_FULL_SORT") != nullptr;  // tests / A-B runs
+    // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the routing kernel only ever raises the flag.  Several sets: always
+    // partitioned (a concatenation of sets is not in order, and the partition is what tags the pairs)
+    const u32 flag0 = getenv("GTARS_IGD_ALWAYS_SORT") || set_bounds ? 1u : 0u;
     const size_t prep_lds = ((size_t)n_tiles + v.n_chrom + 1) * 4;
-    const bool bucket = !full_sort && tl.bnd && n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024;
+    const bool bucket = igd_bucket_path(v, tl);
     // routing and histogram fused (no prepared columns at all): when the routing kernel's LDS image fits and a workgroup's
     // chunk fits its 16-bit counters
-    const u32 rt_wg = multisplit_workgroups(nq);
-    const u32 rt_chunk = multisplit_chunk(nq);  // a multiple of the 4 queries a lane takes per step
+    u32 rt_wg = multisplit_workgroups(nq);
+    u32 rt_chunk = multisplit_chunk(nq);  // a multiple of the 4 queries a lane takes per step
     const size_t rt_lds = igd_route_lds_bytes(n_tiles, v.n_chrom, tl.route_n);
-    const bool fused = bucket && tl.route_lut && rt_lds <= 160 * 1024 - 64 && rt_chunk <= 65535u && !getenv("GTARS_IGD_NO_FUSED_ROUTE");
     int dev = 0, cus = 256;
     GT_HIP(hipGetDevice(&dev));
     GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (bucket && multisplit_totals(scratch, n_tiles + 1, nq)) {
+        // two-level split: the routing kernel leaves bin TOTALS (atomics), not one table row per workgroup, so its grid is its own
+        // to choose -- every CU gets a chunk once there are 4096 queries per workgroup (a 1.1M-query batch ran on 67 CUs: 35 us)
+        rt_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
+        rt_chunk = ((nq + rt_wg - 1) / rt_wg + 3u) & ~3u;
+    }
+    const bool fused = bucket && tl.route_lut && rt_lds <= 160 * 1024 - 64 && rt_chunk <= 65535u && !getenv("GTARS_IGD_NO_FUSED_ROUTE");
     static std::mutex attr_mu;
     {
         u32 *d_tot0 = fused ? multisplit_totals(scratch, n_tiles + 1, nq) : nullptr;
-        const u32 n_tot0 = d_tot0 ? n_tiles + 1 : 0u, n_init = std::max<u32>(std::max<u32>(v.n_files, n_tot0), 1u);
-        hipLaunchKernelGGL(k_igd_call_init, dim3((n_init + 255) / 256), dim3(256), 0, st, (unsigned long long *)hits, v.n_files, d_unsorted,
+        const u32 n_tot0 = d_tot0 ? n_tiles + 1 : 0u, n_init = std::max<u32>(std::max<u32>(n_bins, n_tot0), 1u);
+        hipLaunchKernelGGL(k_igd_call_init, dim3((n_init + 255) / 256), dim3(256), 0, st, (unsigned long long *)hits, n_bins, d_unsorted,
                            flag0, d_tot0, n_tot0);
     }
     if (fused) {
@@ -1184,9 +1254,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         // kernels for one that is not, and the sweep takes its inputs accordingly.
         // K1 (multisplit): (start, end) pairs grouped by owner tile; bin_off[t], bin_off[t + 1] bound tile t's queries
         gtars_status s1 = fused ? multisplit_pairs(perm, true, qs, qe, true, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
-                                                   scratch, scratch_bytes, st, d_unsorted, true)
+                                                   scratch, scratch_bytes, st, d_unsorted, true, set_bounds)
                                 : multisplit_pairs(perm, false, ks, ke, false, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
-                                                   scratch, scratch_bytes, st, d_unsorted, false);  // ss and se are adjacent: 2 * nq words
+                                                   scratch, scratch_bytes, st, d_unsorted, false, set_bounds);  // ss, se adjacent: 2 * nq words
         if (s1) return s1;
         part_flag = d_unsorted;
         part_ab = ss;
@@ -1197,7 +1267,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         ss = const_cast<u32 *>(fused ? qs : ks);
         se = const_cast<u32 *>(fused ? qe : ke);
         ProfScope p("k_igd_tile_ranges", st);
-        if (fused) {
+        if (flag0) {
+            // the partition is certain (several sets, or forced): nothing to enqueue for the in-order continuation
+        } else if (fused) {
             hipLaunchKernelGGL(k_igd_chrom_segments<true>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, oc, qs, qe, (const u32 *)nullptr,
                                nq, v.n_chrom, cq_off, d_unsorted);
             hipLaunchKernelGGL(k_igd_tile_ranges<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles,
@@ -1232,18 +1304,27 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     }
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
     if (!tl.pm || !tl.files16 || !tl.tab) return fail(GTARS_ERR_INTERNAL, "IGD sweep: the per-tile tables were not built");
-    // starts | ends | prefix-max ends | [pme_file] | files (u16) | bins
-    const size_t lds = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14) + (((size_t)v.n_files + 1) & ~(size_t)1) * 4;
+    // starts | ends | prefix-max ends | [pme_file] | files (u16) | counters (u32, or 16-bit two per word: mode 2 when that admits
+    // another workgroup per CU)
+    const size_t lds_rec = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14);
+    size_t lds = lds_rec + (((size_t)n_bins + 1) & ~(size_t)1) * 4;
+    const size_t lds16 = lds_rec + ((size_t)n_bins + 3) / 4 * 8;
     const bool mo1 = min_overlap == 1;
     auto kern = mode == 2 ? k_igd_sweep<2, true> : mode == 1 ? k_igd_sweep<1, false> : mo1 ? k_igd_sweep<0, true> : k_igd_sweep<0, false>;
+    const size_t lds_cu = 160 * 1024;  // what a CU has; the static part (search tables) is ~2 KB per workgroup
+    const bool b16 = mode == 2 && !getenv("GTARS_IGD_NO_B16") && lds_cu / (lds16 + 2304) > lds_cu / (lds + 2304) && lds_cu / (lds + 2304) < 3;
+    if (b16) {
+        kern = k_igd_sweep<2, true, true>;
+        lds = lds16;
+    }
     {
         // the dynamic-LDS limit belongs to the function, not to the calling thread: raised once per device to the largest
         // size any launch can ask for (5 staged arrays + 16384 file bins) and never lowered
         static std::mutex mu;
-        static bool done[4][64] = {};
+        static bool done[5][64] = {};
         int dev = 0;
         GT_HIP(hipGetDevice(&dev));
-        const int slot = mode == 0 && !mo1 ? 3 : mode;
+        const int slot = b16 ? 4 : mode == 0 && !mo1 ? 3 : mode;
         std::lock_guard<std::mutex> lock(mu);
         if (dev >= 0 && dev < 64 && !done[slot][dev]) {
             GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1258,7 +1339,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     {
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.pm, tl.files16, tl.tab, n_tiles, ss, se,
-                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql);
+                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql, n_bins);
     }
     GT_HIP(hipGetLastError());
     // which continuation the device took (profiling mode: a deterministic fact for the tests, not a timing)

@@ -125,6 +125,19 @@ k_radix_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals, u32 
 // Large splits therefore go through k_split_pass below (tiles reordered by bin in LDS, stores leave as runs): 0.12 ms.
 constexpr int MS_TPB = 1024;
 
+// Several query SETS in one partitioned batch (set k = rows [bound[k - 1], bound[k]) of the input, at most 4): the set of a row
+// travels in the top bits of its (a, b) pair -- bit 31 of b = set & 1, bit 31 of a = set >> 1 -- which the values themselves
+// never use (IGD coordinates are non-negative i32: igd.rs:514-517 rejects or clamps everything else before this point).
+struct SetTags {
+    u32 b1, b2, b3;  // first row of set 1, 2, 3 (0xFFFFFFFF: no such set)
+    __device__ __forceinline__ void apply(u32 row, u32 &a, u32 &b) const {
+        if (b1 == 0xFFFFFFFFu) return;  // (uniform) one set: nothing to tag
+        const u32 set = (row >= b1 ? 1u : 0u) + (row >= b2 ? 1u : 0u) + (row >= b3 ? 1u : 0u);
+        a |= (set >> 1) << 31;
+        b |= (set & 1u) << 31;
+    }
+};
+
 template <class KeyT>
 __global__ void __launch_bounds__(MS_TPB)
 k_ms_hist(const KeyT *__restrict__ key, u32 n, u32 n_bins, u32 chunk, u32 *__restrict__ table, const u32 *__restrict__ run_if) {
@@ -222,7 +235,8 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off,
 template <class KeyT, bool CLAMP>
 __global__ void __launch_bounds__(MS_TPB)
 k_ms_scatter(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n, u32 n_bins, u32 chunk,
-             const u32 *__restrict__ table, const u32 *__restrict__ bin_off, u32 drop_bin, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if) {
+             const u32 *__restrict__ table, const u32 *__restrict__ bin_off, u32 drop_bin, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if,
+             SetTags tags) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 ms_bins[];
     const u32 *row = table + (size_t)blockIdx.x * n_bins;
@@ -242,6 +256,7 @@ k_ms_scatter(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             va[j] = ok ? a[i] : 0u;
             vb[j] = ok ? b[i] : 0u;
             if (CLAMP) va[j] = (i32)va[j] < 0 ? 0u : va[j];
+            tags.apply(i, va[j], vb[j]);
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) pos[j] = k[j] != drop_bin ? atomicAdd(&ms_bins[k[j]], 1u) : 0u;
@@ -278,7 +293,8 @@ static_assert(SP_BINS == SP_TPB, "one thread per tile-local bin (counter reset, 
 template <bool FINE, class KeyT, bool CLAMP>
 __global__ void __launch_bounds__(SP_TPB)
 k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
-             u32 shift, u32 drop_bin, u32 *__restrict__ cursor, KeyT *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if) {
+             u32 shift, u32 drop_bin, u32 *__restrict__ cursor, KeyT *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if,
+             SetTags tags) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 sp_lds[];
     u32 *s_k = sp_lds, *s_a = s_k + SP_TILE, *s_b = s_a + SP_TILE;
@@ -308,6 +324,7 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
                 va[j] = ok ? a[i] : 0u;
                 vb[j] = ok ? b[i] : 0u;
                 if (CLAMP) va[j] = (i32)va[j] < 0 ? 0u : va[j];
+                tags.apply(i, va[j], vb[j]);  // (the second pass carries the pairs as they are)
             }
             if (k[j] != 0xFFFFFFFFu) kmin = min(kmin, k[j]);
         }
@@ -393,7 +410,9 @@ u32 *multisplit_totals(void *ws, u32 n_bins, u32 n) { return multisplit_two_leve
 // that computes the keys.
 template <class KeyT, bool CLAMP>
 static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
-                                       u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready) {
+                                       u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
+                                       const u32 *set_bounds) {
+    const SetTags tags = set_bounds ? SetTags{set_bounds[0], set_bounds[1], set_bounds[2]} : SetTags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     if (n_bins == 0 || n_bins > MS_MAX_BINS) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
     if (ws_bytes < multisplit_ws_bytes(n_bins, n)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
     const u32 n_wg = multisplit_workgroups(n);
@@ -441,30 +460,32 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
         const unsigned grid = std::min<u32>(256, tiles);
         ProfScope p("k_split_pass", st);
         hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n,
-                           shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if);
+                           shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags);
         hipLaunchKernelGGL((k_split_pass<true, KeyT, false>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
-                           (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if);
+                           (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if,
+                           SetTags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
     } else {
         ProfScope p("k_ms_scatter", st);
         hipLaunchKernelGGL((k_ms_scatter<KeyT, CLAMP>), dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off,
-                           drop_bin, out_ab, run_if);
+                           drop_bin, out_ab, run_if, tags);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;
 }
 
 gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
-                              uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready) {
+                              uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
+                              const u32 *set_bounds) {
     if (key16 && n_bins > 65535u) return fail(GTARS_ERR_INTERNAL, "multisplit: 16-bit keys need <= 65535 bins");
     if (key16)
         return clamp_a ? multisplit_pairs_t<unsigned short, true>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
-                                                                  ws_bytes, st, run_if, table_ready)
+                                                                  ws_bytes, st, run_if, table_ready, set_bounds)
                        : multisplit_pairs_t<unsigned short, false>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
-                                                                   ws_bytes, st, run_if, table_ready);
+                                                                   ws_bytes, st, run_if, table_ready, set_bounds);
     return clamp_a ? multisplit_pairs_t<u32, true>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
-                                                   table_ready)
+                                                   table_ready, set_bounds)
                    : multisplit_pairs_t<u32, false>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
-                                                    table_ready);
+                                                    table_ready, set_bounds);
 }
 
 __global__ void k_iota(u32 *__restrict__ p, u32 n) {

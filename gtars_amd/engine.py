@@ -266,6 +266,26 @@ class IgdIndex:
                      binary: bool = False, stream: int = 0):
         check(lib.gtars_igd_count_device(self._h, d_qc, d_qs, d_qe, nq, int(min_overlap), int(binary), d_hits, stream))
 
+    def count_sets(self, sets, min_overlap: int = 1, binary: bool = False) -> np.ndarray:
+        """Several query sets [(chrom, start, end), ...] in one call -> u64[len(sets), n_files]; row k is what
+        count_set_overlaps / count_region_hits returns for set k alone (up to 4 sets share one pass over the database:
+        gtars_igd_count_sets, the count step of run_lola, gtars-lola/src/enrichment.rs:198-221)."""
+        cols = [[as_u32(x[j]) for x in sets] for j in range(3)]
+        off = np.zeros(len(sets) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(c) for c in cols[0]])
+        qc, qs, qe = (np.ascontiguousarray(np.concatenate(c)) if len(sets) else np.zeros(0, dtype=np.uint32) for c in cols)
+        hits = np.zeros((len(sets), self.n_files), dtype=np.uint64)
+        if len(sets):
+            check(lib.gtars_igd_count_sets(self._h, ptr(qc), ptr(qs), ptr(qe), ptr(off), len(sets), int(min_overlap), int(binary), ptr(hits)))
+        return hits
+
+    def count_sets_device(self, d_qc: int, d_qs: int, d_qe: int, set_off, d_hits: int, min_overlap: int = 1,
+                          binary: bool = False, stream: int = 0):
+        """Device form: the concatenated batch on the device, `set_off` a host sequence of len(sets) + 1 row offsets, d_hits
+        u64[len(sets) * n_files].  Asynchronous on `stream`."""
+        off = np.ascontiguousarray(set_off, dtype=np.uint64)
+        check(lib.gtars_igd_count_sets_device(self._h, d_qc, d_qs, d_qe, ptr(off), len(off) - 1, int(min_overlap), int(binary), d_hits, stream))
+
     def count_overlaps_per_query(self, qc, qs, qe, min_overlap: int = 1) -> np.ndarray:
         qc, qs, qe = as_u32(qc), as_u32(qs), as_u32(qe)
         out = np.zeros(len(qc), dtype=np.uint32)

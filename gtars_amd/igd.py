@@ -275,6 +275,18 @@ class Igd:
         self._require()
         return self._engine.count_region_hits(*self._encode(regions), min_overlap=min_overlap)[: self.num_files()]
 
+    def count_region_hits_sets(self, region_sets, min_overlap: int = 1) -> np.ndarray:
+        """Additive batch form: count_region_hits of every set of `region_sets` -> u64[len(region_sets), num_files].  Up to four
+        sets share one pass over the database (gtars_igd_count_sets); run_lola's count step (the universe and the user sets,
+        gtars-lola/src/enrichment.rs:198-221) goes through here."""
+        self._require()
+        return self._engine.count_sets([self._encode(r) for r in region_sets], min_overlap=min_overlap, binary=True)[:, : self.num_files()]
+
+    def count_set_overlaps_sets(self, region_sets, min_overlap: int = 1) -> np.ndarray:
+        """The pairwise counterpart: count_set_overlaps of every set -> u64[len(region_sets), num_files]."""
+        self._require()
+        return self._engine.count_sets([self._encode(r) for r in region_sets], min_overlap=min_overlap, binary=False)[:, : self.num_files()]
+
     def find_overlaps_regionset(self, query, min_overlap: int = 1) -> List[Tuple[int, int]]:
         self._require()
         q, s = self._engine.find_overlaps_regionset(*self._encode(query), min_overlap=min_overlap)

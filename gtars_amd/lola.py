@@ -330,14 +330,17 @@ def lola_counts(user_sets, universe, region_db: RegionDB, min_overlap: int = 1):
     uni = _as_regions(universe)
     if len(uni) == 0:
         raise RuntimeError("LOLA error: EmptyUniverse")
-    universe_hits = igd.count_region_hits(uni, min_overlap)
+    # the universe and the user sets in one call: up to four sets share one pass over the region DB (the reference walks it once
+    # per set, enrichment.rs:198-215)
+    user_regs = [_as_regions(us) for us in user_sets]
+    support = igd.count_region_hits_sets([uni] + user_regs, min_overlap)
+    universe_hits = support[0]
     dev = torch.device("cuda", torch.cuda.current_device())
     d_uni = torch.from_numpy(universe_hits.astype(np.int64)).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
     all_hits, cells = [], []
-    for us in user_sets:
-        regs = _as_regions(us)
-        hits = igd.count_region_hits(regs, min_overlap)
+    for k, regs in enumerate(user_regs):
+        hits = support[1 + k]
         d_user = torch.from_numpy(hits.astype(np.int64)).to(dev)
         out = [torch.empty(n_db, dtype=torch.int64, device=dev) for _ in range(4)]
         check(lib.gtars_lola_contingency_device(d_user.data_ptr(), d_uni.data_ptr(), n_db, len(regs), len(uni),

@@ -176,6 +176,34 @@ class HipEngine:
     def igd_count(self, g, qc, qs, qe, min_overlap: int, binary: bool):
         return self.igd_count_resident(g, self.upload(qc, qs, qe), min_overlap, binary)
 
+    def upload_sets(self, sets):
+        """several query sets [(chrom, start, end), ...] as ONE resident batch + their row offsets: what
+        igd_count_sets_resident takes (up to four sets then share one pass over the database)"""
+        off = np.zeros(len(sets) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x[0]) for x in sets])
+        cols = [np.concatenate([np.ascontiguousarray(x[j], dtype=np.uint32) for x in sets]) if sets else np.zeros(0, dtype=np.uint32)
+                for j in range(3)]
+        return [self._dev(c) for c in cols], off
+
+    def igd_count_sets_resident(self, g, handle, min_overlap: int, binary: bool, hits=None, sync: bool = True):
+        """-> int64[len(sets), n_files] on the device (gtars_igd_count_sets_device)"""
+        import torch
+
+        d, off = handle
+        if hits is None:
+            hits = torch.zeros(len(off) - 1, g.n_files, dtype=torch.int64, device=self.device)
+        if d[0].numel():
+            g.count_sets_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), off, hits.data_ptr(), min_overlap, binary,
+                                torch.cuda.current_stream().cuda_stream)
+        else:
+            hits.zero_()
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        return hits
+
+    def igd_count_sets(self, g, sets, min_overlap: int, binary: bool):
+        return self.igd_count_sets_resident(g, self.upload_sets(sets), min_overlap, binary)
+
     def index(self, chrom, start, end, n_chrom: int):
         from .engine import OverlapIndex
 
@@ -263,6 +291,29 @@ class ShardedIgd:
         lq = self.local_queries(q)
         return self.engine.upload(lq["chrom"], lq["start"], lq["end"])
 
+    def upload_local_sets(self, sets):
+        """this rank's shares of several query sets as one resident batch (for ``count_sets_resident``)"""
+        local = [self.local_queries(q) for q in sets]
+        return self.engine.upload_sets([(l["chrom"], l["start"], l["end"]) for l in local])
+
+    def count_sets_resident(self, handle, min_overlap: int = 1, binary: bool = False, hits=None):
+        """[len(sets), F] support / hit vectors of the uploaded sets -- one pass over the local database for up to four sets --
+        and ONE all-reduce of the whole block"""
+        hits = self.engine.igd_count_sets_resident(self.g, handle, min_overlap, binary, hits, sync=False)
+        if self.world > 1:
+            all_reduce_hits_(hits, self.group)
+        return hits
+
+    def count_sets_local(self, sets, min_overlap: int = 1, binary: bool = False):
+        """local [len(sets), F] block (no collective); engines without a batch form count set by set"""
+        import torch
+
+        local = [self.local_queries(q) for q in sets]
+        batch = getattr(self.engine, "igd_count_sets", None)
+        if batch is not None:
+            return batch(self.g, [(l["chrom"], l["start"], l["end"]) for l in local], min_overlap, binary)
+        return torch.stack([self.engine.igd_count(self.g, l["chrom"], l["start"], l["end"], min_overlap, binary) for l in local])
+
     def count_resident(self, handle, min_overlap: int = 1, binary: bool = False, hits=None):
         """count + all-reduce on queries uploaded with ``upload_local``; nothing but the F-long vector leaves the device"""
         hits = self.engine.igd_count_resident(self.g, handle, min_overlap, binary, hits, sync=False)
@@ -281,12 +332,12 @@ class ShardedIgd:
 def lola_counts_sharded(sdb: ShardedIgd, user_sets: Sequence[Dict[str, np.ndarray]], universe: Dict[str, np.ndarray],
                         min_overlap: int = 1):
     """Support vectors of LOLA (enrichment.rs:176-221) with the database sharded: ``a[u][f]`` = regions of user set u
-    that hit DB set f, ``pooled[f]`` the same for the universe.  All (1 + U) local vectors are reduced by ONE all-reduce
-    of (1 + U) * F int64 values.  Returns (support [U, F], pooled [F]) as int64 tensors on the engine's device."""
+    that hit DB set f, ``pooled[f]`` the same for the universe.  The universe and the user sets go through the local database
+    as one batch of sets (up to four per pass), and all (1 + U) local vectors are reduced by ONE all-reduce of (1 + U) * F
+    int64 values.  Returns (support [U, F], pooled [F]) as int64 tensors on the engine's device."""
     import torch
 
-    vecs = [sdb.count_local(universe, min_overlap, True)] + [sdb.count_local(us, min_overlap, True) for us in user_sets]
-    stacked = torch.stack(vecs)
+    stacked = sdb.count_sets_local([universe] + list(user_sets), min_overlap, True)
     if sdb.world > 1:
         all_reduce_hits_(stacked, sdb.group)
     return stacked[1:], stacked[0]

@@ -276,6 +276,18 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qchr
 gtars_status gtars_igd_count(const gtars_igd_t *g, const uint32_t *qchrom,
                              const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
                              int32_t min_overlap, int binary, uint64_t *hits);
+/* n_sets query sets against one database in one call: the concatenated batch, set k = rows
+ * [set_off[k], set_off[k + 1]) (set_off: HOST array of n_sets + 1 offsets, set_off[0] = 0); d_hits / hits: u64[n_sets][n_files],
+ * row k = what gtars_igd_count(_device) returns for set k alone.  This is the count step of run_lola
+ * (gtars-lola/src/enrichment.rs:198-221: universe_hits = igd.count_region_hits(universe), then user_hits per user set):
+ * the reference walks the database once per set, here up to 4 sets share ONE pass over it (the partition tags each query
+ * with its set, the sweep keeps a row of counters per set); what cannot share a pass is counted set by set. */
+gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d_qchrom, const uint32_t *d_qstart,
+                                         const uint32_t *d_qend, const uint64_t *set_off, uint32_t n_sets,
+                                         int32_t min_overlap, int binary, uint64_t *d_hits, void *stream);
+gtars_status gtars_igd_count_sets(const gtars_igd_t *g, const uint32_t *qchrom, const uint32_t *qstart,
+                                  const uint32_t *qend, const uint64_t *set_off, uint32_t n_sets,
+                                  int32_t min_overlap, int binary, uint64_t *hits);
 /* Igd::count_overlaps_per_query (distinct `value`s per query) */
 gtars_status gtars_igd_count_per_query(const gtars_igd_t *g, const uint32_t *qchrom,
                                        const uint32_t *qstart, const uint32_t *qend,

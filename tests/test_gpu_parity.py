@@ -3,6 +3,8 @@
 Integer / index work: every comparison is exact equality (token ids AND their
 order, CSR offsets, counts, per-file hit vectors).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1203,3 +1205,77 @@ def test_igd_two_level_partition_with_a_sparse_tail(ga, monkeypatch):
         monkeypatch.delenv("GTARS_IGD_SWEEP_MIN")
         assert int(shuffled.sum()) > n_hot  # the hot window is covered
         assert np.array_equal(shuffled, in_order) and np.array_equal(shuffled, per_query)
+
+
+def _random_query_set(rng, n, n_chrom, span, wmax, spoiled=0.02):
+    """n queries, a few of them unknown chromosomes, inverted, or negative as i32 (rejected or clamped by igd.rs:514-517)"""
+    qc = rng.integers(0, n_chrom, n).astype(np.uint32)
+    qs = rng.integers(0, span, n).astype(np.int64)
+    qe = qs + rng.integers(1, wmax, n)
+    bad = rng.random(n) < spoiled
+    kind = rng.integers(0, 3, n)
+    qc = np.where(bad & (kind == 0), UNK, qc).astype(np.uint32)
+    qe = np.where(bad & (kind == 1), qs - 5, qe)
+    qs = np.where(bad & (kind == 2), 2**32 - 1 - rng.integers(0, 1000, n), qs)  # negative as i32: clamped to 0
+    return qc, (qs % 2**32).astype(np.uint32), (qe % 2**32).astype(np.uint32)
+
+
+@pytest.mark.parametrize("n_db,sizes", [(150_000, (400_000, 60_000)), (2_300_000, (1_100_000, 90_000, 0, 7_000)),
+                                        (150_000, (300_000, 20_000, 20_000, 20_000, 250_000, 1_000)), (150_000, (3_000, 500))])
+def test_igd_query_sets_share_one_pass(ga, n_db, sizes):
+    """gtars_igd_count_sets: the count step of run_lola (enrichment.rs:198-221 -- count_region_hits of the universe and of every
+    user set over the same Igd).  Up to four sets share one sweep of the database (the partition tags the pairs, one row of
+    counters per set); every row must equal what the oracle returns for that set ALONE, pairwise and binary, min_overlap 1
+    (pme_file form) and 3 (credited-file-list form); how many passes were shared is read from the profiling facts, not from
+    a clock.  Cases: one- and two-level partitions, an empty set in the middle, more than four sets (two groups), sets
+    below the sweep's crossover (counted set by set)."""
+    rng = np.random.default_rng(n_db + len(sizes))
+    n_chrom, F, span = 3, 40, 30_000_000
+    c = rng.integers(0, n_chrom, n_db)
+    s = rng.integers(0, span, n_db)
+    e = s + rng.integers(1, 3_000, n_db)
+    f = rng.integers(0, F, n_db)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n_db), n_chrom=n_chrom, n_files=F)
+    sets = [_random_query_set(rng, n, n_chrom, span + 5_000, 800) for n in sizes]
+    _lib = ga._lib
+    for binary, mo in ((True, 1), (False, 1), (False, 3), (True, 3)):
+        ref = o.count_region_hits if binary else o.count_set_overlaps
+        want = np.stack([ref(qc, qs, qe, mo, n_files=F) for qc, qs, qe in sets])
+        g.count_sets(sets[:1], mo, binary)  # builds pme_file outside the profiled call
+        _lib.lib.gtars_prof_reset()
+        _lib.lib.gtars_prof_enable(1)
+        got = g.count_sets(sets, mo, binary)
+        prof = _lib.prof_read()
+        _lib.lib.gtars_prof_enable(0)
+        assert np.array_equal(got, want), (binary, mo, np.argwhere(got != want)[:5])
+        shared = prof.get("igd_sets_shared_pass", {"launches": 0})["launches"]
+        if sizes == (3_000, 500):
+            assert shared == 0  # below the crossover: the per-query kernel, set by set
+        elif len(sizes) == 6:
+            assert shared == 2  # sets 0-3 and sets 4-5
+        else:
+            assert shared == 1
+    # the same rows again set by set (what the shared pass replaces)
+    os.environ["GTARS_IGD_SWEEP_MIN"] = "1"
+    try:
+        for k, (qc, qs, qe) in enumerate(sets):
+            assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F)), k
+    finally:
+        del os.environ["GTARS_IGD_SWEEP_MIN"]
+
+
+def test_igd_query_sets_argument_checks(ga):
+    rng = np.random.default_rng(5)
+    g = ga.IgdIndex(np.zeros(10, dtype=np.uint32), np.arange(10) * 10, np.arange(10) * 10 + 5, np.zeros(10, dtype=np.uint32), n_chrom=1, n_files=1)
+    assert g.count_sets([], 1, True).shape == (0, 1)
+    assert g.count_sets([(np.zeros(0), np.zeros(0), np.zeros(0))] * 3, 1, True).tolist() == [[0], [0], [0]]
+    q = (np.zeros(4, dtype=np.uint32), np.array([0, 10, 20, 200], dtype=np.uint32), np.array([6, 11, 22, 300], dtype=np.uint32))
+    assert g.count_sets([q, q], 1, False).tolist() == [[3], [3]]
+    assert g.count_sets([q, q], 0, False).tolist() == [g.count_set_overlaps(*q, 0).tolist()] * 2  # min_overlap < 1: set by set
+    import ctypes as C
+    off = np.array([1, 4], dtype=np.uint64)
+    hits = np.zeros(1, dtype=np.uint64)
+    lib, ptr = ga._lib.lib, ga._lib.ptr
+    assert lib.gtars_igd_count_sets(g._h, ptr(q[0]), ptr(q[1]), ptr(q[2]), ptr(off), 1, 1, 0, ptr(hits)) != 0  # set_off[0] != 0
+    off = np.array([0, 4, 2], dtype=np.uint64)
+    assert lib.gtars_igd_count_sets(g._h, ptr(q[0]), ptr(q[1]), ptr(q[2]), ptr(off), 2, 1, 0, ptr(hits)) != 0  # decreasing

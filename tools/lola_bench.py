@@ -43,15 +43,20 @@ def main():
     sdb = sharding.ShardedIgd(eng, db, synth.N_CHROM, F, mode="bucket", balance_with=[uni["chrom"]])
     tb = time.time() - t
     del db
-    hu, hs = sdb.upload_local(uni), sdb.upload_local(user)
+    hboth = sdb.upload_local_sets([uni, user])
     stacked = torch.zeros(2, F, dtype=torch.int64, device=dev)
+    by_set = os.environ.get("SET_BY_SET") == "1"  # A/B: one count per set instead of the shared pass
+    hu, hs = (sdb.upload_local(uni), sdb.upload_local(user)) if by_set else (None, None)
 
     def run():
-        # two binary IGD counts into one 2 x F buffer, ONE all-reduce, then the contingency cells
-        eng.igd_count_resident(sdb.g, hu, 1, True, stacked[0], sync=False)
-        eng.igd_count_resident(sdb.g, hs, 1, True, stacked[1], sync=False)
-        if world > 1:
-            sharding.all_reduce_hits_(stacked)
+        # both support vectors into one 2 x F buffer (one pass over the local region DB), ONE all-reduce, then the cells
+        if by_set:
+            eng.igd_count_resident(sdb.g, hu, 1, True, stacked[0], sync=False)
+            eng.igd_count_resident(sdb.g, hs, 1, True, stacked[1], sync=False)
+            if world > 1:
+                sharding.all_reduce_hits_(stacked)
+        else:
+            sdb.count_sets_resident(hboth, 1, True, stacked)
         return sharding.contingency(stacked[1:], stacked[0], [nuser], len(uni["chrom"]))
 
     def barrier():
