@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(RT_TPB)
 k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
             const u32 *__restrict__ bnd, const u32 *__restrict__ chrom_tile_off, const u32 *__restrict__ route_base,
             const u32 *__restrict__ route_len, const u32 *__restrict__ route_lut, u32 n_lut, u32 route_shift, u32 n_tiles, u32 chunk,
-            unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, u32 *__restrict__ unsorted) {
+            unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, const u32 *__restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // the batch is in owner order (k_igd_order_check): nothing to route, the sweep takes it as it lies
     extern __shared__ u32 rt_lds[];
     u32 *s_bnd = rt_lds, *s_cto = s_bnd + n_tiles, *s_base = s_cto + n_chrom + 1, *s_len = s_base + n_chrom + 1;
     u32 *s_lutw = s_len + n_chrom;
@@ -205,15 +206,12 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
     __syncthreads();
     STAMP(0);
     const u32 lo_q = blockIdx.x * chunk, hi_q = min(nq, lo_q + chunk);
-    const int lane = threadIdx.x & 63;
-    bool bad = false;
     // A lane takes RT_U = 4 CONSECUTIVE queries per step.  VEC (16-byte aligned columns, chunk a multiple of 4): three 16-byte
-    // loads and one 8-byte key store per step instead of twelve loads and four stores, the order check runs inside the lane
-    // for three of the four and needs ONE neighbour value per step (the loop was instruction-bound: 17.8k cycles per step by
-    // the in-kernel stamps, ~500 VALU instructions per wave and step).  The raw columns of the NEXT step are loaded while the
-    // current one is searched (one workgroup per CU: nothing else covers the HBM latency); lane 0 also fetches the element
-    // in front of its wave's 256, so that the order check never waits for a dependent load.
-    u32 nc[RT_U], ns[RT_U], ne[RT_U], pc0 = 0, ps0 = 0, pe0 = 0;
+    // loads and one 8-byte key store per step instead of twelve loads and four stores (the loop was instruction-bound: 17.8k
+    // cycles per step by the in-kernel stamps, ~500 VALU instructions per wave and step).  The raw columns of the NEXT step
+    // are loaded while the current one is searched (one workgroup per CU: nothing else covers the HBM latency).  Whether the
+    // batch is in order is no longer this kernel's business (k_igd_order_check runs in front of it).
+    u32 nc[RT_U], ns[RT_U], ne[RT_U];
     auto fetch = [&](u32 base) {
         const u32 i0 = base + threadIdx.x * RT_U;
         if (VEC && i0 + RT_U <= hi_q) {
@@ -231,10 +229,6 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
                 ne[u] = in ? qe[i0 + u] : 0u;
             }
         }
-        const bool edge = lane == 0 && i0 > 0 && i0 < hi_q;
-        pc0 = edge ? qc[i0 - 1] : 0u;
-        ps0 = edge ? qs[i0 - 1] : 0u;
-        pe0 = edge ? qe[i0 - 1] : 0u;
     };
     fetch(lo_q);
     for (u32 base = lo_q; base < hi_q; base += RT_TPB * RT_U) {
@@ -249,25 +243,7 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
             s[u] = e[u] = 0;
             if (ok[u]) igd_prep_one(nc[u], ns[u], ne[u], n_chrom, c[u], s[u], e[u]);
         }
-        u32 ec;
-        i32 es, ee;
-        igd_prep_one(pc0, ps0, pe0, n_chrom, ec, es, ee);  // lane 0: the element before this wave's
         if (base + RT_TPB * RT_U < hi_q) fetch(base + RT_TPB * RT_U);
-        {
-            // already in (chromosome, start) order?  then the sweep can skip the partition (BED inputs usually are)
-            u32 pc = __shfl_up(c[RT_U - 1], 1, 64);
-            u32 ps = __shfl_up((u32)s[RT_U - 1], 1, 64);
-            if (lane == 0) {
-                pc = ec;
-                ps = (u32)es;
-            }
-#pragma unroll
-            for (int u = 0; u < RT_U; ++u) {
-                if (ok[u] && i0 + u > 0 && (pc > c[u] || (pc == c[u] && ps > (u32)s[u]))) bad = true;
-                pc = c[u];
-                ps = (u32)s[u];
-            }
-        }
 #pragma unroll
         for (int u = 0; u < RT_U; ++u) {
             // the owner: first tile of the chromosome whose bound is > start, bracketed by the static table
@@ -308,7 +284,6 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
                 if (ok[u]) key[i0 + u] = (unsigned short)tt[u];
         }
     }
-    if (__any(bad) && lane == 0) *unsorted = 1u;
     STAMP(1);
     __syncthreads();
     STAMP(2);
@@ -333,12 +308,90 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
 
 // start of a batch call: the result vector, the "arrived out of owner order" flag and (fused routing) the bin totals -- one
 // launch instead of four memsets
-__global__ void k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict__ flag, u32 flag_value,
-                                u32 *__restrict__ tot, u32 n_tot) {
+// Workgroup 0 also PROBES the batch's order (probe_n > 0: its first <= 4096 queries): a shuffled batch is recognised here, and the
+// full order check behind this kernel returns at once.
+constexpr u32 ORD_PROBE = 4096;
+__device__ __forceinline__ bool igd_out_of_order(u32 pc, i32 ps, u32 c, i32 s) { return pc > c || (pc == c && (u32)ps > (u32)s); }
+__global__ void __launch_bounds__(256)
+k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict__ flag, u32 flag_value, u32 *__restrict__ tot, u32 n_tot,
+                const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 probe_n, u32 n_chrom) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_files) hits[i] = 0ull;
     if (i < n_tot) tot[i] = 0u;
-    if (i == 0) *flag = flag_value;
+    if (blockIdx.x == 0) {
+        bool bad = false;
+        if (probe_n > 1) {
+            constexpr u32 PER = ORD_PROBE / 256;
+            const u32 a = threadIdx.x * PER, b = min(probe_n, a + PER + 1);  // pairs (k - 1, k) for k in (a, b)
+            if (a + 1 < b) {
+                u32 pc, c;
+                i32 ps, pe, s2, e2;
+                igd_prep_one(qc[a], qs[a], qe[a], n_chrom, pc, ps, pe);
+                for (u32 k = a + 1; k < b; ++k) {
+                    igd_prep_one(qc[k], qs[k], qe[k], n_chrom, c, s2, e2);
+                    bad = bad || igd_out_of_order(pc, ps, c, s2);
+                    pc = c;
+                    ps = s2;
+                }
+            }
+        }
+        const int any_bad = __syncthreads_or(bad ? 1 : 0);
+        if (threadIdx.x == 0) *flag = flag_value | (any_bad ? 1u : 0u);
+    }
+}
+
+// Is the batch in (chromosome, start) order after the validity rules and the start clamp (igd.rs:514-517; rejected queries count
+// as chromosome n_chrom, i.e. they must come last)?  Raises *flag otherwise.  A pass of its own over the raw columns (12 bytes
+// per query at streaming speed: ~25 us for 1e7 queries) instead of a side job of the routing kernel, so that a batch that IS in
+// order -- BED files usually are -- never pays for routing it (0.09 ms at config 3); returns at once when the probe in
+// k_igd_call_init has already seen disorder.
+constexpr int ORD_TPB = 256;
+template <bool VEC>
+__global__ void __launch_bounds__(ORD_TPB)
+k_igd_order_check(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
+                  u32 *__restrict__ flag) {
+    if (*flag) return;
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    for (u64 base = (u64)blockIdx.x * (ORD_TPB * 4); base < nq; base += (u64)gridDim.x * (ORD_TPB * 4)) {
+        const u64 i0 = base + (u64)threadIdx.x * 4;
+        u32 rc[4], rs[4], re[4];
+        if (VEC && i0 + 4 <= nq) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(qc + i0), b = *reinterpret_cast<const uint4 *>(qs + i0),
+                        d = *reinterpret_cast<const uint4 *>(qe + i0);
+            rc[0] = a.x, rc[1] = a.y, rc[2] = a.z, rc[3] = a.w;
+            rs[0] = b.x, rs[1] = b.y, rs[2] = b.z, rs[3] = b.w;
+            re[0] = d.x, re[1] = d.y, re[2] = d.z, re[3] = d.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = i0 + u < nq;
+                rc[u] = in ? qc[i0 + u] : GTARS_UNKNOWN_CHROM;  // past the end: "rejected", sorts last
+                rs[u] = in ? qs[i0 + u] : 0u;
+                re[u] = in ? qe[i0 + u] : 0u;
+            }
+        }
+        // the element in front of this lane's four: the previous lane's last one; lane 0 reads it
+        const bool edge = lane == 0 && i0 > 0 && i0 < nq;
+        const u32 ec = edge ? qc[i0 - 1] : 0u, es = edge ? qs[i0 - 1] : 0u, ee = edge ? qe[i0 - 1] : 0u;
+        u32 c[4];
+        i32 s[4], e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
+        u32 pc = __shfl_up(c[3], 1, 64);
+        i32 ps = __shfl_up(s[3], 1, 64);
+        if (lane == 0) {
+            i32 pe;
+            igd_prep_one(ec, es, ee, n_chrom, pc, ps, pe);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u > 0 && i0 + u < nq && igd_out_of_order(pc, ps, c[u], s[u])) bad = true;
+            pc = c[u];
+            ps = s[u];
+        }
+    }
+    if (__any(bad) && lane == 0) *flag = 1u;
 }
 
 __global__ void k_igd_tile_bounds(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
@@ -1207,8 +1260,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     {
         u32 *d_tot0 = fused ? multisplit_totals(scratch, n_tiles + 1, nq) : nullptr;
         const u32 n_tot0 = d_tot0 ? n_tiles + 1 : 0u, n_init = std::max<u32>(std::max<u32>(n_bins, n_tot0), 1u);
+        // (the probe only where the order check follows: the fused routing path)
         hipLaunchKernelGGL(k_igd_call_init, dim3((n_init + 255) / 256), dim3(256), 0, st, (unsigned long long *)hits, n_bins, d_unsorted,
-                           flag0, d_tot0, n_tot0);
+                           flag0, d_tot0, n_tot0, qc, qs, qe, fused && !flag0 ? std::min<u32>(nq, ORD_PROBE) : 0u, v.n_chrom);
     }
     if (fused) {
         if (scratch_bytes < multisplit_ws_bytes(n_tiles + 1, nq)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
@@ -1223,6 +1277,12 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         }
         u32 *d_tot = multisplit_totals(scratch, n_tiles + 1, nq);  // null: the one-level split wants the per-workgroup table
         const bool vec = ((((uintptr_t)qc) | ((uintptr_t)qs) | ((uintptr_t)qe)) & 15u) == 0 && (((uintptr_t)perm) & 7u) == 0;
+        if (!flag0) {
+            ProfScope p("k_igd_order_check", st);
+            const unsigned og = (unsigned)std::max<u64>(1, std::min<u64>((u64)cus * 8, ((u64)nq + ORD_TPB * 4 - 1) / (ORD_TPB * 4)));
+            hipLaunchKernelGGL(vec ? k_igd_order_check<true> : k_igd_order_check<false>, dim3(og), dim3(ORD_TPB), 0, st, qc, qs, qe, nq,
+                               v.n_chrom, d_unsorted);
+        }
         ProfScope p("k_igd_route", st);
         hipLaunchKernelGGL(vec ? k_igd_route<true> : k_igd_route<false>, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom,
                            tl.bnd, tl.chrom_tile_off, tl.route_base, tl.route_len, tl.route_lut, tl.route_n, tl.route_shift, n_tiles,

@@ -48,6 +48,19 @@ def one(seed):
     for mo in (1, int(rng.integers(2, 40)), int(rng.choice([0, -1, -30, -20_000]))):
         assert np.array_equal(g.count_set_overlaps(qc, qs, qe, mo), o.count_set_overlaps(qc, qs, qe, mo, n_files=F)), ("pair", seed, mo)
         assert np.array_equal(g.count_region_hits(qc, qs, qe, mo), o.count_region_hits(qc, qs, qe, mo, n_files=F)), ("bin", seed, mo)
+    # several query sets in one call (gtars_igd_count_sets): the batch cut into 2-6 sets at random rows, some of them empty
+    n_sets = int(rng.integers(2, 7))
+    cuts = np.sort(rng.integers(0, nq + 1, n_sets - 1))
+    if rng.random() < 0.3 and n_sets > 2:
+        cuts[1] = cuts[0]  # an empty set
+    bounds = [0] + cuts.tolist() + [nq]
+    sets = [(qc[a:b] % 2**32, qs[a:b] % 2**32, qe[a:b] % 2**32) for a, b in zip(bounds[:-1], bounds[1:])]
+    for binary in (True, False):
+        mo = int(rng.choice([1, 1, 7]))
+        got = g.count_sets(sets, mo, binary)
+        ref = o.count_region_hits if binary else o.count_set_overlaps
+        for k, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+            assert np.array_equal(got[k], ref(qc[a:b], qs[a:b], qe[a:b], mo, n_files=F)), ("sets", seed, binary, mo, k)
     if nq <= 5000 and n <= 3000:
         ok = (qs < 2**31) & (qe < 2**31)  # count_overlaps_per_query / find_overlaps_regionset take the query as it is
         mo = int(rng.choice([1, 5, 0, -30]))
@@ -89,6 +102,11 @@ def one_big(seed):
     os.environ.pop("GTARS_IGD_SWEEP_MIN", None)
     assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), o.count_set_overlaps(qc, qs, qe, 1, n_files=F)), ("big pair", seed, shape)
     assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F)), ("big bin", seed, shape)
+    # the same batch as three sets sharing one pass (the two-level partition tags the pairs)
+    b1, b2 = sorted(int(x) for x in rng.integers(0, nq + 1, 2))
+    got = g.count_sets([(qc[:b1], qs[:b1], qe[:b1]), (qc[b1:b2], qs[b1:b2], qe[b1:b2]), (qc[b2:], qs[b2:], qe[b2:])], 1, True)
+    for k, (a, b) in enumerate(((0, b1), (b1, b2), (b2, nq))):
+        assert np.array_equal(got[k], o.count_region_hits(qc[a:b], qs[a:b], qe[a:b], 1, n_files=F)), ("big sets", seed, shape, k)
     return nq
 
 

@@ -1216,7 +1216,9 @@ def _random_query_set(rng, n, n_chrom, span, wmax, spoiled=0.02):
     kind = rng.integers(0, 3, n)
     qc = np.where(bad & (kind == 0), UNK, qc).astype(np.uint32)
     qe = np.where(bad & (kind == 1), qs - 5, qe)
-    qs = np.where(bad & (kind == 2), 2**32 - 1 - rng.integers(0, 1000, n), qs)  # negative as i32: clamped to 0
+    neg = bad & (kind == 2)
+    qe = np.where(neg, rng.integers(1, wmax, n), qe)  # (short: the clamped query is [0, end))
+    qs = np.where(neg, 2**32 - 1 - rng.integers(0, 1000, n), qs)  # negative as i32: clamped to 0
     return qc, (qs % 2**32).astype(np.uint32), (qe % 2**32).astype(np.uint32)
 
 
@@ -1230,7 +1232,7 @@ def test_igd_query_sets_share_one_pass(ga, n_db, sizes):
     a clock.  Cases: one- and two-level partitions, an empty set in the middle, more than four sets (two groups), sets
     below the sweep's crossover (counted set by set)."""
     rng = np.random.default_rng(n_db + len(sizes))
-    n_chrom, F, span = 3, 40, 30_000_000
+    n_chrom, F, span = 3, 40, 30_000_000 if n_db < 1_000_000 else 240_000_000  # ~15-30 overlapping records per query
     c = rng.integers(0, n_chrom, n_db)
     s = rng.integers(0, span, n_db)
     e = s + rng.integers(1, 3_000, n_db)
