@@ -193,7 +193,7 @@ struct DevBuf {
     size_t n = 0;
     gtars_status upload(const std::vector<T> &h) {
         n = h.size();
-        GT_HIP(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
+        GT_HIP(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T) + 32));  // + slack: the IGD sweep stages whole 16-byte vectors
         if (n) GT_HIP(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
         return GTARS_OK;
     }
@@ -405,7 +405,7 @@ struct gtars_igd {
         gtars_status st = ws.alloc(wsb);
         if (st) return st;
         i32 *p = nullptr;
-        GT_HIP(hipMalloc((void **)&p, (size_t)n * 4));
+        GT_HIP(hipMalloc((void **)&p, (size_t)n * 4 + 32));
         st = igd_build_pme_file(view(), p, ws.p, wsb, nullptr);
         hipError_t e = hipDeviceSynchronize();
         if (st || e != hipSuccess) {
@@ -483,9 +483,9 @@ struct gtars_igd {
         if ((st = launch_igd_tile_bounds(view(), tile_first.p, tile_cnt.p, tile_chrom.p, n_tiles, tile_bnd.p, nullptr))) return st;
         if (n_tiles && n_files <= 65535) {
             // one pass over the database: prefix maxima, u16 file ids, search tables (what the sweep streams with the records)
-            GT_HIP(hipMalloc((void **)&tile_pm.p, (size_t)n * 4));
+            GT_HIP(hipMalloc((void **)&tile_pm.p, (size_t)n * 4 + 32));  // + slack: staged as whole 16-byte vectors
             tile_pm.n = n;
-            GT_HIP(hipMalloc((void **)&tile_files16.p, ((size_t)n + 1) / 2 * 4));
+            GT_HIP(hipMalloc((void **)&tile_files16.p, ((size_t)n + 1) / 2 * 4 + 32));
             tile_files16.n = n;
             GT_HIP(hipMalloc((void **)&tile_tab.p, (size_t)n_tiles * IGD_TILE_TAB_WORDS * 4));
             tile_tab.n = (size_t)n_tiles * IGD_TILE_TAB_WORDS;
@@ -1872,7 +1872,7 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
         const size_t ws_bytes = device_sort_perm_ws_bytes(n32);
         if ((st = ws.alloc(ws_bytes))) return bail(st);
         if ((st = device_sort_perm_ws(d_kc, d_s, nullptr, n32, n_chrom + 1, d_perm, ws.p, ws_bytes, nullptr))) return bail(st);
-        const size_t kb = std::max<u64>(kept, 1) * 4;
+        const size_t kb = std::max<u64>(kept, 1) * 4 + 32;  // + slack: the sweep stages whole 16-byte vectors
         if (hipMalloc((void **)&g->starts.p, kb) != hipSuccess || hipMalloc((void **)&g->ends.p, kb) != hipSuccess ||
             hipMalloc((void **)&g->files.p, kb) != hipSuccess || hipMalloc((void **)&g->values.p, kb) != hipSuccess)
             return bail(fail(GTARS_ERR_HIP, "IGD build: device allocation failed"));

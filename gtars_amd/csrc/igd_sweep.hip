@@ -648,14 +648,20 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
         qh = part_ql + 1;
     }
     constexpr int CAP = IGD_TILE + IGD_HALO;
-    i32 *t_s = reinterpret_cast<i32 *>(sm);
-    i32 *t_e = t_s + CAP;
-    i32 *t_pm = t_e + CAP;                             // prefix maximum of the ends (IgdTiles::pm)
-    i32 *t_pf = t_pm + CAP;                            // MODE 2: pme_file of the staged records
-    unsigned short *t_f = reinterpret_cast<unsigned short *>(t_pf + (MODE == 2 ? CAP : 0));  // file ids, u16; CAP is even
+    // The columns are staged as whole 16-byte vectors from the 16-byte boundary at or below the tile's first record (a dword-per-
+    // lane copy is 5 x 5 loads and as many LDS stores per thread and tile: a fifth of the kernel's instructions): LDS slot j of a
+    // column holds the record at (p0 & ~3) + j, so record i of the tile sits at slot i + (p0 & 3) -- the per-tile pointers t_*
+    // below point there.  The u16 file ids are 8 to a vector: slot i + (p0 & 7).
+    constexpr int CAPV = CAP + 4, CAPF = CAP + 8;
+    static_assert(CAPV % 4 == 0 && CAPF % 8 == 0, "every column starts on a 16-byte boundary");
+    i32 *b_s = reinterpret_cast<i32 *>(sm);
+    i32 *b_e = b_s + CAPV;
+    i32 *b_pm = b_e + CAPV;                            // prefix maximum of the ends (IgdTiles::pm)
+    i32 *b_pf = b_pm + CAPV;                           // MODE 2: pme_file of the staged records
+    unsigned short *b_f = reinterpret_cast<unsigned short *>(b_pf + (MODE == 2 ? CAPV : 0));  // file ids, u16
     // [n_bins]: n_files counters per query SET.  A partitioned batch may hold up to 4 sets (gtars_igd_count_sets_device): the set
     // of a query travels in bit 31 of its (start, end) pair (SetTags, sort.hip) and selects the row of counters its hits go to
-    u32 *bins = reinterpret_cast<u32 *>(t_f + CAP);
+    u32 *bins = reinterpret_cast<u32 *>(b_f + CAPF);
     auto untag = [&](i32 &s, i32 &e) -> u32 {  // -> the query's first counter
         const u32 set = (((u32)s >> 31) << 1) | ((u32)e >> 31);
         s &= 0x7FFFFFFF;
@@ -695,7 +701,6 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
     };
     u32 since = 0;  // queries served since the last flush (B16)
     for (u32 i = threadIdx.x; i < n_words; i += SW_TPB) bins[i] = 0;
-    constexpr int RPT = (CAP + SW_TPB - 1) / SW_TPB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #if IGD_STAMPS
     u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -725,20 +730,31 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
         // stage the tile: records + the search tables.  No register prefetch across the query phase: with 3 - 4 workgroups per
         // CU the other workgroups' query phases cover this one's loads (measured: prefetching one tile ahead bought nothing and
         // cost 15 registers).
+        const u32 d4 = p0 & 3u, d8 = p0 & 7u;
+        i32 *t_s = b_s + d4, *t_e = b_e + d4, *t_pm = b_pm + d4, *t_pf = b_pf + d4;
+        unsigned short *t_f = b_f + d8;
         {
-            i32 rs[RPT], re[RPT], rp[RPT], rq[MODE == 2 ? RPT : 1];
-            unsigned short rf[RPT];
+            constexpr int RV = (CAPV / 4 + SW_TPB - 1) / SW_TPB;  // 16-byte vectors per thread and 4-byte column
+            static_assert(CAPF / 8 <= SW_TPB, "one vector of file ids per thread");
+            const u32 nv4 = (n_lds + d4 + 3u) >> 2, nv8 = (n_lds + d8 + 7u) >> 3;
+            typedef u32 v4u __attribute__((ext_vector_type(4)));  // (a native vector: arrays of HIP's uint4 struct went to scratch)
+            const v4u *g_s = reinterpret_cast<const v4u *>(v.starts + (p0 - d4)), *g_e = reinterpret_cast<const v4u *>(v.ends + (p0 - d4)),
+                      *g_p = reinterpret_cast<const v4u *>(pm + (p0 - d4)), *g_f = reinterpret_cast<const v4u *>(files16 + (p0 - d8)),
+                      *g_q = MODE == 2 ? reinterpret_cast<const v4u *>(pme_file + (p0 - d4)) : nullptr;
+            v4u rs[RV], re[RV], rp[RV], rq[MODE == 2 ? RV : 1], rf = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const u32 i = threadIdx.x + (u32)k * SW_TPB;
-                if (i < n_lds) {
-                    rs[k] = v.starts[p0 + i];
-                    re[k] = v.ends[p0 + i];
-                    rp[k] = pm[p0 + i];
-                    rf[k] = files16[p0 + i];
-                    if (MODE == 2) rq[MODE == 2 ? k : 0] = pme_file[p0 + i];
+            for (int k = 0; k < RV; ++k) {
+                const u32 q = threadIdx.x + (u32)k * SW_TPB;
+                rs[k] = re[k] = rp[k] = v4u{0, 0, 0, 0};
+                if (MODE == 2) rq[MODE == 2 ? k : 0] = v4u{0, 0, 0, 0};
+                if (q < nv4) {
+                    rs[k] = g_s[q];
+                    re[k] = g_e[q];
+                    rp[k] = g_p[q];
+                    if (MODE == 2) rq[MODE == 2 ? k : 0] = g_q[q];
                 }
             }
+            if (threadIdx.x < nv8) rf = g_f[threadIdx.x];
             u32 lw[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -746,16 +762,16 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                 lw[k] = w < 2u * TAB_LUT_WORDS ? tab[TAB_DESC + w] : 0u;
             }
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const u32 i = threadIdx.x + (u32)k * SW_TPB;
-                if (i < n_lds) {
-                    t_s[i] = rs[k];
-                    t_e[i] = re[k];
-                    t_pm[i] = rp[k];
-                    t_f[i] = rf[k];
-                    if (MODE == 2) t_pf[i] = rq[MODE == 2 ? k : 0];
+            for (int k = 0; k < RV; ++k) {
+                const u32 q = threadIdx.x + (u32)k * SW_TPB;
+                if (q < nv4) {
+                    reinterpret_cast<v4u *>(b_s)[q] = rs[k];
+                    reinterpret_cast<v4u *>(b_e)[q] = re[k];
+                    reinterpret_cast<v4u *>(b_pm)[q] = rp[k];
+                    if (MODE == 2) reinterpret_cast<v4u *>(b_pf)[q] = rq[MODE == 2 ? k : 0];
                 }
             }
+            if (threadIdx.x < nv8) reinterpret_cast<v4u *>(b_f)[threadIdx.x] = rf;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const u32 w = threadIdx.x + (u32)k * SW_TPB;
@@ -1366,7 +1382,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     if (!tl.pm || !tl.files16 || !tl.tab) return fail(GTARS_ERR_INTERNAL, "IGD sweep: the per-tile tables were not built");
     // starts | ends | prefix-max ends | [pme_file] | files (u16) | counters (u32, or 16-bit two per word: mode 2 when that admits
     // another workgroup per CU)
-    const size_t lds_rec = (size_t)(IGD_TILE + IGD_HALO) * (mode == 2 ? 18 : 14);
+    const size_t lds_rec = (size_t)(IGD_TILE + IGD_HALO + 4) * (mode == 2 ? 16 : 12) + (size_t)(IGD_TILE + IGD_HALO + 8) * 2;
     size_t lds = lds_rec + (((size_t)n_bins + 1) & ~(size_t)1) * 4;
     const size_t lds16 = lds_rec + ((size_t)n_bins + 3) / 4 * 8;
     const bool mo1 = min_overlap == 1;
