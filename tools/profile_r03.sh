@@ -27,7 +27,7 @@ for which, scale in (("igd_fetch", 2048.0), ("igd_write", 1024.0)):
         agg[n][1] += 1
     out[which] = {k: {"bytes": v[0], "dispatches": v[1]} for k, v in agg.items()}
 CALLS = 6  # bench.py IGD_PMC_CALLS
-path = ("k_igd_call_init", "k_igd_prep", "k_igd_route", "k_ms_", "k_split_", "k_igd_chrom_segments", "k_igd_tile_ranges", "k_igd_sweep")
+path = ("k_igd_call_init", "k_igd_order_check", "k_igd_prep", "k_igd_route", "k_ms_", "k_split_", "k_igd_chrom_segments", "k_igd_tile_ranges", "k_igd_sweep")
 per = {}
 for k in set(out["igd_fetch"]) | set(out["igd_write"]):
     if k.startswith(path):
