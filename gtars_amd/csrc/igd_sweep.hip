@@ -308,9 +308,10 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
 
 // start of a batch call: the result vector, the "arrived out of owner order" flag and (fused routing) the bin totals -- one
 // launch instead of four memsets
-// Workgroup 0 also PROBES the batch's order (probe_n > 0: its first <= 4096 queries): a shuffled batch is recognised here, and the
-// full order check behind this kernel returns at once.
-constexpr u32 ORD_PROBE = 4096;
+// Workgroup 0 also PROBES the batch's order (probe_n > 0: its first <= 1024 queries, every thread's loads issued together -- a
+// 16-element loop per thread was a chain of 16 memory round trips, 8 us on every call): a shuffled batch is recognised here, and
+// the full order check behind this kernel returns at once.
+constexpr u32 ORD_PROBE = 1024;
 __device__ __forceinline__ bool igd_out_of_order(u32 pc, i32 ps, u32 c, i32 s) { return pc > c || (pc == c && (u32)ps > (u32)s); }
 __global__ void __launch_bounds__(256)
 k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict__ flag, u32 flag_value, u32 *__restrict__ tot, u32 n_tot,
@@ -322,17 +323,24 @@ k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restr
         bool bad = false;
         if (probe_n > 1) {
             constexpr u32 PER = ORD_PROBE / 256;
-            const u32 a = threadIdx.x * PER, b = min(probe_n, a + PER + 1);  // pairs (k - 1, k) for k in (a, b)
-            if (a + 1 < b) {
-                u32 pc, c;
-                i32 ps, pe, s2, e2;
-                igd_prep_one(qc[a], qs[a], qe[a], n_chrom, pc, ps, pe);
-                for (u32 k = a + 1; k < b; ++k) {
-                    igd_prep_one(qc[k], qs[k], qe[k], n_chrom, c, s2, e2);
-                    bad = bad || igd_out_of_order(pc, ps, c, s2);
-                    pc = c;
-                    ps = s2;
-                }
+            const u32 a = threadIdx.x * PER;  // pairs (k - 1, k) for k in (a, a + PER], k < probe_n
+            u32 rc[PER + 1], rs[PER + 1], re[PER + 1];
+#pragma unroll
+            for (u32 k = 0; k <= PER; ++k) {
+                const bool in = a + k < probe_n;
+                rc[k] = in ? qc[a + k] : 0u;
+                rs[k] = in ? qs[a + k] : 0u;
+                re[k] = in ? qe[a + k] : 0u;
+            }
+            u32 pc = 0, c;
+            i32 ps = 0, pe, s2, e2;
+#pragma unroll
+            for (u32 k = 0; k <= PER; ++k) {
+                igd_prep_one(rc[k], rs[k], re[k], n_chrom, c, s2, e2);
+                if (k > 0 && a + k < probe_n) bad = bad || igd_out_of_order(pc, ps, c, s2);
+                pc = c;
+                ps = s2;
+                (void)pe;
             }
         }
         const int any_bad = __syncthreads_or(bad ? 1 : 0);
