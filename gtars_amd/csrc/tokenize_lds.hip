@@ -224,6 +224,11 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
                                (kk.w <= s[j] ? 1u : 0u);
                     }
                     b += cnt;
+                } else if (shift == 1) {
+                    // two blocks per unit: the unit's last key is > q_start already (that is how the unit was found), so the
+                    // first block's key decides -- ONE dependent load (the halving loop below took two, the first of them
+                    // for the key whose answer is known)
+                    b += a.blk_first[b] <= s[j] ? 1u : 0u;
                 } else {
                     u32 l2 = b, n2 = min(1u << shift, be[j] - b);
                     while (n2 > 0) {
