@@ -339,6 +339,9 @@ struct gtars_index {
 struct gtars_igd {
     u32 n_chrom = 0, n_files = 0;
     u64 n = 0;
+    // Databases with records longer than IGD_PIECE_BP keep a second index of PIECES for the min_overlap == 1 counts (see
+    // build_pieces_view below); null otherwise.  Owned.
+    gtars_igd *pieces = nullptr;
     // host copy of the stored starts / ends: filled at build by the host-sort path, on first use
     // (total_records / export) after a device build
     mutable std::vector<i32> h_starts, h_ends;
@@ -543,8 +546,10 @@ struct gtars_igd {
         v.n_chrom = n_chrom;
         v.n = (u32)n;
         v.n_files = n_files;
+        v.pieces = piece_flags ? 1u : 0u;
         return v;
     }
+    bool piece_flags = false;  // this IS a pieces view: bit 31 of a file id marks a continuation piece
 };
 
 extern "C" {
@@ -1819,9 +1824,12 @@ gtars_status gtars_subset_source_indices(const gtars_index_t *ix, const uint32_t
 
 // ---------------------------------------------------------------------- IGD
 
-static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *start, const int32_t *end,
+// PIECE_FLAG in a record's file id (pieces view only, see build_pieces_view): the record is a continuation piece
+constexpr u32 IGD_PIECE_FLAG = 0x80000000u;
+static gtars_status gtars_igd_build_core(const uint32_t *chrom, const int32_t *start, const int32_t *end,
                              const int32_t *value, const uint32_t *file_idx, uint64_t n, uint32_t n_chrom,
-                             uint32_t n_files, gtars_igd_t **out) {
+                             uint32_t n_files, bool piece_flags, gtars_igd_t **out) {
+    const u32 fmask = piece_flags ? ~IGD_PIECE_FLAG : 0xFFFFFFFFu;
     if (!out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (n && (!chrom || !start || !end || !file_idx)) return fail(GTARS_ERR_INVALID_ARG, "NULL record arrays");
@@ -1842,7 +1850,7 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
                 continue;
             }
             if (chrom[i] >= n_chrom) return fail(GTARS_ERR_INVALID_ARG, "record chromosome id >= n_chrom");
-            if (file_idx[i] >= n_files) return fail(GTARS_ERR_INVALID_ARG, "record file_idx >= n_files");
+            if ((file_idx[i] & fmask) >= n_files) return fail(GTARS_ERR_INVALID_ARG, "record file_idx >= n_files");
             kc[i] = chrom[i];
             hoff[chrom[i] + 1]++;
             hml[chrom[i]] = std::max(hml[chrom[i]], end[i] - start[i]);
@@ -1850,6 +1858,7 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
         }
         for (u32 c = 0; c < n_chrom; ++c) hoff[c + 1] += hoff[c];
         auto *g = new gtars_igd();
+        g->piece_flags = piece_flags;
         g->n_chrom = n_chrom;
         g->n_files = n_files;
         g->n = kept;
@@ -1925,7 +1934,7 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
     for (u64 i = 0; i < n; ++i) {
         if (start[i] < 0 || end[i] < 0 || start[i] >= end[i]) continue;
         if (chrom[i] >= n_chrom) return fail(GTARS_ERR_INVALID_ARG, "record chromosome id >= n_chrom");
-        if (file_idx[i] >= n_files) return fail(GTARS_ERR_INVALID_ARG, "record file_idx >= n_files");
+        if ((file_idx[i] & fmask) >= n_files) return fail(GTARS_ERR_INVALID_ARG, "record file_idx >= n_files");
         keep.push_back((u32)i);
     }
     // chromosome-major, then start, ties in insertion order (finalize: stable sort by start, igd.rs:157-167)
@@ -1934,6 +1943,7 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
         return start[a] < start[b];
     });
     auto *g = new gtars_igd();
+    g->piece_flags = piece_flags;
     g->n_chrom = n_chrom;
     g->n_files = n_files;
     g->n = keep.size();
@@ -1988,8 +1998,97 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
     return GTARS_OK;
 }
 
+// ---- the pieces view ----------------------------------------------------------------------------------------------------------
+// The flat layout (one record per stored interval, sorted by start) finds a query's candidates through the prefix maximum of the
+// ends and routes it by the chromosome's LONGEST record: one multi-kilobase record inflates both for everything behind it, and a
+// database with 1 % of 5-100 kbp records (broad peaks) took 15.6 ms for config 3's batch instead of 0.5 (0.1 % of records up to
+// 1 Mbp: 182 ms).  The reference bounds the damage by replicating a record into every 16384-bp tile it spans (igd.rs:109-153) and
+// counting it in the first tile of the query only (:812-817).  Same idea, for the long records only: a record longer than
+// IGD_PIECE_BP is cut at the multiples of IGD_PIECE_BP into PIECES that are stored as records of their own (continuation pieces
+// flagged in bit 31 of the file id, bit 15 of the u16 copy), and a piece counts for a query iff it overlaps it AND (it is its
+// record's first piece OR it starts at or before the query's start) -- i.e. the piece that holds max(q.start, record.start): every
+// overlapping record exactly once.  No record of the view is longer than IGD_PIECE_BP, so prefix maxima and ownership stay local.
+// "No earlier piece of the same file ends after q.start" still identifies the file's first counted piece (the earliest piece that
+// ends after q.start is a counted one: the pieces of a record before its counted piece end at or before q.start), so the binary
+// count keeps its pme_file form.  Used for min_overlap == 1 (the LOLA / igd-search default); other values keep the flat layout.
+constexpr i32 IGD_PIECE_BP = 16384;
+static i32 igd_piece_bp() {
+    if (getenv("GTARS_IGD_NO_PIECES")) return 0;
+    if (const char *e = getenv("GTARS_IGD_PIECE_BP")) {  // tests: small pieces on small databases
+        const long v = atol(e);
+        if (v >= 16 && v <= (1 << 30)) return (i32)v;
+    }
+    return IGD_PIECE_BP;
+}
+
+static gtars_status build_pieces_view(gtars_igd *g, const uint32_t *chrom, const int32_t *start, const int32_t *end,
+                                      const uint32_t *file_idx, uint64_t n) {
+    const i32 P = igd_piece_bp();
+    if (!P || !g || !g->n) return GTARS_OK;
+    u64 n_long = 0, n_pieces = 0;
+    for (u64 i = 0; i < n; ++i) {
+        if (start[i] < 0 || end[i] < 0 || start[i] >= end[i]) continue;  // Igd::add drop rule
+        ++n_pieces;
+        if (end[i] - start[i] > P) {
+            ++n_long;
+            n_pieces += (u64)((end[i] - 1) / P - start[i] / P);
+        }
+    }
+    if (!n_long) return GTARS_OK;
+    if (n_pieces >= 0xFFFFFFF0ull) return GTARS_OK;  // (would not fit the 32-bit record index: the flat layout serves)
+    std::vector<u32> pc(n_pieces), pf(n_pieces);
+    std::vector<i32> ps(n_pieces), pe(n_pieces);
+    u64 k = 0;
+    for (u64 i = 0; i < n; ++i) {
+        const i32 s0 = start[i], e0 = end[i];
+        if (s0 < 0 || e0 < 0 || s0 >= e0) continue;
+        if (e0 - s0 <= P) {
+            pc[k] = chrom[i], ps[k] = s0, pe[k] = e0, pf[k] = file_idx[i];
+            ++k;
+            continue;
+        }
+        i32 a = s0;
+        bool first = true;
+        while (a < e0) {
+            const i64 nb = ((i64)a / P + 1) * (i64)P;  // next multiple of P above a
+            const i32 b = (i32)std::min<i64>(nb, e0);
+            pc[k] = chrom[i], ps[k] = a, pe[k] = b, pf[k] = file_idx[i] | (first ? 0u : IGD_PIECE_FLAG);
+            ++k;
+            first = false;
+            a = b;
+        }
+    }
+    gtars_igd *pv = nullptr;
+    gtars_status st = gtars_igd_build_core(pc.data(), ps.data(), pe.data(), nullptr, pf.data(), k, g->n_chrom, g->n_files, true, &pv);
+    if (st) return st;
+    g->pieces = pv;
+    return GTARS_OK;
+}
+
+static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *start, const int32_t *end,
+                                         const int32_t *value, const uint32_t *file_idx, uint64_t n, uint32_t n_chrom,
+                                         uint32_t n_files, gtars_igd_t **out) {
+    gtars_status st = gtars_igd_build_core(chrom, start, end, value, file_idx, n, n_chrom, n_files, false, out);
+    if (st) return st;
+    st = build_pieces_view(*out, chrom, start, end, file_idx, n);
+    if (st) {
+        gtars_igd_free(*out);
+        *out = nullptr;
+    }
+    return st;
+}
+
+// which index serves a count: the pieces view for min_overlap == 1 when the database has one (binary counts: only in their
+// pme_file form)
+static const gtars_igd *igd_count_target(const gtars_igd *g, int32_t min_overlap, int binary) {
+    if (!g->pieces || min_overlap != 1) return g;
+    if (binary && getenv("GTARS_IGD_NO_PME")) return g;
+    return g->pieces;
+}
+
 void gtars_igd_free(gtars_igd_t *g) {
     if (!g) return;
+    gtars_igd_free(g->pieces);
     g->starts.release();
     g->ends.release();
     g->values.release();
@@ -2059,6 +2158,11 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
         if ((st = g->ensure_ntiles())) return st;
         return launch_igd_count(g->view(), nullptr, d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
     }
+    {
+        const gtars_igd *t = igd_count_target(g, min_overlap, binary);  // (the pieces view of a database with long records)
+        if (t != g && g_prof_on) g_prof_entries[prof_entry("igd_pieces_view")].launches += 1;  // (a fact for the tests)
+        g = t;
+    }
     if (igd_sweep_supported(g->view(), nq)) {
         // large batch: group the queries by owner tile once, stream the database once (igd_sweep.hip)
         const bool no_pme = getenv("GTARS_IGD_NO_PME") != nullptr;  // tests / A-B runs: the credited-file list instead
@@ -2071,7 +2175,8 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
     }
     // small batch: one thread per query (kernels.hip); binary counts with min_overlap == 1 through pme_file as well
     if (binary && min_overlap == 1 && !getenv("GTARS_IGD_NO_PME") && (st = g->ensure_pme())) return st;
-    return launch_igd_count(g->view(), g->tiles().pme_file, d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream);
+    return launch_igd_count(g->view(), g->tiles().pme_file, d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream,
+                            g->tiles().pm);
 }
 
 // Several query sets against one database (LOLA: the universe and the user sets, enrichment.rs:198-221 -- the reference calls
@@ -2091,6 +2196,7 @@ gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d
     if (st) return st;
     if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
     const size_t F = g->n_files;
+    const gtars_igd *gs = igd_count_target(g, min_overlap, binary);  // what a shared pass sweeps
     static const bool no_shared = getenv("GTARS_IGD_NO_SHARED_PASS") != nullptr;  // tests / A-B runs
     for (u32 k0 = 0; k0 < n_sets;) {
         // the longest run of <= 4 consecutive sets that can share a pass
@@ -2098,7 +2204,7 @@ gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d
         if (min_overlap >= 1 && !no_shared) {
             u32 best = k0 + 1;
             for (u32 k = k0 + 2; k <= std::min<u32>(n_sets, k0 + 4); ++k)
-                if (igd_sweep_sets_supported(g->view(), g->tiles(), set_off[k] - set_off[k0], k - k0)) best = k;
+                if (igd_sweep_sets_supported(gs->view(), gs->tiles(), set_off[k] - set_off[k0], k - k0)) best = k;
             k1 = best;
         }
         const u64 lo = set_off[k0], n = set_off[k1] - lo;
@@ -2107,13 +2213,13 @@ gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d
             if (st) return st;
         } else {
             const bool no_pme = getenv("GTARS_IGD_NO_PME") != nullptr;
-            if (binary && min_overlap == 1 && !no_pme && (st = g->ensure_pme())) return st;
+            if (binary && min_overlap == 1 && !no_pme && (st = gs->ensure_pme())) return st;
             Workspace &ws = tls_workspace(2, (hipStream_t)stream);
-            st = ws.reserve(igd_sweep_ws_bytes(n, g->n_tiles, g->n_chrom));
+            st = ws.reserve(igd_sweep_ws_bytes(n, gs->n_tiles, gs->n_chrom));
             if (st) return st;
             u32 bounds[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             for (u32 k = k0 + 1; k < k1; ++k) bounds[k - k0 - 1] = (u32)(set_off[k] - lo);
-            st = launch_igd_sweep(g->view(), g->tiles(), d_qc + lo, d_qs + lo, d_qe + lo, n, min_overlap, binary, d_hits + (size_t)k0 * F,
+            st = launch_igd_sweep(gs->view(), gs->tiles(), d_qc + lo, d_qs + lo, d_qe + lo, n, min_overlap, binary, d_hits + (size_t)k0 * F,
                                   ws.ptr, ws.bytes, (hipStream_t)stream, k1 - k0, bounds);
             if (st) return st;
             if (g_prof_on) g_prof_entries[prof_entry("igd_sets_shared_pass")].launches += 1;  // (a fact for the tests, not a time)

@@ -129,7 +129,11 @@ struct IgdView {
     u32 n_chrom;
     u32 n;
     u32 n_files;
+    // 1: a PIECES view (api.hip, build_pieces_view): records longer than 16384 bp were cut into pieces, bit 31 of files[] (bit 15
+    // of the u16 copy) marks a continuation piece, which counts for a query only if it starts at or before the query's start
+    u32 pieces;
 };
+constexpr u32 IGD_FILE_MASK = 0x7FFFFFFFu;
 
 // ---- per-thread grow-only device workspace ----------------------------------
 // host-side bookkeeping of a chained-scan workspace that is reused across launches without
@@ -208,8 +212,9 @@ size_t scan_ws_bytes(u64 n);
 
 // pme_file (may be null): IgdTiles::pme_file, used for binary counts with min_overlap == 1
 // (min_overlap < 1 needs v.chrom_ntiles)
+// pm (IgdTiles::pm, may be null): the scan of a query starts at the first record whose prefix-max end is > q_start
 gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
-                              i32 min_overlap, int binary, u64 *hits, hipStream_t st);
+                              i32 min_overlap, int binary, u64 *hits, hipStream_t st, const i32 *pm = nullptr);
 gtars_status launch_occupy(u32 workgroups, u32 lds_bytes, u32 microseconds, hipStream_t st);
 gtars_status launch_hist_u32(const u32 *ids, u64 n, u32 n_bins, u32 *bins, hipStream_t st);
 gtars_status launch_has_adjacent_equal(const u32 *a, u64 n, u32 *dup, hipStream_t st);

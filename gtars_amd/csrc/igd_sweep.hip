@@ -534,7 +534,10 @@ k_igd_tile_tables(IgdView v, const u32 *__restrict__ tile_first, const u32 *__re
     for (u32 i = threadIdx.x; i < n; i += SW_TPB) {
         t_s[i] = v.starts[p0 + i];
         t_e[i] = v.ends[p0 + i];
-        if (i < cnt && files16) files16[p0 + i] = (unsigned short)v.files[p0 + i];
+        if (i < cnt && files16) {
+            const u32 f = v.files[p0 + i];  // (pieces view: the continuation flag moves from bit 31 to bit 15; ids are < 16384 there)
+            files16[p0 + i] = (unsigned short)((f & 0x7FFFu) | ((f >> 31) << 15));
+        }
     }
     __syncthreads();
     // t_pm[i] = max(carry, ends[0..i]); blocked layout: thread k owns records [k * RPT, (k + 1) * RPT)
@@ -639,7 +642,10 @@ __device__ __forceinline__ u32 sweep_query_slot(int lane, int wave) {
 // MO1: min_overlap == 1 (a candidate record is a hit iff its end is > q_start; its start is not read).
 // Register budget = what the LDS footprint admits: 4 workgroups per CU (8 waves per SIMD, 64 VGPRs) for the pairwise form,
 // 3 (80 VGPRs) with the staged pme_file column; the credited-file-list form keeps its 16 list registers.
-template <int MODE, bool MO1, bool B16 = false>
+// PIECES: the database is a pieces view (IgdView::pieces): bit 15 of a staged file id marks a continuation piece, which is a
+// hit only if it also starts at or before the query's start (then it is the piece that holds the query's start; first pieces
+// count whenever they overlap) -- min_overlap == 1 forms only.
+template <int MODE, bool MO1, bool B16 = false, bool PIECES = false>
 __global__ void __launch_bounds__(SW_TPB, MODE == 0 ? 8 : MODE == 2 ? 6 : 4)
 k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__ pm, const unsigned short *__restrict__ files16,
             const u32 *__restrict__ tile_tab, u32 n_tiles, const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
@@ -687,6 +693,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
     // 2000 files, config 4: 3 instead of 2) -- the packed increment costs three more instructions per hit (config 3's dense
     // binary batch: 0.32 -> 0.355 ms with it, for no gain in residency).
     static_assert(!B16 || MODE == 2, "16-bit counters need the one-credit-per-query bound of the pme_file form");
+    static_assert(!PIECES || (MO1 && MODE != 1), "a pieces view serves the min_overlap == 1 forms only");
     const u32 n_words = B16 ? (n_bins + 1) / 2 : n_bins;
     auto bump = [&](u32 b) {
         if (B16)
@@ -864,7 +871,9 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                             const i32 ov = (re < e ? re : e) - (rs > s ? rs : s);
                             if (ov < min_overlap) continue;
                             if (MODE == 2 && pme_file[p0 + r] > s) continue;
-                            bump(boff + v.files[p0 + r]);
+                            const u32 fr = v.files[p0 + r];
+                            if (PIECES && (fr >> 31) && rs > s) continue;  // a continuation piece that does not hold the query's start
+                            bump(boff + (fr & IGD_FILE_MASK));
                         }
                     }
                 }
@@ -899,7 +908,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                             const u32 r = on[u] ? lo_[u] + k : 0u;
                             re[u] = t_e[r];
                             f[u] = t_f[r];
-                            rs[u] = MO1 ? 0 : t_s[r];
+                            rs[u] = (MO1 && !PIECES) ? 0 : t_s[r];
                             pf[u] = MODE == 2 ? t_pf[r] : 0;
                         }
 #pragma unroll
@@ -910,6 +919,10 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                             else
                                 hit = (re[u] < qe_[u] ? re[u] : qe_[u]) - (rs[u] > qs_[u] ? rs[u] : qs_[u]) >= min_overlap;
                             if (MODE == 2) hit = hit && pf[u] <= qs_[u];  // no earlier record of this file reaches the query
+                            if (PIECES) {
+                                hit = hit && (!(f[u] >> 15) || rs[u] <= qs_[u]);
+                                f[u] &= 0x7FFFu;
+                            }
                             if (hit && on[u]) {
                                 if (GTARS_IGD_ABLATE & 2) {
                                     if (re[u] == 0x7FFFFFF0) bins[0] = 1;
@@ -1150,6 +1163,11 @@ k_pme_scan_aggs(SegAgg *__restrict__ agg, u32 n_waves) {
     }
 }
 
+__global__ void k_file_keys(const u32 *__restrict__ files, u32 *__restrict__ key, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = files[i] & IGD_FILE_MASK;
+}
+
 __global__ void k_iota_u32(u32 *__restrict__ p, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
@@ -1169,7 +1187,7 @@ gtars_status igd_build_pme_file(const IgdView &v, i32 *pme, void *ws, size_t ws_
     SegAgg *agg = (SegAgg *)(v1 + n);
     void *sort_ws = (void *)(((uintptr_t)(agg + n_waves) + 63) & ~(uintptr_t)63);
     const size_t sort_bytes = ws_bytes - (size_t)((char *)sort_ws - (char *)ws);
-    GT_HIP(hipMemcpyAsync(k0, v.files, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_file_keys, dim3((n + 255) / 256), dim3(256), 0, st, v.files, k0, n);  // (without a pieces view's flag bit)
     hipLaunchKernelGGL(k_iota_u32, dim3((n + 255) / 256), dim3(256), 0, st, v0, n);
     int bits = 1;
     while (bits < 32 && (1ull << bits) < (u64)v.n_files) ++bits;
@@ -1260,7 +1278,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     void *scratch = (void *)(((uintptr_t)(d_unsorted + 16) + 63) & ~(uintptr_t)63);
     const size_t scratch_bytes = ws_bytes - (size_t)((char *)scratch - (char *)ws);
     (void)sc;
-    // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the routing kernel only ever raises the flag.  Several sets: always
+    // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the order check only ever raises the flag.  Several sets: always
     // partitioned (a concatenation of sets is not in order, and the partition is what tags the pairs)
     const u32 flag0 = getenv("GTARS_IGD_ALWAYS_SORT") || set_bounds ? 1u : 0u;
     const size_t prep_lds = ((size_t)n_tiles + v.n_chrom + 1) * 4;
@@ -1401,14 +1419,18 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         kern = k_igd_sweep<2, true, true>;
         lds = lds16;
     }
+    if (v.pieces) {
+        if (mode == 1 || !mo1) return fail(GTARS_ERR_INTERNAL, "IGD sweep: a pieces view serves min_overlap == 1 only");
+        kern = mode == 2 ? (b16 ? k_igd_sweep<2, true, true, true> : k_igd_sweep<2, true, false, true>) : k_igd_sweep<0, true, false, true>;
+    }
     {
         // the dynamic-LDS limit belongs to the function, not to the calling thread: raised once per device to the largest
         // size any launch can ask for (5 staged arrays + 16384 file bins) and never lowered
         static std::mutex mu;
-        static bool done[5][64] = {};
+        static bool done[10][64] = {};
         int dev = 0;
         GT_HIP(hipGetDevice(&dev));
-        const int slot = b16 ? 4 : mode == 0 && !mo1 ? 3 : mode;
+        const int slot = (b16 ? 4 : mode == 0 && !mo1 ? 3 : mode) + (v.pieces ? 5 : 0);
         std::lock_guard<std::mutex> lock(mu);
         if (dev >= 0 && dev < 64 && !done[slot][dev]) {
             GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -605,8 +605,12 @@ struct IgdQual {
 };
 // -> false: no record can qualify (unknown / empty chromosome, or -- tiled -- the query starts past the contig's last tile);
 // lo = where the scan starts
+// pm (may be null): IgdTiles::pm, the prefix maximum of the ends over the chromosome's records -- with it (and min_overlap >= 1)
+// the scan starts at the first record whose prefix-max end is > q_start, i.e. at the first record that CAN overlap, instead of
+// at lower_bound(q_start - the chromosome's longest record): one multi-megabase record in a database would otherwise make
+// every query of its chromosome walk through everything that starts within that distance before it.
 __device__ __forceinline__ bool igd_walk_setup(const IgdView &v, u32 c, i32 qs, i32 qe, i32 min_overlap, IgdQual &q, u32 &lo,
-                                               u32 &seg_hi) {
+                                               u32 &seg_hi, const i32 *__restrict__ pm = nullptr) {
     if (c >= v.n_chrom) return false;
     const u32 seg_lo = v.chrom_off[c];
     seg_hi = v.chrom_off[c + 1];
@@ -624,15 +628,20 @@ __device__ __forceinline__ bool igd_walk_setup(const IgdView &v, u32 c, i32 qs, 
         q.n2 = min((qe - 1) / IGD_NBP_COUNT, nt - 1);
         key += (i64)min_overlap;  // a record left of the query may end up to -min_overlap before it
     }
+    if (pm && !q.tiled) {
+        // first record with pm > qs (pm ascends inside a chromosome; a qualifying record ends at or after qs + min_overlap > qs)
+        lo = lower_bound_i32(pm, seg_lo, seg_hi, qs < 0x7FFFFFFF ? qs + 1 : qs);
+        return true;
+    }
     lo = lower_bound_i32(v.starts, seg_lo, seg_hi, key > 0 ? (i32)key : 0);  // starts are >= 0
     return true;
 }
 
 template <class F>
-__device__ __forceinline__ void igd_walk(const IgdView &v, u32 c, i32 qs, i32 qe, i32 min_overlap, F &&f) {
+__device__ __forceinline__ void igd_walk(const IgdView &v, u32 c, i32 qs, i32 qe, i32 min_overlap, F &&f, const i32 *__restrict__ pm = nullptr) {
     IgdQual q;
     u32 i, seg_hi;
-    if (!igd_walk_setup(v, c, qs, qe, min_overlap, q, i, seg_hi)) return;
+    if (!igd_walk_setup(v, c, qs, qe, min_overlap, q, i, seg_hi, pm)) return;
     for (; i < seg_hi; ++i) {
         const i32 s = v.starts[i];
         if (s >= qe) break;
@@ -646,7 +655,7 @@ constexpr int IGD_LDS_FILES = 8192;  // 32 KiB of u32 bins per workgroup
 // ends after the query's start (see k_igd_sweep, igd_sweep.hip) -- no look at the scanned prefix at all.
 template <bool BINARY, bool USE_LDS>
 __global__ void __launch_bounds__(256)
-k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
+k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__ pm, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
             const u32 *__restrict__ qe, u64 nq, i32 min_overlap, unsigned long long *__restrict__ hits) {
     __shared__ u32 bins[USE_LDS ? IGD_LDS_FILES : 1];
     if (USE_LDS) {
@@ -661,28 +670,36 @@ k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
         const u32 c = qc[q];
         if (!BINARY) {
             igd_walk(v, c, s, e, min_overlap, [&](u32 i) {
-                const u32 f = v.files[i];
+                u32 f = v.files[i];
+                if (f >> 31) {  // pieces view: a continuation piece counts only if it holds the query's start (IgdView::pieces)
+                    if (v.starts[i] > s) return;
+                    f &= IGD_FILE_MASK;
+                }
                 if (USE_LDS)
                     atomicAdd(&bins[f], 1u);
                 else
                     atomicAdd(&hits[f], 1ull);
-            });
+            }, pm);
         } else if (pme_file) {
             igd_walk(v, c, s, e, min_overlap, [&](u32 i) {
                 if (pme_file[i] > s) return;
-                const u32 f = v.files[i];
+                u32 f = v.files[i];
+                if (f >> 31) {
+                    if (v.starts[i] > s) return;
+                    f &= IGD_FILE_MASK;
+                }
                 if (USE_LDS)
                     atomicAdd(&bins[f], 1u);
                 else
                     atomicAdd(&hits[f], 1ull);
-            });
+            }, pm);
         } else {
             // count file f once per query: only at the first hit (in scan order) that belongs to f.
             // "Is there an earlier hit of the same file" looks at the file ids of the (short) scanned
             // prefix first and tests the overlap only for records of the same file.
             IgdQual qual;
             u32 lo = 0, seg_hi0 = 0;
-            if (!igd_walk_setup(v, c, s, e, min_overlap, qual, lo, seg_hi0)) continue;
+            if (!igd_walk_setup(v, c, s, e, min_overlap, qual, lo, seg_hi0, pm)) continue;
             unsigned long long seen0 = 0, seen1 = 0;  // 128-bit filter of files already credited
             igd_walk(v, c, s, e, min_overlap, [&](u32 i) {
                 const u32 f = v.files[i];
@@ -704,7 +721,7 @@ k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
                     else
                         atomicAdd(&hits[f], 1ull);
                 }
-            });
+            }, pm);
         }
     }
     if (USE_LDS) {
@@ -717,8 +734,11 @@ k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const u32 *__restrict__
 }
 
 gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
-                              i32 min_overlap, int binary, u64 *hits, hipStream_t st) {
+                              i32 min_overlap, int binary, u64 *hits, hipStream_t st, const i32 *pm) {
     if (!binary || min_overlap != 1) pme_file = nullptr;
+    if (min_overlap < 1 || getenv("GTARS_IGD_NO_PM_START")) pm = nullptr;  // (the environment switch: tests / A-B)
+    if (v.pieces && (min_overlap != 1 || (binary && !pme_file)))
+        return fail(GTARS_ERR_INTERNAL, "IGD count: a pieces view serves min_overlap == 1 (binary: the pme_file form) only");
     if (min_overlap < 1 && !v.chrom_ntiles) return fail(GTARS_ERR_INTERNAL, "IGD count with min_overlap < 1 needs the contigs' tile counts");
     GT_HIP(hipMemsetAsync(hits, 0, sizeof(u64) * (v.n_files ? v.n_files : 1), st));
     if (nq == 0 || v.n == 0) return GTARS_OK;
@@ -731,14 +751,14 @@ gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *
     ProfScope p(binary ? "k_igd_count<binary>" : "k_igd_count<pairwise>", st);
     if (binary) {
         if (lds)
-            hipLaunchKernelGGL((k_igd_count<true, true>), dim3(grid), dim3(256), 0, st, v, pme_file, qc, qs, qe, nq, min_overlap, h);
+            hipLaunchKernelGGL((k_igd_count<true, true>), dim3(grid), dim3(256), 0, st, v, pme_file, pm, qc, qs, qe, nq, min_overlap, h);
         else
-            hipLaunchKernelGGL((k_igd_count<true, false>), dim3(grid), dim3(256), 0, st, v, pme_file, qc, qs, qe, nq, min_overlap, h);
+            hipLaunchKernelGGL((k_igd_count<true, false>), dim3(grid), dim3(256), 0, st, v, pme_file, pm, qc, qs, qe, nq, min_overlap, h);
     } else {
         if (lds)
-            hipLaunchKernelGGL((k_igd_count<false, true>), dim3(grid), dim3(256), 0, st, v, pme_file, qc, qs, qe, nq, min_overlap, h);
+            hipLaunchKernelGGL((k_igd_count<false, true>), dim3(grid), dim3(256), 0, st, v, pme_file, pm, qc, qs, qe, nq, min_overlap, h);
         else
-            hipLaunchKernelGGL((k_igd_count<false, false>), dim3(grid), dim3(256), 0, st, v, pme_file, qc, qs, qe, nq, min_overlap, h);
+            hipLaunchKernelGGL((k_igd_count<false, false>), dim3(grid), dim3(256), 0, st, v, pme_file, pm, qc, qs, qe, nq, min_overlap, h);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;

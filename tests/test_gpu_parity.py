@@ -1281,3 +1281,81 @@ def test_igd_query_sets_argument_checks(ga):
     assert lib.gtars_igd_count_sets(g._h, ptr(q[0]), ptr(q[1]), ptr(q[2]), ptr(off), 1, 1, 0, ptr(hits)) != 0  # set_off[0] != 0
     off = np.array([0, 4, 2], dtype=np.uint64)
     assert lib.gtars_igd_count_sets(g._h, ptr(q[0]), ptr(q[1]), ptr(q[2]), ptr(off), 2, 1, 0, ptr(hits)) != 0  # decreasing
+
+
+def test_igd_per_query_counts_with_one_giant_record(ga, monkeypatch):
+    """The per-query kernel (batches below the sweep's crossover) starts a query's scan at the first record whose prefix-max end
+    is > q_start (IgdTiles::pm) instead of at lower_bound(q_start - the chromosome's longest record): with one 60-Mbp record
+    in the database the old start made every query of that chromosome walk ~half the chromosome.  Same vectors as the oracle
+    and as the old start (GTARS_IGD_NO_PM_START), pairwise and binary, min_overlap 1 and 4."""
+    rng = np.random.default_rng(99)
+    n, F, span = 300_000, 25, 100_000_000
+    c = rng.integers(0, 2, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 900, n)
+    f = rng.integers(0, F, n)
+    c[7], s[7], e[7] = 0, 20_000_000, 80_000_000  # the giant
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=2, n_files=F)
+    qc, qs, qe = _random_query_set(rng, 20_000, 2, span + 2_000, 700)
+    for mo in (1, 4):
+        want_p = o.count_set_overlaps(qc, qs, qe, mo, n_files=F)
+        want_b = o.count_region_hits(qc, qs, qe, mo, n_files=F)
+        assert np.array_equal(g.count_set_overlaps(qc, qs, qe, mo), want_p)
+        assert np.array_equal(g.count_region_hits(qc, qs, qe, mo), want_b)
+        monkeypatch.setenv("GTARS_IGD_NO_PM_START", "1")
+        assert np.array_equal(g.count_set_overlaps(qc, qs, qe, mo), want_p)
+        assert np.array_equal(g.count_region_hits(qc, qs, qe, mo), want_b)
+        monkeypatch.delenv("GTARS_IGD_NO_PM_START")
+    monkeypatch.setenv("GTARS_IGD_NO_PME", "1")  # the credited-file form of the binary count
+    assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F))
+
+
+@pytest.mark.parametrize("piece_bp", [None, 64])
+def test_igd_counts_on_databases_with_long_records(ga, monkeypatch, piece_bp):
+    """Databases with records longer than 16384 bp (broad peaks, one 30-Mbp record) are counted through a second index of
+    PIECES for min_overlap == 1 (api.hip build_pieces_view: long records cut at multiples of 16384 bp, a continuation piece
+    counts only if it holds the query's start -- the reference's own tile rule, igd.rs:109-153 / 812-817).  Every form must
+    equal the oracle's literal tile walk over the ORIGINAL records: sweep and per-query kernels, pairwise and binary, several
+    query sets in one pass, and min_overlap 3 (served by the flat layout).  piece_bp = 64: the same with tiny pieces, so that
+    almost every record is cut."""
+    if piece_bp:
+        monkeypatch.setenv("GTARS_IGD_PIECE_BP", str(piece_bp))
+    rng = np.random.default_rng(2024)
+    n, F, span = 120_000, 30, 60_000_000
+    c = rng.integers(0, 2, n)
+    s = rng.integers(0, span, n)
+    w = rng.integers(1, 900, n)
+    wide = rng.random(n) < 0.03
+    w = np.where(wide, rng.integers(5_000, 300_000, n), w)
+    e = s + w
+    c[11], s[11], e[11] = 1, 10_000_000, 40_000_000
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=2, n_files=F)
+    big = _random_query_set(rng, 150_000, 2, span + 2_000, 700)       # above the sweep's crossover
+    small = _random_query_set(rng, 9_000, 2, span + 2_000, 5_000)     # per-query kernel
+    _lib = ga._lib
+    for qc, qs, qe in (big, small):
+        _lib.lib.gtars_prof_reset()
+        _lib.lib.gtars_prof_enable(1)
+        got_p, got_b = g.count_set_overlaps(qc, qs, qe, 1), g.count_region_hits(qc, qs, qe, 1)
+        prof = _lib.prof_read()
+        _lib.lib.gtars_prof_enable(0)
+        assert prof.get("igd_pieces_view", {"launches": 0})["launches"] == 2, prof.keys()
+        assert np.array_equal(got_p, o.count_set_overlaps(qc, qs, qe, 1, n_files=F))
+        assert np.array_equal(got_b, o.count_region_hits(qc, qs, qe, 1, n_files=F))
+        assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 3), o.count_set_overlaps(qc, qs, qe, 3, n_files=F))
+        assert np.array_equal(g.count_region_hits(qc, qs, qe, 3), o.count_region_hits(qc, qs, qe, 3, n_files=F))
+    sets = [big, small, _random_query_set(rng, 40_000, 2, span, 300)]
+    for binary in (True, False):
+        ref = o.count_region_hits if binary else o.count_set_overlaps
+        assert np.array_equal(g.count_sets(sets, 1, binary), np.stack([ref(qc, qs, qe, 1, n_files=F) for qc, qs, qe in sets]))
+    # the flat layout gives the same vectors (what the pieces view replaces)
+    monkeypatch.setenv("GTARS_IGD_NO_PIECES", "1")
+    g2 = ga.IgdIndex(c, s, e, f, np.arange(n), n_chrom=2, n_files=F)
+    qc, qs, qe = small
+    assert np.array_equal(g2.count_set_overlaps(qc, qs, qe, 1), o.count_set_overlaps(qc, qs, qe, 1, n_files=F))
+    # everything that is not a count still sees one record per stored interval
+    assert len(g) == len(g2) == n  # (every record is valid here)
+    ok = (qs < 2**31) & (qe < 2**31)
+    assert np.array_equal(g.count_overlaps_per_query(qc[ok][:2000], qs[ok][:2000], qe[ok][:2000], 1),
+                          o.count_overlaps_per_query(qc[ok][:2000], qs[ok][:2000], qe[ok][:2000], 1))
