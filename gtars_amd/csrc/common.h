@@ -129,7 +129,7 @@ struct IgdView {
     u32 n_chrom;
     u32 n;
     u32 n_files;
-    // 1: a PIECES view (api.hip, build_pieces_view): records longer than 16384 bp were cut into pieces, bit 31 of files[] (bit 15
+    // 1: a PIECES view (api.hip, build_pieces_view): records longer than the piece length were cut into pieces, bit 31 of files[] (bit 15
     // of the u16 copy) marks a continuation piece, which counts for a query only if it starts at or before the query's start
     u32 pieces;
 };

@@ -1312,8 +1312,8 @@ def test_igd_per_query_counts_with_one_giant_record(ga, monkeypatch):
 
 @pytest.mark.parametrize("piece_bp", [None, 64])
 def test_igd_counts_on_databases_with_long_records(ga, monkeypatch, piece_bp):
-    """Databases with records longer than 16384 bp (broad peaks, one 30-Mbp record) are counted through a second index of
-    PIECES for min_overlap == 1 (api.hip build_pieces_view: long records cut at multiples of 16384 bp, a continuation piece
+    """Databases with records much longer than most (broad peaks, one 30-Mbp record) are counted through a second index of
+    PIECES for min_overlap == 1 (api.hip build_pieces_view: long records cut at multiples of the piece length, a continuation piece
     counts only if it holds the query's start -- the reference's own tile rule, igd.rs:109-153 / 812-817).  Every form must
     equal the oracle's literal tile walk over the ORIGINAL records: sweep and per-query kernels, pairwise and binary, several
     query sets in one pass, and min_overlap 3 (served by the flat layout).  piece_bp = 64: the same with tiny pieces, so that
