@@ -427,6 +427,61 @@ def igd_pmc_child():
     torch.cuda.synchronize()
 
 
+def bench_igd_broad_peaks(dev, stream, ndb=IGD3["ndb"], nq=IGD3["nq"], n_files=IGD3["n_files"], frac=0.01, wmax=100_000):
+    """Config 3 with LONG records in the database (not a BASELINE config: a robustness figure): `frac` of the records get a
+    width of U[5000, wmax) instead of 200 + U[0, 800) -- broad peaks.  The flat record layout degrades by 30x on this database
+    (one long record inflates the prefix maxima and the ownership of everything behind it); the library counts it through its
+    pieces view.  Timed: the min_overlap == 1 batch counts; verified: identical per-file vectors from an index
+    built WITHOUT the pieces view (one call each)."""
+    import torch
+
+    import gtars_amd
+    from gtars_amd import synth
+
+    db = synth.make_igd_db(ndb, n_files)
+    rng = np.random.default_rng(1)
+    wide = rng.random(ndb) < frac
+    db["end"] = np.where(wide, db["start"].astype(np.int64) + rng.integers(5_000, wmax, ndb), db["end"]).astype(db["end"].dtype)
+    q = synth.make_background_queries(nq)
+    qc, qs, qe = (_dev(q[k], dev) for k in ("chrom", "start", "end"))
+    hits = torch.zeros(n_files, dtype=torch.int64, device=dev)
+    out = {"db_intervals": ndb, "queries": nq, "files": n_files, "long_fraction": frac, "long_width": [5000, wmax]}
+    vecs = {}
+    for label, env in (("pieces_view", None), ("flat_layout", "1")):
+        if env:
+            os.environ["GTARS_IGD_NO_PIECES"] = env
+        else:
+            os.environ.pop("GTARS_IGD_NO_PIECES", None)
+        try:
+            t = time.time()
+            g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=n_files)
+            o = {"build_s": round(time.time() - t, 2)}
+        finally:
+            os.environ.pop("GTARS_IGD_NO_PIECES", None)
+        for binary in (False, True):
+            f = lambda: g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, hits.data_ptr(), 1, binary, stream)
+            f()
+            torch.cuda.synchronize()
+            reps = 3 if env is None else 1
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                f()
+            torch.cuda.synchronize()
+            key = "binary" if binary else "pairwise"
+            o[key + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+            h = hits.cpu().numpy().copy()
+            if env is None:
+                vecs[key] = h
+                o[key + "_hits"] = int(h.sum())
+            elif not np.array_equal(h, vecs[key]):
+                raise SystemExit(f"bench.py: igd_broad_peaks: {key} vectors of the pieces view and the flat layout differ")
+        out[label] = o
+        del g
+        torch.cuda.empty_cache()
+    out["verified"] = "per-file vectors identical to the flat layout's (one call each)"
+    return out
+
+
 def bench_lola_config4(dev, stream, n_sets=LOLA4["n_sets"], per_set=LOLA4["per_set"], n_universe=LOLA4["n_universe"],
                        n_user=LOLA4["n_user"], cpu=True):
     """BASELINE config 4 on ONE GPU: support counts of one user set and of the universe against a 2000-set region DB
@@ -966,6 +1021,7 @@ def main():
             torch.cuda.empty_cache()
             cpu = not args.no_cpu_baseline
             out["igd_config3"] = bench_igd_config3(dev, stream, cpu=cpu, pmc=not args.no_pmc)
+            out["igd_config3_broad_peaks"] = bench_igd_broad_peaks(dev, stream)
             out["lola_config4"] = bench_lola_config4(dev, stream, cpu=cpu)
             out["fragsplit_config5"] = bench_fragsplit_config5(files=args.c5_files)
         if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N=1 only
