@@ -2215,7 +2215,7 @@ gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d
     if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
     const size_t F = g->n_files;
     const gtars_igd *gs = igd_count_target(g, min_overlap, binary);  // what a shared pass sweeps
-    static const bool no_shared = getenv("GTARS_IGD_NO_SHARED_PASS") != nullptr;  // tests / A-B runs
+    const bool no_shared = getenv("GTARS_IGD_NO_SHARED_PASS") != nullptr;  // tests / A-B runs
     for (u32 k0 = 0; k0 < n_sets;) {
         // the longest run of <= 4 consecutive sets that can share a pass
         u32 k1 = k0 + 1;
