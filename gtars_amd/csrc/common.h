@@ -237,9 +237,25 @@ size_t multisplit_ws_bytes(u32 n_bins, u32 n);
 // key: u32 keys, or unsigned short keys when key16 (n_bins <= 65535); clamp_a: a = max((i32)a, 0) on the way (raw IGD query
 // starts); table_ready: the caller has already counted the keys into multisplit_table(ws) -- one row of n_bins counters per
 // workgroup of a multisplit_workgroups(n)-workgroup grid over contiguous chunks of ceil(n / workgroups) elements
+// Bins (tiles of the IGD sweep) far heavier than the average, listed in PARTS of `part` elements so that their consumer can hand
+// them to several workgroups: part 0 of every bin is implied, parts 1 .. ceil(total / part) - 1 of a bin with more than `part`
+// elements are appended to list[] as (bin, part) -- at most cap entries (sum over bins of total / part never exceeds n / part);
+// *count is zeroed by the caller.  part == 0: nothing is listed.
+struct HeavyBins {
+    uint2 *list = nullptr;
+    u32 *count = nullptr;
+    u32 part = 0, n_real_bins = 0, cap = 0;
+    __device__ __forceinline__ void note(u32 bin, u32 total) const {
+        if (!part || bin >= n_real_bins || total <= part) return;
+        const u32 extra = (total - 1) / part;  // parts 1 .. extra
+        const u32 at = atomicAdd(count, extra);
+        for (u32 p = 0; p < extra; ++p)
+            if (at + p < cap) list[at + p] = make_uint2(bin, p + 1);
+    }
+};
 gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
                               uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if = nullptr,
-                              bool table_ready = false, const u32 *set_bounds = nullptr);
+                              bool table_ready = false, const u32 *set_bounds = nullptr, const HeavyBins *heavy = nullptr);
 // set_bounds (host, 3 values; null: one set): the input holds up to 4 row ranges ("sets") -- first row of set 1, 2, 3, 0xFFFFFFFF
 // for a set that does not exist; the set of a row leaves in bit 31 of its pair (b: set & 1, a: set >> 1; see SetTags, sort.hip)
 u32 multisplit_workgroups(u32 n);

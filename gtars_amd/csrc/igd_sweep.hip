@@ -344,7 +344,10 @@ k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restr
             }
         }
         const int any_bad = __syncthreads_or(bad ? 1 : 0);
-        if (threadIdx.x == 0) *flag = flag_value | (any_bad ? 1u : 0u);
+        if (threadIdx.x == 0) {
+            flag[0] = flag_value | (any_bad ? 1u : 0u);
+            flag[1] = 0u;  // number of listed heavy-tile parts (HeavyBins::count)
+        }
     }
 }
 
@@ -480,7 +483,7 @@ template <bool CLAMP>
 __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
                                   const u32 *__restrict__ tile_chrom, u32 n_tiles, const u32 *__restrict__ sorted_qs,
                                   const u32 *__restrict__ cq_off, u32 *__restrict__ ql, u32 *__restrict__ qh,
-                                  const u32 *__restrict__ skip_if) {
+                                  const u32 *__restrict__ skip_if, HeavyBins heavy) {
     if (skip_if && *skip_if) return;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
@@ -489,8 +492,11 @@ __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first,
     const u32 lo = cq_off[c], hi = cq_off[c + 1];
     const bool first_of_chrom = p0 == v.chrom_off[c];
     // key > prev_last  <=>  q.start >= prev_last + max_len + 1   (keys clamped to 0 belong to the first tile)
-    ql[t] = first_of_chrom ? lo : lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 - 1] + max_len + 1);
-    qh[t] = lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 + cnt - 1] + max_len + 1);
+    const u32 a = first_of_chrom ? lo : lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 - 1] + max_len + 1);
+    const u32 b = lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 + cnt - 1] + max_len + 1);
+    ql[t] = a;
+    qh[t] = b;
+    heavy.note(t, b - a);  // a tile far heavier than the average is served in parts (k_igd_sweep)
 }
 
 // ---- the sweep ---------------------------------------------------------------------------------
@@ -650,7 +656,8 @@ __global__ void __launch_bounds__(SW_TPB, MODE == 0 ? 8 : MODE == 2 ? 6 : 4)
 k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__ pm, const unsigned short *__restrict__ files16,
             const u32 *__restrict__ tile_tab, u32 n_tiles, const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap, unsigned long long *__restrict__ hits,
-            const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab, const u32 *__restrict__ part_ql, u32 n_bins) {
+            const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab, const u32 *__restrict__ part_ql, u32 n_bins,
+            const uint2 *__restrict__ heavy_list, const u32 *__restrict__ heavy_count, u32 heavy_part, u32 heavy_cap) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
     // whether the batch had to be partitioned was decided on the device (the routing kernel): take the partition's
     // interleaved (start, end) pairs and bin offsets, or the batch as it arrived with the tile ranges
@@ -720,13 +727,28 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
 #if IGD_STAMPS
     u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Work items: every tile's first `heavy_part` queries (item = tile), then the listed further parts of the tiles that own far
+    // more queries than the average (HeavyBins: filled by the bin scan or by k_igd_tile_ranges) -- a batch with half of its
+    // queries inside one 50-kb window kept ONE workgroup busy for 32 ms (10M queries) before; the parts of such a tile now spread
+    // over the grid, each staging the tile again.
+    const u32 n_heavy = heavy_part ? min(*heavy_count, heavy_cap) : 0u;
+    for (u32 item = blockIdx.x; item < n_tiles + n_heavy; item += gridDim.x) {
+        u32 tile = item, part = 0;
+        if (item >= n_tiles) {
+            const uint2 hp = heavy_list[item - n_tiles];
+            tile = hp.x;
+            part = hp.y;
+        }
         const u32 *__restrict__ tab = tile_tab + (size_t)tile * TAB_WORDS;  // uniform: the descriptor comes by scalar loads
         const u32 p0 = tab[0], cnt = tab[1], n_lds = tab[3], n_seg = tab[10];
         const i32 S0 = (i32)tab[4], S1 = (i32)tab[5], P0 = (i32)tab[7], P1 = (i32)tab[8];
         const u32 sh_s = tab[6], sh_p = tab[9];
         (void)cnt;
-        const u32 q_lo = ql[tile], q_hi = (GTARS_IGD_ABLATE & 8) ? q_lo : qh[tile];
+        u32 q_lo = ql[tile], q_hi = (GTARS_IGD_ABLATE & 8) ? q_lo : qh[tile];
+        if (heavy_part) {  // this item's share of the tile's queries
+            q_lo = min(q_hi, q_lo + part * heavy_part);
+            q_hi = min(q_hi, q_lo + heavy_part);
+        }
         // the tile's first SW_TPB queries: loaded now, used once the tile is staged (MODE 0 / 2)
         i32 pf_s = 0, pf_e = 0;
         if constexpr (MODE != 1) {
@@ -1217,9 +1239,11 @@ bool igd_sweep_supported(const IgdView &v, u64 nq) {
     return v.n > 0 && v.n_files > 0 && v.n_files <= 16384 && nq >= min_q && nq < (1ull << 31);
 }
 
+constexpr u32 HEAVY_PART_MIN = 4096;  // queries per part of a heavy tile, at least (a multiple of SW_TPB)
 size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom) {
-    // kc ks ke | sorted qs qe chrom | perm (or owner tiles) | ql qh | cq_off | bin offsets | slack | partition / sort scratch
-    return (size_t)nq * 4 * 7 + (size_t)n_tiles * 12 + ((size_t)n_chrom + 2) * 4 + 512 +
+    // kc ks ke | sorted qs qe chrom | perm (or owner tiles) | ql qh | cq_off | bin offsets | slack | heavy-tile parts |
+    // partition / sort scratch
+    return (size_t)nq * 4 * 7 + (size_t)n_tiles * 12 + ((size_t)n_chrom + 2) * 4 + 512 + ((size_t)nq / HEAVY_PART_MIN + 16) * 8 +
            std::max(device_sort_perm_ws_bytes((u32)nq), multisplit_ws_bytes(n_tiles + 1, (u32)nq));
 }
 
@@ -1274,8 +1298,16 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     u32 *sc = ke + nq, *ss = sc + nq, *se = ss + nq, *perm = se + nq;  // perm doubles as the owner-tile column
     u32 *ql = perm + nq, *qh = ql + n_tiles, *cq_off = qh + n_tiles;
     u32 *bin_off = cq_off + v.n_chrom + 2;  // [n_tiles + 2]
-    u32 *d_unsorted = bin_off + n_tiles + 2;
-    void *scratch = (void *)(((uintptr_t)(d_unsorted + 16) + 63) & ~(uintptr_t)63);
+    u32 *d_unsorted = bin_off + n_tiles + 2;  // [0]: the "not in owner order" flag, [1]: number of listed heavy-tile parts
+    // tiles that own far more queries than the average are served in parts of heavy_part queries (k_igd_sweep's work items)
+    HeavyBins heavy;
+    heavy.list = reinterpret_cast<uint2 *>(((uintptr_t)(d_unsorted + 16) + 7) & ~(uintptr_t)7);
+    heavy.count = d_unsorted + 1;
+    heavy.part = std::max<u32>(HEAVY_PART_MIN, (u32)std::min<u64>(8ull * (nq / std::max<u32>(n_tiles, 1)), 1u << 30) / SW_TPB * SW_TPB);
+    heavy.n_real_bins = n_tiles;
+    heavy.cap = nq / heavy.part + 1;
+    if (getenv("GTARS_IGD_NO_HEAVY_PARTS")) heavy.part = 0;  // tests / A-B runs
+    void *scratch = (void *)(((uintptr_t)(heavy.list + (size_t)nq / HEAVY_PART_MIN + 8) + 63) & ~(uintptr_t)63);
     const size_t scratch_bytes = ws_bytes - (size_t)((char *)scratch - (char *)ws);
     (void)sc;
     // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the order check only ever raises the flag.  Several sets: always
@@ -1356,9 +1388,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         // kernels for one that is not, and the sweep takes its inputs accordingly.
         // K1 (multisplit): (start, end) pairs grouped by owner tile; bin_off[t], bin_off[t + 1] bound tile t's queries
         gtars_status s1 = fused ? multisplit_pairs(perm, true, qs, qe, true, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
-                                                   scratch, scratch_bytes, st, d_unsorted, true, set_bounds)
+                                                   scratch, scratch_bytes, st, d_unsorted, true, set_bounds, &heavy)
                                 : multisplit_pairs(perm, false, ks, ke, false, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
-                                                   scratch, scratch_bytes, st, d_unsorted, false, set_bounds);  // ss, se adjacent: 2 * nq words
+                                                   scratch, scratch_bytes, st, d_unsorted, false, set_bounds, &heavy);  // ss, se adjacent: 2 * nq words
         if (s1) return s1;
         part_flag = d_unsorted;
         part_ab = ss;
@@ -1375,12 +1407,12 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
             hipLaunchKernelGGL(k_igd_chrom_segments<true>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, oc, qs, qe, (const u32 *)nullptr,
                                nq, v.n_chrom, cq_off, d_unsorted);
             hipLaunchKernelGGL(k_igd_tile_ranges<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles,
-                               ss, cq_off, ql, qh, d_unsorted);
+                               ss, cq_off, ql, qh, d_unsorted, heavy);
         } else {
             hipLaunchKernelGGL(k_igd_chrom_segments<false>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, oc, (const u32 *)nullptr,
                                (const u32 *)nullptr, (const u32 *)nullptr, nq, v.n_chrom, cq_off, d_unsorted);
             hipLaunchKernelGGL(k_igd_tile_ranges<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles,
-                               ss, cq_off, ql, qh, d_unsorted);
+                               ss, cq_off, ql, qh, d_unsorted, heavy);
         }
     } else {
         if (!getenv("GTARS_IGD_ALWAYS_SORT")) {
@@ -1402,7 +1434,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         hipLaunchKernelGGL(k_igd_chrom_segments<false>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, kc, (const u32 *)nullptr,
                            (const u32 *)nullptr, perm, nq, v.n_chrom, cq_off, (const u32 *)nullptr);
         hipLaunchKernelGGL(k_igd_tile_ranges<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles, ss,
-                           cq_off, ql, qh, (const u32 *)nullptr);
+                           cq_off, ql, qh, (const u32 *)nullptr, heavy);
     }
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
     if (!tl.pm || !tl.files16 || !tl.tab) return fail(GTARS_ERR_INTERNAL, "IGD sweep: the per-tile tables were not built");
@@ -1445,7 +1477,8 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     {
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.pm, tl.files16, tl.tab, n_tiles, ss, se,
-                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql, n_bins);
+                           interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql, n_bins,
+                           (const uint2 *)heavy.list, (const u32 *)heavy.count, heavy.part, heavy.cap);
     }
     GT_HIP(hipGetLastError());
     // which continuation the device took (profiling mode: a deterministic fact for the tests, not a timing)

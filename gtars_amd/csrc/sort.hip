@@ -181,11 +181,12 @@ __global__ void k_ms_colscan(u32 *__restrict__ table, u32 n_wg, u32 n_bins, u32 
     tot[b] = run;
 }
 
-// bin_off[0 .. n_bins] = exclusive scan of tot (one workgroup); for the two-level split (cur_a != null) also the cursors its
+// bin_off[0 .. n_bins] = exclusive scan of tot (one workgroup); bins far heavier than the average are also listed in pieces
+// (HeavyBins, common.h: the consumer may hand the pieces of such a bin to several workgroups); for the two-level split (cur_a != null) also the cursors its
 // passes reserve runs from: cur_b[i] = bin_off[i], cur_a[j] = bin_off[j << shift] (was a launch of its own)
 __global__ void __launch_bounds__(MS_TPB)
 k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off, u32 shift, u32 *__restrict__ cur_a,
-             u32 *__restrict__ cur_b, const u32 *__restrict__ run_if) {
+             u32 *__restrict__ cur_b, const u32 *__restrict__ run_if, HeavyBins heavy) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     // Every wave takes a contiguous run of S * 64 bins (S <= 36 for MS_MAX_BINS): S coalesced loads in flight together, S wave
     // scans on the DPP path with a running carry, ONE barrier for the waves' totals (a round-per-1024-bins loop with two
@@ -222,6 +223,7 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off,
         const u32 b = first + k * 64u + lane;
         if (k < S && b < n_bins) {
             const u32 o = base + v[k];
+            heavy.note(b, tot[b]);
             bin_off[b] = o;
             if (cur_a) {
                 cur_b[b] = o;
@@ -411,7 +413,7 @@ u32 *multisplit_totals(void *ws, u32 n_bins, u32 n) { return multisplit_two_leve
 template <class KeyT, bool CLAMP>
 static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
                                        u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
-                                       const u32 *set_bounds) {
+                                       const u32 *set_bounds, const HeavyBins *heavy) {
     const SetTags tags = set_bounds ? SetTags{set_bounds[0], set_bounds[1], set_bounds[2]} : SetTags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     if (n_bins == 0 || n_bins > MS_MAX_BINS) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
     if (ws_bytes < multisplit_ws_bytes(n_bins, n)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
@@ -451,7 +453,7 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
         u32 shift = 0;
         while (((n_bins - 1) >> shift) >= 256u) ++shift;
         hipLaunchKernelGGL(k_ms_binscan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off, shift, two_level ? cur_a : (u32 *)nullptr, cur_b,
-                           run_if);
+                           run_if, heavy ? *heavy : HeavyBins{});
     }
     if (two_level) {
         u32 shift = 0;
@@ -475,17 +477,17 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
 
 gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
                               uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
-                              const u32 *set_bounds) {
+                              const u32 *set_bounds, const HeavyBins *heavy) {
     if (key16 && n_bins > 65535u) return fail(GTARS_ERR_INTERNAL, "multisplit: 16-bit keys need <= 65535 bins");
     if (key16)
         return clamp_a ? multisplit_pairs_t<unsigned short, true>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
-                                                                  ws_bytes, st, run_if, table_ready, set_bounds)
+                                                                  ws_bytes, st, run_if, table_ready, set_bounds, heavy)
                        : multisplit_pairs_t<unsigned short, false>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
-                                                                   ws_bytes, st, run_if, table_ready, set_bounds);
+                                                                   ws_bytes, st, run_if, table_ready, set_bounds, heavy);
     return clamp_a ? multisplit_pairs_t<u32, true>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
-                                                   table_ready, set_bounds)
+                                                   table_ready, set_bounds, heavy)
                    : multisplit_pairs_t<u32, false>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
-                                                    table_ready, set_bounds);
+                                                    table_ready, set_bounds, heavy);
 }
 
 __global__ void k_iota(u32 *__restrict__ p, u32 n) {
