@@ -543,6 +543,7 @@ struct gtars_igd {
         v.chrom_off = chrom_off.p;
         v.chrom_maxlen = chrom_maxlen.p;
         v.chrom_ntiles = ntiles_ready ? chrom_ntiles.p : nullptr;
+        v.pm = getenv("GTARS_IGD_NO_PM_START") ? nullptr : tile_pm.p;
         v.n_chrom = n_chrom;
         v.n = (u32)n;
         v.n_files = n_files;

@@ -126,6 +126,9 @@ struct IgdView {
     // [n_chrom] tiles of the reference's contig at nbp = 16384, (largest end - 1) / 16384 + 1 -- what the walk of
     // igd.rs:772-846 needs to reproduce min_overlap <= 0; null until such a query is made (gtars_igd::ensure_ntiles)
     const i32 *chrom_ntiles;
+    // IgdTiles::pm when built (null otherwise): prefix maximum of the ends inside a chromosome -- the per-query kernels start a
+    // min_overlap >= 1 scan at the first record whose prefix-max end is > q_start
+    const i32 *pm;
     u32 n_chrom;
     u32 n;
     u32 n_files;

@@ -783,7 +783,10 @@ __device__ __forceinline__ void igd_walk_ref_order(const IgdView &v, u32 c, i32 
     const bool tiled = min_overlap < 1;  // see IgdQual: the first tile then only serves the records PRESENT in it
     if (tiled && n1 >= v.chrom_ntiles[c]) return;
     i64 key = (i64)qs - (i64)v.chrom_maxlen[c] + (tiled ? (i64)min_overlap : 0);
-    const u32 lo = lower_bound_i32(v.starts, seg_lo, seg_hi, key > 0 ? (i32)key : 0);
+    // min_overlap >= 1: nothing before the first record whose prefix-max end is > q_start can qualify (same records reported,
+    // in the same order; one long record in the chromosome no longer makes every query walk back by its length)
+    const u32 lo = (!tiled && v.pm) ? lower_bound_i32(v.pm, seg_lo, seg_hi, qs < 0x7FFFFFFF ? qs + 1 : qs)
+                                    : lower_bound_i32(v.starts, seg_lo, seg_hi, key > 0 ? (i32)key : 0);
     const u32 hi = lower_bound_i32(v.starts, lo, seg_hi, qe);
     if (lo >= hi) return;
     // group boundaries: first group = starts < (n1+1)*nbp
