@@ -113,15 +113,17 @@ def one_big(seed):
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "big":
         t = time.time()
+        base = int(sys.argv[3]) if len(sys.argv) > 3 else 9000  # first seed: another base = another set of shapes
         for seed in range(int(sys.argv[2])):
-            one_big(9000 + seed)
+            one_big(base + seed)
             print(f"  big {seed + 1}, {time.time() - t:.0f} s", flush=True)
         print(f"fuzz_igd: {sys.argv[2]} large configurations bit-exact vs the oracle ({time.time() - t:.0f} s)")
         return
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    base = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     t = time.time()
     for seed in range(rounds):
-        one(5000 + seed)
+        one(base + seed)
         if seed % 25 == 24:
             print(f"  {seed + 1} rounds, {time.time() - t:.0f} s", flush=True)
     print(f"fuzz_igd: {rounds} random configurations bit-exact vs the oracle ({time.time() - t:.0f} s)")

@@ -77,10 +77,11 @@ def one(seed):
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    base = int(sys.argv[2]) if len(sys.argv) > 2 else 1000  # first seed: another base = another set of shapes
     t = time.time()
     tot = 0
     for seed in range(rounds):
-        n, nq, h = one(1000 + seed)
+        n, nq, h = one(base + seed)
         tot += h
     print(f"fuzz_tokenize: {rounds} random configurations bit-exact vs the oracle ({tot} ids compared, {time.time() - t:.0f} s)")
 
