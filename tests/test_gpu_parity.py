@@ -1205,6 +1205,12 @@ def test_igd_two_level_partition_with_a_sparse_tail(ga, monkeypatch):
         monkeypatch.delenv("GTARS_IGD_SWEEP_MIN")
         assert int(shuffled.sum()) > n_hot  # the hot window is covered
         assert np.array_equal(shuffled, in_order) and np.array_equal(shuffled, per_query)
+        # the hot tile owns ~1.19M queries: it is served in ~290 parts by as many work items of the sweep (HeavyBins); the same
+        # vectors with one workgroup per tile
+        monkeypatch.setenv("GTARS_IGD_NO_HEAVY_PARTS", "1")
+        assert np.array_equal(count(qc, qs, qe, 1), shuffled)
+        assert np.array_equal(count(qc[order], qs[order], qe[order], 1), shuffled)
+        monkeypatch.delenv("GTARS_IGD_NO_HEAVY_PARTS")
 
 
 def _random_query_set(rng, n, n_chrom, span, wmax, spoiled=0.02):
