@@ -360,7 +360,11 @@ constexpr int ORD_TPB = 256;
 template <bool VEC>
 __global__ void __launch_bounds__(ORD_TPB)
 k_igd_order_check(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
-                  u32 *__restrict__ flag) {
+                  u32 *__restrict__ flag, u32 *__restrict__ cq_off) {
+    // By-product for the in-order continuation: cq_off[c] = first row whose (prepared) chromosome is >= c, c = 0 .. n_chrom -- the
+    // thread that sees a chromosome change at row i writes the entries of every chromosome in between (a batch in order has each
+    // boundary exactly once; a batch out of order raises the flag and nobody reads the table).  Was a kernel of its own
+    // (k_igd_chrom_segments: n_chrom + 1 binary searches over the batch, 7 us + a launch).
     if (*flag) return;
     const int lane = threadIdx.x & 63;
     bool bad = false;
@@ -397,7 +401,16 @@ k_igd_order_check(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u > 0 && i0 + u < nq && igd_out_of_order(pc, ps, c[u], s[u])) bad = true;
+            const u64 i = i0 + u;
+            if (i < nq) {
+                if (i > 0 && igd_out_of_order(pc, ps, c[u], s[u])) bad = true;
+                // chromosome boundaries (c[u] <= n_chrom after the validity rules)
+                const u32 from = i == 0 ? 0u : pc + 1u;
+                if (i == 0 || c[u] > pc)
+                    for (u32 k = from; k <= c[u]; ++k) cq_off[k] = (u32)i;
+                if (i == (u64)nq - 1)
+                    for (u32 k = c[u] + 1u; k <= n_chrom; ++k) cq_off[k] = nq;
+            }
             pc = c[u];
             ps = s[u];
         }
@@ -1355,7 +1368,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
             ProfScope p("k_igd_order_check", st);
             const unsigned og = (unsigned)std::max<u64>(1, std::min<u64>((u64)cus * 8, ((u64)nq + ORD_TPB * 4 - 1) / (ORD_TPB * 4)));
             hipLaunchKernelGGL(vec ? k_igd_order_check<true> : k_igd_order_check<false>, dim3(og), dim3(ORD_TPB), 0, st, qc, qs, qe, nq,
-                               v.n_chrom, d_unsorted);
+                               v.n_chrom, d_unsorted, cq_off);
         }
         ProfScope p("k_igd_route", st);
         hipLaunchKernelGGL(vec ? k_igd_route<true> : k_igd_route<false>, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom,
@@ -1404,8 +1417,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         if (flag0) {
             // the partition is certain (several sets, or forced): nothing to enqueue for the in-order continuation
         } else if (fused) {
-            hipLaunchKernelGGL(k_igd_chrom_segments<true>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, oc, qs, qe, (const u32 *)nullptr,
-                               nq, v.n_chrom, cq_off, d_unsorted);
+            // (the chromosome segments cq_off come from the order check)
             hipLaunchKernelGGL(k_igd_tile_ranges<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles,
                                ss, cq_off, ql, qh, d_unsorted, heavy);
         } else {
