@@ -1340,6 +1340,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         // two-level split: the routing kernel leaves bin TOTALS (atomics), not one table row per workgroup, so its grid is its own
         // to choose -- every CU gets a chunk once there are 4096 queries per workgroup (a 1.1M-query batch ran on 67 CUs: 35 us)
         rt_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
+        // (and never more than 65532 queries per workgroup -- its 16-bit counters: batches beyond 16.7M queries take more
+        // workgroups than CUs, which queue, instead of falling back to the two-kernel preparation)
+        rt_wg = std::max<u32>(rt_wg, (nq + 65531u) / 65532u);
         rt_chunk = ((nq + rt_wg - 1) / rt_wg + 3u) & ~3u;
     }
     const bool fused = bucket && tl.route_lut && rt_lds <= 160 * 1024 - 64 && rt_chunk <= 65535u && !getenv("GTARS_IGD_NO_FUSED_ROUTE");
