@@ -235,7 +235,8 @@ gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, 
 // K1 (sort.hip): one-pass partition of (a, b) pairs by a small key (< n_bins <= MS_MAX_BINS), not stable: out_ab receives
 // the pairs interleaved, bin_off[n_bins + 1] the bin boundaries; elements whose key is `drop_bin` are left out (their bin
 // must be the last one)
-constexpr u32 MS_MAX_BINS = 36864;  // 144 KB of LDS counters
+constexpr u32 MS_MAX_BINS = 36864;       // one-level split: 144 KB of LDS counters
+constexpr u32 MS_MAX_BINS_2L = 65535;    // two-level split (no per-bin LDS state): what 16-bit keys can name
 size_t multisplit_ws_bytes(u32 n_bins, u32 n);
 // key: u32 keys, or unsigned short keys when key16 (n_bins <= 65535); clamp_a: a = max((i32)a, 0) on the way (raw IGD query
 // starts); table_ready: the caller has already counted the keys into multisplit_table(ws) -- one row of n_bins counters per

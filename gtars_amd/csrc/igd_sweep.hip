@@ -163,10 +163,14 @@ k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const
 // a 10-step binary search of the chromosome's tile bounds.
 constexpr int RT_TPB = 1024;
 constexpr int RT_U = 4;  // queries per thread and step (their loads and searches overlap)
-size_t igd_route_lds_bytes(u32 n_tiles, u32 n_chrom, u32 n_lut) {
-    return ((size_t)n_tiles + 3 * (size_t)n_chrom + 2 + ((size_t)n_lut + 1) / 2 + ((size_t)n_tiles + 2) / 2) * 4;
+// bnd_lds: the tile bounds in LDS too (4 bytes per tile on top of the 2 of the counters: databases up to ~52M records); without
+// them the last steps of the owner search read the bounds from global memory (L2-resident: 4 bytes per tile), which carries the
+// fused routing to 65534 tiles = 134M records (before: the two-kernel preparation from 52M, a full radix sort of the batch from
+// 75M records: 1.8 ms instead of 0.9 for config 3's batch against 100M records)
+size_t igd_route_lds_bytes(u32 n_tiles, u32 n_chrom, u32 n_lut, bool bnd_lds) {
+    return ((bnd_lds ? (size_t)n_tiles : 0) + 3 * (size_t)n_chrom + 2 + ((size_t)n_lut + 1) / 2 + ((size_t)n_tiles + 2) / 2) * 4;
 }
-template <bool VEC>
+template <bool VEC, bool BND_LDS = true>
 __global__ void __launch_bounds__(RT_TPB)
 k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
             const u32 *__restrict__ bnd, const u32 *__restrict__ chrom_tile_off, const u32 *__restrict__ route_base,
@@ -174,14 +178,14 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
             unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, const u32 *__restrict__ run_if) {
     if (run_if && *run_if == 0) return;  // the batch is in owner order (k_igd_order_check): nothing to route, the sweep takes it as it lies
     extern __shared__ u32 rt_lds[];
-    u32 *s_bnd = rt_lds, *s_cto = s_bnd + n_tiles, *s_base = s_cto + n_chrom + 1, *s_len = s_base + n_chrom + 1;
+    u32 *s_bnd = rt_lds, *s_cto = s_bnd + (BND_LDS ? n_tiles : 0u), *s_base = s_cto + n_chrom + 1, *s_len = s_base + n_chrom + 1;
     u32 *s_lutw = s_len + n_chrom;
     u32 *bins = s_lutw + (n_lut + 1) / 2;  // (n_tiles + 2) / 2 words: bin b in half (b & 1) of word b >> 1
     const unsigned short *s_lut = reinterpret_cast<const unsigned short *>(s_lutw);
 #if IGD_STAMPS
     u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
-    {
+    if (BND_LDS) {
         // the tile bounds: 16-byte loads, four in flight per thread (a dword-per-step copy loop is a chain of L2 round trips)
         const u32 n4 = n_tiles >> 2;
         const uint4 *src = reinterpret_cast<const uint4 *>(bnd);
@@ -262,7 +266,7 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
             for (int u = 0; u < RT_U; ++u) {
                 if (l[u] < h[u]) {
                     const u32 mid = l[u] + ((h[u] - l[u]) >> 1);
-                    if (s_bnd[mid] <= (u32)s[u])
+                    if ((BND_LDS ? s_bnd[mid] : bnd[mid]) <= (u32)s[u])
                         l[u] = mid + 1;
                     else
                         h[u] = mid;
@@ -1284,11 +1288,22 @@ gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, con
     return GTARS_OK;
 }
 
+// the fused routing kernel can serve this database: with the tile bounds in LDS (bnd_lds) or, for larger databases, in global
+// memory -- up to 65534 tiles (16-bit owner keys)
+static bool igd_fused_route_fits(const IgdView &v, const IgdTiles &tl, bool *bnd_lds) {
+    if (!tl.route_lut || getenv("GTARS_IGD_NO_FUSED_ROUTE") || tl.n_tiles + 1 > MS_MAX_BINS_2L) return false;
+    const size_t limit = 160 * 1024 - 64;
+    const bool with_bnd = igd_route_lds_bytes(tl.n_tiles, v.n_chrom, tl.route_n, true) <= limit && !getenv("GTARS_IGD_ROUTE_BND_GLOBAL");
+    if (bnd_lds) *bnd_lds = with_bnd;
+    return with_bnd || igd_route_lds_bytes(tl.n_tiles, v.n_chrom, tl.route_n, false) <= limit;
+}
 static bool igd_bucket_path(const IgdView &v, const IgdTiles &tl) {
-    // queries grouped by owner tile in one partition, when the tile bounds fit in LDS (76M records); otherwise
-    // (and for GTARS_IGD_FULL_SORT=1: tests / A-B runs) the batch is fully sorted by (chromosome, start) with the radix sort
+    // queries grouped by owner tile in one partition: through the fused routing kernel (up to 65534 tiles = 134M records), or
+    // through the two-kernel preparation when its tile bounds fit in LDS and the one-level counters can hold the tiles (75M
+    // records); otherwise (and for GTARS_IGD_FULL_SORT=1: tests / A-B runs) the batch is fully sorted by (chromosome, start)
     const size_t prep_lds = ((size_t)tl.n_tiles + v.n_chrom + 1) * 4;
-    return !getenv("GTARS_IGD_FULL_SORT") && tl.bnd && tl.n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024;
+    if (getenv("GTARS_IGD_FULL_SORT") || !tl.bnd) return false;
+    return igd_fused_route_fits(v, tl, nullptr) || (tl.n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024);
 }
 
 // several query sets in one sweep: only through the partition (the set of a query travels with its pair), at most 4 sets (two
@@ -1332,7 +1347,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     // chunk fits its 16-bit counters
     u32 rt_wg = multisplit_workgroups(nq);
     u32 rt_chunk = multisplit_chunk(nq);  // a multiple of the 4 queries a lane takes per step
-    const size_t rt_lds = igd_route_lds_bytes(n_tiles, v.n_chrom, tl.route_n);
+    bool bnd_lds = true;
+    const bool route_fits = igd_fused_route_fits(v, tl, &bnd_lds);
+    const size_t rt_lds = igd_route_lds_bytes(n_tiles, v.n_chrom, tl.route_n, bnd_lds);
     int dev = 0, cus = 256;
     GT_HIP(hipGetDevice(&dev));
     GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1345,7 +1362,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         rt_wg = std::max<u32>(rt_wg, (nq + 65531u) / 65532u);
         rt_chunk = ((nq + rt_wg - 1) / rt_wg + 3u) & ~3u;
     }
-    const bool fused = bucket && tl.route_lut && rt_lds <= 160 * 1024 - 64 && rt_chunk <= 65535u && !getenv("GTARS_IGD_NO_FUSED_ROUTE");
+    const bool fused = bucket && route_fits && rt_chunk <= 65535u;
+    if (bucket && !fused && !(n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024))
+        return fail(GTARS_ERR_INTERNAL, "IGD sweep: neither routing form fits this database");  // (cannot happen: see igd_bucket_path)
     static std::mutex attr_mu;
     {
         u32 *d_tot0 = fused ? multisplit_totals(scratch, n_tiles + 1, nq) : nullptr;
@@ -1360,8 +1379,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
             static bool done[64] = {};
             std::lock_guard<std::mutex> lock(attr_mu);
             if (dev >= 0 && dev < 64 && !done[dev]) {
-                GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_igd_route<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_igd_route<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                const void *fns[] = {reinterpret_cast<const void *>(k_igd_route<true, true>), reinterpret_cast<const void *>(k_igd_route<false, true>),
+                                     reinterpret_cast<const void *>(k_igd_route<true, false>), reinterpret_cast<const void *>(k_igd_route<false, false>)};
+                for (const void *fn : fns) GT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 done[dev] = true;
             }
         }
@@ -1374,7 +1394,8 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
                                v.n_chrom, d_unsorted, cq_off);
         }
         ProfScope p("k_igd_route", st);
-        hipLaunchKernelGGL(vec ? k_igd_route<true> : k_igd_route<false>, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom,
+        auto route = bnd_lds ? (vec ? k_igd_route<true, true> : k_igd_route<false, true>) : (vec ? k_igd_route<true, false> : k_igd_route<false, false>);
+        hipLaunchKernelGGL(route, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom,
                            tl.bnd, tl.chrom_tile_off, tl.route_base, tl.route_len, tl.route_lut, tl.route_n, tl.route_shift, n_tiles,
                            rt_chunk, reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted);
     } else {

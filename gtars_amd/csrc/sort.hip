@@ -188,10 +188,10 @@ __global__ void __launch_bounds__(MS_TPB)
 k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off, u32 shift, u32 *__restrict__ cur_a,
              u32 *__restrict__ cur_b, const u32 *__restrict__ run_if, HeavyBins heavy) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
-    // Every wave takes a contiguous run of S * 64 bins (S <= 36 for MS_MAX_BINS): S coalesced loads in flight together, S wave
+    // Every wave takes a contiguous run of S * 64 bins (S <= 64 for MS_MAX_BINS_2L + 1 bins): S coalesced loads in flight together, S wave
     // scans on the DPP path with a running carry, ONE barrier for the waves' totals (a round-per-1024-bins loop with two
     // barriers per round took 15 us for 24k bins).
-    constexpr u32 NW = MS_TPB / 64, MAXS = (MS_MAX_BINS + MS_TPB - 1) / MS_TPB;
+    constexpr u32 NW = MS_TPB / 64, MAXS = (MS_MAX_BINS_2L + 1 + MS_TPB - 1) / MS_TPB;
     __shared__ u32 s_wtot[NW];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 S = (n_bins + MS_TPB - 1) / MS_TPB, first = wave * S * 64u;
@@ -400,6 +400,7 @@ u32 multisplit_chunk(u32 n) {
 u32 *multisplit_table(void *ws) { return (u32 *)ws; }
 static bool multisplit_two_level(u32 n_bins, u32 n) {
     static const bool one_level = getenv("GTARS_MS_ONE_LEVEL") != nullptr;  // A/B
+    if (n_bins > MS_MAX_BINS) return true;  // beyond the one-level split's LDS counters (databases of 75M+ records)
     return n_bins > 1024 && n >= (1u << 20) && !one_level;
 }
 // where a table_ready caller of the two-level split leaves the bin TOTALS (zeroed by the caller, filled with atomics) instead of
@@ -415,7 +416,7 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
                                        u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
                                        const u32 *set_bounds, const HeavyBins *heavy) {
     const SetTags tags = set_bounds ? SetTags{set_bounds[0], set_bounds[1], set_bounds[2]} : SetTags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (n_bins == 0 || n_bins > MS_MAX_BINS) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
+    if (n_bins == 0 || n_bins > MS_MAX_BINS_2L + 1) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
     if (ws_bytes < multisplit_ws_bytes(n_bins, n)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
     const u32 n_wg = multisplit_workgroups(n);
     const u32 chunk = multisplit_chunk(n);
@@ -423,7 +424,7 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
     u32 *cur_a = tot + n_bins, *cur_b = cur_a + 1024;
     KeyT *tmp_key = (KeyT *)(((uintptr_t)(cur_b + n_bins) + 63) & ~(uintptr_t)63);
     uint2 *tmp_ab = reinterpret_cast<uint2 *>(reinterpret_cast<u32 *>(tmp_key) + (((size_t)n + 15) & ~(size_t)15));
-    const size_t lds = (size_t)n_bins * 4;
+    const size_t lds = (size_t)n_bins * 4;  // (one-level kernels only: n_bins <= MS_MAX_BINS there)
     constexpr size_t sp_lds = ((size_t)SP_TILE * 3 + (size_t)SP_BINS * 3) * 4;
     // the dynamic-LDS limits belong to the functions (per device); a failed attempt is retried by the next call
     static std::mutex mu;
@@ -441,6 +442,8 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
             done[dev & 15] = true;
         }
     }
+    if (n_bins > MS_MAX_BINS && !table_ready)
+        return fail(GTARS_ERR_INTERNAL, "multisplit: more bins than the counting kernel's LDS holds (the caller must count them itself)");
     if (!table_ready) {
         ProfScope p("k_ms_hist", st);
         hipLaunchKernelGGL(k_ms_hist<KeyT>, dim3(n_wg), dim3(MS_TPB), lds, st, key, n, n_bins, chunk, table, run_if);

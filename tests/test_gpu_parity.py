@@ -1365,3 +1365,30 @@ def test_igd_counts_on_databases_with_long_records(ga, monkeypatch, piece_bp):
     ok = (qs < 2**31) & (qe < 2**31)
     assert np.array_equal(g.count_overlaps_per_query(qc[ok][:2000], qs[ok][:2000], qe[ok][:2000], 1),
                           o.count_overlaps_per_query(qc[ok][:2000], qs[ok][:2000], qe[ok][:2000], 1))
+
+
+def test_igd_routing_with_tile_bounds_in_global_memory(ga, monkeypatch):
+    """Databases beyond ~52M records route their queries with the tile bounds in global memory instead of LDS (k_igd_route<.,
+    false>; up to 65534 tiles = 134M records), and beyond 36863 tiles the split is two-level whatever the batch size.  Forced
+    here on a small database (GTARS_IGD_ROUTE_BND_GLOBAL): same vectors as the oracle, shuffled and in order, one and three
+    query sets."""
+    rng = np.random.default_rng(4242)
+    n, F, span = 400_000, 17, 80_000_000
+    c = rng.integers(0, 3, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 1200, n)
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=3, n_files=F)
+    qc, qs, qe = _random_query_set(rng, 1_100_000, 3, span + 3_000, 600)
+    want_p = o.count_set_overlaps(qc, qs, qe, 1, n_files=F)
+    want_b = o.count_region_hits(qc, qs, qe, 1, n_files=F)
+    monkeypatch.setenv("GTARS_IGD_ROUTE_BND_GLOBAL", "1")
+    assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), want_p)
+    assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), want_b)
+    order = np.lexsort((qs, np.where((qs >= qe) | (qc == UNK) | (qe >= 2**31), 0xFFFFFFFF, qc)))
+    assert np.array_equal(g.count_set_overlaps(qc[order], qs[order], qe[order], 1), want_p)
+    cut = 700_000
+    sets = [(qc[:cut], qs[:cut], qe[:cut]), (qc[cut:], qs[cut:], qe[cut:])]
+    got = g.count_sets(sets, 1, True)
+    for k, (a, b, d) in enumerate(sets):
+        assert np.array_equal(got[k], o.count_region_hits(a, b, d, 1, n_files=F)), k
