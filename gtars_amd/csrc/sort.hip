@@ -184,6 +184,7 @@ __global__ void k_ms_colscan(u32 *__restrict__ table, u32 n_wg, u32 n_bins, u32 
 // bin_off[0 .. n_bins] = exclusive scan of tot (one workgroup); bins far heavier than the average are also listed in pieces
 // (HeavyBins, common.h: the consumer may hand the pieces of such a bin to several workgroups); for the two-level split (cur_a != null) also the cursors its
 // passes reserve runs from: cur_b[i] = bin_off[i], cur_a[j] = bin_off[j << shift] (was a launch of its own)
+template <u32 MAXS>  // bins per thread at most: 36 for the common sizes (<= MS_MAX_BINS), 64 up to MS_MAX_BINS_2L + 1
 __global__ void __launch_bounds__(MS_TPB)
 k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off, u32 shift, u32 *__restrict__ cur_a,
              u32 *__restrict__ cur_b, const u32 *__restrict__ run_if, HeavyBins heavy) {
@@ -191,7 +192,7 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off,
     // Every wave takes a contiguous run of S * 64 bins (S <= 64 for MS_MAX_BINS_2L + 1 bins): S coalesced loads in flight together, S wave
     // scans on the DPP path with a running carry, ONE barrier for the waves' totals (a round-per-1024-bins loop with two
     // barriers per round took 15 us for 24k bins).
-    constexpr u32 NW = MS_TPB / 64, MAXS = (MS_MAX_BINS_2L + 1 + MS_TPB - 1) / MS_TPB;
+    constexpr u32 NW = MS_TPB / 64;
     __shared__ u32 s_wtot[NW];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 S = (n_bins + MS_TPB - 1) / MS_TPB, first = wave * S * 64u;
@@ -204,6 +205,7 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off,
 #pragma unroll
     for (u32 k = 0; k < MAXS; ++k) {
         if (k < S) {  // (uniform)
+            heavy.note(first + k * 64u + lane, v[k]);  // (the bin's own total, while it is still in the register)
             const u32 inc = wave_inclusive_scan_u32(v[k], (int)lane);
             v[k] = carry + inc - v[k];  // exclusive, inside the wave's run
             carry += __builtin_amdgcn_readlane(inc, 63);
@@ -223,7 +225,6 @@ k_ms_binscan(const u32 *__restrict__ tot, u32 n_bins, u32 *__restrict__ bin_off,
         const u32 b = first + k * 64u + lane;
         if (k < S && b < n_bins) {
             const u32 o = base + v[k];
-            heavy.note(b, tot[b]);
             bin_off[b] = o;
             if (cur_a) {
                 cur_b[b] = o;
@@ -455,7 +456,9 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
             hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot, run_if);
         u32 shift = 0;
         while (((n_bins - 1) >> shift) >= 256u) ++shift;
-        hipLaunchKernelGGL(k_ms_binscan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off, shift, two_level ? cur_a : (u32 *)nullptr, cur_b,
+        constexpr u32 S_SMALL = (MS_MAX_BINS + MS_TPB - 1) / MS_TPB, S_LARGE = (MS_MAX_BINS_2L + 1 + MS_TPB - 1) / MS_TPB;
+        auto scan = n_bins <= MS_MAX_BINS ? k_ms_binscan<S_SMALL> : k_ms_binscan<S_LARGE>;
+        hipLaunchKernelGGL(scan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off, shift, two_level ? cur_a : (u32 *)nullptr, cur_b,
                            run_if, heavy ? *heavy : HeavyBins{});
     }
     if (two_level) {
