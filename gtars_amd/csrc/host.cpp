@@ -2344,13 +2344,11 @@ static gtars_status gtars_fragsplit_impl(const char *files_dir, const gtars_barc
     return GTARS_OK;
 }
 
-static gtars_status gtars_fragsplit_tokenize_impl(const gtars_tokenizer_t *t, const char *files_dir, const gtars_barcode_map_t *m,
-                                      gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
-    if (!t || !files_dir || !m || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
-    *out = nullptr;
-    std::vector<std::string> files;
-    gtars_status st = list_regular_files(files_dir, files);
-    if (st) return st;
+// the pipeline over an explicit list of files, visited in the order given (the directory form passes its regular files in byte
+// order of their names; a rank of the sharded driver passes its run of that list)
+static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const std::vector<std::string> &files, const gtars_barcode_map_t *m,
+                                            gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
+    gtars_status st = GTARS_OK;
     const size_t nc = m->labels.size();
     // per cluster: fragment columns in the order the cluster file would have them (files in order, lines in order),
     // chromosome ids of the TOKENIZER's dictionary, barcode ids in first-seen order
@@ -2436,10 +2434,37 @@ static gtars_status gtars_fragsplit_tokenize_impl(const gtars_tokenizer_t *t, co
     return GTARS_OK;
 }
 
+static gtars_status gtars_fragsplit_tokenize_impl(const gtars_tokenizer_t *t, const char *files_dir, const gtars_barcode_map_t *m,
+                                      gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
+    if (!t || !files_dir || !m || !out) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    std::vector<std::string> files;
+    gtars_status st = list_regular_files(files_dir, files);
+    if (st) return st;
+    return fragsplit_tokenize_core(t, files, m, out, n_reads);
+}
+
+static gtars_status gtars_fragsplit_tokenize_files_impl(const gtars_tokenizer_t *t, const char *const *paths, uint64_t n_paths,
+                                                        const gtars_barcode_map_t *m, gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
+    if (!t || !m || !out || (n_paths && !paths)) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    std::vector<std::string> files;
+    for (uint64_t i = 0; i < n_paths; ++i) {
+        if (!paths[i]) return fail(GTARS_ERR_INVALID_ARG, "NULL path");
+        files.emplace_back(paths[i]);
+    }
+    return fragsplit_tokenize_core(t, files, m, out, n_reads);
+}
+
 }  // extern "C"
 
 // ---- the C ABI never lets a C++ exception cross it (std::bad_alloc of a huge build, std::length_error ...)
 extern "C" {
+
+gtars_status gtars_fragsplit_tokenize_files(const gtars_tokenizer_t *t, const char *const *paths, uint64_t n_paths,
+                                            const gtars_barcode_map_t *m, gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
+    return gtars::guarded([&]() -> gtars_status { return gtars_fragsplit_tokenize_files_impl(t, paths, n_paths, m, out, n_reads); });
+}
 
 gtars_status gtars_regionset_from_bed(const char *path, gtars_regionset_t **out) {
     return gtars::guarded([&]() -> gtars_status { return gtars_regionset_from_bed_impl(path, out); });

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List, Optional, Set
+from typing import Dict, List, Optional, Sequence, Set
 
 import numpy as np
 
@@ -71,13 +71,7 @@ def pseudobulk_fragment_files(files: str, mapping: BarcodeToClusterMap, output: 
     return {"reads": int(n_reads.value), "written": int(n_written.value)}
 
 
-def fragsplit_tokenize(files: str, mapping: BarcodeToClusterMap, tokenizer, as_arrays: bool = False):
-    """The fragsplit -> tokenizer pipeline without the intermediate files: {cluster label: {barcode: [ids]}}, for every
-    cluster exactly what ``tokenize_fragment_file(output/cluster_<id>.bed.gz, tokenizer)`` would return.
-    ``as_arrays``: {cluster: (barcodes, offsets uint64[nb+1], ids uint32[...])} instead (no per-id Python objects)."""
-    out = C.POINTER(C.POINTER(_lib.FragmentTokens))()
-    n_reads = C.c_uint64()
-    _check(lib.gtars_fragsplit_tokenize(tokenizer._h, os.fspath(files).encode(), mapping._h, C.byref(out), C.byref(n_reads)))
+def _collect_cluster_results(out, mapping: BarcodeToClusterMap, as_arrays: bool):
     labels = mapping.cluster_labels()
     res = {}
     try:
@@ -97,3 +91,31 @@ def fragsplit_tokenize(files: str, mapping: BarcodeToClusterMap, tokenizer, as_a
             lib.gtars_fragment_tokens_free(out[c])
         lib.gtars_free(C.cast(out, C.c_void_p))
     return res
+
+
+def fragsplit_tokenize(files: str, mapping: BarcodeToClusterMap, tokenizer, as_arrays: bool = False):
+    """The fragsplit -> tokenizer pipeline without the intermediate files: {cluster label: {barcode: [ids]}}, for every
+    cluster exactly what ``tokenize_fragment_file(output/cluster_<id>.bed.gz, tokenizer)`` would return.
+    ``as_arrays``: {cluster: (barcodes, offsets uint64[nb+1], ids uint32[...])} instead (no per-id Python objects)."""
+    out = C.POINTER(C.POINTER(_lib.FragmentTokens))()
+    n_reads = C.c_uint64()
+    _check(lib.gtars_fragsplit_tokenize(tokenizer._h, os.fspath(files).encode(), mapping._h, C.byref(out), C.byref(n_reads)))
+    return _collect_cluster_results(out, mapping, as_arrays)
+
+
+def list_fragment_files(files: str) -> List[str]:
+    """The regular files of the folder ``files`` in byte order of their names: the order ``fragsplit_tokenize`` /
+    ``pseudobulk_fragment_files`` visit them in (the reference's read_dir order is unspecified, split.rs:41-55)."""
+    d = os.fspath(files)
+    names = sorted((n for n in os.listdir(d) if os.path.isfile(os.path.join(d, n))), key=os.fsencode)
+    return [os.path.join(d, n) for n in names]
+
+
+def fragsplit_tokenize_files(paths: Sequence[str], mapping: BarcodeToClusterMap, tokenizer, as_arrays: bool = False):
+    """``fragsplit_tokenize`` over an explicit list of fragment files, visited in the order given (one rank's run of the
+    folder's sorted list: ``sharding.fragsplit_tokenize_sharded``)."""
+    out = C.POINTER(C.POINTER(_lib.FragmentTokens))()
+    n_reads = C.c_uint64()
+    arr = (C.c_char_p * max(len(paths), 1))(*[os.fspath(p).encode() for p in paths])
+    _check(lib.gtars_fragsplit_tokenize_files(tokenizer._h, arr, len(paths), mapping._h, C.byref(out), C.byref(n_reads)))
+    return _collect_cluster_results(out, mapping, as_arrays)

@@ -93,13 +93,34 @@ def all_reduce_hits_(hits, group=None):
     return hits
 
 
-def all_gather_csr_device(offsets, ids, n_hits: int, group=None):
+class CsrGatherPlan:
+    """Per-rank sizes of a CSR all-gather and the index tensors that strip the padding: returned by ``all_gather_csr_device``
+    and accepted back by it, so that a caller that gathers batches of the SAME per-rank shape again (every rank must pass the
+    plan, or none: the size exchange is a collective) skips the size exchange and its host round trip."""
+
+    def __init__(self, nqs, nhs, dev):
+        import torch
+
+        self.nqs, self.nhs = list(nqs), list(nhs)
+
+        def strip(lens):
+            pad = max(max(lens), 1)
+            idx = [torch.arange(r * pad, r * pad + n, dtype=torch.int64) for r, n in enumerate(lens)]
+            return pad, torch.cat(idx).to(dev) if idx else torch.zeros(0, dtype=torch.int64, device=dev)
+
+        self.pad_q, self.sel_q = strip(self.nqs)
+        self.pad_h, self.sel_h = strip(self.nhs)
+
+
+def all_gather_csr_device(offsets, ids, n_hits: int, group=None, plan: Optional[CsrGatherPlan] = None, return_plan: bool = False):
     """C2: the global CSR from per-rank CSRs of consecutive query ranges, on the device.
 
     offsets: int64[nq_r + 1] (the u64 offsets of the C ABI), ids: int32[>= n_hits] (u32 token ids, bit-identical).
-    Returns (global offsets int64[sum nq_r + 1], global ids int32[sum H_r]).  Wire format: one all-gather of
-    (nq_r, H_r), one of the per-query counts as int32, one of the ids as int32 -- all-gatherv emulated by padding to
-    the largest rank (ranks are balanced to +-1 query, ids to a few per cent)."""
+    Returns (global offsets int64[sum nq_r + 1], global ids int32[sum H_r]) (+ the plan with ``return_plan``).  Wire format:
+    one all-gather of (nq_r, H_r) -- skipped when a ``plan`` from an earlier call with the same per-rank shapes is passed --,
+    one of the per-query counts as int32, one of the ids as int32: all-gatherv emulated by padding to the largest rank (ranks
+    are balanced to +-1 query, ids to a few per cent); the padding is stripped by ONE index_select per payload (the plan's
+    index tensors), not by a Python loop over ranks."""
     import torch
     import torch.distributed as dist
 
@@ -108,28 +129,29 @@ def all_gather_csr_device(offsets, ids, n_hits: int, group=None):
     dev = offsets.device
     cdev = torch.device("cpu") if stage else dev
     nq = offsets.numel() - 1
-    meta = torch.tensor([nq, n_hits], dtype=torch.int64, device=cdev)
-    metas = torch.empty(2 * world, dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(metas, meta, group=group)
-    metas = metas.cpu().view(world, 2)
-    nqs, nhs = [int(x) for x in metas[:, 0]], [int(x) for x in metas[:, 1]]
+    if plan is None:
+        meta = torch.tensor([nq, n_hits], dtype=torch.int64, device=cdev)
+        metas = torch.empty(2 * world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(metas, meta, group=group)
+        metas = metas.cpu().view(world, 2)  # (the one host round trip: sizes of the result buffers)
+        plan = CsrGatherPlan([int(x) for x in metas[:, 0]], [int(x) for x in metas[:, 1]], cdev)
+    elif len(plan.nqs) != world:
+        raise ValueError("all_gather_csr_device: the plan was made for another world size")
 
-    def gatherv(x, lens):
-        pad = max(max(lens), 1)
+    def gatherv(x, pad, sel):
         buf = torch.zeros(pad, dtype=torch.int32, device=cdev)
         buf[: x.numel()] = x.to(cdev)
         out = torch.empty(pad * world, dtype=torch.int32, device=cdev)
         dist.all_gather_into_tensor(out, buf, group=group)
-        out = out.view(world, pad)
-        return torch.cat([out[r, : lens[r]] for r in range(world)]).to(dev)
+        return out.index_select(0, sel).to(dev)
 
     counts = (offsets[1:] - offsets[:-1]).to(torch.int32)  # hits per query < 2^32
-    g_counts = gatherv(counts, nqs)
-    g_ids = gatherv(ids[:n_hits], nhs)
-    g_off = torch.zeros(sum(nqs) + 1, dtype=torch.int64, device=dev)
+    g_counts = gatherv(counts, plan.pad_q, plan.sel_q)
+    g_ids = gatherv(ids[:n_hits], plan.pad_h, plan.sel_h)
+    g_off = torch.zeros(sum(plan.nqs) + 1, dtype=torch.int64, device=dev)
     # counts are u32 carried in int32: widen through the unsigned value before summing
     torch.cumsum(g_counts.to(torch.int64) & 0xFFFFFFFF, dim=0, out=g_off[1:])
-    return g_off, g_ids
+    return (g_off, g_ids, plan) if return_plan else (g_off, g_ids)
 
 
 # --------------------------------------------------------------------------- the product engine
@@ -233,6 +255,14 @@ def _rank_world(group=None) -> Tuple[int, int]:
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _in_process_group() -> bool:
+    """a process group exists (even of one rank): the drivers then run their collectives -- a world-size-1 RCCL group on one
+    GPU executes exactly the device-tensor branch the 8-GPU job takes"""
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
 class ShardedIgd:
     """An IGD database spread over the ranks of a process group.
 
@@ -250,6 +280,7 @@ class ShardedIgd:
         self.engine, self.mode, self.group = engine, mode, group
         self.n_chrom, self.n_files = n_chrom, n_files
         self.rank, self.world = _rank_world(group)
+        self.collective = _in_process_group()
         self.owner: Optional[np.ndarray] = None
         cols = ("chrom", "start", "end", "file")
         bucket = mode == "bucket" and self.world > 1
@@ -300,7 +331,7 @@ class ShardedIgd:
         """[len(sets), F] support / hit vectors of the uploaded sets -- one pass over the local database for up to four sets --
         and ONE all-reduce of the whole block"""
         hits = self.engine.igd_count_sets_resident(self.g, handle, min_overlap, binary, hits, sync=False)
-        if self.world > 1:
+        if self.collective:
             all_reduce_hits_(hits, self.group)
         return hits
 
@@ -317,14 +348,14 @@ class ShardedIgd:
     def count_resident(self, handle, min_overlap: int = 1, binary: bool = False, hits=None):
         """count + all-reduce on queries uploaded with ``upload_local``; nothing but the F-long vector leaves the device"""
         hits = self.engine.igd_count_resident(self.g, handle, min_overlap, binary, hits, sync=False)
-        if self.world > 1:
+        if self.collective:
             all_reduce_hits_(hits, self.group)
         return hits
 
     def count(self, q, min_overlap: int = 1, binary: bool = False):
         """global per-file hit vector (int64 tensor on the engine's device), identical on every rank"""
         hits = self.count_local(q, min_overlap, binary)
-        if self.world > 1:
+        if self.collective:
             all_reduce_hits_(hits, self.group)
         return hits
 
@@ -338,7 +369,7 @@ def lola_counts_sharded(sdb: ShardedIgd, user_sets: Sequence[Dict[str, np.ndarra
     import torch
 
     stacked = sdb.count_sets_local([universe] + list(user_sets), min_overlap, True)
-    if sdb.world > 1:
+    if sdb.collective:
         all_reduce_hits_(stacked, sdb.group)
     return stacked[1:], stacked[0]
 
@@ -360,6 +391,88 @@ def tokenize_sharded(engine, ix, q: Dict[str, np.ndarray], gather: bool = True, 
     rank, world = _rank_world(group)
     lo, hi = shard_range(len(q["chrom"]), rank, world)
     offsets, ids = engine.tokenize(ix, q["chrom"][lo:hi], q["start"][lo:hi], q["end"][lo:hi])
-    if world > 1 and gather:
+    if _in_process_group() and gather:
         return all_gather_csr_device(offsets, ids, int(ids.numel()), group)
     return offsets, ids
+
+
+# --------------------------------------------------------------------------- fragment pipeline (BASELINE config 5)
+
+def file_runs(sizes: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Cut a list of files (given by their sizes, in visiting order) into ``world`` CONTIGUOUS runs of about equal total size:
+    run r = [lo, hi).  Contiguous, not round-robin: the per-cluster results of consecutive runs then merge by plain
+    concatenation per barcode (the pipeline's result depends on the file order only through the order of a barcode's ids).
+    Deterministic, so every rank computes the same cut from the same directory listing."""
+    n = len(sizes)
+    tot = float(sum(max(int(x), 1) for x in sizes))
+    cuts, acc, r = [0], 0.0, 1
+    for i, x in enumerate(sizes):
+        acc += max(int(x), 1)
+        while r < world and acc >= tot * r / world:
+            cuts.append(i + 1)
+            r += 1
+    while len(cuts) < world + 1:
+        cuts.append(n)
+    cuts[world] = n
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def merge_cluster_results(parts: Sequence[Dict[str, tuple]]) -> Dict[str, tuple]:
+    """Per-cluster ``(barcodes, offsets, ids)`` results of CONSECUTIVE file runs -> the result of the whole list: a barcode's
+    ids are the concatenation of its ids in run order (a cluster file holds the routed lines of the files in order, and
+    tokenize_fragment_file appends per barcode, utils/fragments.rs:61-82), barcodes in first-seen order."""
+    out = {}
+    labels = list(parts[0].keys()) if parts else []
+    for label in labels:
+        index: Dict[str, int] = {}
+        chunks: List[List[np.ndarray]] = []
+        for part in parts:
+            names, offs, ids = part[label]
+            for b, name in enumerate(names):
+                k = index.get(name)
+                if k is None:
+                    k = index[name] = len(chunks)
+                    chunks.append([])
+                chunks[k].append(ids[int(offs[b]):int(offs[b + 1])])
+        offs = np.zeros(len(chunks) + 1, dtype=np.uint64)
+        if chunks:
+            offs[1:] = np.cumsum([sum(len(c) for c in ch) for ch in chunks])
+        flat = [c for ch in chunks for c in ch]
+        ids = np.concatenate(flat).astype(np.uint32, copy=False) if flat else np.zeros(0, dtype=np.uint32)
+        out[label] = (list(index.keys()), offs, ids)
+    return out
+
+
+def fragsplit_tokenize_sharded(files_dir: str, mapping, tokenizer, gather: bool = True, group=None, run=None):
+    """The fragsplit -> tokenizer pipeline (gtars-fragsplit/src/split.rs:36-151 feeding utils/fragments.rs:61-82) over the
+    ranks of a process group: files are independent, so the folder's sorted file list is cut into ``world``
+    contiguous runs balanced by file size, every rank runs the fused pipeline on its run (its own host decompress threads,
+    its own GPU), and nothing crosses ranks on the data path.
+
+    ``gather=True``: the per-cluster ``{label: (barcodes, offsets, ids)}`` of the WHOLE folder on every rank (one
+    all_gather_object of the per-rank results, merged per barcode in run order) -- identical to the single-process
+    ``fragsplit.fragsplit_tokenize(files_dir, mapping, tokenizer, as_arrays=True)``.  ``gather=False``: this rank's results
+    only, plus a manifest ``{"rank", "world", "files": [lo, hi), "paths"}`` under the key ``"__manifest__"`` -- what a
+    per-rank consumer (one output shard per GPU) wants at the config's 1e9 fragments.
+
+    ``run(paths, mapping, tokenizer)`` is the per-rank pipeline (default: the product's ``fragsplit_tokenize_files``)."""
+    import os
+
+    from . import fragsplit
+
+    rank, world = _rank_world(group)
+    paths = fragsplit.list_fragment_files(files_dir)
+    lo, hi = file_runs([os.path.getsize(p) for p in paths], world)[rank]
+    if run is None:
+        run = lambda ps, m, t: fragsplit.fragsplit_tokenize_files(ps, m, t, as_arrays=True)
+    local = run(paths[lo:hi], mapping, tokenizer)
+    if _in_process_group() and gather:
+        import torch.distributed as dist
+
+        parts = [None] * world
+        dist.all_gather_object(parts, local, group=group)
+        return merge_cluster_results(parts)
+    if not gather:
+        local = dict(local)
+        local["__manifest__"] = {"rank": rank, "world": world, "files": [lo, hi], "paths": paths[lo:hi]}
+    return local

@@ -193,6 +193,11 @@ gtars_status gtars_fragsplit(const char *files_dir, const gtars_barcode_map_t *m
 /* *out: array of n_clusters results (gtars_fragment_tokens_free each, gtars_free the array) */
 gtars_status gtars_fragsplit_tokenize(const gtars_tokenizer_t *t, const char *files_dir, const gtars_barcode_map_t *m,
                                       gtars_fragment_tokens_t ***out, uint64_t *n_reads);
+/* the same pipeline over an explicit list of fragment files, visited in the order given: what one rank of the multi-GPU
+ * driver runs on its run of the directory's sorted file list (files are independent; the per-cluster results
+ * of consecutive runs merge by concatenation per barcode, gtars_amd/sharding.py fragsplit_tokenize_sharded) */
+gtars_status gtars_fragsplit_tokenize_files(const gtars_tokenizer_t *t, const char *const *paths, uint64_t n_paths,
+                                            const gtars_barcode_map_t *m, gtars_fragment_tokens_t ***out, uint64_t *n_reads);
 
 /* ------------------------------------------------------------------------
  * .gtok  (gtars-io/src/gtok.rs:125-210, consts.rs:1-3)

@@ -530,6 +530,138 @@ def test_two_ranks_share_one_gpu_sharded_drivers():
     assert res[0]["bucket_db_is_cut"]
 
 
+def _rccl_world1_rank(port, q):
+    """ONE rank, backend nccl (= RCCL): the drivers' collectives run on device tensors, no host staging."""
+    import os
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from gtars_amd import sharding, synth
+    from test_sharding_gloo import sharded_checks
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        out = {"backend_is_nccl": dist.get_backend() == "nccl"}
+        eng = sharding.HipEngine(dev)
+        # the direct calls the verdict names, against the unsharded vectors
+        F = 41
+        db = synth.make_igd_db(150_000, F)
+        bq = synth.make_background_queries(120_000)
+        whole = eng.igd(db["chrom"], db["start"], db["end"], db["file"], synth.N_CHROM, F)
+        sdb = sharding.ShardedIgd(eng, db, synth.N_CHROM, F, mode="bucket", balance_with=[bq["chrom"]])
+        out["collective_enabled_at_world_1"] = bool(sdb.collective and sdb.world == 1)
+        h = sdb.upload_local(bq)
+        for binary in (False, True):
+            exp = eng.igd_count(whole, bq["chrom"], bq["start"], bq["end"], 1, binary)
+            got = sdb.count_resident(h, 1, binary)  # count + dist.all_reduce(hits) on the device tensor
+            torch.cuda.synchronize()
+            out[f"count_resident_{'binary' if binary else 'pairwise'}"] = bool(got.is_cuda and torch.equal(got, exp))
+        uni = synth.make_universe(60_000, seed=3)
+        sel = np.sort(np.random.default_rng(2).choice(len(uni["chrom"]), 9_000, replace=False))
+        user = {k: uni[k][sel] for k in ("chrom", "start", "end")}
+        hs = sdb.upload_local_sets([uni, user])
+        got = sdb.count_sets_resident(hs, 1, True)
+        torch.cuda.synchronize()
+        exp = torch.stack([eng.igd_count(whole, x["chrom"], x["start"], x["end"], 1, True) for x in (uni, user)])
+        out["count_sets_resident"] = bool(got.is_cuda and torch.equal(got, exp))
+        u = synth.make_universe(5_000)
+        tq = synth.make_queries(u, 50_001)
+        ix = eng.index(u["chrom"], u["start"], u["end"], synth.N_CHROM)
+        off, ids = eng.tokenize(ix, tq["chrom"], tq["start"], tq["end"])
+        g_off, g_ids, plan = sharding.all_gather_csr_device(off, ids, int(ids.numel()), return_plan=True)
+        g2_off, g2_ids = sharding.all_gather_csr_device(off, ids, int(ids.numel()), plan=plan)
+        torch.cuda.synchronize()
+        out["all_gather_csr_device"] = bool(g_off.is_cuda and torch.equal(g_off, off) and torch.equal(g_ids, ids)
+                                            and torch.equal(g2_off, off) and torch.equal(g2_ids, ids))
+        # and the whole driver checklist of the gloo tests under RCCL
+        out.update({"drivers_" + k: v for k, v in sharded_checks(eng, 0, 1).items()})
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_executes_the_device_collectives():
+    """The RCCL branch of the collectives (all_reduce of the per-file vector(s), all_gather_into_tensor of the CSR) on DEVICE
+    tensors: a world-size-1 `nccl` process group on the one GPU of the test box initialises an RCCL communicator and runs the
+    same calls an 8-GPU job makes (what is reduced: gtars-lola/src/enrichment.rs:198-221).  Results == the unsharded ones."""
+    import sys
+
+    import torch.multiprocessing as mp
+
+    from test_sharding_gloo import _free_port
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_rank, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert res and all(res.values()), res
+    assert "drivers_tokenize_gather_plan_reuse" in res and "count_sets_resident" in res
+
+
+def _hip_fragment_rank(rank, world, port, q, ub, fd, mp_path):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from gtars_amd import fragsplit
+    from gtars_amd.fragsplit import BarcodeToClusterMap
+    from gtars_amd.tokenizers import Tokenizer
+    from test_sharding_gloo import fragment_pipeline_checks, oracle_fragment_pipeline, same_cluster_results
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tok, m = Tokenizer.from_bed(ub), BarcodeToClusterMap.from_file(mp_path)
+        expected = fragsplit.fragsplit_tokenize(fd, m, tok, as_arrays=True)  # the single-process product result ...
+        out = fragment_pipeline_checks(fd, m, tok, None, expected, world)
+        if rank == 0:  # ... which is the oracle's
+            out["single_process_equals_oracle"] = same_cluster_results(
+                expected, oracle_fragment_pipeline(fragsplit.list_fragment_files(fd), oracle.OracleBarcodeMap(mp_path), oracle.OracleTokenizer(ub)))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_fragment_pipeline(tmp_path):
+    """BASELINE config 5's multi-GPU split on the product path: two ranks (gloo, sharing this GPU) each run the
+    fused fragsplit -> tokenizer pipeline on their run of the sorted file list; gathered and rank-local + merged results == the
+    single-process pipeline == the oracle (split.rs:36-151, utils/fragments.rs:61-82)."""
+    import sys
+
+    import torch.multiprocessing as mp
+
+    from test_sharding_gloo import _free_port, write_fragment_inputs
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    ub, fd, mpth = write_fragment_inputs(tmp_path, files=13, frags=1500, clusters=5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_fragment_rank, args=(r, 2, port, q, ub, fd, mpth)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [0, 1]
+    for rank, checks in res.items():
+        assert checks and all(checks.values()), (rank, checks)
+    assert res[0]["single_process_equals_oracle"]
+
+
 def test_bench_tools_run_with_two_ranks_on_one_gpu():
     """tools/igd_bench.py and tools/lola_bench.py --gpus 2 under torch.distributed.run (gloo: both ranks on this GPU) give the
     same totals as their single-GPU runs (small sizes)."""

@@ -104,6 +104,15 @@ def sharded_checks(engine, rank, world):
     exp_off, exp_ids = engine.tokenize(ix, q["chrom"], q["start"], q["end"])
     g_off, g_ids = sharding.tokenize_sharded(engine, ix, q, gather=True)
     out["tokenize_gather"] = bool(torch.equal(g_off.cpu(), exp_off.cpu()) and torch.equal(g_ids.cpu(), exp_ids.cpu()))
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        # a second gather of the same shapes through the first one's plan: no size exchange, same CSR
+        l_off, l_ids = sharding.tokenize_sharded(engine, ix, q, gather=False)
+        a_off, a_ids, plan = sharding.all_gather_csr_device(l_off, l_ids, int(l_ids.numel()), return_plan=True)
+        b_off, b_ids = sharding.all_gather_csr_device(l_off, l_ids, int(l_ids.numel()), plan=plan)
+        out["tokenize_gather_plan_reuse"] = bool(torch.equal(a_off.cpu(), exp_off.cpu()) and torch.equal(b_off.cpu(), exp_off.cpu())
+                                                 and torch.equal(a_ids.cpu(), exp_ids.cpu()) and torch.equal(b_ids.cpu(), exp_ids.cpu()))
     return out
 
 
@@ -170,3 +179,126 @@ def test_two_rank_gloo_matches_single_process():
 def test_single_process_drivers_need_no_process_group():
     checks = sharded_checks(OracleEngine(), 0, 1)
     assert all(checks.values()), checks
+
+
+# ------------------------------------------------------------ the fragment pipeline over ranks (BASELINE config 5)
+
+
+def oracle_fragment_pipeline(paths, om, otok):
+    """CPU stand-in for fragsplit.fragsplit_tokenize_files (test infrastructure): oracle.fragsplit over the files in the order
+    given, then tokenize_fragment_file's rules (utils/fragments.rs:61-82) on every cluster's routed lines ->
+    {label: (barcodes in first-seen order, offsets, ids)}, labels in byte order like the product."""
+    import oracle
+
+    d = os.path.dirname(paths[0]) if paths else "."
+    routed = oracle.fragsplit(d, om, file_order=[os.path.basename(p) for p in paths])
+    out = {}
+    for label in sorted(om.cluster_labels, key=lambda x: x.encode()):
+        per = {}
+        for line in routed[label]:
+            if line.startswith("#"):
+                continue
+            parts = line.split()
+            per.setdefault(parts[3], []).extend(otok.encode_regions([(parts[0], int(parts[1]), int(parts[2]))]))
+        offs = np.zeros(len(per) + 1, dtype=np.uint64)
+        if per:
+            offs[1:] = np.cumsum([len(v) for v in per.values()])
+        ids = np.array([x for v in per.values() for x in v], dtype=np.uint32)
+        out[label] = (list(per), offs, ids)
+    return out
+
+
+def same_cluster_results(a, b):
+    if list(a) != list(b):
+        return False
+    for k in a:
+        if list(a[k][0]) != list(b[k][0]) or not np.array_equal(np.asarray(a[k][1], dtype=np.uint64), np.asarray(b[k][1], dtype=np.uint64)):
+            return False
+        if not np.array_equal(np.asarray(a[k][2], dtype=np.uint32), np.asarray(b[k][2], dtype=np.uint32)):
+            return False
+    return True
+
+
+def write_fragment_inputs(tmp, files=11, frags=400, clusters=5):
+    from gtars_amd import synth
+
+    u = synth.make_universe(3_000)
+    return synth.write_config5_inputs(str(tmp), u, files, frags, clusters)[:3]
+
+
+def fragment_pipeline_checks(files_dir, mapping, tokenizer, run, expected, world):
+    """gathered == the single-process result on every rank; rank-local results + manifests tile the file list and merge to
+    the same thing"""
+    import torch.distributed as dist
+
+    from gtars_amd import sharding
+
+    out = {}
+    got = sharding.fragsplit_tokenize_sharded(files_dir, mapping, tokenizer, gather=True, run=run)
+    out["fragments_gathered"] = same_cluster_results(got, expected)
+    local = sharding.fragsplit_tokenize_sharded(files_dir, mapping, tokenizer, gather=False, run=run)
+    man = local.pop("__manifest__")
+    parts = [None] * world
+    if world > 1:
+        dist.all_gather_object(parts, (man["files"], local))
+    else:
+        parts = [(man["files"], local)]
+    runs = [p[0] for p in parts]
+    out["fragments_runs_tile_the_files"] = bool(runs[0][0] == 0 and all(a[1] == b[0] for a, b in zip(runs, runs[1:]))
+                                                and runs[-1][1] == len(os.listdir(files_dir)))
+    out["fragments_every_rank_has_files"] = all(r[1] > r[0] for r in runs)
+    out["fragments_local_merge"] = same_cluster_results(sharding.merge_cluster_results([p[1] for p in parts]), expected)
+    return out
+
+
+def _fragment_worker(rank, world, port, q, ub, fd, mp):
+    import torch.distributed as dist
+
+    import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        om, otok = oracle.OracleBarcodeMap(mp), oracle.OracleTokenizer(ub)
+        from gtars_amd import fragsplit
+
+        expected = oracle_fragment_pipeline(fragsplit.list_fragment_files(fd), om, otok)
+        q.put((rank, fragment_pipeline_checks(fd, om, otok, oracle_fragment_pipeline, expected, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_fragment_pipeline(tmp_path):
+    """config 5's file-parallel split on two gloo ranks (CPU stand-in pipeline = the oracle): contiguous runs of the sorted file
+    list, per-rank results merged per barcode in run order == the single-process result (barcodes recur across files)."""
+    import torch.multiprocessing as mp
+
+    ub, fd, mpth = write_fragment_inputs(tmp_path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fragment_worker, args=(r, 2, port, q, ub, fd, mpth)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [0, 1]
+    for rank, checks in res.items():
+        assert checks and all(checks.values()), (rank, checks)
+
+
+def test_file_runs_and_merge():
+    from gtars_amd.sharding import file_runs, merge_cluster_results
+
+    for sizes in ([5] * 7, [100, 1, 1, 1], [1, 1], [], [3] * 10, [0, 0, 9, 0]):
+        for w in (1, 2, 3, 4, 8):
+            r = file_runs(sizes, w)
+            assert len(r) == w and r[0][0] == 0 and r[-1][1] == len(sizes)
+            assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(r, r[1:] + [(len(sizes), len(sizes))]))
+    assert file_runs([5] * 8, 4) == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    a = {"k": (["x", "y"], np.array([0, 2, 3], dtype=np.uint64), np.array([1, 2, 3], dtype=np.uint32))}
+    b = {"k": (["y", "z"], np.array([0, 1, 1], dtype=np.uint64), np.array([9], dtype=np.uint32))}
+    m = merge_cluster_results([a, b])["k"]
+    assert m[0] == ["x", "y", "z"] and m[1].tolist() == [0, 2, 4, 4] and m[2].tolist() == [1, 2, 3, 9]
