@@ -295,7 +295,19 @@ struct IgdTiles {
     u32 route_n, route_shift;
     u32 n_tiles;
 };
-constexpr u32 IGD_TILE_TAB_WORDS = 528;
+// words per tile: a 12-word descriptor + the two direct-mapped search tables (u16 entries, buckets + 2 of them): over the
+// staged starts (exact searches start from it) and over the prefix-max ends (its lower bracket IS the first candidate: the
+// sweep never reads the prefix maxima themselves, so this table is the finer one)
+#ifndef IGD_LUT_P_BUCKETS
+#define IGD_LUT_P_BUCKETS 1024
+#endif
+#ifndef IGD_LUT_S_BUCKETS
+#define IGD_LUT_S_BUCKETS 1024
+#endif
+constexpr u32 IGD_LUT_S_NB = IGD_LUT_S_BUCKETS, IGD_LUT_P_NB = IGD_LUT_P_BUCKETS;
+static_assert((IGD_LUT_S_NB & (IGD_LUT_S_NB - 1)) == 0 && IGD_LUT_S_NB >= 256 && IGD_LUT_S_NB <= 4096, "a power of two");
+static_assert((IGD_LUT_P_NB & (IGD_LUT_P_NB - 1)) == 0 && IGD_LUT_P_NB >= 256 && IGD_LUT_P_NB <= 4096, "a power of two");
+constexpr u32 IGD_TILE_TAB_WORDS = (12 + (IGD_LUT_S_NB + 2) / 2 + (IGD_LUT_P_NB + 2) / 2 + 3) / 4 * 4;  // 1040: 4 KB per 2048 records
 gtars_status launch_igd_tile_tables(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
                                     const i32 *tile_carry, u32 n_tiles, i32 *pm, unsigned short *files16, u32 *tile_tab, hipStream_t st);
 bool igd_sweep_supported(const IgdView &v, u64 nq);

@@ -19,6 +19,7 @@
 // Bound: HBM.  Algorithmic bytes 12*Nq + 16*Ndb + 8*F; no MFMA (integer compare/scan).
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #include "scan.h"
@@ -49,13 +50,16 @@ __device__ unsigned long long g_route_stamps[8];
     do {         \
     } while (0)
 #endif
-constexpr int LUT_NB = 512;  // buckets of the per-tile search tables
-// smallest shift with (span >> shift) < LUT_NB
+constexpr int LUT_NB_S = (int)IGD_LUT_S_NB, LUT_NB_P = (int)IGD_LUT_P_NB;  // buckets of the per-tile search tables
+// smallest shift with (span >> shift) < NB (NB a power of two)
+template <int NB>
 __device__ __forceinline__ u32 lut_shift(u32 span) {
+    constexpr int K = 31 - __builtin_clz((unsigned)NB);
     const int bits = 32 - __clz((int)(span | 1u));  // significant bits of span
-    return bits > 9 ? (u32)(bits - 9) : 0u;
+    return bits > K ? (u32)(bits - K) : 0u;
 }
-// first index i in [0, n) with key[i] >= x, through the table: the answer lies in [lut[b], lut[b + 1]] for b = bucket(x)
+// first index i in [0, n) with key[i] >= x, through the table: the answer lies in [lut[b], lut[b + 1]] for b = bucket(x) -- the
+// two entries come by ONE 4-byte LDS read (2-byte aligned: gfx950 allows unaligned DS access)
 __device__ __forceinline__ void lut_range(const unsigned short *lut, i32 x, i32 k0, i32 k1, u32 sh, u32 n, u32 &l, u32 &h) {
     if (x <= k0) {
         l = h = 0;
@@ -63,19 +67,22 @@ __device__ __forceinline__ void lut_range(const unsigned short *lut, i32 x, i32 
         l = h = n;
     } else {
         const u32 b = (u32)(x - k0) >> sh;
-        l = lut[b];
-        h = lut[b + 1];
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        typedef us2 us2_a2 __attribute__((aligned(2)));
+        typedef const __attribute__((address_space(3))) us2_a2 *lds_us2;
+        const us2 p = *(lds_us2)(uintptr_t)(lut + b);
+        l = p.x;
+        h = p.y;
     }
 }
-#ifndef IGD_PAIR_UNROLL
-#define IGD_PAIR_UNROLL 1  // queries of a lane group whose candidate reads are in flight together
-#endif
-#ifndef IGD_PREFETCH
-#define IGD_PREFETCH 1  // next tile's records loaded into registers before the current tile's queries are served
-#endif
-#ifndef IGD_GROUP_LANES
-#define IGD_GROUP_LANES 4  // lanes that walk one query's candidate records together (pair loop of the sweep; 4 / 8 / 16: 0.263 / 0.278 / 0.318 ms)
-#endif
+// lanes that walk one query's candidate records together (pair loop of the sweep; measured 4 / 8 / 16: 0.263 / 0.278 / 0.318 ms):
+// a QUAD, so that a query's state reaches its group through DPP quad_perm moves (VALU) instead of ds_bpermute (the LDS pipe,
+// which is what the sweep is bound by)
+constexpr int IGD_GROUP_LANES = 4;
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v) {  // every lane of a quad receives the value of the quad's lane K
+    return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, true);
+}
 constexpr int IGD_SEEN = 32;   // per-thread list of credited files (binary counting)  // records after the tile kept in LDS too (a query's scan may run past its tile)
 
 // ---- query preparation: validity rules of Igd::count_overlaps (igd.rs:514-517) ------------------
@@ -535,8 +542,9 @@ __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first,
 // In round 2 the sweep scanned the prefix maximum in LDS for every tile of every call (2.4k cycles per tile by the in-kernel
 // stamps) and searched without tables (the searches were 0.19 of the sweep's 0.41 ms).
 constexpr int TAB_DESC = 12;  // p0, cnt, chrom, n_lds, S0, S1, shift_s, P0, P1, shift_p, n_seg, -
-constexpr int TAB_LUT_WORDS = (LUT_NB + 2) / 2;
-constexpr int TAB_WORDS = (TAB_DESC + 2 * TAB_LUT_WORDS + 3) / 4 * 4;
+constexpr int TAB_LUT_S_WORDS = (LUT_NB_S + 2) / 2, TAB_LUT_P_WORDS = (LUT_NB_P + 2) / 2;
+constexpr int TAB_LUT_WORDS = TAB_LUT_S_WORDS + TAB_LUT_P_WORDS;
+constexpr int TAB_WORDS = (TAB_DESC + TAB_LUT_WORDS + 3) / 4 * 4;
 static_assert(TAB_WORDS == (int)IGD_TILE_TAB_WORDS, "common.h states the table size");
 
 __global__ void __launch_bounds__(SW_TPB)
@@ -546,7 +554,7 @@ k_igd_tile_tables(IgdView v, const u32 *__restrict__ tile_first, const u32 *__re
     constexpr int CAP = IGD_TILE + IGD_HALO;
     constexpr int RPT = (CAP + SW_TPB - 1) / SW_TPB;
     __shared__ i32 t_s[CAP], t_e[CAP], t_pm[CAP];
-    __shared__ unsigned short lut_s[LUT_NB + 2], lut_p[LUT_NB + 2];
+    __shared__ unsigned short lut_s[LUT_NB_S + 2], lut_p[LUT_NB_P + 2];
     __shared__ i32 s_wmax[SW_TPB / 64];
     const u32 t = blockIdx.x;
     if (t >= n_tiles) return;
@@ -594,14 +602,14 @@ k_igd_tile_tables(IgdView v, const u32 *__restrict__ tile_first, const u32 *__re
         }
     }
     const i32 S0 = t_s[0], S1 = t_s[n - 1], P0 = max(carry, t_e[0]), P1 = all_max;
-    const u32 sh_s = lut_shift((u32)(S1 - S0)), sh_p = lut_shift((u32)(P1 - P0));
+    const u32 sh_s = lut_shift<LUT_NB_S>((u32)(S1 - S0)), sh_p = lut_shift<LUT_NB_P>((u32)(P1 - P0));
     {
         // the buckets behind the last key ("no such record"), disjoint from the buckets the loop below writes
         const u32 last_s = (u32)(S1 - S0) >> sh_s, last_p = (u32)(P1 - P0) >> sh_p;
-        for (u32 b = threadIdx.x; b < (u32)LUT_NB + 2; b += SW_TPB) {
+        for (u32 b = threadIdx.x; b < (u32)LUT_NB_S + 2; b += SW_TPB)
             if (b > last_s) lut_s[b] = (unsigned short)n;
+        for (u32 b = threadIdx.x; b < (u32)LUT_NB_P + 2; b += SW_TPB)
             if (b > last_p) lut_p[b] = (unsigned short)n;
-        }
     }
     __syncthreads();
     // buckets (bucket of the previous key, bucket of this key] start at record i; record 0 opens bucket 0
@@ -632,9 +640,9 @@ k_igd_tile_tables(IgdView v, const u32 *__restrict__ tile_first, const u32 *__re
         tab[10] = seg_hi - p0;
         tab[11] = 0;
     }
-    for (u32 w = threadIdx.x; w < 2u * TAB_LUT_WORDS; w += SW_TPB) {
-        const unsigned short *src = w < (u32)TAB_LUT_WORDS ? lut_s : lut_p;
-        const u32 k = w < (u32)TAB_LUT_WORDS ? w : w - TAB_LUT_WORDS;
+    for (u32 w = threadIdx.x; w < (u32)TAB_LUT_WORDS; w += SW_TPB) {
+        const unsigned short *src = w < (u32)TAB_LUT_S_WORDS ? lut_s : lut_p;
+        const u32 k = w < (u32)TAB_LUT_S_WORDS ? w : w - TAB_LUT_S_WORDS;
         tab[TAB_DESC + w] = (u32)src[2 * k] | ((u32)src[2 * k + 1] << 16);
     }
 }
@@ -663,13 +671,22 @@ __device__ __forceinline__ u32 sweep_query_slot(int lane, int wave) {
 // "ends after q.start" is all that is left of the overlap test, and the largest such end is a per-record constant of
 // the database (IgdTiles::pme_file).  Binary counting then costs what pairwise counting costs.
 // MO1: min_overlap == 1 (a candidate record is a hit iff its end is > q_start; its start is not read).
-// Register budget = what the LDS footprint admits: 4 workgroups per CU (8 waves per SIMD, 64 VGPRs) for the pairwise form,
-// 3 (80 VGPRs) with the staged pme_file column; the credited-file-list form keeps its 16 list registers.
 // PIECES: the database is a pieces view (IgdView::pieces): bit 15 of a staged file id marks a continuation piece, which is a
 // hit only if it also starts at or before the query's start (then it is the piece that holds the query's start; first pieces
 // count whenever they overlap) -- min_overlap == 1 forms only.
+//
+// What a tile streams (round 4): starts, ends, u16 file ids (+ pme_file for MODE 2) and the two search tables -- NOT the
+// prefix maxima.  A query's first candidate used to be found exactly (binary search of the staged prefix-max column, 4 bytes per
+// record from HBM and in LDS, three dependent LDS round trips per query); now it is the LOWER BRACKET of the static table over
+// the prefix maxima (IgdTiles::tab): every record in front of it has a prefix-max end <= q_start and so cannot overlap, and the
+// records between the bracket and the exact position (about one on average with 1024 buckets) end at or before q_start too --
+// they fail the hit test like any other candidate that does not overlap.  A bracket wider than LO_REFINE records (prefix maxima
+// that stay flat behind a long record) is narrowed by a search of the prefix maxima in global memory (IgdView::pm; rare).
+// LDS per workgroup: starts (4 B) + {end, file} or {end, pme_file} pairs (8 B, ONE ds_read_b64 per candidate) [+ u16 file ids for
+// MODE 2]: 28 / 32 KB instead of 32 / 42, so the pme_file form keeps 4 workgroups per CU.
+constexpr u32 LO_REFINE = 24;
 template <int MODE, bool MO1, bool B16 = false, bool PIECES = false>
-__global__ void __launch_bounds__(SW_TPB, MODE == 0 ? 8 : MODE == 2 ? 6 : 4)
+__global__ void __launch_bounds__(SW_TPB, MODE == 1 ? 4 : 8)
 k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__ pm, const unsigned short *__restrict__ files16,
             const u32 *__restrict__ tile_tab, u32 n_tiles, const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap, unsigned long long *__restrict__ hits,
@@ -689,33 +706,30 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
     // The columns are staged as whole 16-byte vectors from the 16-byte boundary at or below the tile's first record (a dword-per-
     // lane copy is 5 x 5 loads and as many LDS stores per thread and tile: a fifth of the kernel's instructions): LDS slot j of a
     // column holds the record at (p0 & ~3) + j, so record i of the tile sits at slot i + (p0 & 3) -- the per-tile pointers t_*
-    // below point there.  The u16 file ids are 8 to a vector: slot i + (p0 & 7).
-    constexpr int CAPV = CAP + 4, CAPF = CAP + 8;
-    static_assert(CAPV % 4 == 0 && CAPF % 8 == 0, "every column starts on a 16-byte boundary");
+    // below point there.
+    constexpr int CAPV = CAP + 4;
+    static_assert(CAPV % 4 == 0, "every column starts on a 16-byte boundary");
     i32 *b_s = reinterpret_cast<i32 *>(sm);
-    i32 *b_e = b_s + CAPV;
-    i32 *b_pm = b_e + CAPV;                            // prefix maximum of the ends (IgdTiles::pm)
-    i32 *b_pf = b_pm + CAPV;                           // MODE 2: pme_file of the staged records
-    unsigned short *b_f = reinterpret_cast<unsigned short *>(b_pf + (MODE == 2 ? CAPV : 0));  // file ids, u16
+    uint2 *b_x = reinterpret_cast<uint2 *>(b_s + CAPV);  // {end, file id} -- MODE 2: {end, pme_file}
+    unsigned short *b_f = reinterpret_cast<unsigned short *>(b_x + CAPV);  // MODE 2: the file ids, u16
     // [n_bins]: n_files counters per query SET.  A partitioned batch may hold up to 4 sets (gtars_igd_count_sets_device): the set
     // of a query travels in bit 31 of its (start, end) pair (SetTags, sort.hip) and selects the row of counters its hits go to
-    u32 *bins = reinterpret_cast<u32 *>(b_f + CAPF);
+    u32 *bins = reinterpret_cast<u32 *>(b_f + (MODE == 2 ? CAPV : 0));
     auto untag = [&](i32 &s, i32 &e) -> u32 {  // -> the query's first counter
         const u32 set = (((u32)s >> 31) << 1) | ((u32)e >> 31);
         s &= 0x7FFFFFFF;
         e &= 0x7FFFFFFF;
         return __umul24(set, v.n_files);  // < 16384 (the launcher's bound on sets x files)
     };
-    static_assert(IGD_TILE + IGD_HALO < 4096, "a candidate count and a counter offset share one shuffled word: 12 + 14 bits");
-    __shared__ u32 s_lutw[2 * TAB_LUT_WORDS];
+    static_assert(IGD_TILE + IGD_HALO < 4096, "a candidate count and a counter offset share one word: 12 + 14 bits");
+    __shared__ u32 s_lutw[TAB_LUT_WORDS];
     const unsigned short *lut_s = reinterpret_cast<const unsigned short *>(s_lutw);
-    const unsigned short *lut_p = reinterpret_cast<const unsigned short *>(s_lutw + TAB_LUT_WORDS);
+    const unsigned short *lut_p = reinterpret_cast<const unsigned short *>(s_lutw + TAB_LUT_S_WORDS);
     constexpr bool BINARY = MODE == 1;
     // B16 (MODE 2 only): 16-bit counters, two per LDS word.  A query credits a (set, file) at most once, so a counter is bounded
     // by the number of queries the workgroup has served since its counters were last flushed -- flushed every <= 65535 queries.
-    // Half the LDS for the counters; the launcher takes this form only when that admits one more workgroup per CU (two sets x
-    // 2000 files, config 4: 3 instead of 2) -- the packed increment costs three more instructions per hit (config 3's dense
-    // binary batch: 0.32 -> 0.355 ms with it, for no gain in residency).
+    // Half the LDS for the counters; the launcher takes this form only when that admits one more workgroup per CU -- the packed
+    // increment costs three more instructions per hit.
     static_assert(!B16 || MODE == 2, "16-bit counters need the one-credit-per-query bound of the pme_file form");
     static_assert(!PIECES || (MO1 && MODE != 1), "a pieces view serves the min_overlap == 1 forms only");
     const u32 n_words = B16 ? (n_bins + 1) / 2 : n_bins;
@@ -749,23 +763,38 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
     // queries inside one 50-kb window kept ONE workgroup busy for 32 ms (10M queries) before; the parts of such a tile now spread
     // over the grid, each staging the tile again.
     const u32 n_heavy = heavy_part ? min(*heavy_count, heavy_cap) : 0u;
-    for (u32 item = blockIdx.x; item < n_tiles + n_heavy; item += gridDim.x) {
-        u32 tile = item, part = 0;
-        if (item >= n_tiles) {
+    const u32 n_items = n_tiles + n_heavy;
+    // An item's descriptor (12 words of its tile's table + its query range) is REQUESTED one tile ahead: the chain descriptor ->
+    // record addresses -> records was two dependent trips to HBM at the head of every tile (the stamps' "stage" phase: 9k of a
+    // tile's 25k cycles).  Every wave requests it for itself with ONE vector load -- lane l < 12 word l of the table, lane 12 / 13
+    // the tile's query range -- and picks the words out of the register with v_readlane when the tile's turn comes.  (Scalar
+    // loads would be the natural form, but the compiler parks the loop-carried values in other SGPRs right behind the loads,
+    // i.e. it waits for them where they are issued.)
+    auto request = [&](u32 item, u32 &tile, u32 &part) -> u32 {
+        tile = item;
+        part = 0;
+        if (item >= n_tiles) {  // a further part of a heavy tile (rare): which tile, by scalar loads
             const uint2 hp = heavy_list[item - n_tiles];
             tile = hp.x;
             part = hp.y;
         }
-        const u32 *__restrict__ tab = tile_tab + (size_t)tile * TAB_WORDS;  // uniform: the descriptor comes by scalar loads
-        const u32 p0 = tab[0], cnt = tab[1], n_lds = tab[3], n_seg = tab[10];
-        const i32 S0 = (i32)tab[4], S1 = (i32)tab[5], P0 = (i32)tab[7], P1 = (i32)tab[8];
-        const u32 sh_s = tab[6], sh_p = tab[9];
-        (void)cnt;
-        u32 q_lo = ql[tile], q_hi = (GTARS_IGD_ABLATE & 8) ? q_lo : qh[tile];
+        const u32 *__restrict__ src = lane < TAB_DESC ? tile_tab + (size_t)tile * TAB_WORDS + lane : (lane == TAB_DESC ? ql : qh) + tile;
+        return lane < TAB_DESC + 2 ? *src : 0u;
+    };
+    u32 n_tile = 0, n_part = 0, n_desc = 0;
+    if (blockIdx.x < n_items) n_desc = request(blockIdx.x, n_tile, n_part);
+    for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const u32 tile = n_tile, desc = n_desc;
+        auto word = [&](int k) -> u32 { return (u32)__builtin_amdgcn_readlane((int)desc, k); };
+        const u32 p0 = word(0), n_lds = word(3), n_seg = word(10), sh_s = word(6), sh_p = word(9);
+        const i32 S0 = (i32)word(4), S1 = (i32)word(5), P0 = (i32)word(7), P1 = (i32)word(8);
+        u32 q_lo = word(TAB_DESC), q_hi = (GTARS_IGD_ABLATE & 8) ? q_lo : word(TAB_DESC + 1);
         if (heavy_part) {  // this item's share of the tile's queries
-            q_lo = min(q_hi, q_lo + part * heavy_part);
+            q_lo = min(q_hi, q_lo + n_part * heavy_part);
             q_hi = min(q_hi, q_lo + heavy_part);
         }
+        const u32 *__restrict__ tab = tile_tab + (size_t)tile * TAB_WORDS;
+        if (item + gridDim.x < n_items) n_desc = request(item + gridDim.x, n_tile, n_part);
         // the tile's first SW_TPB queries: loaded now, used once the tile is staged (MODE 0 / 2)
         i32 pf_s = 0, pf_e = 0;
         if constexpr (MODE != 1) {
@@ -781,73 +810,99 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                 }
             }
         }
-        // stage the tile: records + the search tables.  No register prefetch across the query phase: with 3 - 4 workgroups per
+        // stage the tile: records + the search tables.  No register prefetch across the query phase: with 4 workgroups per
         // CU the other workgroups' query phases cover this one's loads (measured: prefetching one tile ahead bought nothing and
         // cost 15 registers).
-        const u32 d4 = p0 & 3u, d8 = p0 & 7u;
-        i32 *t_s = b_s + d4, *t_e = b_e + d4, *t_pm = b_pm + d4, *t_pf = b_pf + d4;
-        unsigned short *t_f = b_f + d8;
+        const u32 d4 = p0 & 3u;
+        i32 *t_s = b_s + d4;
+        uint2 *t_x = b_x + d4;
+        unsigned short *t_f = b_f + d4;
         {
             constexpr int RV = (CAPV / 4 + SW_TPB - 1) / SW_TPB;  // 16-byte vectors per thread and 4-byte column
-            static_assert(CAPF / 8 <= SW_TPB, "one vector of file ids per thread");
-            const u32 nv4 = (n_lds + d4 + 3u) >> 2, nv8 = (n_lds + d8 + 7u) >> 3;
+            const u32 nv4 = (n_lds + d4 + 3u) >> 2;
             typedef u32 v4u __attribute__((ext_vector_type(4)));  // (a native vector: arrays of HIP's uint4 struct went to scratch)
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
             const v4u *g_s = reinterpret_cast<const v4u *>(v.starts + (p0 - d4)), *g_e = reinterpret_cast<const v4u *>(v.ends + (p0 - d4)),
-                      *g_p = reinterpret_cast<const v4u *>(pm + (p0 - d4)), *g_f = reinterpret_cast<const v4u *>(files16 + (p0 - d8)),
                       *g_q = MODE == 2 ? reinterpret_cast<const v4u *>(pme_file + (p0 - d4)) : nullptr;
-            v4u rs[RV], re[RV], rp[RV], rq[MODE == 2 ? RV : 1], rf = {0, 0, 0, 0};
+            const v2u *g_f = reinterpret_cast<const v2u *>(files16 + (p0 - d4));  // four u16 ids per vector of four records
+            v4u rs[RV], re[RV], rq[MODE == 2 ? RV : 1];
+            v2u rf[RV];
 #pragma unroll
             for (int k = 0; k < RV; ++k) {
                 const u32 q = threadIdx.x + (u32)k * SW_TPB;
-                rs[k] = re[k] = rp[k] = v4u{0, 0, 0, 0};
+                rs[k] = re[k] = v4u{0, 0, 0, 0};
+                rf[k] = v2u{0, 0};
                 if (MODE == 2) rq[MODE == 2 ? k : 0] = v4u{0, 0, 0, 0};
                 if (q < nv4) {
                     rs[k] = g_s[q];
                     re[k] = g_e[q];
-                    rp[k] = g_p[q];
+                    rf[k] = g_f[q];
                     if (MODE == 2) rq[MODE == 2 ? k : 0] = g_q[q];
                 }
             }
-            if (threadIdx.x < nv8) rf = g_f[threadIdx.x];
-            u32 lw[2];
+            constexpr int LWN = (TAB_LUT_WORDS + SW_TPB - 1) / SW_TPB;  // table words per thread
+            u32 lw[LWN];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < LWN; ++k) {
                 const u32 w = threadIdx.x + (u32)k * SW_TPB;
-                lw[k] = w < 2u * TAB_LUT_WORDS ? tab[TAB_DESC + w] : 0u;
+                lw[k] = w < (u32)TAB_LUT_WORDS ? tab[TAB_DESC + w] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < RV; ++k) {
                 const u32 q = threadIdx.x + (u32)k * SW_TPB;
                 if (q < nv4) {
                     reinterpret_cast<v4u *>(b_s)[q] = rs[k];
-                    reinterpret_cast<v4u *>(b_e)[q] = re[k];
-                    reinterpret_cast<v4u *>(b_pm)[q] = rp[k];
-                    if (MODE == 2) reinterpret_cast<v4u *>(b_pf)[q] = rq[MODE == 2 ? k : 0];
+                    v4u x0, x1;
+                    if (MODE == 2) {
+                        const v4u pq = rq[MODE == 2 ? k : 0];
+                        x0 = v4u{re[k].x, pq.x, re[k].y, pq.y};
+                        x1 = v4u{re[k].z, pq.z, re[k].w, pq.w};
+                        reinterpret_cast<v2u *>(b_f)[q] = rf[k];
+                    } else {
+                        x0 = v4u{re[k].x, rf[k].x & 0xFFFFu, re[k].y, rf[k].x >> 16};
+                        x1 = v4u{re[k].z, rf[k].y & 0xFFFFu, re[k].w, rf[k].y >> 16};
+                    }
+                    reinterpret_cast<v4u *>(b_x)[2 * q] = x0;
+                    reinterpret_cast<v4u *>(b_x)[2 * q + 1] = x1;
                 }
             }
-            if (threadIdx.x < nv8) reinterpret_cast<v4u *>(b_f)[threadIdx.x] = rf;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < LWN; ++k) {
                 const u32 w = threadIdx.x + (u32)k * SW_TPB;
-                if (w < 2u * TAB_LUT_WORDS) s_lutw[w] = lw[k];
+                if (w < (u32)TAB_LUT_WORDS) s_lutw[w] = lw[k];
             }
         }
         __syncthreads();  // the tile is in LDS (and, first tile, the bins are zeroed)
         STAMP(0);
+        // first candidate of a query that starts at s: the lower bracket of the prefix-max table (see the kernel's header)
+        auto first_candidate = [&](i32 s) -> u32 {
+            u32 lo, hi;
+            lut_range(lut_p, s + 1, P0, P1, sh_p, n_lds, lo, hi);
+            if (hi - lo > LO_REFINE && pm) {  // flat prefix maxima (a long record in front): the exact position, from global memory
+                while (lo < hi) {
+                    const u32 mid = lo + ((hi - lo) >> 1);
+                    if (pm[p0 + mid] <= s)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+            }
+            return lo;
+        };
         // record i (relative to p0): LDS if staged, global otherwise (rare: scans longer than the halo)
         auto r_start = [&](u32 i) -> i32 { return i < n_lds ? t_s[i] : v.starts[p0 + i]; };
-        auto r_end = [&](u32 i) -> i32 { return i < n_lds ? t_e[i] : v.ends[p0 + i]; };
-        auto r_file = [&](u32 i) -> u32 { return i < n_lds ? t_f[i] : v.files[p0 + i]; };
+        auto r_end = [&](u32 i) -> i32 { return i < n_lds ? (i32)t_x[i].x : v.ends[p0 + i]; };
+        auto r_file = [&](u32 i) -> u32 { return i < n_lds ? (MODE == 2 ? (u32)t_f[i] : t_x[i].y) : v.files[p0 + i]; };
         if constexpr (MODE != 1) {
-            // A hit is decided by the (query, record) PAIR alone.  A query's candidates are the records [lo, hi): lo = first
-            // record that can overlap it (prefix-max end > q_start), hi = first record that starts at or after q_end (the
+            // A hit is decided by the (query, record) PAIR alone.  A query's candidates are the records [lo, hi): lo = the first
+            // record that can overlap it (bracket of the prefix-max table), hi = first record that starts at or after q_end (the
             // reference's scan stops there, igd.rs:772-846).  Waves work on their own, no workgroup barrier inside a tile:
-            // (1) one lane per query finds (lo, hi) through the tile's search tables, the two searches advancing together;
-            // (2) the pairs are walked by GROUPS of GL lanes -- group g takes the queries of its own GL lanes one after the
-            // other, its lanes read CONSECUTIVE records.  Records past the staged range (rare) are scanned by the query's own
-            // lane from global memory.
+            // (1) one lane per query finds (lo, hi): one table lookup, and the tile's start table + a short binary search;
+            // (2) the pairs are walked by QUADS -- quad g takes the queries of its own 4 lanes one after the other (their state
+            // arrives by DPP quad_perm moves), its lanes read CONSECUTIVE records, one 8-byte LDS read each.  Records past the
+            // staged range (rare) are scanned by the query's own lane from global memory.
             constexpr int GL = IGD_GROUP_LANES;
-            const int grp = lane / GL, sub = lane % GL;
+            const int sub = lane % GL;
             const u32 kq = sweep_query_slot(lane, wave);
             for (u32 qb = q_lo; qb < q_hi; qb += SW_TPB) {
                 if (B16) {
@@ -875,33 +930,33 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                         e = (i32)sqe[qi];
                     }
                     if (interleaved) boff = untag(s, e);
-                    u32 hi, a, b;
+                    u32 a, b;
                     if (GTARS_IGD_ABLATE & 16) {
                         lo = ((u32)s * 2654435761u) % (n_lds > 40 ? n_lds - 40 : 1u);
                         a = lo + 20;
                     } else {
-                        // lo = first record with prefix-max end > s (>= s + 1), a = first record with start >= e
-                        lut_range(lut_p, s + 1, P0, P1, sh_p, n_lds, lo, hi);
+                        lo = first_candidate(s);
+                        // a = first record with start >= e
                         lut_range(lut_s, e, S0, S1, sh_s, n_lds, a, b);
-                        while (lo < hi || a < b) {
-                            const u32 m1 = lo + ((hi - lo) >> 1), m2 = a + ((b - a) >> 1);
-                            const bool go1 = lo < hi, go2 = a < b;
-                            const i32 v1 = go1 ? t_pm[m1] : 0, v2 = go2 ? t_s[m2] : 0;
-                            if (go1) {
-                                if (v1 <= s)
-                                    lo = m1 + 1;
-                                else
-                                    hi = m1;
-                            }
-                            if (go2) {
-                                if (v2 < e)
-                                    a = m2 + 1;
-                                else
-                                    b = m2;
-                            }
+                        while (b - a > 4u) {  // (rare with 1024 buckets over ~2300 staged records)
+                            const u32 m2 = a + ((b - a) >> 1);
+                            if (t_s[m2] < e)
+                                a = m2 + 1;
+                            else
+                                b = m2;
+                        }
+                        if (a < b) {
+                            // the bracket's <= 4 starts by ONE 16-byte LDS read (4-byte aligned); they ascend, so the answer is a +
+                            // the number of them below e.  (Slots past the bracket may lie past the staged records: ignored.)
+                            typedef i32 i4 __attribute__((ext_vector_type(4)));
+                            typedef i4 i4_a4 __attribute__((aligned(4)));
+                            typedef const __attribute__((address_space(3))) i4_a4 *lds_i4;
+                            const i4 x = *(lds_i4)(uintptr_t)(t_s + a);
+                            const u32 nb = b - a;
+                            a += (x.x < e ? 1u : 0u) + (nb > 1 && x.y < e ? 1u : 0u) + (nb > 2 && x.z < e ? 1u : 0u) + (nb > 3 && x.w < e ? 1u : 0u);
                         }
                     }
-                    len = a - lo;  // a >= lo: every record before lo ends at or before s, hence starts before e
+                    len = a > lo ? a - lo : 0u;  // (a >= lo: every record before lo ends at or before s, hence starts before e)
                     if (!(GTARS_IGD_ABLATE & 16) && a == n_lds && n_seg > n_lds) {
                         // the scan runs past the staged records: the rest from global memory, by this lane
                         for (u32 r = max(lo, n_lds); r < n_seg; ++r) {
@@ -918,60 +973,85 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                 }
                 if (GTARS_IGD_ABLATE & 1) len = min(len, 1u);
                 STAMP(3);
-                // the group's GL queries, IGD_PAIR_UNROLL at a time (their candidate reads issued together)
-                constexpr int U = IGD_PAIR_UNROLL;
-                static_assert(GL % U == 0, "slots per step divide the group");
-#pragma unroll 1
-                for (int i0 = 0; i0 < GL; i0 += U) {
-                    i32 qs_[U], qe_[U];
-                    u32 lo_[U], len_[U], bo_[U], mx = 0;
-                    const u32 len_bo = len | (boff << 12);  // one shuffle for both (a shuffle is an LDS instruction)
+                const u32 len_bo = len | (boff << 12);
+                // the quad's four queries, one after the other
+                // WALK_U candidates of a lane per step, their LDS reads issued together (inline asm: left to itself the compiler
+                // reads a pair's end, branches on the overlap test and only then reads the file id -- two dependent LDS round
+                // trips for every candidate, 490 cycles per step by the in-kernel stamps with 8 waves per SIMD).  Lanes past the
+                // query's last candidate read whatever follows in LDS (in range of the allocation or zero) and ignore it.
+                constexpr int WALK_U = 3;
+                auto walk = [&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    const i32 qs_ = quad_bcast<k>(s);
+                    const u32 lo_ = (u32)quad_bcast<k>((int)lo), lb = (u32)quad_bcast<k>((int)len_bo);
+                    const i32 qe_ = MO1 ? 0 : quad_bcast<k>(e);
+                    const u32 len_ = lb & 0xFFFu, bo_ = lb >> 12;
+                    constexpr bool NEED_S = !(MO1 && !PIECES);
+                    for (u32 j = (u32)sub; j < len_; j += GL * WALK_U) {
+                        const u32 r = lo_ + j;
+                        const u32 ax = (u32)(uintptr_t)(t_x + r), as = (u32)(uintptr_t)(t_s + r), af = (u32)(uintptr_t)(t_f + r);
+                        u64 x[WALK_U];
+                        u32 fs[WALK_U] = {0, 0, 0};
+                        i32 ss[WALK_U] = {0, 0, 0};
+                        static_assert(WALK_U == 3 && GL == 4, "the offsets below");
+                        if (MODE == 2 && NEED_S)
+                            asm volatile("ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:32\n\tds_read_b64 %2, %9 offset:64\n\t"
+                                         "ds_read_u16 %3, %10\n\tds_read_u16 %4, %10 offset:8\n\tds_read_u16 %5, %10 offset:16\n\t"
+                                         "ds_read_b32 %6, %11\n\tds_read_b32 %7, %11 offset:16\n\tds_read_b32 %8, %11 offset:32\n\t"
+                                         "s_waitcnt lgkmcnt(0)"
+                                         : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(fs[0]), "=&v"(fs[1]), "=&v"(fs[2]), "=&v"(ss[0]), "=&v"(ss[1]), "=&v"(ss[2])
+                                         : "v"(ax), "v"(af), "v"(as)
+                                         : "memory");
+                        else if (MODE == 2)
+                            asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:32\n\tds_read_b64 %2, %6 offset:64\n\t"
+                                         "ds_read_u16 %3, %7\n\tds_read_u16 %4, %7 offset:8\n\tds_read_u16 %5, %7 offset:16\n\t"
+                                         "s_waitcnt lgkmcnt(0)"
+                                         : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(fs[0]), "=&v"(fs[1]), "=&v"(fs[2])
+                                         : "v"(ax), "v"(af)
+                                         : "memory");
+                        else if (NEED_S)
+                            asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:32\n\tds_read_b64 %2, %6 offset:64\n\t"
+                                         "ds_read_b32 %3, %7\n\tds_read_b32 %4, %7 offset:16\n\tds_read_b32 %5, %7 offset:32\n\t"
+                                         "s_waitcnt lgkmcnt(0)"
+                                         : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(ss[0]), "=&v"(ss[1]), "=&v"(ss[2])
+                                         : "v"(ax), "v"(as)
+                                         : "memory");
+                        else
+                            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:32\n\tds_read_b64 %2, %3 offset:64\n\t"
+                                         "s_waitcnt lgkmcnt(0)"
+                                         : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2])
+                                         : "v"(ax)
+                                         : "memory");
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int src = grp * GL + i0 + u;  // this group's (i0 + u)-th query
-                        qs_[u] = __shfl(s, src, 64);
-                        lo_[u] = (u32)__shfl((int)lo, src, 64);
-                        const u32 lb = (u32)__shfl((int)len_bo, src, 64);
-                        len_[u] = lb & 0xFFFu;
-                        bo_[u] = lb >> 12;
-                        qe_[u] = MO1 ? 0 : __shfl(e, src, 64);
-                        mx = max(mx, len_[u]);
-                    }
-                    for (u32 k = (u32)sub; k < mx; k += GL) {
-                        i32 re[U], rs[U], pf[U];
-                        u32 f[U];
-                        bool on[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            on[u] = k < len_[u];
-                            const u32 r = on[u] ? lo_[u] + k : 0u;
-                            re[u] = t_e[r];
-                            f[u] = t_f[r];
-                            rs[u] = (MO1 && !PIECES) ? 0 : t_s[r];
-                            pf[u] = MODE == 2 ? t_pf[r] : 0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
+                        for (int u = 0; u < WALK_U; ++u) {
+                            const i32 re = (i32)(u32)x[u];
+                            const u32 hi32 = (u32)(x[u] >> 32);
+                            u32 f = MODE == 2 ? fs[u] : hi32;
+                            const i32 rs = ss[u];
                             bool hit;
                             if (MO1)
-                                hit = re[u] > qs_[u];
+                                hit = re > qs_;
                             else
-                                hit = (re[u] < qe_[u] ? re[u] : qe_[u]) - (rs[u] > qs_[u] ? rs[u] : qs_[u]) >= min_overlap;
-                            if (MODE == 2) hit = hit && pf[u] <= qs_[u];  // no earlier record of this file reaches the query
+                                hit = (re < qe_ ? re : qe_) - (rs > qs_ ? rs : qs_) >= min_overlap;
+                            if (MODE == 2) hit = hit && (i32)hi32 <= qs_;  // no earlier record of this file reaches the query
                             if (PIECES) {
-                                hit = hit && (!(f[u] >> 15) || rs[u] <= qs_[u]);
-                                f[u] &= 0x7FFFu;
+                                hit = hit && (!(f >> 15) || rs <= qs_);
+                                f &= 0x7FFFu;
                             }
-                            if (hit && on[u]) {
+                            if (hit && j + (u32)(u * GL) < len_) {
                                 if (GTARS_IGD_ABLATE & 2) {
-                                    if (re[u] == 0x7FFFFFF0) bins[0] = 1;
+                                    if (re == 0x7FFFFFF0) bins[0] = 1;
                                 } else {
-                                    bump(bo_[u] + f[u]);
+                                    bump(bo_ + f);
                                 }
                             }
                         }
                     }
-                }
+                };
+                walk(std::integral_constant<int, 0>{});
+                walk(std::integral_constant<int, 1>{});
+                walk(std::integral_constant<int, 2>{});
+                walk(std::integral_constant<int, 3>{});
                 STAMP(4);
             }
         } else
@@ -988,19 +1068,10 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                 s = max((i32)sqs[qi], 0);
                 e = (i32)sqe[qi];
             }
-            // an overlap of >= 1 bp needs end > q_start: start at the first staged record whose prefix-max
-            // end is > q_start.  It is never before lower_bound(q_start - max_len) (everything in between
-            // ends at or before q_start), so ownership by this tile still holds; if no staged record
-            // qualifies the scan goes on in global memory from the end of the staged range.
-            u32 lo, hi;
-            lut_range(lut_p, s + 1, P0, P1, sh_p, n_lds, lo, hi);
-            while (lo < hi) {
-                const u32 mid = lo + ((hi - lo) >> 1);
-                if (t_pm[mid] <= s)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
+            // an overlap of >= 1 bp needs end > q_start: start at the first candidate (every staged record in front of it ends at
+            // or before q_start).  It is never before lower_bound(q_start - max_len), so ownership by this tile still holds; if no
+            // staged record qualifies the scan goes on in global memory from the end of the staged range.
+            const u32 lo = first_candidate(s);
             // binary counting: the files already credited to this query, as packed u16 pairs in
             // registers (no memory latency in the membership test); 0xFFFF = empty (n_files <= 16384)
             u32 n_seen = 0;
@@ -1011,9 +1082,10 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                 i32 rs, re;
                 u32 f;
                 if (r < n_lds) {
+                    const uint2 x = t_x[r];
                     rs = t_s[r];
-                    re = t_e[r];
-                    f = t_f[r];
+                    re = (i32)x.x;
+                    f = x.y;
                 } else {
                     rs = v.starts[p0 + r];
                     re = v.ends[p0 + r];
@@ -1474,15 +1546,17 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     }
     const int mode = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
     if (!tl.pm || !tl.files16 || !tl.tab) return fail(GTARS_ERR_INTERNAL, "IGD sweep: the per-tile tables were not built");
-    // starts | ends | prefix-max ends | [pme_file] | files (u16) | counters (u32, or 16-bit two per word: mode 2 when that admits
-    // another workgroup per CU)
-    const size_t lds_rec = (size_t)(IGD_TILE + IGD_HALO + 4) * (mode == 2 ? 16 : 12) + (size_t)(IGD_TILE + IGD_HALO + 8) * 2;
+    // starts | {end, file} pairs (mode 2: {end, pme_file} pairs + u16 file ids) | counters (u32, or 16-bit two per word: mode 2
+    // when that admits another workgroup per CU)
+    const size_t lds_rec = (size_t)(IGD_TILE + IGD_HALO + 4) * (mode == 2 ? 14 : 12);
     size_t lds = lds_rec + (((size_t)n_bins + 1) & ~(size_t)1) * 4;
     const size_t lds16 = lds_rec + ((size_t)n_bins + 3) / 4 * 8;
     const bool mo1 = min_overlap == 1;
     auto kern = mode == 2 ? k_igd_sweep<2, true> : mode == 1 ? k_igd_sweep<1, false> : mo1 ? k_igd_sweep<0, true> : k_igd_sweep<0, false>;
     const size_t lds_cu = 160 * 1024;  // what a CU has; the static part (search tables) is ~2 KB per workgroup
-    const bool b16 = mode == 2 && !getenv("GTARS_IGD_NO_B16") && lds_cu / (lds16 + 2304) > lds_cu / (lds + 2304) && lds_cu / (lds + 2304) < 3;
+    const size_t lds_static = (size_t)TAB_LUT_WORDS * 4 + 256;
+    const bool b16 = mode == 2 && !getenv("GTARS_IGD_NO_B16") && lds_cu / (lds16 + lds_static) > lds_cu / (lds + lds_static) &&
+                     lds_cu / (lds + lds_static) < 4;
     if (b16) {
         kern = k_igd_sweep<2, true, true>;
         lds = lds16;
@@ -1502,7 +1576,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         std::lock_guard<std::mutex> lock(mu);
         if (dev >= 0 && dev < 64 && !done[slot][dev]) {
             GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(((size_t)(IGD_TILE + IGD_HALO) * 5 + 16384 + 2048) * 4)));
+                                       (int)(((size_t)(IGD_TILE + IGD_HALO + 4) * 4 + 16384 + 2048) * 4)));
             done[slot][dev] = true;
         }
     }

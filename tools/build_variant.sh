@@ -1,11 +1,23 @@
 #!/bin/sh
 # Build an experimental variant of the library (extra -D flags) into build/variants/lib_<name>.so.
 # The variants travel to the GPU box with gpurun; select one with GTARS_AMD_LIB=$PWD/build/variants/lib_<name>.so
-# usage: sh tools/build_variant.sh <name> "<extra hipcc flags>"
+# usage: sh tools/build_variant.sh <name> "<extra hipcc flags>" [file.hip ...]
+#   With file names: only those translation units are recompiled with the flags, the rest comes from build/obj (the objects
+#   of the regular build: run `python __graft_entry__.py` first).  Without: every unit is recompiled.
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p build/variants
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $2 -I include -o build/variants/lib_$1.so \
-  -x c++ gtars_amd/csrc/host.cpp -x hip gtars_amd/csrc/api.hip -x hip gtars_amd/csrc/kernels.hip \
-  -x hip gtars_amd/csrc/sort.hip -x hip gtars_amd/csrc/igd_sweep.hip -x hip gtars_amd/csrc/tokenize_lds.hip -lz -lpthread
-echo "built build/variants/lib_$1.so"
+name=$1; flags=$2; shift 2 || true
+mkdir -p build/variants build/vobj/$name
+objs=""
+for src in host.cpp api.hip kernels.hip sort.hip igd_sweep.hip tokenize_lds.hip; do
+  o=build/obj/$src.o
+  if [ $# -eq 0 ] || echo " $* " | grep -q " $src "; then
+    o=build/vobj/$name/$src.o
+    case $src in *.hip) lang=hip;; *) lang=c++;; esac
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -I include -x $lang -c gtars_amd/csrc/$src -o $o &
+  fi
+  objs="$objs $o"
+done
+wait
+hipcc --offload-arch=gfx950 -fPIC -shared -o build/variants/lib_$name.so $objs -lz -lpthread
+echo "built build/variants/lib_$name.so"
