@@ -302,12 +302,12 @@ struct IgdTiles {
 #define IGD_LUT_P_BUCKETS 1024
 #endif
 #ifndef IGD_LUT_S_BUCKETS
-#define IGD_LUT_S_BUCKETS 1024
+#define IGD_LUT_S_BUCKETS 512
 #endif
 constexpr u32 IGD_LUT_S_NB = IGD_LUT_S_BUCKETS, IGD_LUT_P_NB = IGD_LUT_P_BUCKETS;
 static_assert((IGD_LUT_S_NB & (IGD_LUT_S_NB - 1)) == 0 && IGD_LUT_S_NB >= 256 && IGD_LUT_S_NB <= 4096, "a power of two");
 static_assert((IGD_LUT_P_NB & (IGD_LUT_P_NB - 1)) == 0 && IGD_LUT_P_NB >= 256 && IGD_LUT_P_NB <= 4096, "a power of two");
-constexpr u32 IGD_TILE_TAB_WORDS = (12 + (IGD_LUT_S_NB + 2) / 2 + (IGD_LUT_P_NB + 2) / 2 + 3) / 4 * 4;  // 1040: 4 KB per 2048 records
+constexpr u32 IGD_TILE_TAB_WORDS = (12 + (IGD_LUT_S_NB + 2) / 2 + (IGD_LUT_P_NB + 2) / 2 + 3) / 4 * 4;  // 784 words: 3 KB per 2048 records
 gtars_status launch_igd_tile_tables(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
                                     const i32 *tile_carry, u32 n_tiles, i32 *pm, unsigned short *files16, u32 *tile_tab, hipStream_t st);
 bool igd_sweep_supported(const IgdView &v, u64 nq);
