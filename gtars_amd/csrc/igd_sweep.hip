@@ -90,17 +90,15 @@ constexpr int IGD_SEEN = 32;   // per-thread list of credited files (binary coun
 // search of the bounds, which the workgroup keeps in LDS (4 B per tile), and notes whether the batch is already in
 // (chromosome, start) order.  tid = n_tiles: no owner (invalid query, unknown chromosome, or past every record's reach).
 constexpr int PREP_TPB = 1024;
+// (values in, values out, selects instead of conditional stores: with reference parameters into per-lane arrays the compiler
+// merged the stores of the two branches through a SELECTED ADDRESS, which forced the arrays -- the routing kernel's s[] and e[] --
+// into scratch memory: 48 bytes per lane written and read back through the vector-memory pipe on every step)
 __device__ __forceinline__ void igd_prep_one(u32 c_in, u32 s_in, u32 e_in, u32 n_chrom, u32 &c, i32 &s, i32 &e) {
-    s = (i32)s_in;
-    e = (i32)e_in;  // `as i32` (igd.rs:549-550)
-    c = c_in;
-    if (s >= e || e <= 0 || c >= n_chrom) {
-        c = n_chrom;  // sorts behind every real chromosome; never served
-        s = 0;
-        e = 0;
-    } else if (s < 0) {
-        s = 0;  // clamp (igd.rs:517)
-    }
+    const i32 s0 = (i32)s_in, e0 = (i32)e_in;  // `as i32` (igd.rs:549-550)
+    const bool bad = s0 >= e0 || e0 <= 0 || c_in >= n_chrom;
+    c = bad ? n_chrom : c_in;        // rejected: sorts behind every real chromosome; never served
+    s = bad ? 0 : (s0 < 0 ? 0 : s0);  // clamp (igd.rs:517)
+    e = bad ? 0 : e0;
 }
 
 template <bool BUCKET>
@@ -222,39 +220,42 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
     // cycles per step by the in-kernel stamps, ~500 VALU instructions per wave and step).  The raw columns of the NEXT step
     // are loaded while the current one is searched (one workgroup per CU: nothing else covers the HBM latency).  Whether the
     // batch is in order is no longer this kernel's business (k_igd_order_check runs in front of it).
-    u32 nc[RT_U], ns[RT_U], ne[RT_U];
-    auto fetch = [&](u32 base) {
-        const u32 i0 = base + threadIdx.x * RT_U;
-        if (VEC && i0 + RT_U <= hi_q) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(qc + i0), b = *reinterpret_cast<const uint4 *>(qs + i0),
-                        d = *reinterpret_cast<const uint4 *>(qe + i0);
-            nc[0] = a.x, nc[1] = a.y, nc[2] = a.z, nc[3] = a.w;
-            ns[0] = b.x, ns[1] = b.y, ns[2] = b.z, ns[3] = b.w;
-            ne[0] = d.x, ne[1] = d.y, ne[2] = d.z, ne[3] = d.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < RT_U; ++u) {
-                const bool in = i0 + u < hi_q;
-                nc[u] = in ? qc[i0 + u] : GTARS_UNKNOWN_CHROM;
-                ns[u] = in ? qs[i0 + u] : 0u;
-                ne[u] = in ? qe[i0 + u] : 0u;
-            }
-        }
-    };
-    fetch(lo_q);
+    // (three plain vectors, not arrays filled through a lambda: those stayed in scratch memory -- 48 bytes per lane written and
+    // read back through the vector-memory pipe on every step)
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    static_assert(RT_U == 4, "a lane's four queries travel as one vector per column");
+    v4u nc, ns, ne;
+#define RT_FETCH(base_)                                                                                     \
+    do {                                                                                                    \
+        const u32 f0 = (base_) + threadIdx.x * RT_U;                                                        \
+        if (VEC && f0 + RT_U <= hi_q) {                                                                     \
+            nc = *reinterpret_cast<const v4u *>(qc + f0);                                                   \
+            ns = *reinterpret_cast<const v4u *>(qs + f0);                                                   \
+            ne = *reinterpret_cast<const v4u *>(qe + f0);                                                   \
+        } else {                                                                                            \
+            nc = v4u{f0 + 0 < hi_q ? qc[f0 + 0] : GTARS_UNKNOWN_CHROM, f0 + 1 < hi_q ? qc[f0 + 1] : GTARS_UNKNOWN_CHROM, \
+                     f0 + 2 < hi_q ? qc[f0 + 2] : GTARS_UNKNOWN_CHROM, f0 + 3 < hi_q ? qc[f0 + 3] : GTARS_UNKNOWN_CHROM}; \
+            ns = v4u{f0 + 0 < hi_q ? qs[f0 + 0] : 0u, f0 + 1 < hi_q ? qs[f0 + 1] : 0u, f0 + 2 < hi_q ? qs[f0 + 2] : 0u, \
+                     f0 + 3 < hi_q ? qs[f0 + 3] : 0u};                                                      \
+            ne = v4u{f0 + 0 < hi_q ? qe[f0 + 0] : 0u, f0 + 1 < hi_q ? qe[f0 + 1] : 0u, f0 + 2 < hi_q ? qe[f0 + 2] : 0u, \
+                     f0 + 3 < hi_q ? qe[f0 + 3] : 0u};                                                      \
+        }                                                                                                   \
+    } while (0)
+    RT_FETCH(lo_q);
     for (u32 base = lo_q; base < hi_q; base += RT_TPB * RT_U) {
         const u32 i0 = base + threadIdx.x * RT_U;
         u32 c[RT_U], l[RT_U], h[RT_U];
         i32 s[RT_U], e[RT_U];
         bool ok[RT_U], owned[RT_U];
+        const u32 rc[RT_U] = {nc.x, nc.y, nc.z, nc.w}, rs[RT_U] = {ns.x, ns.y, ns.z, ns.w}, re[RT_U] = {ne.x, ne.y, ne.z, ne.w};
 #pragma unroll
         for (int u = 0; u < RT_U; ++u) {
             ok[u] = i0 + u < hi_q;
             c[u] = n_chrom;
             s[u] = e[u] = 0;
-            if (ok[u]) igd_prep_one(nc[u], ns[u], ne[u], n_chrom, c[u], s[u], e[u]);
+            if (ok[u]) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
         }
-        if (base + RT_TPB * RT_U < hi_q) fetch(base + RT_TPB * RT_U);
+        if (base + RT_TPB * RT_U < hi_q) RT_FETCH(base + RT_TPB * RT_U);
 #pragma unroll
         for (int u = 0; u < RT_U; ++u) {
             // the owner: first tile of the chromosome whose bound is > start, bracketed by the static table
@@ -295,12 +296,18 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
                 if (ok[u]) key[i0 + u] = (unsigned short)tt[u];
         }
     }
+#undef RT_FETCH
     STAMP(1);
     __syncthreads();
     STAMP(2);
     if (tot) {
-        // the two-level split only needs the bin totals (its passes reserve runs with atomics on the bins' cursors)
-        for (u32 b = threadIdx.x; b <= n_tiles; b += RT_TPB) {
+        // the two-level split only needs the bin totals (its passes reserve runs with atomics on the bins' cursors).  Every
+        // workgroup starts at a different bin: walking the bins in the same order at the same time put all 256 workgroups'
+        // atomics on the same few cache lines (the flush was 12 % of the kernel by the in-kernel stamps)
+        const u32 nb = n_tiles + 1, rot = (u32)(((u64)blockIdx.x * nb) / gridDim.x);
+        for (u32 i = threadIdx.x; i < nb; i += RT_TPB) {
+            u32 b = i + rot;
+            b = b >= nb ? b - nb : b;
             const u32 x = (bins[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
             if (x) atomicAdd(&tot[b], x);
         }
