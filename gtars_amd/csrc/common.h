@@ -267,6 +267,10 @@ u32 multisplit_chunk(u32 n);  // elements per workgroup of that grid (a multiple
 u32 *multisplit_table(void *ws);
 // table_ready callers of a two-level split (large n, many bins) leave only the bin totals here (zeroed first); null: one-level
 u32 *multisplit_totals(void *ws, u32 n_bins, u32 n);
+// ... and the totals of the split's coarse bins (bin >> multisplit_coarse_shift(n_bins), <= 256 of them) here, inside the zeroed words
+u32 *multisplit_coarse_totals(void *ws, u32 n_bins, u32 n);
+u32 multisplit_coarse_shift(u32 n_bins);
+size_t multisplit_zeroed_words(u32 n_bins);  // what such a caller zeroes from multisplit_totals() on (totals + relative cursors)
 
 // K1 (sort.hip): permutation that orders rows by (chrom, k1, [k2], input order); device columns in/out
 gtars_status device_sort_perm(const u32 *d_chrom, const u32 *d_k1, const u32 *d_k2, u32 n, u32 n_chrom, u32 *d_perm,

@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(RT_TPB)
 k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
             const u32 *__restrict__ bnd, const u32 *__restrict__ chrom_tile_off, const u32 *__restrict__ route_base,
             const u32 *__restrict__ route_len, const u32 *__restrict__ route_lut, u32 n_lut, u32 route_shift, u32 n_tiles, u32 chunk,
-            unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, const u32 *__restrict__ run_if) {
+            unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, const u32 *__restrict__ run_if,
+            u32 *__restrict__ ctot, u32 cshift) {
     if (run_if && *run_if == 0) return;  // the batch is in owner order (k_igd_order_check): nothing to route, the sweep takes it as it lies
     extern __shared__ u32 rt_lds[];
     u32 *s_bnd = rt_lds, *s_cto = s_bnd + (BND_LDS ? n_tiles : 0u), *s_base = s_cto + n_chrom + 1, *s_len = s_base + n_chrom + 1;
@@ -310,6 +311,22 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
             b = b >= nb ? b - nb : b;
             const u32 x = (bins[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
             if (x) atomicAdd(&tot[b], x);
+        }
+        // ... and the totals of the split's COARSE bins (2^cshift fine bins each, <= 256 of them): the first pass of the split
+        // scans these for itself instead of summing 24k fine totals again (multisplit_pairs, FOLD)
+        if (ctot) {
+            const u32 n_coarse = ((nb - 1u) >> cshift) + 1u;
+            u32 j = threadIdx.x + (rot >> cshift);
+            j = j >= n_coarse ? j - n_coarse : j;
+            if (threadIdx.x < n_coarse && j < n_coarse) {
+                u32 sum = 0;
+                const u32 b0 = j << cshift, b1 = min(nb, b0 + (1u << cshift));
+                for (u32 w = b0 >> 1; w < (b1 + 1u) >> 1; ++w) {  // (b0 is even: cshift >= 3)
+                    const u32 x = bins[w];
+                    sum += (x & 0xFFFFu) + (2u * w + 1u < b1 ? x >> 16 : 0u);
+                }
+                if (sum) atomicAdd(&ctot[j], sum);
+            }
         }
     } else {
         u32 *row = table + (size_t)blockIdx.x * (n_tiles + 1);
@@ -1447,7 +1464,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     static std::mutex attr_mu;
     {
         u32 *d_tot0 = fused ? multisplit_totals(scratch, n_tiles + 1, nq) : nullptr;
-        const u32 n_tot0 = d_tot0 ? n_tiles + 1 : 0u, n_init = std::max<u32>(std::max<u32>(n_bins, n_tot0), 1u);
+        const u32 n_tot0 = d_tot0 ? (u32)multisplit_zeroed_words(n_tiles + 1) : 0u, n_init = std::max<u32>(std::max<u32>(n_bins, n_tot0), 1u);
         // (the probe only where the order check follows: the fused routing path)
         hipLaunchKernelGGL(k_igd_call_init, dim3((n_init + 255) / 256), dim3(256), 0, st, (unsigned long long *)hits, n_bins, d_unsorted,
                            flag0, d_tot0, n_tot0, qc, qs, qe, fused && !flag0 ? std::min<u32>(nq, ORD_PROBE) : 0u, v.n_chrom);
@@ -1476,7 +1493,8 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         auto route = bnd_lds ? (vec ? k_igd_route<true, true> : k_igd_route<false, true>) : (vec ? k_igd_route<true, false> : k_igd_route<false, false>);
         hipLaunchKernelGGL(route, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom,
                            tl.bnd, tl.chrom_tile_off, tl.route_base, tl.route_len, tl.route_lut, tl.route_n, tl.route_shift, n_tiles,
-                           rt_chunk, reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted);
+                           rt_chunk, reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted,
+                           d_tot ? multisplit_coarse_totals(scratch, n_tiles + 1, nq) : (u32 *)nullptr, multisplit_coarse_shift(n_tiles + 1));
     } else {
         ProfScope p("k_igd_prep_queries", st);
         const u32 n_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));

@@ -293,18 +293,75 @@ static_assert(SP_BINS == SP_TPB, "one thread per tile-local bin (counter reset, 
 // KeyT: u32, or unsigned short when every bin fits 16 bits (2 bytes per element less to read and write in both passes).
 // CLAMP (first pass on raw query columns): a = max((i32)a, 0) -- the start clamp of Igd::count_overlaps (igd.rs:517) applied
 // on the way, so that no prepared copy of the columns is ever written.
-template <bool FINE, class KeyT, bool CLAMP>
+// FOLD: the scan of the bin totals is part of the passes (no k_ms_binscan launch: 12 us + a launch for 24k bins).  The cursors
+// then hold RELATIVE counts (zeroed by the caller with the totals), and
+//   pass A: every workgroup sums the fine totals `tot` into the <= 256 coarse totals and scans them for itself (a base per coarse
+//           bin in LDS: 24k loads that hit L2, while its first tile's elements are in flight) -- a run is reserved at
+//           base + atomicAdd(relative cursor); workgroup w additionally writes the fine offsets bin_off[] of coarse bin w, w +
+//           grid, ... (what pass B and the consumer read) and notes the heavy bins;
+//   pass B: a run is reserved at bin_off[bin] + atomicAdd(relative cursor).
+template <bool FINE, class KeyT, bool CLAMP, bool FOLD = false>
 __global__ void __launch_bounds__(SP_TPB)
 k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
              u32 shift, u32 drop_bin, u32 *__restrict__ cursor, KeyT *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if,
-             SetTags tags) {
+             SetTags tags, const u32 *__restrict__ tot = nullptr, u32 n_bins = 0, u32 *__restrict__ bin_off = nullptr, HeavyBins heavy = HeavyBins{},
+             const u32 *__restrict__ ctot = nullptr) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 sp_lds[];
     u32 *s_k = sp_lds, *s_a = s_k + SP_TILE, *s_b = s_a + SP_TILE;
     u32 *cnt = s_b + SP_TILE, *toff = cnt + SP_BINS, *gbase = toff + SP_BINS;
     __shared__ u32 s_scan[SP_TPB / 64];
     __shared__ u32 s_min;
+    __shared__ u32 s_cbase[FOLD && !FINE ? 257 : 1];  // exclusive offsets of the coarse bins (+ the grand total)
     const u32 n_tiles = (n + SP_TILE - 1) / SP_TILE;
+    // One workgroup per CU (its tile fills the LDS), so nothing else hides a tile's memory latencies: the NEXT tile's elements
+    // are requested into a second set of registers before the current tile is ranked (in flight during ranking, reservation,
+    // LDS reorder and write-out), and a bin's run reservation -- a global atomic WITH return -- is only waited for after the
+    // tile has been reordered in LDS (the reorder needs the tile-local layout, not the global base).  Before: every tile paid a
+    // load round trip and an atomic round trip back to back, 13 us per 8192-element tile (164 KB moved: 12.6 GB/s per CU).
+    u32 nk[SP_ITEMS], na[SP_ITEMS], nb[SP_ITEMS];
+    auto request = [&](u32 tile) {
+        const u32 base = tile * SP_TILE;
+#pragma unroll
+        for (int j = 0; j < SP_ITEMS; ++j) {
+            const u32 i = base + (u32)j * SP_TPB + threadIdx.x;
+            const u32 ic = i < n ? i : n - 1u;  // (unconditional loads: the wait counts stay exact; the copy is ignored)
+            nk[j] = (u32)key[ic];
+            if (FINE) {
+                const uint2 p = ab_in[ic];
+                na[j] = p.x;
+                nb[j] = p.y;
+            } else {
+                na[j] = a[ic];
+                nb[j] = b[ic];
+            }
+        }
+    };
+    if (blockIdx.x < n_tiles) request(blockIdx.x);
+    if constexpr (FOLD && !FINE) {
+        // the coarse totals were left by the caller's counting kernel (multisplit_coarse_totals)
+        const u32 n_coarse = ((n_bins - 1u) >> shift) + 1u;
+        u32 grand;
+        const u32 mine = threadIdx.x < n_coarse ? ctot[threadIdx.x] : 0u;  // coarse bin threadIdx.x
+        const u32 ex = block_exclusive_scan<SP_TPB>(mine, s_scan, grand);
+        if (threadIdx.x < 256u) s_cbase[threadIdx.x] = ex;
+        if (threadIdx.x == 0) s_cbase[256] = grand;
+        __syncthreads();
+        // fine offsets of this workgroup's coarse bins (2^shift <= 256 fine bins each) + the heavy-bin list
+        for (u32 jc = blockIdx.x; jc < n_coarse; jc += gridDim.x) {
+            const u32 fb = (jc << shift) + threadIdx.x;
+            const bool in = threadIdx.x < (1u << shift) && fb < n_bins;
+            const u32 v = in ? tot[fb] : 0u;
+            u32 tt;
+            const u32 fe = block_exclusive_scan<SP_TPB>(v, s_scan, tt);
+            if (in) {
+                bin_off[fb] = s_cbase[jc] + fe;
+                heavy.note(fb, v);
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) bin_off[n_bins] = s_cbase[256];
+        __syncthreads();  // cnt is the tile loop's again
+    }
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const u32 base = tile * SP_TILE;
         cnt[threadIdx.x] = 0;  // SP_BINS == SP_TPB
@@ -315,22 +372,20 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
         for (int j = 0; j < SP_ITEMS; ++j) {
             const u32 i = base + (u32)j * SP_TPB + threadIdx.x;
             const bool ok = i < n;
-            k[j] = ok ? (u32)key[i] : 0xFFFFFFFFu;
+            k[j] = ok ? nk[j] : 0xFFFFFFFFu;
+            va[j] = ok ? na[j] : 0u;
+            vb[j] = ok ? nb[j] : 0u;
             if (FINE) {
-                const uint2 p = ok ? ab_in[i] : make_uint2(0u, 0u);
-                va[j] = p.x;
-                vb[j] = p.y;
                 // no owner: dropped HERE, not in the first pass -- that pass must fill all n slots of its output (the drop
                 // bin's coarse segment included), or this one would read whatever an earlier call left behind the kept ones
                 if (k[j] == drop_bin) k[j] = 0xFFFFFFFFu;
             } else {
-                va[j] = ok ? a[i] : 0u;
-                vb[j] = ok ? b[i] : 0u;
                 if (CLAMP) va[j] = (i32)va[j] < 0 ? 0u : va[j];
                 tags.apply(i, va[j], vb[j]);  // (the second pass carries the pairs as they are)
             }
             if (k[j] != 0xFFFFFFFFu) kmin = min(kmin, k[j]);
         }
+        if (tile + gridDim.x < n_tiles) request(tile + gridDim.x);
         u32 bin0 = 0;
         if (FINE) {
             // the tile's window of keys starts at its smallest coarse bin
@@ -354,16 +409,22 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
                 rank[j] = atomicAdd(&cnt[x], 1u);
             } else {
                 // outside the tile's window (FINE only): its own slot from the bin's cursor
-                out_ab[atomicAdd(&cursor[k[j]], 1u)] = make_uint2(va[j], vb[j]);
+                out_ab[(FOLD ? bin_off[k[j]] : 0u) + atomicAdd(&cursor[k[j]], 1u)] = make_uint2(va[j], vb[j]);
             }
         }
         __syncthreads();
+        u32 my_cnt, my_base = 0;
         {
-            // tile-local layout + one reserved run per non-empty bin
-            const u32 c = cnt[threadIdx.x];
+            // tile-local layout + one reserved run per non-empty bin (the reservation's answer is picked up after the reorder)
+            my_cnt = cnt[threadIdx.x];
             u32 total;
-            toff[threadIdx.x] = block_exclusive_scan<SP_TPB>(c, s_scan, total);
-            if (c) gbase[threadIdx.x] = atomicAdd(&cursor[FINE ? bin0 + threadIdx.x : threadIdx.x], c);
+            toff[threadIdx.x] = block_exclusive_scan<SP_TPB>(my_cnt, s_scan, total);
+            if (my_cnt) {
+                const u32 bin = FINE ? bin0 + threadIdx.x : threadIdx.x;
+                u32 rel0 = 0;
+                if (FOLD) rel0 = FINE ? bin_off[bin] : s_cbase[bin];
+                my_base = rel0 + atomicAdd(&cursor[bin], my_cnt);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -374,16 +435,22 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             s_a[slot] = va[j];
             s_b[slot] = vb[j];
         }
+        gbase[threadIdx.x] = my_base;
         __syncthreads();
         const u32 staged = toff[SP_BINS - 1] + cnt[SP_BINS - 1];
-        for (u32 j = threadIdx.x; j < staged; j += SP_TPB) {
-            const u32 kk = s_k[j];
-            const u32 x = FINE ? kk - bin0 : kk >> shift;
-            const u32 pos = gbase[x] + (j - toff[x]);
-            out_ab[pos] = make_uint2(s_a[j], s_b[j]);
-            if (!FINE) out_key[pos] = (KeyT)kk;
+#pragma unroll
+        for (int r = 0; r < SP_ITEMS; ++r) {  // (a fixed number of rounds: the compiler then knows how many stores are in flight)
+            const u32 j = threadIdx.x + (u32)r * SP_TPB;
+            if (j < staged) {
+                const u32 kk = s_k[j];
+                const u32 x = FINE ? kk - bin0 : kk >> shift;
+                const u32 pos = gbase[x] + (j - toff[x]);
+                out_ab[pos] = make_uint2(s_a[j], s_b[j]);
+                if (!FINE) out_key[pos] = (KeyT)kk;
+            }
         }
-        __syncthreads();  // LDS reused by the next tile
+        // LDS is reused by the next tile: order the LDS accesses only -- a full barrier would also drain this tile's stores
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -407,6 +474,19 @@ static bool multisplit_two_level(u32 n_bins, u32 n) {
 // where a table_ready caller of the two-level split leaves the bin TOTALS (zeroed by the caller, filled with atomics) instead of
 // per-workgroup rows; null when the split of (n_bins, n) is one-level and wants the table
 u32 *multisplit_totals(void *ws, u32 n_bins, u32 n) { return multisplit_two_level(n_bins, n) ? (u32 *)ws + (size_t)256 * n_bins : nullptr; }
+// words from multisplit_totals() on that such a caller zeroes before it counts: the totals and, behind them, the passes'
+// relative cursors (coarse [1024], fine [n_bins])
+size_t multisplit_zeroed_words(u32 n_bins) { return (size_t)n_bins * 2 + 1024; }
+u32 multisplit_coarse_shift(u32 n_bins) {
+    u32 shift = 0;
+    while (((n_bins - 1) >> shift) >= 256u) ++shift;
+    return shift;
+}
+// (the coarse cursors use the first 256 of their 1024 words: the coarse totals live in the next 256)
+u32 *multisplit_coarse_totals(void *ws, u32 n_bins, u32 n) {
+    u32 *tot = multisplit_totals(ws, n_bins, n);
+    return tot ? tot + n_bins + 256 : nullptr;
+}
 
 // KeyT / CLAMP: see k_split_pass.  table_ready: the caller's own kernel has already counted the keys into the table
 // (multisplit_table(ws), one row of n_bins counters per workgroup of a multisplit_workgroups(n) x MS_TPB grid whose workgroup w
@@ -438,7 +518,9 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
             const void *fns[] = {reinterpret_cast<const void *>(k_ms_hist<KeyT>), reinterpret_cast<const void *>(k_ms_scatter<KeyT, CLAMP>)};
             for (const void *fn : fns) GT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MS_MAX_BINS * 4)));
             const void *sp[] = {reinterpret_cast<const void *>(k_split_pass<false, KeyT, CLAMP>),
-                                reinterpret_cast<const void *>(k_split_pass<true, KeyT, false>)};
+                                reinterpret_cast<const void *>(k_split_pass<true, KeyT, false>),
+                                reinterpret_cast<const void *>(k_split_pass<false, KeyT, CLAMP, true>),
+                                reinterpret_cast<const void *>(k_split_pass<true, KeyT, false, true>)};
             for (const void *fn : sp) GT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds));
             done[dev & 15] = true;
         }
@@ -450,9 +532,12 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
         hipLaunchKernelGGL(k_ms_hist<KeyT>, dim3(n_wg), dim3(MS_TPB), lds, st, key, n, n_bins, chunk, table, run_if);
     }
     const bool two_level = multisplit_two_level(n_bins, n);
-    {
+    // the caller has counted the totals itself (and zeroed the relative cursors behind them: multisplit_zeroed_words): the bin
+    // scan is folded into the two passes
+    const bool fold = table_ready && two_level;
+    if (!fold) {
         ProfScope p("k_ms_scan", st);
-        if (!(table_ready && two_level))  // otherwise the caller has left the totals themselves (multisplit_totals)
+        if (!table_ready || !two_level)  // (a table_ready caller of a one-level split has filled the per-workgroup table)
             hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot, run_if);
         u32 shift = 0;
         while (((n_bins - 1) >> shift) >= 256u) ++shift;
@@ -467,11 +552,22 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
         const u32 tiles = (n + SP_TILE - 1) / SP_TILE;
         const unsigned grid = std::min<u32>(256, tiles);
         ProfScope p("k_split_pass", st);
-        hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n,
-                           shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags);
-        hipLaunchKernelGGL((k_split_pass<true, KeyT, false>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
-                           (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if,
-                           SetTags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu});
+        const SetTags no_tags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (fold) {
+            hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP, true>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr,
+                               n, shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)tot, n_bins, bin_off,
+                               heavy ? *heavy : HeavyBins{}, (const u32 *)(cur_a + 256));
+            hipLaunchKernelGGL((k_split_pass<true, KeyT, false, true>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
+                               (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if,
+                               no_tags, (const u32 *)nullptr, n_bins, bin_off, HeavyBins{}, (const u32 *)nullptr);
+        } else {
+            hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n,
+                               shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)nullptr, 0u, (u32 *)nullptr, HeavyBins{},
+                               (const u32 *)nullptr);
+            hipLaunchKernelGGL((k_split_pass<true, KeyT, false>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
+                               (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if,
+                               no_tags, (const u32 *)nullptr, 0u, (u32 *)nullptr, HeavyBins{}, (const u32 *)nullptr);
+        }
     } else {
         ProfScope p("k_ms_scatter", st);
         hipLaunchKernelGGL((k_ms_scatter<KeyT, CLAMP>), dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off,
