@@ -396,6 +396,8 @@ struct gtars_igd {
     // static routing table (IgdTiles::route_*)
     DevBuf<u32> route_lut, route_base, route_len;
     u32 route_n = 0, route_shift = 0;
+    DevBuf<u32> route_flut, route_kq, route_fbase;  // IgdTiles::route_f*
+    u32 route_fn = 0, route_fshift = 0;
     // IgdTiles::pme_file, built on the first binary count with min_overlap == 1
     mutable std::mutex pme_mu;
     mutable DevBuf<i32> pme_file;
@@ -471,6 +473,11 @@ struct gtars_igd {
         t.route_len = route_len.p;
         t.route_n = route_n;
         t.route_shift = route_shift;
+        t.route_flut = route_fn ? route_flut.p : nullptr;
+        t.route_kq = route_kq.p;
+        t.route_fbase = route_fbase.p;
+        t.route_fn = route_fn;
+        t.route_fshift = route_fshift;
         t.n_tiles = n_tiles;
         return t;
     }
@@ -530,6 +537,42 @@ struct gtars_igd {
                 if ((st = route_len.upload(len))) return st;
                 route_n = base[n_chrom];
                 route_shift = sh;
+            }
+            // the fine tables (IgdTiles::route_f*), when they fit the routing kernel's LDS next to its 16-bit counters
+            u32 fsh0 = 16;
+            if (const char *e = getenv("GTARS_IGD_ROUTE_FSHIFT_MIN")) fsh0 = (u32)std::min(31, std::max(16, atoi(e)));  // tests: coarse buckets
+            for (u32 fsh = fsh0; fsh < 32; ++fsh) {
+                u64 nf = 0;
+                std::vector<u32> fbase(n_chrom + 1, 0);
+                for (u32 c = 0; c < n_chrom; ++c) {
+                    const u64 nb = len[c] ? (((u64)len[c] - 1) >> fsh) + 2 : 1;
+                    nf += nb;
+                    fbase[c + 1] = (u32)std::min<u64>(nf, 0xFFFFFFFFu);
+                }
+                if (igd_route_fine_lds_bytes(n_tiles, n_chrom, nf) > 160 * 1024 - 64) continue;
+                std::vector<unsigned short> fl(((size_t)nf + 2) & ~(size_t)1, 0), kq(((size_t)n_tiles + 2) & ~(size_t)1, 0);
+                const u32 mask = (u32)((1ull << fsh) - 1);
+                for (u32 c = 0; c < n_chrom; ++c) {
+                    u32 t = cto[c];
+                    const u32 t1 = cto[c + 1], nb = fbase[c + 1] - fbase[c];
+                    for (u32 j = 0; j < nb; ++j) {
+                        const u64 x = (u64)j << fsh;
+                        while (t < t1 && (u64)hb[t] - 1 < x) ++t;  // first tile with key >= x
+                        fl[fbase[c] + j] = (unsigned short)t;
+                    }
+                    for (u32 k = cto[c]; k < t1; ++k) kq[k] = (unsigned short)(((hb[k] - 1u) & mask) >> (fsh - 16));
+                }
+                auto pack = [](const std::vector<unsigned short> &v) {
+                    std::vector<u32> w(v.size() / 2);
+                    for (size_t i = 0; i < w.size(); ++i) w[i] = (u32)v[2 * i] | ((u32)v[2 * i + 1] << 16);
+                    return w;
+                };
+                if ((st = route_flut.upload(pack(fl)))) return st;
+                if ((st = route_kq.upload(pack(kq)))) return st;
+                if ((st = route_fbase.upload(fbase))) return st;
+                route_fn = (u32)nf;
+                route_fshift = fsh;
+                break;
             }
         }
         return GTARS_OK;
@@ -2127,6 +2170,9 @@ void gtars_igd_free(gtars_igd_t *g) {
     g->route_lut.release();
     g->route_base.release();
     g->route_len.release();
+    g->route_flut.release();
+    g->route_kq.release();
+    g->route_fbase.release();
     g->pme_file.release();
     delete g;
 }

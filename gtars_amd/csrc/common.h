@@ -259,7 +259,8 @@ struct HeavyBins {
 };
 gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
                               uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if = nullptr,
-                              bool table_ready = false, const u32 *set_bounds = nullptr, const HeavyBins *heavy = nullptr);
+                              bool table_ready = false, const u32 *set_bounds = nullptr, const HeavyBins *heavy = nullptr,
+                              u32 n_count_rows = 0);  // table_ready + two-level: rows the caller's counting kernel wrote
 // set_bounds (host, 3 values; null: one set): the input holds up to 4 row ranges ("sets") -- first row of set 1, 2, 3, 0xFFFFFFFF
 // for a set that does not exist; the set of a row leaves in bit 31 of its pair (b: set & 1, a: set >> 1; see SetTags, sort.hip)
 u32 multisplit_workgroups(u32 n);
@@ -269,6 +270,9 @@ u32 *multisplit_table(void *ws);
 u32 *multisplit_totals(void *ws, u32 n_bins, u32 n);
 // ... and the totals of the split's coarse bins (bin >> multisplit_coarse_shift(n_bins), <= 256 of them) here, inside the zeroed words
 u32 *multisplit_coarse_totals(void *ws, u32 n_bins, u32 n);
+// ... and its fine counts as one ROW per counting workgroup at multisplit_table(ws): 16-bit counts packed two per word (a
+// workgroup counts at most 65535 elements), multisplit_row_words(n_bins) words per row (zero-padded to whole 16-byte vectors)
+__host__ __device__ inline u32 multisplit_row_words(u32 n_bins) { return (((n_bins + 1u) >> 1) + 3u) & ~3u; }
 u32 multisplit_coarse_shift(u32 n_bins);
 size_t multisplit_zeroed_words(u32 n_bins);  // what such a caller zeroes from multisplit_totals() on (totals + relative cursors)
 
@@ -297,6 +301,15 @@ struct IgdTiles {
     // null when the database has more than 65535 tiles
     const u32 *route_lut, *route_base, *route_len;
     u32 route_n, route_shift;
+    // FINE routing tables (null when they would not fit the routing kernel's LDS next to its counters): buckets of 2^route_fshift
+    // (>= 2^16) positions, so fine that a bucket holds about one tile boundary, and the boundaries themselves as 16-bit offsets
+    // inside their bucket.  key[t] = bnd[t] - 1 (the last position tile t owns); route_flut[route_fbase[c] + j] (u16, two per
+    // word) = first tile of chromosome c with key >= j << route_fshift; route_kq[t] (u16, two per word) = (key[t] mod
+    // 2^route_fshift) >> (route_fshift - 16): the owner of (c, s) is the first tile t in [flut[j], flut[j + 1]), j = s >>
+    // route_fshift, with kq[t] > sq -- or == sq and, when route_fshift > 16, bnd[t] > s (a global read, one query in 2^16) -- else
+    // flut[j + 1].  One or two LDS probes instead of a binary search of the chromosome's bounds.
+    const u32 *route_flut, *route_kq, *route_fbase;
+    u32 route_fn, route_fshift;
     u32 n_tiles;
 };
 // words per tile: a 12-word descriptor + the two direct-mapped search tables (u16 entries, buckets + 2 of them): over the
@@ -314,6 +327,7 @@ static_assert((IGD_LUT_P_NB & (IGD_LUT_P_NB - 1)) == 0 && IGD_LUT_P_NB >= 256 &&
 constexpr u32 IGD_TILE_TAB_WORDS = (12 + (IGD_LUT_S_NB + 2) / 2 + (IGD_LUT_P_NB + 2) / 2 + 3) / 4 * 4;  // 784 words: 3 KB per 2048 records
 gtars_status launch_igd_tile_tables(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
                                     const i32 *tile_carry, u32 n_tiles, i32 *pm, unsigned short *files16, u32 *tile_tab, hipStream_t st);
+size_t igd_route_fine_lds_bytes(u32 n_tiles, u32 n_chrom, u64 n_fine);  // LDS of the routing kernel with the fine tables
 bool igd_sweep_supported(const IgdView &v, u64 nq);
 size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom);
 size_t igd_pme_ws_bytes(u32 n);

@@ -168,50 +168,63 @@ k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const
 // a 10-step binary search of the chromosome's tile bounds.
 constexpr int RT_TPB = 1024;
 constexpr int RT_U = 4;  // queries per thread and step (their loads and searches overlap)
-// bnd_lds: the tile bounds in LDS too (4 bytes per tile on top of the 2 of the counters: databases up to ~52M records); without
-// them the last steps of the owner search read the bounds from global memory (L2-resident: 4 bytes per tile), which carries the
-// fused routing to 65534 tiles = 134M records (before: the two-kernel preparation from 52M, a full radix sort of the batch from
-// 75M records: 1.8 ms instead of 0.9 for config 3's batch against 100M records)
-size_t igd_route_lds_bytes(u32 n_tiles, u32 n_chrom, u32 n_lut, bool bnd_lds) {
-    return ((bnd_lds ? (size_t)n_tiles : 0) + 3 * (size_t)n_chrom + 2 + ((size_t)n_lut + 1) / 2 + ((size_t)n_tiles + 2) / 2) * 4;
+// Two forms of the owner search:
+//   FINE (databases whose fine tables fit the LDS next to the counters: up to ~36k tiles = 75M records): IgdTiles::route_f* --
+//     buckets of 2^route_fshift positions with about one tile boundary each, the boundaries as 16-bit offsets inside their
+//     bucket: the pair of table entries by one 4-byte LDS read, then one or two 2-byte probes (round 3 kept the 4-byte bounds
+//     themselves in LDS behind a 4096-entry table and halved ~6 candidates: 2 + ~4 dependent LDS round trips);
+//   otherwise the 4096-entry table and a binary search of the bounds in global memory (L2-resident: 4 bytes per tile), which
+//     carries the fused routing to 65534 tiles = 134M records.
+// LDS image of the routing kernel: {table base, last bound} per chromosome | table (u16) | [FINE: boundary offsets (u16)] |
+// counters (u16), every section on a 16-byte boundary (the tables are copied by 16-byte loads)
+__host__ __device__ inline u32 rt_up4(u32 words) { return (words + 3u) & ~3u; }
+size_t igd_route_lds_bytes(u32 n_tiles, u32 n_chrom, u32 n_lut) {  // (bounds in global memory)
+    return ((size_t)rt_up4(2 * (n_chrom + 1)) + rt_up4((n_lut + 2) / 2) + (n_tiles + 2) / 2) * 4;
 }
-template <bool VEC, bool BND_LDS = true>
+size_t igd_route_fine_lds_bytes(u32 n_tiles, u32 n_chrom, u64 n_fine) {
+    if (n_fine > 0x7FFFFFF0ull) return ~(size_t)0;
+    return ((size_t)rt_up4(2 * (n_chrom + 1)) + rt_up4(((u32)n_fine + 2) / 2) + rt_up4((n_tiles + 2) / 2) + (n_tiles + 2) / 2) * 4;
+}
+template <bool VEC, bool FINE>
 __global__ void __launch_bounds__(RT_TPB)
 k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
             const u32 *__restrict__ bnd, const u32 *__restrict__ chrom_tile_off, const u32 *__restrict__ route_base,
             const u32 *__restrict__ route_len, const u32 *__restrict__ route_lut, u32 n_lut, u32 route_shift, u32 n_tiles, u32 chunk,
             unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, const u32 *__restrict__ run_if,
-            u32 *__restrict__ ctot, u32 cshift) {
+            u32 *__restrict__ ctot, u32 cshift, const u32 *__restrict__ route_kq) {
     if (run_if && *run_if == 0) return;  // the batch is in owner order (k_igd_order_check): nothing to route, the sweep takes it as it lies
     extern __shared__ u32 rt_lds[];
-    u32 *s_bnd = rt_lds, *s_cto = s_bnd + (BND_LDS ? n_tiles : 0u), *s_base = s_cto + n_chrom + 1, *s_len = s_base + n_chrom + 1;
-    u32 *s_lutw = s_len + n_chrom;
-    u32 *bins = s_lutw + (n_lut + 1) / 2;  // (n_tiles + 2) / 2 words: bin b in half (b & 1) of word b >> 1
+    // FINE: route_base / route_lut / n_lut / route_shift are the FINE tables' (IgdTiles::route_fbase / route_flut / route_fn /
+    // route_fshift); {base, len} pairs per chromosome | table | [boundary offsets] | counters
+    uint2 *s_bl = reinterpret_cast<uint2 *>(rt_lds);
+    u32 *s_lutw = rt_lds + rt_up4(2 * (n_chrom + 1));
+    u32 *s_kqw = s_lutw + rt_up4((n_lut + 2) / 2);
+    u32 *bins = s_kqw + (FINE ? rt_up4((n_tiles + 2) / 2) : 0u);  // (n_tiles + 2) / 2 words: bin b in half (b & 1) of word b >> 1
     const unsigned short *s_lut = reinterpret_cast<const unsigned short *>(s_lutw);
+    const unsigned short *s_kq = reinterpret_cast<const unsigned short *>(s_kqw);
 #if IGD_STAMPS
     u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
-    if (BND_LDS) {
-        // the tile bounds: 16-byte loads, four in flight per thread (a dword-per-step copy loop is a chain of L2 round trips)
-        const u32 n4 = n_tiles >> 2;
-        const uint4 *src = reinterpret_cast<const uint4 *>(bnd);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_bnd);
-        for (u32 i0 = threadIdx.x; i0 < n4; i0 += RT_TPB * 4) {
-            uint4 x[4];
+    for (u32 c = threadIdx.x; c <= n_chrom; c += RT_TPB) s_bl[c] = make_uint2(route_base[c], c < n_chrom ? route_len[c] : 0u);
+    {
+        // the tables: 16-byte loads, four in flight per thread (a dword-per-step copy loop is a chain of L2 round trips)
+        auto copy = [&](const u32 *__restrict__ src, u32 *dst, u32 n_words) {  // (both 16-byte aligned; n_words any)
+            const u32 n4 = n_words >> 2;
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+            for (u32 i0 = threadIdx.x; i0 < n4; i0 += RT_TPB * 4) {
+                uint4 x[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = i0 + (u32)k * RT_TPB < n4 ? src[i0 + (u32)k * RT_TPB] : make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < 4; ++k) x[k] = i0 + (u32)k * RT_TPB < n4 ? s4[i0 + (u32)k * RT_TPB] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (i0 + (u32)k * RT_TPB < n4) dst[i0 + (u32)k * RT_TPB] = x[k];
-        }
-        for (u32 t = (n4 << 2) + threadIdx.x; t < n_tiles; t += RT_TPB) s_bnd[t] = bnd[t];
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + (u32)k * RT_TPB < n4) d4[i0 + (u32)k * RT_TPB] = x[k];
+            }
+            for (u32 w = (n4 << 2) + threadIdx.x; w < n_words; w += RT_TPB) dst[w] = src[w];
+        };
+        copy(route_lut, s_lutw, (n_lut + 1) / 2);
+        if (FINE) copy(route_kq, s_kqw, (n_tiles + 1) / 2);
     }
-    for (u32 c = threadIdx.x; c <= n_chrom; c += RT_TPB) {
-        s_cto[c] = chrom_tile_off[c];
-        s_base[c] = route_base[c];
-        if (c < n_chrom) s_len[c] = route_len[c];
-    }
-    for (u32 w = threadIdx.x; w < (n_lut + 1) / 2; w += RT_TPB) s_lutw[w] = route_lut[w];
     for (u32 w = threadIdx.x; w < (n_tiles + 2) / 2; w += RT_TPB) bins[w] = 0;
     __syncthreads();
     STAMP(0);
@@ -261,25 +274,54 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
         for (int u = 0; u < RT_U; ++u) {
             // the owner: first tile of the chromosome whose bound is > start, bracketed by the static table
             l[u] = h[u] = 0;
-            owned[u] = c[u] < n_chrom && (u32)s[u] < s_len[c[u]];  // otherwise: invalid, unknown chromosome or past every bound
+            const uint2 bl = s_bl[min(c[u], n_chrom)];  // {table base, last bound} of the chromosome
+            owned[u] = c[u] < n_chrom && (u32)s[u] < bl.y;  // otherwise: invalid, unknown chromosome or past every bound
             if (owned[u]) {
-                const u32 j = s_base[c[u]] + ((u32)s[u] >> route_shift);
-                l[u] = s_lut[j];
-                h[u] = s_lut[j + 1];
+                const u32 j = bl.x + ((u32)s[u] >> route_shift);
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                typedef us2 us2_a2 __attribute__((aligned(2)));
+                typedef const __attribute__((address_space(3))) us2_a2 *lds_us2;
+                const us2 p = *(lds_us2)(uintptr_t)(s_lut + j);  // both entries by one 4-byte read (2-byte aligned)
+                l[u] = p.x;
+                h[u] = p.y;
             }
         }
-        bool more = true;
-        while (more) {
-            more = false;
+        if constexpr (FINE) {
+            // tiles [l, h) have their boundary inside the query's bucket: the first one whose 16-bit offset is > the query's --
+            // or equal and, with buckets wider than 2^16, really >= (the exact bound, global memory: one query in 2^16)
+            const u32 qsh = route_shift - 16u, msk = (1u << route_shift) - 1u;
+            bool more = true;
+            while (more) {
+                more = false;
 #pragma unroll
-            for (int u = 0; u < RT_U; ++u) {
-                if (l[u] < h[u]) {
-                    const u32 mid = l[u] + ((h[u] - l[u]) >> 1);
-                    if ((BND_LDS ? s_bnd[mid] : bnd[mid]) <= (u32)s[u])
-                        l[u] = mid + 1;
-                    else
-                        h[u] = mid;
-                    more = more || l[u] < h[u];
+                for (int u = 0; u < RT_U; ++u) {
+                    if (l[u] < h[u]) {
+                        const u32 kq = s_kq[l[u]], sq = ((u32)s[u] & msk) >> qsh;
+                        bool below = kq < sq;
+                        if (kq == sq && qsh) below = bnd[l[u]] <= (u32)s[u];
+                        if (below) {
+                            l[u] += 1;
+                            more = more || l[u] < h[u];
+                        } else {
+                            h[u] = l[u];
+                        }
+                    }
+                }
+            }
+        } else {
+            bool more = true;
+            while (more) {
+                more = false;
+#pragma unroll
+                for (int u = 0; u < RT_U; ++u) {
+                    if (l[u] < h[u]) {
+                        const u32 mid = l[u] + ((h[u] - l[u]) >> 1);
+                        if (bnd[mid] <= (u32)s[u])
+                            l[u] = mid + 1;
+                        else
+                            h[u] = mid;
+                        more = more || l[u] < h[u];
+                    }
                 }
             }
         }
@@ -302,31 +344,35 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
     __syncthreads();
     STAMP(2);
     if (tot) {
-        // the two-level split only needs the bin totals (its passes reserve runs with atomics on the bins' cursors).  Every
-        // workgroup starts at a different bin: walking the bins in the same order at the same time put all 256 workgroups'
-        // atomics on the same few cache lines (the flush was 12 % of the kernel by the in-kernel stamps)
-        const u32 nb = n_tiles + 1, rot = (u32)(((u64)blockIdx.x * nb) / gridDim.x);
-        for (u32 i = threadIdx.x; i < nb; i += RT_TPB) {
-            u32 b = i + rot;
-            b = b >= nb ? b - nb : b;
-            const u32 x = (bins[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu;
-            if (x) atomicAdd(&tot[b], x);
+        // Two-level split: the workgroup's counters leave as they are -- a ROW of packed 16-bit counts, plain 16-byte stores --
+        // and the split's first pass sums the rows of the bins it needs (multisplit_pairs, FOLD).  Round 3 added every non-zero
+        // counter to a global total: 20k atomics per workgroup, 5M per call, a third of this kernel by the in-kernel stamps.
+        const u32 nb = n_tiles + 1, rw = multisplit_row_words(nb), have = (n_tiles + 2) / 2;
+        u32 *row = table + (size_t)blockIdx.x * rw;  // (`tot` only says that the split is two-level)
+        for (u32 w4 = threadIdx.x * 4u; w4 < rw; w4 += RT_TPB * 4u) {
+            uint4 x;
+            x.x = w4 + 0 < have ? bins[w4 + 0] : 0u;
+            x.y = w4 + 1 < have ? bins[w4 + 1] : 0u;
+            x.z = w4 + 2 < have ? bins[w4 + 2] : 0u;
+            x.w = w4 + 3 < have ? bins[w4 + 3] : 0u;
+            *reinterpret_cast<uint4 *>(row + w4) = x;
         }
-        // ... and the totals of the split's COARSE bins (2^cshift fine bins each, <= 256 of them): the first pass of the split
-        // scans these for itself instead of summing 24k fine totals again (multisplit_pairs, FOLD)
-        if (ctot) {
-            const u32 n_coarse = ((nb - 1u) >> cshift) + 1u;
-            u32 j = threadIdx.x + (rot >> cshift);
-            j = j >= n_coarse ? j - n_coarse : j;
-            if (threadIdx.x < n_coarse && j < n_coarse) {
-                u32 sum = 0;
-                const u32 b0 = j << cshift, b1 = min(nb, b0 + (1u << cshift));
-                for (u32 w = b0 >> 1; w < (b1 + 1u) >> 1; ++w) {  // (b0 is even: cshift >= 3)
+        // ... and the totals of the split's COARSE bins (2^cshift fine bins each, <= 256 of them), which every workgroup of that
+        // pass needs: thread t sums quarter (t & 3) of coarse bin t >> 2 from the LDS counters, one atomic per coarse bin
+        {
+            const u32 n_coarse = ((nb - 1u) >> cshift) + 1u, per = 1u << (cshift - 2u);  // (cshift >= 3: per is even)
+            const u32 j = threadIdx.x >> 2;
+            u32 sum = 0;
+            if (j < n_coarse) {
+                const u32 b0 = (j << cshift) + (threadIdx.x & 3u) * per, b1 = min(nb, b0 + per);
+                for (u32 w = b0 >> 1; 2u * w < b1; ++w) {
                     const u32 x = bins[w];
                     sum += (x & 0xFFFFu) + (2u * w + 1u < b1 ? x >> 16 : 0u);
                 }
-                if (sum) atomicAdd(&ctot[j], sum);
             }
+            sum += (u32)__shfl_xor((int)sum, 1, 64);
+            sum += (u32)__shfl_xor((int)sum, 2, 64);
+            if ((threadIdx.x & 3u) == 0 && j < n_coarse && sum) atomicAdd(&ctot[j], sum);
         }
     } else {
         u32 *row = table + (size_t)blockIdx.x * (n_tiles + 1);
@@ -1384,14 +1430,15 @@ gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, con
     return GTARS_OK;
 }
 
-// the fused routing kernel can serve this database: with the tile bounds in LDS (bnd_lds) or, for larger databases, in global
-// memory -- up to 65534 tiles (16-bit owner keys)
-static bool igd_fused_route_fits(const IgdView &v, const IgdTiles &tl, bool *bnd_lds) {
+// the fused routing kernel can serve this database: with the fine tables in LDS or, for larger databases, the tile bounds in
+// global memory -- up to 65534 tiles (16-bit owner keys)
+static bool igd_fused_route_fits(const IgdView &v, const IgdTiles &tl, bool *fine) {
     if (!tl.route_lut || getenv("GTARS_IGD_NO_FUSED_ROUTE") || tl.n_tiles + 1 > MS_MAX_BINS_2L) return false;
     const size_t limit = 160 * 1024 - 64;
-    const bool with_bnd = igd_route_lds_bytes(tl.n_tiles, v.n_chrom, tl.route_n, true) <= limit && !getenv("GTARS_IGD_ROUTE_BND_GLOBAL");
-    if (bnd_lds) *bnd_lds = with_bnd;
-    return with_bnd || igd_route_lds_bytes(tl.n_tiles, v.n_chrom, tl.route_n, false) <= limit;
+    const bool with_fine = tl.route_flut && igd_route_fine_lds_bytes(tl.n_tiles, v.n_chrom, tl.route_fn) <= limit &&
+                           !getenv("GTARS_IGD_ROUTE_BND_GLOBAL");
+    if (fine) *fine = with_fine;
+    return with_fine || igd_route_lds_bytes(tl.n_tiles, v.n_chrom, tl.route_n) <= limit;
 }
 static bool igd_bucket_path(const IgdView &v, const IgdTiles &tl) {
     // queries grouped by owner tile in one partition: through the fused routing kernel (up to 65534 tiles = 134M records), or
@@ -1443,9 +1490,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     // chunk fits its 16-bit counters
     u32 rt_wg = multisplit_workgroups(nq);
     u32 rt_chunk = multisplit_chunk(nq);  // a multiple of the 4 queries a lane takes per step
-    bool bnd_lds = true;
-    const bool route_fits = igd_fused_route_fits(v, tl, &bnd_lds);
-    const size_t rt_lds = igd_route_lds_bytes(n_tiles, v.n_chrom, tl.route_n, bnd_lds);
+    bool fine = false;
+    const bool route_fits = igd_fused_route_fits(v, tl, &fine);
+    const size_t rt_lds = fine ? igd_route_fine_lds_bytes(n_tiles, v.n_chrom, tl.route_fn) : igd_route_lds_bytes(n_tiles, v.n_chrom, tl.route_n);
     int dev = 0, cus = 256;
     GT_HIP(hipGetDevice(&dev));
     GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1490,11 +1537,13 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
                                v.n_chrom, d_unsorted, cq_off);
         }
         ProfScope p("k_igd_route", st);
-        auto route = bnd_lds ? (vec ? k_igd_route<true, true> : k_igd_route<false, true>) : (vec ? k_igd_route<true, false> : k_igd_route<false, false>);
-        hipLaunchKernelGGL(route, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom,
-                           tl.bnd, tl.chrom_tile_off, tl.route_base, tl.route_len, tl.route_lut, tl.route_n, tl.route_shift, n_tiles,
-                           rt_chunk, reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted,
-                           d_tot ? multisplit_coarse_totals(scratch, n_tiles + 1, nq) : (u32 *)nullptr, multisplit_coarse_shift(n_tiles + 1));
+        auto route = fine ? (vec ? k_igd_route<true, true> : k_igd_route<false, true>) : (vec ? k_igd_route<true, false> : k_igd_route<false, false>);
+        hipLaunchKernelGGL(route, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom, tl.bnd, tl.chrom_tile_off,
+                           fine ? tl.route_fbase : tl.route_base, tl.route_len, fine ? tl.route_flut : tl.route_lut,
+                           fine ? tl.route_fn : tl.route_n, fine ? tl.route_fshift : tl.route_shift, n_tiles, rt_chunk,
+                           reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted,
+                           d_tot ? multisplit_coarse_totals(scratch, n_tiles + 1, nq) : (u32 *)nullptr, multisplit_coarse_shift(n_tiles + 1),
+                           tl.route_kq);
     } else {
         ProfScope p("k_igd_prep_queries", st);
         const u32 n_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
@@ -1522,7 +1571,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         // kernels for one that is not, and the sweep takes its inputs accordingly.
         // K1 (multisplit): (start, end) pairs grouped by owner tile; bin_off[t], bin_off[t + 1] bound tile t's queries
         gtars_status s1 = fused ? multisplit_pairs(perm, true, qs, qe, true, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
-                                                   scratch, scratch_bytes, st, d_unsorted, true, set_bounds, &heavy)
+                                                   scratch, scratch_bytes, st, d_unsorted, true, set_bounds, &heavy, rt_wg)
                                 : multisplit_pairs(perm, false, ks, ke, false, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
                                                    scratch, scratch_bytes, st, d_unsorted, false, set_bounds, &heavy);  // ss, se adjacent: 2 * nq words
         if (s1) return s1;

@@ -295,17 +295,17 @@ static_assert(SP_BINS == SP_TPB, "one thread per tile-local bin (counter reset, 
 // on the way, so that no prepared copy of the columns is ever written.
 // FOLD: the scan of the bin totals is part of the passes (no k_ms_binscan launch: 12 us + a launch for 24k bins).  The cursors
 // then hold RELATIVE counts (zeroed by the caller with the totals), and
-//   pass A: every workgroup sums the fine totals `tot` into the <= 256 coarse totals and scans them for itself (a base per coarse
-//           bin in LDS: 24k loads that hit L2, while its first tile's elements are in flight) -- a run is reserved at
-//           base + atomicAdd(relative cursor); workgroup w additionally writes the fine offsets bin_off[] of coarse bin w, w +
-//           grid, ... (what pass B and the consumer read) and notes the heavy bins;
+//   pass A: every workgroup scans the <= 256 coarse totals (left by the caller's counting kernel) for itself: a base per coarse
+//           bin in LDS -- a run is reserved at base + atomicAdd(relative cursor); workgroup w additionally sums the counting
+//           workgroups' rows over the fine bins of coarse bin w, w + grid, ..., scans them and writes the fine offsets bin_off[]
+//           (what pass B and the consumer read), and notes the heavy bins;
 //   pass B: a run is reserved at bin_off[bin] + atomicAdd(relative cursor).
 template <bool FINE, class KeyT, bool CLAMP, bool FOLD = false>
 __global__ void __launch_bounds__(SP_TPB)
 k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
              u32 shift, u32 drop_bin, u32 *__restrict__ cursor, KeyT *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if,
-             SetTags tags, const u32 *__restrict__ tot = nullptr, u32 n_bins = 0, u32 *__restrict__ bin_off = nullptr, HeavyBins heavy = HeavyBins{},
-             const u32 *__restrict__ ctot = nullptr) {
+             SetTags tags, const u32 *__restrict__ rows = nullptr, u32 n_bins = 0, u32 *__restrict__ bin_off = nullptr, HeavyBins heavy = HeavyBins{},
+             const u32 *__restrict__ ctot = nullptr, u32 n_rows = 0) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     extern __shared__ u32 sp_lds[];
     u32 *s_k = sp_lds, *s_a = s_k + SP_TILE, *s_b = s_a + SP_TILE;
@@ -349,9 +349,38 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
         __syncthreads();
         // fine offsets of this workgroup's coarse bins (2^shift <= 256 fine bins each) + the heavy-bin list
         for (u32 jc = blockIdx.x; jc < n_coarse; jc += gridDim.x) {
+            // the fine totals of coarse bin jc = the column sums of the counting workgroups' rows (16-bit counts, two per word):
+            // 2^shift / 8 16-byte vectors per row, as many rows side by side as the workgroup has threads for, partial sums
+            // combined in LDS
+            const u32 vpr = (1u << shift) >> 3, rw = multisplit_row_words(n_bins), w0 = (jc << shift) >> 1;  // (shift >= 3)
+            cnt[threadIdx.x] = 0;  // (2^shift <= 256 <= SP_BINS counters)
+            __syncthreads();
+            const u32 vec = threadIdx.x % vpr, wv = w0 + 4u * vec;
+            for (u32 r0 = 0; r0 < n_rows; r0 += 4u * (SP_TPB / vpr)) {
+                uint4 x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32 r = r0 + (u32)q * (SP_TPB / vpr) + threadIdx.x / vpr;
+                    x[q] = r < n_rows && wv < rw ? *reinterpret_cast<const uint4 *>(rows + (size_t)r * rw + wv) : make_uint4(0, 0, 0, 0);
+                }
+                u32 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    lo[0] += x[q].x & 0xFFFFu, hi[0] += x[q].x >> 16;
+                    lo[1] += x[q].y & 0xFFFFu, hi[1] += x[q].y >> 16;
+                    lo[2] += x[q].z & 0xFFFFu, hi[2] += x[q].z >> 16;
+                    lo[3] += x[q].w & 0xFFFFu, hi[3] += x[q].w >> 16;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (lo[k]) atomicAdd(&cnt[8u * vec + 2u * k], lo[k]);
+                    if (hi[k]) atomicAdd(&cnt[8u * vec + 2u * k + 1u], hi[k]);
+                }
+            }
+            __syncthreads();
             const u32 fb = (jc << shift) + threadIdx.x;
             const bool in = threadIdx.x < (1u << shift) && fb < n_bins;
-            const u32 v = in ? tot[fb] : 0u;
+            const u32 v = in ? cnt[threadIdx.x] : 0u;
             u32 tt;
             const u32 fe = block_exclusive_scan<SP_TPB>(v, s_scan, tt);
             if (in) {
@@ -455,8 +484,13 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
 }
 
 // table [256][n_bins] | tot [n_bins] | cursors (coarse [1024], fine [n_bins]) | first-level output: keys [n], pairs [n]
+// (the table region also holds a table_ready caller's rows of packed 16-bit counts: one row per counting workgroup -- at most
+// max(512, n / 65532 + 2) of them, a workgroup counts <= 65535 elements -- of multisplit_row_words(n_bins) words)
+static size_t multisplit_table_words(u32 n_bins, u32 n) {
+    return std::max<size_t>((size_t)256 * n_bins, (size_t)std::max<u32>(512u, n / 65532u + 2u) * multisplit_row_words(n_bins));
+}
 size_t multisplit_ws_bytes(u32 n_bins, u32 n) {
-    return ((size_t)256 * n_bins + 2 * (size_t)n_bins + 1024 + 256) * 4 + (size_t)n * 12 + 256;
+    return (multisplit_table_words(n_bins, n) + 2 * (size_t)n_bins + 1024 + 256) * 4 + (size_t)n * 12 + 256;
 }
 
 // elements per workgroup of the counting / scatter grid: a multiple of 4 (callers that count the keys themselves take four
@@ -473,7 +507,7 @@ static bool multisplit_two_level(u32 n_bins, u32 n) {
 }
 // where a table_ready caller of the two-level split leaves the bin TOTALS (zeroed by the caller, filled with atomics) instead of
 // per-workgroup rows; null when the split of (n_bins, n) is one-level and wants the table
-u32 *multisplit_totals(void *ws, u32 n_bins, u32 n) { return multisplit_two_level(n_bins, n) ? (u32 *)ws + (size_t)256 * n_bins : nullptr; }
+u32 *multisplit_totals(void *ws, u32 n_bins, u32 n) { return multisplit_two_level(n_bins, n) ? (u32 *)ws + multisplit_table_words(n_bins, n) : nullptr; }
 // words from multisplit_totals() on that such a caller zeroes before it counts: the totals and, behind them, the passes'
 // relative cursors (coarse [1024], fine [n_bins])
 size_t multisplit_zeroed_words(u32 n_bins) { return (size_t)n_bins * 2 + 1024; }
@@ -495,13 +529,13 @@ u32 *multisplit_coarse_totals(void *ws, u32 n_bins, u32 n) {
 template <class KeyT, bool CLAMP>
 static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
                                        u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
-                                       const u32 *set_bounds, const HeavyBins *heavy) {
+                                       const u32 *set_bounds, const HeavyBins *heavy, u32 n_count_rows) {
     const SetTags tags = set_bounds ? SetTags{set_bounds[0], set_bounds[1], set_bounds[2]} : SetTags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     if (n_bins == 0 || n_bins > MS_MAX_BINS_2L + 1) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
     if (ws_bytes < multisplit_ws_bytes(n_bins, n)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
     const u32 n_wg = multisplit_workgroups(n);
     const u32 chunk = multisplit_chunk(n);
-    u32 *table = (u32 *)ws, *tot = table + (size_t)256 * n_bins;
+    u32 *table = (u32 *)ws, *tot = table + multisplit_table_words(n_bins, n);
     u32 *cur_a = tot + n_bins, *cur_b = cur_a + 1024;
     KeyT *tmp_key = (KeyT *)(((uintptr_t)(cur_b + n_bins) + 63) & ~(uintptr_t)63);
     uint2 *tmp_ab = reinterpret_cast<uint2 *>(reinterpret_cast<u32 *>(tmp_key) + (((size_t)n + 15) & ~(size_t)15));
@@ -555,18 +589,18 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
         const SetTags no_tags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (fold) {
             hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP, true>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr,
-                               n, shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)tot, n_bins, bin_off,
-                               heavy ? *heavy : HeavyBins{}, (const u32 *)(cur_a + 256));
+                               n, shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)table, n_bins, bin_off,
+                               heavy ? *heavy : HeavyBins{}, (const u32 *)(cur_a + 256), n_count_rows);
             hipLaunchKernelGGL((k_split_pass<true, KeyT, false, true>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
                                (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if,
-                               no_tags, (const u32 *)nullptr, n_bins, bin_off, HeavyBins{}, (const u32 *)nullptr);
+                               no_tags, (const u32 *)nullptr, n_bins, bin_off, HeavyBins{}, (const u32 *)nullptr, 0u);
         } else {
             hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n,
                                shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)nullptr, 0u, (u32 *)nullptr, HeavyBins{},
-                               (const u32 *)nullptr);
+                               (const u32 *)nullptr, 0u);
             hipLaunchKernelGGL((k_split_pass<true, KeyT, false>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
                                (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if,
-                               no_tags, (const u32 *)nullptr, 0u, (u32 *)nullptr, HeavyBins{}, (const u32 *)nullptr);
+                               no_tags, (const u32 *)nullptr, 0u, (u32 *)nullptr, HeavyBins{}, (const u32 *)nullptr, 0u);
         }
     } else {
         ProfScope p("k_ms_scatter", st);
@@ -579,17 +613,17 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
 
 gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
                               uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
-                              const u32 *set_bounds, const HeavyBins *heavy) {
+                              const u32 *set_bounds, const HeavyBins *heavy, u32 n_count_rows) {
     if (key16 && n_bins > 65535u) return fail(GTARS_ERR_INTERNAL, "multisplit: 16-bit keys need <= 65535 bins");
     if (key16)
         return clamp_a ? multisplit_pairs_t<unsigned short, true>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
-                                                                  ws_bytes, st, run_if, table_ready, set_bounds, heavy)
+                                                                  ws_bytes, st, run_if, table_ready, set_bounds, heavy, n_count_rows)
                        : multisplit_pairs_t<unsigned short, false>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
-                                                                   ws_bytes, st, run_if, table_ready, set_bounds, heavy);
+                                                                   ws_bytes, st, run_if, table_ready, set_bounds, heavy, n_count_rows);
     return clamp_a ? multisplit_pairs_t<u32, true>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
-                                                   table_ready, set_bounds, heavy)
+                                                   table_ready, set_bounds, heavy, n_count_rows)
                    : multisplit_pairs_t<u32, false>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
-                                                    table_ready, set_bounds, heavy);
+                                                    table_ready, set_bounds, heavy, n_count_rows);
 }
 
 __global__ void k_iota(u32 *__restrict__ p, u32 n) {

@@ -1367,6 +1367,53 @@ def test_igd_counts_on_databases_with_long_records(ga, monkeypatch, piece_bp):
                           o.count_overlaps_per_query(qc[ok][:2000], qs[ok][:2000], qe[ok][:2000], 1))
 
 
+def test_igd_fine_routing_tables_boundary_probes(ga, monkeypatch):
+    """The routing kernel's fine tables (IgdTiles::route_f*: ~one tile boundary per bucket, boundaries as 16-bit offsets inside
+    their bucket; an offset equal to the query's is settled by the exact bound when buckets are wider than 2^16).  Queries that
+    start exactly at, one before and one after EVERY ownership bound (last start of each 2048-record tile + the chromosome's
+    longest record + 1) plus a random batch, with 2^16-wide buckets (exact offsets) and with 2^20-wide ones forced
+    (GTARS_IGD_ROUTE_FSHIFT_MIN: 16-bp quantisation, many boundaries per bucket): per-file vectors == the oracle's, and the
+    vectors of the bounds-in-global-memory form."""
+    rng = np.random.default_rng(77)
+    n, F, span = 300_000, 23, 60_000_000
+    c = rng.integers(0, 3, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 900, n)
+    f = rng.integers(0, F, n)
+    # the ownership bounds, restated: records in (chromosome, start) order, tiles of 2048 records inside a chromosome
+    probes = []
+    for ch in range(3):
+        sel = c == ch
+        ss = np.sort(s[sel])
+        max_len = int((e[sel] - s[sel]).max())
+        last = ss[2047::2048].tolist() + [int(ss[-1])]
+        for b in (int(x) + max_len + 1 for x in last):
+            for d in (-17, -16, -2, -1, 0, 1, 15, 16):
+                if b + d >= 0:
+                    probes.append((ch, b + d, b + d + 40))
+    pc, ps, pe = (np.array(x, dtype=np.int64) for x in zip(*probes))
+    rc, rs, re_ = _random_query_set(rng, 200_000, 3, span + 3_000, 600)
+    qc = np.concatenate([pc, rc.astype(np.int64)])
+    qs = np.concatenate([ps, rs.astype(np.int64)])
+    qe = np.concatenate([pe, re_.astype(np.int64)])
+    perm = rng.permutation(len(qc))
+    qc, qs, qe = qc[perm], qs[perm], qe[perm]
+    monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
+    vecs = []
+    for fshift in (None, "20", "global"):
+        if fshift == "global":
+            monkeypatch.setenv("GTARS_IGD_ROUTE_BND_GLOBAL", "1")
+        elif fshift:
+            monkeypatch.setenv("GTARS_IGD_ROUTE_FSHIFT_MIN", fshift)
+        g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=3, n_files=F)
+        monkeypatch.delenv("GTARS_IGD_ROUTE_FSHIFT_MIN", raising=False)
+        got = g.count_set_overlaps(qc, qs, qe, 1)
+        assert np.array_equal(got, o.count_set_overlaps(qc, qs, qe, 1, n_files=F)), fshift
+        assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F)), fshift
+        vecs.append(got)
+    assert np.array_equal(vecs[0], vecs[1]) and np.array_equal(vecs[0], vecs[2])
+
+
 def test_igd_routing_with_tile_bounds_in_global_memory(ga, monkeypatch):
     """Databases beyond ~52M records route their queries with the tile bounds in global memory instead of LDS (k_igd_route<.,
     false>; up to 65534 tiles = 134M records), and beyond 36863 tiles the split is two-level whatever the batch size.  Forced
