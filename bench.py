@@ -280,7 +280,7 @@ IGD3 = dict(ndb=50_000_000, nq=10_000_000, n_files=1000)
 # oracle by tests/test_gpu_parity.py::test_config3_igd_full_size_properties) -- any sharding must reproduce them
 IGD3_TOTALS = (149452392, 148309462)
 IGD_PMC_CALLS = 6
-IGD_COUNT_KERNELS = ("k_igd_call_init", "k_igd_order_check", "k_igd_prep", "k_igd_route", "k_ms_", "k_split_", "k_igd_chrom_segments", "k_igd_tile_ranges", "k_igd_sweep")
+IGD_COUNT_KERNELS = ("k_igd_begin", "k_igd_call_init", "k_igd_order_check", "k_igd_prep", "k_igd_route", "k_ms_", "k_split_", "k_igd_chrom_segments", "k_igd_tile_ranges", "k_igd_sweep")
 LOLA4 = dict(n_sets=2000, per_set=25_000, n_universe=1_000_000, n_user=100_000)
 LOLA4_SUPPORT_SUM = 1793489
 

@@ -63,6 +63,10 @@ gtars_status Workspace::reserve(size_t need) {
     GT_HIP(hipMalloc(&ptr, want));
     bytes = want;
     device = dev;
+    // the head of the buffer is state that outlives a call (launch_igd_sweep's order flags): zero when the buffer is new
+    igd_calls = 0;
+    GT_HIP(hipMemset(ptr, 0, 64));
+    GT_HIP(hipDeviceSynchronize());
     return GTARS_OK;
 }
 
@@ -2236,7 +2240,7 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
         st = ws.reserve(igd_sweep_ws_bytes(nq, g->n_tiles, g->n_chrom));
         if (st) return st;
         return launch_igd_sweep(g->view(), g->tiles(), d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, ws.ptr, ws.bytes,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, ws.igd_calls++);
     }
     // small batch: one thread per query (kernels.hip); binary counts with min_overlap == 1 through pme_file as well
     if (binary && min_overlap == 1 && !getenv("GTARS_IGD_NO_PME") && (st = g->ensure_pme())) return st;
@@ -2285,7 +2289,7 @@ gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d
             u32 bounds[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             for (u32 k = k0 + 1; k < k1; ++k) bounds[k - k0 - 1] = (u32)(set_off[k] - lo);
             st = launch_igd_sweep(gs->view(), gs->tiles(), d_qc + lo, d_qs + lo, d_qe + lo, n, min_overlap, binary, d_hits + (size_t)k0 * F,
-                                  ws.ptr, ws.bytes, (hipStream_t)stream, k1 - k0, bounds);
+                                  ws.ptr, ws.bytes, (hipStream_t)stream, ws.igd_calls++, k1 - k0, bounds);
             if (st) return st;
             if (g_prof_on) g_prof_entries[prof_entry("igd_sets_shared_pass")].launches += 1;  // (a fact for the tests, not a time)
         }

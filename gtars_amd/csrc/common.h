@@ -152,6 +152,7 @@ struct Workspace {
     size_t bytes = 0;
     int device = -1;
     ScanEpoch ep;
+    u32 igd_calls = 0;  // IGD sweeps served by this buffer (launch_igd_sweep: the parity picks one of two flag words at its head)
     gtars_status reserve(size_t need);
     ~Workspace();
 };
@@ -341,8 +342,10 @@ gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, con
                                      hipStream_t st);
 // n_sets > 1: the batch is the concatenation of n_sets <= 4 query sets (set_bounds as for multisplit_pairs), hits is
 // u64[n_sets][n_files]; needs igd_sweep_sets_supported
+// ws: a workspace whose first 64 bytes were zero when it was allocated and are never touched by anybody else (Workspace::reserve
+// zeroes them); call_no: how many sweeps this workspace has served before (Workspace::igd_calls++): its parity picks the order flag
 gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, i32 min_overlap,
-                              int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st, u32 n_sets = 1,
+                              int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st, u32 call_no, u32 n_sets = 1,
                               const u32 *set_bounds = nullptr);
 bool igd_sweep_sets_supported(const IgdView &v, const IgdTiles &tl, u64 nq, u32 n_sets);
 constexpr u32 IGD_TILE_RECORDS = 2048;

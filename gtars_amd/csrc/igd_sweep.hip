@@ -158,6 +158,41 @@ k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const
     if (__any(bad) && lane == 0) *unsorted = 1u;
 }
 
+// first index in [lo, hi) with a[i] >= key; CLAMP: a holds raw i32 starts, negative ones count as 0 (igd.rs:517)
+template <bool CLAMP>
+__device__ __forceinline__ u32 lb_u32(const u32 *__restrict__ a, u32 lo, u32 hi, u64 key) {
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        const u32 x = a[mid];
+        if ((u64)(CLAMP && (i32)x < 0 ? 0u : x) < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// Every query is OWNED by exactly one tile: the tile that holds its lower_bound position
+// p = first record of the chromosome with start >= key, key = max(q.start - max_len, 0).
+// key is monotone in q.start, so the owned queries of a tile are a contiguous range [ql, qh) of the
+// sorted queries:   last_start(previous tile) < key <= last_start(this tile).
+template <bool CLAMP>
+__device__ __forceinline__ void igd_tile_range_one(const IgdView &v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
+                                                   const u32 *__restrict__ tile_chrom, u32 t, const u32 *__restrict__ sorted_qs,
+                                                   const u32 *__restrict__ cq_off, u32 *__restrict__ ql, u32 *__restrict__ qh,
+                                                   const HeavyBins &heavy) {
+    const u32 c = tile_chrom[t], p0 = tile_first[t], cnt = tile_cnt[t];
+    const u64 max_len = (u64)v.chrom_maxlen[c];
+    const u32 lo = cq_off[c], hi = cq_off[c + 1];
+    const bool first_of_chrom = p0 == v.chrom_off[c];
+    // key > prev_last  <=>  q.start >= prev_last + max_len + 1   (keys clamped to 0 belong to the first tile)
+    const u32 a = first_of_chrom ? lo : lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 - 1] + max_len + 1);
+    const u32 b = lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 + cnt - 1] + max_len + 1);
+    ql[t] = a;
+    qh[t] = b;
+    heavy.note(t, b - a);  // a tile far heavier than the average is served in parts (k_igd_sweep)
+}
+
 // ---- routing: owner tile of every query + the partition's histogram, in ONE pass over the raw batch ------------------------
 // Round 2 prepared the batch in one kernel (four columns written: clamped chromosome / start / end and the owner tile, 160 MB
 // for config 3) and counted the owner tiles in a second one.  Here the raw columns are read once, the owner tile leaves as a
@@ -191,8 +226,19 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
             const u32 *__restrict__ bnd, const u32 *__restrict__ chrom_tile_off, const u32 *__restrict__ route_base,
             const u32 *__restrict__ route_len, const u32 *__restrict__ route_lut, u32 n_lut, u32 route_shift, u32 n_tiles, u32 chunk,
             unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, const u32 *__restrict__ run_if,
-            u32 *__restrict__ ctot, u32 cshift, const u32 *__restrict__ route_kq) {
-    if (run_if && *run_if == 0) return;  // the batch is in owner order (k_igd_order_check): nothing to route, the sweep takes it as it lies
+            u32 *__restrict__ ctot, u32 cshift, const u32 *__restrict__ route_kq, IgdView v, const u32 *__restrict__ tile_first,
+            const u32 *__restrict__ tile_cnt, const u32 *__restrict__ tile_chrom, const u32 *__restrict__ cq_off, u32 *__restrict__ ql,
+            u32 *__restrict__ qh, HeavyBins heavy) {
+    if (run_if && *run_if == 0) {
+        // the batch is in owner order (the order check in front of this kernel): nothing to route, the sweep takes it as it lies --
+        // and this launch computes the tiles' query ranges instead (what k_igd_tile_ranges did in a launch of its own)
+        // (tile t goes to workgroup t mod grid: the binary searches are chains of dependent loads, so they want to be spread
+        // over every CU's memory path rather than packed into the first few workgroups)
+        if (ql)
+            for (u32 t = threadIdx.x * gridDim.x + blockIdx.x; t < n_tiles; t += gridDim.x * RT_TPB)
+                igd_tile_range_one<true>(v, tile_first, tile_cnt, tile_chrom, t, qs, cq_off, ql, qh, heavy);
+        return;
+    }
     extern __shared__ u32 rt_lds[];
     // FINE: route_base / route_lut / n_lut / route_shift are the FINE tables' (IgdTiles::route_fbase / route_flut / route_fn /
     // route_fshift); {base, len} pairs per chromosome | table | [boundary offsets] | counters
@@ -394,9 +440,13 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
 // the full order check behind this kernel returns at once.
 constexpr u32 ORD_PROBE = 1024;
 __device__ __forceinline__ bool igd_out_of_order(u32 pc, i32 ps, u32 c, i32 s) { return pc > c || (pc == c && (u32)ps > (u32)s); }
+// The flag lives in one of TWO words at the head of the workspace, by the call's parity: a call raises the word of its parity
+// (zero when the call starts) and zeroes the other one for the next call -- nobody ever clears a word that somebody else may be
+// raising in the same launch (Workspace::reserve zeroes both when it allocates).
 __global__ void __launch_bounds__(256)
 k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict__ flag, u32 flag_value, u32 *__restrict__ tot, u32 n_tot,
-                const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 probe_n, u32 n_chrom) {
+                const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 probe_n, u32 n_chrom,
+                u32 *__restrict__ next_flag, u32 *__restrict__ heavy_count) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_files) hits[i] = 0ull;
     if (i < n_tot) tot[i] = 0u;
@@ -426,8 +476,9 @@ k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restr
         }
         const int any_bad = __syncthreads_or(bad ? 1 : 0);
         if (threadIdx.x == 0) {
-            flag[0] = flag_value | (any_bad ? 1u : 0u);
-            flag[1] = 0u;  // number of listed heavy-tile parts (HeavyBins::count)
+            if (flag_value | (any_bad ? 1u : 0u)) flag[0] = 1u;
+            next_flag[0] = 0u;
+            heavy_count[0] = 0u;  // number of listed heavy-tile parts (HeavyBins::count)
         }
     }
 }
@@ -499,6 +550,87 @@ k_igd_order_check(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const 
     if (__any(bad) && lane == 0) *flag = 1u;
 }
 
+// k_igd_call_init + k_igd_order_check as ONE launch (the fused routing path; a launch costs ~5 us on this chain): every thread
+// zeroes its words of the result vector and of the split's totals / cursors, workgroup 0 the next call's flag and the heavy-tile
+// count; then the order check -- a workgroup leaves as soon as it (or anybody) has seen disorder: no probe launch in front.
+template <bool VEC>
+__global__ void __launch_bounds__(ORD_TPB)
+k_igd_begin(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict__ tot, u32 n_tot, u32 *__restrict__ flag,
+            u32 *__restrict__ next_flag, u32 *__restrict__ heavy_count, u32 flag0, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
+            const u32 *__restrict__ qe, u32 nq, u32 n_chrom, u32 *__restrict__ cq_off) {
+    for (u32 i = blockIdx.x * ORD_TPB + threadIdx.x; i < max(n_files, n_tot); i += gridDim.x * ORD_TPB) {
+        if (i < n_files) hits[i] = 0ull;
+        if (i < n_tot) tot[i] = 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        next_flag[0] = 0u;
+        heavy_count[0] = 0u;
+        if (flag0) flag[0] = 1u;
+    }
+    if (flag0) return;  // the partition is certain (several query sets, or forced): nothing to check
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    for (u64 base = (u64)blockIdx.x * (ORD_TPB * 4); base < nq; base += (u64)gridDim.x * (ORD_TPB * 4)) {
+        if (*reinterpret_cast<volatile const u32 *>(flag)) return;  // (somebody has seen disorder: the batch will be partitioned)
+        const u64 i0 = base + (u64)threadIdx.x * 4;
+        u32 rc[4], rs[4], re[4];
+        if (VEC && i0 + 4 <= nq) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(qc + i0), b = *reinterpret_cast<const uint4 *>(qs + i0),
+                        d = *reinterpret_cast<const uint4 *>(qe + i0);
+            rc[0] = a.x, rc[1] = a.y, rc[2] = a.z, rc[3] = a.w;
+            rs[0] = b.x, rs[1] = b.y, rs[2] = b.z, rs[3] = b.w;
+            re[0] = d.x, re[1] = d.y, re[2] = d.z, re[3] = d.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = i0 + u < nq;
+                rc[u] = in ? qc[i0 + u] : GTARS_UNKNOWN_CHROM;  // past the end: "rejected", sorts last
+                rs[u] = in ? qs[i0 + u] : 0u;
+                re[u] = in ? qe[i0 + u] : 0u;
+            }
+        }
+        // the element in front of this lane's four: the previous lane's last one; lane 0 reads it
+        const bool edge = lane == 0 && i0 > 0 && i0 < nq;
+        const u32 ec = edge ? qc[i0 - 1] : 0u, es = edge ? qs[i0 - 1] : 0u, ee = edge ? qe[i0 - 1] : 0u;
+        u32 c[4];
+        i32 s[4], e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
+        u32 pc = __shfl_up(c[3], 1, 64);
+        i32 ps = __shfl_up(s[3], 1, 64);
+        if (lane == 0) {
+            i32 pe;
+            igd_prep_one(ec, es, ee, n_chrom, pc, ps, pe);
+        }
+        const u32 pc0 = pc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u < nq && i0 + u > 0 && igd_out_of_order(pc, ps, c[u], s[u])) bad = true;
+            pc = c[u];
+            ps = s[u];
+        }
+        if (__any(bad)) {  // (before anything is written: a shuffled batch must leave here at once)
+            if (lane == 0) *flag = 1u;
+            return;
+        }
+        // chromosome boundaries (c[u] <= n_chrom after the validity rules): cq_off[c] = first row whose chromosome is >= c -- the
+        // thread that sees a chromosome change at row i writes the entries of every chromosome in between
+        pc = pc0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u64 i = i0 + u;
+            if (i < nq) {
+                const u32 from = i == 0 ? 0u : pc + 1u;
+                if (i == 0 || c[u] > pc)
+                    for (u32 k = from; k <= c[u]; ++k) cq_off[k] = (u32)i;
+                if (i == (u64)nq - 1)
+                    for (u32 k = c[u] + 1u; k <= n_chrom; ++k) cq_off[k] = nq;
+            }
+            pc = c[u];
+        }
+    }
+}
+
 __global__ void k_igd_tile_bounds(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
                                   const u32 *__restrict__ tile_chrom, u32 n_tiles, u32 *__restrict__ bnd) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -513,20 +645,6 @@ gtars_status launch_igd_tile_bounds(const IgdView &v, const u32 *tile_first, con
     hipLaunchKernelGGL(k_igd_tile_bounds, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tile_first, tile_cnt, tile_chrom, n_tiles, bnd);
     GT_HIP(hipGetLastError());
     return GTARS_OK;
-}
-
-// first index in [lo, hi) with a[i] >= key; CLAMP: a holds raw i32 starts, negative ones count as 0 (igd.rs:517)
-template <bool CLAMP>
-__device__ __forceinline__ u32 lb_u32(const u32 *__restrict__ a, u32 lo, u32 hi, u64 key) {
-    while (lo < hi) {
-        const u32 mid = lo + ((hi - lo) >> 1);
-        const u32 x = a[mid];
-        if ((u64)(CLAMP && (i32)x < 0 ? 0u : x) < key)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
 }
 
 // per-chromosome segments of the sorted queries
@@ -569,10 +687,6 @@ __global__ void k_gather2_u32(const u32 *__restrict__ a, const u32 *__restrict__
     }
 }
 
-// Every query is OWNED by exactly one tile: the tile that holds its lower_bound position
-// p = first record of the chromosome with start >= key, key = max(q.start - max_len, 0).
-// key is monotone in q.start, so the owned queries of a tile are a contiguous range [ql, qh) of the
-// sorted queries:   last_start(previous tile) < key <= last_start(this tile).
 template <bool CLAMP>
 __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt,
                                   const u32 *__restrict__ tile_chrom, u32 n_tiles, const u32 *__restrict__ sorted_qs,
@@ -581,16 +695,7 @@ __global__ void k_igd_tile_ranges(IgdView v, const u32 *__restrict__ tile_first,
     if (skip_if && *skip_if) return;
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
-    const u32 c = tile_chrom[t], p0 = tile_first[t], cnt = tile_cnt[t];
-    const u64 max_len = (u64)v.chrom_maxlen[c];
-    const u32 lo = cq_off[c], hi = cq_off[c + 1];
-    const bool first_of_chrom = p0 == v.chrom_off[c];
-    // key > prev_last  <=>  q.start >= prev_last + max_len + 1   (keys clamped to 0 belong to the first tile)
-    const u32 a = first_of_chrom ? lo : lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 - 1] + max_len + 1);
-    const u32 b = lb_u32<CLAMP>(sorted_qs, lo, hi, (u64)v.starts[p0 + cnt - 1] + max_len + 1);
-    ql[t] = a;
-    qh[t] = b;
-    heavy.note(t, b - a);  // a tile far heavier than the average is served in parts (k_igd_sweep)
+    igd_tile_range_one<CLAMP>(v, tile_first, tile_cnt, tile_chrom, t, sorted_qs, cq_off, ql, qh, heavy);
 }
 
 // ---- the sweep ---------------------------------------------------------------------------------
@@ -1402,7 +1507,7 @@ constexpr u32 HEAVY_PART_MIN = 4096;  // queries per part of a heavy tile, at le
 size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom) {
     // kc ks ke | sorted qs qe chrom | perm (or owner tiles) | ql qh | cq_off | bin offsets | slack | heavy-tile parts |
     // partition / sort scratch
-    return (size_t)nq * 4 * 7 + (size_t)n_tiles * 12 + ((size_t)n_chrom + 2) * 4 + 512 + ((size_t)nq / HEAVY_PART_MIN + 16) * 8 +
+    return 64 + (size_t)nq * 4 * 7 + (size_t)n_tiles * 12 + ((size_t)n_chrom + 2) * 4 + 512 + ((size_t)nq / HEAVY_PART_MIN + 16) * 8 +
            std::max(device_sort_perm_ws_bytes((u32)nq), multisplit_ws_bytes(n_tiles + 1, (u32)nq));
 }
 
@@ -1456,7 +1561,7 @@ bool igd_sweep_sets_supported(const IgdView &v, const IgdTiles &tl, u64 nq, u32 
 }
 
 gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq64,
-                              i32 min_overlap, int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st, u32 n_sets,
+                              i32 min_overlap, int binary, u64 *hits, void *ws, size_t ws_bytes, hipStream_t st, u32 call_no, u32 n_sets,
                               const u32 *set_bounds) {
     const u32 nq = (u32)nq64;
     const u32 n_tiles = tl.n_tiles;
@@ -1465,15 +1570,18 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     if (n_sets <= 1) set_bounds = nullptr;
     const u32 n_bins = v.n_files * std::max<u32>(n_sets, 1);
     if (ws_bytes < igd_sweep_ws_bytes(nq, n_tiles, v.n_chrom)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
-    u32 *kc = (u32 *)ws, *ks = kc + nq, *ke = ks + nq;
+    // the first 16 words of the workspace outlive the call: the two order flags (see k_igd_call_init) and the heavy-tile count
+    u32 *persist = (u32 *)ws;
+    u32 *kc = persist + 16, *ks = kc + nq, *ke = ks + nq;
     u32 *sc = ke + nq, *ss = sc + nq, *se = ss + nq, *perm = se + nq;  // perm doubles as the owner-tile column
     u32 *ql = perm + nq, *qh = ql + n_tiles, *cq_off = qh + n_tiles;
     u32 *bin_off = cq_off + v.n_chrom + 2;  // [n_tiles + 2]
-    u32 *d_unsorted = bin_off + n_tiles + 2;  // [0]: the "not in owner order" flag, [1]: number of listed heavy-tile parts
+    u32 *d_unsorted = persist + (call_no & 1u), *d_next_flag = persist + ((call_no + 1u) & 1u);  // the "not in owner order" flag
+    u32 *after_off = bin_off + n_tiles + 2;
     // tiles that own far more queries than the average are served in parts of heavy_part queries (k_igd_sweep's work items)
     HeavyBins heavy;
-    heavy.list = reinterpret_cast<uint2 *>(((uintptr_t)(d_unsorted + 16) + 7) & ~(uintptr_t)7);
-    heavy.count = d_unsorted + 1;
+    heavy.list = reinterpret_cast<uint2 *>(((uintptr_t)(after_off + 16) + 7) & ~(uintptr_t)7);
+    heavy.count = persist + 2;  // number of listed heavy-tile parts
     heavy.part = std::max<u32>(HEAVY_PART_MIN, (u32)std::min<u64>(8ull * (nq / std::max<u32>(n_tiles, 1)), 1u << 30) / SW_TPB * SW_TPB);
     heavy.n_real_bins = n_tiles;
     heavy.cap = nq / heavy.part + 1;
@@ -1509,13 +1617,11 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     if (bucket && !fused && !(n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024))
         return fail(GTARS_ERR_INTERNAL, "IGD sweep: neither routing form fits this database");  // (cannot happen: see igd_bucket_path)
     static std::mutex attr_mu;
-    {
-        u32 *d_tot0 = fused ? multisplit_totals(scratch, n_tiles + 1, nq) : nullptr;
-        const u32 n_tot0 = d_tot0 ? (u32)multisplit_zeroed_words(n_tiles + 1) : 0u, n_init = std::max<u32>(std::max<u32>(n_bins, n_tot0), 1u);
-        // (the probe only where the order check follows: the fused routing path)
+    u32 *d_tot0 = fused ? multisplit_totals(scratch, n_tiles + 1, nq) : nullptr;
+    const u32 n_tot0 = d_tot0 ? (u32)multisplit_zeroed_words(n_tiles + 1) : 0u, n_init = std::max<u32>(std::max<u32>(n_bins, n_tot0), 1u);
+    if (!fused)
         hipLaunchKernelGGL(k_igd_call_init, dim3((n_init + 255) / 256), dim3(256), 0, st, (unsigned long long *)hits, n_bins, d_unsorted,
-                           flag0, d_tot0, n_tot0, qc, qs, qe, fused && !flag0 ? std::min<u32>(nq, ORD_PROBE) : 0u, v.n_chrom);
-    }
+                           flag0, d_tot0, n_tot0, qc, qs, qe, 0u, v.n_chrom, d_next_flag, heavy.count);
     if (fused) {
         if (scratch_bytes < multisplit_ws_bytes(n_tiles + 1, nq)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
         {
@@ -1530,11 +1636,13 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         }
         u32 *d_tot = multisplit_totals(scratch, n_tiles + 1, nq);  // null: the one-level split wants the per-workgroup table
         const bool vec = ((((uintptr_t)qc) | ((uintptr_t)qs) | ((uintptr_t)qe)) & 15u) == 0 && (((uintptr_t)perm) & 7u) == 0;
-        if (!flag0) {
-            ProfScope p("k_igd_order_check", st);
-            const unsigned og = (unsigned)std::max<u64>(1, std::min<u64>((u64)cus * 8, ((u64)nq + ORD_TPB * 4 - 1) / (ORD_TPB * 4)));
-            hipLaunchKernelGGL(vec ? k_igd_order_check<true> : k_igd_order_check<false>, dim3(og), dim3(ORD_TPB), 0, st, qc, qs, qe, nq,
-                               v.n_chrom, d_unsorted, cq_off);
+        {
+            // result vector, totals / cursors, flags -- and, unless the partition is certain, the order check -- in ONE launch
+            ProfScope p("k_igd_begin", st);
+            const u64 og_check = std::min<u64>((u64)cus * 8, ((u64)nq + ORD_TPB * 4 - 1) / (ORD_TPB * 4));
+            const unsigned og = (unsigned)std::max<u64>(1, flag0 ? (n_init + ORD_TPB - 1) / ORD_TPB : std::max<u64>(og_check, std::min<u64>(64, (n_init + ORD_TPB - 1) / ORD_TPB)));
+            hipLaunchKernelGGL(vec ? k_igd_begin<true> : k_igd_begin<false>, dim3(og), dim3(ORD_TPB), 0, st, (unsigned long long *)hits, n_bins,
+                               d_tot0, n_tot0, d_unsorted, d_next_flag, heavy.count, flag0, qc, qs, qe, nq, v.n_chrom, cq_off);
         }
         ProfScope p("k_igd_route", st);
         auto route = fine ? (vec ? k_igd_route<true, true> : k_igd_route<false, true>) : (vec ? k_igd_route<true, false> : k_igd_route<false, false>);
@@ -1543,7 +1651,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
                            fine ? tl.route_fn : tl.route_n, fine ? tl.route_fshift : tl.route_shift, n_tiles, rt_chunk,
                            reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted,
                            d_tot ? multisplit_coarse_totals(scratch, n_tiles + 1, nq) : (u32 *)nullptr, multisplit_coarse_shift(n_tiles + 1),
-                           tl.route_kq);
+                           tl.route_kq, v, tl.first, tl.cnt, tl.chrom, (const u32 *)cq_off, flag0 ? (u32 *)nullptr : ql, qh, heavy);
     } else {
         ProfScope p("k_igd_prep_queries", st);
         const u32 n_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
@@ -1587,9 +1695,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         if (flag0) {
             // the partition is certain (several sets, or forced): nothing to enqueue for the in-order continuation
         } else if (fused) {
-            // (the chromosome segments cq_off come from the order check)
-            hipLaunchKernelGGL(k_igd_tile_ranges<true>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles,
-                               ss, cq_off, ql, qh, d_unsorted, heavy);
+            // (the routing kernel has computed the tile ranges itself when the batch turned out to be in order: cq_off from k_igd_begin)
         } else {
             hipLaunchKernelGGL(k_igd_chrom_segments<false>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, oc, (const u32 *)nullptr,
                                (const u32 *)nullptr, (const u32 *)nullptr, nq, v.n_chrom, cq_off, d_unsorted);

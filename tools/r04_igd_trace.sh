@@ -19,7 +19,7 @@ rows.sort()
 # calls = runs of kernels starting at k_igd_call_init
 calls, cur = [], None
 for s, e, n in rows:
-    if n.startswith("k_igd_call_init"):
+    if n.startswith("k_igd_call_init") or n.startswith("k_igd_begin"):
         cur = []
         calls.append(cur)
     if cur is not None and (n.startswith("k_igd") or n.startswith("k_ms_") or n.startswith("k_split")):
@@ -27,7 +27,7 @@ for s, e, n in rows:
 agg = collections.defaultdict(list)
 for c in calls:
     if len(c) < 3: continue
-    route = [e - s for s, e, n in c if n.startswith("k_igd_route")]
+    route = [e - s for s, e, n in c if n.startswith("k_split_pass")]
     sig = ("shuffled" if route and route[0] > 20000 else "in order",) + tuple(x[2][:28] for x in c)
     span = c[-1][1] - c[0][0]
     busy = sum(e - s for s, e, _ in c)
