@@ -318,10 +318,25 @@ def bench_igd_config3(dev, stream, ndb=IGD3["ndb"], nq=IGD3["nq"], n_files=IGD3[
     out = {"db_intervals": ndb, "queries": nq, "files": n_files, "gen_s": round(tgen, 2), "build_s": round(tbuild, 2),
            "algorithmic_bytes": byts}
     order = np.lexsort((q["start"], q["chrom"]))
+    # The timed calls ROTATE through NB distinct device-resident copies of the batch (3 x 120 MB > the 256 MB Infinity Cache), like
+    # the headline's 32 tokenizer batches: a call never finds its queries in the cache because the previous call left them there.
+    # The shuffled copies are the same queries in three different orders (same totals), the sorted ones three buffers.
+    NB = 3
+    out["query_batches_rotated"] = NB
     for label, sel in (("shuffled", None), ("sorted_input", order)):
-        qc, qs, qe = (_dev(q[k] if sel is None else q[k][sel], dev) for k in ("chrom", "start", "end"))
+        batches = []
+        for b in range(NB):
+            pick = sel if sel is not None else (None if b == 0 else np.random.default_rng(100 + b).permutation(nq))
+            batches.append(tuple(_dev(q[k] if pick is None else q[k][pick], dev) for k in ("chrom", "start", "end")))
+        qc, qs, qe = batches[0]
         for binary in (False, True):
-            f = lambda: g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, hits.data_ptr(), 1, binary, stream)
+            turn = [0]
+
+            def f():
+                c_, s_, e_ = batches[turn[0] % NB]
+                turn[0] += 1
+                g.count_device(c_.data_ptr(), s_.data_ptr(), e_.data_ptr(), nq, hits.data_ptr(), 1, binary, stream)
+
             f()
             torch.cuda.synchronize()
             # the call is asynchronous on its stream (no host round trip inside): K calls enqueued back to back, HIP events
@@ -345,12 +360,13 @@ def bench_igd_config3(dev, stream, ndb=IGD3["ndb"], nq=IGD3["nq"], n_files=IGD3[
             key = ("binary" if binary else "pairwise") + "_" + label
             out[key] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt), "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 5),
                         "total_hits": tot, "ms_single_call_host_wall": round(statistics.median(walls) * 1e3, 3),
-                        "timing": f"median of 5 x ({K} calls enqueued back to back, HIP events on the launch stream) / {K}"}
+                        "timing": f"median of 5 x ({K} calls enqueued back to back over {NB} rotating batches, HIP events on the launch "
+                                  f"stream) / {K}"}
             if (ndb, nq, n_files) == (IGD3["ndb"], IGD3["nq"], IGD3["n_files"]):
                 if tot != IGD3_TOTALS[1 if binary else 0]:
                     raise SystemExit(f"bench.py: igd_config3 {key}: {tot} hits, expected {IGD3_TOTALS[1 if binary else 0]}")
                 out[key]["verified"] = "total hits == the config's known total; sample == oracle (cpu_baseline)"
-        del qc, qs, qe
+        del qc, qs, qe, batches
     if cpu:
         # B1 on a sample: the oracle indexes the WHOLE database (build time stated, not part of the rate), then counts the
         # first `ns` queries of the shuffled batch; the GPU counts the same sample and must return the same vectors
@@ -574,9 +590,10 @@ def bench_lola_config4(dev, stream, n_sets=LOLA4["n_sets"], per_set=LOLA4["per_s
     return out
 
 
-def bench_fragsplit_config5(files=300, frags=10_000, clusters=20, cpu_files=60):
-    """BASELINE config 5 at a reduced file count (the config names 10k fragment files on 8 GPUs; per-file cost is what
-    scales): gzip'd fragment files -> barcode routing -> per-cluster tokenization, end to end from the .gz files."""
+def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=4):
+    """BASELINE config 5 at the config's PER-FILE size (1e5 fragments, 500 barcodes: SURVEY 8d C5) and a reduced file count (the
+    config names 10,000 files on 8 GPUs; files are independent, so per-file cost is what scales): gzip'd fragment files ->
+    barcode routing -> per-cluster tokenization, end to end from the .gz files."""
     import shutil
     import tempfile
 
@@ -610,7 +627,7 @@ def bench_fragsplit_config5(files=300, frags=10_000, clusters=20, cpu_files=60):
         n = files * frags
         out = {"files": files, "fragments_per_file": frags, "fragments": n, "clusters": m.n_clusters(),
                "input_gz_MB": round(gz_bytes / 1e6, 1), "gen_s": round(t_gen, 1), "host_threads": os.cpu_count(),
-               "scale_note": f"{files} of the config's 10,000 files (1/{10000 // files}); one GPU",
+               "scale_note": f"{files} files x {frags} fragments = {n} of the config's 1e9 fragments (1/{round(1e9 / n)}); one GPU",
                "routed_fragments": st["written"], "token_ids": ids_fused,
                "host_gunzip_parse": {"s": round(t_parse, 3), "fragments_per_s": round(n_parsed / t_parse), "note": "gtars_fragments_read, one file at a time"},
                "two_step": {"fragsplit_s": round(t_split, 3), "tokenize_cluster_files_s": round(t_tok, 3),
@@ -689,6 +706,7 @@ def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scal
     o3 = {"db_intervals": ndb, "queries": nq, "files": F, "algorithmic_bytes": byts, "scaling": "strong",
           "sharding": "chromosome buckets (LPT over database + query weights); every rank ingests only its chromosomes' rows",
           "collective": f"one all-reduce(SUM) of {F} int64 per call ({backend})",
+          "timing": "host wall time of one call incl. the all-reduce and the barriers around it, max over ranks, median of 7",
           "ingest_s_rank0": round(t_ingest, 2)}
     locals_ = [None] * world
     dist.all_gather_object(locals_, {"db_intervals": sdb.local_intervals, "queries": local_q})
@@ -745,15 +763,77 @@ def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scal
         raise SystemExit("bench.py: lola_config4_sharded: identities / support sum differ from the single-GPU result")
     out["lola_config4_sharded"] = {"sets": n_sets, "db_intervals": n_sets * per_set, "universe": nuni, "user": n_user,
                                    "scaling": "strong", "counts_ms": round(dt * 1e3, 3), "support_sum": int(a.sum()),
+                                   "timing": "host wall time of one call incl. the all-reduce and the barriers around it, max over ranks, "
+                                             "median of 7",
                                    "collective": f"one all-reduce(SUM) of 2 x {n_sets} int64 per call ({backend}): the user set's "
                                                  f"and the universe's support vectors (enrichment.rs:198-221)",
                                    "local_db_intervals_rank0": sdb.local_intervals,
                                    "verified": "a,b,c,d identities; support sum == the single-GPU value"}
     del sdb, hboth
     torch.cuda.empty_cache()
+    # ---- config 5: the fragment pipeline, files dealt to the ranks (no collective on the data path) ----
+    out["fragsplit_config5_sharded"] = bench_fragsplit_sharded(dist, rank, world, max_over_ranks, barrier, files=max(8, 32 // scale),
+                                                               frags=100_000 // scale)
     if scale != 1:
         out["configs_scaled_down_by"] = scale
     return out
+
+
+def bench_fragsplit_sharded(dist, rank, world, max_over_ranks, barrier, files=32, frags=100_000, clusters=20):
+    """BASELINE config 5 over N ranks: rank 0 writes the synthetic fragment files (one node: the ranks share the directory), every
+    rank runs the fused fragsplit -> tokenizer pipeline on its contiguous run of the sorted file list (balanced by compressed
+    size) with its own host threads and its own GPU, results stay rank-local (`gather=False`: one output shard per GPU, what the
+    config's 1e9 fragments call for).  Weak in files per rank it is not: the file count is fixed, so this is strong scaling."""
+    import shutil
+    import tempfile
+
+    from gtars_amd import sharding, synth
+    from gtars_amd.fragsplit import BarcodeToClusterMap, fragsplit_tokenize
+    from gtars_amd.tokenizers import Tokenizer
+
+    box = [None]
+    if rank == 0:
+        tmp = tempfile.mkdtemp(prefix="gtars_c5s_", dir=os.environ.get("TMPDIR", "/tmp"))
+        t = time.time()
+        ub, fd, mp, gz_bytes = synth.write_config5_inputs(tmp, synth.make_universe(100_000), files, frags, clusters)
+        box[0] = (tmp, ub, fd, mp, gz_bytes, time.time() - t)
+    dist.broadcast_object_list(box, src=0)
+    tmp, ub, fd, mp, gz_bytes, t_gen = box[0]
+    try:
+        tok, m = Tokenizer.from_bed(ub), BarcodeToClusterMap.from_file(mp)
+        sharding.fragsplit_tokenize_sharded(fd, m, tok, gather=False)  # warm-up (device buffers, page cache)
+        times = []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            local = sharding.fragsplit_tokenize_sharded(fd, m, tok, gather=False)
+            barrier()
+            times.append(max_over_ranks(time.perf_counter() - t0))
+        dt = statistics.median(times)
+        man = local.pop("__manifest__")
+        mine = {"files": man["files"], "token_ids": sum(int(v[1][-1]) for v in local.values())}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        n = files * frags
+        o = {"files": files, "fragments_per_file": frags, "fragments": n, "clusters": clusters, "input_gz_MB": round(gz_bytes / 1e6, 1),
+             "gen_s": round(t_gen, 1), "scaling": "strong", "value": n / dt, "unit": "fragments/s end to end (all ranks)",
+             "s": round(dt, 3), "per_rank": per_rank,
+             "sharding": "contiguous runs of the sorted file list, balanced by compressed size; results rank-local (no collective on the "
+                         "data path)",
+             "timing": "host wall time incl. barriers, max over ranks, median of 3",
+             "scale_note": f"{files} files x {frags} fragments = {n} of the config's 1e9 fragments (1/{round(1e9 / n)})"}
+        if rank == 0:
+            whole = fragsplit_tokenize(fd, m, tok, as_arrays=True)
+            want = sum(int(v[1][-1]) for v in whole.values())
+            got = sum(r["token_ids"] for r in per_rank)
+            if want != got:
+                raise SystemExit(f"bench.py: fragsplit_config5_sharded: {got} token ids over the ranks, {want} in one process")
+            o["verified"] = "token ids summed over the ranks == the single-process pipeline's (tests/test_gpu_host.py compares every id)"
+        return o
+    finally:
+        barrier()
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -769,7 +849,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / igd_config3 / lola_config4 / host path")
     ap.add_argument("--large", type=str, default="64000000,256000000,1000000000", help="batch sizes of roofline_large")
-    ap.add_argument("--c5-files", type=int, default=300, help="fragment files of fragsplit_config5 (the config names 10,000)")
+    ap.add_argument("--c5-files", type=int, default=48, help="fragment files (1e5 fragments each) of fragsplit_config5 (the config names 10,000)")
     ap.add_argument("--scale-configs", type=int, default=1, help="tests only: divide the sizes of configs 3 / 4 (sharded objects) by this")
     ap.add_argument("--igd-pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -935,6 +1015,49 @@ def main():
             "frac_of_measured_copy_6.29TBps": achieved / 6290.0,
         }
 
+    # ---- the same steps on POSITION-SORTED batches: what Tokenizer.tokenize(path) delivers (a file-loaded RegionSet is sorted by
+    # (chr, start), gtars-core/src/models/region_set.rs:182) -- reported next to the shuffled headline, never instead of it ----
+    sorted_input = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        ns_b = min(nb, 8)  # 8 x 45 MB of queries and results: past the Infinity Cache like the headline's rotation
+        sb = []
+        for b in range(ns_b):
+            qb = q0 if b == 0 else synth.make_queries(u, nq, seed=4 + 7919 * b)
+            o = np.lexsort((qb["start"], qb["chrom"]))
+            qs_sorted = {k: np.ascontiguousarray(qb[k][o]) for k in ("chrom", "start", "end")}
+            d = [_dev(qs_sorted[k], dev) for k in ("chrom", "start", "end")]
+            sb.append((d, torch.empty(nq + 1, dtype=torch.int64, device=dev), torch.empty(batches[b][5] + 1024, dtype=torch.int32, device=dev),
+                       qs_sorted if b == 0 else None))
+        turn = [0]
+
+        def sstep():
+            d, off, ids, _ = sb[turn[0] % ns_b]
+            turn[0] += 1
+            return ix.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), ids.data_ptr(), ids.numel(),
+                                      stream, sync=False)
+
+        for _ in range(max(args.warmup, ns_b)):
+            sstep()
+        torch.cuda.synchronize()
+        ks = []
+        for _ in range(11):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ts)
+            for _ in range(args.steps):
+                sstep()
+            e1.record(ts)
+            torch.cuda.synchronize()
+            ks.append(e0.elapsed_time(e1) / args.steps)
+        sms = statistics.median(ks)
+        d0, off0, ids0, q_sorted0 = sb[0]
+        sv = verify_tokenization(u, q_sorted0, off0, ids0, batches[0][5], "the timed output of sorted batch 0")
+        sorted_input = {"value": nq / (sms * 1e-3), "unit": "query intervals/s", "ms_per_step": sms,
+                        "frac": algorithmic_bytes(nq, round(h_mean), nu) / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "what": f"the same {nq}-query batches in (chromosome, start) order, {ns_b} rotating; HIP events over {args.steps} "
+                                f"steps, median of 11", "verified": sv}
+        del sb
+        torch.cuda.empty_cache()
+
     # ---- N > 1: the same steps when one consumer needs the whole batch (all-gatherv of the CSR over RCCL) ----
     with_allgather = None
     if dist is not None:
@@ -998,6 +1121,8 @@ def main():
                        "max_ms_per_step": max(rep_wall) / args.steps * 1e3},
             "roofline": roofline,
         }
+        if sorted_input:
+            out["sorted_input"] = sorted_input
         if with_allgather:
             out["with_allgather"] = with_allgather
         if sharded:

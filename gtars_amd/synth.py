@@ -164,10 +164,11 @@ def make_single_chrom(n: int, seed: int) -> Tuple[np.ndarray, np.ndarray, np.nda
     return np.zeros(n, dtype=np.uint32), s.astype(np.uint32), (s + w).astype(np.uint32)
 
 
-def write_config5_inputs(tmp: str, universe: Dict[str, np.ndarray], files: int, frags: int, clusters: int = 20):
+def write_config5_inputs(tmp: str, universe: Dict[str, np.ndarray], files: int, frags: int, clusters: int = 20, barcodes: int = 500):
     """BASELINE config 5 inputs under ``tmp``: ``universe.bed``, ``frags/sample<k>.bed.gz`` (``frags`` position-sorted
-    fragments and 200 barcodes each, gzip level 1) and ``map.tsv`` (80 % of the barcodes mapped to ``clusters`` clusters:
-    the rest stands for cells dropped in QC).  -> (universe path, fragment dir, map path, compressed bytes)."""
+    fragments and ``barcodes`` barcodes each -- SURVEY 8d C5: 500 --, gzip level 1) and ``map.tsv`` (80 % of the barcodes mapped
+    to ``clusters`` clusters: the rest stands for cells dropped in QC).  -> (universe path, fragment dir, map path, compressed
+    bytes)."""
     import gzip
     import os
 
@@ -178,20 +179,26 @@ def write_config5_inputs(tmp: str, universe: Dict[str, np.ndarray], files: int, 
     fd = os.path.join(tmp, "frags")
     os.mkdir(fd)
     name_arr = np.array(names + ["chrUn_synthetic"])
-    map_lines, total_bytes = [], 0
-    for k in range(files):
+
+    def one(k: int) -> int:
         q = make_queries(universe, frags, seed=5000 + k)
         order = np.lexsort((q["start"], q["chrom"]))
-        bc = np.random.default_rng(k).integers(0, 200, frags)
+        bc = np.random.default_rng(k).integers(0, barcodes, frags)
         c = np.minimum(q["chrom"][order], len(names))
         cols = [name_arr[c], q["start"][order].astype(str), q["end"][order].astype(str),
                 np.char.add("BC", np.char.zfill(bc.astype(str), 5)), np.full(frags, "1")]
         text = "\n".join("\t".join(r) for r in zip(*cols)) + "\n"
         data = gzip.compress(text.encode(), compresslevel=1)
-        total_bytes += len(data)
         with open(os.path.join(fd, f"sample{k:05d}.bed.gz"), "wb") as fh:
             fh.write(data)
-        map_lines += [f"sample{k:05d}+BC{b:05d}\tcl{(k + b) % clusters}" for b in range(160)]
+        return len(data)
+
+    # (threads: the sorts, the random draws and zlib release the interpreter lock)
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:
+        total_bytes = sum(ex.map(one, range(files)))
+    map_lines = [f"sample{k:05d}+BC{b:05d}\tcl{(k + b) % clusters}" for k in range(files) for b in range(barcodes * 4 // 5)]
     mp = os.path.join(tmp, "map.tsv")
     with open(mp, "w") as fh:
         fh.write("\n".join(map_lines) + "\n")

@@ -891,6 +891,11 @@ def test_bench_py_launches_its_own_ranks():
     og.finalize()
     sup = og.count_region_hits(uni["chrom"][sel], uni["start"][sel], uni["end"][sel], 1, n_files=n_sets)
     assert s4["support_sum"] == int(sup.sum()) and s4["user"] == 1000
+    # config 5 at 1/100 per file: the file list is cut into two runs, the ranks' token ids add up to the single-process count
+    s5 = out["fragsplit_config5_sharded"]
+    runs = sorted(x["files"] for x in s5["per_rank"])
+    assert runs[0][0] == 0 and runs[0][1] == runs[1][0] and runs[1][1] == s5["files"] and all(b > a for a, b in runs)
+    assert s5["verified"] and s5["fragments"] == s5["files"] * s5["fragments_per_file"] and s5["value"] > 0
     # fewer devices than ranks under nccl: refused before anything runs
     env["GTARS_BENCH_BACKEND"] = "nccl"
     import torch
