@@ -282,6 +282,16 @@ struct gtars_index {
     u32 acc_n_blocks = 0, acc_n_units = 0, acc_n_buckets = 0, acc_lut_words = 0, acc_q_words = 0;
     u32 acc_lut_shift = 0, acc_q_shift = 0, acc_search_top = 0, acc_top_shift = 0;
     bool has_accel = false;
+    // stored position -> input row (both kinds)
+    std::vector<u32> h_rows;
+    // FLAT COMPANION of an AIList-kind index with nested sub-lists (null otherwise): the same intervals and values as a Bits-kind
+    // index with its blocked structure.  The reference's default IndexedRegionSet index IS AIList (indexed_region_set.rs:111-113),
+    // and everything it answers through it -- count / any / find_overlaps (sorted unique source rows) / subset_by_overlaps /
+    // intersect_all -- does not depend on the enumeration order, so those calls run on the companion's LDS kernels; only
+    // enumeration in AIList::find order (ailist.rs:153-178, 238-263) stays on this index.  flat_pos[p'] = this index's stored
+    // position of the companion's stored position p' (for the device bitmap of gtars_mark_overlapped_device).
+    gtars_index *flat = nullptr;
+    DevBuf<u32> flat_pos;
     // per-chromosome sorted copy of the ends, built on the first Bits::count call (bits.rs:118-121)
     mutable std::mutex ends_mu;
     mutable DevBuf<u32> ends_sorted;
@@ -702,9 +712,11 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
             ix->h_ends[p] = end[i];
             ix->h_vals[p] = val ? val[i] : i;
         }
+        ix->h_rows = perm;
     } else {
         // AIList::build (ailist.rs:105-151) + decompose (ailist.rs:198-236)
         ix->h_max_ends.resize(n);
+        ix->h_rows.resize(n);
         ix->h_chrom_sub.assign(n_chrom + 1, 0);
         const size_t min_cov = 10;
         u64 filled = 0;
@@ -734,6 +746,7 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
                         ix->h_starts[filled] = start[i];
                         ix->h_ends[filled] = end[i];
                         ix->h_vals[filled] = val ? val[i] : i;
+                        ix->h_rows[filled] = i;
                         filled++;
                     }
                 }
@@ -950,12 +963,31 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
         gtars_index_free(ix);
         return st;
     }
+    if (kind == GTARS_KIND_AILIST && !single_sublist && n > 0) {
+        // nested sub-lists: the flat companion (see gtars_index::flat) -- optional: an index without it answers every call on
+        // the generic kernels, as before
+        gtars_index *fl = nullptr;
+        if (gtars_index_build_impl(chrom, start, end, val, n, n_chrom, GTARS_KIND_BITS, &fl) == GTARS_OK && fl && fl->has_accel &&
+            tokenize_lds_supported(fl->accel())) {
+            std::vector<u32> inv(n), map(n);
+            for (u64 p = 0; p < n; ++p) inv[ix->h_rows[p]] = (u32)p;
+            for (u64 p = 0; p < n; ++p) map[p] = inv[fl->h_rows[p]];
+            if (ix->flat_pos.upload(map) == GTARS_OK) {
+                ix->flat = fl;
+                fl = nullptr;
+            }
+        }
+        if (fl) gtars_index_free(fl);
+        set_error("");
+    }
     *out = ix;
     return GTARS_OK;
 }
 
 void gtars_index_free(gtars_index_t *ix) {
     if (!ix) return;
+    gtars_index_free(ix->flat);
+    ix->flat_pos.release();
     ix->starts.release();
     ix->ends.release();
     ix->vals.release();
@@ -1033,9 +1065,16 @@ static bool use_lds_path(const gtars_index *ix) {
 
 // K2 dispatch: Bits-kind indexes with the blocked structure count through k_count_lds, everything else
 // (AIList order is irrelevant for counts, but its index has no blocked structure) through k_count
+// the index whose blocked structure answers an ORDER-INDEPENDENT call on `ix`: ix itself, the flat companion of a nested AIList
+// index (gtars_index::flat), or null (generic kernels)
+static const gtars_index *lds_target(const gtars_index *ix) {
+    if (use_lds_path(ix)) return ix;
+    if (ix->flat && use_lds_path(ix->flat)) return ix->flat;
+    return nullptr;
+}
 static gtars_status count_dispatch(const gtars_index *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min,
                                    i32 min_overlap, u32 *counts, u8 *any, hipStream_t st) {
-    if (use_lds_path(ix)) return launch_count_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, counts, any, st);
+    if (const gtars_index *t = lds_target(ix)) return launch_count_lds(t->accel(), qc, qs, qe, nq, has_min, min_overlap, counts, any, st);
     return launch_count(ix->view(), ix->kind, qc, qs, qe, nq, has_min, min_overlap, counts, any, st);
 }
 static gtars_status run_fused(const gtars_index *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
@@ -1661,6 +1700,7 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
     *out_n = 0;
     st = require_device();
     if (st) return st;
+    if (lds_target(ix) == ix->flat && ix->flat) ix = ix->flat;  // (sorted unique source rows: the same from either order)
     // Every source row that shares a hit's coordinates is itself a hit (same
     // overlap, same filter), so "all rows sharing coordinates, sorted, dedup"
     // (indexed_region_set.rs:246-263) == the hit source indices, sorted.
@@ -1722,10 +1762,19 @@ gtars_status gtars_mark_overlapped_device(const gtars_index_t *ix, const uint32_
     if (st) return st;
     if (!d_mark && ix->n) return fail(GTARS_ERR_INVALID_ARG, "d_mark is NULL");
     if ((st = require_device())) return st;
-    if (!use_lds_path(ix)) return fail(GTARS_ERR_INVALID_ARG, "index has no blocked structure: use gtars_subset_by_overlaps");
+    const gtars_index *t = lds_target(ix);
+    if (!t) return fail(GTARS_ERR_INVALID_ARG, "index has no blocked structure: use gtars_subset_by_overlaps");
     hipStream_t s = (hipStream_t)stream;
-    GT_HIP(hipMemsetAsync(d_mark, 0, ((size_t)ix->n + 31) / 32 * 4, s));
-    return launch_mark_lds(ix->accel_pos(), d_qc, d_qs, d_qe, nq, has_min, min_overlap, d_mark, s);
+    const size_t mark_bytes = ((size_t)ix->n + 31) / 32 * 4;
+    GT_HIP(hipMemsetAsync(d_mark, 0, mark_bytes, s));
+    if (t == ix) return launch_mark_lds(ix->accel_pos(), d_qc, d_qs, d_qe, nq, has_min, min_overlap, d_mark, s);
+    // nested AIList: marked by the flat companion's positions, then carried over to this index's stored positions
+    Workspace &ws = tls_workspace(3, s);
+    if ((st = ws.reserve(mark_bytes + 64))) return st;
+    u32 *tmp = (u32 *)((char *)ws.ptr + 64);
+    GT_HIP(hipMemsetAsync(tmp, 0, mark_bytes, s));
+    if ((st = launch_mark_lds(t->accel_pos(), d_qc, d_qs, d_qe, nq, has_min, min_overlap, tmp, s))) return st;
+    return launch_permute_marks(tmp, ix->flat_pos.p, ix->n, d_mark, s);
 }
 
 }  // extern "C"
@@ -1772,6 +1821,7 @@ static gtars_status gtars_subset_by_overlaps_impl(const gtars_index_t *ix, const
         bool operator==(const Trip &o) const { return c == o.c && s == o.s && e == o.e; }
     };
     std::vector<Trip> hits;
+    if (lds_target(ix) == ix->flat && ix->flat) ix = ix->flat;  // (a set of coordinates: the same from either stored order)
     if (use_lds_path(ix)) {
         std::vector<u32> pos;
         if ((st = subset_positions(ix, qc, qs, qe, nq, has_min, min_overlap, pos))) return st;
@@ -1837,6 +1887,7 @@ static gtars_status gtars_subset_source_indices_impl(const gtars_index_t *ix, co
     *out_n = 0;
     if ((st = require_device())) return st;
     std::vector<u32> vals;
+    if (lds_target(ix) == ix->flat && ix->flat) ix = ix->flat;  // (a set of source rows: the same from either stored order)
     if (use_lds_path(ix)) {
         std::vector<u32> pos;
         if ((st = subset_positions(ix, qc, qs, qe, nq, has_min, min_overlap, pos))) return st;

@@ -1639,7 +1639,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         {
             // result vector, totals / cursors, flags -- and, unless the partition is certain, the order check -- in ONE launch
             ProfScope p("k_igd_begin", st);
-            const u64 og_check = std::min<u64>((u64)cus * 8, ((u64)nq + ORD_TPB * 4 - 1) / (ORD_TPB * 4));
+            // (every workgroup reads at least one 12-KB step of the batch before it can see disorder: cus x 4 of them keep 12 MB in
+            // flight for a batch that IS in order and cost a shuffled one 12 MB, not 25)
+            const u64 og_check = std::min<u64>((u64)cus * 4, ((u64)nq + ORD_TPB * 4 - 1) / (ORD_TPB * 4));
             const unsigned og = (unsigned)std::max<u64>(1, flag0 ? (n_init + ORD_TPB - 1) / ORD_TPB : std::max<u64>(og_check, std::min<u64>(64, (n_init + ORD_TPB - 1) / ORD_TPB)));
             hipLaunchKernelGGL(vec ? k_igd_begin<true> : k_igd_begin<false>, dim3(og), dim3(ORD_TPB), 0, st, (unsigned long long *)hits, n_bins,
                                d_tot0, n_tot0, d_unsorted, d_next_flag, heavy.count, flag0, qc, qs, qe, nq, v.n_chrom, cq_off);

@@ -955,6 +955,26 @@ gtars_status launch_has_adjacent_equal(const u32 *a, u64 n, u32 *dup, hipStream_
     return GTARS_OK;
 }
 
+// out bit map[p] |= in bit p, p < n: a bitmap over one stored order carried to another (the flat companion of a nested
+// AIList index marks hits by ITS positions; the caller wants the index's own: gtars_mark_overlapped_device).  `out` zeroed.
+__global__ void __launch_bounds__(256)
+k_permute_marks(const u32 *__restrict__ in, const u32 *__restrict__ map, u64 n, u32 *__restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        if (in[p >> 5] & (1u << (p & 31u))) {
+            const u32 q = map[p];
+            atomicOr(&out[q >> 5], 1u << (q & 31u));
+        }
+    }
+}
+
+gtars_status launch_permute_marks(const u32 *in, const u32 *map, u64 n, u32 *out, hipStream_t st) {
+    if (!n) return GTARS_OK;
+    hipLaunchKernelGGL(k_permute_marks, dim3(stream_grid(n, 256)), dim3(256), 0, st, in, map, n, out);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
 // ---------------------------------------------------------------- LOLA cells
 __global__ void k_lola_contingency(const u64 *__restrict__ user_hits, const u64 *__restrict__ universe_hits,
                                    u64 n_files, i64 user_size, i64 universe_size, i64 *__restrict__ a,

@@ -73,6 +73,8 @@ class OverlapIndex:
 
     def sublist_offsets(self, c: int):
         n = int(lib.gtars_index_n_sublists(self._h, c))
+        if n == 0:  # (a chromosome without intervals, or a Bits-kind index)
+            return []
         out = np.zeros(n, dtype=np.uint64)
         check(lib.gtars_index_sublist_offsets(self._h, c, ptr(out)))
         return [int(x) for x in out]

@@ -273,6 +273,69 @@ def test_index_side_subset_kats_and_random(ga, kind, monkeypatch):
         assert sorted(set(got)) == list(zip(*[x.tolist() for x in exp]))
 
 
+def test_nested_ailist_index_answers_order_free_calls_on_its_flat_companion(ga):
+    """The reference's default IndexedRegionSet index is AIList (indexed_region_set.rs:111-113), and count / any / find_overlaps
+    (sorted unique source rows) / subset_by_overlaps / intersect_all do not depend on its enumeration order: an AIList-kind
+    index with NESTED sub-lists (ChIP-like C2' universe: 1 % of the intervals 5-100 kbp wide) answers them on the blocked
+    structure of a flat companion -- the LDS kernels run (profiling facts), the results are the oracle's, and the device bitmap
+    of gtars_mark_overlapped_device is in THIS index's stored (sub-list major) order.  AIList-order enumeration stays exact."""
+    import torch
+
+    from gtars_amd import _lib
+
+    rng = np.random.default_rng(2024)
+    n, n_chrom, span = 60_000, 3, 12_000_000  # an interval per 600 bp; 2 % of them 5-100 kbp wide: they contain dozens of others
+    c = rng.integers(0, n_chrom, n).astype(np.uint32)
+    s = rng.integers(0, span, n).astype(np.uint32)
+    w = np.where(rng.random(n) < 0.02, rng.integers(5_000, 100_000, n), rng.integers(100, 900, n))
+    e = (s + w).astype(np.uint32)
+    nq = 300_000
+    qc = rng.integers(0, n_chrom + 1, nq).astype(np.uint32)
+    qc[qc == n_chrom] = UNK
+    qs = rng.integers(0, span + 50_000, nq).astype(np.uint32)
+    qe = (qs + rng.integers(0, 700, nq)).astype(np.uint32)
+    g, o = _pair(ga, c, s, e, n_chrom=n_chrom, kind=KIND_AILIST)
+    assert max(len(g.sublist_offsets(ch)) for ch in range(n_chrom)) > 1  # nested: no blocked structure of its own
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    try:
+        for mo in (None, 1, 30):
+            assert np.array_equal(g.count_overlaps(qc, qs, qe, mo), o.count_overlaps(qc, qs, qe, mo).astype(np.uint32)), mo
+            assert np.array_equal(g.any_overlaps(qc, qs, qe, mo), o.any_overlaps(qc, qs, qe, mo)), mo
+        n_small = 40_000
+        og, ig = g.find_overlap_indices(qc[:n_small], qs[:n_small], qe[:n_small])
+        oo, io = o.irs_find_overlaps(c, s, e, qc[:n_small], qs[:n_small], qe[:n_small])
+        assert og.tolist() == oo.tolist() and ig.tolist() == io.tolist()
+        for mo in (None, 25):
+            got = g.subset_by_overlaps(qc, qs, qe, mo)
+            exp = oracle.mco_subset_by_overlaps(o, qc, qs, qe, mo)
+            assert all(a.tolist() == b.tolist() for a, b in zip(got, exp)), mo
+            assert g.subset_source_indices(qc, qs, qe, mo).tolist() == oracle.irs_subset_by_overlaps(o, c, s, e, qc, qs, qe, mo).tolist()
+        dev = torch.device("cuda:0")
+        d = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint32).view(np.int32)).to(dev) for x in (qc, qs, qe)]
+        mark = torch.full(((len(c) + 31) // 32,), -1, dtype=torch.int32, device=dev)  # the call zeroes it
+        g.mark_overlapped_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(qc), mark.data_ptr(), None,
+                                 torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        prof = _lib.prof_read()
+    finally:
+        _lib.lib.gtars_prof_enable(0)
+    assert "k_count_lds" in prof and "k_mark_lds" in prof and "k_count" not in prof, sorted(prof)
+    bits = np.unpackbits(mark.cpu().numpy().view(np.uint8), bitorder="little")[: len(c)].astype(bool)
+    got, base = [], 0
+    for ch in range(n_chrom):
+        ss, ee, _ = g.stored(ch)  # this index's stored order: sub-list major
+        sel = bits[base : base + len(ss)]
+        got += [(ch, int(a), int(b)) for a, b in zip(ss[sel], ee[sel])]
+        base += len(ss)
+    exp = oracle.mco_subset_by_overlaps(o, qc, qs, qe)
+    assert sorted(set(got)) == list(zip(*[x.tolist() for x in exp]))
+    # enumeration in AIList::find order (ailist.rs:153-178) is still this index's own business
+    off_g, ids_g = g.tokenize(qc[:n_small], qs[:n_small], qe[:n_small])
+    off_o, ids_o = o.tokenize(qc[:n_small], qs[:n_small], qe[:n_small])
+    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+
+
 def test_config1_1k_by_1k(ga):
     # BASELINE config 1: 1k x 1k single chromosome (SURVEY 8d C1)
     from gtars_amd import synth

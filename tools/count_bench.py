@@ -11,9 +11,12 @@ from gtars_amd import synth
 
 def main():
     dev = torch.device("cuda:0")
-    u = synth.make_universe(100_000)
+    # OVERLAPPING=1: the ChIP-like C2' universe (overlaps kept, 1 % wide intervals: nested AIList sub-lists); KIND=ailist: the
+    # reference's default IndexedRegionSet index (its order-free calls run on the flat companion's blocked structure)
+    u = synth.make_universe(100_000, overlapping=os.environ.get("OVERLAPPING") == "1")
     base = synth.make_queries(u, 1_000_000)
-    ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    kind = gtars_amd.KIND_AILIST if os.environ.get("KIND", "bits") == "ailist" else gtars_amd.KIND_BITS
+    ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM, kind=kind)
     st = torch.cuda.current_stream().cuda_stream
     for rep in (1, 64):
         qc, qs, qe = (torch.from_numpy(base[k].view(np.int32)).to(dev).repeat(rep) for k in ("chrom", "start", "end"))
