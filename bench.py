@@ -468,12 +468,14 @@ def bench_igd_broad_peaks(dev, stream, ndb=IGD3["ndb"], nq=IGD3["nq"], n_files=I
             os.environ["GTARS_IGD_NO_PIECES"] = env
         else:
             os.environ.pop("GTARS_IGD_NO_PIECES", None)
+        gtars_amd.reload_env()  # (the library snapshots its switches at first use)
         try:
             t = time.time()
             g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=n_files)
             o = {"build_s": round(time.time() - t, 2)}
         finally:
             os.environ.pop("GTARS_IGD_NO_PIECES", None)
+            gtars_amd.reload_env()
         for binary in (False, True):
             f = lambda: g.count_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, hits.data_ptr(), 1, binary, stream)
             f()

@@ -6,7 +6,7 @@ ABI in include/gtars_amd.h).  Importing this package loads that library and
 fails loudly if it has not been built; there is no CPU fallback.
 """
 from . import _lib  # noqa: F401  (raises ImportError when the HIP library is missing)
-from ._lib import KIND_AILIST, KIND_BITS, UNKNOWN_CHROM, CapacityError, GtarsError, NoDeviceError, device_count
+from ._lib import KIND_AILIST, KIND_BITS, UNKNOWN_CHROM, CapacityError, GtarsError, NoDeviceError, device_count, reload_env
 from .engine import IgdIndex, OverlapIndex
 
 __all__ = [
@@ -19,5 +19,6 @@ __all__ = [
     "NoDeviceError",
     "CapacityError",
     "device_count",
+    "reload_env",
 ]
 __version__ = "0.1.0"

@@ -110,6 +110,7 @@ _SIG = {
     "gtars_igd_count_per_query": (C.c_int, [vp, vp, vp, vp, u64, i32, vp]),
     "gtars_igd_find_pairs": (C.c_int, [vp, vp, vp, vp, u64, i32, pp, pp, pu64]),
     "gtars_lola_contingency_device": (C.c_int, [vp, vp, u64, i64, i64, vp, vp, vp, vp, vp]),
+    "gtars_debug_reload_env": (None, []),
     "gtars_prof_enable": (None, [C.c_int]),
     "gtars_prof_reset": (None, []),
     "gtars_prof_read": (C.c_int, [vp, vp, vp, C.c_int]),
@@ -283,3 +284,9 @@ def prof_read():
     launches = (C.c_uint64 * cap)()
     n = lib.gtars_prof_read(C.cast(names, vp), C.cast(ms, vp), C.cast(launches, vp), cap)
     return {names[i].decode(): {"total_ms": ms[i], "launches": int(launches[i])} for i in range(min(n, cap))}
+
+
+def reload_env() -> None:
+    """The library reads its GTARS_* switches ONCE, into a snapshot taken at first use; a process that changes one afterwards
+    (tests, A/B harnesses) calls this to make the library take a new snapshot.  No library call may be in flight."""
+    lib.gtars_debug_reload_env()

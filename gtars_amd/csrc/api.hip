@@ -12,6 +12,9 @@
 #include <thread>
 #include <tuple>
 
+#include <memory>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace gtars {
@@ -20,6 +23,39 @@ namespace gtars {
 static thread_local std::string g_last_error;
 
 void set_error(const std::string &msg) { g_last_error = msg; }
+
+// ---- environment snapshot (common.h: cfg_get) ----------------------------------
+extern "C" char **environ;
+namespace {
+using EnvMap = std::unordered_map<std::string, std::string>;
+std::mutex g_env_mu;
+std::shared_ptr<const EnvMap> g_env;  // never freed while a reader may hold a value: old snapshots are kept (g_env_old)
+std::vector<std::shared_ptr<const EnvMap>> g_env_old;
+std::shared_ptr<const EnvMap> take_env_snapshot() {
+    auto m = std::make_shared<EnvMap>();
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "GTARS_", 6) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (!eq) continue;
+        (*m)[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+    }
+    return m;
+}
+}  // namespace
+const char *cfg_get(const char *name) {
+    std::shared_ptr<const EnvMap> m;
+    {
+        std::lock_guard<std::mutex> lk(g_env_mu);
+        if (!g_env) g_env = take_env_snapshot();
+        m = g_env;
+    }
+    auto it = m->find(name);
+    return it == m->end() ? nullptr : it->second.c_str();  // (the snapshot outlives the call: see g_env_old)
+}
+long cfg_int(const char *name, long dflt) {
+    const char *v = cfg_get(name);
+    return v && *v ? atol(v) : dflt;
+}
 
 gtars_status fail(gtars_status st, const std::string &msg) {
     g_last_error = msg;
@@ -242,7 +278,7 @@ static gtars_status guarded(F &&f) {
 // K1 policy: large builds are ordered by the device radix sort, small ones by std::stable_sort
 // (identical results; GTARS_DEVICE_SORT=0/1 forces one path, used by the tests)
 static bool use_device_sort(u64 n) {
-    if (const char *e = getenv("GTARS_DEVICE_SORT")) return atoi(e) != 0;
+    if (const char *e = cfg_get("GTARS_DEVICE_SORT")) return atoi(e) != 0;
     return n >= (1u << 16);
 }
 
@@ -478,7 +514,7 @@ struct gtars_igd {
         t.carry = tile_carry.p;
         t.bnd = tile_bnd.p;
         t.chrom_tile_off = chrom_tile_off.p;
-        t.pme_file = pme_ready && !getenv("GTARS_IGD_NO_PME") ? pme_file.p : nullptr;
+        t.pme_file = pme_ready && !cfg_get("GTARS_IGD_NO_PME") ? pme_file.p : nullptr;
         t.pm = tile_pm.p;
         t.files16 = tile_files16.p;
         t.tab = tile_tab.p;
@@ -554,7 +590,7 @@ struct gtars_igd {
             }
             // the fine tables (IgdTiles::route_f*), when they fit the routing kernel's LDS next to its 16-bit counters
             u32 fsh0 = 16;
-            if (const char *e = getenv("GTARS_IGD_ROUTE_FSHIFT_MIN")) fsh0 = (u32)std::min(31, std::max(16, atoi(e)));  // tests: coarse buckets
+            if (const char *e = cfg_get("GTARS_IGD_ROUTE_FSHIFT_MIN")) fsh0 = (u32)std::min(31, std::max(16, atoi(e)));  // tests: coarse buckets
             for (u32 fsh = fsh0; fsh < 32; ++fsh) {
                 u64 nf = 0;
                 std::vector<u32> fbase(n_chrom + 1, 0);
@@ -600,7 +636,7 @@ struct gtars_igd {
         v.chrom_off = chrom_off.p;
         v.chrom_maxlen = chrom_maxlen.p;
         v.chrom_ntiles = ntiles_ready ? chrom_ntiles.p : nullptr;
-        v.pm = getenv("GTARS_IGD_NO_PM_START") ? nullptr : tile_pm.p;
+        v.pm = cfg_get("GTARS_IGD_NO_PM_START") ? nullptr : tile_pm.p;
         v.n_chrom = n_chrom;
         v.n = (u32)n;
         v.n_files = n_files;
@@ -627,6 +663,13 @@ int gtars_device_count(void) {
 void gtars_free(void *p) { free(p); }
 
 void gtars_prof_enable(int on) { g_prof_on = on != 0; }
+// test hook: take a new snapshot of the GTARS_* environment (common.h: cfg_get); the caller makes sure that no call is in flight
+void gtars_debug_reload_env(void) {
+    auto m = take_env_snapshot();
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    if (g_env) g_env_old.push_back(g_env);  // (a value handed out by cfg_get stays valid)
+    g_env = m;
+}
 void gtars_prof_reset(void) {
     prof_drain();
     g_prof_entries.clear();
@@ -789,7 +832,7 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
             const long budget = 148 * 1024 - 20l * (long)n_chrom - 16 - 2l * (kBucketMax + 8);
             if (budget > 4096) unit_max = (u32)std::min<long>(budget / 2 / 8 * 8, 65528);  // lut entries are u16
         }
-        if (const char *e = getenv("GTARS_TOP_MAX")) {
+        if (const char *e = cfg_get("GTARS_TOP_MAX")) {
             const long v = atol(e);
             if (v >= 64) unit_max = (u32)std::min<long>(v, 65528);
         }
@@ -828,7 +871,7 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
                 }
             h_idc[c] = v0 - (u32)ACC_OWN * h_cblk[c];  // mod 2^32
         }
-        if (getenv("GTARS_NO_AFFINE_IDS")) affine = false;  // tests: force the id records
+        if (cfg_get("GTARS_NO_AFFINE_IDS")) affine = false;  // tests: force the id records
         ix->acc_ids_affine = affine;
         h_rec2.assign((size_t)nb * 8, 0);
         if (!affine) h_rec4.assign((size_t)nb * 16, 0);
@@ -882,7 +925,7 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
         {
             const long left = 158l * 1024 - 16l * 1024 - 2l * (long)(n_units + 16) - 20l * (long)n_chrom - 64;
             while (kBucketMax < 16384 && 2l * (2 * (long)kBucketMax + 16) <= left) kBucketMax *= 2;
-            if (const char *e = getenv("GTARS_TOK_BUCKETS")) {
+            if (const char *e = cfg_get("GTARS_TOK_BUCKETS")) {
                 const long v = atol(e);
                 if (v >= 64 && v <= 65536) kBucketMax = (u32)v;
             }
@@ -1057,8 +1100,7 @@ static size_t fused_ws_bytes(const gtars_index *ix, u64 nq) {
     return std::max(enumerate_fused_ws_bytes(nq), tokenize_lds_ws_bytes(nq));
 }
 static bool use_lds_path(const gtars_index *ix) {
-    static const bool disabled = getenv("GTARS_NO_LDS_PATH") != nullptr;
-    if (getenv("GTARS_NO_LDS_PATH_FOR_TEST")) return false;  // tests: read on every call, so one process can compare both paths
+    const bool disabled = cfg_flag("GTARS_NO_LDS_PATH") || cfg_flag("GTARS_NO_LDS_PATH_FOR_TEST");  // A/B runs, tests
     // has_accel: a Bits-kind index, or an AIList-kind one whose chromosomes all have a single sub-list
     return !disabled && ix->has_accel && tokenize_lds_supported(ix->accel());
 }
@@ -1112,7 +1154,7 @@ static gtars_status run_fused_sync(const gtars_index *ix, const u32 *qc, const u
     gtars_status st = run_fused(ix, qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s);
     if (st) return st;
     st = read_scan_head(ws, s, total);
-    if (st == GTARS_OK && getenv("GTARS_TEST_FORCE_LOOKBACK_TIMEOUT")) st = GTARS_ERR_INTERNAL;  // test hook
+    if (st == GTARS_OK && cfg_get("GTARS_TEST_FORCE_LOOKBACK_TIMEOUT")) st = GTARS_ERR_INTERNAL;  // test hook
     if (st != GTARS_ERR_INTERNAL || !use_lds_path(ix) || out.starts || out.ends) return st;
     ep = ScanEpoch();
     st = launch_enumerate_fused(ix->view(), ix->kind, qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, s);
@@ -1392,7 +1434,7 @@ HostPipe &tls_host_pipe() {
 // staging; the next 1M-query call should not find a thread holding on to it).  GTARS_PIPE_KEEP_MB overrides.
 size_t pipe_keep_bytes() {
     static const size_t keep = [] {
-        const char *e = getenv("GTARS_PIPE_KEEP_MB");
+        const char *e = cfg_get("GTARS_PIPE_KEEP_MB");
         return (size_t)(e && *e ? atoll(e) : 1024) << 20;
     }();
     return keep;
@@ -1420,7 +1462,7 @@ static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, co
     // (a chunk costs ~25 us of fixed copy / launch / hand-over overhead per direction: 1M queries in one chunk 512 us,
     // in 2 / 4 / 8 chunks 564 / 745 / 1231 us -- chunks pay from ~4M queries each)
     if (chain) n_chunks = (int)std::min<u64>(PIPE_MAX_CHUNKS, std::max<u64>(1, nq / (4u << 20)));
-    if (const char *e = getenv("GTARS_PIPE_CHUNKS")) n_chunks = std::max(1, std::min(chain ? PIPE_MAX_CHUNKS : 1, atoi(e)));
+    if (const char *e = cfg_get("GTARS_PIPE_CHUNKS")) n_chunks = std::max(1, std::min(chain ? PIPE_MAX_CHUNKS : 1, atoi(e)));
     const u64 chunk = ((nq + n_chunks - 1) / n_chunks + 4095) / 4096 * 4096;
     n_chunks = (int)((nq + chunk - 1) / chunk);
     // device layout: qc | qs | qe | offsets | ids (capacity: what the caller can take, at least a typical batch's hits)
@@ -2115,8 +2157,8 @@ static gtars_status gtars_igd_build_core(const uint32_t *chrom, const int32_t *s
 // typical records (config 3's widths with 1 % of 5-100 kbp records: 2048; measured 1.49 / 1.01 / 0.87 / 0.79 ms at 16384 / 8192 /
 // 4096 / 2048).  The reference's 16384 is the upper bound.  0: no pieces view.
 static i32 igd_piece_bp(const int32_t *start, const int32_t *end, uint64_t n) {
-    if (getenv("GTARS_IGD_NO_PIECES")) return 0;
-    if (const char *e = getenv("GTARS_IGD_PIECE_BP")) {  // tests: tiny pieces on small databases
+    if (cfg_get("GTARS_IGD_NO_PIECES")) return 0;
+    if (const char *e = cfg_get("GTARS_IGD_PIECE_BP")) {  // tests: tiny pieces on small databases
         const long v = atol(e);
         if (v >= 16 && v <= (1 << 30)) return (i32)v;
     }
@@ -2199,7 +2241,7 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
 // pme_file form)
 static const gtars_igd *igd_count_target(const gtars_igd *g, int32_t min_overlap, int binary) {
     if (!g->pieces || min_overlap != 1) return g;
-    if (binary && getenv("GTARS_IGD_NO_PME")) return g;
+    if (binary && cfg_get("GTARS_IGD_NO_PME")) return g;
     return g->pieces;
 }
 
@@ -2285,7 +2327,7 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
     }
     if (igd_sweep_supported(g->view(), nq)) {
         // large batch: group the queries by owner tile once, stream the database once (igd_sweep.hip)
-        const bool no_pme = getenv("GTARS_IGD_NO_PME") != nullptr;  // tests / A-B runs: the credited-file list instead
+        const bool no_pme = cfg_get("GTARS_IGD_NO_PME") != nullptr;  // tests / A-B runs: the credited-file list instead
         if (binary && min_overlap == 1 && !no_pme && (st = g->ensure_pme())) return st;
         Workspace &ws = tls_workspace(2, (hipStream_t)stream);
         st = ws.reserve(igd_sweep_ws_bytes(nq, g->n_tiles, g->n_chrom));
@@ -2294,7 +2336,7 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
                                 (hipStream_t)stream, ws.igd_calls++);
     }
     // small batch: one thread per query (kernels.hip); binary counts with min_overlap == 1 through pme_file as well
-    if (binary && min_overlap == 1 && !getenv("GTARS_IGD_NO_PME") && (st = g->ensure_pme())) return st;
+    if (binary && min_overlap == 1 && !cfg_get("GTARS_IGD_NO_PME") && (st = g->ensure_pme())) return st;
     return launch_igd_count(g->view(), g->tiles().pme_file, d_qc, d_qs, d_qe, nq, min_overlap, binary, d_hits, (hipStream_t)stream,
                             g->tiles().pm);
 }
@@ -2317,7 +2359,7 @@ gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d
     if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
     const size_t F = g->n_files;
     const gtars_igd *gs = igd_count_target(g, min_overlap, binary);  // what a shared pass sweeps
-    const bool no_shared = getenv("GTARS_IGD_NO_SHARED_PASS") != nullptr;  // tests / A-B runs
+    const bool no_shared = cfg_get("GTARS_IGD_NO_SHARED_PASS") != nullptr;  // tests / A-B runs
     for (u32 k0 = 0; k0 < n_sets;) {
         // the longest run of <= 4 consecutive sets that can share a pass
         u32 k1 = k0 + 1;
@@ -2332,7 +2374,7 @@ gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d
             st = gtars_igd_count_device(g, d_qc + lo, d_qs + lo, d_qe + lo, n, min_overlap, binary, d_hits + (size_t)k0 * F, stream);
             if (st) return st;
         } else {
-            const bool no_pme = getenv("GTARS_IGD_NO_PME") != nullptr;
+            const bool no_pme = cfg_get("GTARS_IGD_NO_PME") != nullptr;
             if (binary && min_overlap == 1 && !no_pme && (st = gs->ensure_pme())) return st;
             Workspace &ws = tls_workspace(2, (hipStream_t)stream);
             st = ws.reserve(igd_sweep_ws_bytes(n, gs->n_tiles, gs->n_chrom));

@@ -31,6 +31,15 @@ gtars_status hip_fail(hipError_t e, const char *what, const char *file, int line
 
 gtars_status require_device();
 
+// ---- environment switches -----------------------------------------------------
+// Every GTARS_* variable is read ONCE, into an immutable snapshot taken at first use (a getenv per call raced with a host
+// program's setenv, and a switch flipped mid-process reached some kernels and not others).  cfg_get returns the snapshot's
+// value or null.  gtars_debug_reload_env() (test hook, not in the public headers' contract) takes a new snapshot: tests and
+// the bench harness call it after they change a switch.
+const char *cfg_get(const char *name);
+inline bool cfg_flag(const char *name) { return cfg_get(name) != nullptr; }
+long cfg_int(const char *name, long dflt);
+
 // ---- device views ----------------------------------------------------------
 // One genome-wide overlap index: every chromosome's intervals concatenated in
 // chromosome-id order, SoA, u32.
@@ -240,9 +249,8 @@ gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, 
 constexpr u32 MS_MAX_BINS = 36864;       // one-level split: 144 KB of LDS counters
 constexpr u32 MS_MAX_BINS_2L = 65535;    // two-level split (no per-bin LDS state): what 16-bit keys can name
 size_t multisplit_ws_bytes(u32 n_bins, u32 n);
-// key: u32 keys, or unsigned short keys when key16 (n_bins <= 65535); clamp_a: a = max((i32)a, 0) on the way (raw IGD query
-// starts); table_ready: the caller has already counted the keys into multisplit_table(ws) -- one row of n_bins counters per
-// workgroup of a multisplit_workgroups(n)-workgroup grid over contiguous chunks of ceil(n / workgroups) elements
+// key: 16-bit keys (n_bins <= 65535); `a` is clamped on the way, a = max((i32)a, 0) (raw IGD query starts, igd.rs:517).  The
+// caller's own kernel has COUNTED the keys before the call (see multisplit_pairs in sort.hip for what it leaves where).
 // Bins (tiles of the IGD sweep) far heavier than the average, listed in PARTS of `part` elements so that their consumer can hand
 // them to several workgroups: part 0 of every bin is implied, parts 1 .. ceil(total / part) - 1 of a bin with more than `part`
 // elements are appended to list[] as (bin, part) -- at most cap entries (sum over bins of total / part never exceeds n / part);
@@ -259,16 +267,15 @@ struct HeavyBins {
             if (at + p < cap) list[at + p] = make_uint2(bin, p + 1);
     }
 };
-gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
-                              uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if = nullptr,
-                              bool table_ready = false, const u32 *set_bounds = nullptr, const HeavyBins *heavy = nullptr,
-                              u32 n_count_rows = 0);  // table_ready + two-level: rows the caller's counting kernel wrote
+gtars_status multisplit_pairs(const unsigned short *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
+                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, const u32 *set_bounds,
+                              const HeavyBins *heavy, u32 n_count_rows);
 // set_bounds (host, 3 values; null: one set): the input holds up to 4 row ranges ("sets") -- first row of set 1, 2, 3, 0xFFFFFFFF
 // for a set that does not exist; the set of a row leaves in bit 31 of its pair (b: set & 1, a: set >> 1; see SetTags, sort.hip)
 u32 multisplit_workgroups(u32 n);
 u32 multisplit_chunk(u32 n);  // elements per workgroup of that grid (a multiple of 4)
 u32 *multisplit_table(void *ws);
-// table_ready callers of a two-level split (large n, many bins) leave only the bin totals here (zeroed first); null: one-level
+// two-level split (large n, many bins): start of the words the caller zeroes (multisplit_zeroed_words); null: one-level
 u32 *multisplit_totals(void *ws, u32 n_bins, u32 n);
 // ... and the totals of the split's coarse bins (bin >> multisplit_coarse_shift(n_bins), <= 256 of them) here, inside the zeroed words
 u32 *multisplit_coarse_totals(void *ws, u32 n_bins, u32 n);

@@ -31,6 +31,7 @@
 
 namespace gtars {
 gtars_status fail(gtars_status st, const std::string &msg);
+const char *cfg_get(const char *name);  // snapshot of the GTARS_* environment (common.h)
 
 // runs f(), turning C++ exceptions into a status (nothing may unwind through the extern "C" boundary)
 template <class F>
@@ -44,6 +45,7 @@ static gtars_status guarded(F &&f) {
     }
 }
 }
+using gtars::cfg_get;
 using gtars::fail;
 
 namespace {
@@ -51,7 +53,7 @@ namespace {
 // Host threads worth starting: hardware threads, capped by the container's CPU quota (cgroup v2 cpu.max)
 // and by `cap`; GTARS_HOST_THREADS overrides.
 unsigned host_thread_budget(unsigned cap) {
-    if (const char *e = getenv("GTARS_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
+    if (const char *e = cfg_get("GTARS_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
     unsigned nt = std::thread::hardware_concurrency();
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
         long long quota = 0, period = 0;

@@ -86,13 +86,10 @@ __device__ __forceinline__ int quad_bcast(int v) {  // every lane of a quad rece
 constexpr int IGD_SEEN = 32;   // per-thread list of credited files (binary counting)  // records after the tile kept in LDS too (a query's scan may run past its tile)
 
 // ---- query preparation: validity rules of Igd::count_overlaps (igd.rs:514-517) ------------------
-// Also finds every query's OWNER tile (IgdTiles::bnd: the first tile of its chromosome with bnd > start) by a binary
-// search of the bounds, which the workgroup keeps in LDS (4 B per tile), and notes whether the batch is already in
-// (chromosome, start) order.  tid = n_tiles: no owner (invalid query, unknown chromosome, or past every record's reach).
-constexpr int PREP_TPB = 1024;
 // (values in, values out, selects instead of conditional stores: with reference parameters into per-lane arrays the compiler
 // merged the stores of the two branches through a SELECTED ADDRESS, which forced the arrays -- the routing kernel's s[] and e[] --
 // into scratch memory: 48 bytes per lane written and read back through the vector-memory pipe on every step)
+constexpr int PREP_TPB = 1024;
 __device__ __forceinline__ void igd_prep_one(u32 c_in, u32 s_in, u32 e_in, u32 n_chrom, u32 &c, i32 &s, i32 &e) {
     const i32 s0 = (i32)s_in, e0 = (i32)e_in;  // `as i32` (igd.rs:549-550)
     const bool bad = s0 >= e0 || e0 <= 0 || c_in >= n_chrom;
@@ -101,19 +98,12 @@ __device__ __forceinline__ void igd_prep_one(u32 c_in, u32 s_in, u32 e_in, u32 n
     e = bad ? 0 : e0;
 }
 
-template <bool BUCKET>
+// Prepared copies of the three columns + "is the batch out of (chromosome, start) order?" -- the FULL-SORT path only: databases
+// beyond 65534 tiles (134M records: 16-bit owner keys do not reach) and GTARS_IGD_FULL_SORT (tests); everything smaller is routed
+// on the raw columns by k_igd_route.
 __global__ void __launch_bounds__(PREP_TPB)
-k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
-                   const u32 *__restrict__ bnd, const u32 *__restrict__ chrom_tile_off, u32 n_tiles, u32 chunk,
-                   u32 *__restrict__ kc, u32 *__restrict__ ks, u32 *__restrict__ ke, u32 *__restrict__ tid,
-                   u32 *__restrict__ unsorted) {
-    extern __shared__ u32 s_bnd[];  // [n_tiles] | chrom_tile_off [n_chrom + 1]
-    u32 *s_cto = s_bnd + n_tiles;
-    if (BUCKET) {
-        for (u32 t = threadIdx.x; t < n_tiles; t += PREP_TPB) s_bnd[t] = bnd[t];
-        for (u32 c = threadIdx.x; c <= n_chrom; c += PREP_TPB) s_cto[c] = chrom_tile_off[c];
-        __syncthreads();
-    }
+k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom, u32 chunk,
+                   u32 *__restrict__ kc, u32 *__restrict__ ks, u32 *__restrict__ ke, u32 *__restrict__ unsorted) {
     const u32 lo = blockIdx.x * chunk, hi = min(nq, lo + chunk);
     const int lane = threadIdx.x & 63;
     bool bad = false;
@@ -123,7 +113,7 @@ k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const
         u32 c = n_chrom;
         i32 s = 0, e = 0;
         if (ok) igd_prep_one(qc[i], qs[i], qe[i], n_chrom, c, s, e);
-        // already in (chromosome, start) order?  then the sweep can skip the partition (BED inputs usually are)
+        // already in (chromosome, start) order?  then the sort is skipped (BED inputs usually are)
         u32 pc = __shfl_up(c, 1, 64);
         u32 ps = __shfl_up((u32)s, 1, 64);
         if (lane == 0 && ok && i > 0) {
@@ -136,23 +126,6 @@ k_igd_prep_queries(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const
             kc[i] = c;
             ks[i] = (u32)s;
             ke[i] = (u32)e;
-            if (BUCKET) {
-                u32 t = n_tiles;
-                if (c < n_chrom) {
-                    u32 l = s_cto[c];
-                    const u32 h0 = s_cto[c + 1];
-                    u32 h = h0;
-                    while (l < h) {
-                        const u32 mid = l + ((h - l) >> 1);
-                        if (s_bnd[mid] <= (u32)s)
-                            l = mid + 1;
-                        else
-                            h = mid;
-                    }
-                    t = l < h0 ? l : n_tiles;
-                }
-                tid[i] = t;
-            }
         }
     }
     if (__any(bad) && lane == 0) *unsorted = 1u;
@@ -279,7 +252,7 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
     // loads and one 8-byte key store per step instead of twelve loads and four stores (the loop was instruction-bound: 17.8k
     // cycles per step by the in-kernel stamps, ~500 VALU instructions per wave and step).  The raw columns of the NEXT step
     // are loaded while the current one is searched (one workgroup per CU: nothing else covers the HBM latency).  Whether the
-    // batch is in order is no longer this kernel's business (k_igd_order_check runs in front of it).
+    // batch is in order is decided in front of this kernel (k_igd_begin).
     // (three plain vectors, not arrays filled through a lambda: those stayed in scratch memory -- 48 bytes per lane written and
     // read back through the vector-memory pipe on every step)
     typedef u32 v4u __attribute__((ext_vector_type(4)));
@@ -483,74 +456,8 @@ k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restr
     }
 }
 
-// Is the batch in (chromosome, start) order after the validity rules and the start clamp (igd.rs:514-517; rejected queries count
-// as chromosome n_chrom, i.e. they must come last)?  Raises *flag otherwise.  A pass of its own over the raw columns (12 bytes
-// per query at streaming speed: ~25 us for 1e7 queries) instead of a side job of the routing kernel, so that a batch that IS in
-// order -- BED files usually are -- never pays for routing it (0.09 ms at config 3); returns at once when the probe in
-// k_igd_call_init has already seen disorder.
 constexpr int ORD_TPB = 256;
-template <bool VEC>
-__global__ void __launch_bounds__(ORD_TPB)
-k_igd_order_check(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u32 nq, u32 n_chrom,
-                  u32 *__restrict__ flag, u32 *__restrict__ cq_off) {
-    // By-product for the in-order continuation: cq_off[c] = first row whose (prepared) chromosome is >= c, c = 0 .. n_chrom -- the
-    // thread that sees a chromosome change at row i writes the entries of every chromosome in between (a batch in order has each
-    // boundary exactly once; a batch out of order raises the flag and nobody reads the table).  Was a kernel of its own
-    // (k_igd_chrom_segments: n_chrom + 1 binary searches over the batch, 7 us + a launch).
-    if (*flag) return;
-    const int lane = threadIdx.x & 63;
-    bool bad = false;
-    for (u64 base = (u64)blockIdx.x * (ORD_TPB * 4); base < nq; base += (u64)gridDim.x * (ORD_TPB * 4)) {
-        const u64 i0 = base + (u64)threadIdx.x * 4;
-        u32 rc[4], rs[4], re[4];
-        if (VEC && i0 + 4 <= nq) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(qc + i0), b = *reinterpret_cast<const uint4 *>(qs + i0),
-                        d = *reinterpret_cast<const uint4 *>(qe + i0);
-            rc[0] = a.x, rc[1] = a.y, rc[2] = a.z, rc[3] = a.w;
-            rs[0] = b.x, rs[1] = b.y, rs[2] = b.z, rs[3] = b.w;
-            re[0] = d.x, re[1] = d.y, re[2] = d.z, re[3] = d.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = i0 + u < nq;
-                rc[u] = in ? qc[i0 + u] : GTARS_UNKNOWN_CHROM;  // past the end: "rejected", sorts last
-                rs[u] = in ? qs[i0 + u] : 0u;
-                re[u] = in ? qe[i0 + u] : 0u;
-            }
-        }
-        // the element in front of this lane's four: the previous lane's last one; lane 0 reads it
-        const bool edge = lane == 0 && i0 > 0 && i0 < nq;
-        const u32 ec = edge ? qc[i0 - 1] : 0u, es = edge ? qs[i0 - 1] : 0u, ee = edge ? qe[i0 - 1] : 0u;
-        u32 c[4];
-        i32 s[4], e[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
-        u32 pc = __shfl_up(c[3], 1, 64);
-        i32 ps = __shfl_up(s[3], 1, 64);
-        if (lane == 0) {
-            i32 pe;
-            igd_prep_one(ec, es, ee, n_chrom, pc, ps, pe);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const u64 i = i0 + u;
-            if (i < nq) {
-                if (i > 0 && igd_out_of_order(pc, ps, c[u], s[u])) bad = true;
-                // chromosome boundaries (c[u] <= n_chrom after the validity rules)
-                const u32 from = i == 0 ? 0u : pc + 1u;
-                if (i == 0 || c[u] > pc)
-                    for (u32 k = from; k <= c[u]; ++k) cq_off[k] = (u32)i;
-                if (i == (u64)nq - 1)
-                    for (u32 k = c[u] + 1u; k <= n_chrom; ++k) cq_off[k] = nq;
-            }
-            pc = c[u];
-            ps = s[u];
-        }
-    }
-    if (__any(bad) && lane == 0) *flag = 1u;
-}
-
-// k_igd_call_init + k_igd_order_check as ONE launch (the fused routing path; a launch costs ~5 us on this chain): every thread
+// Start of a call on the partition path, ONE launch (round 3: k_igd_call_init + k_igd_order_check; a launch costs ~5 us): every thread
 // zeroes its words of the result vector and of the split's totals / cursors, workgroup 0 the next call's flag and the heavy-tile
 // count; then the order check -- a workgroup leaves as soon as it (or anybody) has seen disorder: no probe launch in front.
 template <bool VEC>
@@ -1493,11 +1400,11 @@ gtars_status igd_build_pme_file(const IgdView &v, i32 *pme, void *ws, size_t ws_
 // ---- launcher ------------------------------------------------------------------------------------
 
 bool igd_sweep_supported(const IgdView &v, u64 nq) {
-    if (getenv("GTARS_NO_IGD_SWEEP")) return false;
+    if (cfg_get("GTARS_NO_IGD_SWEEP")) return false;
     // The sweep reads the whole database once per batch (0.37 ms per 5e7 records) whatever the batch size; the per-query
     // kernel costs ~1.2 ns per query at config-3/4 densities.  Crossover measured on config 4 (5e7 records): ~300k
     // queries -- the 1e5-region user set goes per query (0.17 instead of 0.37 ms), the 1e6-region universe sweeps.
-    const u64 min_q = getenv("GTARS_IGD_SWEEP_MIN") ? (u64)atoll(getenv("GTARS_IGD_SWEEP_MIN"))
+    const u64 min_q = cfg_get("GTARS_IGD_SWEEP_MIN") ? (u64)atoll(cfg_get("GTARS_IGD_SWEEP_MIN"))
                                                     : std::max<u64>(1u << 16, (u64)v.n / 256);
     // u32 LDS bins: a workgroup adds at most (its queries x hits) -- keep the batch below 2^31 queries
     return v.n > 0 && v.n_files > 0 && v.n_files <= 16384 && nq >= min_q && nq < (1ull << 31);
@@ -1535,29 +1442,23 @@ gtars_status launch_igd_tile_max_end(const i32 *ends, const u32 *tile_first, con
     return GTARS_OK;
 }
 
-// the fused routing kernel can serve this database: with the fine tables in LDS or, for larger databases, the tile bounds in
-// global memory -- up to 65534 tiles (16-bit owner keys)
-static bool igd_fused_route_fits(const IgdView &v, const IgdTiles &tl, bool *fine) {
-    if (!tl.route_lut || getenv("GTARS_IGD_NO_FUSED_ROUTE") || tl.n_tiles + 1 > MS_MAX_BINS_2L) return false;
+// The routing kernel can serve this database -- with the fine tables in LDS or, for larger databases, the tile bounds in global
+// memory -- up to 65534 tiles = 134M records (16-bit owner keys): the batch is then PARTITIONED by owner tile (or taken as it
+// lies when it is in order).  Beyond that, and for GTARS_IGD_FULL_SORT=1 (tests / A-B runs), the batch is fully sorted by
+// (chromosome, start).  (Round 2's two-kernel preparation in front of the partition is gone: no database size selected it.)
+static bool igd_route_fits(const IgdView &v, const IgdTiles &tl, bool *fine) {
+    if (!tl.route_lut || !tl.bnd || cfg_flag("GTARS_IGD_FULL_SORT") || tl.n_tiles + 1 > MS_MAX_BINS_2L) return false;
     const size_t limit = 160 * 1024 - 64;
     const bool with_fine = tl.route_flut && igd_route_fine_lds_bytes(tl.n_tiles, v.n_chrom, tl.route_fn) <= limit &&
-                           !getenv("GTARS_IGD_ROUTE_BND_GLOBAL");
+                           !cfg_flag("GTARS_IGD_ROUTE_BND_GLOBAL");
     if (fine) *fine = with_fine;
     return with_fine || igd_route_lds_bytes(tl.n_tiles, v.n_chrom, tl.route_n) <= limit;
-}
-static bool igd_bucket_path(const IgdView &v, const IgdTiles &tl) {
-    // queries grouped by owner tile in one partition: through the fused routing kernel (up to 65534 tiles = 134M records), or
-    // through the two-kernel preparation when its tile bounds fit in LDS and the one-level counters can hold the tiles (75M
-    // records); otherwise (and for GTARS_IGD_FULL_SORT=1: tests / A-B runs) the batch is fully sorted by (chromosome, start)
-    const size_t prep_lds = ((size_t)tl.n_tiles + v.n_chrom + 1) * 4;
-    if (getenv("GTARS_IGD_FULL_SORT") || !tl.bnd) return false;
-    return igd_fused_route_fits(v, tl, nullptr) || (tl.n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024);
 }
 
 // several query sets in one sweep: only through the partition (the set of a query travels with its pair), at most 4 sets (two
 // tag bits), one row of LDS counters per set
 bool igd_sweep_sets_supported(const IgdView &v, const IgdTiles &tl, u64 nq, u32 n_sets) {
-    return n_sets >= 1 && n_sets <= 4 && (u64)n_sets * v.n_files <= 16384 && igd_sweep_supported(v, nq) && igd_bucket_path(v, tl);
+    return n_sets >= 1 && n_sets <= 4 && (u64)n_sets * v.n_files <= 16384 && igd_sweep_supported(v, nq) && igd_route_fits(v, tl, nullptr);
 }
 
 gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq64,
@@ -1585,45 +1486,38 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     heavy.part = std::max<u32>(HEAVY_PART_MIN, (u32)std::min<u64>(8ull * (nq / std::max<u32>(n_tiles, 1)), 1u << 30) / SW_TPB * SW_TPB);
     heavy.n_real_bins = n_tiles;
     heavy.cap = nq / heavy.part + 1;
-    if (getenv("GTARS_IGD_NO_HEAVY_PARTS")) heavy.part = 0;  // tests / A-B runs
+    if (cfg_flag("GTARS_IGD_NO_HEAVY_PARTS")) heavy.part = 0;  // tests / A-B runs
     void *scratch = (void *)(((uintptr_t)(heavy.list + (size_t)nq / HEAVY_PART_MIN + 8) + 63) & ~(uintptr_t)63);
     const size_t scratch_bytes = ws_bytes - (size_t)((char *)scratch - (char *)ws);
     (void)sc;
     // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the order check only ever raises the flag.  Several sets: always
     // partitioned (a concatenation of sets is not in order, and the partition is what tags the pairs)
-    const u32 flag0 = getenv("GTARS_IGD_ALWAYS_SORT") || set_bounds ? 1u : 0u;
-    const size_t prep_lds = ((size_t)n_tiles + v.n_chrom + 1) * 4;
-    const bool bucket = igd_bucket_path(v, tl);
-    // routing and histogram fused (no prepared columns at all): when the routing kernel's LDS image fits and a workgroup's
-    // chunk fits its 16-bit counters
-    u32 rt_wg = multisplit_workgroups(nq);
-    u32 rt_chunk = multisplit_chunk(nq);  // a multiple of the 4 queries a lane takes per step
+    const bool always_sort = cfg_flag("GTARS_IGD_ALWAYS_SORT");
+    const u32 flag0 = always_sort || set_bounds ? 1u : 0u;
     bool fine = false;
-    const bool route_fits = igd_fused_route_fits(v, tl, &fine);
-    const size_t rt_lds = fine ? igd_route_fine_lds_bytes(n_tiles, v.n_chrom, tl.route_fn) : igd_route_lds_bytes(n_tiles, v.n_chrom, tl.route_n);
+    const bool routed = igd_route_fits(v, tl, &fine);
     int dev = 0, cus = 256;
     GT_HIP(hipGetDevice(&dev));
     GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (bucket && multisplit_totals(scratch, n_tiles + 1, nq)) {
-        // two-level split: the routing kernel leaves bin TOTALS (atomics), not one table row per workgroup, so its grid is its own
-        // to choose -- every CU gets a chunk once there are 4096 queries per workgroup (a 1.1M-query batch ran on 67 CUs: 35 us)
-        rt_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
-        // (and never more than 65532 queries per workgroup -- its 16-bit counters: batches beyond 16.7M queries take more
-        // workgroups than CUs, which queue, instead of falling back to the two-kernel preparation)
-        rt_wg = std::max<u32>(rt_wg, (nq + 65531u) / 65532u);
-        rt_chunk = ((nq + rt_wg - 1) / rt_wg + 3u) & ~3u;
-    }
-    const bool fused = bucket && route_fits && rt_chunk <= 65535u;
-    if (bucket && !fused && !(n_tiles + 1 <= MS_MAX_BINS && prep_lds <= 160 * 1024))
-        return fail(GTARS_ERR_INTERNAL, "IGD sweep: neither routing form fits this database");  // (cannot happen: see igd_bucket_path)
+    const u32 *t_ql = ql, *t_qh = qh;
+    int interleaved = 0;
+    const u32 *part_flag = nullptr, *part_ab = nullptr, *part_ql = nullptr;
     static std::mutex attr_mu;
-    u32 *d_tot0 = fused ? multisplit_totals(scratch, n_tiles + 1, nq) : nullptr;
-    const u32 n_tot0 = d_tot0 ? (u32)multisplit_zeroed_words(n_tiles + 1) : 0u, n_init = std::max<u32>(std::max<u32>(n_bins, n_tot0), 1u);
-    if (!fused)
-        hipLaunchKernelGGL(k_igd_call_init, dim3((n_init + 255) / 256), dim3(256), 0, st, (unsigned long long *)hits, n_bins, d_unsorted,
-                           flag0, d_tot0, n_tot0, qc, qs, qe, 0u, v.n_chrom, d_next_flag, heavy.count);
-    if (fused) {
+    if (routed) {
+        // ---- the partition path: begin (zeroing + order check) | route (or tile ranges) | split A | split B ----
         if (scratch_bytes < multisplit_ws_bytes(n_tiles + 1, nq)) return fail(GTARS_ERR_INTERNAL, "IGD sweep workspace too small");
+        // The routing kernel's grid: a two-level split (large batches, many tiles) takes the workgroups' counter ROWS, so the grid
+        // is this kernel's own to choose -- every CU gets a chunk once there are 4096 queries per workgroup (a 1.1M-query batch
+        // ran on 67 CUs: 35 us), and never more than 65532 queries per workgroup (16-bit counters: batches beyond 16.7M queries
+        // take more workgroups than CUs, which queue); a one-level split wants one table row per workgroup of ITS grid.
+        u32 *d_tot = multisplit_totals(scratch, n_tiles + 1, nq);  // null: one-level split
+        u32 rt_wg = multisplit_workgroups(nq), rt_chunk = multisplit_chunk(nq);  // (a multiple of the 4 queries a lane takes per step)
+        if (d_tot) {
+            rt_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
+            rt_wg = std::max<u32>(rt_wg, (nq + 65531u) / 65532u);
+            rt_chunk = ((nq + rt_wg - 1) / rt_wg + 3u) & ~3u;
+        }
+        if (rt_chunk > 65535u) return fail(GTARS_ERR_INTERNAL, "IGD sweep: routing chunk exceeds the 16-bit counters");  // (cannot happen)
         {
             static bool done[64] = {};
             std::lock_guard<std::mutex> lock(attr_mu);
@@ -1634,7 +1528,8 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
                 done[dev] = true;
             }
         }
-        u32 *d_tot = multisplit_totals(scratch, n_tiles + 1, nq);  // null: the one-level split wants the per-workgroup table
+        const size_t rt_lds = fine ? igd_route_fine_lds_bytes(n_tiles, v.n_chrom, tl.route_fn) : igd_route_lds_bytes(n_tiles, v.n_chrom, tl.route_n);
+        const u32 n_tot0 = d_tot ? (u32)multisplit_zeroed_words(n_tiles + 1) : 0u, n_init = std::max<u32>(std::max<u32>(n_bins, n_tot0), 1u);
         const bool vec = ((((uintptr_t)qc) | ((uintptr_t)qs) | ((uintptr_t)qe)) & 15u) == 0 && (((uintptr_t)perm) & 7u) == 0;
         {
             // result vector, totals / cursors, flags -- and, unless the partition is certain, the order check -- in ONE launch
@@ -1644,68 +1539,44 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
             const u64 og_check = std::min<u64>((u64)cus * 4, ((u64)nq + ORD_TPB * 4 - 1) / (ORD_TPB * 4));
             const unsigned og = (unsigned)std::max<u64>(1, flag0 ? (n_init + ORD_TPB - 1) / ORD_TPB : std::max<u64>(og_check, std::min<u64>(64, (n_init + ORD_TPB - 1) / ORD_TPB)));
             hipLaunchKernelGGL(vec ? k_igd_begin<true> : k_igd_begin<false>, dim3(og), dim3(ORD_TPB), 0, st, (unsigned long long *)hits, n_bins,
-                               d_tot0, n_tot0, d_unsorted, d_next_flag, heavy.count, flag0, qc, qs, qe, nq, v.n_chrom, cq_off);
+                               d_tot, n_tot0, d_unsorted, d_next_flag, heavy.count, flag0, qc, qs, qe, nq, v.n_chrom, cq_off);
         }
-        ProfScope p("k_igd_route", st);
-        auto route = fine ? (vec ? k_igd_route<true, true> : k_igd_route<false, true>) : (vec ? k_igd_route<true, false> : k_igd_route<false, false>);
-        hipLaunchKernelGGL(route, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom, tl.bnd, tl.chrom_tile_off,
-                           fine ? tl.route_fbase : tl.route_base, tl.route_len, fine ? tl.route_flut : tl.route_lut,
-                           fine ? tl.route_fn : tl.route_n, fine ? tl.route_fshift : tl.route_shift, n_tiles, rt_chunk,
-                           reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted,
-                           d_tot ? multisplit_coarse_totals(scratch, n_tiles + 1, nq) : (u32 *)nullptr, multisplit_coarse_shift(n_tiles + 1),
-                           tl.route_kq, v, tl.first, tl.cnt, tl.chrom, (const u32 *)cq_off, flag0 ? (u32 *)nullptr : ql, qh, heavy);
-    } else {
-        ProfScope p("k_igd_prep_queries", st);
-        const u32 n_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
-        const u32 chunk = ((nq + n_wg - 1) / n_wg + PREP_TPB - 1) / PREP_TPB * PREP_TPB;
-        const size_t lds = bucket ? prep_lds : 0;
-        auto kern = bucket ? k_igd_prep_queries<true> : k_igd_prep_queries<false>;
-        if (lds > 48 * 1024) {
-            static bool done[64] = {};
-            std::lock_guard<std::mutex> lock(attr_mu);
-            if (dev >= 0 && dev < 64 && !done[dev]) {
-                GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                done[dev] = true;
-            }
+        {
+            ProfScope p("k_igd_route", st);
+            auto route = fine ? (vec ? k_igd_route<true, true> : k_igd_route<false, true>) : (vec ? k_igd_route<true, false> : k_igd_route<false, false>);
+            hipLaunchKernelGGL(route, dim3(rt_wg), dim3(RT_TPB), rt_lds, st, qc, qs, qe, nq, v.n_chrom, tl.bnd, tl.chrom_tile_off,
+                               fine ? tl.route_fbase : tl.route_base, tl.route_len, fine ? tl.route_flut : tl.route_lut,
+                               fine ? tl.route_fn : tl.route_n, fine ? tl.route_fshift : tl.route_shift, n_tiles, rt_chunk,
+                               reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted,
+                               d_tot ? multisplit_coarse_totals(scratch, n_tiles + 1, nq) : (u32 *)nullptr, multisplit_coarse_shift(n_tiles + 1),
+                               tl.route_kq, v, tl.first, tl.cnt, tl.chrom, (const u32 *)cq_off, flag0 ? (u32 *)nullptr : ql, qh, heavy);
         }
-        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(PREP_TPB), lds, st, qc, qs, qe, nq, v.n_chrom, tl.bnd, tl.chrom_tile_off, n_tiles,
-                           chunk, kc, ks, ke, perm, d_unsorted);
-    }
-    const u32 *t_ql = ql, *t_qh = qh;
-    int interleaved = 0;
-    const u32 *part_flag = nullptr, *part_ab = nullptr, *part_ql = nullptr;
-    u32 h_unsorted = 1;
-    if (bucket) {
-        // No host round trip: both continuations are enqueued and the flag the routing kernel leaves on the device
-        // picks one -- the partition kernels return at once for a batch that is already in owner order, the range
-        // kernels for one that is not, and the sweep takes its inputs accordingly.
+        // No host round trip: both continuations are enqueued and the flag the order check leaves on the device picks one -- the
+        // partition kernels return at once for a batch that is already in owner order (the routing launch has computed its tile
+        // ranges instead), and the sweep takes its inputs accordingly.
         // K1 (multisplit): (start, end) pairs grouped by owner tile; bin_off[t], bin_off[t + 1] bound tile t's queries
-        gtars_status s1 = fused ? multisplit_pairs(perm, true, qs, qe, true, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
-                                                   scratch, scratch_bytes, st, d_unsorted, true, set_bounds, &heavy, rt_wg)
-                                : multisplit_pairs(perm, false, ks, ke, false, nq, n_tiles + 1, n_tiles, reinterpret_cast<uint2 *>(ss), bin_off,
-                                                   scratch, scratch_bytes, st, d_unsorted, false, set_bounds, &heavy);  // ss, se adjacent: 2 * nq words
+        gtars_status s1 = multisplit_pairs(reinterpret_cast<const unsigned short *>(perm), qs, qe, nq, n_tiles + 1, n_tiles,
+                                           reinterpret_cast<uint2 *>(ss), bin_off, scratch, scratch_bytes, st, d_unsorted, set_bounds, &heavy,
+                                           rt_wg);  // ss, se adjacent: 2 * nq words
         if (s1) return s1;
         part_flag = d_unsorted;
         part_ab = ss;
         part_ql = bin_off;
-        // the in-order continuation reads the batch where it lies: the caller's raw columns (fused; clamped on the way) or
-        // the prepared ones
-        const u32 *oc = fused ? qc : kc;
-        ss = const_cast<u32 *>(fused ? qs : ks);
-        se = const_cast<u32 *>(fused ? qe : ke);
-        ProfScope p("k_igd_tile_ranges", st);
-        if (flag0) {
-            // the partition is certain (several sets, or forced): nothing to enqueue for the in-order continuation
-        } else if (fused) {
-            // (the routing kernel has computed the tile ranges itself when the batch turned out to be in order: cq_off from k_igd_begin)
-        } else {
-            hipLaunchKernelGGL(k_igd_chrom_segments<false>, dim3((v.n_chrom + 1 + 63) / 64), dim3(64), 0, st, oc, (const u32 *)nullptr,
-                               (const u32 *)nullptr, (const u32 *)nullptr, nq, v.n_chrom, cq_off, d_unsorted);
-            hipLaunchKernelGGL(k_igd_tile_ranges<false>, dim3((n_tiles + 255) / 256), dim3(256), 0, st, v, tl.first, tl.cnt, tl.chrom, n_tiles,
-                               ss, cq_off, ql, qh, d_unsorted, heavy);
-        }
+        // the in-order continuation reads the batch where it lies: the caller's raw columns (clamped on the way)
+        ss = const_cast<u32 *>(qs);
+        se = const_cast<u32 *>(qe);
     } else {
-        if (!getenv("GTARS_IGD_ALWAYS_SORT")) {
+        // ---- the full-sort path (databases beyond 134M records; GTARS_IGD_FULL_SORT): prepared columns, radix sort ----
+        hipLaunchKernelGGL(k_igd_call_init, dim3((std::max<u32>(n_bins, 1u) + 255) / 256), dim3(256), 0, st, (unsigned long long *)hits, n_bins,
+                           d_unsorted, flag0, (u32 *)nullptr, 0u, qc, qs, qe, 0u, v.n_chrom, d_next_flag, heavy.count);
+        {
+            ProfScope p("k_igd_prep_queries", st);
+            const u32 n_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
+            const u32 chunk = ((nq + n_wg - 1) / n_wg + PREP_TPB - 1) / PREP_TPB * PREP_TPB;
+            hipLaunchKernelGGL(k_igd_prep_queries, dim3(n_wg), dim3(PREP_TPB), 0, st, qc, qs, qe, nq, v.n_chrom, chunk, kc, ks, ke, d_unsorted);
+        }
+        u32 h_unsorted = 1;
+        if (!always_sort) {
             GT_HIP(hipMemcpyAsync(&h_unsorted, d_unsorted, sizeof(u32), hipMemcpyDeviceToHost, st));
             GT_HIP(hipStreamSynchronize(st));
         }
@@ -1737,7 +1608,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     auto kern = mode == 2 ? k_igd_sweep<2, true> : mode == 1 ? k_igd_sweep<1, false> : mo1 ? k_igd_sweep<0, true> : k_igd_sweep<0, false>;
     const size_t lds_cu = 160 * 1024;  // what a CU has; the static part (search tables) is ~2 KB per workgroup
     const size_t lds_static = (size_t)TAB_LUT_WORDS * 4 + 256;
-    const bool b16 = mode == 2 && !getenv("GTARS_IGD_NO_B16") && lds_cu / (lds16 + lds_static) > lds_cu / (lds + lds_static) &&
+    const bool b16 = mode == 2 && !cfg_get("GTARS_IGD_NO_B16") && lds_cu / (lds16 + lds_static) > lds_cu / (lds + lds_static) &&
                      lds_cu / (lds + lds_static) < 4;
     if (b16) {
         kern = k_igd_sweep<2, true, true>;
@@ -1774,7 +1645,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     }
     GT_HIP(hipGetLastError());
     // which continuation the device took (profiling mode: a deterministic fact for the tests, not a timing)
-    if (bucket) prof_note_device_flag("igd_batch_partitioned", "igd_batch_in_owner_order", d_unsorted, st);
+    if (routed) prof_note_device_flag("igd_batch_partitioned", "igd_batch_in_owner_order", d_unsorted, st);
     return GTARS_OK;
 }
 

@@ -736,7 +736,7 @@ k_igd_count(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
 gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                               i32 min_overlap, int binary, u64 *hits, hipStream_t st, const i32 *pm) {
     if (!binary || min_overlap != 1) pme_file = nullptr;
-    if (min_overlap < 1 || getenv("GTARS_IGD_NO_PM_START")) pm = nullptr;  // (the environment switch: tests / A-B)
+    if (min_overlap < 1 || cfg_get("GTARS_IGD_NO_PM_START")) pm = nullptr;  // (the environment switch: tests / A-B)
     if (v.pieces && (min_overlap != 1 || (binary && !pme_file)))
         return fail(GTARS_ERR_INTERNAL, "IGD count: a pieces view serves min_overlap == 1 (binary: the pme_file form) only");
     if (min_overlap < 1 && !v.chrom_ntiles) return fail(GTARS_ERR_INTERNAL, "IGD count with min_overlap < 1 needs the contigs' tile counts");

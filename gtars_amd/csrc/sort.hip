@@ -138,30 +138,6 @@ struct SetTags {
     }
 };
 
-template <class KeyT>
-__global__ void __launch_bounds__(MS_TPB)
-k_ms_hist(const KeyT *__restrict__ key, u32 n, u32 n_bins, u32 chunk, u32 *__restrict__ table, const u32 *__restrict__ run_if) {
-    if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
-    extern __shared__ u32 ms_bins[];
-    for (u32 b = threadIdx.x; b < n_bins; b += MS_TPB) ms_bins[b] = 0;
-    __syncthreads();
-    const u32 lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (u32 base = lo; base < hi; base += MS_TPB * 8) {
-        u32 k[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32 i = base + (u32)j * MS_TPB + threadIdx.x;
-            k[j] = i < hi ? (u32)key[i] : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (k[j] != 0xFFFFFFFFu) atomicAdd(&ms_bins[k[j]], 1u);
-    }
-    __syncthreads();
-    u32 *row = table + (size_t)blockIdx.x * n_bins;
-    for (u32 b = threadIdx.x; b < n_bins; b += MS_TPB) row[b] = ms_bins[b];
-}
-
 // per bin: exclusive prefix over the workgroups (in place) and the bin total; 16 independent loads per step
 __global__ void k_ms_colscan(u32 *__restrict__ table, u32 n_wg, u32 n_bins, u32 *__restrict__ tot, const u32 *__restrict__ run_if) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
@@ -293,14 +269,14 @@ static_assert(SP_BINS == SP_TPB, "one thread per tile-local bin (counter reset, 
 // KeyT: u32, or unsigned short when every bin fits 16 bits (2 bytes per element less to read and write in both passes).
 // CLAMP (first pass on raw query columns): a = max((i32)a, 0) -- the start clamp of Igd::count_overlaps (igd.rs:517) applied
 // on the way, so that no prepared copy of the columns is ever written.
-// FOLD: the scan of the bin totals is part of the passes (no k_ms_binscan launch: 12 us + a launch for 24k bins).  The cursors
-// then hold RELATIVE counts (zeroed by the caller with the totals), and
+// The scan of the bin totals is part of the passes (no k_ms_binscan launch: 12 us + a launch for 24k bins).  The cursors hold
+// RELATIVE counts (zeroed by the caller), and
 //   pass A: every workgroup scans the <= 256 coarse totals (left by the caller's counting kernel) for itself: a base per coarse
 //           bin in LDS -- a run is reserved at base + atomicAdd(relative cursor); workgroup w additionally sums the counting
 //           workgroups' rows over the fine bins of coarse bin w, w + grid, ..., scans them and writes the fine offsets bin_off[]
 //           (what pass B and the consumer read), and notes the heavy bins;
 //   pass B: a run is reserved at bin_off[bin] + atomicAdd(relative cursor).
-template <bool FINE, class KeyT, bool CLAMP, bool FOLD = false>
+template <bool FINE, class KeyT, bool CLAMP>
 __global__ void __launch_bounds__(SP_TPB)
 k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
              u32 shift, u32 drop_bin, u32 *__restrict__ cursor, KeyT *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if,
@@ -312,7 +288,7 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
     u32 *cnt = s_b + SP_TILE, *toff = cnt + SP_BINS, *gbase = toff + SP_BINS;
     __shared__ u32 s_scan[SP_TPB / 64];
     __shared__ u32 s_min;
-    __shared__ u32 s_cbase[FOLD && !FINE ? 257 : 1];  // exclusive offsets of the coarse bins (+ the grand total)
+    __shared__ u32 s_cbase[!FINE ? 257 : 1];  // exclusive offsets of the coarse bins (+ the grand total)
     const u32 n_tiles = (n + SP_TILE - 1) / SP_TILE;
     // One workgroup per CU (its tile fills the LDS), so nothing else hides a tile's memory latencies: the NEXT tile's elements
     // are requested into a second set of registers before the current tile is ranked (in flight during ranking, reservation,
@@ -338,7 +314,7 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
         }
     };
     if (blockIdx.x < n_tiles) request(blockIdx.x);
-    if constexpr (FOLD && !FINE) {
+    if constexpr (!FINE) {
         // the coarse totals were left by the caller's counting kernel (multisplit_coarse_totals)
         const u32 n_coarse = ((n_bins - 1u) >> shift) + 1u;
         u32 grand;
@@ -438,7 +414,7 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
                 rank[j] = atomicAdd(&cnt[x], 1u);
             } else {
                 // outside the tile's window (FINE only): its own slot from the bin's cursor
-                out_ab[(FOLD ? bin_off[k[j]] : 0u) + atomicAdd(&cursor[k[j]], 1u)] = make_uint2(va[j], vb[j]);
+                out_ab[bin_off[k[j]] + atomicAdd(&cursor[k[j]], 1u)] = make_uint2(va[j], vb[j]);
             }
         }
         __syncthreads();
@@ -450,8 +426,11 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             toff[threadIdx.x] = block_exclusive_scan<SP_TPB>(my_cnt, s_scan, total);
             if (my_cnt) {
                 const u32 bin = FINE ? bin0 + threadIdx.x : threadIdx.x;
-                u32 rel0 = 0;
-                if (FOLD) rel0 = FINE ? bin_off[bin] : s_cbase[bin];
+                u32 rel0;
+                if constexpr (FINE)
+                    rel0 = bin_off[bin];
+                else
+                    rel0 = s_cbase[bin];
                 my_base = rel0 + atomicAdd(&cursor[bin], my_cnt);
             }
         }
@@ -501,7 +480,7 @@ u32 multisplit_chunk(u32 n) {
 }
 u32 *multisplit_table(void *ws) { return (u32 *)ws; }
 static bool multisplit_two_level(u32 n_bins, u32 n) {
-    static const bool one_level = getenv("GTARS_MS_ONE_LEVEL") != nullptr;  // A/B
+    const bool one_level = cfg_flag("GTARS_MS_ONE_LEVEL");  // A/B
     if (n_bins > MS_MAX_BINS) return true;  // beyond the one-level split's LDS counters (databases of 75M+ records)
     return n_bins > 1024 && n >= (1u << 20) && !one_level;
 }
@@ -522,14 +501,17 @@ u32 *multisplit_coarse_totals(void *ws, u32 n_bins, u32 n) {
     return tot ? tot + n_bins + 256 : nullptr;
 }
 
-// KeyT / CLAMP: see k_split_pass.  table_ready: the caller's own kernel has already counted the keys into the table
-// (multisplit_table(ws), one row of n_bins counters per workgroup of a multisplit_workgroups(n) x MS_TPB grid whose workgroup w
-// covers elements [w * chunk, (w + 1) * chunk), chunk = ceil(n / workgroups)) -- the IGD routing kernel does, in the pass
-// that computes the keys.
-template <class KeyT, bool CLAMP>
-static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
-                                       u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
-                                       const u32 *set_bounds, const HeavyBins *heavy, u32 n_count_rows) {
+// The caller's own kernel (the IGD routing kernel, in the pass that computes the keys) has already COUNTED the keys: for a
+// one-level split one row of n_bins u32 counters per workgroup of a multisplit_workgroups(n) x MS_TPB grid whose workgroup w
+// covers elements [w * chunk, (w + 1) * chunk) at multisplit_table(ws); for a two-level split (multisplit_totals(ws) != null)
+// n_count_rows rows of packed 16-bit counts there, the coarse totals at multisplit_coarse_totals(ws), and
+// multisplit_zeroed_words(n_bins) zeroed words from multisplit_totals(ws) on.  Keys are 16 bits wide (n_bins <= 65535); the start
+// clamp of Igd::count_overlaps (igd.rs:517) is applied to `a` on the way.
+gtars_status multisplit_pairs(const unsigned short *key, const u32 *a, const u32 *b, u32 n, u32 n_bins, u32 drop_bin, uint2 *out_ab,
+                              u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, const u32 *set_bounds,
+                              const HeavyBins *heavy, u32 n_count_rows) {
+    typedef unsigned short KeyT;
+    constexpr bool CLAMP = true;
     const SetTags tags = set_bounds ? SetTags{set_bounds[0], set_bounds[1], set_bounds[2]} : SetTags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     if (n_bins == 0 || n_bins > MS_MAX_BINS_2L + 1) return fail(GTARS_ERR_INTERNAL, "multisplit: too many bins");
     if (ws_bytes < multisplit_ws_bytes(n_bins, n)) return fail(GTARS_ERR_INTERNAL, "multisplit workspace too small");
@@ -539,7 +521,7 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
     u32 *cur_a = tot + n_bins, *cur_b = cur_a + 1024;
     KeyT *tmp_key = (KeyT *)(((uintptr_t)(cur_b + n_bins) + 63) & ~(uintptr_t)63);
     uint2 *tmp_ab = reinterpret_cast<uint2 *>(reinterpret_cast<u32 *>(tmp_key) + (((size_t)n + 15) & ~(size_t)15));
-    const size_t lds = (size_t)n_bins * 4;  // (one-level kernels only: n_bins <= MS_MAX_BINS there)
+    const size_t lds = (size_t)n_bins * 4;  // (one-level kernel only: n_bins <= MS_MAX_BINS there)
     constexpr size_t sp_lds = ((size_t)SP_TILE * 3 + (size_t)SP_BINS * 3) * 4;
     // the dynamic-LDS limits belong to the functions (per device); a failed attempt is retried by the next call
     static std::mutex mu;
@@ -549,81 +531,42 @@ static gtars_status multisplit_pairs_t(const KeyT *key, const u32 *a, const u32 
     {
         std::lock_guard<std::mutex> lock(mu);
         if (!done[dev & 15]) {
-            const void *fns[] = {reinterpret_cast<const void *>(k_ms_hist<KeyT>), reinterpret_cast<const void *>(k_ms_scatter<KeyT, CLAMP>)};
-            for (const void *fn : fns) GT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MS_MAX_BINS * 4)));
+            GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ms_scatter<KeyT, CLAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(MS_MAX_BINS * 4)));
             const void *sp[] = {reinterpret_cast<const void *>(k_split_pass<false, KeyT, CLAMP>),
-                                reinterpret_cast<const void *>(k_split_pass<true, KeyT, false>),
-                                reinterpret_cast<const void *>(k_split_pass<false, KeyT, CLAMP, true>),
-                                reinterpret_cast<const void *>(k_split_pass<true, KeyT, false, true>)};
+                                reinterpret_cast<const void *>(k_split_pass<true, KeyT, false>)};
             for (const void *fn : sp) GT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds));
             done[dev & 15] = true;
         }
     }
-    if (n_bins > MS_MAX_BINS && !table_ready)
-        return fail(GTARS_ERR_INTERNAL, "multisplit: more bins than the counting kernel's LDS holds (the caller must count them itself)");
-    if (!table_ready) {
-        ProfScope p("k_ms_hist", st);
-        hipLaunchKernelGGL(k_ms_hist<KeyT>, dim3(n_wg), dim3(MS_TPB), lds, st, key, n, n_bins, chunk, table, run_if);
-    }
     const bool two_level = multisplit_two_level(n_bins, n);
-    // the caller has counted the totals itself (and zeroed the relative cursors behind them: multisplit_zeroed_words): the bin
-    // scan is folded into the two passes
-    const bool fold = table_ready && two_level;
-    if (!fold) {
-        ProfScope p("k_ms_scan", st);
-        if (!table_ready || !two_level)  // (a table_ready caller of a one-level split has filled the per-workgroup table)
-            hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot, run_if);
-        u32 shift = 0;
-        while (((n_bins - 1) >> shift) >= 256u) ++shift;
-        constexpr u32 S_SMALL = (MS_MAX_BINS + MS_TPB - 1) / MS_TPB, S_LARGE = (MS_MAX_BINS_2L + 1 + MS_TPB - 1) / MS_TPB;
-        auto scan = n_bins <= MS_MAX_BINS ? k_ms_binscan<S_SMALL> : k_ms_binscan<S_LARGE>;
-        hipLaunchKernelGGL(scan, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off, shift, two_level ? cur_a : (u32 *)nullptr, cur_b,
-                           run_if, heavy ? *heavy : HeavyBins{});
-    }
     if (two_level) {
-        u32 shift = 0;
-        while (((n_bins - 1) >> shift) >= 256u) ++shift;
+        // the bin scan is part of the two passes (k_split_pass: relative cursors, column sums of the counting workgroups' rows)
+        const u32 shift = multisplit_coarse_shift(n_bins);
         const u32 tiles = (n + SP_TILE - 1) / SP_TILE;
         const unsigned grid = std::min<u32>(256, tiles);
         ProfScope p("k_split_pass", st);
         const SetTags no_tags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (fold) {
-            hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP, true>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr,
-                               n, shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)table, n_bins, bin_off,
-                               heavy ? *heavy : HeavyBins{}, (const u32 *)(cur_a + 256), n_count_rows);
-            hipLaunchKernelGGL((k_split_pass<true, KeyT, false, true>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
-                               (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if,
-                               no_tags, (const u32 *)nullptr, n_bins, bin_off, HeavyBins{}, (const u32 *)nullptr, 0u);
-        } else {
-            hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n,
-                               shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)nullptr, 0u, (u32 *)nullptr, HeavyBins{},
-                               (const u32 *)nullptr, 0u);
-            hipLaunchKernelGGL((k_split_pass<true, KeyT, false>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key,
-                               (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if,
-                               no_tags, (const u32 *)nullptr, 0u, (u32 *)nullptr, HeavyBins{}, (const u32 *)nullptr, 0u);
-        }
+        hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n, shift,
+                           drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)table, n_bins, bin_off, heavy ? *heavy : HeavyBins{},
+                           (const u32 *)(cur_a + 256), n_count_rows);
+        hipLaunchKernelGGL((k_split_pass<true, KeyT, false>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key, (const u32 *)nullptr,
+                           (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if, no_tags,
+                           (const u32 *)nullptr, n_bins, bin_off, HeavyBins{}, (const u32 *)nullptr, 0u);
     } else {
+        {
+            ProfScope p("k_ms_scan", st);
+            hipLaunchKernelGGL(k_ms_colscan, dim3((n_bins + 255) / 256), dim3(256), 0, st, table, n_wg, n_bins, tot, run_if);
+            constexpr u32 S_SMALL = (MS_MAX_BINS + MS_TPB - 1) / MS_TPB;
+            hipLaunchKernelGGL(k_ms_binscan<S_SMALL>, dim3(1), dim3(MS_TPB), 0, st, tot, n_bins, bin_off, 0u, (u32 *)nullptr, cur_b, run_if,
+                               heavy ? *heavy : HeavyBins{});
+        }
         ProfScope p("k_ms_scatter", st);
-        hipLaunchKernelGGL((k_ms_scatter<KeyT, CLAMP>), dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off,
-                           drop_bin, out_ab, run_if, tags);
+        hipLaunchKernelGGL((k_ms_scatter<KeyT, CLAMP>), dim3(n_wg), dim3(MS_TPB), lds, st, key, a, b, n, n_bins, chunk, table, bin_off, drop_bin,
+                           out_ab, run_if, tags);
     }
     GT_HIP(hipGetLastError());
     return GTARS_OK;
-}
-
-gtars_status multisplit_pairs(const void *key, bool key16, const u32 *a, const u32 *b, bool clamp_a, u32 n, u32 n_bins, u32 drop_bin,
-                              uint2 *out_ab, u32 *bin_off, void *ws, size_t ws_bytes, hipStream_t st, const u32 *run_if, bool table_ready,
-                              const u32 *set_bounds, const HeavyBins *heavy, u32 n_count_rows) {
-    if (key16 && n_bins > 65535u) return fail(GTARS_ERR_INTERNAL, "multisplit: 16-bit keys need <= 65535 bins");
-    if (key16)
-        return clamp_a ? multisplit_pairs_t<unsigned short, true>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
-                                                                  ws_bytes, st, run_if, table_ready, set_bounds, heavy, n_count_rows)
-                       : multisplit_pairs_t<unsigned short, false>((const unsigned short *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws,
-                                                                   ws_bytes, st, run_if, table_ready, set_bounds, heavy, n_count_rows);
-    return clamp_a ? multisplit_pairs_t<u32, true>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
-                                                   table_ready, set_bounds, heavy, n_count_rows)
-                   : multisplit_pairs_t<u32, false>((const u32 *)key, a, b, n, n_bins, drop_bin, out_ab, bin_off, ws, ws_bytes, st, run_if,
-                                                    table_ready, set_bounds, heavy, n_count_rows);
 }
 
 __global__ void k_iota(u32 *__restrict__ p, u32 n) {

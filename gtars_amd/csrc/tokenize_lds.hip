@@ -983,7 +983,7 @@ k_count_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
 // ---------------------------------------------------------------- launchers
 
 static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
+    const char *v = cfg_get(name);
     return v && *v ? atoi(v) : dflt;
 }
 
@@ -1105,7 +1105,7 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     // one 1024-thread workgroup per CU: one LDS copy of the search keys, 16 waves -- what 128 VGPRs admit
     const u32 stage = stage_words(a, TPB, 1);
     const size_t lds = tok_lds_bytes(a) + (size_t)stage * 4 * (TPB / 64);
-    static const u32 spin_limit = (u32)env_int("GTARS_TOK_SPIN_LIMIT", 4096);
+    const u32 spin_limit = (u32)env_int("GTARS_TOK_SPIN_LIMIT", 4096);
     const u64 tile_q = tok_tile_queries(TPB / G, QPT * R);
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     const u64 grid = std::min<u64>((u64)cus, (tiles + G - 1) / G);

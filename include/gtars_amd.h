@@ -159,6 +159,12 @@ gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qchrom
  * another stream (tests/test_gpu_parity.py: the chained scan must complete with the right result whatever is resident). */
 gtars_status gtars_debug_occupy_device(void *stream, uint32_t workgroups, uint32_t lds_bytes, uint32_t microseconds);
 
+/* Test / A-B hook.  The library reads its GTARS_* environment switches (test and ablation knobs: GTARS_IGD_SWEEP_MIN,
+ * GTARS_NO_LDS_PATH, GTARS_HOST_THREADS ...) ONCE, into an immutable snapshot taken at first use -- never with a getenv per
+ * call, which races with a host program's setenv.  A process that changes a switch afterwards calls this to make the library take
+ * a new snapshot; no other library call may be in flight. */
+void gtars_debug_reload_env(void);
+
 /* bins[id] += 1 for every id < n_bins (device pointers): the scatter-add of gtars-scoring's count matrices
  * (CountMatrix::increment, gtars-scoring/src/fragment_scoring.rs:88-105) -- one matrix row per call, the ids being
  * the token ids of one fragment file's probes (gtars_tokenize_device). */

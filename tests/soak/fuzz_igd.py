@@ -44,6 +44,7 @@ def one(seed):
         os.environ["GTARS_IGD_SWEEP_MIN"] = "1"
     else:
         os.environ.pop("GTARS_IGD_SWEEP_MIN", None)
+    gtars_amd.reload_env()
     # min_overlap <= 0: the reference's tile walk also admits non-overlapping records (per-query kernels with the tile test)
     for mo in (1, int(rng.integers(2, 40)), int(rng.choice([0, -1, -30, -20_000]))):
         assert np.array_equal(g.count_set_overlaps(qc, qs, qe, mo), o.count_set_overlaps(qc, qs, qe, mo, n_files=F)), ("pair", seed, mo)
@@ -100,6 +101,7 @@ def one_big(seed):
         order = np.lexsort((qs, np.where(qc == UNK, n_chrom, qc)))
         qc, qs, qe = qc[order], qs[order], qe[order]
     os.environ.pop("GTARS_IGD_SWEEP_MIN", None)
+    gtars_amd.reload_env()
     assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), o.count_set_overlaps(qc, qs, qe, 1, n_files=F)), ("big pair", seed, shape)
     assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F)), ("big bin", seed, shape)
     # the same batch as three sets sharing one pass (the two-level partition tags the pairs)

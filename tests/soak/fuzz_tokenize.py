@@ -47,6 +47,7 @@ def one(seed):
         os.environ["GTARS_TOK_BUCKETS"] = str(buckets)
     else:
         os.environ.pop("GTARS_TOK_BUCKETS", None)
+    gtars_amd.reload_env()  # (the library snapshots its switches at first use)
     g = gtars_amd.OverlapIndex(c, s, e, val, n_chrom=n_chrom, kind=kind)
     o = oracle.Index(c, s, e, val, n_chrom=n_chrom, kind=kind)
     nq = int(rng.choice([1, 5, 257, 4096, 4097, 70_001]))

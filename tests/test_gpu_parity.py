@@ -1328,11 +1328,13 @@ def test_igd_query_sets_share_one_pass(ga, n_db, sizes):
             assert shared == 1
     # the same rows again set by set (what the shared pass replaces)
     os.environ["GTARS_IGD_SWEEP_MIN"] = "1"
+    ga.reload_env()
     try:
         for k, (qc, qs, qe) in enumerate(sets):
             assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F)), k
     finally:
         del os.environ["GTARS_IGD_SWEEP_MIN"]
+        ga.reload_env()
 
 
 def test_igd_query_sets_argument_checks(ga):

@@ -73,6 +73,7 @@ def main():
         return k
 
     os.environ["GTARS_HOST_THREADS"] = "1"  # parallelism across files, not inside one
+    lib.gtars_debug_reload_env()
     many = [p + ".gz" for p in files] * 8
     for w in (8, 32, 64):
         with ThreadPoolExecutor(max_workers=w) as ex:

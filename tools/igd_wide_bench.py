@@ -26,6 +26,7 @@ def main():
     for label, env in (("pieces_view", None), ("flat_layout", "1")):
         if env: os.environ["GTARS_IGD_NO_PIECES"] = env
         else: os.environ.pop("GTARS_IGD_NO_PIECES", None)
+        gtars_amd.reload_env()
         t = time.time()
         g = gtars_amd.IgdIndex(db["chrom"], db["start"], db["end"], db["file"], n_chrom=synth.N_CHROM, n_files=F)
         tb = time.time() - t

@@ -24,6 +24,7 @@ def main():
             os.environ.pop("GTARS_HOST_THREADS", None)
         else:
             os.environ["GTARS_HOST_THREADS"] = th
+        _lib.lib.gtars_debug_reload_env()  # (the library snapshots its switches at first use)
         for path in (bed, bed + ".gz"):
             best = 1e9
             for _ in range(3):

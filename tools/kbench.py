@@ -43,6 +43,7 @@ def main():
         os.environ["GTARS_TOK_ROUNDS"] = rr
         os.environ["GTARS_TOK_TPB"] = tpb
         os.environ["GTARS_TOK_WG_PER_CU"] = wg
+        gtars_amd.reload_env()
         for n in sizes:
             reps = max(3, min(200, int(4e8 // n)))
             n2, h, dt = run(ix, q, n, reps, dev)
