@@ -48,9 +48,14 @@ def read_bed3_lines(path: str) -> Tuple[List[str], np.ndarray, np.ndarray, np.nd
         _lib.lib.gtars_fragments_free(h)
 
 
+HIT_CHUNK = 1 << 20  # hit lines formatted per call of the C++ writer
+
+
 def run_overlaprs(universe: str, query: str, backend: str = "bits", out: TextIO = sys.stdout) -> int:
-    """-> number of hit lines written.  Text in and out go through the C++ host layer (chunked in-place parse, one
-    formatted buffer); the whole query file is one device batch in between."""
+    """-> number of hit lines written.  Text in and out go through the C++ host layer (chunked in-place parse, hit lines formatted
+    and written a million at a time); the whole query file is one device batch in between -- so a malformed line anywhere in the
+    query file fails the run BEFORE any hit line is written (the reference streams line by line, handlers.rs:114-155, and has
+    written the hits of the lines in front of the bad one: INTEGRATION.md)."""
     import ctypes as C
 
     from . import _lib
@@ -68,15 +73,38 @@ def run_overlaprs(universe: str, query: str, backend: str = "bits", out: TextIO 
     offsets, hs, he, _ = ix.find_overlaps(qc, qs, qe)
     n = int(len(hs))
     if n:
-        hit_chrom = np.ascontiguousarray(np.repeat(qc, np.diff(offsets.astype(np.int64))), dtype=np.uint32)
+        # formatted and written in chunks of HIT_CHUNK hits (one C++ buffer and one bytes object per chunk, straight to the
+        # stream's binary layer when it has one): a 1e9-hit run needs tens of MB of text in flight, not tens of GB
+        counts = np.diff(offsets.astype(np.int64))
         arr = (C.c_char_p * len(names))(*[nme.encode() for nme in names])
-        text, ln = C.c_void_p(), C.c_uint64()
-        _lib.check(_lib.lib.gtars_format_hit_lines(C.cast(arr, C.c_void_p), _lib.ptr(hit_chrom), _lib.ptr(np.ascontiguousarray(hs)),
-                                                   _lib.ptr(np.ascontiguousarray(he)), n, C.byref(text), C.byref(ln)))
-        try:
-            out.write(C.string_at(text, ln.value).decode())
-        finally:
-            _lib.lib.gtars_free(text)
+        hs, he = np.ascontiguousarray(hs), np.ascontiguousarray(he)
+        sink = getattr(out, "buffer", None)
+        if sink is not None:
+            out.flush()
+        q_lo = 0
+        for lo in range(0, n, HIT_CHUNK):
+            hi = min(n, lo + HIT_CHUNK)
+            # the queries whose hits [lo, hi) belong to: offsets is their CSR
+            q_hi = int(np.searchsorted(offsets, hi, side="left"))
+            q_first = max(int(np.searchsorted(offsets, lo, side="right")) - 1, 0)
+            rep = counts[q_first:q_hi].copy()
+            rep[0] -= lo - int(offsets[q_first])
+            rep[-1] -= int(offsets[q_hi]) - hi
+            hit_chrom = np.ascontiguousarray(np.repeat(qc[q_first:q_hi], rep), dtype=np.uint32)
+            text, ln = C.c_void_p(), C.c_uint64()
+            _lib.check(_lib.lib.gtars_format_hit_lines(C.cast(arr, C.c_void_p), _lib.ptr(hit_chrom), _lib.ptr(hs[lo:hi]), _lib.ptr(he[lo:hi]),
+                                                       hi - lo, C.byref(text), C.byref(ln)))
+            try:
+                data = C.string_at(text, ln.value)
+            finally:
+                _lib.lib.gtars_free(text)
+            if sink is not None:
+                sink.write(data)
+            else:
+                out.write(data.decode())
+            q_lo = q_hi
+        if sink is not None:
+            sink.flush()
     return n
 
 

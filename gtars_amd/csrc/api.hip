@@ -2009,13 +2009,16 @@ static gtars_status gtars_igd_build_core(const uint32_t *chrom, const int32_t *s
         };
         ScopedDev in, ws;
         const u32 n32 = (u32)n;
-        if ((st = in.alloc((size_t)n * 4 * 6))) return bail(st);
-        u32 *d_kc = in.as<u32>(), *d_s = d_kc + n, *d_e = d_s + n, *d_f = d_e + n, *d_v = d_f + n, *d_perm = d_v + n;
+        // (a pieces view serves counts only: no values column, here or on the host path below)
+        const bool with_values = !piece_flags;
+        if ((st = in.alloc((size_t)n * 4 * (with_values ? 6 : 5)))) return bail(st);
+        u32 *d_kc = in.as<u32>(), *d_s = d_kc + n, *d_e = d_s + n, *d_f = d_e + n, *d_v = d_f + n, *d_perm = with_values ? d_v + n : d_v;
         if (hipMemcpy(d_kc, kc.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_s, start, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_e, end, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_f, file_idx, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            (value ? hipMemcpy(d_v, value, n * 4, hipMemcpyHostToDevice) : hipMemset(d_v, 0, n * 4)) != hipSuccess)
+            (!with_values ? hipSuccess
+                          : value ? hipMemcpy(d_v, value, n * 4, hipMemcpyHostToDevice) : hipMemset(d_v, 0, n * 4)) != hipSuccess)
             return bail(fail(GTARS_ERR_HIP, "IGD build: upload failed"));
         // chromosome-major, then start, ties in insertion order (finalize: stable sort by start, igd.rs:157-167);
         // kept starts are >= 0, so u32 order == i32 order
@@ -2024,14 +2027,15 @@ static gtars_status gtars_igd_build_core(const uint32_t *chrom, const int32_t *s
         if ((st = device_sort_perm_ws(d_kc, d_s, nullptr, n32, n_chrom + 1, d_perm, ws.p, ws_bytes, nullptr))) return bail(st);
         const size_t kb = std::max<u64>(kept, 1) * 4 + 32;  // + slack: the sweep stages whole 16-byte vectors
         if (hipMalloc((void **)&g->starts.p, kb) != hipSuccess || hipMalloc((void **)&g->ends.p, kb) != hipSuccess ||
-            hipMalloc((void **)&g->files.p, kb) != hipSuccess || hipMalloc((void **)&g->values.p, kb) != hipSuccess)
+            hipMalloc((void **)&g->files.p, kb) != hipSuccess || (with_values && hipMalloc((void **)&g->values.p, kb) != hipSuccess))
             return bail(fail(GTARS_ERR_HIP, "IGD build: device allocation failed"));
-        g->starts.n = g->ends.n = g->files.n = g->values.n = kept;
+        g->starts.n = g->ends.n = g->files.n = kept;
+        g->values.n = with_values ? kept : 0;
         const u32 k32 = (u32)kept;
         if ((st = device_gather_u32(d_s, d_perm, k32, (u32 *)g->starts.p, nullptr))) return bail(st);
         if ((st = device_gather_u32(d_e, d_perm, k32, (u32 *)g->ends.p, nullptr))) return bail(st);
         if ((st = device_gather_u32(d_f, d_perm, k32, g->files.p, nullptr))) return bail(st);
-        if ((st = device_gather_u32(d_v, d_perm, k32, (u32 *)g->values.p, nullptr))) return bail(st);
+        if (with_values && (st = device_gather_u32(d_v, d_perm, k32, (u32 *)g->values.p, nullptr))) return bail(st);
         if (hipDeviceSynchronize() != hipSuccess) return bail(fail(GTARS_ERR_HIP, "IGD build: device sort failed"));
         std::vector<u32> tf, tc, tch;
         for (u32 c = 0; c < n_chrom; ++c)
@@ -2126,7 +2130,7 @@ static gtars_status gtars_igd_build_core(const uint32_t *chrom, const int32_t *s
     if (!st) st = g->tile_cnt.upload(tc);
     if (!st) st = g->tile_chrom.upload(tch);
     if (!st) st = g->ends.upload(g->h_ends);
-    if (!st) st = g->values.upload(hv);
+    if (!st && !piece_flags) st = g->values.upload(hv);  // (a pieces view serves counts only)
     if (!st) st = g->files.upload(hf);
     if (!st) st = g->chrom_off.upload(hoff);
     if (!st) st = g->chrom_maxlen.upload(hml);
@@ -2184,6 +2188,7 @@ static gtars_status build_pieces_view(gtars_igd *g, const uint32_t *chrom, const
     if (!g || !g->n) return GTARS_OK;
     const i32 P = igd_piece_bp(start, end, n);
     if (!P) return GTARS_OK;
+    if (cfg_flag("GTARS_IGD_TEST_PIECES_FAIL")) return fail(GTARS_ERR_HIP, "test hook: the pieces view could not be allocated");
     u64 n_long = 0, n_pieces = 0;
     for (u64 i = 0; i < n; ++i) {
         if (start[i] < 0 || end[i] < 0 || start[i] >= end[i]) continue;  // Igd::add drop rule
@@ -2229,12 +2234,17 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
                                          uint32_t n_files, gtars_igd_t **out) {
     gtars_status st = gtars_igd_build_core(chrom, start, end, value, file_idx, n, n_chrom, n_files, false, out);
     if (st) return st;
-    st = build_pieces_view(*out, chrom, start, end, file_idx, n);
-    if (st) {
-        gtars_igd_free(*out);
-        *out = nullptr;
+    // The pieces view is an accelerator, not part of the database: when it cannot be built (device or host memory: it is a second
+    // copy of the records) the flat layout alone serves every query correctly, only slower for databases with long records.
+    try {
+        if (build_pieces_view(*out, chrom, start, end, file_idx, n) != GTARS_OK) {
+            (void)hipGetLastError();
+            set_error("");
+        }
+    } catch (const std::bad_alloc &) {
+        (*out)->pieces = nullptr;
     }
-    return st;
+    return GTARS_OK;
 }
 
 // which index serves a count: the pieces view for min_overlap == 1 when the database has one (binary counts: only in their

@@ -1515,6 +1515,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         if (d_tot) {
             rt_wg = std::max<u32>(1, std::min<u32>((u32)cus, (nq + 4095) / 4096));
             rt_wg = std::max<u32>(rt_wg, (nq + 65531u) / 65532u);
+            // (test hook: a small cap sends a small batch through the many-workgroup form -- more rows than CUs)
+            const u32 cap = (u32)std::min<long>(65532, std::max<long>(64, cfg_int("GTARS_IGD_ROUTE_CHUNK_MAX", 65532)));
+            rt_wg = std::max<u32>(rt_wg, std::min<u32>(512u, (nq + cap - 1) / cap));  // (<= 512 rows: multisplit_ws_bytes)
             rt_chunk = ((nq + rt_wg - 1) / rt_wg + 3u) & ~3u;
         }
         if (rt_chunk > 65535u) return fail(GTARS_ERR_INTERNAL, "IGD sweep: routing chunk exceeds the 16-bit counters");  // (cannot happen)
@@ -1608,8 +1611,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     auto kern = mode == 2 ? k_igd_sweep<2, true> : mode == 1 ? k_igd_sweep<1, false> : mo1 ? k_igd_sweep<0, true> : k_igd_sweep<0, false>;
     const size_t lds_cu = 160 * 1024;  // what a CU has; the static part (search tables) is ~2 KB per workgroup
     const size_t lds_static = (size_t)TAB_LUT_WORDS * 4 + 256;
-    const bool b16 = mode == 2 && !cfg_get("GTARS_IGD_NO_B16") && lds_cu / (lds16 + lds_static) > lds_cu / (lds + lds_static) &&
-                     lds_cu / (lds + lds_static) < 4;
+    const bool b16 = mode == 2 && !cfg_flag("GTARS_IGD_NO_B16") &&
+                     (cfg_flag("GTARS_IGD_FORCE_B16") ||  // (test hook)
+                      (lds_cu / (lds16 + lds_static) > lds_cu / (lds + lds_static) && lds_cu / (lds + lds_static) < 4));
     if (b16) {
         kern = k_igd_sweep<2, true, true>;
         lds = lds16;

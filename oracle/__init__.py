@@ -821,6 +821,116 @@ def fisher_pvalue(a: int, b: int, c: int, d: int, enrichment: bool = True) -> fl
     return min(1.0, math.exp(m) * math.fsum(math.exp(v - m) for v in logs))
 
 
+def _brent_reference(f, a: float, b: float, tol: float, max_iter: int) -> float:
+    """brent (gtars-lola/src/enrichment.rs:400-486), statement by statement: the root finder the reference's odds_ratio uses."""
+    eps = 2.220446049250313e-16
+    fa, fb = f(a), f(b)
+    if abs(fa) < tol:
+        return a
+    if abs(fb) < tol:
+        return b
+    if fa * fb > 0.0:
+        return (a + b) / 2.0
+    c, fc = a, fa
+    d = b - a
+    e = d
+    for _ in range(max_iter):
+        if fb * fc > 0.0:
+            c, fc = a, fa
+            d = b - a
+            e = d
+        if abs(fc) < abs(fb):
+            a, b, c = b, c, b
+            fa, fb, fc = fb, fc, fb
+        tol1 = 2.0 * eps * abs(b) + 0.5 * tol
+        m = 0.5 * (c - b)
+        if abs(m) <= tol1 or fb == 0.0:
+            return b
+        if abs(e) >= tol1 and abs(fa) > abs(fb):
+            s_ = fb / fa
+            if abs(a - c) < eps:
+                p_, q_ = 2.0 * m * s_, 1.0 - s_
+            else:
+                qv, r = fa / fc, fb / fc
+                p_ = s_ * (2.0 * m * qv * (qv - r) - (b - a) * (r - 1.0))
+                q_ = (qv - 1.0) * (r - 1.0) * (s_ - 1.0)
+            if p_ > 0.0:
+                q_ = -q_
+            else:
+                p_ = -p_
+            if 2.0 * p_ < min(3.0 * m * q_ - abs(tol1 * q_), e * q_):
+                e = d
+                d = p_ / q_
+            else:
+                d = m
+                e = m
+        else:
+            d = m
+            e = m
+        a, fa = b, fb
+        if abs(d) > tol1:
+            b += d
+        else:
+            b += tol1 if m > 0.0 else -tol1
+        fb = f(b)
+    return b
+
+
+def odds_ratio_reference(a: int, b: int, c: int, d: int) -> float:
+    """ContingencyTable::odds_ratio (gtars-lola/src/enrichment.rs:62-160) as the reference computes it: log-densities of the
+    central hypergeometric distribution by recurrence (:85-99), the noncentral mean with compensated sums (:101-135), Brent's
+    method on [0, 1] in omega, or in 1 / omega when the estimate is above 1 (:137-159; absolute tolerance 1e-8 in that
+    variable).  The product's odds_ratio (gtars_amd/lola.py) solves the same equation with its own method: this is what
+    tests/test_lola_stats_cpu.py compares it with on a grid."""
+    import math
+
+    m, n, k, x = a + c, b + d, a + b, a
+    lo = k - n if k > n else 0
+    hi = min(k, m)
+    if lo == hi:
+        return float("nan")
+    if x == lo:
+        return 0.0
+    if x == hi:
+        return float("inf")
+    size = hi - lo + 1
+    logdc = [0.0]
+    for i in range(1, size):
+        y = lo + i - 1
+        logdc.append(logdc[i - 1] + math.log(m - y) + math.log(k - y) - math.log(y + 1) - math.log(n - k + y + 1))
+
+    def mean_nhyper(omega: float) -> float:
+        if omega == 0.0:
+            return float(lo)
+        if math.isinf(omega):
+            return float(hi)
+        lg = math.log(omega)
+        lv = [ld + (lo + i) * lg for i, ld in enumerate(logdc)]
+        mx = max(lv)
+        s_ = sc = ws = wc = 0.0
+        for i, v in enumerate(lv):
+            w = math.exp(v - mx)
+            y = float(lo + i)
+            yw = y * w - wc
+            wt = ws + yw
+            wc = (wt - ws) - yw
+            ws = wt
+            sw = w - sc
+            st = s_ + sw
+            sc = (st - s_) - sw
+            s_ = st
+        return ws / s_
+
+    xf = float(x)
+    mu1 = mean_nhyper(1.0)
+    if abs(mu1 - xf) < 1e-12:
+        return 1.0
+    if mu1 > xf:
+        return _brent_reference(lambda t: mean_nhyper(t) - xf, 0.0, 1.0, 1e-8, 100)
+    t = _brent_reference(lambda t: mean_nhyper(1.0 / t) - xf, 2.220446049250313e-16, 1.0, 1e-8, 100)
+    return 1.0 / t
+
+
 def bh_qvalues(p_value_logs: Sequence[float]) -> List[float]:
     """apply_fdr_correction for ONE user set (gtars-lola/src/output.rs:35-113), results in input order."""
     n = len(p_value_logs)

@@ -936,6 +936,21 @@ def test_cli_overlaprs_text_matches_the_reference_rules(golden_dir, tmp_path):
         buf = io.StringIO()
         cli.run_overlaprs(str(up), str(qp), backend, buf)
         assert buf.getvalue() == oracle.overlaprs_text(str(up), str(qp), backend)
+    # the hit lines leave in chunks (a million per call of the C++ writer): chunk borders inside a query's hits and a binary sink
+    chunk0 = cli.HIT_CHUNK
+    try:
+        cli.HIT_CHUNK = 7
+        raw = io.BytesIO()
+        buf = io.TextIOWrapper(raw, encoding="ascii", newline="")
+        cli.run_overlaprs(str(up), str(qp), "bits", buf)
+        buf.flush()
+        assert raw.getvalue().decode() == oracle.overlaprs_text(str(up), str(qp), "bits")
+        cli.HIT_CHUNK = 1
+        buf = io.StringIO()
+        cli.run_overlaprs(peaks, query, "ailist", buf)
+        assert buf.getvalue() == oracle.overlaprs_text(peaks, query, "ailist")
+    finally:
+        cli.HIT_CHUNK = chunk0
     # through the command line
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "gtars_amd", "overlaprs", "-u", peaks, "-q", query], cwd=root, capture_output=True,

@@ -1425,6 +1425,14 @@ def test_igd_counts_on_databases_with_long_records(ga, monkeypatch, piece_bp):
     g2 = ga.IgdIndex(c, s, e, f, np.arange(n), n_chrom=2, n_files=F)
     qc, qs, qe = small
     assert np.array_equal(g2.count_set_overlaps(qc, qs, qe, 1), o.count_set_overlaps(qc, qs, qe, 1, n_files=F))
+    # ... and a pieces view that cannot be built (memory) does not fail the database: the flat layout serves it
+    monkeypatch.delenv("GTARS_IGD_NO_PIECES")
+    monkeypatch.setenv("GTARS_IGD_TEST_PIECES_FAIL", "1")
+    g3 = ga.IgdIndex(c, s, e, f, np.arange(n), n_chrom=2, n_files=F)
+    monkeypatch.delenv("GTARS_IGD_TEST_PIECES_FAIL")
+    assert np.array_equal(g3.count_set_overlaps(qc, qs, qe, 1), o.count_set_overlaps(qc, qs, qe, 1, n_files=F))
+    assert np.array_equal(g3.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F))
+    monkeypatch.setenv("GTARS_IGD_NO_PIECES", "1")  # (what follows compares with the flat index g2)
     # everything that is not a count still sees one record per stored interval
     assert len(g) == len(g2) == n  # (every record is valid here)
     ok = (qs < 2**31) & (qe < 2**31)
@@ -1477,6 +1485,54 @@ def test_igd_fine_routing_tables_boundary_probes(ga, monkeypatch):
         assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F)), fshift
         vecs.append(got)
     assert np.array_equal(vecs[0], vecs[1]) and np.array_equal(vecs[0], vecs[2])
+
+
+def test_igd_packed_counter_flush_and_many_routing_workgroups(ga, monkeypatch):
+    """Two branches only large inputs reach, forced at small sizes: (1) the sweep's 16-bit packed counters (binary counts, B16)
+    are handed over in the middle of a tile when a workgroup has served 65535 queries since its last flush -- a database of
+    three tiles and 400k queries, so that one workgroup serves > 100k queries of one tile, with B16 selected naturally (2000
+    files, one set), forced (two sets x 1500 files) and disabled; (2) the routing kernel with MORE workgroups than CUs (batches
+    beyond 16.7M queries; here the chunk is capped at 3000 queries: 400 rows of counters for the split to sum).  Per-file
+    vectors == the oracle's, and the forms agree with each other."""
+    rng = np.random.default_rng(31)
+    n, span = 6_000, 3_000_000  # three 2048-record tiles on one chromosome
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 800, n)
+    c = np.zeros(n, dtype=np.int64)
+    monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
+    monkeypatch.setenv("GTARS_IGD_NO_HEAVY_PARTS", "1")  # (a heavy tile stays with ONE workgroup: that is the point here)
+    nq = 400_000
+    qc, qs, qe = _random_query_set(rng, nq, 1, span + 2_000, 500)
+    for F, n_sets, env in ((2000, 1, None), (1500, 2, "GTARS_IGD_FORCE_B16"), (1500, 2, "GTARS_IGD_NO_B16")):
+        f = rng.integers(0, F, n)
+        g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=1, n_files=F)
+        if env:
+            monkeypatch.setenv(env, "1")
+        if n_sets == 1:
+            got = g.count_region_hits(qc, qs, qe, 1)
+            assert np.array_equal(got, o.count_region_hits(qc, qs, qe, 1, n_files=F)), (F, env)
+        else:
+            cut = 230_000
+            sets = [(qc[:cut], qs[:cut], qe[:cut]), (qc[cut:], qs[cut:], qe[cut:])]
+            got = g.count_sets(sets, 1, True)
+            for k, (a, b, d) in enumerate(sets):
+                assert np.array_equal(got[k], o.count_region_hits(a, b, d, 1, n_files=F)), (F, env, k)
+        if env:
+            monkeypatch.delenv(env)
+    monkeypatch.delenv("GTARS_IGD_NO_HEAVY_PARTS")
+    # (2) many routing workgroups: a database with enough tiles for the two-level split (> 1024 bins), 1.2M queries in 400 chunks
+    n, F, span = 2_300_000, 19, 200_000_000
+    c = rng.integers(0, 2, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 700, n)
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=2, n_files=F)
+    qc, qs, qe = _random_query_set(rng, 1_200_000, 2, span + 2_000, 500)
+    want = o.count_set_overlaps(qc, qs, qe, 1, n_files=F)
+    assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), want)
+    monkeypatch.setenv("GTARS_IGD_ROUTE_CHUNK_MAX", "3000")
+    assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), want)
+    assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F))
 
 
 def test_igd_routing_with_tile_bounds_in_global_memory(ga, monkeypatch):

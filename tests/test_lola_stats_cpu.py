@@ -211,3 +211,31 @@ def test_build_restricted_universe_kats():
     # gaps are never filled, touching intervals are cut at the shared boundary (GenomicRanges disjoin)
     assert lola.build_restricted_universe([[("c", 0, 10), ("c", 10, 20), ("c", 5, 12)]]) == [
         ("c", 0, 5), ("c", 5, 10), ("c", 10, 12), ("c", 12, 20)]
+
+
+def test_odds_ratio_grid_against_the_reference_method():
+    """lola.odds_ratio solves the CMLE equation with its own method (Newton in log-odds); the reference uses Brent's method to an
+    absolute 1e-8 in omega -- or in 1 / omega above 1, i.e. to a RELATIVE ~1e-8 * omega there (enrichment.rs:137-159).  On a
+    grid of tables the two agree to that: |ours - ref| <= 2e-8 + 1e-6 * ref below 1 and <= ref * (1e-6 + 4e-8 * ref) above
+    (the deliberate divergence in the last digits is stated in INTEGRATION.md); edge values are identical."""
+    import math
+
+    import oracle
+    from gtars_amd.lola import odds_ratio
+
+    rng = np.random.default_rng(12)
+    tables = [(1, 1, 2, 6), (10, 5, 3, 20), (3, 0, 2, 9), (0, 4, 5, 1), (999, 1, 1, 999), (1, 999, 999, 1), (50, 50, 50, 50),
+              (2, 30, 400, 5000), (120, 3, 7, 9000), (7, 7, 7, 7), (1, 0, 0, 1), (0, 0, 3, 4), (5, 5, 0, 0)]
+    for _ in range(250):
+        scale = int(rng.choice([5, 40, 400, 5000]))
+        tables.append(tuple(int(v) for v in rng.integers(0, scale, 4)))
+    worst = 0.0
+    for a, b, c, d in tables:
+        ours, ref = odds_ratio(a, b, c, d), oracle.odds_ratio_reference(a, b, c, d)
+        if math.isnan(ref) or math.isinf(ref) or ref == 0.0:
+            assert (math.isnan(ours) and math.isnan(ref)) or ours == ref, (a, b, c, d, ours, ref)
+            continue
+        tol = 2e-8 + 1e-6 * ref if ref <= 1.0 else ref * (1e-6 + 4e-8 * ref)
+        assert abs(ours - ref) <= tol, (a, b, c, d, ours, ref)
+        worst = max(worst, abs(ours - ref) / ref)
+    assert worst < 1e-3
