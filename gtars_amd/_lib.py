@@ -84,6 +84,7 @@ _SIG = {
     "gtars_tokenize_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64, vp]),
     "gtars_fill_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, vp]),
     "gtars_histogram_u32_device": (C.c_int, [vp, u64, u32, vp, vp]),
+    "gtars_histogram_rows_device": (C.c_int, [vp, vp, vp, u64, u32, u32, u32, vp, vp]),
     "gtars_debug_occupy_device": (C.c_int, [vp, u32, u32, u32]),
     "gtars_tokenize": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
     "gtars_tokenize_into": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64]),

@@ -1207,6 +1207,15 @@ gtars_status gtars_histogram_u32_device(const uint32_t *d_ids, uint64_t n, uint3
     return launch_hist_u32(d_ids, n, n_bins, d_bins, (hipStream_t)stream);
 }
 
+gtars_status gtars_histogram_rows_device(const uint64_t *d_offsets, const uint32_t *d_ids, const uint32_t *d_row, uint64_t nq,
+                                         uint32_t row0, uint32_t n_rows, uint32_t n_cols, uint32_t *d_mat, void *stream) {
+    if (nq && (!d_offsets || !d_row)) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    if ((uint64_t)n_rows * n_cols && !d_mat) return fail(GTARS_ERR_INVALID_ARG, "d_mat is NULL");
+    gtars_status st = require_device();
+    if (st) return st;
+    return launch_hist_rows(d_offsets, d_ids, d_row, nq, row0, n_rows, n_cols, d_mat, (hipStream_t)stream);
+}
+
 gtars_status gtars_fill_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
                                const uint32_t *d_qe, uint64_t nq, const uint64_t *d_offsets,
                                uint32_t *d_ids, void *stream) {

@@ -230,6 +230,8 @@ gtars_status launch_igd_count(const IgdView &v, const i32 *pme_file, const u32 *
                               i32 min_overlap, int binary, u64 *hits, hipStream_t st, const i32 *pm = nullptr);
 gtars_status launch_occupy(u32 workgroups, u32 lds_bytes, u32 microseconds, hipStream_t st);
 gtars_status launch_hist_u32(const u32 *ids, u64 n, u32 n_bins, u32 *bins, hipStream_t st);
+gtars_status launch_hist_rows(const u64 *offsets, const u32 *ids, const u32 *row, u64 nq, u32 row0, u32 n_rows, u32 n_cols, u32 *mat,
+                              hipStream_t st);
 gtars_status launch_has_adjacent_equal(const u32 *a, u64 n, u32 *dup, hipStream_t st);
 gtars_status launch_permute_marks(const u32 *in, const u32 *map, u64 n, u32 *out, hipStream_t st);  // out bit map[p] |= in bit p
 gtars_status launch_igd_count_per_query(const IgdView &v, const u32 *qc, const u32 *qs, const u32 *qe,

@@ -939,6 +939,32 @@ gtars_status launch_hist_u32(const u32 *ids, u64 n, u32 n_bins, u32 *bins, hipSt
     return GTARS_OK;
 }
 
+// mat[(row[q] - row0) * n_cols + ids[h]] += 1 for every hit h of query q (CSR offsets / ids of a tokenization) whose row lies in
+// [row0, row0 + n_rows): the scatter-add of gtars-scoring's barcode x peak counts (barcode_scoring_from_fragments,
+// fragment_scoring.rs:125-155: one count per (barcode, overlapped peak)), a band of barcodes per call.  One thread per query.
+__global__ void __launch_bounds__(256)
+k_hist_rows(const u64 *__restrict__ offsets, const u32 *__restrict__ ids, const u32 *__restrict__ row, u64 nq, u32 row0, u32 n_rows,
+            u32 n_cols, u32 *__restrict__ mat) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+        const u32 r = row[q] - row0;
+        if (r >= n_rows) continue;
+        for (u64 h = offsets[q]; h < offsets[q + 1]; ++h) {
+            const u32 k = ids[h];
+            if (k < n_cols) atomicAdd(&mat[(size_t)r * n_cols + k], 1u);
+        }
+    }
+}
+
+gtars_status launch_hist_rows(const u64 *offsets, const u32 *ids, const u32 *row, u64 nq, u32 row0, u32 n_rows, u32 n_cols, u32 *mat,
+                              hipStream_t st) {
+    if (nq == 0 || n_rows == 0 || n_cols == 0) return GTARS_OK;
+    ProfScope p("k_hist_rows", st);
+    hipLaunchKernelGGL(k_hist_rows, dim3(stream_grid(nq, 256)), dim3(256), 0, st, offsets, ids, row, nq, row0, n_rows, n_cols, mat);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
 // *dup = 1 if two neighbours of a SORTED array are equal
 __global__ void __launch_bounds__(256)
 k_has_adjacent_equal(const u32 *__restrict__ a, u64 n, u32 *__restrict__ dup) {

@@ -125,17 +125,75 @@ def region_scoring_from_fragments(fragments: Union[str, Sequence[str]], consensu
     return mat.cpu().numpy().view(np.uint32)
 
 
+BAND_CELLS = 1 << 26  # cells of the device-resident band of the barcode x peak matrix (256 MB of u32)
+
+
 def barcode_scoring_from_fragments(fragment_file: str, consensus: Union[str, ConsensusSet]) -> Dict[str, Dict[int, int]]:
-    """fragment_scoring.rs:125-155: barcode -> {peak index -> count} (fragment itself as the probe)."""
+    """fragment_scoring.rs:125-155: barcode -> {peak index -> count} (the fragment itself as the probe).
+
+    On the device: the fragments are tokenized in one batch (``gtars_tokenize_device``), and every (barcode, peak) hit is
+    scatter-added into a device-resident BAND of the barcode x peak matrix (``gtars_histogram_rows_device``: as many barcodes at a
+    time as fit ``BAND_CELLS`` cells); a band comes back to the host once, and only its non-zero cells become dictionary entries."""
+    import torch
+
     cons = consensus if isinstance(consensus, ConsensusSet) else ConsensusSet(consensus)
     c, s, e, b, barcodes = _read_fragments(fragment_file, cons)
-    offsets, ids = cons.index.tokenize(c, s, e)
-    per_query = np.diff(offsets.astype(np.int64))
-    # (barcode, peak) pairs of all hits, counted by one sort
-    pair = np.repeat(b.astype(np.int64), per_query) * max(len(cons), 1) + ids.astype(np.int64)
-    uniq, cnt = np.unique(pair, return_counts=True)
     out: Dict[str, Dict[int, int]] = {}
-    n_peaks = max(len(cons), 1)
-    for u, k in zip(uniq.tolist(), cnt.tolist()):
-        out.setdefault(barcodes[u // n_peaks], {})[u % n_peaks] = k
+    n_peaks, nq = len(cons), len(c)
+    if nq == 0 or n_peaks == 0 or not barcodes:
+        return out
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+    d = [torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev) for x in (c, s, e, b)]
+    offsets = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+    ids = torch.empty(2 * nq + 1024, dtype=torch.int32, device=dev)
+    try:
+        h = cons.index.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(),
+                                       ids.numel(), stream, sync=True)
+    except _lib.CapacityError as err:  # more than two peaks per fragment on average: once more with the exact size
+        ids = torch.empty(err.needed, dtype=torch.int32, device=dev)
+        h = cons.index.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(),
+                                       ids.numel(), stream, sync=True)
+    if h == 0:
+        return out
+    rows = max(1, min(len(barcodes), BAND_CELLS // n_peaks))
+    band = torch.empty((rows, n_peaks), dtype=torch.int32, device=dev)
+    for row0 in range(0, len(barcodes), rows):
+        nr = min(rows, len(barcodes) - row0)
+        band.zero_()
+        check(lib.gtars_histogram_rows_device(offsets.data_ptr(), ids.data_ptr(), d[3].data_ptr(), nq, row0, nr, n_peaks, band.data_ptr(),
+                                              stream))
+        m = band[:nr].cpu().numpy().view(np.uint32)
+        r, k = np.nonzero(m)
+        for ri, ki, v in zip(r.tolist(), k.tolist(), m[r, k].tolist()):
+            out.setdefault(barcodes[row0 + ri], {})[ki] = v
     return out
+
+
+def write_sparse_counts_to_mtx(barcode_counts: Dict[str, Dict[int, int]], num_peaks: int, output_prefix: str) -> None:
+    """write_sparse_counts_to_mtx (gtars-scoring/src/matrix_market.rs:26-92): ``{prefix}_matrix.mtx.gz`` (Matrix Market coordinate
+    integer general; barcodes sorted, triplets sorted by (row, col), 1-based), ``{prefix}_barcodes.tsv.gz`` (one barcode per line,
+    sorted) and ``{prefix}_features.tsv.gz`` (``peak_<i>`` per line) -- gzip level 6 like flate2's default."""
+    import gzip
+
+    barcodes = sorted(barcode_counts, key=lambda x: x.encode())  # Rust's String order is byte order
+    trip = [(ri, col, cnt) for ri, bc in enumerate(barcodes) for col, cnt in barcode_counts[bc].items()]
+    trip.sort(key=lambda t: (t[0], t[1]))
+    with gzip.open(f"{output_prefix}_matrix.mtx.gz", "wt", compresslevel=6, newline="\n") as fh:
+        fh.write("%%MatrixMarket matrix coordinate integer general\n")
+        fh.write(f"{len(barcodes)} {num_peaks} {len(trip)}\n")
+        fh.write("".join(f"{r + 1} {c + 1} {v}\n" for r, c, v in trip))
+    with gzip.open(f"{output_prefix}_barcodes.tsv.gz", "wt", compresslevel=6, newline="\n") as fh:
+        fh.write("".join(f"{bc}\n" for bc in barcodes))
+    with gzip.open(f"{output_prefix}_features.tsv.gz", "wt", compresslevel=6, newline="\n") as fh:
+        fh.write("".join(f"peak_{i}\n" for i in range(num_peaks)))
+
+
+def write_count_matrix(matrix: np.ndarray, filename: str) -> None:
+    """CountMatrix::write_to_file (gtars-scoring/src/counts.rs:89-105): one line per row, values joined by ",", gzip."""
+    import gzip
+
+    m = np.asarray(matrix)
+    with gzip.open(filename, "wt", compresslevel=6, newline="\n") as fh:
+        for row in m.reshape(m.shape[0], -1) if m.ndim else m.reshape(1, 1):
+            fh.write(",".join(str(int(v)) for v in row) + "\n")

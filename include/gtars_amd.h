@@ -171,6 +171,13 @@ void gtars_debug_reload_env(void);
 gtars_status gtars_histogram_u32_device(const uint32_t *d_ids, uint64_t n, uint32_t n_bins, uint32_t *d_bins,
                                         void *stream);
 
+/* mat[(row[q] - row0) * n_cols + id] += 1 for every token id of query q (the CSR of a gtars_tokenize_device call) whose row lies
+ * in [row0, row0 + n_rows): the scatter-add of barcode_scoring_from_fragments (gtars-scoring/src/fragment_scoring.rs:125-155: one
+ * count per (barcode, overlapped peak)) into a device-resident band of the barcode x peak matrix; d_row[q] = barcode id of
+ * fragment q.  Device pointers; d_mat is not cleared. */
+gtars_status gtars_histogram_rows_device(const uint64_t *d_offsets, const uint32_t *d_ids, const uint32_t *d_row, uint64_t nq,
+                                         uint32_t row0, uint32_t n_rows, uint32_t n_cols, uint32_t *d_mat, void *stream);
+
 /* ------------------------------------------------------------------------
  * Counts / any / find with the optional min-overlap filter.
  * Replaces MultiChromOverlapper::count_overlaps / any_overlaps /

@@ -424,6 +424,53 @@ def test_region_scoring_matrix_kat(golden_dir):
         region_scoring_from_fragments([], cons, "nope")
 
 
+def test_barcode_scoring_on_the_device_and_matrix_market_output(tmp_path):
+    """barcode_scoring_from_fragments (fragment_scoring.rs:125-155) counts (barcode, peak) pairs in a device-resident band of the
+    barcode x peak matrix -- one band and many small ones give the oracle's per-barcode peak counts -- and
+    write_sparse_counts_to_mtx (matrix_market.rs:26-92) writes what scipy reads back as that matrix."""
+    import gzip
+
+    from scipy.io import mmread
+
+    from gtars_amd import scoring, synth
+
+    u = synth.make_universe(3_000)
+    ub, fd, _mp = synth.write_config5_inputs(str(tmp_path), u, 1, 20_000, 5, barcodes=300)[:3]
+    frag = os.path.join(fd, sorted(os.listdir(fd))[0])
+    # a consensus set's peak index is the region's rank in (chr string, start) order (a file-loaded RegionSet is sorted,
+    # region_set.rs:182), a tokenizer's id its line number: write the universe in that order so that the two coincide
+    rows = sorted(zip((synth.CHROM_NAMES[c] for c in u["chrom"]), u["start"].tolist(), u["end"].tolist()))
+    ub = str(tmp_path / "consensus_sorted.bed")
+    with open(ub, "w") as fh:
+        fh.write("".join(f"{c}\t{a}\t{b}\n" for c, a, b in rows))
+    t = oracle.OracleTokenizer(ub)
+    n_peaks = len(u["chrom"])
+    exp = {}
+    for bcode, ids in t.tokenize_fragment_file(frag).items():
+        row = {}
+        for i in ids:
+            if i < n_peaks:  # (a fragment without a hit contributes the unk id: not a peak)
+                row[i] = row.get(i, 0) + 1
+        if row:
+            exp[bcode] = row
+    band0 = scoring.BAND_CELLS
+    try:
+        for cells in (band0, 7 * n_peaks, n_peaks):  # all barcodes at once; 7 per band; 1 per band
+            scoring.BAND_CELLS = cells
+            got = scoring.barcode_scoring_from_fragments(frag, ub)
+            assert got == exp, cells
+    finally:
+        scoring.BAND_CELLS = band0
+    prefix = str(tmp_path / "out")
+    scoring.write_sparse_counts_to_mtx(got, n_peaks, prefix)
+    m = mmread(gzip.open(prefix + "_matrix.mtx.gz")).tocsr()
+    names = gzip.open(prefix + "_barcodes.tsv.gz", "rt").read().split()
+    assert names == sorted(exp) and m.shape == (len(exp), n_peaks) and m.nnz == sum(len(r) for r in exp.values())
+    for ri, bcode in enumerate(names):
+        assert {int(k): int(v) for k, v in zip(m[ri].indices, m[ri].data)} == exp[bcode]
+    assert gzip.open(prefix + "_features.tsv.gz", "rt").read().split()[:2] == ["peak_0", "peak_1"]
+
+
 def test_fragment_files_in_parallel_host_threads(tmp_path):
     """tokenize_fragment_files: many files through a host thread pool (one device workspace per thread, the
     index shared read-only) give exactly the per-file results, in input order."""

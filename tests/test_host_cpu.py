@@ -385,3 +385,21 @@ def test_dense_region_ids_and_hit_lines(tmp_path):
         assert C.string_at(text, ln.value) == b"chr10\t0\t7\nchrA\t4294967295\t5\nchr10\t12\t4000000000\n"
     finally:
         _lib.lib.gtars_free(text)
+
+
+def test_scoring_output_writers(tmp_path):
+    """write_sparse_counts_to_mtx (gtars-scoring/src/matrix_market.rs:26-92) and CountMatrix::write_to_file (counts.rs:89-105):
+    the exact text the reference writes -- barcodes in byte order, triplets sorted by (row, col), 1-based, `peak_<i>` features;
+    rows of a dense matrix joined by commas."""
+    import gzip
+
+    from gtars_amd import scoring
+
+    prefix = str(tmp_path / "m")
+    scoring.write_sparse_counts_to_mtx({"TTG": {2: 5}, "AAC": {3: 1, 0: 2}, "Abc": {}}, 4, prefix)
+    assert gzip.open(prefix + "_matrix.mtx.gz", "rt").read() == ("%%MatrixMarket matrix coordinate integer general\n3 4 3\n"
+                                                                  "1 1 2\n1 4 1\n3 3 5\n")
+    assert gzip.open(prefix + "_barcodes.tsv.gz", "rt").read() == "AAC\nAbc\nTTG\n"
+    assert gzip.open(prefix + "_features.tsv.gz", "rt").read() == "peak_0\npeak_1\npeak_2\npeak_3\n"
+    scoring.write_count_matrix(np.array([[2, 2, 1, 3], [4, 1, 3, 1]], dtype=np.uint32), str(tmp_path / "c.csv.gz"))
+    assert gzip.open(tmp_path / "c.csv.gz", "rt").read() == "2,2,1,3\n4,1,3,1\n"
