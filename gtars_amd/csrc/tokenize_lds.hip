@@ -77,6 +77,9 @@ __device__ __forceinline__ void st_stream2(u64 *p, u64 a, u64 b) {
 #ifndef GTARS_TOK_STAMPS
 #define GTARS_TOK_STAMPS 0
 #endif
+#ifndef GTARS_TOK_UNIT2_EXACT
+#define GTARS_TOK_UNIT2_EXACT 1  // 1: the in-unit step of two-block units reads the first block.s key (a dependent load per query); 0: round-4 experiment, slower (profiles/r04)
+#endif
 #if GTARS_TOK_STAMPS
 __device__ unsigned long long g_tok_stamps[2][12];
 #define TSTAMP(k)                                         \
@@ -226,9 +229,14 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
                     b += cnt;
                 } else if (shift == 1) {
                     // two blocks per unit: the unit's last key is > q_start already (that is how the unit was found), so the
-                    // first block's key decides -- ONE dependent load (the halving loop below took two, the first of them
-                    // for the key whose answer is known)
+                    // first block's key decides -- ONE dependent load (a halving loop took two, the first of them for the key
+                    // whose answer is known).  Round 4 tried NO in-unit step (start at the unit's first block: exact, because
+                    // every interval in front of the unit ends at or before q_start, and the dead intervals just fail the overlap
+                    // test): slower -- 941 vs 731 us per 64M queries at 140k regions -- because a first candidate in the record's
+                    // later slots sends the scan into walk_tail, whose dependent loads cost more than the key load saved.
+#if GTARS_TOK_UNIT2_EXACT
                     b += a.blk_first[b] <= s[j] ? 1u : 0u;
+#endif
                 } else {
                     u32 l2 = b, n2 = min(1u << shift, be[j] - b);
                     while (n2 > 0) {
@@ -264,8 +272,43 @@ __host__ __device__ __forceinline__ size_t tok_lds_bytes(const AccelView &a) {
     return ((size_t)a.lut_words + a.q_words + 4 * (size_t)a.n_chrom + (((size_t)a.n_chrom + 3) & ~(size_t)3)) * sizeof(u32);
 }
 
+#ifndef GTARS_TOK_FILL_DMA
+#define GTARS_TOK_FILL_DMA 0  // 1: the LDS image is filled by global_load_lds_dwordx4 (round-4 experiment: no gain, see profiles/r04); 0: loads + ds_write_b128
+#endif
+// The two key arrays by LDS-DMA: one wave-instruction moves 64 consecutive 16-byte vectors (the LDS destination is a wave-uniform
+// base + lane x 16, the source address is per lane), no VGPR in between and none of the 13 LDS cycles a ds_write_b128 costs.
+// Waves take 1-KiB pieces round-robin, starting at a different piece in every workgroup.  The caller waits (vmcnt) and barriers.
+template <int TPB>
+__device__ __forceinline__ void fill_search_lds_dma(const AccelView &a, u32 *smem) {
+    constexpr u32 NW = TPB / 64;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 n4a = a.lut_words >> 2, n4b = a.q_words >> 2;
+    const u32 pa = (n4a + 63u) >> 6, pb = (n4b + 63u) >> 6, np = pa + pb;  // 1-KiB pieces of the two arrays
+    const u32 rot = (u32)(((u64)blockIdx.x * 2654435761ull) % np);
+    for (u32 i = wave; i < np; i += NW) {
+        u32 p = i + rot;
+        p = p >= np ? p - np : p;
+        const bool second = p >= pa;
+        const u32 piece = second ? p - pa : p, n4 = second ? n4b : n4a, v = (piece << 6) + lane;
+        const u32 *src = (second ? a.qkeys : a.lut) + (size_t)v * 4;
+        u32 *dst = smem + (second ? a.lut_words : 0u) + ((size_t)piece << 8);  // (wave-uniform: the piece's first word)
+        if (v < n4)
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+    uint4 *s_ctab = reinterpret_cast<uint4 *>(smem + a.lut_words + a.q_words);
+    u32 *s_idc = smem + a.lut_words + a.q_words + 4 * a.n_chrom;
+    for (u32 i = threadIdx.x; i < a.n_chrom; i += TPB) {
+        s_ctab[i] = a.chrom_tab[i];
+        s_idc[i] = a.idc[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA writes count as vector-memory operations)
+}
+
 template <int TPB>
 __device__ __forceinline__ void fill_search_lds(const AccelView &a, u32 *smem) {
+#if GTARS_TOK_FILL_DMA
+    return fill_search_lds_dma<TPB>(a, smem);
+#endif
     // 16-byte loads, GTARS_TOK_FILL_U in flight.  Every workgroup copies the same arrays: start each one at a
     // different place so that they do not all queue on the same L2 channel at the same time.
     // (A hand-batched form with the loads of a whole batch held in a register array went to scratch -- 176 bytes per lane --
