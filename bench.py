@@ -592,7 +592,7 @@ def bench_lola_config4(dev, stream, n_sets=LOLA4["n_sets"], per_set=LOLA4["per_s
     return out
 
 
-def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=4):
+def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
     """BASELINE config 5 at the config's PER-FILE size (1e5 fragments, 500 barcodes: SURVEY 8d C5) and a reduced file count (the
     config names 10,000 files on 8 GPUs; files are independent, so per-file cost is what scales): gzip'd fragment files ->
     barcode routing -> per-cluster tokenization, end to end from the .gz files."""
@@ -638,24 +638,22 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=4):
                "value": n / t_fused, "unit": "fragments/s end to end (fused route + tokenize)"}
         if ids_two != ids_fused:
             raise SystemExit("bench.py: fragsplit_config5: fused and two-step pipelines disagree")
-        # B1 on a sample of the files: the oracle's fragsplit (split.rs:36-151 restated) + OracleTokenizer per cluster file
-        sd = os.path.join(tmp, "sample")
-        os.mkdir(sd)
-        for pth in paths[:cpu_files]:
-            os.symlink(pth, os.path.join(sd, os.path.basename(pth)))
+        # B1 on a sample of the files: the oracle's compiled restatement (fragsplit_oracle.c: split.rs:36-151 routing +
+        # fragments.rs:61-82 per-line tokenization), one thread, from the same .gz files; its per-cluster id counts are held
+        # against the device pipeline's over the same files
+        sample = paths[:cpu_files]
+        om, otok = oracle.OracleBarcodeMap(mp), oracle.OracleTokenizer(ub)
         t = time.perf_counter()
-        om = oracle.OracleBarcodeMap(mp)
-        routed = oracle.fragsplit(sd, om)
-        otok = oracle.OracleTokenizer(ub)
-        n_ids = 0
-        for label, lines in routed.items():
-            regs = [ln.split("\t")[:3] for ln in lines]
-            n_ids += len(otok.encode_regions([(r[0], int(r[1]), int(r[2])) for r in regs]))
+        cpu = oracle.fragsplit_tokenize_compiled(sample, om, otok)
         t_cpu = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": cpu_files * frags / t_cpu, "unit": "fragments/s", "cores": 1, "kind": "port",
-                               "sample": f"{cpu_files} of the {files} files through oracle.fragsplit + OracleTokenizer (pure-Python "
-                                         f"restatement of split.rs / tokenizer.rs, one thread, {t_cpu:.1f} s): a port, far slower than "
-                                         f"compiled Rust would be -- reported for completeness, not as a fair CPU figure"}
+        from gtars_amd.fragsplit import fragsplit_tokenize_files
+        dev = fragsplit_tokenize_files(sample, m, tok, as_arrays=True)
+        if {k: int(v[1][-1]) for k, v in dev.items()} != {k: v[0] for k, v in cpu.items()}:
+            raise SystemExit("bench.py: fragsplit_config5: device pipeline and the compiled CPU restatement disagree")
+        out["cpu_baseline"] = {"value": len(sample) * frags / t_cpu, "unit": "fragments/s", "cores": 1, "kind": "port",
+                               "sample": f"{len(sample)} of the {files} files ({len(sample) * frags} fragments) through oracle/fragsplit_oracle.c "
+                                         f"(compiled C restatement of split.rs + fragments.rs: gunzip, parse, route, one "
+                                         f"tokenize per line; one thread, {t_cpu:.2f} s); per-cluster id counts equal the device's"}
         out["verified"] = "fused == two-step id counts (every file is compared with the oracle by tests/test_gpu_host.py)"
         return out
     finally:

@@ -39,12 +39,11 @@ KIND_AILIST = 1
 
 def build(force: bool = False) -> str:
     """Compile the C oracle in place (gcc, a second or two)."""
-    src = os.path.join(_HERE, "gtars_oracle.c")
-    hdr = os.path.join(_HERE, "gtars_oracle.h")
+    srcs = [os.path.join(_HERE, n) for n in ("gtars_oracle.c", "fragsplit_oracle.c", "gtars_oracle.h", "Makefile")]
     stale = (
         force
         or not os.path.exists(_LIB_PATH)
-        or (os.path.exists(src) and os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+        or (all(os.path.exists(x) for x in srcs) and os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(x) for x in srcs))
     )
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "libgtars_oracle.so"], stdout=subprocess.DEVNULL)
@@ -108,6 +107,9 @@ def lib():
     L.orc_igd_find_overlaps_regionset.argtypes = [vp, _u32p, _u32p, _u32p, u64, i32, _u32p, _u32p, u64]
     L.orc_igd_count_overlaps_per_query.argtypes = [vp, _u32p, _u32p, _u32p, u64, i32, _u32p]
     L.orc_lola_contingency.argtypes = [_u64p, _u64p, u64, i64, i64, _i64p, _i64p, _i64p, _i64p]
+    cpp = C.POINTER(C.c_char_p)
+    L.orc_fragsplit_tokenize.restype = u64
+    L.orc_fragsplit_tokenize.argtypes = [vp, cpp, u64, cpp, _u32p, u64, u32, cpp, u32, u32, _u64p, _u64p, _u64p]
     L.orc_splitmix64.restype = u64
     L.orc_splitmix64.argtypes = [C.POINTER(u64)]
     _lib = L
@@ -782,6 +784,28 @@ def fragsplit(files_dir: str, mapping: OracleBarcodeMap, file_order: Optional[Se
                 if cluster is not None:
                     out[cluster].append(f"{chr_}\t{start}\t{end}\t{barcode}\t{support}\n")
     return out
+
+
+def fragsplit_tokenize_compiled(paths: Sequence[str], mapping: OracleBarcodeMap, tok: "OracleTokenizer") -> Dict[str, Tuple[int, int, int]]:
+    """The config-5 pipeline in compiled C on one thread (fragsplit_oracle.c: split.rs:36-151 routing + fragments.rs:61-82
+    per-line tokenization): {cluster label: (ids, sum of ids, distinct barcodes)}.  The same summary of `fragsplit` +
+    `OracleTokenizer` is what tests/test_oracle_golden.py holds it to."""
+    labels = sorted(mapping.cluster_labels)
+    lid = {l: i for i, l in enumerate(labels)}
+    keys = list(mapping.map)
+    names = [None] * len(tok.chrom_ids)
+    for name, cid in tok.chrom_ids.items():
+        names[cid] = name
+    arr = lambda xs: (C.c_char_p * max(len(xs), 1))(*[x.encode() for x in xs])
+    nl = max(len(labels), 1)
+    ids, sm, bc = (np.zeros(nl, dtype=np.uint64) for _ in range(3))
+    unk = tok.universe.region_to_id[tok.special["unk"]]
+    r = lib().orc_fragsplit_tokenize(tok.index._h, arr(list(paths)), len(paths), arr(keys),
+                                     _u32([lid[mapping.map[k]] for k in keys]) if keys else _EMPTY32, len(keys), len(labels),
+                                     arr(names), len(names), unk, ids, sm, bc)
+    if r == 0xFFFFFFFFFFFFFFFF:
+        raise ValueError("fragsplit_tokenize_compiled: unreadable file or malformed fragment line")
+    return {l: (int(ids[i]), int(sm[i]), int(bc[i])) for i, l in enumerate(labels)}
 
 
 # ----------------------------------------------------------------------------- LOLA statistics (independent restatement)

@@ -149,6 +149,14 @@ void orc_lola_contingency(const uint64_t *user_hits,
 /* synthetic-data PRNG shared by generators */
 uint64_t orc_splitmix64(uint64_t *state);
 
+/* fragsplit_oracle.c: pseudobulk_fragment_files (gtars-fragsplit/src/split.rs:36-151) feeding tokenize_fragment_file
+ * (gtars-tokenizers/src/utils/fragments.rs:61-82), one thread, clusters kept in memory.  map_keys[i] ("{stem}+{barcode}") ->
+ * map_cluster[i] < n_clusters; chrom_names[c] is the name of the index's chromosome id c.  Per cluster: ids, sum of ids,
+ * distinct barcodes.  Returns the number of fragment lines read, (uint64_t)-1 on an unreadable file or a malformed line. */
+uint64_t orc_fragsplit_tokenize(const orc_index *ix, const char *const *files, uint64_t n_files, const char *const *map_keys,
+                                const uint32_t *map_cluster, uint64_t n_map, uint32_t n_clusters, const char *const *chrom_names,
+                                uint32_t n_chrom, uint32_t unk_id, uint64_t *out_ids, uint64_t *out_sum, uint64_t *out_barcodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,6 +324,81 @@ def test_fragment_tokenization(golden_dir):
     assert all(len(v) >= 1 for v in res.values())
 
 
+def _python_pipeline_summary(paths, om, otok):
+    """the pure-Python restatement (oracle.fragsplit + tokenize_fragment_file's rules), summarised like the compiled one"""
+    routed = oracle.fragsplit(os.path.dirname(paths[0]), om, file_order=[os.path.basename(p) for p in paths])
+    out = {}
+    for label in sorted(om.cluster_labels):
+        ids, sm, bcs = 0, 0, set()
+        for line in routed[label]:
+            if line.startswith("#"):
+                continue
+            parts = line.split()
+            got = otok.encode_regions([(parts[0], int(parts[1]), int(parts[2]))])
+            ids, sm = ids + len(got), sm + sum(got)
+            bcs.add(parts[3])
+        out[label] = (ids, sm, len(bcs))
+    return out
+
+
+def test_compiled_fragment_pipeline_equals_the_python_restatement(golden_dir, tmp_path):
+    """fragsplit_oracle.c (bench.py's CPU baseline for config 5) against oracle.fragsplit + OracleTokenizer: the reference's
+    fragsplit fixtures, then files with CRLF, extra columns, '#' lines, unknown chromosomes, unmapped barcodes, multi-dot
+    names and a later duplicate map key; malformed lines are errors in both."""
+    import gzip
+
+    fd = os.path.join(golden_dir, "fragments", "fragsplit")
+    om = oracle.OracleBarcodeMap(os.path.join(golden_dir, "barcode_cluster_map.tsv"))
+    for toml in ("tokenizer_bits.toml", "tokenizer_ailist.toml"):
+        otok = oracle.OracleTokenizer(os.path.join(golden_dir, "tokenizers", toml))
+        paths = sorted(os.path.join(fd, n) for n in os.listdir(fd))
+        got = oracle.fragsplit_tokenize_compiled(paths, om, otok)
+        assert got == _python_pipeline_summary(paths, om, otok) and sum(v[0] for v in got.values()) > 0
+
+    rng = np.random.default_rng(5)
+    ub = tmp_path / "u.bed"
+    starts = np.sort(rng.integers(0, 2_000_000, 3000))
+    ub.write_text("".join(f"chr{1 + i % 3}\t{s}\t{s + int(w)}\n" for i, (s, w) in enumerate(zip(starts, rng.integers(50, 4000, 3000)))))
+    otok = oracle.OracleTokenizer(str(ub))
+    d = tmp_path / "frags"
+    d.mkdir()
+    names = ["a.bed.gz", "b.sample.tsv.gz", "c.bed", "d.x.y.z.bed.gz"]
+    barcodes = [f"BC{i:03d}" for i in range(40)]
+    maplines = []
+    for fi, name in enumerate(names):
+        lines = []
+        for _ in range(1500):
+            s = int(rng.integers(0, 2_000_000))
+            ch = ("chr1", "chr2", "chr3", "chrUn")[int(rng.integers(0, 4))]
+            tail = ("\t1", "\t2\textra\tcolumns", "\t1\r")[int(rng.integers(0, 3))]
+            lines.append(f"{ch}\t{s}\t{s + int(rng.integers(1, 9000))}\t{barcodes[int(rng.integers(0, 40))]}{tail}\n")
+        lines.insert(7, f"#chr1\t5\t9\t{barcodes[0]}\t1\n")
+        text = "".join(lines)
+        if fi == 2:
+            (d / name).write_text(text.rstrip("\n"))  # no trailing newline
+        else:
+            with gzip.open(d / name, "wt", newline="") as f:
+                f.write(text)
+        stem = name.split(".")[0]
+        maplines += [f"{stem}+{b}\tcl{(i + fi) % 6}\n" for i, b in enumerate(barcodes) if (i + fi) % 5]
+    maplines.append(f"a+{barcodes[1]}\tcl_late\n")  # the later line wins
+    maplines.append("nofile+XX\tcl_empty\n")
+    mp = tmp_path / "map.tsv"
+    mp.write_text("".join(maplines))
+    om = oracle.OracleBarcodeMap(str(mp))
+    paths = [str(d / n) for n in names]
+    got = oracle.fragsplit_tokenize_compiled(paths, om, otok)
+    assert got == _python_pipeline_summary(paths, om, otok)
+    assert got["cl_empty"] == (0, 0, 0) and got["cl_late"][2] == 1 and sum(v[0] for v in got.values()) > 3000
+    (d / "bad.bed").write_text("chr1\t1\t2\tBC000\n")
+    with pytest.raises(ValueError):
+        oracle.fragsplit_tokenize_compiled(paths + [str(d / "bad.bed")], om, otok)
+    (d / "bad.bed").write_text(f"chr1\t1\tx2\t{barcodes[2]}\t1\n")
+    om.map["bad+" + barcodes[2]] = "cl0"
+    with pytest.raises(ValueError):
+        oracle.fragsplit_tokenize_compiled([str(d / "bad.bed")], om, otok)
+
+
 def test_scoring_matrix_kat_pins_inverted_queries(golden_dir):
     # gtars-scoring/src/fragment_scoring.rs:178-206 -- [[2,2,1,3],[4,1,3,1]]; the end probe [e-5, e-6) is an
     # inverted interval, so this pins Interval::overlap (interval.rs:47-50) for inverted queries through Bits::find
