@@ -39,7 +39,8 @@ universe and user set (config 4) -- is measured at N > 1 in `igd_config3_sharded
 ingests only its chromosomes, counts, and ONE all-reduce of the per-file vector(s) yields the global counts
 (what must be reduced: gtars-lola/src/enrichment.rs:198-221).  `ranks` lists what every rank saw (device, backend).
 
-Rank 0 prints ONE JSON line.  At N = 1 it also carries: larger batches (`roofline_large`), BASELINE config 3
+Rank 0 prints ONE JSON line.  At N = 1 it also carries: larger batches (`roofline_large`), a hit-heavy batch
+(`roofline_hit_heavy`: 1 Mbp-wide queries, ~33 ids each), BASELINE config 3
 (`igd_config3`) and config 4 on one GPU (`lola_config4`), each with a sampled CPU baseline and a parity check of the
 sample against the oracle, config 5 at a reduced file count (`fragsplit_config5`), the PCIe-inclusive host-buffer rate
 and the CPU baselines (the oracle on the GPU box's host cores).  Every timed output is checked in the run (`verified`).
@@ -1130,6 +1131,15 @@ def main():
         if world == 1 and not args.no_extras:
             sizes = [int(t) for t in args.large.split(",") if t]
             out["roofline_large"] = bench_large(ix, u, q0, nu, sizes, dev, stream)
+            # hit-heavy batches (not a BASELINE config): every query of the base batch widened to 1 Mbp -- ~33 ids per query,
+            # the ids dominate the bytes; wide queries' tails are measured instead of walked and their ids leave by wave-wide
+            # stores (tokenize_lds.hip: tail_run / coop_runs)
+            qw = dict(q0)
+            qw["end"] = np.minimum(q0["start"].astype(np.int64) + 1_000_000, 0x7FFFFFFF).astype(q0["end"].dtype)
+            hh = bench_large(ix, u, qw, nu, [16_000_000], dev, stream)[0]
+            hh["ids_per_query"] = round(hh["hits"] / hh["queries"], 1)
+            hh["batch"] = "the 1M-query base batch with every query widened to 1 Mbp, tiled 16x on the device"
+            out["roofline_hit_heavy"] = hh
             # PCIe-inclusive rates through the host-pointer entry points (H2D of the queries, kernel, D2H of offsets +
             # ids).  Reported for context only; never `value`.  `streaming`: gtars_tokenize_into with
             # output arrays the caller reuses (chunked copy / kernel / copy-back pipeline, nothing allocated);

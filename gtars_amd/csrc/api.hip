@@ -313,8 +313,8 @@ struct gtars_index {
     std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
     // blocked acceleration structure (Bits kind), see AccelView in common.h
-    DevBuf<u32> acc_rec2, acc_rec4, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab, acc_idc, acc_idc_pos;
-    bool acc_ids_affine = false;
+    DevBuf<u32> acc_rec2, acc_rec4, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab, acc_idc, acc_idc_pos, acc_chrom_iv_end;
+    bool acc_ids_affine = false, acc_ends_mono = false;
     u32 acc_n_blocks = 0, acc_n_units = 0, acc_n_buckets = 0, acc_lut_words = 0, acc_q_words = 0;
     u32 acc_lut_shift = 0, acc_q_shift = 0, acc_search_top = 0, acc_top_shift = 0;
     bool has_accel = false;
@@ -353,6 +353,8 @@ struct gtars_index {
         a.top_shift = acc_top_shift;
         a.n_chrom = n_chrom;
         a.max_chrom_n = max_chrom_n();
+        a.ends_mono = acc_ends_mono && !cfg_flag("GTARS_TOK_NO_RUNS") ? 1u : 0u;  // (the switch: tests and A/B runs of the tail walk)
+        a.chrom_iv_end = acc_chrom_iv_end.p;
         return a;
     }
     // The same structure with ids that are the STORED POSITIONS of the hits (position of (block b, slot k) =
@@ -808,7 +810,7 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
         ix->h_chrom_sub[n_chrom] = (u32)ix->h_sub_off.size();
     }
 
-    std::vector<u32> h_rec2, h_rec4, h_blk_first, h_lut, h_q, h_cblk, h_ctab, h_idc;
+    std::vector<u32> h_rec2, h_rec4, h_blk_first, h_lut, h_q, h_cblk, h_ctab, h_idc, h_iv_end;
     // The blocked structure is skipped (generic kernels serve the index) when it would not fit the LDS
     // kernels anyway: more units than the LDS budget holds even at the coarsest unit size (thousands of
     // non-empty contigs: every one needs at least one unit), or more blocks than a query's state word
@@ -877,6 +879,18 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
         if (!affine) h_rec4.assign((size_t)nb * 16, 0);
         h_blk_first.assign(nb, 0xFFFFFFFFu);
         std::vector<u64> chrom_span(n_chrom, 0);  // max end + 1 (0: no intervals)
+        // AccelView::ends_mono / chrom_iv_end: do the ends ascend with the starts everywhere (and no interval is inverted)?
+        bool mono = true;
+        h_iv_end.assign(n_chrom, 0);
+        for (u32 c = 0; c < n_chrom; ++c) {
+            u32 real = 0;
+            for (u32 p = off[c]; p < off[c + 1]; ++p) {
+                if (ix->h_starts[p] > ix->h_ends[p] || (p > off[c] && ix->h_ends[p] < ix->h_ends[p - 1])) mono = false;
+                if (ix->h_starts[p] != 0xFFFFFFFFu) real = p - off[c] + 1;
+            }
+            h_iv_end[c] = (u32)ACC_OWN * h_cblk[c] + real;
+        }
+        ix->acc_ends_mono = mono;
         for (u32 c = 0; c < n_chrom; ++c) {
             u32 pm = 0;  // prefix max of the ends, in (start, end) order
             for (u32 b = h_cblk[c]; b < h_cblk[c + 1]; ++b) {
@@ -992,6 +1006,7 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
         st = ix->acc_idc_pos.upload(h_idc_pos);
     }
     if (!st && ix->has_accel) st = ix->acc_blk_first.upload(h_blk_first);
+    if (!st && ix->has_accel) st = ix->acc_chrom_iv_end.upload(h_iv_end);
     if (!st && ix->has_accel) st = ix->acc_lut.upload(h_lut);
     if (!st && ix->has_accel) st = ix->acc_qkeys.upload(h_q);
     if (!st && ix->has_accel) st = ix->acc_chrom_tab.upload(h_ctab);
@@ -1044,6 +1059,7 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->acc_idc.release();
     ix->acc_idc_pos.release();
     ix->acc_blk_first.release();
+    ix->acc_chrom_iv_end.release();
     ix->acc_lut.release();
     ix->ends_sorted.release();
     ix->acc_qkeys.release();

@@ -121,6 +121,12 @@ struct AccelView {
     u32 n_chrom;
     u32 ids_affine;
     u32 max_chrom_n;  // most intervals on one chromosome: bounds a query's hits (tile totals are 32-bit)
+    // 1: on every chromosome the ends ascend with the starts and no interval is inverted (start <= end) -- disjoint universes, what
+    // consensus peak sets are.  A query's hits are then ONE run of stored positions (first interval that ends after q_start ..
+    // last that starts before q_end): the tail of a wide query is measured by a second search instead of walked (tail_run,
+    // tokenize_lds.hip).  chrom_iv_end[c] = ACC_OWN * first block of c + intervals of c that start below 0xFFFFFFFF.
+    u32 ends_mono;
+    const u32 *chrom_iv_end;
 };
 
 // IGD database: all stored intervals (tile replicas are NOT materialised),

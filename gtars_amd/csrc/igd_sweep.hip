@@ -32,7 +32,10 @@ namespace gtars {
 constexpr int IGD_TILE = (int)IGD_TILE_RECORDS;
 constexpr int SW_TPB = 512;
 
-constexpr int IGD_HALO = 256;
+#ifndef GTARS_IGD_HALO
+#define GTARS_IGD_HALO 256  // records staged behind a tile's own (a query's scan runs on into them; beyond: global memory, by the query's lane)
+#endif
+constexpr int IGD_HALO = GTARS_IGD_HALO;
 #ifndef IGD_STAMPS
 #define IGD_STAMPS 0  // diagnostic build: per-phase shader-clock totals of wave 0 of every workgroup (tools/r03_sweep_stamps.py)
 #endif

@@ -38,6 +38,7 @@ namespace gtars {
 // timing experiments only (tools/build_variant.sh; results are then WRONG by construction):
 //   1 no look-back (a made-up base)   2 no id stores   4 no offset stores   8 no record burst (made-up records)
 //   16 no LDS search (a made-up block)   32 no LDS fill (the search runs on whatever the LDS holds)
+//   64 wide queries' wave-wide stores left out (coop_runs runs)   128 coop_runs left out
 #ifndef GTARS_TOK_ABLATE
 #define GTARS_TOK_ABLATE 0
 #endif
@@ -116,6 +117,10 @@ __device__ __forceinline__ u32 block_mask4(const uint4 &S, const uint4 &E, u32 q
 // register: first block (22 bits) + 4-bit hit mask.
 constexpr u32 B0_BITS = 22;
 constexpr u32 B0_MASK = (1u << B0_BITS) - 1u;
+// ... or, for a wide query in run form (tail_run; ids that follow from the position): its hit count n < 2^28 (low 22 bits | high 6 bits
+// above the mask) + the mask -- a query's hits are bounded by the index's 2 * (2^22 - 1) intervals (tokenize_lds_supported)
+__device__ __forceinline__ u32 run_state(u32 n, u32 m) { return (n & B0_MASK) | (m << B0_BITS) | ((n >> B0_BITS) << (B0_BITS + 4)); }
+__device__ __forceinline__ u32 run_state_n(u32 st) { return (st & B0_MASK) | ((st >> (B0_BITS + 4)) << B0_BITS); }
 
 // Tail of a query whose scan runs past block b0's look-ahead intervals (rare).  Record b holds intervals
 // ACC_OWN * b .. ACC_OWN * b + 3, so the walk goes on with records b0 + 2, b0 + 4, ... and uses all four slots.
@@ -272,6 +277,43 @@ __host__ __device__ __forceinline__ size_t tok_lds_bytes(const AccelView &a) {
     return ((size_t)a.lut_words + a.q_words + 4 * (size_t)a.n_chrom + (((size_t)a.n_chrom + 3) & ~(size_t)3)) * sizeof(u32);
 }
 
+// Tail of a wide query on an index whose ends ascend with the starts (AccelView::ends_mono): the query's hits are one run of
+// stored positions, so the tail is MEASURED, not walked -- a second LDS search, for q_end, finds the first block whose largest
+// end is >= q_end (every interval in front of it ends, hence starts, before q_end), and that block's starts give the run's end.
+// Returns the number of intervals at padded position >= ACC_OWN * b0 + 4 that start before q_end -- what walk_tail counts when
+// the first record has a hit (every later interval then ends after q_start too).  33 ids per query: the walk was 8 dependent
+// record loads per lane, twice (count phase and write phase).
+template <u32 STRIDE>
+__device__ __forceinline__ u32 tail_run(const AccelView &a, const SearchLds &L, const uint4 *__restrict__ recs, u32 c, u32 b0, u32 be,
+                                        u32 qe) {
+    const u32 sq = qe - 1u;  // (a query with a tail has q_end > the fourth start >= 0)
+    u32 B, BE;
+    search_blocks<1>(a, L.lut, L.q, L.ctab, &c, &sq, &B, &BE);
+    u32 last;
+    for (;;) {
+        if (B >= be) {  // q_end lies beyond the chromosome's largest end
+            last = a.chrom_iv_end[c];
+            break;
+        }
+        const uint4 S = recs[(size_t)B * STRIDE];
+        if (S.x == 0xFFFFFFFFu) {  // a padding block
+            last = a.chrom_iv_end[c];
+            break;
+        }
+        if (S.z >= qe) {  // the run ends inside this block's own two (sentinels never count)
+            last = (u32)ACC_OWN * B + (S.x < qe ? 1u : 0u) + (S.y < qe ? 1u : 0u);
+            break;
+        }
+        ++B;  // (floor-quantised keys: the block found may lie a block early)
+    }
+    const u32 first_tail = (u32)ACC_OWN * b0 + 4u;
+    return last > first_tail ? last - first_tail : 0u;
+}
+#ifndef GTARS_TOK_RUNS
+#define GTARS_TOK_RUNS 5  // 1: tails of wide queries measured (tail_run), 4: their ids leave by wave-wide stores (experiments: subsets)
+#endif
+constexpr u32 COOP_MIN = 16;  // ids of one query from which on they leave by wave-wide stores (write_queries)
+
 #ifndef GTARS_TOK_FILL_DMA
 #define GTARS_TOK_FILL_DMA 0  // 1: the LDS image is filled by global_load_lds_dwordx4 (round-4 experiment: no gain, see profiles/r04); 0: loads + ds_write_b128
 #endif
@@ -395,6 +437,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
         tsum[r] = 0;
         t[r].more_bits = 0;
     }
+    u32 pend = 0;  // bit r * QPT + j: a wide query in run form whose tail is still to be measured
     auto issue = [&](int u) {  // search + record loads of unit u
         const int r = u / 2, j0 = (u & 1) * UQ, p = u & 1;
         if (GTARS_TOK_ABLATE & 16) {
@@ -438,7 +481,12 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
             m = act[p][k] ? m : 0u;
             const bool more = act[p][k] && (S[p][k].w < qe_) && (b0[p][k] + 2 < be[p][k]);
             u32 n = __popc(m);
-            if (more) n += walk_tail<FILTER, STRIDE>(recs, b0[p][k], be[p][k], qs_, qe_, min_bp, [](u32, int) {});
+            if (more) {
+                if ((GTARS_TOK_RUNS & 1) && !FILTER && a.ends_mono && m)
+                    pend |= 1u << (r * QPT + j);  // run form: the tail is measured below, by the ONE copy of tail_run
+                else
+                    n += walk_tail<FILTER, STRIDE>(recs, b0[p][k], be[p][k], qs_, qe_, min_bp, [](u32, int) {});
+            }
             tsum[r] += n;
             t[r].st[j] = (b0[p][k] & B0_MASK) | (m << B0_BITS);
             t[r].more_bits |= (more ? 1u : 0u) << j;
@@ -465,16 +513,50 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
         if (u > 0) finish(u - 1);
     }
     finish(NU - 1);
+    // Wide queries on an index whose ends ascend with the starts (run form): a lane measures its tails one after the other, the
+    // query picked out of the register arrays by select chains -- inlined into finish() above, tail_run's search came eight times
+    // per kernel and pushed the two-round kernels into scratch memory (60 bytes per lane; 64M C2 queries 578 -> 627 us).
+    if constexpr (!FILTER && (GTARS_TOK_RUNS & 1)) {
+        while (pend) {
+            const u32 k = (u32)__ffs((int)pend) - 1u;
+            pend &= pend - 1u;
+            u32 cq = c[0][0], eq = e[0][0], stv = t[0].st[0];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int j = 0; j < QPT; ++j) {
+                    const bool me = k == (u32)(r * QPT + j);
+                    cq = me ? c[r][j] : cq;
+                    eq = me ? e[r][j] : eq;
+                    stv = me ? t[r].st[j] : stv;
+                }
+            const u32 m = (stv >> B0_BITS) & 15u;
+            const u32 nt = tail_run<STRIDE>(a, L, recs, cq, stv & B0_MASK, L.ctab[cq].w, eq);
+            // ids that follow from the position: the write phase needs the run's length, not the block (the first id is aux + the
+            // first set bit of m) -- nothing is searched or loaded there again
+            const u32 nst = IMPL ? run_state(__popc(m) + nt, m) : stv;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                tsum[r] += (k / QPT == (u32)r) ? nt : 0u;
+#pragma unroll
+                for (int j = 0; j < QPT; ++j) t[r].st[j] = k == (u32)(r * QPT + j) ? nst : t[r].st[j];
+            }
+        }
+    }
 }
 
 // Emits the hits of the lane's QPT queries (first query q0) in result order: put(position, id) for every hit when
 // `want_ids`, o4[j] = position of query j's first hit; `run` = position of the lane's first hit.
 // REV: a query's hits leave in DESCENDING stored order (AIList::find, ailist.rs:238-263): the i-th hit of the forward
 // scan goes to slot n - 1 - i of the query's n.
+// Run form (ids that follow from the position, no min-overlap filter, AccelView::ends_mono): a wide query's ids are id0, id0 + 1,
+// ... -- nothing is walked; with `defer` (the wave's ids go straight to memory) a query of >= COOP_MIN ids is not emitted here:
+// the caller writes it with the whole wave (coop_runs).
 template <int QPT, bool FILTER, bool IMPL, bool REV, class Put>
 __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                              const u32 *__restrict__ qs, const u32 *__restrict__ qe, i32 min_bp,
-                                             const TileQ<QPT, IMPL> &t, u64 q0, u64 run, bool want_ids, u64 (&o4)[QPT], Put &&put) {
+                                             const TileQ<QPT, IMPL> &t, u64 q0, u64 run, bool want_ids, u64 (&o4)[QPT], bool defer,
+                                             Put &&put) {
     constexpr u32 STRIDE = IMPL ? 2 : 4;
     const uint4 *__restrict__ recs = IMPL ? a.rec2 : a.rec4;
     const u32 *recw = reinterpret_cast<const u32 *>(a.rec4);
@@ -482,16 +564,31 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
     for (int j = 0; j < QPT; ++j) {
         o4[j] = run;
         const u32 b0 = t.st[j] & B0_MASK;
-        u32 m = t.st[j] >> B0_BITS;
+        u32 m = (t.st[j] >> B0_BITS) & 15u;
         const bool more = (t.more_bits & (1u << j)) != 0;
+        if constexpr (IMPL && !FILTER && (GTARS_TOK_RUNS & 1)) {
+            if (more && a.ends_mono && m) {  // run form (count_rounds): the state word holds the hit count
+                const u32 n_run = run_state_n(t.st[j]);
+                if (want_ids && !((GTARS_TOK_RUNS & 4) && defer && n_run >= COOP_MIN)) {  // (deferred: coop_runs)
+                    const u32 id0 = t.aux[j] + (u32)(__ffs((int)m) - 1);
+                    for (u32 i = 0; i < n_run; ++i) put(REV ? run + (n_run - 1u - i) : run + i, id0 + i);
+                }
+                run += n_run;
+                continue;
+            }
+        }
         u32 cq = 0, sq = 0, eq = 0, be = 0;
         u32 n_all = __popc(m);  // the query's hits
+        bool tail_counted = false;
         if (more) {
             cq = qc[q0 + j];
             sq = qs[q0 + j];
             eq = qe[q0 + j];
             be = L.ctab[cq].w;
-            if (REV || !want_ids) n_all += walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [](u32, int) {});
+            if (REV || !want_ids) {
+                n_all += walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [](u32, int) {});
+                tail_counted = true;
+            }
         }
         // slot of the i-th hit of the forward scan
         auto slot = [&](u32 i) -> u64 { return REV ? run + (n_all - 1u - i) : run + i; };
@@ -529,16 +626,90 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
         } else {
             i = __popc(m);
         }
-        if (more && (want_ids || !REV)) {
-            if (want_ids) {
-                const u32 n_tail = walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
-                    put(slot(i++), IMPL ? t.aux[IMPL ? j : 0] + (u32)ACC_OWN * (b - b0) + (u32)k : recw[b * 16u + 8u + (u32)k]);
-                });
-                if (!REV) n_all += n_tail;
-            }
+        if (more && want_ids) {
+            const u32 n_tail = walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
+                put(slot(i++), IMPL ? t.aux[IMPL ? j : 0] + (u32)ACC_OWN * (b - b0) + (u32)k : recw[b * 16u + 8u + (u32)k]);
+            });
+            if (!tail_counted) n_all += n_tail;
         }
         run += n_all;
     }
+}
+
+// Hit-heavy batches (the wave's ids do not fit its LDS buffer): a wide query in run form has the ids id0, id0 + 1, ..., which the
+// whole wave writes instead of one scattered 4-byte store per lane and id (2.5 clk of the CU's vector-memory path each: 1 Mbp
+// queries, 33 ids each, ran at 0.07 of the HBM roofline).
+// What bounds this path is the INSTRUCTION COUNT, not memory: with the stores left out the first form below took as long.  A
+// wave-wide instruction occupies its SIMD for 4 cycles whether it serves 64 queries or one run, so one run's scalar bookkeeping
+// (~60 instructions: state by v_readlane, window masks, branches) cost ~47 cycles of the CU per query -- more than the stores.
+// Measured forms, 16M queries x 33 ids / 1M x 311 ids (profiles/r04/tok_experiments.txt): run by run, 256-byte-aligned dword
+// stores 1366 / 347 us; runs laid end to end in an LDS window, 16-byte flushes 2036 / 321; in a register window 1484 / 560.
+// This form: a source lane's FOUR queries at once.  Their runs [S_j, S_j + n_j) come by v_readlane (n_j = 0 for a query the lane
+// emitted itself); the lanes then walk the 256-byte-aligned pieces of the lane's region, position x = piece + lane picks its
+// run by compares (four sub / compare / add / select groups -- lane-parallel work), and a piece leaves as one store when the
+// walk moves past it; a piece that straddles two source lanes is carried over and stored once.
+template <int QPT, bool REV>
+__device__ __forceinline__ void coop_runs(const TileQ<QPT, true> &t, const u64 (&o4)[QPT], u64 wave_base, u32 *__restrict__ ovals,
+                                          u64 cap, int lane) {
+    static_assert(QPT == 4, "four runs per source lane");
+    // per lane: start, length and id offset of its queries' runs (length 0: not a deferred run)
+    u32 S[QPT], N[QPT], K[QPT];
+    u32 any_big = 0;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        const u32 m = (t.st[j] >> B0_BITS) & 15u, n = run_state_n(t.st[j]);
+        const bool big = ((t.more_bits >> j) & 1u) && m && n >= COOP_MIN;
+        S[j] = (u32)(o4[j] - wave_base);
+        N[j] = big ? n : 0u;
+        const u32 id0 = t.aux[j] + (u32)(__ffs((int)(m | 16u)) - 1);
+        K[j] = REV ? id0 + (n - 1u) + S[j] : id0 - S[j];  // id of output position x: K + x, reversed K - x
+        any_big |= N[j];
+    }
+    unsigned long long todo = __ballot(any_big != 0);
+    if (!todo || wave_base >= cap) return;
+    u32 *__restrict__ out = ovals + wave_base;                                             // (wave-uniform)
+    const u32 room = cap - wave_base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(cap - wave_base);  // ids the caller's buffer still takes
+    // the piece being filled: output positions [w0, w0 + 64); lane l holds the id of position w0 + l when `has`
+    u32 w0 = 0, val = 0;
+    bool has = false;
+    bool open = false;  // (wave-uniform) some lane of the piece is filled
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        u32 s_[QPT], n_[QPT], k_[QPT];
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            s_[j] = (u32)__builtin_amdgcn_readlane((int)S[j], src);
+            n_[j] = (u32)__builtin_amdgcn_readlane((int)N[j], src);
+            k_[j] = (u32)__builtin_amdgcn_readlane((int)K[j], src);
+        }
+        // the lane's region: from its first run's start to its last run's end (runs ascend with j)
+        u32 lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j)
+            if (n_[j]) {
+                lo = lo < s_[j] ? lo : s_[j];
+                hi = s_[j] + n_[j];
+            }
+        hi = hi < room ? hi : room;
+        for (u32 w = lo & ~63u; w < hi; w += 64) {
+            if (w != w0) {  // (w > w0: the regions come in ascending order)
+                if (open && has) __builtin_nontemporal_store(val, &out[w0 + (u32)lane]);
+                has = false;
+                w0 = w;
+            }
+            open = true;
+            const u32 x = w + (u32)lane;
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                const bool in = x - s_[j] < n_[j];
+                val = in ? (REV ? k_[j] - x : k_[j] + x) : val;
+                has = has || in;
+            }
+            has = has && x < room;
+        }
+    }
+    if (open && has) __builtin_nontemporal_store(val, &out[w0 + (u32)lane]);
 }
 
 // write phase: CSR offsets and token ids of the lane's QPT queries.  wave_base = global offset
@@ -553,13 +724,16 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
     const bool staged = cap && t.wtotal <= stage_cap && wave_base + t.wtotal <= cap;
     u64 o4[QPT];
     // ids go either to the wave's LDS buffer (index relative to wave_base) or straight to memory
-    emit_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, [&](u64 pos, u32 id) {
+    emit_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, !staged, [&](u64 pos, u32 id) {
         if (GTARS_TOK_ABLATE & 2) return;
         if (staged)
             stage[(u32)(pos - wave_base)] = id;
         else if (pos < cap)
             ovals[pos] = id;
     });
+    if constexpr (IMPL && !FILTER && (GTARS_TOK_RUNS & 4) != 0) {
+        if (!staged && cap && a.ends_mono && !(GTARS_TOK_ABLATE & (2 | 128))) coop_runs<QPT, REV>(t, o4, wave_base, ovals, cap, lane);
+    }
     if (staged && !(GTARS_TOK_ABLATE & 2)) {
         // the wave's ids, contiguous: 256 bytes per store instruction (LDS operations of a wave execute in order)
         for (u32 i = (u32)lane; i < t.wtotal; i += 64) __builtin_nontemporal_store(stage[i], &ovals[wave_base + i]);
@@ -587,7 +761,7 @@ __device__ __forceinline__ bool stage_queries(const AccelView &a, const SearchLd
                                               u32 (&orel)[QPT]) {
     if (cap && t.wtotal > stage_cap) return false;
     u64 o4[QPT];
-    emit_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, [&](u64 pos, u32 id) {
+    emit_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, false, [&](u64 pos, u32 id) {
         if (GTARS_TOK_ABLATE & 2) return;
         stage[(u32)pos] = id;
     });
@@ -653,8 +827,11 @@ __device__ __forceinline__ u64 help_count_tile(const AccelView &a, const SearchL
         search_blocks<1>(a, L.lut, L.q, L.ctab, &c, &s, &b0, &be);
         if (b0 < be) {
             const uint4 S = a.rec2[(size_t)b0 * 2], E = a.rec2[(size_t)b0 * 2 + 1];
-            n += __popc(block_mask4<FILTER>(S, E, s, e, min_bp));
-            if (S.w < e && b0 + 2 < be) n += walk_tail<FILTER, 2>(a.rec2, b0, be, s, e, min_bp, [](u32, int) {});
+            const u32 m = block_mask4<FILTER>(S, E, s, e, min_bp);
+            n += __popc(m);
+            if (S.w < e && b0 + 2 < be)
+                n += (!FILTER && a.ends_mono && m) ? tail_run<2>(a, L, a.rec2, c, b0, be, e)
+                                                   : walk_tail<FILTER, 2>(a.rec2, b0, be, s, e, min_bp, [](u32, int) {});
         }
     }
     return wave_reduce_sum_u64(n);
@@ -1000,9 +1177,11 @@ k_count_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
         } else {
 #pragma unroll
             for (int j = 0; j < QPT; ++j) {
-                n[j] = act[j] ? __popc(block_mask4<FILTER>(S[j], E[j], s[j], e[j], min_bp)) : 0u;
+                const u32 m = act[j] ? block_mask4<FILTER>(S[j], E[j], s[j], e[j], min_bp) : 0u;
+                n[j] = __popc(m);
                 if (act[j] && S[j].w < e[j] && b0[j] + 2 < be[j])
-                    n[j] += walk_tail<FILTER, 2>(a.rec2, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
+                    n[j] += (!FILTER && a.ends_mono && m) ? tail_run<2>(a, L, a.rec2, c[j], b0[j], be[j], e[j])
+                                                          : walk_tail<FILTER, 2>(a.rec2, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
             }
 #pragma unroll
             for (int j = 0; j < QPT; ++j) {

@@ -29,6 +29,12 @@ def one(seed):
     if rng.random() < 0.2 and n > 3:          # inverted universe intervals
         k = rng.integers(0, n, 3)
         e[k] = np.maximum(s[k].astype(np.int64) - 5, 0)
+    if rng.random() < 0.3 and n > 1:          # a disjoint universe (ends ascend with the starts): wide queries take the run form
+        order = np.lexsort((s, c))
+        c, s, e = c[order], s[order], e[order].astype(np.int64)
+        same = c[1:] == c[:-1]
+        e[:-1] = np.where(same, np.minimum(e[:-1], s[1:]), e[:-1])
+        e = np.maximum(e, s)
     val = rng.permutation(n).astype(np.uint32)
     if rng.random() < 0.5:                    # a sorted universe file: ids follow from the position (no id records)
         order = np.lexsort((e, s, c))

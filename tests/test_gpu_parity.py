@@ -814,6 +814,83 @@ def test_tokenize_wide_nested_and_degenerate_universe_intervals(ga):
     assert len(ids_o) > 20 * nq  # the wide intervals make every query a multi-hit query
 
 
+def _disjoint_universe(rng, n_chrom, per_chrom, span):
+    """sorted, disjoint (ends ascend with the starts), with touching neighbours, equal ends, zero-length intervals and chromosomes
+    of odd / tiny sizes"""
+    C_, S, E = [], [], []
+    for c in range(n_chrom):
+        n = per_chrom if c else 1  # chromosome 0: a single interval
+        n += c % 2
+        cuts = np.sort(rng.choice(span, 2 * n, replace=False))
+        s, e = cuts[0::2].copy(), cuts[1::2].copy()
+        k = rng.integers(0, n - 1, max(n // 50, 1)) if n > 1 else []
+        for i in k:
+            e[i] = s[i + 1]            # touching
+        for i in (rng.integers(0, n - 1, max(n // 80, 1)) if n > 1 else []):
+            e[i] = e[i + 1]            # equal ends (the earlier one contains nothing: starts still ascend)
+        for i in rng.integers(0, n, max(n // 100, 1)):
+            e[i] = s[i] if i == 0 or e[i - 1] <= s[i] else e[i]  # zero-length
+        e = np.maximum.accumulate(np.maximum(e, s))              # (keep the ends ascending after the edits)
+        C_.append(np.full(n, c)); S.append(s); E.append(e)
+    return np.concatenate(C_), np.concatenate(S), np.concatenate(E)
+
+
+def _wide_queries(rng, n_chrom, span, nq, typical):
+    qc = rng.integers(0, n_chrom + 1, nq)  # (n_chrom: an unknown chromosome)
+    qs = rng.integers(0, span, nq).astype(np.int64)
+    w = np.where(rng.random(nq) < 0.4, rng.integers(0, 400, nq), rng.integers(0, 2 * typical, nq))
+    qe = qs + w
+    k = rng.integers(0, nq, nq // 20)
+    qe[k] = span + rng.integers(0, 1000, len(k))       # to the chromosome's end and past it
+    k = rng.integers(0, nq, nq // 50)
+    qs[k] = 0; qe[k] = 0xFFFFFFFF                      # everything on the chromosome
+    k = rng.integers(0, nq, nq // 50)
+    qe[k] = np.maximum(qs[k] - rng.integers(0, 30, len(k)), 0)  # zero-length / inverted
+    return qc, qs, qe
+
+
+@pytest.mark.parametrize("kind", BOTH)
+@pytest.mark.parametrize("explicit_ids", [False, True])
+def test_wide_queries_on_disjoint_universes_take_the_run_form(ga, monkeypatch, kind, explicit_ids):
+    """Hit-heavy batches on a universe whose ends ascend with the starts: a wide query's tail is measured by a second search
+    (tail_run) and, with position-derived ids, its ids leave by wave-wide stores -- against the oracle's scan, and against the
+    walked form (GTARS_TOK_NO_RUNS); one and two rounds / wave groups per tile; tokenize, count, any, find (position view)."""
+    rng = np.random.default_rng(77 + int(explicit_ids))
+    n_chrom, span = 5, 4_000_000
+    C_, S, E = _disjoint_universe(rng, n_chrom, 9_001, span)
+    val = rng.permutation(len(S)).astype(np.uint32) if explicit_ids else None
+    g, o = _pair(ga, C_, S, E, val, n_chrom=n_chrom, kind=kind)
+    qc, qs, qe = _wide_queries(rng, n_chrom, span, 30_000, typical=40_000)  # ~90 ids per wide query
+    _assert_same_queries(g, o, qc[:6000], qs[:6000], qe[:6000], min_overlaps=(None, 1, 300))
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    assert len(ids_o) > 40 * len(qc)
+    for rounds, groups in (("1", "1"), ("2", "1"), ("1", "2"), ("2", "2")):
+        monkeypatch.setenv("GTARS_TOK_ROUNDS", rounds)
+        monkeypatch.setenv("GTARS_TOK_GROUPS", groups)
+        off_g, ids_g = g.tokenize(qc, qs, qe)
+        assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o), (rounds, groups)
+    monkeypatch.setenv("GTARS_TOK_NO_RUNS", "1")
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+    assert g.count_overlaps(qc, qs, qe).tolist() == o.count_overlaps(qc, qs, qe).tolist()
+
+
+@pytest.mark.parametrize("top_max", ["64", "600"])
+def test_run_form_with_padded_units(ga, monkeypatch, top_max):
+    """the same with several blocks per search unit (GTARS_TOP_MAX: the chromosomes' block ranges are padded to whole units, a
+    query that reaches past a chromosome's last interval lands on a padding block) and a narrow-query majority, so that wide
+    queries share their waves with staged ones"""
+    monkeypatch.setenv("GTARS_TOP_MAX", top_max)
+    rng = np.random.default_rng(int(top_max))
+    n_chrom, span = 7, 2_000_000
+    C_, S, E = _disjoint_universe(rng, n_chrom, 3_333, span)
+    g, o = _pair(ga, C_, S, E, n_chrom=n_chrom)
+    qc, qs, qe = _wide_queries(rng, n_chrom, span, 40_000, typical=60_000)
+    narrow = rng.random(len(qc)) < 0.97
+    qe = np.where(narrow & (qe > qs), np.minimum(qe, qs + 300), qe)
+    _assert_same_queries(g, o, qc, qs, qe, min_overlaps=(None,))
+
+
 def test_config3_igd_full_size_properties(ga):
     """BASELINE config 3 at full size (5e7 records, F = 1000, 1e7 queries): size-independent properties of
     the per-file vectors, plus bit-exact parity with the oracle's literal tile walk on one chromosome."""
@@ -1151,6 +1228,7 @@ def test_tokenize_async_while_another_stream_holds_cus(ga, hog_wgs, hog_lds):
         for qc, qs, qe, n, offsets, ids, off_o, ids_o, rep in cases:
             offsets.zero_()
             ids.zero_()
+            s_tok.wait_stream(torch.cuda.current_stream())  # (the clears run on the current stream: they must not overtake the launch)
             with torch.cuda.stream(s_tok):
                 g.tokenize_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), n, offsets.data_ptr(), ids.data_ptr(), ids.numel(),
                                   s_tok.cuda_stream, sync=False)
