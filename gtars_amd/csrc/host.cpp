@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -2186,14 +2187,21 @@ namespace {
 struct SplitFile {
     std::string data;
     std::vector<std::string> text;                           // [n_clusters]
-    struct Row { const char *chr; uint32_t chr_n; const char *bc; uint32_t bc_n; uint32_t s, e; };
-    std::vector<std::vector<Row>> rows;                      // [n_clusters]
+    // fused pipeline: per cluster the routed fragments as columns -- chromosome ids of the tokenizer's dictionary, barcode ids
+    // LOCAL to this file and cluster (first-seen order; `barcodes.names`).  Filled by the thread that parses the file, while the
+    // line is in its cache: resolving the strings per cluster afterwards, by other threads, cost two cache misses per row (as
+    // much wall time as gunzip + parse: 54 of 129 ms for 48 files x 1e5 fragments).
+    struct Cols {
+        std::vector<uint32_t> c, s, e, b;
+        ViewDict barcodes;
+    };
+    std::vector<Cols> cols;                                  // [n_clusters]
     uint64_t n_reads = 0, n_written = 0;
     gtars_status st = GTARS_OK;
     std::string err;
 };
 
-void split_one_file(const std::string &path, const gtars_barcode_map &m, bool want_text, SplitFile &out) {
+void split_one_file(const std::string &path, const gtars_barcode_map &m, bool want_text, SplitFile &out, const Dict *chroms) {
     std::string err;
     if (!read_all(path, out.data, err)) {
         out.st = GTARS_ERR_IO;
@@ -2201,7 +2209,10 @@ void split_one_file(const std::string &path, const gtars_barcode_map &m, bool wa
         return;
     }
     const size_t nc = m.labels.size();
-    if (want_text) out.text.resize(nc); else out.rows.resize(nc);
+    if (want_text) out.text.resize(nc); else out.cols.resize(nc);
+    const char *lc = nullptr;  // the last chromosome name looked up (fragment files are sorted: it rarely changes)
+    size_t lcn = 0;
+    uint32_t lcid = 0;
     const std::string stem = remove_all_extensions(path);
     std::string key = stem + "+";
     const size_t key0 = key.size();
@@ -2239,15 +2250,24 @@ void split_one_file(const std::string &path, const gtars_barcode_map &m, bool wa
                     t.push_back(k == 4 ? '\n' : '\t');
                 }
             } else if (f[0][0] != '#') {  // tokenize_fragment_file skips '#' lines of the cluster file
-                SplitFile::Row r;
-                if (!parse_u32_view(f[1], fl[1], r.s) || !parse_u32_view(f[2], fl[2], r.e)) {
+                uint32_t rs = 0, re = 0;
+                if (!parse_u32_view(f[1], fl[1], rs) || !parse_u32_view(f[2], fl[2], re)) {
                     out.st = GTARS_ERR_PARSE;
-                    out.err = std::string("Failed to parse ") + (parse_u32_view(f[1], fl[1], r.s) ? "end" : "start") +
+                    out.err = std::string("Failed to parse ") + (parse_u32_view(f[1], fl[1], rs) ? "end" : "start") +
                               " position of a routed fragment (" + path + " line " + std::to_string(index) + ")";
                     return;
                 }
-                r.chr = f[0]; r.chr_n = (uint32_t)fl[0]; r.bc = f[3]; r.bc_n = (uint32_t)fl[3];
-                out.rows[cl].push_back(r);
+                if (!(lc && lcn == fl[0] && memcmp(lc, f[0], lcn) == 0)) {
+                    const int64_t cid = chroms ? chroms->find(std::string(f[0], fl[0])) : -1;
+                    lcid = cid < 0 ? GTARS_UNKNOWN_CHROM : (uint32_t)cid;
+                    lc = f[0];
+                    lcn = fl[0];
+                }
+                SplitFile::Cols &k = out.cols[cl];
+                k.c.push_back(lcid);
+                k.s.push_back(rs);
+                k.e.push_back(re);
+                k.b.push_back(k.barcodes.get_or_add(f[3], fl[3]));
             }
             ++out.n_written;
         }
@@ -2259,7 +2279,8 @@ void split_one_file(const std::string &path, const gtars_barcode_map &m, bool wa
 
 // files in waves of `wave` (parsed in parallel), handed to `sink(first_file_index, wave_results)` in file order
 template <class Sink>
-gtars_status for_each_split_wave(const std::vector<std::string> &files, const gtars_barcode_map &m, bool want_text, Sink &&sink) {
+gtars_status for_each_split_wave(const std::vector<std::string> &files, const gtars_barcode_map &m, bool want_text, const Dict *chroms,
+                                 Sink &&sink) {
     const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_thread_budget(64), files.size()));
     const size_t wave = (size_t)nt * 2;
     for (size_t base = 0; base < files.size(); base += wave) {
@@ -2267,7 +2288,7 @@ gtars_status for_each_split_wave(const std::vector<std::string> &files, const gt
         std::vector<SplitFile> res(n);
         std::atomic<size_t> next{0};
         auto work = [&] {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) split_one_file(files[base + i], m, want_text, res[i]);
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) split_one_file(files[base + i], m, want_text, res[i], chroms);
         };
         std::vector<std::thread> th;
         for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
@@ -2319,7 +2340,7 @@ static gtars_status gtars_fragsplit_impl(const char *files_dir, const gtars_barc
         gzbuffer(outs[c], 1 << 18);
     }
     uint64_t reads = 0, written = 0;
-    st = for_each_split_wave(files, *m, true, [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
+    st = for_each_split_wave(files, *m, true, nullptr, [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
         // every cluster's stream is compressed by one thread per wave, the wave's files in order
         std::atomic<size_t> next{0};
         std::atomic<int> bad{0};
@@ -2355,61 +2376,80 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
     // per cluster: fragment columns in the order the cluster file would have them (files in order, lines in order),
     // chromosome ids of the TOKENIZER's dictionary, barcode ids in first-seen order
     struct Cluster {
-        std::vector<uint32_t> c, s, e, b;
+        std::vector<uint32_t> c, s, e, b;  // b: barcode ids in the cluster's first-seen order
         ViewDict barcodes;
     };
     std::vector<Cluster> cl(nc);
     uint64_t reads = 0;
-    st = for_each_split_wave(files, *m, false, [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
+    const bool timing = cfg_get("GTARS_HOST_TIMING") != nullptr;  // stderr: seconds per stage (tools/fragsplit_bench.py)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_append = 0;
+    auto over_clusters = [&](auto &&body) {  // body(c) for every cluster, on up to 64 threads
         std::atomic<size_t> next{0};
         auto work = [&] {
-            for (size_t c = next.fetch_add(1); c < nc; c = next.fetch_add(1)) {
-                Cluster &k = cl[c];
-                const char *lc = nullptr;
-                size_t lcn = 0;
-                uint32_t lcid = 0;
-                for (SplitFile &f : res)
-                    for (const SplitFile::Row &r : f.rows[c]) {
-                        if (!(lc && lcn == r.chr_n && memcmp(lc, r.chr, lcn) == 0)) {
-                            const int64_t cid = t->chroms.find(std::string(r.chr, r.chr_n));
-                            lcid = cid < 0 ? GTARS_UNKNOWN_CHROM : (uint32_t)cid;
-                            lc = r.chr;
-                            lcn = r.chr_n;
-                        }
-                        k.c.push_back(lcid);
-                        k.s.push_back(r.s);
-                        k.e.push_back(r.e);
-                        k.b.push_back(k.barcodes.get_or_add(r.bc, r.bc_n));
-                    }
-            }
+            for (size_t c = next.fetch_add(1); c < nc; c = next.fetch_add(1)) body(c);
         };
         const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_thread_budget(64), nc));
         std::vector<std::thread> th;
         for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
         work();
         for (auto &tt : th) tt.join();
+    };
+    st = for_each_split_wave(files, *m, false, &t->chroms, [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
+        const double t_a = now();
+        // the wave's files appended to every cluster in file order: column copies, the file-local barcode ids mapped through the
+        // cluster's dictionary (one lookup per distinct barcode of a file, in its first-seen order, so the cluster's order is
+        // what one pass over the cluster file would see)
+        over_clusters([&](size_t c) {
+            Cluster &k = cl[c];
+            size_t add = 0;
+            for (SplitFile &f : res) add += f.cols[c].c.size();
+            k.c.reserve(k.c.size() + add);
+            k.s.reserve(k.s.size() + add);
+            k.e.reserve(k.e.size() + add);
+            k.b.reserve(k.b.size() + add);
+            std::vector<uint32_t> map;
+            for (SplitFile &f : res) {
+                SplitFile::Cols &q = f.cols[c];
+                map.resize(q.barcodes.names.size());
+                for (size_t i = 0; i < map.size(); ++i) map[i] = k.barcodes.get_or_add(q.barcodes.names[i].data(), q.barcodes.names[i].size());
+                k.c.insert(k.c.end(), q.c.begin(), q.c.end());
+                k.s.insert(k.s.end(), q.s.begin(), q.s.end());
+                k.e.insert(k.e.end(), q.e.begin(), q.e.end());
+                for (uint32_t lb : q.b) k.b.push_back(map[lb]);
+            }
+        });
         for (SplitFile &f : res) reads += f.n_reads;
+        t_append += now() - t_a;
         return GTARS_OK;
     });
     if (st) return st;
+    const double t_split_done = now();
+    // ONE tokenizer call over all clusters' fragments (cluster after cluster), then every cluster regrouped by barcode
+    std::vector<uint64_t> coff(nc + 1, 0);
+    for (size_t c = 0; c < nc; ++c) coff[c + 1] = coff[c] + cl[c].c.size();
+    const uint64_t n_all = coff[nc];
+    std::vector<uint32_t> qc(n_all), qs(n_all), qe(n_all);
+    over_clusters([&](size_t c) {
+        std::copy(cl[c].c.begin(), cl[c].c.end(), qc.begin() + coff[c]);
+        std::copy(cl[c].s.begin(), cl[c].s.end(), qs.begin() + coff[c]);
+        std::copy(cl[c].e.begin(), cl[c].e.end(), qe.begin() + coff[c]);
+    });
+    std::vector<uint64_t> off(n_all + 1, 0);
+    uint32_t *ids = nullptr;
+    uint64_t h = 0;
+    st = gtars_tokenize(t->index, qc.data(), qs.data(), qe.data(), n_all, off.data(), &ids, &h);
+    if (st) return st;
+    const double t_tok_done = now();
     auto **arr = (gtars_fragment_tokens_t **)calloc(nc ? nc : 1, sizeof(gtars_fragment_tokens_t *));
-    auto bail = [&](gtars_status e) {
-        for (size_t c = 0; c < nc; ++c) gtars_fragment_tokens_free(arr[c]);
-        free(arr);
-        return e;
-    };
-    for (size_t c = 0; c < nc; ++c) {
+    over_clusters([&](size_t c) {
         Cluster &k = cl[c];
-        const uint64_t n = k.c.size();
-        std::vector<uint64_t> off(n + 1, 0);
-        uint32_t *ids = nullptr;
-        uint64_t h = 0;
-        st = gtars_tokenize(t->index, k.c.data(), k.s.data(), k.e.data(), n, off.data(), &ids, &h);
-        if (st) return bail(st);
+        const uint64_t n = k.c.size(), q0 = coff[c];
         const uint64_t nb = k.barcodes.names.size();
         std::vector<uint64_t> cnt(nb + 1, 0);
         for (uint64_t i = 0; i < n; ++i) {
-            const uint64_t hits = off[i + 1] - off[i];
+            const uint64_t hits = off[q0 + i + 1] - off[q0 + i];
             cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
         }
         for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
@@ -2423,16 +2463,19 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
         std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
         for (uint64_t i = 0; i < n; ++i) {
             uint64_t &w = fill[k.b[i]];
-            if (off[i + 1] == off[i])
+            if (off[q0 + i + 1] == off[q0 + i])
                 ft->ids[w++] = t->unk_id;
             else
-                for (uint64_t x = off[i]; x < off[i + 1]; ++x) ft->ids[w++] = ids[x];
+                for (uint64_t x = off[q0 + i]; x < off[q0 + i + 1]; ++x) ft->ids[w++] = ids[x];
         }
-        gtars_free(ids);
         arr[c] = ft;
-    }
+    });
+    gtars_free(ids);
     *out = arr;
     if (n_reads) *n_reads = reads;
+    if (timing)
+        fprintf(stderr, "[gtars host timing] fragsplit_tokenize: %zu files, gunzip + parse + route %.3f s, per-cluster append %.3f s, tokenize (one call, %llu fragments) %.3f s, regroup of %zu clusters %.3f s\n",
+                files.size(), t_split_done - t_begin - t_append, t_append, (unsigned long long)n_all, t_tok_done - t_split_done, nc, now() - t_tok_done);
     return GTARS_OK;
 }
 
