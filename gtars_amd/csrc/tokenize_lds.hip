@@ -120,6 +120,10 @@ constexpr u32 B0_MASK = (1u << B0_BITS) - 1u;
 // ... or, for a wide query in run form (tail_run; ids that follow from the position): its hit count n < 2^28 (low 22 bits | high 6 bits
 // above the mask) + the mask -- a query's hits are bounded by the index's 2 * (2^22 - 1) intervals (tokenize_lds_supported)
 __device__ __forceinline__ u32 run_state(u32 n, u32 m) { return (n & B0_MASK) | (m << B0_BITS) | ((n >> B0_BITS) << (B0_BITS + 4)); }
+#ifndef GTARS_TOK_STAGE_RUNS
+#define GTARS_TOK_STAGE_RUNS 1  // 1: the early staging of round 0 (stage_queries) emits run-form queries itself; 0: see there
+#endif
+constexpr u32 RUN_FLAG_BIT = 8;  // TileQ::more_bits: some query of the lane's round is in run form
 __device__ __forceinline__ u32 run_state_n(u32 st) { return (st & B0_MASK) | ((st >> (B0_BITS + 4)) << B0_BITS); }
 
 // Tail of a query whose scan runs past block b0's look-ahead intervals (rare).  Record b holds intervals
@@ -538,6 +542,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 tsum[r] += (k / QPT == (u32)r) ? nt : 0u;
+                if (IMPL) t[r].more_bits |= (k / QPT == (u32)r) ? 1u << RUN_FLAG_BIT : 0u;
 #pragma unroll
                 for (int j = 0; j < QPT; ++j) t[r].st[j] = k == (u32)(r * QPT + j) ? nst : t[r].st[j];
             }
@@ -552,7 +557,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
 // Run form (ids that follow from the position, no min-overlap filter, AccelView::ends_mono): a wide query's ids are id0, id0 + 1,
 // ... -- nothing is walked; with `defer` (the wave's ids go straight to memory) a query of >= COOP_MIN ids is not emitted here:
 // the caller writes it with the whole wave (coop_runs).
-template <int QPT, bool FILTER, bool IMPL, bool REV, class Put>
+template <int QPT, bool FILTER, bool IMPL, bool REV, bool RUNFORM, class Put>
 __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                              const u32 *__restrict__ qs, const u32 *__restrict__ qe, i32 min_bp,
                                              const TileQ<QPT, IMPL> &t, u64 q0, u64 run, bool want_ids, u64 (&o4)[QPT], bool defer,
@@ -566,7 +571,7 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
         const u32 b0 = t.st[j] & B0_MASK;
         u32 m = (t.st[j] >> B0_BITS) & 15u;
         const bool more = (t.more_bits & (1u << j)) != 0;
-        if constexpr (IMPL && !FILTER && (GTARS_TOK_RUNS & 1)) {
+        if constexpr (RUNFORM && IMPL && !FILTER && (GTARS_TOK_RUNS & 1)) {
             if (more && a.ends_mono && m) {  // run form (count_rounds): the state word holds the hit count
                 const u32 n_run = run_state_n(t.st[j]);
                 if (want_ids && !((GTARS_TOK_RUNS & 4) && defer && n_run >= COOP_MIN)) {  // (deferred: coop_runs)
@@ -724,7 +729,7 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
     const bool staged = cap && t.wtotal <= stage_cap && wave_base + t.wtotal <= cap;
     u64 o4[QPT];
     // ids go either to the wave's LDS buffer (index relative to wave_base) or straight to memory
-    emit_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, !staged, [&](u64 pos, u32 id) {
+    emit_queries<QPT, FILTER, IMPL, REV, true>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, !staged, [&](u64 pos, u32 id) {
         if (GTARS_TOK_ABLATE & 2) return;
         if (staged)
             stage[(u32)(pos - wave_base)] = id;
@@ -760,8 +765,14 @@ __device__ __forceinline__ bool stage_queries(const AccelView &a, const SearchLd
                                               const TileQ<QPT, IMPL> &t, u64 q0, u64 cap, u32 *stage, u32 stage_cap,
                                               u32 (&orel)[QPT]) {
     if (cap && t.wtotal > stage_cap) return false;
+    // (GTARS_TOK_STAGE_RUNS = 0, measured and rejected: leave a wave-round that holds a query in run form to write_queries, so that
+    // the two copies of this early staging carry no run-form code -- 4 KB less code, but the wave-wide test in front of the
+    // staging cost the C2 batches 8 %: 1M 16.6 -> 18.0 us, 64M 567 -> 598)
+#if !GTARS_TOK_STAGE_RUNS
+    if (IMPL && !FILTER && (GTARS_TOK_RUNS & 1) && __ballot((t.more_bits >> RUN_FLAG_BIT) & 1u)) return false;
+#endif
     u64 o4[QPT];
-    emit_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, false, [&](u64 pos, u32 id) {
+    emit_queries<QPT, FILTER, IMPL, REV, GTARS_TOK_STAGE_RUNS != 0>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, false, [&](u64 pos, u32 id) {
         if (GTARS_TOK_ABLATE & 2) return;
         stage[(u32)pos] = id;
     });
@@ -827,11 +838,8 @@ __device__ __forceinline__ u64 help_count_tile(const AccelView &a, const SearchL
         search_blocks<1>(a, L.lut, L.q, L.ctab, &c, &s, &b0, &be);
         if (b0 < be) {
             const uint4 S = a.rec2[(size_t)b0 * 2], E = a.rec2[(size_t)b0 * 2 + 1];
-            const u32 m = block_mask4<FILTER>(S, E, s, e, min_bp);
-            n += __popc(m);
-            if (S.w < e && b0 + 2 < be)
-                n += (!FILTER && a.ends_mono && m) ? tail_run<2>(a, L, a.rec2, c, b0, be, e)
-                                                   : walk_tail<FILTER, 2>(a.rec2, b0, be, s, e, min_bp, [](u32, int) {});
+            n += __popc(block_mask4<FILTER>(S, E, s, e, min_bp));
+            if (S.w < e && b0 + 2 < be) n += walk_tail<FILTER, 2>(a.rec2, b0, be, s, e, min_bp, [](u32, int) {});  // (rare path: walked)
         }
     }
     return wave_reduce_sum_u64(n);
