@@ -17,9 +17,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <condition_variable>
 #include <numeric>
 #include <set>
 #include <string>
@@ -2376,15 +2379,25 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
     // per cluster: fragment columns in the order the cluster file would have them (files in order, lines in order),
     // chromosome ids of the TOKENIZER's dictionary, barcode ids in first-seen order
     struct Cluster {
-        std::vector<uint32_t> c, s, e, b;  // b: barcode ids in the cluster's first-seen order
+        std::vector<uint32_t> b;  // barcode ids (the cluster's first-seen order) of its fragments, wave after wave
         ViewDict barcodes;
     };
+    // one wave's routed fragments as tokenizer input, cluster after cluster, and what the tokenizer made of them
+    struct Wave {
+        std::vector<uint64_t> coff;     // [n_clusters + 1]
+        std::vector<uint32_t> c, s, e;
+        std::vector<uint64_t> off;      // [fragments + 1]
+        uint32_t *ids = nullptr;
+        gtars_status st = GTARS_OK;
+        std::string err;
+    };
     std::vector<Cluster> cl(nc);
-    uint64_t reads = 0;
+    std::deque<Wave> waves;
+    uint64_t reads = 0, n_all = 0;
     const bool timing = cfg_get("GTARS_HOST_TIMING") != nullptr;  // stderr: seconds per stage (tools/fragsplit_bench.py)
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    double t_append = 0;
+    double t_append = 0, t_tok = 0;
     auto over_clusters = [&](auto &&body) {  // body(c) for every cluster, on up to 64 threads
         std::atomic<size_t> next{0};
         auto work = [&] {
@@ -2396,62 +2409,114 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
         work();
         for (auto &tt : th) tt.join();
     };
+    // The tokenizer calls (one per wave: copy in, kernel, copy out) run on ONE helper thread, so that a wave is tokenized while
+    // the next one is being inflated and parsed (folders of more files than one wave holds: the config's 10,000).
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Wave *> jobs;
+    bool closing = false;
+    std::thread tok_thread([&] {
+        for (;;) {
+            Wave *w = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return closing || !jobs.empty(); });
+                if (jobs.empty()) return;
+                w = jobs.front();
+                jobs.pop_front();
+            }
+            const double t0 = now();
+            uint64_t h = 0;
+            w->st = gtars_tokenize(t->index, w->c.data(), w->s.data(), w->e.data(), w->c.size(), w->off.data(), &w->ids, &h);
+            if (w->st) w->err = gtars_last_error();
+            t_tok += now() - t0;
+        }
+    });
+    auto finish_tokenizer = [&] {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closing = true;
+        }
+        cv.notify_all();
+        if (tok_thread.joinable()) tok_thread.join();
+    };
+    struct AtExit {  // (an exception on the way -- out of memory -- must not meet a joinable thread)
+        std::function<void()> f;
+        ~AtExit() { f(); }
+    } join_at_exit{finish_tokenizer};
+    auto free_waves = [&] {
+        for (Wave &w : waves) gtars_free(w.ids);
+    };
     st = for_each_split_wave(files, *m, false, &t->chroms, [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
         const double t_a = now();
-        // the wave's files appended to every cluster in file order: column copies, the file-local barcode ids mapped through the
+        waves.emplace_back();
+        Wave &w = waves.back();
+        w.coff.assign(nc + 1, 0);
+        for (size_t c = 0; c < nc; ++c) {
+            uint64_t add = 0;
+            for (SplitFile &f : res) add += f.cols[c].c.size();
+            w.coff[c + 1] = w.coff[c] + add;
+        }
+        const uint64_t n = w.coff[nc];
+        w.c.resize(n);
+        w.s.resize(n);
+        w.e.resize(n);
+        w.off.assign(n + 1, 0);
+        // the wave's files, in file order, behind every cluster: column copies; the file-local barcode ids mapped through the
         // cluster's dictionary (one lookup per distinct barcode of a file, in its first-seen order, so the cluster's order is
         // what one pass over the cluster file would see)
         over_clusters([&](size_t c) {
             Cluster &k = cl[c];
-            size_t add = 0;
-            for (SplitFile &f : res) add += f.cols[c].c.size();
-            k.c.reserve(k.c.size() + add);
-            k.s.reserve(k.s.size() + add);
-            k.e.reserve(k.e.size() + add);
-            k.b.reserve(k.b.size() + add);
+            k.b.reserve(k.b.size() + (size_t)(w.coff[c + 1] - w.coff[c]));
+            uint64_t at = w.coff[c];
             std::vector<uint32_t> map;
             for (SplitFile &f : res) {
                 SplitFile::Cols &q = f.cols[c];
                 map.resize(q.barcodes.names.size());
                 for (size_t i = 0; i < map.size(); ++i) map[i] = k.barcodes.get_or_add(q.barcodes.names[i].data(), q.barcodes.names[i].size());
-                k.c.insert(k.c.end(), q.c.begin(), q.c.end());
-                k.s.insert(k.s.end(), q.s.begin(), q.s.end());
-                k.e.insert(k.e.end(), q.e.begin(), q.e.end());
+                std::copy(q.c.begin(), q.c.end(), w.c.begin() + at);
+                std::copy(q.s.begin(), q.s.end(), w.s.begin() + at);
+                std::copy(q.e.begin(), q.e.end(), w.e.begin() + at);
+                at += q.c.size();
                 for (uint32_t lb : q.b) k.b.push_back(map[lb]);
             }
         });
         for (SplitFile &f : res) reads += f.n_reads;
+        n_all += n;
+        if (n) {
+            std::lock_guard<std::mutex> lk(mu);
+            jobs.push_back(&w);
+        }
+        cv.notify_all();
         t_append += now() - t_a;
         return GTARS_OK;
     });
-    if (st) return st;
     const double t_split_done = now();
-    // ONE tokenizer call over all clusters' fragments (cluster after cluster), then every cluster regrouped by barcode
-    std::vector<uint64_t> coff(nc + 1, 0);
-    for (size_t c = 0; c < nc; ++c) coff[c + 1] = coff[c] + cl[c].c.size();
-    const uint64_t n_all = coff[nc];
-    std::vector<uint32_t> qc(n_all), qs(n_all), qe(n_all);
-    over_clusters([&](size_t c) {
-        std::copy(cl[c].c.begin(), cl[c].c.end(), qc.begin() + coff[c]);
-        std::copy(cl[c].s.begin(), cl[c].s.end(), qs.begin() + coff[c]);
-        std::copy(cl[c].e.begin(), cl[c].e.end(), qe.begin() + coff[c]);
-    });
-    std::vector<uint64_t> off(n_all + 1, 0);
-    uint32_t *ids = nullptr;
-    uint64_t h = 0;
-    st = gtars_tokenize(t->index, qc.data(), qs.data(), qe.data(), n_all, off.data(), &ids, &h);
-    if (st) return st;
+    finish_tokenizer();
+    if (st) {
+        free_waves();
+        return st;
+    }
+    for (Wave &w : waves)
+        if (w.st) {
+            const gtars_status e = w.st;
+            const std::string msg = w.err;
+            free_waves();
+            return fail(e, msg);
+        }
     const double t_tok_done = now();
+    // every cluster regrouped by barcode: its fragments' ids wave after wave (= the cluster file's line order)
     auto **arr = (gtars_fragment_tokens_t **)calloc(nc ? nc : 1, sizeof(gtars_fragment_tokens_t *));
     over_clusters([&](size_t c) {
         Cluster &k = cl[c];
-        const uint64_t n = k.c.size(), q0 = coff[c];
         const uint64_t nb = k.barcodes.names.size();
         std::vector<uint64_t> cnt(nb + 1, 0);
-        for (uint64_t i = 0; i < n; ++i) {
-            const uint64_t hits = off[q0 + i + 1] - off[q0 + i];
-            cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
-        }
+        uint64_t i = 0;
+        for (Wave &w : waves)
+            for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
+                const uint64_t hits = w.off[r + 1] - w.off[r];
+                cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
+            }
         for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
         auto *ft = (gtars_fragment_tokens_t *)calloc(1, sizeof(gtars_fragment_tokens_t));
         ft->n_barcodes = nb;
@@ -2461,21 +2526,24 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
         memcpy(ft->offsets, cnt.data(), (nb + 1) * sizeof(uint64_t));
         for (uint64_t b = 0; b < nb; ++b) ft->barcodes[b] = dup_cstr(k.barcodes.names[b]);
         std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
-        for (uint64_t i = 0; i < n; ++i) {
-            uint64_t &w = fill[k.b[i]];
-            if (off[q0 + i + 1] == off[q0 + i])
-                ft->ids[w++] = t->unk_id;
-            else
-                for (uint64_t x = off[q0 + i]; x < off[q0 + i + 1]; ++x) ft->ids[w++] = ids[x];
-        }
+        i = 0;
+        for (Wave &w : waves)
+            for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
+                uint64_t &at = fill[k.b[i]];
+                if (w.off[r + 1] == w.off[r])
+                    ft->ids[at++] = t->unk_id;
+                else
+                    for (uint64_t x = w.off[r]; x < w.off[r + 1]; ++x) ft->ids[at++] = w.ids[x];
+            }
         arr[c] = ft;
     });
-    gtars_free(ids);
+    free_waves();
     *out = arr;
     if (n_reads) *n_reads = reads;
     if (timing)
-        fprintf(stderr, "[gtars host timing] fragsplit_tokenize: %zu files, gunzip + parse + route %.3f s, per-cluster append %.3f s, tokenize (one call, %llu fragments) %.3f s, regroup of %zu clusters %.3f s\n",
-                files.size(), t_split_done - t_begin - t_append, t_append, (unsigned long long)n_all, t_tok_done - t_split_done, nc, now() - t_tok_done);
+        fprintf(stderr, "[gtars host timing] fragsplit_tokenize: %zu files in %zu wave(s), gunzip + parse + route %.3f s, per-cluster append %.3f s, tokenizer calls %.3f s (of which %.3f s after the last wave was parsed; %llu fragments), regroup of %zu clusters %.3f s\n",
+                files.size(), waves.size(), t_split_done - t_begin - t_append, t_append, t_tok, t_tok_done - t_split_done,
+                (unsigned long long)n_all, nc, now() - t_tok_done);
     return GTARS_OK;
 }
 
