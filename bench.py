@@ -593,6 +593,19 @@ def bench_lola_config4(dev, stream, n_sets=LOLA4["n_sets"], per_set=LOLA4["per_s
     return out
 
 
+def _usable_host_threads() -> int:
+    """hardware threads this process may use: affinity mask and the container's CPU quota (what the library's host pipelines
+    start at most -- csrc/host.cpp, host_thread_budget)"""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    quota = _cpu_max().split()
+    if len(quota) == 2 and quota[0].isdigit() and int(quota[1]) > 0:
+        avail = min(avail, max(1, -(-int(quota[0]) // int(quota[1]))))
+    return avail
+
+
 def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
     """BASELINE config 5 at the config's PER-FILE size (1e5 fragments, 500 barcodes: SURVEY 8d C5) and a reduced file count (the
     config names 10,000 files on 8 GPUs; files are independent, so per-file cost is what scales): gzip'd fragment files ->
@@ -629,7 +642,7 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
         ids_fused = sum(int(v[1][-1]) for v in fused.values())
         n = files * frags
         out = {"files": files, "fragments_per_file": frags, "fragments": n, "clusters": m.n_clusters(),
-               "input_gz_MB": round(gz_bytes / 1e6, 1), "gen_s": round(t_gen, 1), "host_threads": os.cpu_count(),
+               "input_gz_MB": round(gz_bytes / 1e6, 1), "gen_s": round(t_gen, 1), "host_threads": _usable_host_threads(), "host_logical_cores": os.cpu_count(),
                "scale_note": f"{files} files x {frags} fragments = {n} of the config's 1e9 fragments (1/{round(1e9 / n)}); one GPU",
                "routed_fragments": st["written"], "token_ids": ids_fused,
                "host_gunzip_parse": {"s": round(t_parse, 3), "fragments_per_s": round(n_parsed / t_parse), "note": "gtars_fragments_read, one file at a time"},
