@@ -2117,7 +2117,58 @@ gtars_status list_regular_files(const std::string &dir, std::vector<std::string>
 struct gtars_barcode_map {
     std::unordered_map<std::string, uint32_t, SvHash> map;  // "stem+barcode" -> cluster index (into labels)
     std::vector<std::string> labels;                        // byte order
+    // the keys in byte order (pointers into `map`: node keys do not move): the keys of ONE fragment file -- those that start
+    // with "stem+" -- are a range of it, which split_one_file turns into a small per-file table keyed by the barcode alone
+    std::vector<std::pair<const std::string *, uint32_t>> sorted;
+    void index_keys() {
+        sorted.clear();
+        sorted.reserve(map.size());
+        for (const auto &kv : map) sorted.emplace_back(&kv.first, kv.second);
+        std::sort(sorted.begin(), sorted.end(), [](const auto &a, const auto &b) { return *a.first < *b.first; });
+    }
 };
+
+namespace {
+// barcode -> (cluster, id of the barcode among its cluster's barcodes in this file, in first-seen order) for ONE fragment file:
+// what "{stem}+{barcode}" resolves to in the map (split.rs:100-106), looked up by the barcode's bytes alone.  A few hundred
+// entries that stay in the parsing core's cache, where the map of a 10,000-file folder (4M keys) is a cache miss per line; and
+// one lookup per line instead of two (cluster, then barcode id).
+struct FileBarcodes {
+    struct Entry {
+        const char *bc = nullptr;
+        uint32_t n = 0, cluster = 0, local = 0xFFFFFFFFu;
+    };
+    std::vector<Entry> slots;
+    size_t mask = 0;
+    void build(const gtars_barcode_map &m, const std::string &prefix) {  // prefix = stem + "+"
+        auto lo = std::lower_bound(m.sorted.begin(), m.sorted.end(), prefix,
+                                   [](const auto &a, const std::string &p) { return *a.first < p; });
+        auto hi = lo;
+        while (hi != m.sorted.end() && hi->first->size() >= prefix.size() && hi->first->compare(0, prefix.size(), prefix) == 0) ++hi;
+        size_t cap = 16;
+        while (cap < (size_t)(hi - lo) * 2) cap <<= 1;
+        slots.assign(cap, Entry());
+        mask = cap - 1;
+        for (auto it = lo; it != hi; ++it) {
+            Entry e;
+            e.bc = it->first->data() + prefix.size();
+            e.n = (uint32_t)(it->first->size() - prefix.size());
+            e.cluster = it->second;
+            size_t k = ViewDict::hash(e.bc, e.n) & mask;
+            while (slots[k].bc) k = (k + 1) & mask;
+            slots[k] = e;
+        }
+    }
+    Entry *find(const char *p, size_t n) {
+        size_t k = ViewDict::hash(p, n) & mask;
+        while (slots[k].bc) {
+            if (slots[k].n == n && memcmp(slots[k].bc, p, n) == 0) return &slots[k];
+            k = (k + 1) & mask;
+        }
+        return nullptr;
+    }
+};
+}  // namespace
 
 extern "C" {
 
@@ -2166,6 +2217,7 @@ gtars_status gtars_barcode_map_from_file(const char *path, gtars_barcode_map_t *
     for (uint32_t i = 0; i < m->labels.size(); ++i) lid[m->labels[i]] = i;
     m->map.reserve(rows.size() * 2);
     for (auto &r : rows) m->map[r.first] = lid[r.second];  // HashMap::insert: the later line wins
+    m->index_keys();
     *out = m.release();
     return GTARS_OK;
 }
@@ -2216,9 +2268,8 @@ void split_one_file(const std::string &path, const gtars_barcode_map &m, bool wa
     const char *lc = nullptr;  // the last chromosome name looked up (fragment files are sorted: it rarely changes)
     size_t lcn = 0;
     uint32_t lcid = 0;
-    const std::string stem = remove_all_extensions(path);
-    std::string key = stem + "+";
-    const size_t key0 = key.size();
+    FileBarcodes mine;
+    mine.build(m, remove_all_extensions(path) + "+");
     const char *p = out.data.data(), *end = p + out.data.size();
     size_t index = 0;
     while (p < end) {
@@ -2241,11 +2292,8 @@ void split_one_file(const std::string &path, const gtars_barcode_map &m, bool wa
             out.err = "Failed to parse fragments file at line " + std::to_string(index) + ": " + std::string(p, (size_t)(le - p));
             return;
         }
-        key.resize(key0);
-        key.append(f[3], fl[3]);
-        auto it = m.map.find(key);
-        if (it != m.map.end()) {  // else: most likely a cell dropped in QC
-            const uint32_t cl = it->second;
+        if (FileBarcodes::Entry *hit = mine.find(f[3], fl[3])) {  // else: most likely a cell dropped in QC
+            const uint32_t cl = hit->cluster;
             if (want_text) {
                 std::string &t = out.text[cl];
                 for (int k = 0; k < 5; ++k) {
@@ -2270,7 +2318,11 @@ void split_one_file(const std::string &path, const gtars_barcode_map &m, bool wa
                 k.c.push_back(lcid);
                 k.s.push_back(rs);
                 k.e.push_back(re);
-                k.b.push_back(k.barcodes.get_or_add(f[3], fl[3]));
+                if (hit->local == 0xFFFFFFFFu) {  // the barcode's first line in this file
+                    hit->local = (uint32_t)k.barcodes.names.size();
+                    k.barcodes.names.emplace_back(f[3], fl[3]);
+                }
+                k.b.push_back(hit->local);
             }
             ++out.n_written;
         }
@@ -2385,8 +2437,11 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
     // one wave's routed fragments as tokenizer input, cluster after cluster, and what the tokenizer made of them
     struct Wave {
         std::vector<uint64_t> coff;     // [n_clusters + 1]
-        std::vector<uint32_t> c, s, e;
-        std::vector<uint64_t> off;      // [fragments + 1]
+        uint64_t n = 0;                 // fragments
+        // columns and CSR offsets [n + 1]: plain allocations -- a std::vector would zero 20 bytes per fragment on the thread that
+        // sits between two waves (10 waves of 2.4M fragments: 60 of the 100 ms that stage took)
+        std::unique_ptr<uint32_t[]> c, s, e;
+        std::unique_ptr<uint64_t[]> off;
         uint32_t *ids = nullptr;
         gtars_status st = GTARS_OK;
         std::string err;
@@ -2427,7 +2482,7 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
             }
             const double t0 = now();
             uint64_t h = 0;
-            w->st = gtars_tokenize(t->index, w->c.data(), w->s.data(), w->e.data(), w->c.size(), w->off.data(), &w->ids, &h);
+            w->st = gtars_tokenize(t->index, w->c.get(), w->s.get(), w->e.get(), w->n, w->off.get(), &w->ids, &h);
             if (w->st) w->err = gtars_last_error();
             t_tok += now() - t0;
         }
@@ -2457,11 +2512,12 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
             for (SplitFile &f : res) add += f.cols[c].c.size();
             w.coff[c + 1] = w.coff[c] + add;
         }
-        const uint64_t n = w.coff[nc];
-        w.c.resize(n);
-        w.s.resize(n);
-        w.e.resize(n);
-        w.off.assign(n + 1, 0);
+        const uint64_t n = w.n = w.coff[nc];
+        w.c.reset(new uint32_t[n + 1]);
+        w.s.reset(new uint32_t[n + 1]);
+        w.e.reset(new uint32_t[n + 1]);
+        w.off.reset(new uint64_t[n + 1]);
+        w.off[0] = 0;  // (a wave without routed fragments is not sent to the tokenizer)
         // the wave's files, in file order, behind every cluster: column copies; the file-local barcode ids mapped through the
         // cluster's dictionary (one lookup per distinct barcode of a file, in its first-seen order, so the cluster's order is
         // what one pass over the cluster file would see)
@@ -2474,9 +2530,9 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
                 SplitFile::Cols &q = f.cols[c];
                 map.resize(q.barcodes.names.size());
                 for (size_t i = 0; i < map.size(); ++i) map[i] = k.barcodes.get_or_add(q.barcodes.names[i].data(), q.barcodes.names[i].size());
-                std::copy(q.c.begin(), q.c.end(), w.c.begin() + at);
-                std::copy(q.s.begin(), q.s.end(), w.s.begin() + at);
-                std::copy(q.e.begin(), q.e.end(), w.e.begin() + at);
+                std::copy(q.c.begin(), q.c.end(), w.c.get() + at);
+                std::copy(q.s.begin(), q.s.end(), w.s.get() + at);
+                std::copy(q.e.begin(), q.e.end(), w.e.get() + at);
                 at += q.c.size();
                 for (uint32_t lb : q.b) k.b.push_back(map[lb]);
             }
