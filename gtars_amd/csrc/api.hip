@@ -314,7 +314,7 @@ struct gtars_index {
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
     // blocked acceleration structure (Bits kind), see AccelView in common.h
     DevBuf<u32> acc_rec2, acc_rec4, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab, acc_idc, acc_idc_pos, acc_chrom_iv_end;
-    bool acc_ids_affine = false, acc_ends_mono = false;
+    bool acc_ids_affine = false, acc_ends_mono = false, acc_runs_ok = false;
     u32 acc_n_blocks = 0, acc_n_units = 0, acc_n_buckets = 0, acc_lut_words = 0, acc_q_words = 0;
     u32 acc_lut_shift = 0, acc_q_shift = 0, acc_search_top = 0, acc_top_shift = 0;
     bool has_accel = false;
@@ -353,7 +353,8 @@ struct gtars_index {
         a.top_shift = acc_top_shift;
         a.n_chrom = n_chrom;
         a.max_chrom_n = max_chrom_n();
-        a.ends_mono = acc_ends_mono && !cfg_flag("GTARS_TOK_NO_RUNS") ? 1u : 0u;  // (the switch: tests and A/B runs of the tail walk)
+        a.runs_ok = acc_runs_ok && !cfg_flag("GTARS_TOK_NO_RUNS") ? 1u : 0u;  // (the switch: tests and A/B runs of the tail walk)
+        a.ends_mono = a.runs_ok && acc_ends_mono ? 1u : 0u;
         a.chrom_iv_end = acc_chrom_iv_end.p;
         return a;
     }
@@ -879,18 +880,20 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
         if (!affine) h_rec4.assign((size_t)nb * 16, 0);
         h_blk_first.assign(nb, 0xFFFFFFFFu);
         std::vector<u64> chrom_span(n_chrom, 0);  // max end + 1 (0: no intervals)
-        // AccelView::ends_mono / chrom_iv_end: do the ends ascend with the starts everywhere (and no interval is inverted)?
-        bool mono = true;
+        // AccelView::runs_ok / ends_mono / chrom_iv_end: is no interval inverted; do the ends ascend with the starts everywhere?
+        bool mono = true, upright = true;
         h_iv_end.assign(n_chrom, 0);
         for (u32 c = 0; c < n_chrom; ++c) {
             u32 real = 0;
             for (u32 p = off[c]; p < off[c + 1]; ++p) {
-                if (ix->h_starts[p] > ix->h_ends[p] || (p > off[c] && ix->h_ends[p] < ix->h_ends[p - 1])) mono = false;
+                if (ix->h_starts[p] > ix->h_ends[p]) upright = false;
+                if (p > off[c] && ix->h_ends[p] < ix->h_ends[p - 1]) mono = false;
                 if (ix->h_starts[p] != 0xFFFFFFFFu) real = p - off[c] + 1;
             }
             h_iv_end[c] = (u32)ACC_OWN * h_cblk[c] + real;
         }
-        ix->acc_ends_mono = mono;
+        ix->acc_runs_ok = upright;
+        ix->acc_ends_mono = mono && upright;
         for (u32 c = 0; c < n_chrom; ++c) {
             u32 pm = 0;  // prefix max of the ends, in (start, end) order
             for (u32 b = h_cblk[c]; b < h_cblk[c + 1]; ++b) {

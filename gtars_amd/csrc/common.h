@@ -121,11 +121,15 @@ struct AccelView {
     u32 n_chrom;
     u32 ids_affine;
     u32 max_chrom_n;  // most intervals on one chromosome: bounds a query's hits (tile totals are 32-bit)
-    // 1: on every chromosome the ends ascend with the starts and no interval is inverted (start <= end) -- disjoint universes, what
-    // consensus peak sets are.  A query's hits are then ONE run of stored positions (first interval that ends after q_start ..
-    // last that starts before q_end): the tail of a wide query is measured by a second search instead of walked (tail_run,
-    // tokenize_lds.hip).  chrom_iv_end[c] = ACC_OWN * first block of c + intervals of c that start below 0xFFFFFFFF.
-    u32 ends_mono;
+    // Run form of wide queries (tail_run, tokenize_lds.hip): the intervals behind a query's first record that start before q_end
+    // are ALL hits -- one run of stored positions, measured by a second search instead of walked -- whenever they all end after
+    // q_start, which holds
+    //   runs_ok   (no interval of the index is inverted, start <= end) and the record's fourth interval starts after q_start
+    //             (everything behind it then starts, hence ends, after q_start): any universe, most wide queries; or
+    //   ends_mono (on every chromosome the ends also ascend with the starts: disjoint universes, what consensus peak sets are)
+    //             and the first record has a hit (everything behind a hit then ends after q_start as well).
+    // chrom_iv_end[c] = ACC_OWN * first block of c + intervals of c that start below 0xFFFFFFFF.
+    u32 runs_ok, ends_mono;
     const u32 *chrom_iv_end;
 };
 

@@ -124,6 +124,7 @@ __device__ __forceinline__ u32 run_state(u32 n, u32 m) { return (n & B0_MASK) | 
 #define GTARS_TOK_STAGE_RUNS 1  // 1: the early staging of round 0 (stage_queries) emits run-form queries itself; 0: see there
 #endif
 constexpr u32 RUN_FLAG_BIT = 8;  // TileQ::more_bits: some query of the lane's round is in run form
+constexpr u32 RUN_Q_BIT = 4;     // ... bit RUN_Q_BIT + j: query j is (its state word holds the hit count, not the block)
 __device__ __forceinline__ u32 run_state_n(u32 st) { return (st & B0_MASK) | ((st >> (B0_BITS + 4)) << B0_BITS); }
 
 // Tail of a query whose scan runs past block b0's look-ahead intervals (rare).  Record b holds intervals
@@ -281,18 +282,22 @@ __host__ __device__ __forceinline__ size_t tok_lds_bytes(const AccelView &a) {
     return ((size_t)a.lut_words + a.q_words + 4 * (size_t)a.n_chrom + (((size_t)a.n_chrom + 3) & ~(size_t)3)) * sizeof(u32);
 }
 
-// Tail of a wide query on an index whose ends ascend with the starts (AccelView::ends_mono): the query's hits are one run of
-// stored positions, so the tail is MEASURED, not walked -- a second LDS search, for q_end, finds the first block whose largest
-// end is >= q_end (every interval in front of it ends, hence starts, before q_end), and that block's starts give the run's end.
-// Returns the number of intervals at padded position >= ACC_OWN * b0 + 4 that start before q_end -- what walk_tail counts when
-// the first record has a hit (every later interval then ends after q_start too).  33 ids per query: the walk was 8 dependent
-// record loads per lane, twice (count phase and write phase).
+// Tail of a wide query in RUN FORM (run_form below; AccelView::runs_ok / ends_mono): the query's hits are one run of stored
+// positions, so the tail is MEASURED, not walked -- a second LDS search, for q_end, finds the first block whose key (the largest
+// end so far) is >= q_end: every interval in front of it ends, hence starts (no interval is inverted), before q_end; from there
+// the blocks' starts give the run's end.  On a universe of disjoint intervals that is the block found or its neighbour; a wide
+// interval in front makes the key run ahead of the starts, and the run's end lies further on: the blocks are stepped through,
+// one 16-byte load each (never more steps than the tail has blocks -- what the walk would load twice over -- and the write
+// phase still needs none).
+// Returns the number of intervals at padded position >= ACC_OWN * b0 + 4 that start before q_end -- what walk_tail counts for
+// such a query.  33 ids per query: the walk was 8 dependent record loads per lane, twice (count phase and write phase).
 template <u32 STRIDE>
 __device__ __forceinline__ u32 tail_run(const AccelView &a, const SearchLds &L, const uint4 *__restrict__ recs, u32 c, u32 b0, u32 be,
                                         u32 qe) {
     const u32 sq = qe - 1u;  // (a query with a tail has q_end > the fourth start >= 0)
     u32 B, BE;
     search_blocks<1>(a, L.lut, L.q, L.ctab, &c, &sq, &B, &BE);
+    B = B > b0 + 1u ? B : b0 + 1u;  // (the record of b0 + 1 holds the tail's first two intervals)
     u32 last;
     for (;;) {
         if (B >= be) {  // q_end lies beyond the chromosome's largest end
@@ -308,10 +313,17 @@ __device__ __forceinline__ u32 tail_run(const AccelView &a, const SearchLds &L, 
             last = (u32)ACC_OWN * B + (S.x < qe ? 1u : 0u) + (S.y < qe ? 1u : 0u);
             break;
         }
-        ++B;  // (floor-quantised keys: the block found may lie a block early)
+        ++B;  // (floor-quantised keys, or a key that runs ahead of the starts)
     }
     const u32 first_tail = (u32)ACC_OWN * b0 + 4u;
     return last > first_tail ? last - first_tail : 0u;
+}
+// Is a query with a tail, first-record hit mask m and fourth start s3 in run form?  Its first record's hits must reach up to the
+// fourth interval without a gap (so that they and the tail are ONE run of ids), and every interval of the tail must end after
+// q_start: because the fourth interval already starts after q_start (any universe without inverted intervals), or because
+// the ends ascend with the starts and the record has a hit (disjoint universes).
+__device__ __forceinline__ bool run_form(const AccelView &a, u32 m, u32 s3, u32 qs) {
+    return a.runs_ok && m && (m + (m & (0u - m))) == 16u && (s3 > qs || a.ends_mono);
 }
 #ifndef GTARS_TOK_RUNS
 #define GTARS_TOK_RUNS 5  // 1: tails of wide queries measured (tail_run), 4: their ids leave by wave-wide stores (experiments: subsets)
@@ -486,7 +498,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
             const bool more = act[p][k] && (S[p][k].w < qe_) && (b0[p][k] + 2 < be[p][k]);
             u32 n = __popc(m);
             if (more) {
-                if ((GTARS_TOK_RUNS & 1) && !FILTER && a.ends_mono && m)
+                if ((GTARS_TOK_RUNS & 1) && !FILTER && run_form(a, m, S[p][k].w, qs_))
                     pend |= 1u << (r * QPT + j);  // run form: the tail is measured below, by the ONE copy of tail_run
                 else
                     n += walk_tail<FILTER, STRIDE>(recs, b0[p][k], be[p][k], qs_, qe_, min_bp, [](u32, int) {});
@@ -542,9 +554,12 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 tsum[r] += (k / QPT == (u32)r) ? nt : 0u;
-                if (IMPL) t[r].more_bits |= (k / QPT == (u32)r) ? 1u << RUN_FLAG_BIT : 0u;
 #pragma unroll
-                for (int j = 0; j < QPT; ++j) t[r].st[j] = k == (u32)(r * QPT + j) ? nst : t[r].st[j];
+                for (int j = 0; j < QPT; ++j) {
+                    const bool me = k == (u32)(r * QPT + j);
+                    t[r].st[j] = me ? nst : t[r].st[j];
+                    if (IMPL) t[r].more_bits |= me ? (1u << RUN_FLAG_BIT) | (1u << (RUN_Q_BIT + j)) : 0u;
+                }
             }
         }
     }
@@ -554,7 +569,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
 // `want_ids`, o4[j] = position of query j's first hit; `run` = position of the lane's first hit.
 // REV: a query's hits leave in DESCENDING stored order (AIList::find, ailist.rs:238-263): the i-th hit of the forward
 // scan goes to slot n - 1 - i of the query's n.
-// Run form (ids that follow from the position, no min-overlap filter, AccelView::ends_mono): a wide query's ids are id0, id0 + 1,
+// Run form (ids that follow from the position, no min-overlap filter; run_form above): a wide query's ids are id0, id0 + 1,
 // ... -- nothing is walked; with `defer` (the wave's ids go straight to memory) a query of >= COOP_MIN ids is not emitted here:
 // the caller writes it with the whole wave (coop_runs).
 template <int QPT, bool FILTER, bool IMPL, bool REV, bool RUNFORM, class Put>
@@ -572,7 +587,7 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
         u32 m = (t.st[j] >> B0_BITS) & 15u;
         const bool more = (t.more_bits & (1u << j)) != 0;
         if constexpr (RUNFORM && IMPL && !FILTER && (GTARS_TOK_RUNS & 1)) {
-            if (more && a.ends_mono && m) {  // run form (count_rounds): the state word holds the hit count
+            if (t.more_bits & (1u << (RUN_Q_BIT + j))) {  // run form (count_rounds): the state word holds the hit count
                 const u32 n_run = run_state_n(t.st[j]);
                 if (want_ids && !((GTARS_TOK_RUNS & 4) && defer && n_run >= COOP_MIN)) {  // (deferred: coop_runs)
                     const u32 id0 = t.aux[j] + (u32)(__ffs((int)m) - 1);
@@ -663,7 +678,7 @@ __device__ __forceinline__ void coop_runs(const TileQ<QPT, true> &t, const u64 (
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
         const u32 m = (t.st[j] >> B0_BITS) & 15u, n = run_state_n(t.st[j]);
-        const bool big = ((t.more_bits >> j) & 1u) && m && n >= COOP_MIN;
+        const bool big = ((t.more_bits >> (RUN_Q_BIT + j)) & 1u) && n >= COOP_MIN;
         S[j] = (u32)(o4[j] - wave_base);
         N[j] = big ? n : 0u;
         const u32 id0 = t.aux[j] + (u32)(__ffs((int)(m | 16u)) - 1);
@@ -737,7 +752,7 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
             ovals[pos] = id;
     });
     if constexpr (IMPL && !FILTER && (GTARS_TOK_RUNS & 4) != 0) {
-        if (!staged && cap && a.ends_mono && !(GTARS_TOK_ABLATE & (2 | 128))) coop_runs<QPT, REV>(t, o4, wave_base, ovals, cap, lane);
+        if (!staged && cap && a.runs_ok && !(GTARS_TOK_ABLATE & (2 | 128))) coop_runs<QPT, REV>(t, o4, wave_base, ovals, cap, lane);
     }
     if (staged && !(GTARS_TOK_ABLATE & 2)) {
         // the wave's ids, contiguous: 256 bytes per store instruction (LDS operations of a wave execute in order)
@@ -1188,7 +1203,7 @@ k_count_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
                 const u32 m = act[j] ? block_mask4<FILTER>(S[j], E[j], s[j], e[j], min_bp) : 0u;
                 n[j] = __popc(m);
                 if (act[j] && S[j].w < e[j] && b0[j] + 2 < be[j])
-                    n[j] += (!FILTER && a.ends_mono && m) ? tail_run<2>(a, L, a.rec2, c[j], b0[j], be[j], e[j])
+                    n[j] += (!FILTER && run_form(a, m, S[j].w, s[j])) ? tail_run<2>(a, L, a.rec2, c[j], b0[j], be[j], e[j])
                                                           : walk_tail<FILTER, 2>(a.rec2, b0[j], be[j], s[j], e[j], min_bp, [](u32, int) {});
             }
 #pragma unroll

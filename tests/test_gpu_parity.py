@@ -875,6 +875,41 @@ def test_wide_queries_on_disjoint_universes_take_the_run_form(ga, monkeypatch, k
     assert g.count_overlaps(qc, qs, qe).tolist() == o.count_overlaps(qc, qs, qe).tolist()
 
 
+@pytest.mark.parametrize("kind", BOTH)
+def test_wide_queries_on_overlapping_universes(ga, monkeypatch, kind):
+    """The run form without ascending ends: a ChIP-like universe (overlapping neighbours, 1 % intervals of 5-100 kbp: the search
+    key runs ahead of the starts, the run's end is found by stepping), wide queries whose first record has holes in its hit mask,
+    and a chromosome with an interval that covers all of it (every tail is stepped through block by block) -- against the oracle
+    and against the walked form."""
+    from gtars_amd import synth
+
+    u = synth.make_universe(30_000, overlapping=True)
+    rng = np.random.default_rng(5)
+    order = np.lexsort((u["start"], u["chrom"]))  # (a sorted universe file: ids follow from the position)
+    C_, S, E = u["chrom"][order], u["start"][order].copy(), u["end"][order].copy()
+    # chromosome 3: one interval over the whole chromosome, in front
+    k = np.flatnonzero(C_ == 3)
+    S[k[0]] = 0; E[k[0]] = int(E[k].max()) + 10
+    g, o = _pair(ga, C_, S, E, n_chrom=synth.N_CHROM, kind=kind)
+    nq = 60_000
+    qc = rng.integers(0, synth.N_CHROM, nq)
+    span = np.array([int(E[C_ == c].max()) if (C_ == c).any() else 1000 for c in range(synth.N_CHROM)])
+    qs = (rng.random(nq) * span[qc]).astype(np.int64)
+    qe = qs + np.where(rng.random(nq) < 0.5, rng.integers(0, 800, nq), rng.integers(20_000, 3_000_000, nq))
+    qc[:300] = 3  # enough queries on the covered chromosome
+    _assert_same_queries(g, o, qc[:8000], qs[:8000], qe[:8000], min_overlaps=(None, 1, 200))
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    assert len(ids_o) > 4 * nq
+    for rounds, groups in (("1", "1"), ("2", "2")):
+        monkeypatch.setenv("GTARS_TOK_ROUNDS", rounds)
+        monkeypatch.setenv("GTARS_TOK_GROUPS", groups)
+        off_g, ids_g = g.tokenize(qc, qs, qe)
+        assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o), (rounds, groups)
+    monkeypatch.setenv("GTARS_TOK_NO_RUNS", "1")
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+
+
 @pytest.mark.parametrize("top_max", ["64", "600"])
 def test_run_form_with_padded_units(ga, monkeypatch, top_max):
     """the same with several blocks per search unit (GTARS_TOP_MAX: the chromosomes' block ranges are padded to whole units, a
