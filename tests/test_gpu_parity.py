@@ -910,6 +910,43 @@ def test_wide_queries_on_overlapping_universes(ga, monkeypatch, kind):
     assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
 
 
+@pytest.mark.parametrize("kind", BOTH)
+def test_wide_queries_with_a_short_id_buffer(ga, kind):
+    """gtars_tokenize_device with fewer id slots than the batch has hits (hit-heavy batch, wave-wide stores): the offsets and the
+    total are complete, the ids up to the capacity are right, nothing is written behind it -- at capacities that cut a wave's
+    region, a run and a 256-byte piece in the middle, and at capacity 0 (offsets only)."""
+    import torch
+
+    rng = np.random.default_rng(123)
+    n_chrom, span = 3, 3_000_000
+    C_, S, E = _disjoint_universe(rng, n_chrom, 7_000, span)
+    g, o = _pair(ga, C_, S, E, n_chrom=n_chrom, kind=kind)
+    qc, qs, qe = _wide_queries(rng, n_chrom, span, 40_000, typical=30_000)
+    qc = np.where(qc >= n_chrom, 0, qc)
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    total = len(ids_o)
+    assert total > 30 * len(qc)
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint32).view(np.int32)).to(dev) for x in (qc, qs, qe)]
+    GUARD = 4096
+    for cap in (0, 1, 63, 64, 1000, total // 3 + 17, total - 1, total, total + 5):
+        off = torch.zeros(len(qc) + 1, dtype=torch.int64, device=dev)
+        ids = torch.full((cap + GUARD,), -7, dtype=torch.int32, device=dev)
+        args = (d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(qc), off.data_ptr(), ids.data_ptr() if cap else 0, cap)
+        if 0 < cap < total:  # the call reports the shortfall (status 4, "need <total>") after everything else is in place
+            from gtars_amd._lib import CapacityError
+
+            with pytest.raises(CapacityError, match=str(total)):
+                g.tokenize_device(*args)
+        else:
+            assert g.tokenize_device(*args) == total
+        assert np.array_equal(off.cpu().numpy().view(np.uint64), off_o)
+        got = ids.cpu().numpy()
+        k = min(cap, total)
+        assert np.array_equal(got[:k].view(np.uint32), ids_o[:k]), cap
+        assert (got[k:] == -7).all(), cap
+
+
 @pytest.mark.parametrize("top_max", ["64", "600"])
 def test_run_form_with_padded_units(ga, monkeypatch, top_max):
     """the same with several blocks per search unit (GTARS_TOP_MAX: the chromosomes' block ranges are padded to whole units, a
