@@ -848,6 +848,32 @@ def test_fragsplit_tokenize_pipeline_equals_two_step(tk, golden_dir, tmp_path):
 
 # ------------------------------------------------------------ LOLA universe helpers (gtars-lola/src/universe.rs:154-301)
 
+def test_config5_at_the_per_file_size_against_the_compiled_restatement(tmp_path):
+    """BASELINE config 5 at the config's per-file size -- 1e5 fragments and 500 barcodes per file, 40 files: more
+    than one wave of the host pipeline on the test box, so the tokenizer calls overlap the parsing -- against the compiled C
+    restatement of fragsplit + tokenize_fragment_file (oracle/fragsplit_oracle.c): ids, sum of ids and distinct barcodes of
+    every cluster; and the first files id by id against the Python restatement."""
+    from test_sharding_gloo import oracle_fragment_pipeline, same_cluster_results
+
+    from gtars_amd import synth
+    from gtars_amd.fragsplit import BarcodeToClusterMap, fragsplit_tokenize, fragsplit_tokenize_files, list_fragment_files
+    from gtars_amd.tokenizers import Tokenizer
+
+    u = synth.make_universe(100_000)
+    ub, fd, mp, _ = synth.write_config5_inputs(str(tmp_path), u, 40, 100_000, 20)
+    tok, m = Tokenizer.from_bed(ub), BarcodeToClusterMap.from_file(mp)
+    om, otok = oracle.OracleBarcodeMap(mp), oracle.OracleTokenizer(ub)
+    paths = list_fragment_files(fd)
+    got = fragsplit_tokenize(fd, m, tok, as_arrays=True)
+    exp = oracle.fragsplit_tokenize_compiled(paths, om, otok)
+    assert sorted(got) == sorted(exp)
+    for label, (names, offs, ids) in got.items():
+        assert (int(offs[-1]), int(ids.astype(np.uint64).sum()), len(names)) == exp[label], label
+    assert sum(v[0] for v in exp.values()) > 3_000_000
+    few = paths[:2]
+    assert same_cluster_results(fragsplit_tokenize_files(few, m, tok, as_arrays=True), oracle_fragment_pipeline(few, om, otok))
+
+
 
 def test_lola_universe_helpers_kats():
     from gtars_amd.lola import check_universe, redefine_user_sets
