@@ -874,6 +874,46 @@ def test_config5_at_the_per_file_size_against_the_compiled_restatement(tmp_path)
     assert same_cluster_results(fragsplit_tokenize_files(few, m, tok, as_arrays=True), oracle_fragment_pipeline(few, om, otok))
 
 
+def test_fused_fragment_pipeline_errors_between_waves(tk, golden_dir, tmp_path, monkeypatch):
+    """The fused pipeline with two host threads (waves of four files, the tokenizer calls on their helper thread): a malformed
+    line in a LATER wave ends the call with the reference's error while an earlier wave is on the GPU -- no hang, nothing
+    leaked into the next call, which returns the full result again."""
+    import gzip
+
+    from gtars_amd.fragsplit import BarcodeToClusterMap, fragsplit_tokenize
+
+    monkeypatch.setenv("GTARS_HOST_THREADS", "2")
+    tk = tk("peaks.bed")
+    peaks = [l.split()[:3] for l in open(os.path.join(golden_dir, "tokenizers", "peaks.bed")) if l.strip()]
+    rng = np.random.default_rng(11)
+    fd = tmp_path / "frags"
+    fd.mkdir()
+    lines_map = []
+    for fi in range(11):
+        with gzip.open(fd / f"f{fi:02d}.bed.gz", "wt") as f:
+            for _ in range(2000):
+                c, s, e = peaks[int(rng.integers(0, len(peaks)))]
+                f.write(f"{c}\t{int(s) + int(rng.integers(0, 50))}\t{int(e) + 5}\tBC{int(rng.integers(0, 9))}\t1\n")
+        lines_map += [f"f{fi:02d}+BC{b}\tk{(fi + b) % 3}" for b in range(9)]
+    mp = tmp_path / "map.tsv"
+    mp.write_text("\n".join(lines_map) + "\n")
+    m = BarcodeToClusterMap.from_file(str(mp))
+    good = fragsplit_tokenize(str(fd), m, tk, as_arrays=True)
+    assert sum(int(v[1][-1]) for v in good.values()) >= 11 * 2000
+    with gzip.open(fd / "f09.bed.gz", "at") as f:  # (third wave) a routed line whose start is not a number
+        f.write("chr1\tx12\t30\tBC1\t1\n")
+    with pytest.raises(RuntimeError, match="Failed to parse start position of a routed fragment"):
+        fragsplit_tokenize(str(fd), m, tk)
+    with gzip.open(fd / "f05.bed.gz", "at") as f:  # (second wave) fewer than five fields: split.rs:84-90
+        f.write("chr1\t12\t30\tBC1\n")
+    with pytest.raises(RuntimeError, match="Failed to parse fragments file at line 2000"):
+        fragsplit_tokenize(str(fd), m, tk)
+    os.remove(fd / "f05.bed.gz")
+    os.remove(fd / "f09.bed.gz")
+    again = fragsplit_tokenize(str(fd), m, tk, as_arrays=True)
+    assert 0 < sum(int(v[1][-1]) for v in again.values()) < sum(int(v[1][-1]) for v in good.values())
+
+
 
 def test_lola_universe_helpers_kats():
     from gtars_amd.lola import check_universe, redefine_user_sets
