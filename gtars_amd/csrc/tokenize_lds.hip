@@ -329,6 +329,7 @@ __device__ __forceinline__ bool run_form(const AccelView &a, u32 m, u32 s3, u32 
 #define GTARS_TOK_RUNS 5  // 1: tails of wide queries measured (tail_run), 4: their ids leave by wave-wide stores (experiments: subsets)
 #endif
 constexpr u32 COOP_MIN = 16;  // ids of one query from which on they leave by wave-wide stores (write_queries)
+constexpr u64 WIDE_IDS_PER_QUERY = 8;  // id slots per query from which on a launch gets the kernels with the run form (launch_tokenize_lds)
 
 #ifndef GTARS_TOK_FILL_DMA
 #define GTARS_TOK_FILL_DMA 0  // 1: the LDS image is filled by global_load_lds_dwordx4 (round-4 experiment: no gain, see profiles/r04); 0: loads + ds_write_b128
@@ -438,7 +439,7 @@ __device__ __forceinline__ void load_queries(const u32 *__restrict__ qc, const u
 // and then waiting for all eight loads leaves the CU's vector-memory pipe idle during every search: 586 -> 555 us per 64M
 // queries for the two-unit split alone).
 // REV: the ids kept for the write phase are those of the LAST two hits (they are emitted first)
-template <int R, int QPT, bool FILTER, bool IMPL, bool REV>
+template <int R, int QPT, bool FILTER, bool IMPL, bool REV, int RUNS>
 __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds &L, const u32 (&c)[R][QPT], const u32 (&s)[R][QPT],
                                              const u32 (&e)[R][QPT], i32 min_bp, TileQ<QPT, IMPL> (&t)[R], u32 (&tsum)[R]) {
     static_assert(QPT == 4, "two units of two queries per round");
@@ -498,7 +499,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
             const bool more = act[p][k] && (S[p][k].w < qe_) && (b0[p][k] + 2 < be[p][k]);
             u32 n = __popc(m);
             if (more) {
-                if ((GTARS_TOK_RUNS & 1) && !FILTER && run_form(a, m, S[p][k].w, qs_))
+                if ((RUNS & 1) && !FILTER && run_form(a, m, S[p][k].w, qs_))
                     pend |= 1u << (r * QPT + j);  // run form: the tail is measured below, by the ONE copy of tail_run
                 else
                     n += walk_tail<FILTER, STRIDE>(recs, b0[p][k], be[p][k], qs_, qe_, min_bp, [](u32, int) {});
@@ -532,7 +533,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
     // Wide queries on an index whose ends ascend with the starts (run form): a lane measures its tails one after the other, the
     // query picked out of the register arrays by select chains -- inlined into finish() above, tail_run's search came eight times
     // per kernel and pushed the two-round kernels into scratch memory (60 bytes per lane; 64M C2 queries 578 -> 627 us).
-    if constexpr (!FILTER && (GTARS_TOK_RUNS & 1)) {
+    if constexpr (!FILTER && (RUNS & 1) != 0) {
         while (pend) {
             const u32 k = (u32)__ffs((int)pend) - 1u;
             pend &= pend - 1u;
@@ -572,7 +573,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
 // Run form (ids that follow from the position, no min-overlap filter; run_form above): a wide query's ids are id0, id0 + 1,
 // ... -- nothing is walked; with `defer` (the wave's ids go straight to memory) a query of >= COOP_MIN ids is not emitted here:
 // the caller writes it with the whole wave (coop_runs).
-template <int QPT, bool FILTER, bool IMPL, bool REV, bool RUNFORM, class Put>
+template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS, class Put>
 __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                              const u32 *__restrict__ qs, const u32 *__restrict__ qe, i32 min_bp,
                                              const TileQ<QPT, IMPL> &t, u64 q0, u64 run, bool want_ids, u64 (&o4)[QPT], bool defer,
@@ -586,10 +587,10 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
         const u32 b0 = t.st[j] & B0_MASK;
         u32 m = (t.st[j] >> B0_BITS) & 15u;
         const bool more = (t.more_bits & (1u << j)) != 0;
-        if constexpr (RUNFORM && IMPL && !FILTER && (GTARS_TOK_RUNS & 1)) {
+        if constexpr (IMPL && !FILTER && (RUNS & 1) != 0) {
             if (t.more_bits & (1u << (RUN_Q_BIT + j))) {  // run form (count_rounds): the state word holds the hit count
                 const u32 n_run = run_state_n(t.st[j]);
-                if (want_ids && !((GTARS_TOK_RUNS & 4) && defer && n_run >= COOP_MIN)) {  // (deferred: coop_runs)
+                if (want_ids && !((RUNS & 4) && defer && n_run >= COOP_MIN)) {  // (deferred: coop_runs)
                     const u32 id0 = t.aux[j] + (u32)(__ffs((int)m) - 1);
                     for (u32 i = 0; i < n_run; ++i) put(REV ? run + (n_run - 1u - i) : run + i, id0 + i);
                 }
@@ -735,7 +736,7 @@ __device__ __forceinline__ void coop_runs(const TileQ<QPT, true> &t, const u64 (
 // write phase: CSR offsets and token ids of the lane's QPT queries.  wave_base = global offset
 // of the wave's first id.  When the wave's ids fit the wave's LDS buffer (`stage`, stage_cap words) they are
 // compacted there and leave as contiguous stores; otherwise (and beyond the caller's capacity) one by one.
-template <int QPT, bool FILTER, bool IMPL, bool REV>
+template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS>
 __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                               const u32 *__restrict__ qs, const u32 *__restrict__ qe, u64 nq, i32 min_bp,
                                               const TileQ<QPT, IMPL> &t, u64 q0, u64 wave_base, u64 *__restrict__ offsets,
@@ -744,14 +745,14 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
     const bool staged = cap && t.wtotal <= stage_cap && wave_base + t.wtotal <= cap;
     u64 o4[QPT];
     // ids go either to the wave's LDS buffer (index relative to wave_base) or straight to memory
-    emit_queries<QPT, FILTER, IMPL, REV, true>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, !staged, [&](u64 pos, u32 id) {
+    emit_queries<QPT, FILTER, IMPL, REV, RUNS>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, !staged, [&](u64 pos, u32 id) {
         if (GTARS_TOK_ABLATE & 2) return;
         if (staged)
             stage[(u32)(pos - wave_base)] = id;
         else if (pos < cap)
             ovals[pos] = id;
     });
-    if constexpr (IMPL && !FILTER && (GTARS_TOK_RUNS & 4) != 0) {
+    if constexpr (IMPL && !FILTER && (RUNS & 4) != 0) {
         if (!staged && cap && a.runs_ok && !(GTARS_TOK_ABLATE & (2 | 128))) coop_runs<QPT, REV>(t, o4, wave_base, ovals, cap, lane);
     }
     if (staged && !(GTARS_TOK_ABLATE & 2)) {
@@ -774,7 +775,7 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
 // go to the wave's LDS buffer at wave-relative positions while wave 0 is still busy with the look-back (the other
 // waves would only wait for it), and once the base is there the buffer is flushed and the offsets are stored.
 // stage_queries returns false when the wave's ids do not fit the buffer (write_queries then serves the round).
-template <int QPT, bool FILTER, bool IMPL, bool REV>
+template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS>
 __device__ __forceinline__ bool stage_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                               const u32 *__restrict__ qs, const u32 *__restrict__ qe, i32 min_bp,
                                               const TileQ<QPT, IMPL> &t, u64 q0, u64 cap, u32 *stage, u32 stage_cap,
@@ -784,10 +785,10 @@ __device__ __forceinline__ bool stage_queries(const AccelView &a, const SearchLd
     // the two copies of this early staging carry no run-form code -- 4 KB less code, but the wave-wide test in front of the
     // staging cost the C2 batches 8 %: 1M 16.6 -> 18.0 us, 64M 567 -> 598)
 #if !GTARS_TOK_STAGE_RUNS
-    if (IMPL && !FILTER && (GTARS_TOK_RUNS & 1) && __ballot((t.more_bits >> RUN_FLAG_BIT) & 1u)) return false;
+    if (IMPL && !FILTER && (RUNS & 1) && __ballot((t.more_bits >> RUN_FLAG_BIT) & 1u)) return false;
 #endif
     u64 o4[QPT];
-    emit_queries<QPT, FILTER, IMPL, REV, GTARS_TOK_STAGE_RUNS != 0>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, false, [&](u64 pos, u32 id) {
+    emit_queries<QPT, FILTER, IMPL, REV, (GTARS_TOK_STAGE_RUNS != 0 ? RUNS : 0)>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, false, [&](u64 pos, u32 id) {
         if (GTARS_TOK_ABLATE & 2) return;
         stage[(u32)pos] = id;
     });
@@ -945,7 +946,7 @@ __device__ __forceinline__ void group_barrier(u32 *ctr, u32 &phase, u32 members,
     asm volatile("" ::: "memory");
 }
 
-template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV>
+template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV, int RUNS>
 __global__ void __launch_bounds__(TPB, TPB / 256)
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
@@ -1029,7 +1030,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
 #if GTARS_TOK_PRIO & 1
             __builtin_amdgcn_s_setprio(1);  // the group that feeds the vector-memory path goes first
 #endif
-            count_rounds<R, QPT, FILTER, IMPL, REV>(a, L, c, s, e, min_bp, cur.q, tsum);
+            count_rounds<R, QPT, FILTER, IMPL, REV, RUNS>(a, L, c, s, e, min_bp, cur.q, tsum);
 #if GTARS_TOK_PRIO & 1
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1062,7 +1063,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         bool pre0 = false;
         const u64 prev_q0 = (u64)prev.tile * TILE + (u64)gtid * QPT;
         if (have_prev && gwave != 0)
-            pre0 = stage_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
+            pre0 = stage_queries<QPT, FILTER, IMPL, REV, RUNS>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
         if (have_prev && gwave == 0) {
             const u64 excl = (GTARS_TOK_ABLATE & 1) ? (u64)prev.tile * 2400u
                                                     : (draw ? resolve_prefix_helping<1>(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help)
@@ -1080,7 +1081,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         TSTAMP(7);
         if (have_prev) {
             if (gwave == 0)
-                pre0 = stage_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
+                pre0 = stage_queries<QPT, FILTER, IMPL, REV, RUNS>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
             TSTAMP(3);
             bar();
             TSTAMP(4);
@@ -1094,7 +1095,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                     flush_queries<QPT>(nq, prev.q[0].wtotal, orel0, q0, s_prefix[grp] + prev.wbase[0], offsets, ovals, cap, off_vec_ok,
                                        stage, lane);
                 else
-                    write_queries<QPT, FILTER, IMPL, REV>(a, L, qc, qs, qe, nq, min_bp, prev.q[r], q0, s_prefix[grp] + prev.wbase[r],
+                    write_queries<QPT, FILTER, IMPL, REV, RUNS>(a, L, qc, qs, qe, nq, min_bp, prev.q[r], q0, s_prefix[grp] + prev.wbase[r],
                                                           offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
             }
         }
@@ -1339,13 +1340,13 @@ static u32 stage_words(const AccelView &a, int tpb, int per_cu) {
     return w >= 128 ? (u32)w : 0u;
 }
 
-template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV>
+template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV, int RUNS>
 static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, const u64 *d_base, u64 *d_total_out,
                                  hipStream_t st) {
     static KernelSetup setup;
     int dev = 0, cus = 256;
-    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV>), dev, cus);
+    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV, RUNS>), dev, cus);
     if (s0) return s0;
     // one 1024-thread workgroup per CU: one LDS copy of the search keys, 16 waves -- what 128 VGPRs admit
     const u32 stage = stage_words(a, TPB, 1);
@@ -1355,7 +1356,7 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     const u64 grid = std::min<u64>((u64)cus, (tiles + G - 1) / G);
     const u64 cap = out.vals ? out.capacity : 0;
-    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
+    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV, RUNS>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
                        min_bp, out.offsets, out.vals, cap, ws, ep.epoch, ep.ticket_base, stage, spin_limit, d_base, d_total_out);
     GT_HIP(hipGetLastError());
     // tickets drawn by this launch: one per tile beyond the first `grid * G`, plus one failing draw per group
@@ -1423,14 +1424,24 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     ScanWs *ws = (ScanWs *)scan_ws;
     if (!impl && !a.rec4) return fail(GTARS_ERR_INTERNAL, "index has no id records");
     ProfScope p("k_tok_lds", st);
-#define GT_TOK_CASE(N, GG, F, I, V)                                                                                         \
-    if (rounds == N && groups == GG && filter == F && impl == I && reverse == V)                                            \
-        return launch_tok_t<TPB, 4, N, GG, F, I, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
+    // Two builds of every kernel without a min-overlap filter: with the run form of wide queries (tail_run, coop_runs) and without.
+    // The run form costs a C2 launch 2-3.5 % (registers of the two-round kernels, code in the tile loop), and a launch whose id
+    // buffer cannot hold WIDE_IDS_PER_QUERY ids per query cannot be a hit-heavy batch that completes -- it would end in
+    // GTARS_ERR_CAPACITY -- so it runs the build without; an offsets-only launch (capacity 0: the sizing pass of a two-pass caller)
+    // keeps the run form, which is what makes a hit-heavy batch's count cheap.  Both builds give the same offsets and ids.
+    const u64 cap_ids = out.vals ? out.capacity : 0;
+    const bool wide = GTARS_TOK_RUNS != 0 && !filter && a.runs_ok && !cfg_flag("GTARS_TOK_NARROW") &&
+                      (cap_ids == 0 || cap_ids / WIDE_IDS_PER_QUERY >= nq || cfg_flag("GTARS_TOK_WIDE"));  // (switches: tests, A/B)
+#define GT_TOK_CASE(N, GG, F, I, V, W)                                                                                      \
+    if (rounds == N && groups == GG && filter == F && impl == I && reverse == V && wide == (W != 0))                        \
+        return launch_tok_t<TPB, 4, N, GG, F, I, V, W>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
 #define GT_TOK_GEOM(N, GG, I)                                                                                               \
-    GT_TOK_CASE(N, GG, false, I, false)                                                                                     \
-    GT_TOK_CASE(N, GG, true, I, false)                                                                                      \
-    GT_TOK_CASE(N, GG, false, I, true)                                                                                      \
-    GT_TOK_CASE(N, GG, true, I, true)
+    GT_TOK_CASE(N, GG, false, I, false, 0)                                                                                  \
+    GT_TOK_CASE(N, GG, false, I, false, GTARS_TOK_RUNS)                                                                     \
+    GT_TOK_CASE(N, GG, true, I, false, 0)                                                                                   \
+    GT_TOK_CASE(N, GG, false, I, true, 0)                                                                                   \
+    GT_TOK_CASE(N, GG, false, I, true, GTARS_TOK_RUNS)                                                                      \
+    GT_TOK_CASE(N, GG, true, I, true, 0)
     GT_TOK_GEOM(1, 1, true)
     GT_TOK_GEOM(2, 1, true)
     GT_TOK_GEOM(1, 2, true)

@@ -53,6 +53,11 @@ def one(seed):
         os.environ["GTARS_TOK_BUCKETS"] = str(buckets)
     else:
         os.environ.pop("GTARS_TOK_BUCKETS", None)
+    for name, pr in (("GTARS_TOK_WIDE", 0.3), ("GTARS_TOK_NARROW", 0.15)):  # which build of the kernels a launch takes (capacity rule overridden)
+        if rng.random() < pr:
+            os.environ[name] = "1"
+        else:
+            os.environ.pop(name, None)
     gtars_amd.reload_env()  # (the library snapshots its switches at first use)
     g = gtars_amd.OverlapIndex(c, s, e, val, n_chrom=n_chrom, kind=kind)
     o = oracle.Index(c, s, e, val, n_chrom=n_chrom, kind=kind)

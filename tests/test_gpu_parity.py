@@ -869,6 +869,10 @@ def test_wide_queries_on_disjoint_universes_take_the_run_form(ga, monkeypatch, k
         monkeypatch.setenv("GTARS_TOK_GROUPS", groups)
         off_g, ids_g = g.tokenize(qc, qs, qe)
         assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o), (rounds, groups)
+    monkeypatch.setenv("GTARS_TOK_NARROW", "1")  # the kernels built without the run form (what a launch with a small id buffer takes)
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+    monkeypatch.delenv("GTARS_TOK_NARROW")
     monkeypatch.setenv("GTARS_TOK_NO_RUNS", "1")
     off_g, ids_g = g.tokenize(qc, qs, qe)
     assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
@@ -960,6 +964,9 @@ def test_run_form_with_padded_units(ga, monkeypatch, top_max):
     qc, qs, qe = _wide_queries(rng, n_chrom, span, 40_000, typical=60_000)
     narrow = rng.random(len(qc)) < 0.97
     qe = np.where(narrow & (qe > qs), np.minimum(qe, qs + 300), qe)
+    _assert_same_queries(g, o, qc, qs, qe, min_overlaps=(None,))
+    # (few ids per query: the launch takes the kernels built without the run form; once more with them)
+    monkeypatch.setenv("GTARS_TOK_WIDE", "1")
     _assert_same_queries(g, o, qc, qs, qe, min_overlaps=(None,))
 
 
