@@ -329,7 +329,7 @@ __device__ __forceinline__ bool run_form(const AccelView &a, u32 m, u32 s3, u32 
 #define GTARS_TOK_RUNS 5  // 1: tails of wide queries measured (tail_run), 4: their ids leave by wave-wide stores (experiments: subsets)
 #endif
 constexpr u32 COOP_MIN = 16;  // ids of one query from which on they leave by wave-wide stores (write_queries)
-constexpr u64 WIDE_IDS_PER_QUERY = 8;  // id slots per query from which on a launch gets the kernels with the run form (launch_tokenize_lds)
+constexpr u64 WIDE_IDS_PER_QUERY = 4;  // id slots per query from which on a launch gets the kernels with the run form (launch_tokenize_lds)
 
 #ifndef GTARS_TOK_FILL_DMA
 #define GTARS_TOK_FILL_DMA 0  // 1: the LDS image is filled by global_load_lds_dwordx4 (round-4 experiment: no gain, see profiles/r04); 0: loads + ds_write_b128
