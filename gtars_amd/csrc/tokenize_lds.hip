@@ -1396,8 +1396,18 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
         }
     }
     const bool impl = a.ids_affine != 0;
-    // two rounds keep 8 queries' state per lane across the scan: with the id pairs of explicit-id records that spills
-    int rounds = impl ? choose_rounds(nq, cus) : 1;
+    const bool filter = has_min && min_overlap > 1;
+    // Two builds of every kernel without a min-overlap filter: with the run form of wide queries (tail_run, coop_runs) and without.
+    // The run form costs a C2 launch 2-3.5 % (registers of the two-round kernels, code in the tile loop), and a launch whose id
+    // buffer cannot hold WIDE_IDS_PER_QUERY ids per query cannot be a hit-heavy batch that completes -- it would end in
+    // GTARS_ERR_CAPACITY -- so it runs the build without; an offsets-only launch (capacity 0: the sizing pass of a two-pass caller)
+    // keeps the run form, which is what makes a hit-heavy batch's count cheap.  Both builds give the same offsets and ids.
+    const u64 cap_ids = out.vals ? out.capacity : 0;
+    const bool wide = GTARS_TOK_RUNS != 0 && !filter && a.runs_ok && !cfg_flag("GTARS_TOK_NARROW") &&
+                      (cap_ids == 0 || cap_ids / WIDE_IDS_PER_QUERY >= nq || cfg_flag("GTARS_TOK_WIDE"));  // (switches: tests, A/B)
+    // two rounds keep 8 queries' state per lane across the scan: with the id pairs of explicit-id records that spills; the kernels
+    // with the run form gain nothing from the second round (16M queries of 33 ids: 1125 us with one round, 1139 with two)
+    int rounds = impl && !wide ? choose_rounds(nq, cus) : 1;
     int groups = choose_groups(nq, cus);
     // a tile's hits are summed in 32 bits: tile queries x (most intervals on one chromosome) must fit
     const u64 dense = std::max<u64>(a.max_chrom_n, 1);
@@ -1419,35 +1429,34 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
         ep.ticket_base = 0;
     }
     ep.epoch += 1;
-    const bool filter = has_min && min_overlap > 1;
     const i32 min_bp = has_min ? min_overlap : 0;
     ScanWs *ws = (ScanWs *)scan_ws;
     if (!impl && !a.rec4) return fail(GTARS_ERR_INTERNAL, "index has no id records");
     ProfScope p("k_tok_lds", st);
-    // Two builds of every kernel without a min-overlap filter: with the run form of wide queries (tail_run, coop_runs) and without.
-    // The run form costs a C2 launch 2-3.5 % (registers of the two-round kernels, code in the tile loop), and a launch whose id
-    // buffer cannot hold WIDE_IDS_PER_QUERY ids per query cannot be a hit-heavy batch that completes -- it would end in
-    // GTARS_ERR_CAPACITY -- so it runs the build without; an offsets-only launch (capacity 0: the sizing pass of a two-pass caller)
-    // keeps the run form, which is what makes a hit-heavy batch's count cheap.  Both builds give the same offsets and ids.
-    const u64 cap_ids = out.vals ? out.capacity : 0;
-    const bool wide = GTARS_TOK_RUNS != 0 && !filter && a.runs_ok && !cfg_flag("GTARS_TOK_NARROW") &&
-                      (cap_ids == 0 || cap_ids / WIDE_IDS_PER_QUERY >= nq || cfg_flag("GTARS_TOK_WIDE"));  // (switches: tests, A/B)
 #define GT_TOK_CASE(N, GG, F, I, V, W)                                                                                      \
     if (rounds == N && groups == GG && filter == F && impl == I && reverse == V && wide == (W != 0))                        \
         return launch_tok_t<TPB, 4, N, GG, F, I, V, W>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
 #define GT_TOK_GEOM(N, GG, I)                                                                                               \
     GT_TOK_CASE(N, GG, false, I, false, 0)                                                                                  \
-    GT_TOK_CASE(N, GG, false, I, false, GTARS_TOK_RUNS)                                                                     \
     GT_TOK_CASE(N, GG, true, I, false, 0)                                                                                   \
     GT_TOK_CASE(N, GG, false, I, true, 0)                                                                                   \
-    GT_TOK_CASE(N, GG, false, I, true, GTARS_TOK_RUNS)                                                                      \
     GT_TOK_CASE(N, GG, true, I, true, 0)
+#define GT_TOK_WIDE(GG, I)                                                                                                  \
+    GT_TOK_CASE(1, GG, false, I, false, GTARS_TOK_RUNS)                                                                     \
+    GT_TOK_CASE(1, GG, false, I, true, GTARS_TOK_RUNS)
     GT_TOK_GEOM(1, 1, true)
     GT_TOK_GEOM(2, 1, true)
     GT_TOK_GEOM(1, 2, true)
     GT_TOK_GEOM(2, 2, true)
     GT_TOK_GEOM(1, 1, false)
     GT_TOK_GEOM(1, 2, false)
+#if GTARS_TOK_RUNS
+    GT_TOK_WIDE(1, true)
+    GT_TOK_WIDE(2, true)
+    GT_TOK_WIDE(1, false)
+    GT_TOK_WIDE(2, false)
+#endif
+#undef GT_TOK_WIDE
 #undef GT_TOK_GEOM
 #undef GT_TOK_CASE
     return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");
