@@ -123,8 +123,10 @@ __device__ __forceinline__ u32 run_state(u32 n, u32 m) { return (n & B0_MASK) | 
 #ifndef GTARS_TOK_STAGE_RUNS
 #define GTARS_TOK_STAGE_RUNS 1  // 1: the early staging of round 0 (stage_queries) emits run-form queries itself; 0: see there
 #endif
-constexpr u32 RUN_FLAG_BIT = 8;  // TileQ::more_bits: some query of the lane's round is in run form
-constexpr u32 RUN_Q_BIT = 4;     // ... bit RUN_Q_BIT + j: query j is (its state word holds the hit count, not the block)
+// TileQ::more_bits: bit j: query j's scan runs past its first record; bit RUN_Q_BIT + j: it is in run form (its state word holds
+// the run's length, not the block); 2 bits at STAB_W_BIT + 2j / 4 bits at STAB_N_BIT + 4j: records tested in front of the run
+// (stab_walk) and their hits
+constexpr u32 RUN_Q_BIT = 4, STAB_W_BIT = 8, STAB_N_BIT = 16;
 __device__ __forceinline__ u32 run_state_n(u32 st) { return (st & B0_MASK) | ((st >> (B0_BITS + 4)) << B0_BITS); }
 
 // Tail of a query whose scan runs past block b0's look-ahead intervals (rare).  Record b holds intervals
@@ -293,11 +295,13 @@ __host__ __device__ __forceinline__ size_t tok_lds_bytes(const AccelView &a) {
 // such a query.  33 ids per query: the walk was 8 dependent record loads per lane, twice (count phase and write phase).
 template <u32 STRIDE>
 __device__ __forceinline__ u32 tail_run(const AccelView &a, const SearchLds &L, const uint4 *__restrict__ recs, u32 c, u32 b0, u32 be,
-                                        u32 qe) {
+                                        u32 qe, u32 skip = 0) {
+    // (skip: records behind the first one that the caller has tested interval by interval -- the run starts behind them)
     const u32 sq = qe - 1u;  // (a query with a tail has q_end > the fourth start >= 0)
     u32 B, BE;
     search_blocks<1>(a, L.lut, L.q, L.ctab, &c, &sq, &B, &BE);
-    B = B > b0 + 1u ? B : b0 + 1u;  // (the record of b0 + 1 holds the tail's first two intervals)
+    const u32 bmin = b0 + 2u + 2u * skip;  // the block whose own two intervals are the run's first
+    B = B > bmin ? B : bmin;
     u32 last;
     for (;;) {
         if (B >= be) {  // q_end lies beyond the chromosome's largest end
@@ -315,15 +319,55 @@ __device__ __forceinline__ u32 tail_run(const AccelView &a, const SearchLds &L, 
         }
         ++B;  // (floor-quantised keys, or a key that runs ahead of the starts)
     }
-    const u32 first_tail = (u32)ACC_OWN * b0 + 4u;
+    const u32 first_tail = (u32)ACC_OWN * bmin;
     return last > first_tail ? last - first_tail : 0u;
+}
+// The records a query's scan crosses before its run starts (RUNS builds): behind the first record, every record whose FIRST
+// interval still starts at or before q_start is tested interval by interval (a long interval in front -- its end is why the scan
+// starts this early -- and short ones that end before q_start: hits with gaps); the first record that starts behind q_start
+// opens the run.  At most STAB_MAX records (their number and their hits travel in TileQ::more_bits); a longer shadow is walked.
+constexpr u32 STAB_MAX = 3;
+struct Stab {
+    u32 w, hits;       // records tested, hits among their intervals
+    bool ok, ended;    // within STAB_MAX; the scan ended inside them (no run behind)
+};
+template <u32 STRIDE, class F>
+__device__ __forceinline__ Stab stab_walk(const uint4 *__restrict__ recs, u32 b0, u32 be, u32 qs, u32 qe, F &&f) {
+    Stab r{0u, 0u, true, false};
+    for (u32 b = b0 + 2u;; b += 2u) {
+        if (b >= be) {
+            r.ended = true;
+            break;
+        }
+        const uint4 S = recs[(size_t)b * STRIDE];
+        if (S.x > qs) break;  // everything from here on starts, hence ends, behind q_start
+        if (r.w == STAB_MAX) {
+            r.ok = false;
+            break;
+        }
+        const uint4 E = recs[(size_t)b * STRIDE + 1];
+        u32 m = block_mask4<false>(S, E, qs, qe, 0);
+        r.hits += __popc(m);
+        while (m) {
+            const int k = __ffs((int)m) - 1;
+            m &= m - 1;
+            f(r.w, k);
+        }
+        ++r.w;
+        if (!(S.w < qe)) {  // (bits.rs:441-443: the scan ends at the first start >= q_end)
+            r.ended = true;
+            break;
+        }
+    }
+    return r;
 }
 // Is a query with a tail, first-record hit mask m and fourth start s3 in run form?  Its first record's hits must reach up to the
 // fourth interval without a gap (so that they and the tail are ONE run of ids), and every interval of the tail must end after
 // q_start: because the fourth interval already starts after q_start (any universe without inverted intervals), or because
 // the ends ascend with the starts and the record has a hit (disjoint universes).
+__device__ __forceinline__ bool mask_joins_tail(u32 m) { return m && (m + (m & (0u - m))) == 16u; }
 __device__ __forceinline__ bool run_form(const AccelView &a, u32 m, u32 s3, u32 qs) {
-    return a.runs_ok && m && (m + (m & (0u - m))) == 16u && (s3 > qs || a.ends_mono);
+    return a.runs_ok && mask_joins_tail(m) && (s3 > qs || a.ends_mono);
 }
 #ifndef GTARS_TOK_RUNS
 #define GTARS_TOK_RUNS 5  // 1: tails of wide queries measured (tail_run), 4: their ids leave by wave-wide stores (experiments: subsets)
@@ -499,8 +543,8 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
             const bool more = act[p][k] && (S[p][k].w < qe_) && (b0[p][k] + 2 < be[p][k]);
             u32 n = __popc(m);
             if (more) {
-                if ((RUNS & 1) && !FILTER && run_form(a, m, S[p][k].w, qs_))
-                    pend |= 1u << (r * QPT + j);  // run form: the tail is measured below, by the ONE copy of tail_run
+                if ((RUNS & 1) && !FILTER && a.runs_ok)  // run form: the tail is measured below, by ONE copy of the code (bit 16 + ..:
+                    pend |= (1u | (run_form(a, m, S[p][k].w, qs_) ? 0x10000u : 0u)) << (r * QPT + j);  // nothing to test in front)
                 else
                     n += walk_tail<FILTER, STRIDE>(recs, b0[p][k], be[p][k], qs_, qe_, min_bp, [](u32, int) {});
             }
@@ -534,24 +578,36 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
     // query picked out of the register arrays by select chains -- inlined into finish() above, tail_run's search came eight times
     // per kernel and pushed the two-round kernels into scratch memory (60 bytes per lane; 64M C2 queries 578 -> 627 us).
     if constexpr (!FILTER && (RUNS & 1) != 0) {
-        while (pend) {
-            const u32 k = (u32)__ffs((int)pend) - 1u;
-            pend &= pend - 1u;
-            u32 cq = c[0][0], eq = e[0][0], stv = t[0].st[0];
+        static_assert(R * QPT <= 16, "the two halves of `pend`");
+        while (pend & 0xFFFFu) {
+            const u32 k = (u32)__ffs((int)(pend & 0xFFFFu)) - 1u;
+            const bool simple = ((pend >> (16 + k)) & 1u) != 0;
+            pend &= ~(1u << k);
+            u32 cq = c[0][0], sq = s[0][0], eq = e[0][0], stv = t[0].st[0];
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int j = 0; j < QPT; ++j) {
                     const bool me = k == (u32)(r * QPT + j);
                     cq = me ? c[r][j] : cq;
+                    sq = me ? s[r][j] : sq;
                     eq = me ? e[r][j] : eq;
                     stv = me ? t[r].st[j] : stv;
                 }
-            const u32 m = (stv >> B0_BITS) & 15u;
-            const u32 nt = tail_run<STRIDE>(a, L, recs, cq, stv & B0_MASK, L.ctab[cq].w, eq);
-            // ids that follow from the position: the write phase needs the run's length, not the block (the first id is aux + the
-            // first set bit of m) -- nothing is searched or loaded there again
-            const u32 nst = IMPL ? run_state(__popc(m) + nt, m) : stv;
+            const u32 m = (stv >> B0_BITS) & 15u, bq = stv & B0_MASK, beq = L.ctab[cq].w;
+            Stab sb{0u, 0u, true, false};
+            if (!simple) sb = stab_walk<STRIDE>(recs, bq, beq, sq, eq, [](u32, int) {});
+            u32 nt, n_run = 0;
+            if (sb.ok) {
+                if (!sb.ended) n_run = tail_run<STRIDE>(a, L, recs, cq, bq, beq, eq, sb.w);
+                nt = sb.hits + n_run;
+            } else {
+                nt = walk_tail<FILTER, STRIDE>(recs, bq, beq, sq, eq, min_bp, [](u32, int) {});  // (a long shadow: walked)
+            }
+            // ids that follow from the position: the write phase needs the run's length, not the block (its ids follow from aux,
+            // the mask and the number of records in front) -- no search there, and loads only for the records in front
+            const bool keep = IMPL && sb.ok;
+            const u32 nst = keep ? run_state(n_run, m) : stv;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 tsum[r] += (k / QPT == (u32)r) ? nt : 0u;
@@ -559,7 +615,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
                 for (int j = 0; j < QPT; ++j) {
                     const bool me = k == (u32)(r * QPT + j);
                     t[r].st[j] = me ? nst : t[r].st[j];
-                    if (IMPL) t[r].more_bits |= me ? (1u << RUN_FLAG_BIT) | (1u << (RUN_Q_BIT + j)) : 0u;
+                    t[r].more_bits |= me && keep ? (1u << (RUN_Q_BIT + j)) | (sb.w << (STAB_W_BIT + 2 * j)) | (sb.hits << (STAB_N_BIT + 4 * j)) : 0u;
                 }
             }
         }
@@ -588,13 +644,37 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
         u32 m = (t.st[j] >> B0_BITS) & 15u;
         const bool more = (t.more_bits & (1u << j)) != 0;
         if constexpr (IMPL && !FILTER && (RUNS & 1) != 0) {
-            if (t.more_bits & (1u << (RUN_Q_BIT + j))) {  // run form (count_rounds): the state word holds the hit count
-                const u32 n_run = run_state_n(t.st[j]);
-                if (want_ids && !((RUNS & 4) && defer && n_run >= COOP_MIN)) {  // (deferred: coop_runs)
-                    const u32 id0 = t.aux[j] + (u32)(__ffs((int)m) - 1);
-                    for (u32 i = 0; i < n_run; ++i) put(REV ? run + (n_run - 1u - i) : run + i, id0 + i);
+            if (t.more_bits & (1u << (RUN_Q_BIT + j))) {  // run form (count_rounds): the state word holds the run's length
+                // forward order of the ids: the first record's hits (mask m), the hits of the w records tested in front of the run
+                // (stab_walk), the run aux + 4 + 4 w, ...  With no record in front and a mask that joins the tail, mask and run are
+                // ONE run from aux + (first bit of m).
+                const u32 n_run = run_state_n(t.st[j]), w = (t.more_bits >> (STAB_W_BIT + 2 * j)) & 3u,
+                          n_stab = (t.more_bits >> (STAB_N_BIT + 4 * j)) & 15u, pm = __popc(m);
+                const bool joined = w == 0 && mask_joins_tail(m);
+                const u32 n_all = pm + n_stab + n_run;
+                if (want_ids) {
+                    auto slot = [&](u32 i) -> u64 { return REV ? run + (n_all - 1u - i) : run + i; };
+                    u32 i = 0;
+                    if (!joined) {
+                        u32 mm = m;
+                        while (mm) {
+                            const int k = __ffs((int)mm) - 1;
+                            mm &= mm - 1;
+                            put(slot(i++), t.aux[j] + (u32)k);
+                        }
+                        if (w) {  // the records in front once more (rare: a start in a long interval's shadow)
+                            const u32 cq = qc[q0 + j], sq = qs[q0 + j], eq = qe[q0 + j];
+                            const u32 b0r = (t.aux[j] - L.idc[cq]) / (u32)ACC_OWN;
+                            stab_walk<STRIDE>(recs, b0r, L.ctab[cq].w, sq, eq, [&](u32 x, int k) { put(slot(i++), t.aux[j] + 4u + 4u * x + (u32)k); });
+                        }
+                    }
+                    const u32 n_here = joined ? pm + n_run : n_run;  // the run (with the mask's ids when they join it)
+                    if (!((RUNS & 4) && defer && n_here >= COOP_MIN)) {  // (else deferred: coop_runs)
+                        const u32 id0 = joined ? t.aux[j] + (u32)(__ffs((int)m) - 1) : t.aux[j] + 4u + 4u * w;
+                        for (u32 x = 0; x < n_here; ++x) put(slot(i++), id0 + x);
+                    }
                 }
-                run += n_run;
+                run += n_all;
                 continue;
             }
         }
@@ -678,11 +758,15 @@ __device__ __forceinline__ void coop_runs(const TileQ<QPT, true> &t, const u64 (
     u32 any_big = 0;
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
-        const u32 m = (t.st[j] >> B0_BITS) & 15u, n = run_state_n(t.st[j]);
+        const u32 m = (t.st[j] >> B0_BITS) & 15u, pm = __popc(m), w = (t.more_bits >> (STAB_W_BIT + 2 * j)) & 3u,
+                  n_stab = (t.more_bits >> (STAB_N_BIT + 4 * j)) & 15u;
+        const bool joined = w == 0 && mask_joins_tail(m);
+        const u32 n = run_state_n(t.st[j]) + (joined ? pm : 0u);  // the run (emit_queries: with the mask's ids when they join it)
         const bool big = ((t.more_bits >> (RUN_Q_BIT + j)) & 1u) && n >= COOP_MIN;
-        S[j] = (u32)(o4[j] - wave_base);
+        // forward order: [mask ids, ids of the records in front] run; reversed: run [...]
+        S[j] = (u32)(o4[j] - wave_base) + (REV || joined ? 0u : pm + n_stab);
         N[j] = big ? n : 0u;
-        const u32 id0 = t.aux[j] + (u32)(__ffs((int)(m | 16u)) - 1);
+        const u32 id0 = joined ? t.aux[j] + (u32)(__ffs((int)m) - 1) : t.aux[j] + 4u + 4u * w;
         K[j] = REV ? id0 + (n - 1u) + S[j] : id0 - S[j];  // id of output position x: K + x, reversed K - x
         any_big |= N[j];
     }
@@ -785,7 +869,7 @@ __device__ __forceinline__ bool stage_queries(const AccelView &a, const SearchLd
     // the two copies of this early staging carry no run-form code -- 4 KB less code, but the wave-wide test in front of the
     // staging cost the C2 batches 8 %: 1M 16.6 -> 18.0 us, 64M 567 -> 598)
 #if !GTARS_TOK_STAGE_RUNS
-    if (IMPL && !FILTER && (RUNS & 1) && __ballot((t.more_bits >> RUN_FLAG_BIT) & 1u)) return false;
+    if (IMPL && !FILTER && (RUNS & 1) && __ballot((t.more_bits >> RUN_Q_BIT) & 15u)) return false;
 #endif
     u64 o4[QPT];
     emit_queries<QPT, FILTER, IMPL, REV, (GTARS_TOK_STAGE_RUNS != 0 ? RUNS : 0)>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, false, [&](u64 pos, u32 id) {
