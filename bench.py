@@ -40,7 +40,8 @@ ingests only its chromosomes, counts, and ONE all-reduce of the per-file vector(
 (what must be reduced: gtars-lola/src/enrichment.rs:198-221).  `ranks` lists what every rank saw (device, backend).
 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries: larger batches (`roofline_large`), a hit-heavy batch
-(`roofline_hit_heavy`: 1 Mbp-wide queries, ~33 ids each), BASELINE config 3
+(`roofline_hit_heavy`: 1 Mbp-wide queries, ~33 ids each; `roofline_hit_heavy_overlapping`: the same on the ChIP-like universe),
+BASELINE config 3
 (`igd_config3`) and config 4 on one GPU (`lola_config4`), each with a sampled CPU baseline and a parity check of the
 sample against the oracle, config 5 at a reduced file count (`fragsplit_config5`), the PCIe-inclusive host-buffer rate
 and the CPU baselines (the oracle on the GPU box's host cores).  Every timed output is checked in the run (`verified`).
@@ -1153,6 +1154,18 @@ def main():
             hh["ids_per_query"] = round(hh["hits"] / hh["queries"], 1)
             hh["batch"] = "the 1M-query base batch with every query widened to 1 Mbp, tiled 16x on the device"
             out["roofline_hit_heavy"] = hh
+            # ... and on the ChIP-like universe (C2': overlapping neighbours, 1 % intervals of 5-100 kbp; sorted file order so that
+            # the ids follow from the position): the run form with records tested in front of the run
+            uo = synth.make_universe(nu, overlapping=True)
+            order = np.lexsort((uo["end"], uo["start"], uo["chrom"]))
+            uo = {k: np.ascontiguousarray(v[order]) for k, v in uo.items()}
+            ixo = gtars_amd.OverlapIndex(uo["chrom"], uo["start"], uo["end"], n_chrom=synth.N_CHROM)
+            ho = bench_large(ixo, uo, qw, nu, [16_000_000], dev, stream)[0]
+            ho["ids_per_query"] = round(ho["hits"] / ho["queries"], 1)
+            ho["batch"] = hh["batch"]
+            ho["universe"] = "synth.make_universe(overlapping=True), position-sorted"
+            out["roofline_hit_heavy_overlapping"] = ho
+            del ixo
             # PCIe-inclusive rates through the host-pointer entry points (H2D of the queries, kernel, D2H of offsets +
             # ids).  Reported for context only; never `value`.  `streaming`: gtars_tokenize_into with
             # output arrays the caller reuses (chunked copy / kernel / copy-back pipeline, nothing allocated);
