@@ -15,6 +15,9 @@ def main():
     # reference's default IndexedRegionSet index (its order-free calls run on the flat companion's blocked structure)
     u = synth.make_universe(100_000, overlapping=os.environ.get("OVERLAPPING") == "1")
     base = synth.make_queries(u, 1_000_000)
+    widen = int(os.environ.get("WIDEN", "0"))  # windowed counts: every query widened to this many bp
+    if widen:
+        base["end"] = (base["start"].astype(np.int64) + widen).clip(max=0x7FFFFFFF).astype(base["end"].dtype)
     kind = gtars_amd.KIND_AILIST if os.environ.get("KIND", "bits") == "ailist" else gtars_amd.KIND_BITS
     ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM, kind=kind)
     st = torch.cuda.current_stream().cuda_stream
