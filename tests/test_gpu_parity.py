@@ -406,6 +406,40 @@ def test_device_pointer_path_and_capacity(ga):
     g.fill_device(qc.data_ptr(), qs.data_ptr(), qe.data_ptr(), nq, offsets.data_ptr(), ids.data_ptr(), stream)
     torch.cuda.synchronize()
     assert np.array_equal(ids[: len(ids_o)].cpu().numpy().view(np.uint32), ids_o)
+    assert np.array_equal(offsets.cpu().numpy().view(np.uint64), off_o)  # (the caller's offsets are read-only to the fill)
+
+
+def test_fill_device_both_ways_and_on_wide_queries(ga, monkeypatch):
+    """gtars_fill_device after a GTARS_ERR_CAPACITY: through the fused tokenizer (an index the LDS kernels serve) and through the
+    generic fill kernel (GTARS_NO_LDS_PATH_FOR_TEST), narrow and hit-heavy batches, both index kinds."""
+    import torch
+
+    rng = np.random.default_rng(99)
+    n_chrom, span = 4, 2_500_000
+    C_, S, E = _disjoint_universe(rng, n_chrom, 5_000, span)
+    dev = torch.device("cuda:0")
+    for kind in BOTH:
+        g, o = _pair(ga, C_, S, E, n_chrom=n_chrom, kind=kind)
+        for typical in (300, 40_000):
+            qc, qs, qe = _wide_queries(rng, n_chrom, span, 20_000, typical=typical)
+            qc = np.where(qc >= n_chrom, 1, qc)
+            off_o, ids_o = o.tokenize(qc, qs, qe)
+            d = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint32).view(np.int32)).to(dev) for x in (qc, qs, qe)]
+            for no_lds in (False, True):
+                if no_lds:
+                    monkeypatch.setenv("GTARS_NO_LDS_PATH_FOR_TEST", "1")
+                off = torch.zeros(len(qc) + 1, dtype=torch.int64, device=dev)
+                h = g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(qc), off.data_ptr(), 0, 0)
+                assert h == len(ids_o)
+                ids = torch.full((h + 64,), -3, dtype=torch.int32, device=dev)
+                g.fill_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(qc), off.data_ptr(), ids.data_ptr())
+                torch.cuda.synchronize()
+                got = ids.cpu().numpy()
+                assert np.array_equal(got[:h].view(np.uint32), ids_o), (kind, typical, no_lds)
+                assert (got[h:] == -3).all()
+                assert np.array_equal(off.cpu().numpy().view(np.uint64), off_o)
+                if no_lds:
+                    monkeypatch.delenv("GTARS_NO_LDS_PATH_FOR_TEST")
 
 
 @pytest.mark.parametrize("rep", [16, 256])
