@@ -31,6 +31,8 @@ enum Mode {
     G64_X2,                    // 64-B record as 8 x dwordx2
     G128_4,                    // 4 x dwordx4 from the first half of a random 128-B line
     GS64_4,                    // 64-B records, lanes of a wave sorted by record (neighbours share lines)
+    G16A_2,                    // 2 x dwordx4 from a random 16-B-aligned address (a 32-byte span that is NOT 32-byte aligned: a
+                               // record array without the look-ahead copies -- block b and block b + 1 -- at half the footprint)
     S1SC, S1CO, S2CO, S4CO,    // stores: scattered dword (stride ~2.3 words), coalesced dword / x2 / x4
     NMODES
 };
@@ -87,6 +89,14 @@ __global__ void __launch_bounds__(1024) k_ta(const u32 *__restrict__ tab, u32 ta
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc ^= v[i].x ^ v[i].w;
             }
+            if (MODE == G16A_2) {
+                const u32x4 *p = (const u32x4 *)(tab + (size_t)(rl % (tab_bytes / 16 - 1)) * 4);
+                u32x4 v[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) v[i] = p[i];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc ^= v[i].x ^ v[i].w;
+            }
             if (MODE == GS64_4) {
                 // a position-sorted batch: the wave's 64 queries fall into ~3 consecutive records
                 const u32 rec = (rw % (n64 - 4)) + (lane * 3 >> 6);
@@ -113,9 +123,9 @@ static const char *NAMES[NMODES] = {
     "coalesced dword", "coalesced dwordx2", "coalesced dwordx3", "coalesced dwordx4",
     "gather 64-B rec, 1 x4", "gather 64-B rec, 2 x4", "gather 64-B rec, 3 x4", "gather 64-B rec, 4 x4",
     "gather 32-B rec, 1 x4", "gather 32-B rec, 2 x4", "gather 64-B rec, 8 x2", "gather 128-B line, 4 x4 (first half)",
-    "sorted wave, 64-B rec, 4 x4", "store dword scattered (id stream)", "store dword coalesced", "store dwordx2 coalesced",
+    "sorted wave, 64-B rec, 4 x4", "gather 2 x4 at a 16-B-aligned address", "store dword scattered (id stream)", "store dword coalesced", "store dwordx2 coalesced",
     "store dwordx4 coalesced"};
-static const int INSTR[NMODES] = {1, 1, 1, 1, 1, 2, 3, 4, 1, 2, 8, 4, 4, 1, 1, 1, 1};
+static const int INSTR[NMODES] = {1, 1, 1, 1, 1, 2, 3, 4, 1, 2, 8, 4, 4, 2, 1, 1, 1, 1};
 
 template <int MODE, int UNROLL>
 static void run(const u32 *tab, u32 tab_bytes, u32 *out, u64 *d_cyc, int wgs, const char *tag) {
@@ -163,8 +173,15 @@ int main(int argc, char **argv) {
     hipMemset(tab, 1, 64u << 20);
     suite<4>(tab, small, out, d_cyc, "2.1MB");
     suite<8>(tab, small, out, d_cyc, "2.1MB");
+    run<G16A_2, 4>(tab, small, out, d_cyc, 256, "2.1MB");
+    run<G16A_2, 4>(tab, small / 2, out, d_cyc, 256, "1.05MB");
     run<G64_4, 4>(tab, 64u << 20, out, d_cyc, 256, "64MB");
     run<G32_2, 4>(tab, 64u << 20, out, d_cyc, 256, "64MB");
+    // a 1M-region universe: 16 MB of 32-byte records against 8 MB without the look-ahead copies (4 MB of L2 per XCD)
+    run<G32_2, 4>(tab, 16u << 20, out, d_cyc, 256, "16MB");
+    run<G16A_2, 4>(tab, 8u << 20, out, d_cyc, 256, "8MB");
+    run<G32_2, 4>(tab, 4u << 20, out, d_cyc, 256, "4MB");
+    run<G16A_2, 4>(tab, 2u << 20, out, d_cyc, 256, "2MB");
     run<S1SC, 4>(tab, 32u << 20, out, d_cyc, 256, "32MB");
     run<S1CO, 4>(tab, 32u << 20, out, d_cyc, 256, "32MB");
     run<S2CO, 4>(tab, 32u << 20, out, d_cyc, 256, "32MB");
