@@ -226,6 +226,11 @@ void prof_note_device_flag(const char *if_set, const char *if_clear, const u32 *
     g_prof_entries[prof_entry(h ? if_set : if_clear)].launches += 1;
 }
 
+// a choice the host made (profiling mode: counts one "launch" of the entry; a fact for the tests, not a time)
+void prof_note_fact(const char *name) {
+    if (g_prof_on) g_prof_entries[prof_entry(name)].launches += 1;
+}
+
 // -------------------------------------------------------------- device bufs
 template <class T>
 struct DevBuf {
@@ -256,6 +261,25 @@ struct ScopedDev {
     template <class T>
     T *as() {
         return (T *)p;
+    }
+};
+
+// the calling thread's current device for the scope: `want`, and what it was before again afterwards
+struct DeviceScope {
+    int before = -1;
+    bool switched = false;
+    gtars_status st = GTARS_OK;
+    explicit DeviceScope(int want) {
+        if (want < 0) return;
+        hipError_t e = hipGetDevice(&before);
+        if (e == hipSuccess && before != want) {
+            e = hipSetDevice(want);
+            switched = e == hipSuccess;
+        }
+        if (e != hipSuccess) st = hip_fail(e, "select the index's device", __FILE__, __LINE__);
+    }
+    ~DeviceScope() {
+        if (switched) (void)hipSetDevice(before);
     }
 };
 
@@ -425,6 +449,10 @@ struct gtars_igd {
     DevBuf<i32> tile_pm;
     DevBuf<unsigned short> tile_files16;
     DevBuf<u32> tile_tab;
+    // ... and of its rank-histogram form (IgdTiles::ends_sorted / erank / tab_r; optional: a failed allocation leaves the walk)
+    DevBuf<i32> tile_ends_sorted;
+    DevBuf<unsigned short> tile_erank;
+    DevBuf<u32> tile_tab_r;
     // per chromosome, the reference contig's tile count at nbp = 16384 (min_overlap <= 0 counts), built on first use
     mutable std::mutex ntiles_mu;
     mutable DevBuf<i32> chrom_ntiles;
@@ -521,6 +549,9 @@ struct gtars_igd {
         t.pm = tile_pm.p;
         t.files16 = tile_files16.p;
         t.tab = tile_tab.p;
+        t.ends_sorted = tile_ends_sorted.p;
+        t.erank = tile_erank.p;
+        t.tab_r = tile_tab_r.p;
         t.route_lut = route_n ? route_lut.p : nullptr;
         t.route_base = route_base.p;
         t.route_len = route_len.p;
@@ -555,6 +586,26 @@ struct gtars_igd {
             if ((st = launch_igd_tile_tables(view(), tile_first.p, tile_cnt.p, tile_chrom.p, tile_carry.p, n_tiles, tile_pm.p, tile_files16.p,
                                              tile_tab.p, nullptr)))
                 return st;
+            // the rank-histogram form's blocks (sorted ends + eranks: 6 bytes per staged record, ~7 per record).  Not for a pieces
+            // view (its continuation rule is not a rank difference) and not under GTARS_IGD_NO_RANK_TABLES (tests / A-B runs)
+            if (!piece_flags && n_files <= 16384 && !cfg_flag("GTARS_IGD_NO_RANK_TABLES")) {
+                const size_t slots = (size_t)n_tiles * IGD_TILE_BLOCK;
+                hipError_t e = hipMalloc((void **)&tile_ends_sorted.p, slots * 4 + 32);
+                if (e == hipSuccess) e = hipMalloc((void **)&tile_erank.p, slots * 2 + 32);
+                if (e == hipSuccess) e = hipMalloc((void **)&tile_tab_r.p, (size_t)n_tiles * IGD_TILE_TABR_WORDS * 4);
+                if (e == hipSuccess) {
+                    tile_ends_sorted.n = tile_erank.n = slots;
+                    tile_tab_r.n = (size_t)n_tiles * IGD_TILE_TABR_WORDS;
+                    if ((st = launch_igd_tile_tables_rank(view(), tile_first.p, tile_cnt.p, tile_chrom.p, n_tiles, tile_ends_sorted.p,
+                                                          tile_erank.p, tile_tab_r.p, nullptr)))
+                        return st;
+                } else {
+                    (void)hipGetLastError();  // out of device memory: the database keeps the walked form
+                    tile_ends_sorted.release();
+                    tile_erank.release();
+                    tile_tab_r.release();
+                }
+            }
         }
         GT_HIP(hipDeviceSynchronize());
         if (n_tiles && n_tiles < 65535) {
@@ -1464,12 +1515,45 @@ struct HostPipe {
         return GTARS_OK;
     }
 };
-// one pipe per (calling thread, device): a thread that switches devices between calls gets that device's pipe
+// one pipe per (calling thread, device): a thread that switches devices between calls gets that device's pipe.  The pipes of a
+// thread that exits go back to a process-wide pool -- device buffer, pinned words, streams, events and the (idle) helper thread
+// included -- from which new threads take theirs, like the workspaces above: a caller that runs every batch on a short-lived
+// thread of its own (fragsplit_tokenize_core's wave tokenizer did) used to leave all of that behind on every call.
+struct HostPipePool {
+    std::mutex mu;
+    std::vector<HostPipe *> idle;
+};
+HostPipePool &host_pipe_pool() {
+    static HostPipePool *p = new HostPipePool();  // never destroyed: thread-exit handlers may run late
+    return *p;
+}
+struct TlsHostPipes {
+    std::map<int, HostPipe *> pipes;
+    ~TlsHostPipes() {
+        HostPipePool &pool = host_pipe_pool();
+        std::lock_guard<std::mutex> g(pool.mu);
+        for (auto &kv : pipes)
+            if (kv.second) pool.idle.push_back(kv.second);
+    }
+};
 HostPipe &tls_host_pipe() {
-    static thread_local std::map<int, HostPipe> pipes;  // streams / helper threads stay until the thread exits
+    static thread_local TlsHostPipes tls;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    return pipes[dev];
+    HostPipe *&slot = tls.pipes[dev];
+    if (!slot) {
+        HostPipePool &pool = host_pipe_pool();
+        std::lock_guard<std::mutex> g(pool.mu);
+        for (size_t i = 0; i < pool.idle.size(); ++i)
+            if (pool.idle[i]->device == dev) {
+                slot = pool.idle[i];
+                pool.idle[i] = pool.idle.back();
+                pool.idle.pop_back();
+                break;
+            }
+    }
+    if (!slot) slot = new HostPipe();
+    return *slot;
 }
 // A batch that needed more than this keeps only this much device memory afterwards (a 1e9-query batch is 22 GB of
 // staging; the next 1M-query call should not find a thread holding on to it).  GTARS_PIPE_KEEP_MB overrides.
@@ -1489,6 +1573,10 @@ static gtars_status hip_try(hipError_t e, const char *what) {
 // offsets[nq + 1] and up to ids_capacity ids into caller memory; *out_n = hits.  ids may be null (offsets only).
 static gtars_status tokenize_pipeline(const gtars_index_t *ix, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, u64 *offsets,
                                       u32 *ids, u64 ids_capacity, u64 *out_n) {
+    // HIP's current device belongs to the host THREAD and starts at 0: a helper thread of the caller (the fragment pipeline's
+    // wave tokenizer) would otherwise stage and launch on device 0 with an index that lives on device k
+    DeviceScope on_index_device(ix->device);
+    if (on_index_device.st) return on_index_device.st;
     HostPipe &hp = tls_host_pipe();
     gtars_status st = hp.init();
     if (st) return st;
@@ -2314,6 +2402,9 @@ void gtars_igd_free(gtars_igd_t *g) {
     g->tile_pm.release();
     g->tile_files16.release();
     g->tile_tab.release();
+    g->tile_ends_sorted.release();
+    g->tile_erank.release();
+    g->tile_tab_r.release();
     g->chrom_ntiles.release();
     g->route_lut.release();
     g->route_base.release();

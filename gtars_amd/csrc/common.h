@@ -317,6 +317,10 @@ struct IgdTiles {
     const i32 *pm;                   // [n] prefix maximum of the ends over the chromosome's records up to each record
     const unsigned short *files16;   // [n] file ids as u16 (null when n_files > 65535: such a database is never swept)
     const u32 *tab;                  // [n_tiles * IGD_TILE_TAB_WORDS] descriptor + two search tables per tile
+    // rank-histogram form of the sweep (k_igd_sweep_rank, round 5), per tile a block of IGD_TILE_BLOCK slots (null: not built):
+    const i32 *ends_sorted;          // the ends of the tile's staged records (tile + halo) in ascending order, padded with INT_MAX
+    const unsigned short *erank;     // slot (p0 & 3) + i: position of staged record i's end in that order
+    const u32 *tab_r;                // [n_tiles * IGD_TILE_TABR_WORDS] descriptor + the search tables over the starts and the sorted ends
     // static routing table (owner tile of a query): entry route_base[c] + j (u16, packed two per word) = first tile of
     // chromosome c whose ownership bound is > (j << route_shift); route_len[c] = the chromosome's last bound (0: no tiles);
     // null when the database has more than 65535 tiles
@@ -346,6 +350,16 @@ constexpr u32 IGD_LUT_S_NB = IGD_LUT_S_BUCKETS, IGD_LUT_P_NB = IGD_LUT_P_BUCKETS
 static_assert((IGD_LUT_S_NB & (IGD_LUT_S_NB - 1)) == 0 && IGD_LUT_S_NB >= 256 && IGD_LUT_S_NB <= 4096, "a power of two");
 static_assert((IGD_LUT_P_NB & (IGD_LUT_P_NB - 1)) == 0 && IGD_LUT_P_NB >= 256 && IGD_LUT_P_NB <= 4096, "a power of two");
 constexpr u32 IGD_TILE_TAB_WORDS = (12 + (IGD_LUT_S_NB + 2) / 2 + (IGD_LUT_P_NB + 2) / 2 + 3) / 4 * 4;  // 784 words: 3 KB per 2048 records
+// the rank-histogram sweep's per-tile data: IGD_TILE_BLOCK = staged records (tile + halo) rounded up to whole 16-byte vectors
+// behind a <= 3-slot alignment shift; its tables: a 12-word descriptor + two search tables of IGD_LUT_R_NB buckets
+#ifndef GTARS_IGD_HALO
+#define GTARS_IGD_HALO 256  // records staged behind a tile's own (a query's scan runs on into them; beyond: global memory, by the query's lane)
+#endif
+constexpr u32 IGD_TILE_BLOCK = 2048 + GTARS_IGD_HALO + 4;
+constexpr u32 IGD_LUT_R_NB = 1024;
+constexpr u32 IGD_TILE_TABR_WORDS = (12 + 2 * ((IGD_LUT_R_NB + 2) / 2) + 3) / 4 * 4;
+gtars_status launch_igd_tile_tables_rank(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom, u32 n_tiles,
+                                         i32 *ends_sorted, unsigned short *erank, u32 *tab_r, hipStream_t st);
 gtars_status launch_igd_tile_tables(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom,
                                     const i32 *tile_carry, u32 n_tiles, i32 *pm, unsigned short *files16, u32 *tile_tab, hipStream_t st);
 size_t igd_route_fine_lds_bytes(u32 n_tiles, u32 n_chrom, u64 n_fine);  // LDS of the routing kernel with the fine tables
@@ -381,6 +395,7 @@ struct ProfScope {
     bool on = false;
 };
 // profiling mode only: counts one launch of entry `if_set` / `if_clear` by the state of a device word (synchronises `st`)
+void prof_note_fact(const char *name);  // profiling mode only: counts one launch of the entry
 void prof_note_device_flag(const char *if_set, const char *if_clear, const u32 *d_flag, hipStream_t st);
 
 }  // namespace gtars

@@ -27,15 +27,13 @@
 namespace gtars {
 
 #ifndef GTARS_IGD_ABLATE
-#define GTARS_IGD_ABLATE 0  // timing experiments (results wrong): 1 one record per query, 2 no histogram atomics, 4 no prefix-max scan, 8 no queries, 16 no searches
+#define GTARS_IGD_ABLATE 0  // timing experiments (results wrong): 1 one record per query, 2 no histogram atomics, 4 no prefix-max scan, 8 no queries, 16 no searches, 32 (rank form) no prefix sums / adds
 #endif
 constexpr int IGD_TILE = (int)IGD_TILE_RECORDS;
 constexpr int SW_TPB = 512;
 
-#ifndef GTARS_IGD_HALO
-#define GTARS_IGD_HALO 256  // records staged behind a tile's own (a query's scan runs on into them; beyond: global memory, by the query's lane)
-#endif
-constexpr int IGD_HALO = GTARS_IGD_HALO;
+constexpr int IGD_HALO = GTARS_IGD_HALO;  // (common.h)
+static_assert(IGD_TILE_BLOCK == (u32)(IGD_TILE + IGD_HALO + 4) && IGD_TILE_RECORDS == 2048, "common.h states the block size");
 #ifndef IGD_STAMPS
 #define IGD_STAMPS 0  // diagnostic build: per-phase shader-clock totals of wave 0 of every workgroup (tools/r03_sweep_stamps.py)
 #endif
@@ -1228,6 +1226,450 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
 }
 
 
+// ---- the rank-histogram sweep (round 5): pairwise counts for min_overlap == 1 without a candidate walk ------------------------
+// k_igd_sweep above walks every query's candidate records in LDS and adds every hit to its file's counter: ~21 LDS reads and ~15
+// LDS atomics on random banks per config-3 query, and the SQ counters say the LDS pipe is what bounds it (71 % busy, 40 % of that
+// bank conflicts).  For min_overlap == 1 a (query, record) pair is a hit iff  r.start < q.end  and  r.end > q.start, and since a
+// valid query has q.start < q.end and a stored record r.start < r.end (igd.rs:114-116, 514-517),  r.end <= q.start  implies
+// r.start < q.end.  So over the tile's staged records R and the queries Q it owns
+//     hits(r) = #{q : r.start < q.end} - #{q : r.end <= q.start}
+//             = #{q : a_q > r} - #{q : e_q > erank(r)},        a_q = #{r in R : r.start < q.end}   (a RANK among the starts),
+//                                                              e_q = #{r in R : r.end <= q.start}  (a RANK among the SORTED ends),
+// erank(r) = position of r's end in the tile's ends sorted ascending.  A query therefore costs two table-assisted searches and
+// TWO LDS atomics (histograms of a_q and e_q) whatever its number of hits; per tile two prefix sums turn the histograms into
+// PA[r] = #{q : a_q <= r} and PE[k] = #{q : e_q <= k}, hits(r) = PE[erank(r)] - PA[r], and one add per record with hits goes to
+// its file's counter.  What it needs from the database, built once per tile with the index (k_igd_tile_tables_rank): the staged
+// records' ends in ascending order, erank as u16, and search tables over the starts and the sorted ends -- 12 bytes per staged
+// record streamed (starts, sorted ends, u16 file ids, u16 eranks) instead of 10; the raw ends are not read at all.
+// Records past the staged range (scans longer than the halo) are counted by the query's own lane from global memory, as above.
+constexpr int TABR_DESC = 12;  // p0, cnt, chrom, n_lds, S0, S1, shift_s, E0, E1, shift_e, n_seg, -
+constexpr int LUT_NB_R = (int)IGD_LUT_R_NB;
+constexpr int TABR_LUT1 = (LUT_NB_R + 2) / 2;  // words of one table
+constexpr int TABR_WORDS = (int)IGD_TILE_TABR_WORDS;
+static_assert(TABR_WORDS >= TABR_DESC + 2 * TABR_LUT1, "common.h states the table size");
+
+__global__ void __launch_bounds__(SW_TPB)
+k_igd_tile_tables_rank(IgdView v, const u32 *__restrict__ tile_first, const u32 *__restrict__ tile_cnt, const u32 *__restrict__ tile_chrom,
+                       u32 n_tiles, i32 *__restrict__ ends_sorted, unsigned short *__restrict__ erank, u32 *__restrict__ tab_r) {
+    constexpr int CAP = IGD_TILE + IGD_HALO;
+    constexpr int NP = 4096;  // size of the sorting network (>= CAP, a power of two)
+    static_assert(CAP <= NP, "the network holds a tile and its halo");
+    __shared__ u64 key[NP];  // (end << 32) | staged index; padding sorts last
+    __shared__ i32 t_s[CAP];
+    __shared__ unsigned short lut_s[LUT_NB_R + 2], lut_e[LUT_NB_R + 2];
+    const u32 t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const u32 p0 = tile_first[t], cnt = tile_cnt[t], c = tile_chrom[t];
+    const u32 seg_hi = v.chrom_off[c + 1];
+    const u32 n = min((u32)CAP, seg_hi - p0);  // tile + halo, never past the chromosome
+    for (u32 i = threadIdx.x; i < (u32)NP; i += SW_TPB) key[i] = i < n ? ((u64)(u32)v.ends[p0 + i] << 32) | i : ~0ull;  // (ends > 0)
+    for (u32 i = threadIdx.x; i < n; i += SW_TPB) t_s[i] = v.starts[p0 + i];
+    __syncthreads();
+    for (u32 k = 2; k <= (u32)NP; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 i = threadIdx.x; i < (u32)NP; i += SW_TPB) {
+                const u32 x = i ^ j;
+                if (x > i) {
+                    const u64 a = key[i], b = key[x];
+                    if ((a > b) == ((i & k) == 0)) {
+                        key[i] = b;
+                        key[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const size_t blk = (size_t)t * IGD_TILE_BLOCK;
+    const u32 d4 = p0 & 3u;
+    for (u32 k = threadIdx.x; k < IGD_TILE_BLOCK; k += SW_TPB) {
+        ends_sorted[blk + k] = k < n ? (i32)(u32)(key[k] >> 32) : 0x7FFFFFFF;
+        if (k < d4 || k >= d4 + n) erank[blk + k] = 0;
+    }
+    for (u32 k = threadIdx.x; k < n; k += SW_TPB) erank[blk + d4 + (u32)(key[k] & 0xFFFFFFFFull)] = (unsigned short)k;
+    const i32 S0 = t_s[0], S1 = t_s[n - 1], E0 = (i32)(u32)(key[0] >> 32), E1 = (i32)(u32)(key[n - 1] >> 32);
+    const u32 sh_s = lut_shift<LUT_NB_R>((u32)(S1 - S0)), sh_e = lut_shift<LUT_NB_R>((u32)(E1 - E0));
+    {
+        const u32 last_s = (u32)(S1 - S0) >> sh_s, last_e = (u32)(E1 - E0) >> sh_e;
+        for (u32 b = threadIdx.x; b < (u32)LUT_NB_R + 2; b += SW_TPB) {
+            if (b > last_s) lut_s[b] = (unsigned short)n;
+            if (b > last_e) lut_e[b] = (unsigned short)n;
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n; i += SW_TPB) {
+        const i32 st = t_s[i], en = (i32)(u32)(key[i] >> 32);
+        const u32 bs1 = (u32)(st - S0) >> sh_s, be1 = (u32)(en - E0) >> sh_e;
+        u32 bs0 = 0, be0 = 0;
+        if (i) {
+            bs0 = ((u32)(t_s[i - 1] - S0) >> sh_s) + 1u;
+            be0 = ((u32)((i32)(u32)(key[i - 1] >> 32) - E0) >> sh_e) + 1u;
+        }
+        for (; bs0 <= bs1; ++bs0) lut_s[bs0] = (unsigned short)i;
+        for (; be0 <= be1; ++be0) lut_e[be0] = (unsigned short)i;
+    }
+    __syncthreads();
+    u32 *tab = tab_r + (size_t)t * TABR_WORDS;
+    if (threadIdx.x == 0) {
+        tab[0] = p0;
+        tab[1] = cnt;
+        tab[2] = c;
+        tab[3] = n;
+        tab[4] = (u32)S0;
+        tab[5] = (u32)S1;
+        tab[6] = sh_s;
+        tab[7] = (u32)E0;
+        tab[8] = (u32)E1;
+        tab[9] = sh_e;
+        tab[10] = seg_hi - p0;
+        tab[11] = 0;
+    }
+    for (u32 w = threadIdx.x; w < (u32)(2 * TABR_LUT1); w += SW_TPB) {
+        const unsigned short *src = w < (u32)TABR_LUT1 ? lut_s : lut_e;
+        const u32 k = w < (u32)TABR_LUT1 ? w : w - TABR_LUT1;
+        tab[TABR_DESC + w] = (u32)src[2 * k] | ((u32)src[2 * k + 1] << 16);
+    }
+}
+
+gtars_status launch_igd_tile_tables_rank(const IgdView &v, const u32 *tile_first, const u32 *tile_cnt, const u32 *tile_chrom, u32 n_tiles,
+                                         i32 *ends_sorted, unsigned short *erank, u32 *tab_r, hipStream_t st) {
+    if (!n_tiles) return GTARS_OK;
+    hipLaunchKernelGGL(k_igd_tile_tables_rank, dim3(n_tiles), dim3(SW_TPB), 0, st, v, tile_first, tile_cnt, tile_chrom, n_tiles, ends_sorted,
+                       erank, tab_r);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
+// One global_load_lds_dwordx4: 16 bytes per lane from the lane's own global address straight into LDS at (wave-uniform) `lds` +
+// lane x 16.  In inline assembly ON PURPOSE: the compiler knows nothing of these transfers, so it neither drains the vector-memory
+// queue in front of every later LDS read (it cannot tell which LDS bytes a transfer writes) nor turns its counted waits for
+// ordinary loads into vmcnt(0) while one is in flight (both seen in the listing of the builtin form).  The caller counts them.
+__device__ __forceinline__ void glds16(const void *g, const void *lds) {
+    const u32 base = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)lds);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(base) : "memory", "m0");
+}
+constexpr int RK_CAPV = IGD_TILE + IGD_HALO + 4;
+constexpr int RK_HW = (RK_CAPV / 2 + 3) / 4 * 4;  // words of one histogram: 16-bit counters two per word, whole 16-byte vectors
+constexpr u32 RK_SUB = 65024;                     // queries per histogram fill: what 16-bit counters hold (a multiple of SW_TPB)
+static_assert(RK_SUB % SW_TPB == 0 && RK_SUB <= 65535, "16-bit counters");
+size_t igd_sweep_rank_lds_bytes(u32 n_bins) { return ((size_t)RK_CAPV * 2 + (size_t)RK_HW * 2 + n_bins) * 4; }
+
+__global__ void __launch_bounds__(SW_TPB, 8)
+k_igd_sweep_rank(IgdView v, const unsigned short *__restrict__ files16, const i32 *__restrict__ ends_sorted,
+                 const unsigned short *__restrict__ erank, const u32 *__restrict__ tab_r, u32 n_tiles, const u32 *__restrict__ sqs,
+                 const u32 *__restrict__ sqe, int interleaved, const u32 *__restrict__ ql, const u32 *__restrict__ qh,
+                 unsigned long long *__restrict__ hits, const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab,
+                 const u32 *__restrict__ part_ql, u32 n_bins, const uint2 *__restrict__ heavy_list, const u32 *__restrict__ heavy_count,
+                 u32 heavy_part, u32 heavy_cap) {
+    extern __shared__ __attribute__((aligned(16))) u32 sm[];
+    if (part_flag && *part_flag) {  // (the batch was partitioned: see k_igd_sweep)
+        sqs = part_ab;
+        sqe = nullptr;
+        interleaved = 1;
+        ql = part_ql;
+        qh = part_ql + 1;
+    }
+    constexpr int CAPV = RK_CAPV;
+    constexpr u32 NW = SW_TPB / 64;
+    i32 *b_s = reinterpret_cast<i32 *>(sm);         // starts: slot j holds the record at (p0 & ~3) + j
+    i32 *b_e = b_s + CAPV;                          // the staged records' ends, ascending
+    u32 *ha = reinterpret_cast<u32 *>(b_e + CAPV);  // histogram of a_q over the starts' SLOTS, then its prefix sums inside a chunk
+    u32 *ge = ha + RK_HW;                           // histogram of e_q over the sorted ends, then its prefix sums inside a chunk
+    u32 *bins = ge + RK_HW;
+    constexpr u32 LUTV = (2 * TABR_LUT1 + 3) / 4;   // 16-byte vectors of the two search tables
+    static_assert(TABR_DESC % 4 == 0 && TABR_DESC + 4 * (int)LUTV <= TABR_WORDS, "the tables are copied as whole vectors of their row");
+    __shared__ __attribute__((aligned(16))) u32 s_lutw[4 * LUTV];
+    // chunks of 256 slots (a wave's four per lane): round 0 = waves 0 .. NW - 1, round 1 = the vectors beyond SW_TPB
+    constexpr u32 R1_WAVES = (RK_CAPV / 4 - SW_TPB + 63) / 64, NCH = NW + R1_WAVES;
+    static_assert(NCH <= 16, "the chunks' bases are scanned inside one DPP row");
+    __shared__ u32 s_tot[2][16];  // [array][chunk]: the chunks' totals of the two prefix sums
+    const unsigned short *lut_s = reinterpret_cast<const unsigned short *>(s_lutw);
+    const unsigned short *lut_e = reinterpret_cast<const unsigned short *>(s_lutw + TABR_LUT1);
+    for (u32 i = threadIdx.x; i < n_bins; i += SW_TPB) bins[i] = 0;
+    if (threadIdx.x < 32u) s_tot[threadIdx.x >> 4][threadIdx.x & 15u] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if IGD_STAMPS
+    u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+    const u32 n_heavy = heavy_part ? min(*heavy_count, heavy_cap) : 0u;
+    const u32 n_items = n_tiles + n_heavy;
+    auto request = [&](u32 item, u32 &tile, u32 &part) -> u32 {  // (as in k_igd_sweep: one vector load per wave)
+        tile = item;
+        part = 0;
+        if (item >= n_tiles) {
+            const uint2 hp = heavy_list[item - n_tiles];
+            tile = hp.x;
+            part = hp.y;
+        }
+        const u32 *__restrict__ src = lane < TABR_DESC ? tab_r + (size_t)tile * TABR_WORDS + lane : (lane == TABR_DESC ? ql : qh) + tile;
+        return lane < TABR_DESC + 2 ? *src : 0u;
+    };
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    typedef u32 v2u __attribute__((ext_vector_type(2)));
+    // A tile's starts, sorted ends and search tables go from global memory straight into LDS (global_load_lds_dwordx4: the
+    // destination is a wave-uniform base + lane x 16, so wave w always fills vectors [64 w, 64 w + 64) of an array -- its own
+    // region, tile after tile), REQUESTED while the previous tile's prefix sums and adds run: those three arrays are dead once
+    // the previous tile's queries are ranked.  The file ids and eranks of a thread's own slots (and the tile's first queries)
+    // follow into registers when the previous tile's are dead.  Nothing in the loop waits for a load it has just issued, and no
+    // barrier drains the vector-memory queue (lds_barrier; the one explicit vmcnt(0) sits at the top of a tile).
+    i32 pf_s = 0, pf_e = 0;
+    auto issue_dma = [&](u32 tile, u32 p0, u32 n_lds, u32 q_lo, u32 q_hi) {
+        const u32 d4 = p0 & 3u, nv4 = (n_lds + d4 + 3u) >> 2, nv4e = (n_lds + 3u) >> 2;
+        const u32 *g_s = reinterpret_cast<const u32 *>(v.starts + (p0 - d4));
+        const u32 *g_e = reinterpret_cast<const u32 *>(ends_sorted + (size_t)tile * IGD_TILE_BLOCK);
+        const u32 *g_t = tab_r + (size_t)tile * TABR_WORDS + TABR_DESC;
+#pragma unroll
+        for (u32 k = 0; k < 2; ++k) {
+            const u32 v0 = k * SW_TPB + (u32)wave * 64u, q = v0 + (u32)lane;  // (v0: wave-uniform)
+            if (k == 0 || (u32)wave < R1_WAVES) {
+                if (q < nv4) glds16(g_s + 4u * q, b_s + 4 * v0);
+                if (q < nv4e) glds16(g_e + 4u * q, b_e + 4 * v0);
+            }
+        }
+        {
+            const u32 v0 = (u32)wave * 64u, q = v0 + (u32)lane;
+            if (v0 < LUTV && q < LUTV) glds16(g_t + 4u * q, s_lutw + 4 * v0);
+        }
+        // the tile's first SW_TPB queries (the previous tile's are ranked): ONE code path for pairs and for columns -- two loads
+        // from selected addresses; a branch per form made the compiler wait for everything in flight between its arms.  (Raw
+        // values: the start clamp of a column batch is applied where they are used -- here it would be a wait for the load.)
+        const u32 qi = q_lo + threadIdx.x;
+        pf_s = pf_e = 0;
+        if (qi < q_hi) {
+            const u32 *ps = interleaved ? sqs + 2u * (size_t)qi : sqs + qi;
+            const u32 *pe = interleaved ? sqs + 2u * (size_t)qi + 1 : sqe + qi;
+            pf_s = (i32)*ps;
+            pf_e = (i32)*pe;
+        }
+    };
+    // File ids and eranks of this thread's slots: ALWAYS two loads (four in the waves that own a second vector), from a clamped
+    // address when the thread's vector lies behind the tile -- the wait at the top of a tile counts them (they are the youngest
+    // operations in flight there and are only needed when the tile's sums are done)
+    v2u rf[2], rr[2];
+    auto issue_regs = [&](u32 tile, u32 p0, u32 n_lds) {
+        const u32 d4 = p0 & 3u, nv4 = (n_lds + d4 + 3u) >> 2;
+        const v2u *g_f = reinterpret_cast<const v2u *>(files16 + (p0 - d4));
+        const v2u *g_r = reinterpret_cast<const v2u *>(erank + (size_t)tile * IGD_TILE_BLOCK);
+#pragma unroll
+        for (u32 k = 0; k < 2; ++k) {
+            if (k == 0 || (u32)wave < R1_WAVES) {
+                const u32 q = min(threadIdx.x + k * SW_TPB, nv4 - 1u);
+                rf[k] = g_f[q];
+                rr[k] = g_r[q];
+            }
+        }
+    };
+    const bool two_vectors = (u32)wave < R1_WAVES;  // (uniform)
+    auto item_queries = [&](u32 desc, u32 part, u32 &q_lo, u32 &q_hi) {
+        q_lo = (u32)__builtin_amdgcn_readlane((int)desc, TABR_DESC);
+        q_hi = (GTARS_IGD_ABLATE & 8) ? q_lo : (u32)__builtin_amdgcn_readlane((int)desc, TABR_DESC + 1);
+        if (heavy_part) {
+            q_lo = min(q_hi, q_lo + part * heavy_part);
+            q_hi = min(q_hi, q_lo + heavy_part);
+        }
+    };
+    // first index in [0, n) of an ascending LDS array with arr[i] >= x: bracket from the table, then four elements at once
+    auto bracket = [&](const i32 *arr, const unsigned short *lut, i32 x, i32 k0, i32 k1, u32 sh, u32 n, u32 &a, u32 &b) {
+        lut_range(lut, x, k0, k1, sh, n, a, b);
+        while (b - a > 4u) {  // (2.25 records per bucket on average)
+            const u32 m2 = a + ((b - a) >> 1);
+            if (arr[m2] < x)
+                a = m2 + 1;
+            else
+                b = m2;
+        }
+    };
+    typedef i32 i4 __attribute__((ext_vector_type(4)));
+    typedef i4 i4_a4 __attribute__((aligned(4)));
+    typedef const __attribute__((address_space(3))) i4_a4 *lds_i4;
+    auto below = [&](const i4 &y0, i32 x, u32 nb) -> u32 {  // how many of the bracket's nb <= 4 ascending elements are < x
+        return (nb > 0 && y0.x < x ? 1u : 0u) + (nb > 1 && y0.y < x ? 1u : 0u) + (nb > 2 && y0.z < x ? 1u : 0u) + (nb > 3 && y0.w < x ? 1u : 0u);
+    };
+    u32 c_tile = 0, c_part = 0, c_desc = 0;
+    if (blockIdx.x < n_items) {
+        c_desc = request(blockIdx.x, c_tile, c_part);
+        u32 q_lo, q_hi;
+        item_queries(c_desc, c_part, q_lo, q_hi);
+        const u32 p0 = (u32)__builtin_amdgcn_readlane((int)c_desc, 0), n_lds = (u32)__builtin_amdgcn_readlane((int)c_desc, 3);
+        issue_dma(c_tile, p0, n_lds, q_lo, q_hi);
+        issue_regs(c_tile, p0, n_lds);
+    } else {
+        rf[0] = rf[1] = rr[0] = rr[1] = v2u{0, 0};
+    }
+    __syncthreads();  // the bins are zero
+    for (u32 item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const u32 desc = c_desc;
+        auto word = [&](int k) -> u32 { return (u32)__builtin_amdgcn_readlane((int)desc, k); };
+        const u32 p0 = word(0), n_lds = word(3), n_seg = word(10), sh_s = word(6), sh_e = word(9);
+        const i32 S0 = (i32)word(4), S1 = (i32)word(5), E0 = (i32)word(7), E1 = (i32)word(8);
+        u32 q_lo, q_hi;
+        item_queries(desc, c_part, q_lo, q_hi);
+        const bool has_next = item + gridDim.x < n_items;
+        // this tile's arrays are in LDS (this wave's share) and its first queries in registers: everything but the youngest two /
+        // four loads -- the file ids and eranks, which the end of the tile needs
+        if (two_vectors)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        u32 n_tile = 0, n_part = 0, n_desc = 0;
+        if (has_next) n_desc = request(item + gridDim.x, n_tile, n_part);
+        u32 nq_lo = 0, nq_hi = 0, np0 = 0, nn_lds = 0;
+        auto decode_next = [&]() {
+            item_queries(n_desc, n_part, nq_lo, nq_hi);
+            np0 = (u32)__builtin_amdgcn_readlane((int)n_desc, 0);
+            nn_lds = (u32)__builtin_amdgcn_readlane((int)n_desc, 3);
+        };
+        const u32 d4 = p0 & 3u;
+        const i32 *t_s = b_s + d4;
+        const u32 nv4 = (n_lds + d4 + 3u) >> 2;
+        STAMP(0);
+        const bool asked = q_lo < q_hi;  // (uniform) does anybody ask about this tile?  if not, only the next one's loads are issued
+        u32 sub = q_lo;
+        do {  // rounds of RK_SUB queries: one for all but monstrous tiles
+            const u32 sub_hi = min(q_hi, sub + RK_SUB);
+            const bool last_sub = sub + RK_SUB >= q_hi;
+            if (asked) {
+            for (u32 i = threadIdx.x; i < (u32)(2 * RK_HW / 4); i += SW_TPB) reinterpret_cast<v4u *>(ha)[i] = v4u{0, 0, 0, 0};  // ha | ge
+            lds_barrier();  // every wave's share of the tile is in LDS, the histograms are zero
+            STAMP(1);
+            for (u32 qb = sub; qb < sub_hi; qb += SW_TPB) {
+                const u32 qi = qb + threadIdx.x;
+                if (qi < sub_hi) {
+                    i32 s, e;
+                    if (qb == q_lo) {
+                        s = interleaved ? pf_s : max(pf_s, 0);
+                        e = pf_e;
+                    } else if (interleaved) {
+                        const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
+                        s = (i32)se2.x;
+                        e = (i32)se2.y;
+                    } else {
+                        s = max((i32)sqs[qi], 0);
+                        e = (i32)sqe[qi];
+                    }
+                    // a = staged records that start before the query's end, k = ... that end at or before its start; the two
+                    // searches side by side (their LDS round trips overlap)
+                    u32 a, ab, k, kb;
+                    bracket(t_s, lut_s, e, S0, S1, sh_s, n_lds, a, ab);
+                    bracket(b_e, lut_e, s + 1, E0, E1, sh_e, n_lds, k, kb);
+                    const i4 ya0 = *(lds_i4)(uintptr_t)(t_s + a);
+                    const i4 yk0 = *(lds_i4)(uintptr_t)(b_e + k);
+                    a += below(ya0, e, ab - a);
+                    k += below(yk0, s + 1, kb - k);
+                    const u32 as = a + d4;
+                    atomicAdd(&ha[as >> 1], 1u << ((as & 1u) * 16u));
+                    atomicAdd(&ge[k >> 1], 1u << ((k & 1u) * 16u));
+                    if (a == n_lds && n_seg > n_lds) {
+                        // the scan runs past the staged records: the rest from global memory, by this lane
+                        for (u32 r = n_lds; r < n_seg; ++r) {
+                            const i32 rs = v.starts[p0 + r];
+                            if (rs >= e) break;
+                            if (v.ends[p0 + r] > s) atomicAdd(&bins[v.files[p0 + r] & IGD_FILE_MASK], 1u);
+                        }
+                    }
+                }
+            }
+            STAMP(2);
+            lds_barrier();  // the histograms are complete; the starts, sorted ends and tables are dead
+            STAMP(3);
+            }
+            // (the compiler's own wait for the file ids and eranks belongs HERE, in front of the transfers it does not count -- on
+            // every path: placed at their use, behind the transfers, it would wait for those as well)
+            asm volatile("" : "+v"(rf[0]), "+v"(rf[1]), "+v"(rr[0]), "+v"(rr[1]));
+            if (last_sub && has_next) {
+                decode_next();
+                issue_dma(n_tile, np0, nn_lds, nq_lo, nq_hi);
+            }
+            if (asked) {
+            // Inclusive prefix sums over the slots, in place: thread q owns the four slots of vector q (and of vector q + SW_TPB);
+            // a wave's 256 slots are a CHUNK: sums inside the chunk now, the chunks' bases after the barrier.  (Everything goes
+            // back to LDS in between: keeping both vectors' eight sums of both arrays in registers across the barrier spilled.)
+#pragma unroll
+            for (u32 k = 0; k < ((GTARS_IGD_ABLATE & 32) ? 0u : 2u); ++k) {
+                const u32 q = threadIdx.x + k * SW_TPB;
+                if (k == 0 || (u32)wave < R1_WAVES) {  // (uniform per wave: the second round is one or two waves)
+                    v2u wa = v2u{0, 0}, we = v2u{0, 0};
+                    if (q < nv4) {
+                        wa = reinterpret_cast<const v2u *>(ha)[q];
+                        we = reinterpret_cast<const v2u *>(ge)[q];
+                    }
+                    const u32 a0 = wa.x & 0xFFFFu, a1 = a0 + (wa.x >> 16), a2 = a1 + (wa.y & 0xFFFFu), a3 = a2 + (wa.y >> 16);
+                    const u32 e0 = we.x & 0xFFFFu, e1 = e0 + (we.x >> 16), e2 = e1 + (we.y & 0xFFFFu), e3 = e2 + (we.y >> 16);
+                    const u32 ta = wave_inclusive_scan_u32(a3, lane), te = wave_inclusive_scan_u32(e3, lane);
+                    const u32 xa = ta - a3, xe = te - e3;  // what the lanes in front of this one hold
+                    if (q < nv4) {
+                        reinterpret_cast<v2u *>(ha)[q] = v2u{(a0 + xa) | ((a1 + xa) << 16), (a2 + xa) | ((a3 + xa) << 16)};
+                        reinterpret_cast<v2u *>(ge)[q] = v2u{(e0 + xe) | ((e1 + xe) << 16), (e2 + xe) | ((e3 + xe) << 16)};
+                    }
+                    if (lane == 63) {
+                        s_tot[0][k * NW + (u32)wave] = ta;
+                        s_tot[1][k * NW + (u32)wave] = te;
+                    }
+                }
+            }
+            lds_barrier();
+            STAMP(4);
+            // the chunks' exclusive bases, every wave for itself: lanes 0..15 hold array 0's, lanes 16..31 array 1's (four DPP steps
+            // inside a row of 16 lanes)
+            u32 base;
+            {
+                const u32 x = lane < 32 ? s_tot[lane >> 4][lane & 15] : 0u;  // (totals of chunks that do not exist are zero)
+                u32 inc = x;
+                inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);  // row_shr:1
+                inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);  // row_shr:2
+                inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);  // row_shr:4
+                inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);  // row_shr:8
+                base = inc - x;
+            }
+            STAMP(5);
+            const unsigned short *pe16 = reinterpret_cast<const unsigned short *>(ge);
+#pragma unroll
+            for (u32 k = 0; k < ((GTARS_IGD_ABLATE & 32) ? 0u : 2u); ++k) {
+                const u32 q = threadIdx.x + k * SW_TPB;
+                if (k == 0 || (u32)wave < R1_WAVES) {
+                    const u32 base_a = (u32)__builtin_amdgcn_readlane((int)base, (int)(k * NW) + wave);
+                    v2u wa = v2u{0, 0};
+                    if (q < nv4) wa = reinterpret_cast<const v2u *>(ha)[q];
+                    const u32 pa[4] = {wa.x & 0xFFFFu, wa.x >> 16, wa.y & 0xFFFFu, wa.y >> 16};
+                    const u32 er[4] = {rr[k].x & 0xFFFFu, rr[k].x >> 16, rr[k].y & 0xFFFFu, rr[k].y >> 16};
+                    const u32 fi[4] = {rf[k].x & 0xFFFFu, rf[k].x >> 16, rf[k].y & 0xFFFFu, rf[k].y >> 16};
+                    u32 pe[4], be[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pe[j] = pe16[er[j]];  // (er = 0 for slots without a record: a valid address)
+                        be[j] = (u32)__builtin_amdgcn_ds_bpermute((int)(4u * (16u + (er[j] >> 8))), (int)base);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u32 i = 4u * q + (u32)j - d4;  // staged record of this slot (wraps for the slots in front of the tile)
+                        // hits(r) = #{q : e_q <= erank(r)} - #{q : a_q <= r}
+                        const u32 c = (pe[j] + be[j]) - (pa[j] + base_a);
+                        if (q < nv4 && i < n_lds && c) atomicAdd(&bins[fi[j]], c);
+                    }
+                }
+            }
+            }
+            if (last_sub && has_next) issue_regs(n_tile, np0, nn_lds);
+            if (asked) lds_barrier();  // the histograms may be overwritten
+            STAMP(6);
+            sub += RK_SUB;
+        } while (sub < q_hi);
+        c_desc = n_desc;
+        c_tile = n_tile;
+        c_part = n_part;
+    }
+#if IGD_STAMPS
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_sweep_stamps[k], st_acc[k]);
+        atomicAdd(&g_sweep_stamps[7], 1ull);
+    }
+#endif
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n_bins; i += SW_TPB) {
+        const u32 b = bins[i];
+        if (b) atomicAdd(&hits[i], (unsigned long long)b);
+    }
+}
+
 // ---- pme_file: per record, the largest end among the EARLIER records of the same file on the same chromosome ----
 // Built once per database on the device (first binary count): a stable radix sort of the record positions by file id
 // groups every (file, chromosome) run in stored order, a segmented exclusive prefix maximum runs over the ends in that
@@ -1624,6 +2066,36 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     if (v.pieces) {
         if (mode == 1 || !mo1) return fail(GTARS_ERR_INTERNAL, "IGD sweep: a pieces view serves min_overlap == 1 only");
         kern = mode == 2 ? (b16 ? k_igd_sweep<2, true, true, true> : k_igd_sweep<2, true, false, true>) : k_igd_sweep<0, true, false, true>;
+    }
+    const bool rank_form = mode == 0 && mo1 && !v.pieces && !set_bounds && tl.ends_sorted && tl.erank && tl.tab_r &&
+                           !cfg_flag("GTARS_IGD_NO_RANK");
+    if (rank_form) {
+        // pairwise counts, min_overlap == 1: the rank-histogram form (no candidate walk)
+        const size_t lds_r = igd_sweep_rank_lds_bytes(n_bins);
+        {
+            static std::mutex mu;
+            static bool done[64] = {};
+            std::lock_guard<std::mutex> lock(mu);
+            if (dev >= 0 && dev < 64 && !done[dev]) {
+                GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_igd_sweep_rank), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)igd_sweep_rank_lds_bytes(16384)));
+                done[dev] = true;
+            }
+        }
+        int per_cu = 1;
+        GT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_igd_sweep_rank, SW_TPB, lds_r));
+        if (per_cu < 1) return fail(GTARS_ERR_INTERNAL, "k_igd_sweep_rank does not fit on a CU");
+        const unsigned grid = (unsigned)std::min<u64>((u64)cus * per_cu, n_tiles);
+        {
+            ProfScope p("k_igd_sweep<pairwise>", st);
+            hipLaunchKernelGGL(k_igd_sweep_rank, dim3(grid), dim3(SW_TPB), lds_r, st, v, tl.files16, tl.ends_sorted, tl.erank, tl.tab_r, n_tiles,
+                               ss, se, interleaved, t_ql, t_qh, (unsigned long long *)hits, part_flag, part_ab, part_ql, n_bins,
+                               (const uint2 *)heavy.list, (const u32 *)heavy.count, heavy.part, heavy.cap);
+        }
+        GT_HIP(hipGetLastError());
+        prof_note_fact("igd_sweep_rank_form");
+        if (routed) prof_note_device_flag("igd_batch_partitioned", "igd_batch_in_owner_order", d_unsorted, st);
+        return GTARS_OK;
     }
     {
         // the dynamic-LDS limit belongs to the function, not to the calling thread: raised once per device to the largest

@@ -247,9 +247,10 @@ k_ms_scatter(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
 }
 
 u32 multisplit_workgroups(u32 n) {
-    // one persistent-sized grid: chunks of at least 16k elements, at most 256 workgroups
+    // one persistent-sized grid: chunks of at least 16k elements, at most 256 workgroups -- unless a chunk would then exceed what
+    // a counting caller's 16-bit counters hold (65532 elements: batches beyond 16.7M elements take more workgroups, which queue)
     const u32 by_size = (n + 16383) / 16384;
-    return std::max<u32>(1, std::min<u32>(256, by_size));
+    return std::max<u32>(std::max<u32>(1, std::min<u32>(256, by_size)), (u32)(((u64)n + 65531u) / 65532u));
 }
 
 // ---- two-level split with tiles reordered in LDS -------------------------------------------------------------
@@ -462,11 +463,12 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
     }
 }
 
-// table [256][n_bins] | tot [n_bins] | cursors (coarse [1024], fine [n_bins]) | first-level output: keys [n], pairs [n]
+// table [max(256, n / 65532 + 2)][n_bins] | tot [n_bins] | cursors (coarse [1024], fine [n_bins]) | first-level output: keys [n], pairs [n]
 // (the table region also holds a table_ready caller's rows of packed 16-bit counts: one row per counting workgroup -- at most
 // max(512, n / 65532 + 2) of them, a workgroup counts <= 65535 elements -- of multisplit_row_words(n_bins) words)
 static size_t multisplit_table_words(u32 n_bins, u32 n) {
-    return std::max<size_t>((size_t)256 * n_bins, (size_t)std::max<u32>(512u, n / 65532u + 2u) * multisplit_row_words(n_bins));
+    return std::max<size_t>((size_t)std::max<u32>(256u, n / 65532u + 2u) * n_bins,
+                            (size_t)std::max<u32>(512u, n / 65532u + 2u) * multisplit_row_words(n_bins));
 }
 size_t multisplit_ws_bytes(u32 n_bins, u32 n) {
     return (multisplit_table_words(n_bins, n) + 2 * (size_t)n_bins + 1024 + 256) * 4 + (size_t)n * 12 + 256;

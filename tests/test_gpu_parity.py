@@ -1726,6 +1726,102 @@ def test_igd_packed_counter_flush_and_many_routing_workgroups(ga, monkeypatch):
     assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F))
 
 
+def test_igd_rank_histogram_sweep(ga, monkeypatch):
+    """Round 5: pairwise counts with min_overlap == 1 sweep without a candidate walk -- per query two ranks (among the tile's
+    starts, among its SORTED ends) into two LDS histograms, per tile two prefix sums and one add per record
+    (k_igd_sweep_rank; igd.rs:504-556, 753-847 is what it must reproduce).  Against the oracle's literal tile walk and against
+    the walked sweep, on databases that reach every branch: chromosomes shorter than a tile, tiles cut by the chromosome's end,
+    duplicate and nested records, records far longer than the halo (the per-lane global scan), equal starts and equal ends
+    across tile borders, one tile that owns > 65k queries with and without heavy-tile parts (the 16-bit histograms are filled
+    in rounds), batches in order and shuffled, invalid / clamped / unknown-chromosome queries."""
+    monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
+    rng = np.random.default_rng(505)
+    _lib = ga._lib
+
+    def check(g, o, qc, qs, qe, F, label):
+        want = o.count_set_overlaps(qc, qs, qe, 1, n_files=F)
+        _lib.lib.gtars_prof_reset()
+        _lib.lib.gtars_prof_enable(1)
+        got = g.count_set_overlaps(qc, qs, qe, 1)
+        facts = _lib.prof_read()
+        _lib.lib.gtars_prof_enable(0)
+        assert "igd_sweep_rank_form" in facts, (label, sorted(facts))
+        assert np.array_equal(got, want), label
+        monkeypatch.setenv("GTARS_IGD_NO_RANK", "1")
+        assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), want), label + " (walked)"
+        monkeypatch.delenv("GTARS_IGD_NO_RANK")
+        order = np.lexsort((qs.astype(np.int64), qc))  # in (chromosome, start) order: the sweep takes the batch as it lies
+        assert np.array_equal(g.count_set_overlaps(qc[order], qs[order], qe[order], 1), want), label + " (in order)"
+
+    # (1) many shapes of database: 5 chromosomes of very different sizes (one with 3 records, one with exactly 2048, one with 2049)
+    sizes = [3, 2048, 2049, 30_000, 7000]
+    c = np.concatenate([np.full(k, i) for i, k in enumerate(sizes)])
+    n = len(c)
+    span = 400_000
+    s = rng.integers(0, span, n)
+    w = rng.integers(1, 900, n)
+    w[rng.integers(0, n, 40)] = rng.integers(20_000, 300_000, 40)  # longer than the halo's reach: the global scan
+    e = s + w
+    dup = rng.integers(0, n, 2000)  # duplicates: equal starts AND equal ends (ranks with ties)
+    s[dup[:1000]] = s[dup[1000:]]
+    e[dup[:1000]] = e[dup[1000:]]
+    keep = c[dup[:1000]] == c[dup[1000:]]
+    s[dup[:1000][~keep]] += 1
+    e = np.maximum(e, s + 1)
+    F = 37
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=len(sizes), n_files=F)
+    nq = 150_000
+    qc = rng.integers(0, len(sizes) + 1, nq)
+    qc = np.where(qc >= len(sizes), UNK, qc)
+    qs = rng.integers(0, span + 5000, nq).astype(np.int64)
+    qe = qs + rng.integers(0, 3000, nq)
+    qs[:30] = 0xFFFFFFF0  # negative as i32: clamped to 0
+    qe[:30] = rng.integers(1, span, 30)
+    qe[30:60] = 0  # rejected
+    qe[60:90] = qs[60:90] + 200_000  # very wide queries
+    monkeypatch.setenv("GTARS_IGD_NO_PIECES", "1")  # (long records would send the min_overlap == 1 counts to the pieces view)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=len(sizes), n_files=F)
+    check(g, o, qc, qs, qe, F, "shapes")
+    monkeypatch.delenv("GTARS_IGD_NO_PIECES")
+    # (2) equal starts / equal ends in long runs across tile borders (5000 records share 3 starts and 4 ends)
+    n = 9000
+    c = np.zeros(n, dtype=np.int64)
+    s = np.sort(rng.choice([1000, 1000, 5000, 9000], n))
+    e = s + rng.choice([10, 4000, 4000, 9000], n)
+    f = rng.integers(0, 5, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=1, n_files=5)
+    qc = np.zeros(70_000, dtype=np.int64)
+    qs = rng.integers(0, 20_000, 70_000).astype(np.int64)
+    qe = qs + rng.integers(1, 6000, 70_000)
+    check(g, o, qc, qs, qe, 5, "ties")
+    # (3) one tile owns > 65k queries: with heavy-tile parts, and as ONE item (histograms filled in rounds of 65024 queries)
+    n, span = 6_000, 3_000_000
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 800, n)
+    c = np.zeros(n, dtype=np.int64)
+    f = rng.integers(0, 700, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=1, n_files=700)
+    qc, qs, qe = _random_query_set(rng, 400_000, 1, span + 2_000, 500)
+    qs[:150_000] = rng.integers(1_000_000, 1_050_000, 150_000)  # 150k queries inside one 50-kb window
+    qe[:150_000] = qs[:150_000] + rng.integers(1, 500, 150_000)
+    check(g, o, qc, qs, qe, 700, "heavy parts")
+    monkeypatch.setenv("GTARS_IGD_NO_HEAVY_PARTS", "1")
+    check(g, o, qc, qs, qe, 700, "one heavy item")
+    monkeypatch.delenv("GTARS_IGD_NO_HEAVY_PARTS")
+    # a database without the rank tables keeps the walk
+    monkeypatch.setenv("GTARS_IGD_NO_RANK_TABLES", "1")
+    g2 = ga.IgdIndex(c, s, e, f, np.arange(n), n_chrom=1, n_files=700)
+    monkeypatch.delenv("GTARS_IGD_NO_RANK_TABLES")
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    got = g2.count_set_overlaps(qc, qs, qe, 1)
+    facts = _lib.prof_read()
+    _lib.lib.gtars_prof_enable(0)
+    assert "igd_sweep_rank_form" not in facts
+    assert np.array_equal(got, o.count_set_overlaps(qc, qs, qe, 1, n_files=700))
+
+
 def test_igd_routing_with_tile_bounds_in_global_memory(ga, monkeypatch):
     """Databases beyond ~52M records route their queries with the tile bounds in global memory instead of LDS (k_igd_route<.,
     false>; up to 65534 tiles = 134M records), and beyond 36863 tiles the split is two-level whatever the batch size.  Forced
