@@ -677,6 +677,12 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
 
 # ------------------------------------------------------------------------------------------------ N > 1
 
+def _lib_host_threads() -> int:
+    from gtars_amd import _lib
+
+    return _lib.lib.gtars_host_threads(64)
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` started plainly: start the N ranks as a child torch.distributed.run (this process has
     not touched a GPU: torch.cuda.device_count() does not initialise one on this image) and return its exit code."""
@@ -697,6 +703,80 @@ def spawn_ranks(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GTARS_BENCH_SPAWNED="1")).returncode
+
+
+STRONG_NOTE = ("strong scaling of a 0.2-0.4 ms single-GPU call: at 8 ranks a rank's share is ~50 us of kernels, so the host-wall figure is "
+               "barrier + all-reduce latency; read per_rank_ms (device time by HIP events, collective time apart) and the *_weak objects "
+               "for what the GPUs do")
+
+
+def timed_sharded_calls(dist, world, barrier, max_over_ranks, call, reps=7):
+    """`call(timing_dict)` once untimed, then `reps` times between barriers: -> (median host wall seconds incl. the collective, max
+    over ranks; per rank: median device ms of its kernels by HIP events and median ms its stream then spends in the collective)"""
+    call(None)
+    times, dev_ms, coll_ms = [], [], []
+    for _ in range(reps):
+        tm = {}
+        barrier()
+        t0 = time.perf_counter()
+        call(tm)
+        barrier()
+        times.append(max_over_ranks(time.perf_counter() - t0))
+        dev_ms.append(tm.get("device_ms", 0.0))
+        coll_ms.append(tm.get("collective_ms", 0.0))
+    mine = {"device_ms": round(statistics.median(dev_ms), 4), "collective_ms": round(statistics.median(coll_ms), 4)}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    return statistics.median(times), per_rank
+
+
+def bench_igd_weak(dist, backend, dev, rank, world, max_over_ranks, barrier, scale=1):
+    """Config 3 weak-scaled: the GENOME grows with the ranks.  Rank r owns chromosomes 25 r .. 25 r + 24 of a (25 x world)-chromosome
+    genome -- the chromosome-bucket sharding of north_star with buckets of equal weight -- with config 3's 5e7 database records and
+    1e7 queries of its own on them (rank r's seeds: 6 + 2 r / 7 + 2 r, so rank 0 holds exactly the single-GPU config), and one
+    all-reduce of the F counters per call, as in the strong-scaled object.  Every rank generates only its own share."""
+    import torch
+
+    from gtars_amd import sharding, synth
+
+    eng = sharding.HipEngine(dev)
+    ndb, nq, F = IGD3["ndb"] // scale, IGD3["nq"] // scale, IGD3["n_files"]
+    db = synth.make_igd_db(ndb, F, seed=6 + 2 * rank)
+    q = synth.make_background_queries(nq, seed=7 + 2 * rank)
+    sdb = sharding.ShardedIgd(eng, db, synth.N_CHROM, F, mode="range")  # (local ids 0..24: the rank's own chromosomes, whole)
+    del db
+    h = eng.upload(q["chrom"], q["start"], q["end"])  # its own queries, all of them (range mode would cut a shared batch)
+    byts = (12 * nq + 16 * ndb + 8 * F) * world
+    o = {"db_intervals": ndb * world, "queries": nq * world, "files": F, "algorithmic_bytes": byts, "scaling": "weak",
+         "per_rank": {"db_intervals": ndb, "queries": nq},
+         "sharding": "chromosome buckets of a genome that grows with the ranks: rank r owns chromosomes 25r..25r+24, its own 5e7 records and "
+                     "1e7 queries on them (the single-GPU config per rank)",
+         "collective": f"one all-reduce(SUM) of {F} int64 per call ({backend})",
+         "timing": "host wall time of one call incl. the all-reduce and the barriers around it, max over ranks, median of 7; per_rank_ms: "
+                   "device time of the rank's kernels by HIP events, and the collective apart"}
+    for binary in (False, True):
+        hits = torch.zeros(F, dtype=torch.int64, device=dev)
+        local = [None]
+
+        def call(tm):
+            sdb.count_resident(h, 1, binary, hits, timing=tm)
+
+        # this rank's own total (no collective), to check the reduced vector against the sum of the ranks' own
+        local_hits = eng.igd_count_resident(sdb.g, h, 1, binary)
+        mine = int(local_hits.sum())
+        dt, per_rank = timed_sharded_calls(dist, world, barrier, max_over_ranks, call)
+        totals = [None] * world
+        dist.all_gather_object(totals, mine)
+        tot = int(hits.sum())
+        if tot != sum(totals) or (scale == 1 and totals[0] != IGD3_TOTALS[1 if binary else 0]):
+            raise SystemExit(f"bench.py: igd_config3_weak: reduced total {tot}, ranks' own {totals}, single-GPU {IGD3_TOTALS}")
+        o["binary" if binary else "pairwise"] = {"ms": round(dt * 1e3, 3), "qps": round(nq * world / dt), "total_hits": tot,
+                                                  "frac_of_all_gpus": round(byts / dt / 1e9 / HBM_PEAK_GBS / world, 5),
+                                                  "per_rank_ms": per_rank,
+                                                  "verified": "reduced total == sum of the ranks' own totals; rank 0's == the single-GPU total"}
+    del sdb, h, q
+    torch.cuda.empty_cache()
+    return o
 
 
 def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scale=1):
@@ -728,24 +808,20 @@ def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scal
     o3["per_rank"] = locals_
     for binary in (False, True):
         hits = torch.zeros(F, dtype=torch.int64, device=dev)
-        sdb.count_resident(h, 1, binary, hits)
-        times = []
-        for _ in range(7):
-            barrier()
-            t0 = time.perf_counter()
-            sdb.count_resident(h, 1, binary, hits)
-            barrier()
-            times.append(max_over_ranks(time.perf_counter() - t0))
-        dt = statistics.median(times)
+        dt, per_rank = timed_sharded_calls(dist, world, barrier, max_over_ranks, lambda tm: sdb.count_resident(h, 1, binary, hits, timing=tm))
         tot = int(hits.sum())
         if scale == 1 and tot != IGD3_TOTALS[1 if binary else 0]:
             raise SystemExit(f"bench.py: igd_config3_sharded: {tot} hits, expected {IGD3_TOTALS[1 if binary else 0]}")
         o3["binary" if binary else "pairwise"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt), "total_hits": tot,
                                                   "frac_of_all_gpus": round(byts / dt / 1e9 / HBM_PEAK_GBS / world, 5),
+                                                  "per_rank_ms": per_rank,
                                                   "verified": "total hits == the single-GPU total" if scale == 1 else None}
+    o3["note"] = STRONG_NOTE
     out["igd_config3_sharded"] = o3
     del sdb, h, q
     torch.cuda.empty_cache()
+    # ---- config 3, weak: the genome, the database and the batch grow with the ranks ----
+    out["igd_config3_weak"] = bench_igd_weak(dist, backend, dev, rank, world, max_over_ranks, barrier, scale)
     # ---- config 4 ----
     n_sets, per_set = LOLA4["n_sets"], LOLA4["per_set"] // scale
     uni = synth.make_universe(LOLA4["n_universe"] // scale, seed=3)
@@ -757,19 +833,14 @@ def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scal
     hboth = sdb.upload_local_sets([uni, user])  # this rank's share of both sets, one resident batch
     stacked = torch.zeros(2, n_sets, dtype=torch.int64, device=dev)
 
-    def run():
-        sdb.count_sets_resident(hboth, 1, True, stacked)  # one pass over the local region DB + the one all-reduce
-        return sharding.contingency(stacked[1:], stacked[0], [n_user], nuni)
+    cells_box = [None]
 
-    run()
-    times = []
-    for _ in range(7):
-        barrier()
-        t0 = time.perf_counter()
-        cells = run()
-        barrier()
-        times.append(max_over_ranks(time.perf_counter() - t0))
-    dt = statistics.median(times)
+    def run(tm=None):
+        sdb.count_sets_resident(hboth, 1, True, stacked, timing=tm)  # one pass over the local region DB + the one all-reduce
+        cells_box[0] = sharding.contingency(stacked[1:], stacked[0], [n_user], nuni)
+
+    dt, lola_per_rank = timed_sharded_calls(dist, world, barrier, max_over_ranks, run)
+    cells = cells_box[0]
     a, b, c, d = [x[0].cpu().numpy() for x in cells]
     uh = stacked[0].cpu().numpy()
     ok = bool(((a + b) == uh).all() and ((a + c) == n_user).all() and ((a + b + c + d) == nuni).all()
@@ -782,19 +853,22 @@ def bench_sharded(dist, backend, dev, rank, world, max_over_ranks, barrier, scal
                                              "median of 7",
                                    "collective": f"one all-reduce(SUM) of 2 x {n_sets} int64 per call ({backend}): the user set's "
                                                  f"and the universe's support vectors (enrichment.rs:198-221)",
-                                   "local_db_intervals_rank0": sdb.local_intervals,
+                                   "local_db_intervals_rank0": sdb.local_intervals, "per_rank_ms": lola_per_rank, "note": STRONG_NOTE,
                                    "verified": "a,b,c,d identities; support sum == the single-GPU value"}
     del sdb, hboth
     torch.cuda.empty_cache()
     # ---- config 5: the fragment pipeline, files dealt to the ranks (no collective on the data path) ----
     out["fragsplit_config5_sharded"] = bench_fragsplit_sharded(dist, rank, world, max_over_ranks, barrier, files=max(8, 32 // scale),
                                                                frags=100_000 // scale)
+    # ... and with the single-GPU object's 48 files PER RANK (weak: what "x times the throughput at N GPUs" is read from)
+    out["fragsplit_config5_weak"] = bench_fragsplit_sharded(dist, rank, world, max_over_ranks, barrier,
+                                                            files=max(2, 48 // scale) * world, frags=100_000 // scale, weak=True)
     if scale != 1:
         out["configs_scaled_down_by"] = scale
     return out
 
 
-def bench_fragsplit_sharded(dist, rank, world, max_over_ranks, barrier, files=32, frags=100_000, clusters=20):
+def bench_fragsplit_sharded(dist, rank, world, max_over_ranks, barrier, files=32, frags=100_000, clusters=20, weak=False):
     """BASELINE config 5 over N ranks: rank 0 writes the synthetic fragment files (one node: the ranks share the directory), every
     rank runs the fused fragsplit -> tokenizer pipeline on its contiguous run of the sorted file list (balanced by compressed
     size) with its own host threads and its own GPU, results stay rank-local (`gather=False`: one output shard per GPU, what the
@@ -831,7 +905,8 @@ def bench_fragsplit_sharded(dist, rank, world, max_over_ranks, barrier, files=32
         dist.all_gather_object(per_rank, mine)
         n = files * frags
         o = {"files": files, "fragments_per_file": frags, "fragments": n, "clusters": clusters, "input_gz_MB": round(gz_bytes / 1e6, 1),
-             "gen_s": round(t_gen, 1), "scaling": "strong", "value": n / dt, "unit": "fragments/s end to end (all ranks)",
+             "gen_s": round(t_gen, 1), "scaling": "weak" if weak else "strong", "value": n / dt, "unit": "fragments/s end to end (all ranks)",
+             "host_threads_per_rank": int(_lib_host_threads()),
              "s": round(dt, 3), "per_rank": per_rank,
              "sharding": "contiguous runs of the sorted file list, balanced by compressed size; results rank-local (no collective on the "
                          "data path)",

@@ -54,8 +54,10 @@ using gtars::fail;
 
 namespace {
 
-// Host threads worth starting: hardware threads, capped by the container's CPU quota (cgroup v2 cpu.max)
-// and by `cap`; GTARS_HOST_THREADS overrides.
+// Host threads worth starting: hardware threads, capped by the container's CPU quota (cgroup v2 cpu.max) and by `cap`, and --
+// when this process is one of several ranks of a launcher on this node (LOCAL_WORLD_SIZE, set by torch.distributed.run) -- its
+// share of them: the fragment pipeline is host-bound, and eight ranks that each start every thread the node has fight over the
+// same cores.  GTARS_HOST_THREADS overrides (a launcher may set it per rank).
 unsigned host_thread_budget(unsigned cap) {
     if (const char *e = cfg_get("GTARS_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
     unsigned nt = std::thread::hardware_concurrency();
@@ -64,6 +66,10 @@ unsigned host_thread_budget(unsigned cap) {
         if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
             nt = std::min<unsigned>(nt, (unsigned)((quota + period - 1) / period));
         fclose(f);
+    }
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) {
+        const int ranks = atoi(e);
+        if (ranks > 1) nt = std::max(1u, nt / (unsigned)ranks);
     }
     return std::max(1u, std::min(nt, cap));
 }
@@ -385,6 +391,8 @@ std::vector<uint32_t> translate_chroms(const gtars_regionset *q, const Dict &d) 
 }
 
 }  // namespace
+
+extern "C" uint32_t gtars_host_threads(uint32_t cap) { return host_thread_budget(cap ? cap : 0xFFFFFFFFu); }
 
 extern "C" {
 

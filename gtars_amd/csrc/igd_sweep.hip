@@ -1343,10 +1343,13 @@ gtars_status launch_igd_tile_tables_rank(const IgdView &v, const u32 *tile_first
 // lane x 16.  In inline assembly ON PURPOSE: the compiler knows nothing of these transfers, so it neither drains the vector-memory
 // queue in front of every later LDS read (it cannot tell which LDS bytes a transfer writes) nor turns its counted waits for
 // ordinary loads into vmcnt(0) while one is in flight (both seen in the listing of the builtin form).  The caller counts them.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // (m0 IS written by the statement: say so, reserved or not)
 __device__ __forceinline__ void glds16(const void *g, const void *lds) {
     const u32 base = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)lds);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(base) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 constexpr int RK_CAPV = IGD_TILE + IGD_HALO + 4;
 constexpr int RK_HW = (RK_CAPV / 2 + 3) / 4 * 4;  // words of one histogram: 16-bit counters two per word, whole 16-byte vectors
 constexpr u32 RK_SUB = 65024;                     // queries per histogram fill: what 16-bit counters hold (a multiple of SW_TPB)

@@ -327,13 +327,35 @@ class ShardedIgd:
         local = [self.local_queries(q) for q in sets]
         return self.engine.upload_sets([(l["chrom"], l["start"], l["end"]) for l in local])
 
-    def count_sets_resident(self, handle, min_overlap: int = 1, binary: bool = False, hits=None):
-        """[len(sets), F] support / hit vectors of the uploaded sets -- one pass over the local database for up to four sets --
-        and ONE all-reduce of the whole block"""
-        hits = self.engine.igd_count_sets_resident(self.g, handle, min_overlap, binary, hits, sync=False)
+    def _timed(self, count, timing):
+        """count() enqueues the local counts and returns the hit tensor; then the one all-reduce.  ``timing`` (a dict, or None):
+        filled with ``device_ms`` -- this rank's kernels, by events on the stream they were launched on -- and ``collective_ms``
+        -- from the end of those kernels to the end of the all-reduce as this rank's stream sees it (RCCL: the wait its stream
+        is given; gloo: the staging through the host as well).  Timing synchronises the stream at the end of the call."""
+        if timing is None or not hasattr(self.engine, "device"):
+            hits = count()
+            if self.collective:
+                all_reduce_hits_(hits, self.group)
+            return hits
+        import torch
+
+        st = torch.cuda.current_stream()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(st)
+        hits = count()
+        e1.record(st)
         if self.collective:
             all_reduce_hits_(hits, self.group)
+        e2.record(st)
+        e2.synchronize()
+        timing["device_ms"] = e0.elapsed_time(e1)
+        timing["collective_ms"] = e1.elapsed_time(e2) if self.collective else 0.0
         return hits
+
+    def count_sets_resident(self, handle, min_overlap: int = 1, binary: bool = False, hits=None, timing=None):
+        """[len(sets), F] support / hit vectors of the uploaded sets -- one pass over the local database for up to four sets --
+        and ONE all-reduce of the whole block (``timing``: see _timed)"""
+        return self._timed(lambda: self.engine.igd_count_sets_resident(self.g, handle, min_overlap, binary, hits, sync=False), timing)
 
     def count_sets_local(self, sets, min_overlap: int = 1, binary: bool = False):
         """local [len(sets), F] block (no collective); engines without a batch form count set by set"""
@@ -345,12 +367,10 @@ class ShardedIgd:
             return batch(self.g, [(l["chrom"], l["start"], l["end"]) for l in local], min_overlap, binary)
         return torch.stack([self.engine.igd_count(self.g, l["chrom"], l["start"], l["end"], min_overlap, binary) for l in local])
 
-    def count_resident(self, handle, min_overlap: int = 1, binary: bool = False, hits=None):
-        """count + all-reduce on queries uploaded with ``upload_local``; nothing but the F-long vector leaves the device"""
-        hits = self.engine.igd_count_resident(self.g, handle, min_overlap, binary, hits, sync=False)
-        if self.collective:
-            all_reduce_hits_(hits, self.group)
-        return hits
+    def count_resident(self, handle, min_overlap: int = 1, binary: bool = False, hits=None, timing=None):
+        """count + all-reduce on queries uploaded with ``upload_local``; nothing but the F-long vector leaves the device
+        (``timing``: see _timed)"""
+        return self._timed(lambda: self.engine.igd_count_resident(self.g, handle, min_overlap, binary, hits, sync=False), timing)
 
     def count(self, q, min_overlap: int = 1, binary: bool = False):
         """global per-file hit vector (int64 tensor on the engine's device), identical on every rank"""

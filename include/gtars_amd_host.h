@@ -199,6 +199,12 @@ gtars_status gtars_fragsplit_tokenize(const gtars_tokenizer_t *t, const char *fi
 gtars_status gtars_fragsplit_tokenize_files(const gtars_tokenizer_t *t, const char *const *paths, uint64_t n_paths,
                                             const gtars_barcode_map_t *m, gtars_fragment_tokens_t ***out, uint64_t *n_reads);
 
+/* Host threads one call of the file pipelines above starts at most: hardware threads, capped by the container's CPU quota
+ * (cgroup v2 cpu.max) and by `cap`, divided by LOCAL_WORLD_SIZE when the process is one of several ranks of a launcher on this
+ * node (torch.distributed.run sets it; each rank of the sharded fragment pipeline inflates and parses on its share of the cores);
+ * GTARS_HOST_THREADS overrides.  Diagnostic: the reference has no threads on this path (gtars-fragsplit/src/split.rs:36-151). */
+uint32_t gtars_host_threads(uint32_t cap);
+
 /* ------------------------------------------------------------------------
  * .gtok  (gtars-io/src/gtok.rs:125-210, consts.rs:1-3)
  * ---------------------------------------------------------------------- */

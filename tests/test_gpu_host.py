@@ -1009,6 +1009,26 @@ def test_bench_py_launches_its_own_ranks():
     runs = sorted(x["files"] for x in s5["per_rank"])
     assert runs[0][0] == 0 and runs[0][1] == runs[1][0] and runs[1][1] == s5["files"] and all(b > a for a, b in runs)
     assert s5["verified"] and s5["fragments"] == s5["files"] * s5["fragments_per_file"] and s5["value"] > 0
+    # round 5: every N > 1 object says what each rank's GPU did (device time by HIP events) apart from the collective, and the
+    # weak-scaled objects carry per-rank work of the single-GPU configs
+    for o in (s3["pairwise"], s3["binary"], s4):
+        pr = o["per_rank_ms"]
+        assert len(pr) == 2 and all(x["device_ms"] > 0 and x["collective_ms"] >= 0 for x in pr), pr
+    w3 = out["igd_config3_weak"]
+    assert w3["scaling"] == "weak" and w3["db_intervals"] == 2 * ndb and w3["queries"] == 2 * nq
+    db, q = synth.make_igd_db(ndb, F), synth.make_background_queries(nq)
+    og = oracle.Igd()
+    og.add_arrays(db["chrom"], db["start"], db["end"], np.arange(ndb, dtype=np.int32), db["file"])
+    og.finalize()
+    db1, q1 = synth.make_igd_db(ndb, F, seed=8), synth.make_background_queries(nq, seed=9)  # rank 1's share of the grown genome
+    og1 = oracle.Igd()
+    og1.add_arrays(db1["chrom"], db1["start"], db1["end"], np.arange(ndb, dtype=np.int32), db1["file"])
+    og1.finalize()
+    want = int(og.count_set_overlaps(q["chrom"], q["start"], q["end"], 1, n_files=F).sum()) + \
+        int(og1.count_set_overlaps(q1["chrom"], q1["start"], q1["end"], 1, n_files=F).sum())
+    assert w3["pairwise"]["total_hits"] == want and len(w3["pairwise"]["per_rank_ms"]) == 2
+    w5 = out["fragsplit_config5_weak"]
+    assert w5["scaling"] == "weak" and w5["files"] == 2 * max(2, 48 // 100) and w5["verified"] and w5["host_threads_per_rank"] >= 1
     # fewer devices than ranks under nccl: refused before anything runs
     env["GTARS_BENCH_BACKEND"] = "nccl"
     import torch
@@ -1016,6 +1036,43 @@ def test_bench_py_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1)], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "visible devices" in r.stderr
+
+
+def test_bench_py_with_eight_ranks_on_one_gpu():
+    """`python bench.py --gpus 8` -- the command of the 8-GPU point of the scaling curve -- with the eight ranks sharing this box's
+    one GPU under gloo, at 1/100 of the sharded configs: every rank reports, every sharded and weak-scaled object verifies
+    itself (bench.py exits non-zero otherwise), the chromosome buckets leave no rank without database rows, and each rank's
+    host-thread budget is its share of the box's."""
+    import json
+    import subprocess
+    import sys
+
+    import gtars_amd._lib as L
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env["GTARS_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--queries", "100000",
+           "--batches", "2", "--min-seconds", "0.01", "--no-cpu-baseline", "--scale-configs", "100"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and sorted(x["rank"] for x in out["ranks"]) == list(range(8))
+    assert len({x["pid"] for x in out["ranks"]}) == 8 and out["verified"]
+    s3 = out["igd_config3_sharded"]
+    assert len(s3["per_rank"]) == 8 and all(x["db_intervals"] > 0 for x in s3["per_rank"])
+    assert sum(x["db_intervals"] for x in s3["per_rank"]) == s3["db_intervals"]
+    for key in ("igd_config3_sharded", "igd_config3_weak"):
+        for form in ("pairwise", "binary"):
+            assert len(out[key][form]["per_rank_ms"]) == 8 and out[key][form]["total_hits"] > 0
+    assert out["igd_config3_weak"]["queries"] == 8 * s3["queries"]
+    assert len(out["lola_config4_sharded"]["per_rank_ms"]) == 8
+    for key in ("fragsplit_config5_sharded", "fragsplit_config5_weak"):
+        o = out[key]
+        assert o["verified"] and sum(b - a for a, b in (x["files"] for x in o["per_rank"])) == o["files"]
+    alone = L.lib.gtars_host_threads(64)
+    assert out["fragsplit_config5_weak"]["host_threads_per_rank"] == max(1, min(64, L.lib.gtars_host_threads(0) // 8)), alone
 
 
 # ------------------------------------------------------------ CLI text front ends (python -m gtars_amd overlaprs / igd)

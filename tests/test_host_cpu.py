@@ -403,3 +403,23 @@ def test_scoring_output_writers(tmp_path):
     assert gzip.open(prefix + "_features.tsv.gz", "rt").read() == "peak_0\npeak_1\npeak_2\npeak_3\n"
     scoring.write_count_matrix(np.array([[2, 2, 1, 3], [4, 1, 3, 1]], dtype=np.uint32), str(tmp_path / "c.csv.gz"))
     assert gzip.open(tmp_path / "c.csv.gz", "rt").read() == "2,2,1,3\n4,1,3,1\n"
+
+
+def test_host_thread_budget_is_shared_between_the_ranks_of_a_node(monkeypatch):
+    """every rank of a launcher gets its SHARE of the node's host threads (LOCAL_WORLD_SIZE, torch.distributed.run): the fragment
+    pipeline is host-bound, eight ranks that each start every thread the node has only fight over the cores; GTARS_HOST_THREADS
+    (a launcher's per-rank setting) overrides; `cap` bounds everything but the override"""
+    import gtars_amd._lib as L
+
+    monkeypatch.delenv("GTARS_HOST_THREADS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    alone = L.lib.gtars_host_threads(0)
+    assert alone >= 1
+    assert L.lib.gtars_host_threads(3) == min(alone, 3)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert L.lib.gtars_host_threads(0) == max(1, alone // 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert L.lib.gtars_host_threads(0) == alone
+    monkeypatch.setenv("GTARS_HOST_THREADS", "5")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert L.lib.gtars_host_threads(2) == 5
