@@ -938,7 +938,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / igd_config3 / lola_config4 / host path")
-    ap.add_argument("--large", type=str, default="64000000,256000000,1000000000", help="batch sizes of roofline_large")
+    ap.add_argument("--large", type=str, default="16000000,64000000,256000000,1000000000", help="batch sizes of roofline_large (SURVEY 8d: 1.6e7 / 2.56e8 / 1e9, and 64M)")
     ap.add_argument("--c5-files", type=int, default=48, help="fragment files (1e5 fragments each) of fragsplit_config5 (the config names 10,000)")
     ap.add_argument("--scale-configs", type=int, default=1, help="tests only: divide the sizes of configs 3 / 4 (sharded objects) by this")
     ap.add_argument("--igd-pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -1103,6 +1103,10 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "bytes_per_query": bytes_per_launch / nq,
             "frac_of_measured_copy_6.29TBps": achieved / 6290.0,
+            "ceiling": "single-pass design (every workgroup stages the 132-KB search image, one chained scan): floor at 1M queries ~15 us = "
+                       "0.20 of the roofline (3.4 us prologue of 34 MB L2->LDS traffic chip-wide + 3.6 us look-back wait on the slowest "
+                       "predecessor); large-batch ceiling 0.48 (one divergent 32-byte record per shuffled query: 2.3 clk of the CU's one "
+                       "vector-memory path); the 0.40 target is not met at 1M -- see roofline_large for 16M..1e9 and DESIGN.md section 3",
         }
 
     # ---- the same steps on POSITION-SORTED batches: what Tokenizer.tokenize(path) delivers (a file-loaded RegionSet is sorted by

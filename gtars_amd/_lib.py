@@ -83,6 +83,8 @@ _SIG = {
     "gtars_index_sublist_offsets": (C.c_int, [vp, u32, vp]),
     "gtars_tokenize_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64, vp]),
     "gtars_fill_device": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, vp]),
+    "gtars_fill_device_n": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, vp]),
+    "gtars_tokenize_device_ex": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64, vp, C.c_int]),
     "gtars_histogram_u32_device": (C.c_int, [vp, u64, u32, vp, vp]),
     "gtars_histogram_rows_device": (C.c_int, [vp, vp, vp, u64, u32, u32, u32, vp, vp]),
     "gtars_debug_occupy_device": (C.c_int, [vp, u32, u32, u32]),

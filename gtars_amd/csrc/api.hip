@@ -1241,15 +1241,22 @@ static gtars_status check_query_args(const void *ix, const void *a, const void *
 gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
                                    const uint32_t *d_qe, uint64_t nq, uint64_t *d_offsets, uint32_t *d_ids,
                                    uint64_t ids_capacity, uint64_t *total_hits, void *stream) {
+    return gtars_tokenize_device_ex(ix, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, ids_capacity, total_hits, stream, GTARS_TOK_AUTO);
+}
+
+gtars_status gtars_tokenize_device_ex(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
+                                      const uint32_t *d_qe, uint64_t nq, uint64_t *d_offsets, uint32_t *d_ids,
+                                      uint64_t ids_capacity, uint64_t *total_hits, void *stream, int hint) {
     gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (!d_offsets) return fail(GTARS_ERR_INVALID_ARG, "d_offsets is NULL");
+    if (hint != GTARS_TOK_AUTO && hint != GTARS_TOK_NARROW && hint != GTARS_TOK_WIDE) return fail(GTARS_ERR_INVALID_ARG, "unknown tokenizer hint");
     hipStream_t s = (hipStream_t)stream;
     Workspace &ws = tls_workspace(0, s);
     const size_t wsb = fused_ws_bytes(ix, nq);
     st = ws.reserve(wsb);
     if (st) return st;
-    EnumOut out{d_offsets, d_ids, nullptr, nullptr, d_ids ? ids_capacity : 0};
+    EnumOut out{d_offsets, d_ids, nullptr, nullptr, d_ids ? ids_capacity : 0, hint};
     if (!total_hits) return run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s);
     {
         st = run_fused_sync(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s, total_hits);
@@ -1286,9 +1293,26 @@ gtars_status gtars_histogram_rows_device(const uint64_t *d_offsets, const uint32
     return launch_hist_rows(d_offsets, d_ids, d_row, nq, row0, n_rows, n_cols, d_mat, (hipStream_t)stream);
 }
 
+static gtars_status fill_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs, const uint32_t *d_qe, uint64_t nq,
+                                const uint64_t *d_offsets, uint32_t *d_ids, u64 capacity, int hint, void *stream);
+
 gtars_status gtars_fill_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
                                const uint32_t *d_qe, uint64_t nq, const uint64_t *d_offsets,
                                uint32_t *d_ids, void *stream) {
+    // (no total: the caller's buffer holds offsets[nq] ids by contract; the build with the run form, as for any unbounded buffer)
+    return fill_device(ix, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, 1ull << 62, GTARS_TOK_AUTO, stream);
+}
+
+gtars_status gtars_fill_device_n(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
+                                 const uint32_t *d_qe, uint64_t nq, const uint64_t *d_offsets,
+                                 uint32_t *d_ids, uint64_t total_hits, void *stream) {
+    // what the sizing pass measured decides the build: fewer than four ids per query is not a hit-heavy batch
+    const int hint = total_hits / 4 >= nq ? GTARS_TOK_WIDE : GTARS_TOK_NARROW;
+    return fill_device(ix, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, std::max<u64>(total_hits, 1), hint, stream);
+}
+
+static gtars_status fill_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs, const uint32_t *d_qe, uint64_t nq,
+                                const uint64_t *d_offsets, uint32_t *d_ids, u64 capacity, int hint, void *stream) {
     gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (!d_offsets || !d_ids) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
@@ -1303,7 +1327,7 @@ gtars_status gtars_fill_device(const gtars_index_t *ix, const uint32_t *d_qc, co
         Workspace &tmp = tls_workspace(4, s);
         st2 = tmp.reserve((size_t)(nq + 1) * sizeof(u64));
         if (st2) return st2;
-        EnumOut out{(u64 *)tmp.ptr, d_ids, nullptr, nullptr, 1ull << 62};
+        EnumOut out{(u64 *)tmp.ptr, d_ids, nullptr, nullptr, capacity, hint};
         return run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s);
     }
     return launch_fill(ix->view(), ix->kind, d_qc, d_qs, d_qe, nq, 0, 0, d_offsets, d_ids, nullptr, nullptr, s);

@@ -184,6 +184,7 @@ struct EnumOut {
     u32 *starts;     // may be null
     u32 *ends;       // may be null
     u64 capacity;    // elements available in each non-null output
+    int hint = 0;    // GTARS_TOK_AUTO / _NARROW / _WIDE (gtars_amd.h): which build of the LDS tokenizer a launch runs
 };
 
 // Head of every fused-scan workspace; after the launch has completed the host

@@ -1487,8 +1487,13 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     // GTARS_ERR_CAPACITY -- so it runs the build without; an offsets-only launch (capacity 0: the sizing pass of a two-pass caller)
     // keeps the run form, which is what makes a hit-heavy batch's count cheap.  Both builds give the same offsets and ids.
     const u64 cap_ids = out.vals ? out.capacity : 0;
+    // The caller may say which it is (EnumOut::hint <- gtars_tokenize_device_ex / gtars_fill_device_n: a two-pass caller knows
+    // its hits per query from the sizing pass); the capacity rule is only the default.
+    const bool by_rule = cap_ids == 0 || cap_ids / WIDE_IDS_PER_QUERY >= nq;
+    const bool want_wide = out.hint == GTARS_TOK_WIDE || (out.hint != GTARS_TOK_NARROW && by_rule);
     const bool wide = GTARS_TOK_RUNS != 0 && !filter && a.runs_ok && !cfg_flag("GTARS_TOK_NARROW") &&
-                      (cap_ids == 0 || cap_ids / WIDE_IDS_PER_QUERY >= nq || cfg_flag("GTARS_TOK_WIDE"));  // (switches: tests, A/B)
+                      (want_wide || cfg_flag("GTARS_TOK_WIDE"));  // (switches: tests, A/B)
+    prof_note_fact(wide ? "tok_build_wide" : "tok_build_narrow");
     // two rounds keep 8 queries' state per lane across the scan: with the id pairs of explicit-id records that spills; the kernels
     // with the run form gain nothing from the second round (16M queries of 33 ids: 1125 us with one round, 1139 with two)
     int rounds = impl && !wide ? choose_rounds(nq, cus) : 1;

@@ -196,16 +196,25 @@ class OverlapIndex:
         hm, mo = _minargs(min_overlap)
         check(lib.gtars_mark_overlapped_device(self._h, d_qc, d_qs, d_qe, nq, hm, mo, d_mark, stream))
 
+    TOK_AUTO, TOK_NARROW, TOK_WIDE = 0, 1, 2  # gtars_amd.h: which build of the fused tokenizer a launch runs
+
     def tokenize_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_offsets: int, d_ids: int,
-                        ids_capacity: int, stream: int = 0, sync: bool = True) -> Optional[int]:
-        """Single fused pass on device buffers.  Returns H when ``sync`` (else None)."""
+                        ids_capacity: int, stream: int = 0, sync: bool = True, hint: int = 0) -> Optional[int]:
+        """Single fused pass on device buffers.  Returns H when ``sync`` (else None).  ``hint``: TOK_NARROW for batches of about
+        one id per query whatever the id buffer's size, TOK_WIDE for hit-heavy ones; TOK_AUTO decides by the capacity."""
         total = C.c_uint64()
-        check(lib.gtars_tokenize_device(self._h, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, ids_capacity,
-                                        C.byref(total) if sync else None, stream))
+        check(lib.gtars_tokenize_device_ex(self._h, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, ids_capacity,
+                                           C.byref(total) if sync else None, stream, hint))
         return int(total.value) if sync else None
 
-    def fill_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_offsets: int, d_ids: int, stream: int = 0):
-        check(lib.gtars_fill_device(self._h, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, stream))
+    def fill_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_offsets: int, d_ids: int, stream: int = 0,
+                    total_hits: Optional[int] = None):
+        """ids for the offsets of a sizing pass; ``total_hits`` (what the caller read back to size ``d_ids``) bounds the writes
+        and picks the tokenizer build"""
+        if total_hits is None:
+            check(lib.gtars_fill_device(self._h, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, stream))
+        else:
+            check(lib.gtars_fill_device_n(self._h, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, total_hits, stream))
 
     def count_overlaps_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_counts: int,
                               min_overlap: Optional[int] = None, stream: int = 0):

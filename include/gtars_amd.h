@@ -132,7 +132,29 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
                                    uint64_t ids_capacity, uint64_t *total_hits,
                                    void *stream);
 
-/* Second pass of a two-pass caller: ids for existing offsets. */
+/* The same call with a HINT about the batch.  The fused tokenizer exists in two builds that give identical offsets and ids: one
+ * with the run form of hit-heavy queries (tens to hundreds of ids per query leave by wave-wide stores: 4x faster on such batches)
+ * and one without it (2-3.5 % faster on batches of ~1 id per query, BASELINE config 2).  GTARS_TOK_AUTO picks by the caller's
+ * id capacity -- a launch whose buffer cannot hold 4 ids per query cannot be a hit-heavy batch that completes; an offsets-only
+ * launch (the sizing pass of a two-pass caller) keeps the run form -- which makes a caller that over-allocates its id buffer pay
+ * the 2-3.5 %.  A caller that knows its batch says so: GTARS_TOK_NARROW (about one id per query), GTARS_TOK_WIDE (many). */
+#define GTARS_TOK_AUTO 0
+#define GTARS_TOK_NARROW 1
+#define GTARS_TOK_WIDE 2
+gtars_status gtars_tokenize_device_ex(const gtars_index_t *ix, const uint32_t *d_qchrom,
+                                      const uint32_t *d_qstart, const uint32_t *d_qend,
+                                      uint64_t nq, uint64_t *d_offsets, uint32_t *d_ids,
+                                      uint64_t ids_capacity, uint64_t *total_hits,
+                                      void *stream, int hint);
+
+/* Second pass of a two-pass caller: ids for existing offsets.  Contract: d_offsets are the offsets a gtars_tokenize_device call
+ * on the SAME index and batch left (offsets[0] == 0), d_ids holds offsets[nq] ids.  gtars_fill_device_n is the form for a caller
+ * that read offsets[nq] back to size d_ids (every two-pass caller has): total_hits bounds what is written (a buffer that turns
+ * out short ends in GTARS_ERR_CAPACITY at the next synchronising call instead of an out-of-bounds write) and picks the build
+ * (total_hits < 4 nq: the narrow one). */
+gtars_status gtars_fill_device_n(const gtars_index_t *ix, const uint32_t *d_qchrom,
+                                 const uint32_t *d_qstart, const uint32_t *d_qend, uint64_t nq,
+                                 const uint64_t *d_offsets, uint32_t *d_ids, uint64_t total_hits, void *stream);
 gtars_status gtars_fill_device(const gtars_index_t *ix, const uint32_t *d_qchrom,
                                const uint32_t *d_qstart, const uint32_t *d_qend,
                                uint64_t nq, const uint64_t *d_offsets, uint32_t *d_ids,

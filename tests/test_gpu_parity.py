@@ -442,6 +442,66 @@ def test_fill_device_both_ways_and_on_wide_queries(ga, monkeypatch):
                     monkeypatch.delenv("GTARS_NO_LDS_PATH_FOR_TEST")
 
 
+def test_tokenizer_build_is_the_callers_choice(ga):
+    """Round 5: which build of the fused tokenizer runs is a HINT the caller can give (gtars_tokenize_device_ex), not only a
+    function of its id buffer's size.  A config-2-like batch into a 4x over-allocated buffer runs the narrow build when told so
+    (by the capacity rule alone it would run the wide one), a two-pass caller's fill (gtars_fill_device_n: total hits known)
+    runs the narrow build for ~1 id per query and the wide one for a hit-heavy batch and never writes past the total; every
+    combination gives the oracle's offsets and ids.  Which build ran is read from the library's profiling facts."""
+    import torch
+
+    from gtars_amd import synth
+
+    _lib = ga._lib
+    u = synth.make_universe(20_000)
+    g = ga.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    o = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM)
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def facts_of(fn):
+        _lib.lib.gtars_prof_reset()
+        _lib.lib.gtars_prof_enable(1)
+        r = fn()
+        torch.cuda.synchronize()
+        f = _lib.prof_read()
+        _lib.lib.gtars_prof_enable(0)
+        return r, {k for k in f if k.startswith("tok_build")}
+
+    q = synth.make_queries(u, 200_000)
+    wide_q = dict(q)
+    wide_q["end"] = (q["start"].astype(np.int64) + 2_000_000).clip(max=2**31 - 1).astype(np.uint32)  # ~13 ids per query
+    for batch, heavy in ((q, False), (wide_q, True)):
+        off_o, ids_o = o.tokenize(batch["chrom"], batch["start"], batch["end"])
+        d = [torch.from_numpy(batch[k].view(np.int32)).to(dev) for k in ("chrom", "start", "end")]
+        nq = len(batch["chrom"])
+        off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+        big = torch.empty(max(4 * nq, len(ids_o)) + 64, dtype=torch.int32, device=dev)  # over-allocated: room for 4 ids per query
+        run = lambda hint: g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), big.data_ptr(),
+                                             big.numel(), st, hint=hint)
+        for hint, want in ((g.TOK_AUTO, "tok_build_wide"), (g.TOK_NARROW, "tok_build_narrow"), (g.TOK_WIDE, "tok_build_wide")):
+            h, facts = facts_of(lambda: run(hint))
+            assert facts == {want}, (heavy, hint, facts)
+            assert h == len(ids_o) and np.array_equal(off.cpu().numpy().view(np.uint64), off_o)
+            assert np.array_equal(big[:h].cpu().numpy().view(np.uint32), ids_o)
+        # the two-pass flow: offsets only, then the fill with the total the caller read back
+        h = g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), 0, 0, st)
+        ids = torch.full((h + 32,), -5, dtype=torch.int32, device=dev)
+        _, facts = facts_of(lambda: g.fill_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), ids.data_ptr(), st,
+                                                  total_hits=h))
+        assert facts == {"tok_build_wide" if heavy else "tok_build_narrow"}, (heavy, facts)
+        got = ids.cpu().numpy()
+        assert np.array_equal(got[:h].view(np.uint32), ids_o) and (got[h:] == -5).all()
+        # a total that is too small bounds the writes (the contract's violation does not run off the buffer)
+        ids.fill_(-5)
+        g.fill_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), ids.data_ptr(), st, total_hits=h // 2)
+        torch.cuda.synchronize()
+        got = ids.cpu().numpy()
+        assert np.array_equal(got[: h // 2].view(np.uint32), ids_o[: h // 2]) and (got[h // 2:] == -5).all()
+    with pytest.raises(ValueError):
+        g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), 0, 0, st, hint=7)
+
+
 @pytest.mark.parametrize("rep", [16, 256])
 def test_full_size_properties(ga, rep):
     """Size-independent properties at the scaling sizes of SURVEY section 8d (1.6e7 and 2.56e8 queries), which
@@ -1006,7 +1066,7 @@ def test_run_form_with_padded_units(ga, monkeypatch, top_max):
 
 def test_config3_igd_full_size_properties(ga):
     """BASELINE config 3 at full size (5e7 records, F = 1000, 1e7 queries): size-independent properties of
-    the per-file vectors, plus bit-exact parity with the oracle's literal tile walk on one chromosome."""
+    the per-file vectors, plus bit-exact parity with the oracle's literal tile walk on six chromosomes (1.2M of the queries)."""
     from gtars_amd import synth
 
     F = 1000
@@ -1029,15 +1089,16 @@ def test_config3_igd_full_size_properties(ga):
     assert np.array_equal(g.count_region_hits(qc[order], qs[order], qe[order], 1), binr)
     # a larger min_overlap can only lose hits
     assert (g.count_set_overlaps(qc[:h], qs[:h], qe[:h], 50) <= g.count_set_overlaps(qc[:h], qs[:h], qe[:h], 1)).all()
-    # oracle parity on chr21 (index 20): literal tile walk over that chromosome's records
+    # oracle parity on six chromosomes (chr17, chr18, chr19, chr21, chr22, chrY: 12 % of the genome): the literal tile walk over
+    # their ~6M records, every query of the batch that lies on them (~1.2M), pairwise and binary
+    chroms = np.array([16, 17, 18, 20, 21, 23])
+    sel = np.nonzero(np.isin(db["chrom"], chroms))[0]
     o = oracle.Igd()
-    L = oracle.lib()
-    sel = np.nonzero(db["chrom"] == 20)[0]
-    for i in sel:
-        L.orc_igd_add(o._h, 20, int(db["start"][i]), int(db["end"][i]), 0, int(db["file"][i]))
+    o.add_arrays(db["chrom"][sel], db["start"][sel], db["end"][sel], np.zeros(len(sel), dtype=np.int64), db["file"][sel])
     o.n_files = F
     o.finalize()
-    qsel = np.nonzero(qc == 20)[0][:20_000]
+    qsel = np.nonzero(np.isin(qc, chroms))[0]
+    assert len(qsel) >= 1_000_000 and len(np.unique(qc[qsel])) == len(chroms)
     assert np.array_equal(g.count_set_overlaps(qc[qsel], qs[qsel], qe[qsel], 1),
                           o.count_set_overlaps(qc[qsel], qs[qsel], qe[qsel], 1, n_files=F))
     assert np.array_equal(g.count_region_hits(qc[qsel], qs[qsel], qe[qsel], 1),
@@ -1724,6 +1785,29 @@ def test_igd_packed_counter_flush_and_many_routing_workgroups(ga, monkeypatch):
     monkeypatch.setenv("GTARS_IGD_ROUTE_CHUNK_MAX", "3000")
     assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), want)
     assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), o.count_region_hits(qc, qs, qe, 1, n_files=F))
+
+
+def test_igd_small_database_with_more_than_16m_queries(ga):
+    """A database of <= 1024 tiles takes the one-level split, whose grid was capped at 256 workgroups: beyond 16.7M queries a
+    workgroup's chunk no longer fitted the routing kernel's 16-bit counters and the call failed with an internal error (round-4
+    advisor finding).  17M queries (a 1M batch tiled 17 times, every copy shuffled differently) against 150k records: 17 x the
+    base batch's vectors, which equal the oracle's; pairwise (rank form) and binary."""
+    rng = np.random.default_rng(77)
+    n, F, span = 150_000, 9, 30_000_000
+    c = rng.integers(0, 2, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 900, n)
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=2, n_files=F)
+    qc, qs, qe = _random_query_set(rng, 1_000_000, 2, span + 1000, 700)
+    want_p = o.count_set_overlaps(qc, qs, qe, 1, n_files=F)
+    want_b = o.count_region_hits(qc, qs, qe, 1, n_files=F)
+    rep = 17
+    perm = np.concatenate([rng.permutation(len(qc)) + k * 0 for k in range(rep)])
+    bc, bs, be = qc[perm], qs[perm], qe[perm]
+    assert len(bc) > 16_800_000
+    assert np.array_equal(g.count_set_overlaps(bc, bs, be, 1), rep * want_p)
+    assert np.array_equal(g.count_region_hits(bc, bs, be, 1), rep * want_b)
 
 
 def test_igd_rank_histogram_sweep(ga, monkeypatch):
