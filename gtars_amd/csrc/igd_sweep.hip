@@ -1,22 +1,32 @@
-// igd_sweep.hip -- K5, batch form: Igd::count_set_overlaps / count_region_hits
-// (gtars-igd/src/igd.rs:544-590) for a large query batch as ONE streaming pass over the database.
+// igd_sweep.hip -- K5, batch form: Igd::count_set_overlaps / count_region_hits (gtars-igd/src/igd.rs:504-590, tile walk
+// :753-847) for a large query batch as ONE streaming pass over the database.
 //
-// The per-query kernel in kernels.hip binary-searches a 5e7-record array for every query (random HBM
-// accesses).  Here the roles are swapped: the QUERIES are sorted once by (chromosome, start) with the
-// device radix sort (K1), the database -- already sorted by (chromosome, start) -- is cut into tiles of
-// IGD_TILE records, and each workgroup stages one tile in LDS (coalesced 16-byte loads: the database is
-// read from HBM once, plus a 256-record halo) and serves the queries it OWNS: a query belongs to the
-// tile that holds its lower_bound position (first record with start >= q.start - max_len), which is a
-// contiguous range [ql, qh) of the sorted queries, found per tile by two binary searches in a tiny
-// pre-pass (one thread per tile).  The owner does an LDS binary search and scans forward while
-// start < q.end -- through the halo and, for the rare long scan, on into global memory -- applying
-// exactly the reference's hit rule
-//     min(r.end, qe) - max(r.start, qs) >= min_overlap                           (igd.rs:792-795)
-// One thread sees all hits of a query, in database order, so pairwise counts see each (query, record)
-// pair once and binary (LOLA support) counting credits a (query, file) pair at its first hit.
-// Per-file counts go to u32 LDS bins, flushed once per workgroup with u64 atomics.
+// The per-query kernel in kernels.hip searches a 5e7-record array for every query (random HBM accesses).  Here the roles are
+// swapped.  The database -- one record per stored interval, sorted by (chromosome, start) -- is cut into tiles of IGD_TILE
+// records; a query is OWNED by the tile that holds the first record that can overlap it (first tile whose bound, last start +
+// longest record + 1, is > q.start), so every record is read from HBM once per batch and the scan of a query's candidates runs
+// out of LDS (the tile + a halo of IGD_HALO records; beyond: the query's own lane, from global memory).  Queries need not be
+// sorted, only PARTITIONED by owner tile.  One call is five launches:
+//   k_igd_begin      result vector, the split's cursors, and the order check: a batch already in (chromosome, start) order is
+//                    swept as it lies (its tiles' query ranges by binary search in the routing launch);
+//   k_igd_route      validity rules (igd.rs:514-517), owner tile of every query through static tables (fine buckets with about
+//                    one tile boundary each), a u16 key per query, per-workgroup rows of 16-bit counts for the split;
+//   k_split_pass x2  (sort.hip) two-level counting split of the (start, end) pairs by key, bin scan included;
+//   the sweep        per tile: stage what the tile's queries need, count, add per-file counts into an LDS histogram, flush once.
+// Three forms of the sweep, all applying exactly the reference's hit rule  min(r.end, qe) - max(r.start, qs) >= min_overlap
+// (igd.rs:792-795), each stored interval once per query whatever the reference's tile replication (igd.rs:812-817):
+//   k_igd_sweep_rank   pairwise counts, min_overlap == 1 (round 5): no candidate walk at all -- two ranks per query (among the
+//                      tile's starts, among its SORTED ends) into two LDS histograms, prefix sums, one add per record; the tile's
+//                      arrays arrive by LDS-DMA a tile ahead (see the comment at the kernel);
+//   k_igd_sweep<0/2>   the candidate walk by quads out of LDS: pairwise counts for other min_overlap values and pieces views,
+//                      binary counts (LOLA support) for min_overlap == 1 through pme_file -- a record is the FIRST hit of its
+//                      file for a query iff it overlaps and no earlier record of the file ends after q.start, a per-record
+//                      constant of the database -- also for up to four query sets in one pass (set tags in the pairs' top bits);
+//   k_igd_sweep<1>     binary counts with a per-query list of credited files (other min_overlap values).
+// Everything a tile's queries need that depends on the database only (search tables, u16 file ids, prefix maxima, sorted ends and
+// their ranks, routing tables) is built once with the index (k_igd_tile_tables, k_igd_tile_tables_rank, api.hip finish_tiles).
 //
-// Bound: HBM.  Algorithmic bytes 12*Nq + 16*Ndb + 8*F; no MFMA (integer compare/scan).
+// Bound: HBM.  Algorithmic bytes 12*Nq + 16*Ndb + 8*F; no MFMA (integer compare / scan / histogram).
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
