@@ -170,6 +170,7 @@ _HOST_SIG = {
     "gtars_tokenizer_encode_ids": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
     "gtars_tokenizer_tokenize_fragment_file": (C.c_int, [vp, cstr, C.POINTER(C.POINTER(FragmentTokens))]),
     "gtars_fragment_tokens_free": (None, [C.POINTER(FragmentTokens)]),
+    "gtars_fragment_tokens_barcodes_joined": (C.c_int, [C.POINTER(FragmentTokens), pp, pu64]),
     "gtars_barcode_map_from_file": (C.c_int, [cstr, pp]),
     "gtars_barcode_map_free": (None, [vp]),
     "gtars_barcode_map_len": (u64, [vp]),
@@ -180,6 +181,7 @@ _HOST_SIG = {
     "gtars_fragsplit_tokenize": (C.c_int, [vp, cstr, vp, C.POINTER(C.POINTER(C.POINTER(FragmentTokens))), pu64]),
     "gtars_fragsplit_tokenize_files": (C.c_int, [vp, vp, u64, vp, C.POINTER(C.POINTER(C.POINTER(FragmentTokens))), pu64]),
     "gtars_host_threads": (u32, [u32]),
+    "gtars_fragsplit_last_stages": (None, [vp]),
     "gtars_gtok_write": (C.c_int, [cstr, vp, u64]),
     "gtars_gtok_read": (C.c_int, [cstr, pp, pu64]),
     "gtars_fragments_read": (C.c_int, [cstr, pp]),

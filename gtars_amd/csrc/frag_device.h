@@ -1,0 +1,72 @@
+// frag_device.h -- the interface between the host layer (host.cpp, plain C++) and the device side of the fused fragment pipeline
+// (fragparse.hip): the inflated TEXT of a wave of fragment files goes to the GPU, which splits it into lines, parses the five
+// fields, resolves chromosome and barcode, groups the routed fragments by cluster and tokenizes them -- what
+// gtars-fragsplit/src/split.rs:84-131 and gtars-tokenizers/src/utils/fragments.rs:12-56 do line by line on one thread.
+// No HIP types here.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/gtars_amd_host.h"
+
+namespace gtars {
+
+// 32-bit FNV-1a with a final mix: the ONE hash of the open-addressing tables both sides use
+inline uint32_t frag_hash(const char *p, uint32_t n) {
+    uint32_t h = 2166136261u;
+    for (uint32_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 16777619u;
+    return h ^ (h >> 15);
+}
+
+// a slot of an open-addressing string table (power-of-two slot count, linear probing): len == 0 is an empty slot
+struct FragSlot {
+    uint32_t off, len;  // the key's bytes in the table's blob
+    uint32_t value;     // cluster index (barcode tables) / chromosome id (chromosome table)
+    uint32_t pad;
+};
+
+// one fragment file of a wave, inflated, as the host hands it over
+struct FragFileIn {
+    const char *text = nullptr;  // the whole file; ends with '\n' unless empty (the caller appends one when the file lacks it)
+    uint64_t n = 0;
+    // the file's barcode table: the map keys that start with "{stem}+", keyed by the barcode alone (split.rs:100-106)
+    const FragSlot *slots = nullptr;
+    uint32_t n_slots = 0;  // a power of two (>= 1)
+    const char *keys = nullptr;
+    uint32_t n_key_bytes = 0;
+};
+
+// what comes back for a wave: the routed fragments CLUSTER-MAJOR (clusters ascending; inside a cluster files in wave order, lines
+// in file order -- the order the cluster's output file would have them), tokenized
+struct FragWaveOut {
+    std::vector<uint64_t> coff;        // [n_clusters + 1] fragments of every cluster
+    uint64_t n = 0;                    // routed fragments that are tokenized (lines whose chromosome field starts with '#' are not)
+    std::unique_ptr<uint16_t[]> file;  // [n] file of the fragment (index into the wave)
+    std::unique_ptr<uint32_t[]> slot;  // [n] slot of its barcode in that file's table
+    // the token CSR: ids of fragment r at ids[x .. x + cnt[r]), x running from cbase[c] at the cluster's first fragment -- one BYTE
+    // per fragment over the link instead of an 8-byte offset; `off` ([n + 1]) instead when some fragment has more than 255 ids
+    std::unique_ptr<uint8_t[]> cnt;    // [n], or null
+    std::vector<uint64_t> cbase;       // [n_clusters + 1] offset of every cluster's first id
+    std::unique_ptr<uint64_t[]> off;   // [n + 1], or null
+    uint32_t *ids = nullptr;           // malloc'ed (free)
+    std::vector<uint64_t> n_reads, n_written;  // per file: lines, routed lines ('#' lines included)
+    int64_t first_error_file = -1;     // first file (wave order) with a line the reference fails on; -1: none.  The caller re-parses
+                                       // that file on the host for the reference's message.
+    double t_h2d = 0, t_parse = 0, t_group = 0, t_tok = 0, t_d2h = 0;  // seconds (GTARS_HOST_TIMING)
+};
+
+// the tokenizer's chromosome dictionary as a device table; created once per pipeline call
+struct FragChroms;
+gtars_status frag_chroms_create(const std::vector<std::string> &names, FragChroms **out);
+void frag_chroms_free(FragChroms *c);
+
+// One wave on the calling thread's current device.  The text of all files together must stay below 4 GiB.
+gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms, const std::vector<FragFileIn> &files, uint32_t n_clusters,
+                              FragWaveOut &out);
+int frag_current_device();  // the calling thread's current HIP device (the wave thread selects the caller's)
+gtars_status frag_select_device(int device);
+
+}  // namespace gtars

@@ -1,0 +1,541 @@
+// fragparse.hip -- the fragment TEXT of the fused fragsplit -> tokenizer pipeline on the device (round 5; BASELINE config 5).
+//
+// Round 4 left config 5 a host benchmark: 48 files x 1e5 fragments took 48 ms on 16 host threads, 42 of them gunzip + parse +
+// route, and zlib's inflate is only ~45 % of that.  Here the host threads inflate and nothing else; a wave's inflated text goes
+// to the GPU, where
+//   k_frag_lines      counts / locates the line ends (one pass each over the text, 64 bytes per lane);
+//   k_frag_parse      one lane per line: the five whitespace-separated fields (split.rs:84-98 / fragments.rs:12-33), the
+//                     barcode -> cluster lookup in the FILE's own key table (the map keys that start with "{stem}+",
+//                     split.rs:100-106), the '#' rule of the cluster file's reader (fragments.rs:61-82), the two integers as
+//                     str::parse::<u32> takes them, the chromosome id of the tokenizer's dictionary;
+//   a stable radix sort of the lines by cluster (sort.hip) and a gather put the routed fragments cluster-major, files in wave
+//   order and lines in file order inside a cluster -- the order the cluster's output file would have them;
+//   the fused tokenizer (tokenize_lds.hip) runs on those columns where they lie.
+// Back to the host go, per routed fragment, its file, the slot of its barcode in the file's table and its token ids: the
+// per-barcode regrouping (HashMap<String, Vec<u32>> of fragments.rs:35-56) stays with the host threads.
+// A line the reference would fail on is only DETECTED here (first file in wave order); the host re-parses that file for the
+// reference's message.  Bound: PCIe for the text in (45 bytes per fragment), then HBM; no MFMA.
+#include "common.h"
+#include "frag_device.h"
+#include "scan.h"
+
+#include <algorithm>
+#include <chrono>
+
+namespace gtars {
+
+namespace {
+
+constexpr int FP_TPB = 256;
+constexpr u32 FP_BYTES = 64;                  // text bytes per lane
+constexpr u32 FP_CHUNK = FP_TPB * FP_BYTES;   // ... per workgroup
+constexpr u32 NO_CLUSTER = 0xFFFFu;           // sort key of a line that is not tokenized (clusters are < 65535)
+
+// 0x80 in every byte of v that equals '\n'
+__device__ __forceinline__ u32 newline_bytes(u32 v) {
+    v ^= 0x0A0A0A0Au;
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+}
+
+// line ends: COUNT per workgroup chunk (FILL = false), or their positions at chunk_base[chunk] + rank (FILL = true)
+template <bool FILL>
+__global__ void __launch_bounds__(FP_TPB)
+k_frag_lines(const u32 *__restrict__ text32, u32 n_bytes, u32 *__restrict__ chunk_cnt, const u32 *__restrict__ chunk_base,
+             u32 *__restrict__ line_end) {
+    __shared__ u32 s_scan[FP_TPB / 64];
+    const u32 b0 = blockIdx.x * FP_CHUNK + threadIdx.x * FP_BYTES;  // (the buffer is padded with zero bytes to whole chunks)
+    const uint4 *p = reinterpret_cast<const uint4 *>(text32 + b0 / 4);
+    uint4 w[FP_BYTES / 16];
+#pragma unroll
+    for (u32 k = 0; k < FP_BYTES / 16; ++k) w[k] = b0 < n_bytes ? p[k] : make_uint4(0, 0, 0, 0);
+    u32 cnt = 0;
+#pragma unroll
+    for (u32 k = 0; k < FP_BYTES / 16; ++k)
+        cnt += __popc(newline_bytes(w[k].x)) + __popc(newline_bytes(w[k].y)) + __popc(newline_bytes(w[k].z)) + __popc(newline_bytes(w[k].w));
+    u32 total;
+    const u32 ex = block_exclusive_scan<FP_TPB>(cnt, s_scan, total);
+    if (!FILL) {
+        if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = total;
+        return;
+    }
+    u32 at = chunk_base[blockIdx.x] + ex;
+#pragma unroll
+    for (u32 k = 0; k < FP_BYTES / 16; ++k) {
+        const u32 ww[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            u32 m = newline_bytes(ww[j]);
+            while (m) {
+                const u32 byte = (u32)(__ffs((int)m) - 1) >> 3;
+                m &= m - 1;
+                line_end[at++] = b0 + k * 16u + j * 4u + byte;
+            }
+        }
+    }
+}
+
+// exclusive scan of the chunk counts (one workgroup), total behind the last entry
+__global__ void __launch_bounds__(1024)
+k_frag_scan_chunks(const u32 *__restrict__ cnt, u32 n, u32 *__restrict__ base) {
+    __shared__ u32 s_scan[16];
+    __shared__ u32 s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 b0 = 0; b0 < n; b0 += 1024) {
+        const u32 i = b0 + threadIdx.x;
+        const u32 v = i < n ? cnt[i] : 0u;
+        u32 total;
+        const u32 ex = block_exclusive_scan<1024>(v, s_scan, total);
+        const u32 carry = s_carry;
+        if (i < n) base[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[n] = s_carry;
+}
+
+// first line of every file: the number of line ends in front of the file's first byte (files end with '\n')
+__global__ void k_frag_file_lines(const u32 *__restrict__ line_end, u32 n_lines, const u32 *__restrict__ file_off, u32 n_files,
+                                  u32 *__restrict__ file_line) {
+    const u32 f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f > n_files) return;
+    const u32 x = file_off[f];
+    u32 lo = 0, hi = n_lines;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (line_end[mid] < x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    file_line[f] = lo;
+}
+
+__device__ __forceinline__ bool dev_is_ws(unsigned char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); }  // isspace(), C locale
+
+// str::parse::<u32>(): optional '+', ASCII digits, must fit
+__device__ __forceinline__ bool dev_parse_u32(const unsigned char *p, u32 n, u32 &out) {
+    u32 i = (n && p[0] == '+') ? 1u : 0u;
+    if (i >= n) return false;
+    u64 v = 0;
+    for (; i < n; ++i) {
+        const u32 d = (u32)p[i] - '0';
+        if (d > 9) return false;
+        v = v * 10 + d;
+        if (v > 0xFFFFFFFFull) return false;
+    }
+    out = (u32)v;
+    return true;
+}
+
+__device__ __forceinline__ u32 dev_hash(const unsigned char *p, u32 n) {  // frag_hash (frag_device.h)
+    u32 h = 2166136261u;
+    for (u32 i = 0; i < n; ++i) h = (h ^ p[i]) * 16777619u;
+    return h ^ (h >> 15);
+}
+
+// slot of key [p, p + n) in an open-addressing table, or 0xFFFFFFFF
+__device__ __forceinline__ u32 table_find(const FragSlot *__restrict__ slots, u32 n_slots, const unsigned char *__restrict__ blob,
+                                          const unsigned char *p, u32 n) {
+    if (!n) return 0xFFFFFFFFu;
+    const u32 mask = n_slots - 1u;
+    u32 k = dev_hash(p, n) & mask;
+    for (u32 probes = 0; probes < n_slots; ++probes) {
+        const FragSlot s = slots[k];
+        if (!s.len) return 0xFFFFFFFFu;
+        if (s.len == n) {
+            const unsigned char *q = blob + s.off;
+            u32 i = 0;
+            while (i < n && q[i] == p[i]) ++i;
+            if (i == n) return k;
+        }
+        k = (k + 1u) & mask;
+    }
+    return 0xFFFFFFFFu;
+}
+
+struct FragTables {
+    const FragSlot *slots;        // all files' tables, one after the other
+    const unsigned char *keys;    // ... and their key blobs
+    const u32 *slot_off;          // [n_files + 1]
+    const u32 *key_off;           // [n_files]
+    const FragSlot *chrom_slots;  // the tokenizer's chromosome dictionary
+    const unsigned char *chrom_keys;
+    u32 n_chrom_slots;
+};
+
+// One lane per line.  key[i] = the line's cluster when it is routed AND tokenized, NO_CLUSTER otherwise; counts per file.
+__global__ void __launch_bounds__(FP_TPB)
+k_frag_parse(const unsigned char *__restrict__ text, const u32 *__restrict__ line_end, u32 n_lines, const u32 *__restrict__ file_line,
+             u32 n_files, FragTables tb, u32 *__restrict__ key, u32 *__restrict__ q_chrom, u32 *__restrict__ q_start, u32 *__restrict__ q_end,
+             u32 *__restrict__ q_slot, u32 *__restrict__ n_written, u32 *__restrict__ err_file) {
+    const u32 i = blockIdx.x * FP_TPB + threadIdx.x;
+    if (i >= n_lines) return;
+    const u32 lo = i ? line_end[i - 1] + 1u : 0u, hi = line_end[i];
+    // the line's file: last f with file_line[f] <= i
+    u32 f = 0;
+    {
+        u32 a = 0, b = n_files;
+        while (a + 1 < b) {
+            const u32 mid = (a + b) >> 1;
+            if (file_line[mid] <= i)
+                a = mid;
+            else
+                b = mid;
+        }
+        f = a;
+    }
+    u32 fs[5], fl[5], nf = 0, p = lo;
+    while (p < hi && nf < 5) {
+        while (p < hi && dev_is_ws(text[p])) ++p;
+        const u32 st = p;
+        while (p < hi && !dev_is_ws(text[p])) ++p;
+        if (p > st) {
+            fs[nf] = st;
+            fl[nf] = p - st;
+            ++nf;
+        }
+    }
+    u32 k = NO_CLUSTER;
+    bool bad = nf < 5, written = false;  // fewer than five fields: "Failed to parse fragments file at line ..." (routed or not)
+    if (!bad) {
+        const u32 so = tb.slot_off[f], ns = tb.slot_off[f + 1] - so;
+        const u32 slot = table_find(tb.slots + so, ns, tb.keys + tb.key_off[f], text + fs[3], fl[3]);
+        if (slot != 0xFFFFFFFFu) {  // else: most likely a cell dropped in QC -- nothing else of the line is looked at
+            written = true;
+            if (text[fs[0]] != '#') {  // (the cluster file's reader skips '#' lines: fragments.rs:70-73)
+                u32 s = 0, e = 0;
+                if (!dev_parse_u32(text + fs[1], fl[1], s) || !dev_parse_u32(text + fs[2], fl[2], e)) {
+                    bad = true;
+                } else {
+                    const u32 cs = table_find(tb.chrom_slots, tb.n_chrom_slots, tb.chrom_keys, text + fs[0], fl[0]);
+                    k = tb.slots[so + slot].value;
+                    q_chrom[i] = cs == 0xFFFFFFFFu ? GTARS_UNKNOWN_CHROM : tb.chrom_slots[cs].value;
+                    q_start[i] = s;
+                    q_end[i] = e;
+                    q_slot[i] = slot;
+                }
+            }
+        }
+    }
+    key[i] = k;
+    if (bad) atomicMin(err_file, f);
+    // routed lines per file: one atomic per wave when the wave's lines share a file (they nearly always do)
+    const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)f);
+    if (__all(f == f0)) {
+        const u64 m = __ballot(written);
+        if (m && (threadIdx.x & 63) == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&n_written[f0], (u32)__popcll(m));
+    } else if (written) {
+        atomicAdd(&n_written[f], 1u);
+    }
+}
+
+__global__ void k_frag_iota(u32 *__restrict__ p, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+// coff[c] = first position of the sorted keys with key >= c, c = 0 .. n_clusters (coff[n_clusters] = tokenized fragments)
+__global__ void k_frag_cluster_offsets(const u32 *__restrict__ sorted_key, u32 n, u32 n_clusters, u32 *__restrict__ coff) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_clusters) return;
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (sorted_key[mid] < c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    coff[c] = lo;
+}
+
+// cluster-major columns of the tokenized fragments: line perm[j] of the wave
+__global__ void k_frag_gather(const u32 *__restrict__ perm, u32 n, const u32 *__restrict__ q_chrom, const u32 *__restrict__ q_start,
+                              const u32 *__restrict__ q_end, const u32 *__restrict__ q_slot, const u32 *__restrict__ file_line, u32 n_files,
+                              u32 *__restrict__ oc, u32 *__restrict__ os, u32 *__restrict__ oe, u32 *__restrict__ oslot,
+                              unsigned short *__restrict__ ofile) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32 i = perm[j];
+    oc[j] = q_chrom[i];
+    os[j] = q_start[i];
+    oe[j] = q_end[i];
+    oslot[j] = q_slot[i];
+    u32 a = 0, b = n_files;
+    while (a + 1 < b) {
+        const u32 mid = (a + b) >> 1;
+        if (file_line[mid] <= i)
+            a = mid;
+        else
+            b = mid;
+    }
+    ofile[j] = (unsigned short)a;
+}
+
+// cnt[j] = min(off[j + 1] - off[j], 255); *wide = 1 when some fragment has more than 255 ids
+__global__ void k_frag_counts8(const u64 *__restrict__ off, u32 n, unsigned char *__restrict__ cnt, u32 *__restrict__ wide) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u64 h = off[j + 1] - off[j];
+    cnt[j] = (unsigned char)(h > 255 ? 255 : h);
+    if (h > 255) *wide = 1u;
+}
+// base[c] = off[coff[c]]
+__global__ void k_frag_cluster_bases(const u64 *__restrict__ off, const u32 *__restrict__ coff, u32 n_clusters, u64 *__restrict__ base) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= n_clusters) base[c] = off[coff[c]];
+}
+
+struct DevMem {
+    void *p = nullptr;
+    ~DevMem() {
+        if (p) (void)hipFree(p);
+    }
+    gtars_status alloc(size_t bytes) {
+        GT_HIP(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+        return GTARS_OK;
+    }
+    template <class T>
+    T *as() const {
+        return (T *)p;
+    }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// builds the slots of an open-addressing table over `n` keys (views), values given; cap = power of two >= 2 n
+void build_table(const std::vector<std::pair<const char *, u32>> &keys, const std::vector<u32> &values, std::vector<FragSlot> &slots,
+                 std::string &blob) {
+    size_t cap = 1;
+    while (cap < keys.size() * 2 + 1) cap <<= 1;
+    slots.assign(cap, FragSlot{0, 0, 0, 0});
+    blob.clear();
+    for (size_t i = 0; i < keys.size(); ++i) {
+        if (!keys[i].second) continue;  // (an empty key can never be a field)
+        u32 k = frag_hash(keys[i].first, keys[i].second) & (u32)(cap - 1);
+        while (slots[k].len) k = (k + 1) & (u32)(cap - 1);
+        slots[k] = FragSlot{(u32)blob.size(), keys[i].second, values[i], 0};
+        blob.append(keys[i].first, keys[i].second);
+    }
+}
+
+}  // namespace
+
+struct FragChroms {
+    DevMem slots, keys;
+    u32 n_slots = 0;
+    int device = 0;
+};
+
+gtars_status frag_chroms_create(const std::vector<std::string> &names, FragChroms **out) {
+    *out = nullptr;
+    gtars_status st = require_device();
+    if (st) return st;
+    std::vector<std::pair<const char *, u32>> keys;
+    std::vector<u32> values;
+    for (size_t i = 0; i < names.size(); ++i) {
+        keys.emplace_back(names[i].data(), (u32)names[i].size());
+        values.push_back((u32)i);
+    }
+    std::vector<FragSlot> slots;
+    std::string blob;
+    build_table(keys, values, slots, blob);
+    std::unique_ptr<FragChroms> c(new FragChroms());
+    GT_HIP(hipGetDevice(&c->device));
+    if ((st = c->slots.alloc(slots.size() * sizeof(FragSlot)))) return st;
+    if ((st = c->keys.alloc(blob.size() + 16))) return st;
+    GT_HIP(hipMemcpy(c->slots.p, slots.data(), slots.size() * sizeof(FragSlot), hipMemcpyHostToDevice));
+    if (!blob.empty()) GT_HIP(hipMemcpy(c->keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    c->n_slots = (u32)slots.size();
+    *out = c.release();
+    return GTARS_OK;
+}
+void frag_chroms_free(FragChroms *c) { delete c; }
+
+int frag_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return dev;
+}
+
+gtars_status frag_select_device(int device) {
+    GT_HIP(hipSetDevice(device));
+    return GTARS_OK;
+}
+
+gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms, const std::vector<FragFileIn> &files, uint32_t n_clusters,
+                              FragWaveOut &out) {
+    const u32 n_files = (u32)files.size();
+    out.coff.assign((size_t)n_clusters + 1, 0);
+    out.n = 0;
+    out.n_reads.assign(n_files, 0);
+    out.n_written.assign(n_files, 0);
+    out.first_error_file = -1;
+    out.ids = nullptr;
+    if (!n_files) return GTARS_OK;
+    if (n_clusters >= NO_CLUSTER || n_files >= 65535) return fail(GTARS_ERR_INVALID_ARG, "fragment wave: too many clusters or files for the device path");
+    u64 total = 0, total_slots = 0, total_keys = 0;
+    for (const FragFileIn &f : files) {
+        if (f.n && f.text[f.n - 1] != '\n') return fail(GTARS_ERR_INTERNAL, "fragment wave: a file's text must end with a newline");
+        total += f.n;
+        total_slots += f.n_slots;
+        total_keys += f.n_key_bytes;
+    }
+    if (total >= 0xFFFF0000ull) return fail(GTARS_ERR_INVALID_ARG, "fragment wave: more than 4 GiB of text");
+    const double t0 = now_s();
+    hipStream_t st = nullptr;
+    const u32 n_bytes = (u32)total;
+    const u32 n_chunks = (n_bytes + FP_CHUNK - 1) / FP_CHUNK;
+    // ---- text + tables to the device ----
+    DevMem d_text, d_slots, d_keys, d_meta, d_chunks;
+    gtars_status s;
+    if ((s = d_text.alloc((size_t)std::max<u32>(n_chunks, 1) * FP_CHUNK + 64))) return s;
+    if ((s = d_slots.alloc(std::max<u64>(total_slots, 1) * sizeof(FragSlot)))) return s;
+    if ((s = d_keys.alloc(total_keys + 16))) return s;
+    std::vector<u32> file_off(n_files + 1, 0), slot_off(n_files + 1, 0), key_off(n_files + 1, 0);
+    for (u32 f = 0; f < n_files; ++f) {
+        file_off[f + 1] = file_off[f] + (u32)files[f].n;
+        slot_off[f + 1] = slot_off[f] + files[f].n_slots;
+        key_off[f + 1] = key_off[f] + files[f].n_key_bytes;
+        if (files[f].n) GT_HIP(hipMemcpyAsync(d_text.as<char>() + file_off[f], files[f].text, files[f].n, hipMemcpyHostToDevice, st));
+        if (files[f].n_slots)
+            GT_HIP(hipMemcpyAsync(d_slots.as<FragSlot>() + slot_off[f], files[f].slots, (size_t)files[f].n_slots * sizeof(FragSlot), hipMemcpyHostToDevice, st));
+        if (files[f].n_key_bytes) GT_HIP(hipMemcpyAsync(d_keys.as<char>() + key_off[f], files[f].keys, files[f].n_key_bytes, hipMemcpyHostToDevice, st));
+    }
+    GT_HIP(hipMemsetAsync(d_text.as<char>() + n_bytes, 0, (size_t)std::max<u32>(n_chunks, 1) * FP_CHUNK + 64 - n_bytes, st));
+    // meta: file_off | slot_off | key_off | file_line [n_files + 1 each] | n_written [n_files] | err_file | coff [n_clusters + 1]
+    const size_t m1 = (size_t)n_files + 1;
+    if ((s = d_meta.alloc((m1 * 4 + n_files + 1 + n_clusters + 1) * 4))) return s;
+    u32 *d_file_off = d_meta.as<u32>(), *d_slot_off = d_file_off + m1, *d_key_off = d_slot_off + m1, *d_file_line = d_key_off + m1;
+    u32 *d_written = d_file_line + m1, *d_err = d_written + n_files, *d_coff = d_err + 1;
+    GT_HIP(hipMemcpyAsync(d_file_off, file_off.data(), m1 * 4, hipMemcpyHostToDevice, st));
+    GT_HIP(hipMemcpyAsync(d_slot_off, slot_off.data(), m1 * 4, hipMemcpyHostToDevice, st));
+    GT_HIP(hipMemcpyAsync(d_key_off, key_off.data(), m1 * 4, hipMemcpyHostToDevice, st));
+    GT_HIP(hipMemsetAsync(d_written, 0, (size_t)n_files * 4, st));
+    GT_HIP(hipMemsetAsync(d_err, 0xFF, 4, st));
+    GT_HIP(hipStreamSynchronize(st));
+    const double t1 = now_s();
+    out.t_h2d = t1 - t0;
+    // ---- line ends ----
+    if ((s = d_chunks.alloc(((size_t)n_chunks + 1) * 2 * 4))) return s;
+    u32 *d_cnt = d_chunks.as<u32>(), *d_base = d_cnt + n_chunks + 1;
+    u32 n_lines = 0;
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_frag_lines<false>, dim3(n_chunks), dim3(FP_TPB), 0, st, d_text.as<u32>(), n_bytes, d_cnt, (const u32 *)nullptr,
+                           (u32 *)nullptr);
+        hipLaunchKernelGGL(k_frag_scan_chunks, dim3(1), dim3(1024), 0, st, (const u32 *)d_cnt, n_chunks, d_base);
+        GT_HIP(hipMemcpyAsync(&n_lines, d_base + n_chunks, 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipStreamSynchronize(st));
+    }
+    DevMem d_lines, d_cols, d_sort, d_outcols;
+    if (n_lines) {
+        if ((s = d_lines.alloc((size_t)n_lines * 4))) return s;
+        u32 *d_line_end = d_lines.as<u32>();
+        hipLaunchKernelGGL(k_frag_lines<true>, dim3(n_chunks), dim3(FP_TPB), 0, st, d_text.as<u32>(), n_bytes, (u32 *)nullptr, (const u32 *)d_base,
+                           d_line_end);
+        hipLaunchKernelGGL(k_frag_file_lines, dim3((n_files + 1 + 63) / 64), dim3(64), 0, st, (const u32 *)d_line_end, n_lines,
+                           (const u32 *)d_file_off, n_files, d_file_line);
+        // ---- parse: per-line columns key | chrom | start | end | slot ----
+        if ((s = d_cols.alloc((size_t)n_lines * 4 * 5))) return s;
+        u32 *d_key = d_cols.as<u32>(), *d_qc = d_key + n_lines, *d_qs = d_qc + n_lines, *d_qe = d_qs + n_lines, *d_qslot = d_qe + n_lines;
+        FragTables tb{d_slots.as<FragSlot>(), d_keys.as<unsigned char>(), d_slot_off, d_key_off, chroms->slots.as<FragSlot>(),
+                      chroms->keys.as<unsigned char>(), chroms->n_slots};
+        hipLaunchKernelGGL(k_frag_parse, dim3((n_lines + FP_TPB - 1) / FP_TPB), dim3(FP_TPB), 0, st, d_text.as<unsigned char>(),
+                           (const u32 *)d_line_end, n_lines, (const u32 *)d_file_line, n_files, tb, d_key, d_qc, d_qs, d_qe, d_qslot, d_written, d_err);
+        GT_HIP(hipGetLastError());
+        // ---- the lines by cluster (stable: wave order inside a cluster), the tokenized ones in front ----
+        const size_t sort_ws = radix_sort_ws_bytes(n_lines);
+        if ((s = d_sort.alloc((size_t)n_lines * 4 * 3 + sort_ws + 64))) return s;
+        u32 *d_v0 = d_sort.as<u32>(), *d_k1 = d_v0 + n_lines, *d_v1 = d_k1 + n_lines;
+        void *ws = (void *)(((uintptr_t)(d_v1 + n_lines) + 63) & ~(uintptr_t)63);
+        hipLaunchKernelGGL(k_frag_iota, dim3((n_lines + 255) / 256), dim3(256), 0, st, d_v0, n_lines);
+        int res = 0;
+        if ((s = radix_sort_pairs(d_key, d_v0, d_k1, d_v1, n_lines, 0, 16, ws, sort_ws, &res, st))) return s;
+        const u32 *sk = res ? d_k1 : d_key, *sp = res ? d_v1 : d_v0;
+        hipLaunchKernelGGL(k_frag_cluster_offsets, dim3((n_clusters + 1 + 255) / 256), dim3(256), 0, st, sk, n_lines, n_clusters, d_coff);
+        std::vector<u32> h_coff((size_t)n_clusters + 1), h_written(n_files), h_file_line(m1);
+        u32 h_err = 0xFFFFFFFFu;
+        GT_HIP(hipMemcpyAsync(h_coff.data(), d_coff, ((size_t)n_clusters + 1) * 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipMemcpyAsync(h_written.data(), d_written, (size_t)n_files * 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipMemcpyAsync(h_file_line.data(), d_file_line, m1 * 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipStreamSynchronize(st));
+        const double t2 = now_s();
+        out.t_parse = t2 - t1;
+        for (u32 f = 0; f < n_files; ++f) {
+            out.n_reads[f] = h_file_line[f + 1] - h_file_line[f];
+            out.n_written[f] = h_written[f];
+        }
+        if (h_err != 0xFFFFFFFFu) {
+            out.first_error_file = h_err;
+            return GTARS_OK;  // (the caller reports it)
+        }
+        for (u32 c = 0; c <= n_clusters; ++c) out.coff[c] = h_coff[c];
+        const u32 n = h_coff[n_clusters];
+        out.n = n;
+        out.file.reset(new uint16_t[(size_t)n + 1]);
+        out.slot.reset(new uint32_t[(size_t)n + 1]);
+        out.cbase.assign((size_t)n_clusters + 1, 0);
+        if (n) {
+            // cluster-major columns c | s | e | slot (u32 each), file (u16), then the token CSR
+            if ((s = d_outcols.alloc((size_t)n * 4 * 4 + (size_t)n * 2 + 64 + ((size_t)n + 1) * 8 + ((size_t)n_clusters + 2) * 8 + (size_t)n + 64))) return s;
+            u32 *oc = d_outcols.as<u32>(), *os = oc + n, *oe = os + n, *oslot = oe + n;
+            u64 *d_off = reinterpret_cast<u64 *>(((uintptr_t)(oslot + n) + 7) & ~(uintptr_t)7);
+            u64 *d_cbase = d_off + n + 1;
+            unsigned short *ofile = reinterpret_cast<unsigned short *>(d_cbase + n_clusters + 1);
+            unsigned char *d_cnt8 = reinterpret_cast<unsigned char *>(ofile + n);
+            hipLaunchKernelGGL(k_frag_gather, dim3((n + 255) / 256), dim3(256), 0, st, sp, n, (const u32 *)d_qc, (const u32 *)d_qs,
+                               (const u32 *)d_qe, (const u32 *)d_qslot, (const u32 *)d_file_line, n_files, oc, os, oe, oslot, ofile);
+            GT_HIP(hipGetLastError());
+            GT_HIP(hipStreamSynchronize(st));
+            const double t3 = now_s();
+            out.t_group = t3 - t2;
+            // ---- tokenize where the columns lie: one fused pass with a guessed capacity, the fill pass when it was short ----
+            u64 cap = (u64)n * 2 + 1024, h = 0;
+            DevMem d_ids;
+            if ((s = d_ids.alloc(cap * 4))) return s;
+            s = gtars_tokenize_device(ix, oc, os, oe, n, (uint64_t *)d_off, d_ids.as<uint32_t>(), cap, &h, st);
+            if (s == GTARS_ERR_CAPACITY) {
+                DevMem bigger;
+                if ((s = bigger.alloc(h * 4))) return s;
+                std::swap(d_ids.p, bigger.p);
+                if ((s = gtars_fill_device_n(ix, oc, os, oe, n, (const uint64_t *)d_off, d_ids.as<uint32_t>(), h, st))) return s;
+                GT_HIP(hipStreamSynchronize(st));
+            } else if (s) {
+                return s;
+            }
+            const double t4 = now_s();
+            out.t_tok = t4 - t3;
+            out.ids = (uint32_t *)malloc(std::max<u64>(h, 1) * 4);
+            if (!out.ids) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+            // the CSR as one byte per fragment + the clusters' bases (8-byte offsets only when a fragment has more than 255 ids)
+            GT_HIP(hipMemsetAsync(d_err, 0, 4, st));  // (reused as the "wide" flag)
+            hipLaunchKernelGGL(k_frag_counts8, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *)d_off, n, d_cnt8, d_err);
+            hipLaunchKernelGGL(k_frag_cluster_bases, dim3((n_clusters + 1 + 255) / 256), dim3(256), 0, st, (const u64 *)d_off, (const u32 *)d_coff,
+                               n_clusters, d_cbase);
+            u32 wide = 0;
+            GT_HIP(hipMemcpyAsync(&wide, d_err, 4, hipMemcpyDeviceToHost, st));
+            GT_HIP(hipMemcpyAsync(out.cbase.data(), d_cbase, ((size_t)n_clusters + 1) * 8, hipMemcpyDeviceToHost, st));
+            GT_HIP(hipMemcpyAsync(out.file.get(), ofile, (size_t)n * 2, hipMemcpyDeviceToHost, st));
+            GT_HIP(hipMemcpyAsync(out.slot.get(), oslot, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            if (h) GT_HIP(hipMemcpyAsync(out.ids, d_ids.p, h * 4, hipMemcpyDeviceToHost, st));
+            GT_HIP(hipStreamSynchronize(st));
+            if (wide) {
+                out.off.reset(new uint64_t[(size_t)n + 1]);
+                GT_HIP(hipMemcpy(out.off.get(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+            } else {
+                out.cnt.reset(new uint8_t[(size_t)n + 1]);
+                GT_HIP(hipMemcpy(out.cnt.get(), d_cnt8, (size_t)n, hipMemcpyDeviceToHost));
+            }
+            out.t_d2h = now_s() - t4;
+        }
+    }
+    return GTARS_OK;
+}
+
+}  // namespace gtars

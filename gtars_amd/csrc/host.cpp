@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/gtars_amd_host.h"
+#include "frag_device.h"
 
 namespace gtars {
 gtars_status fail(gtars_status st, const std::string &msg);
@@ -703,6 +704,26 @@ struct gtars_tokenizer {
     Dict chroms;
     gtars_index_t *index = nullptr;
     uint32_t unk_id = 0;
+    // the chromosome dictionary as a device table (fragparse.hip), made by the first fused fragment pipeline call on a device and
+    // kept with the tokenizer: building it per call cost 23 ms of a 65-ms call (device allocations synchronise)
+    mutable std::mutex frag_mu;
+    mutable gtars::FragChroms *frag_chroms = nullptr;
+    mutable int frag_chroms_device = -1;
+    gtars_status device_chroms(gtars::FragChroms **out) const {
+        std::lock_guard<std::mutex> lk(frag_mu);
+        const int dev = gtars::frag_current_device();
+        if (frag_chroms && frag_chroms_device != dev) {
+            gtars::frag_chroms_free(frag_chroms);
+            frag_chroms = nullptr;
+        }
+        if (!frag_chroms) {
+            gtars_status st = gtars::frag_chroms_create(chroms.names, &frag_chroms);
+            if (st) return st;
+            frag_chroms_device = dev;
+        }
+        *out = frag_chroms;
+        return GTARS_OK;
+    }
 };
 
 namespace {
@@ -1193,6 +1214,7 @@ gtars_status gtars_tokenizer_from_bed(const char *path, gtars_tokenizer_t **out)
 void gtars_tokenizer_free(gtars_tokenizer_t *t) {
     if (!t) return;
     gtars_index_free(t->index);
+    gtars::frag_chroms_free(t->frag_chroms);
     delete t;
 }
 
@@ -1591,6 +1613,24 @@ void gtars_fragment_tokens_free(gtars_fragment_tokens_t *ft) {
     free(ft->offsets);
     free(ft->ids);
     free(ft);
+}
+
+gtars_status gtars_fragment_tokens_barcodes_joined(const gtars_fragment_tokens_t *ft, char **out, uint64_t *out_len) {
+    if (!ft || !out || !out_len) return fail(GTARS_ERR_INVALID_ARG, "NULL argument");
+    size_t total = 0;
+    std::vector<size_t> len(ft->n_barcodes);
+    for (uint64_t b = 0; b < ft->n_barcodes; ++b) total += (len[b] = strlen(ft->barcodes[b])) + 1;
+    char *buf = (char *)malloc(total ? total : 1);
+    if (!buf) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    size_t at = 0;
+    for (uint64_t b = 0; b < ft->n_barcodes; ++b) {
+        memcpy(buf + at, ft->barcodes[b], len[b]);
+        at += len[b];
+        buf[at++] = '\n';
+    }
+    *out = buf;
+    *out_len = total ? total - 1 : 0;
+    return GTARS_OK;
 }
 
 // ===================================================================== gtok
@@ -2340,6 +2380,66 @@ void split_one_file(const std::string &path, const gtars_barcode_map &m, bool wa
     }
 }
 
+// One input file for the DEVICE path of the fused pipeline (fragparse.hip): the inflated text as it is -- the GPU splits and
+// parses it -- and the file's barcode table in the device's format (FileBarcodes above, keyed by the barcode alone).
+struct TextFile {
+    std::string data;
+    std::vector<gtars::FragSlot> slots;
+    std::string keys;
+    std::vector<uint32_t> local;  // slot -> id of the barcode among its cluster's barcodes (first-seen order; filled at regroup)
+    gtars_status st = GTARS_OK;
+    std::string err;
+};
+
+void load_text_file(const std::string &path, const gtars_barcode_map &m, TextFile &out) {
+    std::string err;
+    if (!read_all(path, out.data, err)) {
+        out.st = GTARS_ERR_IO;
+        out.err = err;
+        return;
+    }
+    if (!out.data.empty() && out.data.back() != '\n') out.data.push_back('\n');  // (BufRead::lines: a last line without one still counts)
+    const std::string prefix = remove_all_extensions(path) + "+";
+    auto lo = std::lower_bound(m.sorted.begin(), m.sorted.end(), prefix, [](const auto &a, const std::string &p) { return *a.first < p; });
+    auto hi = lo;
+    while (hi != m.sorted.end() && hi->first->size() >= prefix.size() && hi->first->compare(0, prefix.size(), prefix) == 0) ++hi;
+    size_t cap = 1;
+    while (cap < (size_t)(hi - lo) * 2 + 1) cap <<= 1;
+    out.slots.assign(cap, gtars::FragSlot{0, 0, 0, 0});
+    for (auto it = lo; it != hi; ++it) {
+        const char *bc = it->first->data() + prefix.size();
+        const uint32_t n = (uint32_t)(it->first->size() - prefix.size());
+        if (!n) continue;  // (a field is never empty)
+        uint32_t k = gtars::frag_hash(bc, n) & (uint32_t)(cap - 1);
+        while (out.slots[k].len) k = (k + 1) & (uint32_t)(cap - 1);
+        out.slots[k] = gtars::FragSlot{(uint32_t)out.keys.size(), n, it->second, 0};
+        out.keys.append(bc, n);
+    }
+    out.local.assign(cap, 0xFFFFFFFFu);
+}
+
+// files in waves (inflated in parallel, one per host thread), handed to `sink(first_file_index, wave)` in file order
+template <class Sink>
+gtars_status for_each_text_wave(const std::vector<std::string> &files, const gtars_barcode_map &m, Sink &&sink) {
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_thread_budget(64), files.size()));
+    const size_t wave = (size_t)nt;
+    for (size_t base = 0; base < files.size(); base += wave) {
+        const size_t n = std::min(wave, files.size() - base);
+        std::vector<TextFile> res(n);
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) load_text_file(files[base + i], m, res[i]);
+        };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        gtars_status st = sink(base, res);
+        if (st) return st;
+    }
+    return GTARS_OK;
+}
+
 // files in waves of `wave` (parsed in parallel), handed to `sink(first_file_index, wave_results)` in file order
 template <class Sink>
 gtars_status for_each_split_wave(const std::vector<std::string> &files, const gtars_barcode_map &m, bool want_text, const Dict *chroms,
@@ -2432,9 +2532,28 @@ static gtars_status gtars_fragsplit_impl(const char *files_dir, const gtars_barc
 
 // the pipeline over an explicit list of files, visited in the order given (the directory form passes its regular files in byte
 // order of their names; a rank of the sharded driver passes its run of that list)
+static thread_local double g_frag_stages[12];
+void gtars_fragsplit_last_stages(double *out12) {
+    if (out12) memcpy(out12, g_frag_stages, sizeof g_frag_stages);
+}
+
+static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const std::vector<std::string> &files, const gtars_barcode_map_t *m,
+                                            gtars_fragment_tokens_t ***out, uint64_t *n_reads, bool allow_device, bool *redo_on_host);
+
 static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const std::vector<std::string> &files, const gtars_barcode_map_t *m,
                                             gtars_fragment_tokens_t ***out, uint64_t *n_reads) {
+    bool redo = false;
+    gtars_status st = fragsplit_tokenize_mode(t, files, m, out, n_reads, true, &redo);
+    // (a wave of more than 3.5 GiB of text -- beyond the device parser's 32-bit positions: the whole call on the host parser)
+    if (redo) st = fragsplit_tokenize_mode(t, files, m, out, n_reads, false, &redo);
+    return st;
+}
+
+static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const std::vector<std::string> &files, const gtars_barcode_map_t *m,
+                                            gtars_fragment_tokens_t ***out, uint64_t *n_reads, bool allow_device, bool *redo_on_host) {
     gtars_status st = GTARS_OK;
+    *redo_on_host = false;
+    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     const size_t nc = m->labels.size();
     // per cluster: fragment columns in the order the cluster file would have them (files in order, lines in order),
     // chromosome ids of the TOKENIZER's dictionary, barcode ids in first-seen order
@@ -2453,9 +2572,29 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
         uint32_t *ids = nullptr;
         gtars_status st = GTARS_OK;
         std::string err;
+        // device path (fragparse.hip): the wave's files as text until the GPU has them, afterwards their barcode tables; file and
+        // barcode slot of every tokenized fragment (cluster-major like the CSR)
+        bool device = false;
+        size_t first_file = 0;
+        std::vector<TextFile> tf;
+        std::unique_ptr<uint16_t[]> file;
+        std::unique_ptr<uint32_t[]> slot;
+        std::unique_ptr<uint8_t[]> cnt;  // ids per fragment, with cbase[c] = the cluster's first id, instead of `off` (FragWaveOut)
+        std::vector<uint64_t> cbase;
+        uint64_t reads = 0;
+        double td[5] = {0, 0, 0, 0, 0};
     };
     std::vector<Cluster> cl(nc);
     std::deque<Wave> waves;
+    // The device path: the host threads only inflate; line splitting, field parsing, barcode and chromosome lookup, the grouping by
+    // cluster and the tokenizer run on the GPU (fragparse.hip).  GTARS_FRAG_HOST_PARSE=1 keeps round 4's host parse (A/B, tests).
+    const bool device_path = allow_device && !cfg_get("GTARS_FRAG_HOST_PARSE") && nc < 65000;
+    gtars::FragChroms *d_chroms = nullptr;  // (the tokenizer's: calls of several threads on one tokenizer share it read-only)
+    if (device_path) {
+        st = t->device_chroms(&d_chroms);
+        if (st) return st;
+    }
+    const int caller_device = gtars::frag_current_device();
     uint64_t reads = 0, n_all = 0;
     const bool timing = cfg_get("GTARS_HOST_TIMING") != nullptr;  // stderr: seconds per stage (tools/fragsplit_bench.py)
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -2479,6 +2618,7 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
     std::deque<Wave *> jobs;
     bool closing = false;
     std::thread tok_thread([&] {
+        (void)gtars::frag_select_device(caller_device);  // (HIP's current device belongs to the thread and starts at 0)
         for (;;) {
             Wave *w = nullptr;
             {
@@ -2489,9 +2629,46 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
                 jobs.pop_front();
             }
             const double t0 = now();
-            uint64_t h = 0;
-            w->st = gtars_tokenize(t->index, w->c.get(), w->s.get(), w->e.get(), w->n, w->off.get(), &w->ids, &h);
-            if (w->st) w->err = gtars_last_error();
+            if (w->device) {
+                std::vector<gtars::FragFileIn> in;
+                for (TextFile &f : w->tf) {
+                    gtars::FragFileIn x;
+                    x.text = f.data.data();
+                    x.n = f.data.size();
+                    x.slots = f.slots.data();
+                    x.n_slots = (uint32_t)f.slots.size();
+                    x.keys = f.keys.data();
+                    x.n_key_bytes = (uint32_t)f.keys.size();
+                    in.push_back(x);
+                }
+                gtars::FragWaveOut o;
+                w->st = gtars::frag_wave_device(t->index, d_chroms, in, (uint32_t)nc, o);
+                if (w->st) {
+                    w->err = gtars_last_error();
+                } else if (o.first_error_file >= 0) {
+                    // a line the reference fails on: its message from the host parser, on that one file
+                    SplitFile again;
+                    split_one_file(files[w->first_file + (size_t)o.first_error_file], *m, false, again, &t->chroms);
+                    w->st = again.st ? again.st : GTARS_ERR_INTERNAL;
+                    w->err = again.st ? again.err : "fragment pipeline: the device parser rejected a line that the host parser accepts";
+                } else {
+                    w->coff = std::move(o.coff);
+                    w->n = o.n;
+                    w->file = std::move(o.file);
+                    w->slot = std::move(o.slot);
+                    w->off = std::move(o.off);
+                    w->cnt = std::move(o.cnt);
+                    w->cbase = std::move(o.cbase);
+                    w->ids = o.ids;
+                    for (uint64_t r : o.n_reads) w->reads += r;
+                    w->td[0] = o.t_h2d, w->td[1] = o.t_parse, w->td[2] = o.t_group, w->td[3] = o.t_tok, w->td[4] = o.t_d2h;
+                }
+                for (TextFile &f : w->tf) std::string().swap(f.data);  // the text is on the device (or no longer needed)
+            } else {
+                uint64_t h = 0;
+                w->st = gtars_tokenize(t->index, w->c.get(), w->s.get(), w->e.get(), w->n, w->off.get(), &w->ids, &h);
+                if (w->st) w->err = gtars_last_error();
+            }
             t_tok += now() - t0;
         }
     });
@@ -2510,7 +2687,7 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
     auto free_waves = [&] {
         for (Wave &w : waves) gtars_free(w.ids);
     };
-    st = for_each_split_wave(files, *m, false, &t->chroms, [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
+    auto host_sink = [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
         const double t_a = now();
         waves.emplace_back();
         Wave &w = waves.back();
@@ -2554,7 +2731,43 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
         cv.notify_all();
         t_append += now() - t_a;
         return GTARS_OK;
-    });
+    };
+    if (!device_path) {
+        st = for_each_split_wave(files, *m, false, &t->chroms, host_sink);
+    } else {
+        st = for_each_text_wave(files, *m, [&](size_t base, std::vector<TextFile> &tf) -> gtars_status {
+            // a file that could not be read: the reference fails there -- unless an EARLIER file of the wave has a line it fails
+            // on (files are visited in order): those are parsed on the host for their message
+            for (size_t i = 0; i < tf.size(); ++i)
+                if (tf[i].st) {
+                    for (size_t j = 0; j < i; ++j) {
+                        SplitFile chk;
+                        split_one_file(files[base + j], *m, false, chk, &t->chroms);
+                        if (chk.st) return fail(chk.st, chk.err);
+                    }
+                    return fail(tf[i].st, tf[i].err);
+                }
+            uint64_t bytes = 0;
+            for (const TextFile &f : tf) bytes += f.data.size();
+            const char *cap_mb = cfg_get("GTARS_FRAG_DEVICE_WAVE_MB");  // (test hook: a small limit)
+            if (bytes >= ((cap_mb ? (uint64_t)atoll(cap_mb) : 3500ull) << 20)) {  // beyond the device path's 32-bit text positions
+                *redo_on_host = true;
+                return fail(GTARS_ERR_INTERNAL, "fragment wave too large for the device parser");
+            }
+            waves.emplace_back();
+            Wave &w = waves.back();
+            w.device = true;
+            w.first_file = base;
+            w.tf = std::move(tf);
+            w.coff.assign(nc + 1, 0);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                jobs.push_back(&w);
+            }
+            cv.notify_all();
+            return GTARS_OK;
+        });
+    }
     const double t_split_done = now();
     finish_tokenizer();
     if (st) {
@@ -2569,6 +2782,34 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
             return fail(e, msg);
         }
     const double t_tok_done = now();
+    if (device_path) {
+        // the cluster-level barcode ids of the device waves' fragments: first-seen order over the waves, i.e. over the files in
+        // order and the lines in order -- what one pass over the cluster's file would see.  A barcode belongs to ONE cluster, so
+        // the clusters' threads touch different slots of the files' tables.
+        for (Wave &w : waves)
+            if (w.device) {
+                reads += w.reads;
+                n_all += w.n;
+            }
+        over_clusters([&](size_t c) {
+            Cluster &k = cl[c];
+            uint64_t total = 0;
+            for (Wave &w : waves) total += w.coff[c + 1] - w.coff[c];
+            k.b.reserve(k.b.size() + (size_t)total);
+            for (Wave &w : waves) {
+                if (!w.device) continue;  // (never: a call is all device waves or all host waves)
+                for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r) {
+                    TextFile &f = w.tf[w.file[r]];
+                    uint32_t &id = f.local[w.slot[r]];
+                    if (id == 0xFFFFFFFFu) {
+                        const gtars::FragSlot &sl = f.slots[w.slot[r]];
+                        id = k.barcodes.get_or_add(f.keys.data() + sl.off, sl.len);
+                    }
+                    k.b.push_back(id);
+                }
+            }
+        });
+    }
     // every cluster regrouped by barcode: its fragments' ids wave after wave (= the cluster file's line order)
     auto **arr = (gtars_fragment_tokens_t **)calloc(nc ? nc : 1, sizeof(gtars_fragment_tokens_t *));
     over_clusters([&](size_t c) {
@@ -2578,7 +2819,7 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
         uint64_t i = 0;
         for (Wave &w : waves)
             for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
-                const uint64_t hits = w.off[r + 1] - w.off[r];
+                const uint64_t hits = w.cnt ? w.cnt[r] : w.off[r + 1] - w.off[r];
                 cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
             }
         for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
@@ -2591,23 +2832,54 @@ static gtars_status fragsplit_tokenize_core(const gtars_tokenizer_t *t, const st
         for (uint64_t b = 0; b < nb; ++b) ft->barcodes[b] = dup_cstr(k.barcodes.names[b]);
         std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
         i = 0;
-        for (Wave &w : waves)
+        for (Wave &w : waves) {
+            uint64_t x = w.cnt ? w.cbase[c] : 0;  // (device waves: the ids of the cluster's fragments follow one another from here)
             for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
                 uint64_t &at = fill[k.b[i]];
-                if (w.off[r + 1] == w.off[r])
+                if (w.cnt) {
+                    const uint64_t hits = w.cnt[r];
+                    if (!hits) ft->ids[at++] = t->unk_id;
+                    for (uint64_t e = x + hits; x < e; ++x) ft->ids[at++] = w.ids[x];
+                } else if (w.off[r + 1] == w.off[r]) {
                     ft->ids[at++] = t->unk_id;
-                else
-                    for (uint64_t x = w.off[r]; x < w.off[r + 1]; ++x) ft->ids[at++] = w.ids[x];
+                } else {
+                    for (uint64_t y = w.off[r]; y < w.off[r + 1]; ++y) ft->ids[at++] = w.ids[y];
+                }
             }
+        }
         arr[c] = ft;
     });
     free_waves();
     *out = arr;
     if (n_reads) *n_reads = reads;
-    if (timing)
-        fprintf(stderr, "[gtars host timing] fragsplit_tokenize: %zu files in %zu wave(s), gunzip + parse + route %.3f s, per-cluster append %.3f s, tokenizer calls %.3f s (of which %.3f s after the last wave was parsed; %llu fragments), regroup of %zu clusters %.3f s\n",
-                files.size(), waves.size(), t_split_done - t_begin - t_append, t_append, t_tok, t_tok_done - t_split_done,
-                (unsigned long long)n_all, nc, now() - t_tok_done);
+    {
+        // the stages of this call, for gtars_fragsplit_last_stages (bench.py's stage report)
+        double *g = g_frag_stages;
+        for (int k = 0; k < 12; ++k) g[k] = 0;
+        g[0] = device_path ? 1 : 0;
+        g[1] = (double)waves.size();
+        g[2] = t_split_done - t_begin - t_append;  // read + inflate (host path: + parse + route)
+        g[3] = t_append;
+        g[4] = t_tok;
+        g[5] = t_tok_done - t_split_done;  // ... of which behind the last wave's files
+        g[6] = now() - t_tok_done;         // regroup by barcode
+        for (Wave &w : waves)
+            for (int k = 0; k < 5; ++k) g[7 + k] += w.td[k];
+    }
+    if (timing) {
+        fprintf(stderr, "[gtars host timing] fragsplit_tokenize: %zu files in %zu wave(s), %s %.3f s, per-cluster append %.3f s, %s %.3f s (of which %.3f s after the last wave was read; %llu fragments), regroup of %zu clusters %.3f s\n",
+                files.size(), waves.size(), device_path ? "gunzip (host threads)" : "gunzip + parse + route", t_split_done - t_begin - t_append,
+                t_append, device_path ? "device waves (text in, parse, group, tokenize, results out)" : "tokenizer calls", t_tok,
+                t_tok_done - t_split_done, (unsigned long long)n_all, nc, now() - t_tok_done);
+        fprintf(stderr, "[gtars host timing]   since the call was entered: %.3f s (set-up before the first wave %.3f s)\n", now() - t_enter, t_begin - t_enter);
+        if (device_path) {
+            double td[5] = {0, 0, 0, 0, 0};
+            for (Wave &w : waves)
+                for (int k = 0; k < 5; ++k) td[k] += w.td[k];
+            fprintf(stderr, "[gtars host timing]   device waves: text to the device %.3f s, line split + parse + sort by cluster %.3f s, gather %.3f s, tokenize %.3f s, results to the host %.3f s\n",
+                    td[0], td[1], td[2], td[3], td[4]);
+        }
+    }
     return GTARS_OK;
 }
 

@@ -159,6 +159,10 @@ typedef struct gtars_fragment_tokens {
 gtars_status gtars_tokenizer_tokenize_fragment_file(const gtars_tokenizer_t *t, const char *path,
                                                     gtars_fragment_tokens_t **out);
 void gtars_fragment_tokens_free(gtars_fragment_tokens_t *ft);
+/* the barcodes of `ft` in one buffer, '\n'-separated (no newline behind the last; barcodes are whitespace-free fields): one call
+ * for a binding that would otherwise convert n_barcodes C strings one by one (19,200 of them were a fifth of the fused
+ * pipeline's 48-file call from Python).  *out: gtars_free. */
+gtars_status gtars_fragment_tokens_barcodes_joined(const gtars_fragment_tokens_t *ft, char **out, uint64_t *out_len);
 
 /* ------------------------------------------------------------------------
  * gtars-fragsplit: pseudobulking of fragment files by a barcode -> cluster map.
@@ -198,6 +202,13 @@ gtars_status gtars_fragsplit_tokenize(const gtars_tokenizer_t *t, const char *fi
  * of consecutive runs merge by concatenation per barcode, gtars_amd/sharding.py fragsplit_tokenize_sharded) */
 gtars_status gtars_fragsplit_tokenize_files(const gtars_tokenizer_t *t, const char *const *paths, uint64_t n_paths,
                                             const gtars_barcode_map_t *m, gtars_fragment_tokens_t ***out, uint64_t *n_reads);
+
+/* Diagnostic: seconds per stage of the calling thread's last gtars_fragsplit_tokenize(_files) call.  out12 = { 1 if the text was
+ * parsed on the device (else on the host threads), waves, read + inflate on the host threads (host parser: + parse + route),
+ * per-cluster append (host parser only), device waves / tokenizer calls in total, of which behind the last wave's files,
+ * regroup by barcode, then for the device waves: text to the device, line split + parse + sort by cluster, gather, tokenize,
+ * results to the host }. */
+void gtars_fragsplit_last_stages(double *out12);
 
 /* Host threads one call of the file pipelines above starts at most: hardware threads, capped by the container's CPU quota
  * (cgroup v2 cpu.max) and by `cap`, divided by LOCAL_WORLD_SIZE when the process is one of several ranks of a launcher on this

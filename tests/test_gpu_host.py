@@ -915,6 +915,99 @@ def test_fused_fragment_pipeline_errors_between_waves(tk, golden_dir, tmp_path, 
 
 
 
+def test_device_fragment_parser_follows_the_reference_line_rules(tk, golden_dir, tmp_path, monkeypatch):
+    """Round 5: the fused pipeline's text is split and parsed ON THE GPU (fragparse.hip).  Every line rule of
+    gtars-fragsplit/src/split.rs:84-131 and gtars-tokenizers/src/utils/fragments.rs:12-82 on hand-made files, the device parser
+    against the host parser (GTARS_FRAG_HOST_PARSE=1) and against the oracle's restatement of the two-step pipeline: CRLF line
+    ends, a last line without a newline, runs of blanks and tabs between and in front of the fields, extra columns, '+' in front
+    of a number, '#' chromosomes (routed, never tokenized), unknown chromosomes (tokenized to unk), barcodes that are not in the
+    map (their lines are not even looked at: garbage numbers are fine there), an empty file, a plain-text (not gzip) file, the
+    same barcode in two files under different clusters; then the failures, each with the reference's message whichever parser
+    saw it first: fewer than five fields (also on unrouted lines, also an empty line), a routed line whose start / end is not
+    a u32, and an unreadable file BEHIND a malformed one (the earlier file's error wins)."""
+    import gzip
+
+    import oracle
+    from gtars_amd.fragsplit import BarcodeToClusterMap, fragsplit_tokenize, list_fragment_files
+    from test_sharding_gloo import oracle_fragment_pipeline, same_cluster_results
+
+    tok = tk("peaks.bed")
+    ub = os.path.join(golden_dir, "tokenizers", "peaks.bed")
+    peaks = [l.split()[:3] for l in open(ub) if l.strip()]
+    rng = np.random.default_rng(5)
+    fd = tmp_path / "frags"
+    fd.mkdir()
+
+    def frag(bc, chrom=None, plus=False):
+        c, s, e = peaks[int(rng.integers(0, len(peaks)))]
+        s, e = int(s) + int(rng.integers(0, 40)), int(e) + 3
+        return (chrom or c, ("+" if plus else "") + str(s), str(e), bc, "2")
+
+    a = ["\t".join(frag(f"A{k % 7}")) for k in range(300)]
+    a[5] = "  " + "   ".join(frag("A1")) + "  \t extra col"  # blanks in front, runs of blanks, extra columns
+    a[6] = "\t".join(frag("A2", plus=True))  # "+123" parses (str::parse::<u32>)
+    a[7] = "\t".join(frag("A3", chrom="#chr1"))  # routed, not tokenized
+    a[8] = "\t".join(frag("A4", chrom="chrNope"))  # unknown chromosome: one unk id
+    a[9] = "chr1\tNaN\t-5\tZZ9\t1"  # a barcode that is not in the map: nothing else of the line matters
+    a[10] = "chr1 100 200 A5 1 7 8 9"
+    (fd / "a.bed").write_text("\r\n".join(a))  # CRLF, plain text, no newline behind the last line
+    b = ["\t".join(frag(f"A{k % 5}")) for k in range(250)]  # the same barcodes as file a, other clusters
+    with gzip.open(fd / "b.bed.gz", "wt") as f:
+        f.write("\n".join(b) + "\n")
+    with gzip.open(fd / "c.bed.gz", "wt") as f:
+        f.write("")  # an empty file
+    with gzip.open(fd / "d.tsv.gz", "wt") as f:  # two extensions: the stem is "d"
+        f.write("\n".join("\t".join(frag("Q1")) for _ in range(40)) + "\n")
+    mp = tmp_path / "map.tsv"
+    mp.write_text("".join(f"a+A{k}\tc{k % 3}\n" for k in range(7)) + "".join(f"b+A{k}\tc{(k + 1) % 4}\n" for k in range(5)) + "d+Q1\tc9\n")
+    m = BarcodeToClusterMap.from_file(str(mp))
+
+    def both_parsers(check):
+        check("device")
+        monkeypatch.setenv("GTARS_FRAG_HOST_PARSE", "1")
+        check("host")
+        monkeypatch.delenv("GTARS_FRAG_HOST_PARSE")
+        monkeypatch.setenv("GTARS_FRAG_DEVICE_WAVE_MB", "0")  # every wave "too large" for the device: the whole call again on the host
+        check("device -> host")
+        monkeypatch.delenv("GTARS_FRAG_DEVICE_WAVE_MB")
+
+    om, otok = oracle.OracleBarcodeMap(str(mp)), oracle.OracleTokenizer(ub)
+    expected = oracle_fragment_pipeline(list_fragment_files(str(fd)), om, otok)
+
+    def good(which):
+        got = fragsplit_tokenize(str(fd), m, tok, as_arrays=True)
+        assert same_cluster_results(got, expected), which
+
+    both_parsers(good)
+    for threads in ("1", "3"):
+        monkeypatch.setenv("GTARS_HOST_THREADS", threads)  # waves of one / three files
+        both_parsers(good)
+    monkeypatch.delenv("GTARS_HOST_THREADS")
+
+    def expect_error(pattern):
+        def check(which):
+            with pytest.raises(RuntimeError, match=pattern):
+                fragsplit_tokenize(str(fd), m, tok)
+        both_parsers(check)
+
+    keep = (fd / "b.bed.gz").read_bytes()
+    for bad_line, pattern in (("chr1\t5\t9\tNOT_IN_MAP", "Failed to parse fragments file at line 250: chr1\t5\t9\tNOT_IN_MAP"),
+                              ("", "Failed to parse fragments file at line 250: $"),
+                              ("chr1\t1x\t9\tA1\t1", "Failed to parse start position of a routed fragment"),
+                              ("chr1\t1\t4294967296\tA1\t1", "Failed to parse end position of a routed fragment"),
+                              ("chr1\t\t\t5\t9\tA1", "Failed to parse fragments file at line 250")):
+        with gzip.open(fd / "b.bed.gz", "wt") as f:
+            f.write("\n".join(b) + "\n" + bad_line + "\nchr1\t1\t2\tA1\t1\n")
+        expect_error(pattern)
+    # an unreadable file behind the malformed one: files are visited in order, the malformed line is what the caller hears of
+    (fd / "bb.bed.gz").write_bytes(b"\x1f\x8b this is not a gzip stream")
+    expect_error("Failed to parse fragments file at line 250")
+    (fd / "b.bed.gz").write_bytes(keep)
+    expect_error("gzip|read error|Failed to")
+    os.remove(fd / "bb.bed.gz")
+    both_parsers(good)
+
+
 def test_lola_universe_helpers_kats():
     from gtars_amd.lola import check_universe, redefine_user_sets
 

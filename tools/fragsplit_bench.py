@@ -35,6 +35,16 @@ def main():
         t = time.perf_counter(); res2 = tokenize_fragment_files(cluster_files, tok, workers=16); t_tok = time.perf_counter() - t
         fragsplit_tokenize(fd, m, tok, as_arrays=True)  # warm-up (device buffers)
         t = time.perf_counter(); fused = fragsplit_tokenize(fd, m, tok, as_arrays=True); t_fused = time.perf_counter() - t
+        # where the fused call's time goes on the Python side: the C call alone, then the conversion of its result
+        import ctypes as C
+        from gtars_amd import _lib
+        from gtars_amd.fragsplit import _collect_cluster_results
+        o_, nr_ = C.POINTER(C.POINTER(_lib.FragmentTokens))(), C.c_uint64()
+        t = time.perf_counter()
+        _lib.check(_lib.lib.gtars_fragsplit_tokenize(tok._h, os.fspath(fd).encode(), m._h, C.byref(o_), C.byref(nr_)))
+        t_c = time.perf_counter() - t
+        t = time.perf_counter(); _collect_cluster_results(o_, m, True); t_py = time.perf_counter() - t
+        out["fused_call_split"] = {"c_call_s": round(t_c, 4), "python_result_conversion_s": round(t_py, 4)}
         ids_two = sum(sum(len(v) for v in d.values()) for d in res2)
         ids_fused = sum(int(v[1][-1]) for v in fused.values())
         out.update({"routed_fragments": st["written"], "token_ids": ids_fused, "same_id_count": ids_two == ids_fused,
