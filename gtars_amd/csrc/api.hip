@@ -1,6 +1,7 @@
 // api.hip -- C ABI of the integer-level engine: index / IGD handles, host and
 // device entry points (declared in include/gtars_amd.h).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -155,6 +156,10 @@ Workspace &tls_workspace(int slot, hipStream_t stream) {
             if (pool.idle[i].device == dev) {
                 w = pool.idle[i];
                 w.ep = ScanEpoch();  // whoever used it last may have left anything in it
+                // ... also in the 64 bytes at its head that outlive a call (launch_igd_sweep's order flags: "zero when the buffer
+                // is new" must hold for an adopted buffer as well)
+                w.igd_calls = 0;
+                if (w.ptr) (void)hipMemset(w.ptr, 0, 64);
                 pool.idle[i] = pool.idle.back();
                 pool.idle.pop_back();
                 break;
@@ -2390,7 +2395,15 @@ static gtars_status gtars_igd_build_impl(const uint32_t *chrom, const int32_t *s
     // The pieces view is an accelerator, not part of the database: when it cannot be built (device or host memory: it is a second
     // copy of the records) the flat layout alone serves every query correctly, only slower for databases with long records.
     try {
-        if (build_pieces_view(*out, chrom, start, end, file_idx, n) != GTARS_OK) {
+        const gtars_status pv = build_pieces_view(*out, chrom, start, end, file_idx, n);
+        if (pv != GTARS_OK) {
+            // (an accelerator that is missing is a slowdown nobody asked about: say so once per process, and why -- a failure that
+            // is not a memory shortage would otherwise only ever show as that slowdown)
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "gtars_amd: the pieces view of an IGD database could not be built (status %d: %s); databases with long records count slower\n",
+                        (int)pv, gtars_last_error());
+            prof_note_fact("igd_pieces_view_dropped");
             (void)hipGetLastError();
             set_error("");
         }

@@ -303,6 +303,26 @@ struct DevMem {
     }
 };
 
+// pieces of a workspace, 256-byte aligned
+struct Carve {
+    char *p = nullptr;
+    size_t at = 0;
+    template <class T>
+    T *take(size_t n) {
+        at = (at + 255) & ~(size_t)255;
+        T *r = reinterpret_cast<T *>(p + at);
+        at += n * sizeof(T);
+        return r;
+    }
+};
+struct View {
+    void *p;
+    template <class T>
+    T *as() const {
+        return (T *)p;
+    }
+};
+
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // builds the slots of an open-addressing table over `n` keys (views), values given; cap = power of two >= 2 n
@@ -392,11 +412,19 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
     const u32 n_bytes = (u32)total;
     const u32 n_chunks = (n_bytes + FP_CHUNK - 1) / FP_CHUNK;
     // ---- text + tables to the device ----
-    DevMem d_text, d_slots, d_keys, d_meta, d_chunks;
-    gtars_status s;
-    if ((s = d_text.alloc((size_t)std::max<u32>(n_chunks, 1) * FP_CHUNK + 64))) return s;
-    if ((s = d_slots.alloc(std::max<u64>(total_slots, 1) * sizeof(FragSlot)))) return s;
-    if ((s = d_keys.alloc(total_keys + 16))) return s;
+    // Device memory comes from three grow-only workspaces of the calling thread (pooled across threads, api.hip tls_workspace):
+    // a wave made ~10 allocations of up to 70 MB, and device allocations / frees synchronise.  Carved by `Carve` below.
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t m1 = (size_t)n_files + 1;
+    const size_t text_bytes = (size_t)std::max<u32>(n_chunks, 1) * FP_CHUNK + 64;
+    const size_t in_bytes = pad(text_bytes) + pad(std::max<u64>(total_slots, 1) * sizeof(FragSlot)) + pad(total_keys + 16) +
+                            pad((m1 * 4 + n_files + 1 + n_clusters + 1) * 4) + pad(((size_t)n_chunks + 1) * 2 * 4) + 1024;
+    Workspace &ws_in = tls_workspace(5, st);
+    gtars_status s = ws_in.reserve(in_bytes);
+    if (s) return s;
+    Carve cin{(char *)ws_in.ptr, 0};
+    View d_text{cin.take<char>(text_bytes)}, d_slots{cin.take<FragSlot>(std::max<u64>(total_slots, 1))}, d_keys{cin.take<char>(total_keys + 16)};
+    View d_meta{cin.take<u32>(m1 * 4 + n_files + 1 + n_clusters + 1)}, d_chunks{cin.take<u32>(((size_t)n_chunks + 1) * 2)};
     std::vector<u32> file_off(n_files + 1, 0), slot_off(n_files + 1, 0), key_off(n_files + 1, 0);
     for (u32 f = 0; f < n_files; ++f) {
         file_off[f + 1] = file_off[f] + (u32)files[f].n;
@@ -409,8 +437,6 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
     }
     GT_HIP(hipMemsetAsync(d_text.as<char>() + n_bytes, 0, (size_t)std::max<u32>(n_chunks, 1) * FP_CHUNK + 64 - n_bytes, st));
     // meta: file_off | slot_off | key_off | file_line [n_files + 1 each] | n_written [n_files] | err_file | coff [n_clusters + 1]
-    const size_t m1 = (size_t)n_files + 1;
-    if ((s = d_meta.alloc((m1 * 4 + n_files + 1 + n_clusters + 1) * 4))) return s;
     u32 *d_file_off = d_meta.as<u32>(), *d_slot_off = d_file_off + m1, *d_key_off = d_slot_off + m1, *d_file_line = d_key_off + m1;
     u32 *d_written = d_file_line + m1, *d_err = d_written + n_files, *d_coff = d_err + 1;
     GT_HIP(hipMemcpyAsync(d_file_off, file_off.data(), m1 * 4, hipMemcpyHostToDevice, st));
@@ -422,7 +448,6 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
     const double t1 = now_s();
     out.t_h2d = t1 - t0;
     // ---- line ends ----
-    if ((s = d_chunks.alloc(((size_t)n_chunks + 1) * 2 * 4))) return s;
     u32 *d_cnt = d_chunks.as<u32>(), *d_base = d_cnt + n_chunks + 1;
     u32 n_lines = 0;
     if (n_chunks) {
@@ -432,16 +457,18 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         GT_HIP(hipMemcpyAsync(&n_lines, d_base + n_chunks, 4, hipMemcpyDeviceToHost, st));
         GT_HIP(hipStreamSynchronize(st));
     }
-    DevMem d_lines, d_cols, d_sort, d_outcols;
     if (n_lines) {
-        if ((s = d_lines.alloc((size_t)n_lines * 4))) return s;
+        const size_t sort_ws = radix_sort_ws_bytes(n_lines);
+        Workspace &ws_ln = tls_workspace(6, st);
+        if ((s = ws_ln.reserve(pad((size_t)n_lines * 4) + pad((size_t)n_lines * 4 * 5) + pad((size_t)n_lines * 4 * 3 + sort_ws + 64) + 1024))) return s;
+        Carve cln{(char *)ws_ln.ptr, 0};
+        View d_lines{cln.take<u32>(n_lines)}, d_cols{cln.take<u32>((size_t)n_lines * 5)}, d_sort{cln.take<char>((size_t)n_lines * 4 * 3 + sort_ws + 64)};
         u32 *d_line_end = d_lines.as<u32>();
         hipLaunchKernelGGL(k_frag_lines<true>, dim3(n_chunks), dim3(FP_TPB), 0, st, d_text.as<u32>(), n_bytes, (u32 *)nullptr, (const u32 *)d_base,
                            d_line_end);
         hipLaunchKernelGGL(k_frag_file_lines, dim3((n_files + 1 + 63) / 64), dim3(64), 0, st, (const u32 *)d_line_end, n_lines,
                            (const u32 *)d_file_off, n_files, d_file_line);
         // ---- parse: per-line columns key | chrom | start | end | slot ----
-        if ((s = d_cols.alloc((size_t)n_lines * 4 * 5))) return s;
         u32 *d_key = d_cols.as<u32>(), *d_qc = d_key + n_lines, *d_qs = d_qc + n_lines, *d_qe = d_qs + n_lines, *d_qslot = d_qe + n_lines;
         FragTables tb{d_slots.as<FragSlot>(), d_keys.as<unsigned char>(), d_slot_off, d_key_off, chroms->slots.as<FragSlot>(),
                       chroms->keys.as<unsigned char>(), chroms->n_slots};
@@ -449,8 +476,6 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
                            (const u32 *)d_line_end, n_lines, (const u32 *)d_file_line, n_files, tb, d_key, d_qc, d_qs, d_qe, d_qslot, d_written, d_err);
         GT_HIP(hipGetLastError());
         // ---- the lines by cluster (stable: wave order inside a cluster), the tokenized ones in front ----
-        const size_t sort_ws = radix_sort_ws_bytes(n_lines);
-        if ((s = d_sort.alloc((size_t)n_lines * 4 * 3 + sort_ws + 64))) return s;
         u32 *d_v0 = d_sort.as<u32>(), *d_k1 = d_v0 + n_lines, *d_v1 = d_k1 + n_lines;
         void *ws = (void *)(((uintptr_t)(d_v1 + n_lines) + 63) & ~(uintptr_t)63);
         hipLaunchKernelGGL(k_frag_iota, dim3((n_lines + 255) / 256), dim3(256), 0, st, d_v0, n_lines);
@@ -483,7 +508,13 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         out.cbase.assign((size_t)n_clusters + 1, 0);
         if (n) {
             // cluster-major columns c | s | e | slot (u32 each), file (u16), then the token CSR
-            if ((s = d_outcols.alloc((size_t)n * 4 * 4 + (size_t)n * 2 + 64 + ((size_t)n + 1) * 8 + ((size_t)n_clusters + 2) * 8 + (size_t)n + 64))) return s;
+            u64 cap = (u64)n * 2 + 1024, h = 0;  // ids: a guessed capacity, the fill pass when it was short
+            const size_t cols_bytes = (size_t)n * 4 * 4 + (size_t)n * 2 + 64 + ((size_t)n + 1) * 8 + ((size_t)n_clusters + 2) * 8 + (size_t)n + 64;
+            Workspace &ws_out = tls_workspace(7, st);
+            if ((s = ws_out.reserve(pad(cols_bytes) + pad(cap * 4) + 1024))) return s;
+            Carve cout_{(char *)ws_out.ptr, 0};
+            View d_outcols{cout_.take<char>(cols_bytes)};
+            u32 *d_ids_ws = cout_.take<u32>(cap);
             u32 *oc = d_outcols.as<u32>(), *os = oc + n, *oe = os + n, *oslot = oe + n;
             u64 *d_off = reinterpret_cast<u64 *>(((uintptr_t)(oslot + n) + 7) & ~(uintptr_t)7);
             u64 *d_cbase = d_off + n + 1;
@@ -496,15 +527,13 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             const double t3 = now_s();
             out.t_group = t3 - t2;
             // ---- tokenize where the columns lie: one fused pass with a guessed capacity, the fill pass when it was short ----
-            u64 cap = (u64)n * 2 + 1024, h = 0;
-            DevMem d_ids;
-            if ((s = d_ids.alloc(cap * 4))) return s;
-            s = gtars_tokenize_device(ix, oc, os, oe, n, (uint64_t *)d_off, d_ids.as<uint32_t>(), cap, &h, st);
+            DevMem bigger;  // (only when the guess was short: a hit-heavy universe)
+            u32 *d_ids_p = d_ids_ws;
+            s = gtars_tokenize_device(ix, oc, os, oe, n, (uint64_t *)d_off, d_ids_p, cap, &h, st);
             if (s == GTARS_ERR_CAPACITY) {
-                DevMem bigger;
                 if ((s = bigger.alloc(h * 4))) return s;
-                std::swap(d_ids.p, bigger.p);
-                if ((s = gtars_fill_device_n(ix, oc, os, oe, n, (const uint64_t *)d_off, d_ids.as<uint32_t>(), h, st))) return s;
+                d_ids_p = bigger.as<u32>();
+                if ((s = gtars_fill_device_n(ix, oc, os, oe, n, (const uint64_t *)d_off, d_ids_p, h, st))) return s;
                 GT_HIP(hipStreamSynchronize(st));
             } else if (s) {
                 return s;
@@ -523,7 +552,7 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             GT_HIP(hipMemcpyAsync(out.cbase.data(), d_cbase, ((size_t)n_clusters + 1) * 8, hipMemcpyDeviceToHost, st));
             GT_HIP(hipMemcpyAsync(out.file.get(), ofile, (size_t)n * 2, hipMemcpyDeviceToHost, st));
             GT_HIP(hipMemcpyAsync(out.slot.get(), oslot, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-            if (h) GT_HIP(hipMemcpyAsync(out.ids, d_ids.p, h * 4, hipMemcpyDeviceToHost, st));
+            if (h) GT_HIP(hipMemcpyAsync(out.ids, d_ids_p, h * 4, hipMemcpyDeviceToHost, st));
             GT_HIP(hipStreamSynchronize(st));
             if (wide) {
                 out.off.reset(new uint64_t[(size_t)n + 1]);

@@ -83,24 +83,50 @@ def _barcodes_of(ft_ptr, nb: int) -> List[str]:
         lib.gtars_free(buf)
 
 
+class _ResultOwner:
+    """keeps one cluster's C result alive for as long as a numpy array still looks at its memory (``as_arrays`` results are
+    views, not copies: the copy of 15 MB of ids was a visible share of a 48-file call)"""
+
+    def __init__(self, ft_ptr):
+        self._addr = C.addressof(ft_ptr.contents)  # (the address itself: ft_ptr lives in the result array, which is freed at once)
+
+    def __del__(self):
+        if self._addr:
+            lib.gtars_fragment_tokens_free(C.cast(C.c_void_p(self._addr), C.POINTER(_lib.FragmentTokens)))
+            self._addr = 0
+
+
+def _view(owner, ptr, n: int, ctype, dtype):
+    if not n:
+        return np.zeros(0, dtype=dtype)
+    buf = (ctype * n).from_address(C.addressof(ptr.contents))
+    buf._owner = owner  # (the array's base chain ends here)
+    return np.frombuffer(buf, dtype=dtype)
+
+
 def _collect_cluster_results(out, mapping: BarcodeToClusterMap, as_arrays: bool):
     labels = mapping.cluster_labels()
     res = {}
+    owned = [False] * len(labels)
     try:
         for c, label in enumerate(labels):
             ft = out[c].contents
             nb = int(ft.n_barcodes)
-            offs = np.ctypeslib.as_array(ft.offsets, shape=(nb + 1,)).copy()
-            total = int(offs[nb])
-            ids = np.ctypeslib.as_array(ft.ids, shape=(max(total, 1),))[:total].copy()
             names = _barcodes_of(out[c], nb)
             if as_arrays:
+                owner = _ResultOwner(out[c])
+                owned[c] = True
+                offs = _view(owner, ft.offsets, nb + 1, C.c_uint64, np.uint64)
+                ids = _view(owner, ft.ids, int(offs[nb]), C.c_uint32, np.uint32)
                 res[label] = (names, offs, ids)
             else:
+                offs = np.ctypeslib.as_array(ft.offsets, shape=(nb + 1,))
+                ids = np.ctypeslib.as_array(ft.ids, shape=(max(int(offs[nb]), 1),))
                 res[label] = {names[b]: [int(v) for v in ids[int(offs[b]):int(offs[b + 1])]] for b in range(nb)}
     finally:
         for c in range(len(labels)):
-            lib.gtars_fragment_tokens_free(out[c])
+            if not owned[c]:
+                lib.gtars_fragment_tokens_free(out[c])
         lib.gtars_free(C.cast(out, C.c_void_p))
     return res
 
