@@ -62,7 +62,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def algorithmic_bytes(nq: int, h: int, nu: int) -> int:

@@ -44,6 +44,11 @@ def one(seed):
         os.environ["GTARS_IGD_SWEEP_MIN"] = "1"
     else:
         os.environ.pop("GTARS_IGD_SWEEP_MIN", None)
+    # round 5: pairwise counts with min_overlap == 1 sweep in rank-histogram form; a quarter of the cases keep the candidate walk
+    if rng.random() < 0.25:
+        os.environ["GTARS_IGD_NO_RANK"] = "1"
+    else:
+        os.environ.pop("GTARS_IGD_NO_RANK", None)
     gtars_amd.reload_env()
     # min_overlap <= 0: the reference's tile walk also admits non-overlapping records (per-query kernels with the tile test)
     for mo in (1, int(rng.integers(2, 40)), int(rng.choice([0, -1, -30, -20_000]))):
