@@ -357,6 +357,15 @@ struct gtars_index {
     // position of the companion's stored position p' (for the device bitmap of gtars_mark_overlapped_device).
     gtars_index *flat = nullptr;
     DevBuf<u32> flat_pos;
+    // ... and, round 5, enumeration in AIList::find order as well: the companion's LDS tokenizer writes the hits as its own stored
+    // positions, and k_ailist_reorder sorts every query's hits by ail_key[position] -- the hit's mirrored position in THIS index's
+    // stored order (sub-list start + sub-list length - 1 - index inside the sub-list: ascending = sub-lists in order, each from
+    // its last interval down, ailist.rs:153-178, 238-263) -- and replaces them by ail_val[key]
+    DevBuf<u32> ail_key, ail_val;
+    // ... unless the universe is so deep (mean number of intervals over a covered position) that most queries have long tails:
+    // there the LDS tokenizer walks and the one-thread-per-query kernel wins (tools/ailist_bench.py: depth 0.5 / 4.6 / 7.7 ->
+    // 0.43 vs 1.52, 2.30 vs 3.07, 3.34 vs 2.71 ms per 16M queries); GTARS_AILIST_REORDER_MAX_DEPTH moves the line (default 6)
+    double ail_depth = 0;
     // per-chromosome sorted copy of the ends, built on the first Bits::count call (bits.rs:118-121)
     mutable std::mutex ends_mu;
     mutable DevBuf<u32> ends_sorted;
@@ -1092,6 +1101,36 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
             if (ix->flat_pos.upload(map) == GTARS_OK) {
                 ix->flat = fl;
                 fl = nullptr;
+                // mirrored positions: for stored position a of sub-list [s0, s1): key = s0 + (s1 - 1 - a)
+                std::vector<u32> mirror(n), key(n), val(n);
+                for (u32 c = 0; c < n_chrom; ++c)
+                    for (u32 h = ix->h_chrom_sub[c]; h + 1 < ix->h_chrom_sub[c + 1]; ++h) {
+                        const u32 s0 = ix->h_sub_off[h], s1 = ix->h_sub_off[h + 1];
+                        for (u32 a = s0; a < s1; ++a) mirror[a] = s0 + (s1 - 1u - a);
+                    }
+                for (u64 p = 0; p < n; ++p) {
+                    key[p] = mirror[map[p]];
+                    val[mirror[map[p]]] = ix->h_vals[map[p]];
+                }
+                {
+                    double bp = 0, span = 0;
+                    for (u32 c = 0; c < n_chrom; ++c) {
+                        const u32 a0 = ix->h_chrom_off[c], a1 = ix->h_chrom_off[c + 1];
+                        if (a0 == a1) continue;
+                        u32 lo = 0xFFFFFFFFu, hi = 0;
+                        for (u32 a = a0; a < a1; ++a) {
+                            lo = std::min(lo, ix->h_starts[a]);
+                            hi = std::max(hi, ix->h_ends[a]);
+                            if (ix->h_ends[a] > ix->h_starts[a]) bp += (double)(ix->h_ends[a] - ix->h_starts[a]);
+                        }
+                        if (hi > lo) span += (double)(hi - lo);
+                    }
+                    ix->ail_depth = span > 0 ? bp / span : 0;
+                }
+                if (ix->ail_key.upload(key) != GTARS_OK || ix->ail_val.upload(val) != GTARS_OK) {
+                    ix->ail_key.release();  // (out of device memory: enumeration stays on the generic kernel)
+                    ix->ail_val.release();
+                }
             }
         }
         if (fl) gtars_index_free(fl);
@@ -1105,6 +1144,8 @@ void gtars_index_free(gtars_index_t *ix) {
     if (!ix) return;
     gtars_index_free(ix->flat);
     ix->flat_pos.release();
+    ix->ail_key.release();
+    ix->ail_val.release();
     ix->starts.release();
     ix->ends.release();
     ix->vals.release();
@@ -1204,6 +1245,16 @@ static gtars_status run_fused(const gtars_index *ix, const u32 *qc, const u32 *q
     if (use_lds_path(ix) && !out.starts && !out.ends)
         return launch_tokenize_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s, nullptr, nullptr,
                                    ix->kind == GTARS_KIND_AILIST);
+    if (ix->kind == GTARS_KIND_AILIST && ix->flat && ix->ail_key.p && ix->ail_val.p && use_lds_path(ix->flat) && !out.starts && !out.ends &&
+        !cfg_flag("GTARS_AILIST_NO_REORDER") && ix->ail_depth < (double)cfg_int("GTARS_AILIST_REORDER_MAX_DEPTH", 6)) {
+        // a nested AIList index: the hit SET from the flat companion's LDS tokenizer (its stored positions, Bits order), the ORDER
+        // by k_ailist_reorder -- one more pass over the offsets and ids instead of the one-thread-per-query generic kernel
+        gtars_status st = launch_tokenize_lds(ix->flat->accel_pos(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s, nullptr,
+                                              nullptr, false);
+        if (st || !out.vals) return st;  // (offsets only: the counts do not depend on the order)
+        prof_note_fact("ailist_nested_on_lds");
+        return launch_ailist_reorder(out.vals, out.offsets, nq, out.capacity, ix->ail_key.p, ix->ail_val.p, s);
+    }
     ep = ScanEpoch();  // the generic kernel clears the workspace itself
     return launch_enumerate_fused(ix->view(), ix->kind, qc, qs, qe, nq, has_min, min_overlap, out, ws,
                                   ws_bytes, s);

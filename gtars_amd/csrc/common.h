@@ -253,6 +253,9 @@ gtars_status launch_igd_fill_pairs(const IgdView &v, const u32 *qc, const u32 *q
 gtars_status launch_lola_contingency(const u64 *user_hits, const u64 *universe_hits, u64 n_files,
                                      i64 user_size, i64 universe_size, i64 *a, i64 *b, i64 *c, i64 *d,
                                      hipStream_t st);
+// a nested AIList index's enumeration order from its flat companion's hits (kernels.hip: k_ailist_reorder)
+gtars_status launch_ailist_reorder(u32 *ids, const u64 *offsets, u64 nq, u64 capacity, const u32 *key_by_pos, const u32 *val_by_key,
+                                   hipStream_t st);
 gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, u32 *new_counts,
                                          hipStream_t st);
 

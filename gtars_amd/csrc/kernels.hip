@@ -575,6 +575,71 @@ gtars_status launch_sort_unique_segments(u32 *vals, const u64 *offsets, u64 nq, 
     return GTARS_OK;
 }
 
+// AIList::find order for a nested AIList index from its flat companion's hits (round 5).  The companion's LDS tokenizer has
+// written every query's hits as STORED POSITIONS of the companion, in Bits order; AIList::find emits sub-list after sub-list,
+// each walked from its last candidate down (ailist.rs:153-178, 238-263).  key_by_pos[p] = the hit's MIRRORED position in the
+// AIList's stored order (sub-list start + sub-list length - 1 - index in the sub-list): ascending keys = sub-lists ascending,
+// positions descending -- exactly that order -- so a query's hits are sorted by key in place (insertion sort: most queries have
+// one or two hits; heap sort beyond 32) and then replaced by their values (val_by_key).  One thread per query.  Queries whose ids
+// lie (partly) beyond `capacity` are left alone: the launch ends in GTARS_ERR_CAPACITY anyway.
+__global__ void __launch_bounds__(256)
+k_ailist_reorder(u32 *__restrict__ ids, const u64 *__restrict__ offsets, u64 nq, u64 capacity, const u32 *__restrict__ key_by_pos,
+                 const u32 *__restrict__ val_by_key) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+        const u64 lo = offsets[q], hi = offsets[q + 1];
+        if (hi == lo || hi > capacity) continue;
+        u32 *a = ids + lo;
+        const u64 n = hi - lo;
+        if (n == 1) {
+            a[0] = val_by_key[key_by_pos[a[0]]];
+            continue;
+        }
+        for (u64 i = 0; i < n; ++i) a[i] = key_by_pos[a[i]];
+        if (n <= 32) {
+            for (u64 i = 1; i < n; ++i) {
+                const u32 x = a[i];
+                u64 j = i;
+                while (j > 0 && a[j - 1] > x) {
+                    a[j] = a[j - 1];
+                    --j;
+                }
+                a[j] = x;
+            }
+        } else {
+            auto sift = [&](u64 root, u64 end) {  // max-heap on a[0, end)
+                const u32 x = a[root];
+                for (;;) {
+                    u64 ch = 2 * root + 1;
+                    if (ch >= end) break;
+                    if (ch + 1 < end && a[ch + 1] > a[ch]) ++ch;
+                    if (a[ch] <= x) break;
+                    a[root] = a[ch];
+                    root = ch;
+                }
+                a[root] = x;
+            };
+            for (u64 i = n / 2; i > 0; --i) sift(i - 1, n);
+            for (u64 end = n - 1; end > 0; --end) {
+                const u32 t = a[0];
+                a[0] = a[end];
+                a[end] = t;
+                sift(0, end);
+            }
+        }
+        for (u64 i = 0; i < n; ++i) a[i] = val_by_key[a[i]];
+    }
+}
+
+gtars_status launch_ailist_reorder(u32 *ids, const u64 *offsets, u64 nq, u64 capacity, const u32 *key_by_pos, const u32 *val_by_key,
+                                   hipStream_t st) {
+    if (nq == 0) return GTARS_OK;
+    ProfScope p("k_ailist_reorder", st);
+    hipLaunchKernelGGL(k_ailist_reorder, dim3(stream_grid(nq, 256)), dim3(256), 0, st, ids, offsets, nq, capacity, key_by_pos, val_by_key);
+    GT_HIP(hipGetLastError());
+    return GTARS_OK;
+}
+
 // ---------------------------------------------------------------- K5: IGD
 //
 // The reference walks nbp-sized tiles (igd.rs:753-847); for min_overlap >= 1

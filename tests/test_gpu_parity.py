@@ -336,6 +336,77 @@ def test_nested_ailist_index_answers_order_free_calls_on_its_flat_companion(ga):
     assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
 
 
+def test_nested_ailist_enumeration_order_from_the_flat_companion(ga, monkeypatch):
+    """Round 5: a tokenizer_type = "ailist" universe with NESTED sub-lists (config.rs:27-41; any overlapping universe) no longer
+    enumerates on the one-thread-per-query kernel: the hit set comes from the flat companion's LDS tokenizer and
+    k_ailist_reorder puts every query's hits into AIList::find order -- sub-list after sub-list, each from its last candidate
+    down (ailist.rs:153-178, 238-263).  Offsets and ids == the oracle's, on heavily nested data (up to dozens of hits per query,
+    several sub-list levels, duplicates of the same interval with different values, queries with > 32 hits: the heap-sort
+    branch), through the host call, the device call, a too-small id buffer + fill, and with a min-overlap filter through
+    find_overlaps; the generic kernel (GTARS_AILIST_NO_REORDER) agrees.  Which path ran is a profiling fact."""
+    import torch
+
+    monkeypatch.setenv("GTARS_AILIST_REORDER_MAX_DEPTH", "1000")  # (this universe is deep: by default it would keep the generic kernel)
+    _lib = ga._lib
+    rng = np.random.default_rng(77)
+    n, n_chrom, span = 50_000, 3, 6_000_000
+    c = rng.integers(0, n_chrom, n).astype(np.uint32)
+    s = rng.integers(0, span, n).astype(np.uint32)
+    w = np.where(rng.random(n) < 0.03, rng.integers(5_000, 300_000, n), rng.integers(100, 900, n))
+    e = (s + w).astype(np.uint32)
+    s[100:140] = s[100]  # forty copies of one interval (values differ: their order among themselves is the stored order)
+    e[100:140] = e[100]
+    c[100:140] = c[100]
+    v = rng.permutation(n).astype(np.uint32)
+    g = ga.OverlapIndex(c, s, e, v, n_chrom=n_chrom, kind=KIND_AILIST)
+    o = oracle.Index(c, s, e, v, n_chrom=n_chrom, kind=KIND_AILIST)
+    assert max(len(g.sublist_offsets(ch)) for ch in range(n_chrom)) > 2  # several levels
+    nq = 120_000
+    qc = rng.integers(0, n_chrom + 1, nq).astype(np.uint32)
+    qc[qc == n_chrom] = UNK
+    qs = rng.integers(0, span + 10_000, nq).astype(np.uint32)
+    qe = (qs + np.where(rng.random(nq) < 0.01, rng.integers(20_000, 60_000, nq), rng.integers(0, 900, nq))).astype(np.uint32)
+    qs[:50] = s[100]  # queries on the forty copies
+    qe[:50] = e[100]
+    qc[:50] = c[100]
+    off_o, ids_o = o.tokenize(qc, qs, qe)
+    assert int(np.diff(off_o.astype(np.int64)).max()) > 32
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    off_g, ids_g = g.tokenize(qc, qs, qe)
+    facts = _lib.prof_read()
+    _lib.lib.gtars_prof_enable(0)
+    assert "ailist_nested_on_lds" in facts and "k_tok_lds" in facts and "k_ailist_reorder" in facts, sorted(facts)
+    assert np.array_equal(off_g, off_o) and np.array_equal(ids_g, ids_o)
+    # device call into a too-small buffer: CAPACITY, offsets complete; the fill pass (generic kernel, AIList order) completes the ids
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    d = [torch.from_numpy(x.view(np.int32)).to(dev) for x in (qc, qs, qe)]
+    off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+    small = torch.empty(len(ids_o) // 3, dtype=torch.int32, device=dev)
+    with pytest.raises(ga.CapacityError):
+        g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), small.data_ptr(), small.numel(), st)
+    assert np.array_equal(off.cpu().numpy().view(np.uint64), off_o)
+    full = torch.empty(len(ids_o), dtype=torch.int32, device=dev)
+    g.fill_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), full.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy().view(np.uint32), ids_o)
+    h = g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), full.data_ptr(), full.numel(), st)
+    assert h == len(ids_o) and np.array_equal(full.cpu().numpy().view(np.uint32), ids_o)
+    monkeypatch.setenv("GTARS_AILIST_NO_REORDER", "1")
+    off_x, ids_x = g.tokenize(qc, qs, qe)
+    assert np.array_equal(off_x, off_o) and np.array_equal(ids_x, ids_o)
+    monkeypatch.delenv("GTARS_AILIST_NO_REORDER")
+    # the default depth line: this universe (mean depth ~14 intervals per covered position) keeps the generic kernel
+    monkeypatch.delenv("GTARS_AILIST_REORDER_MAX_DEPTH")
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    off_y, ids_y = g.tokenize(qc, qs, qe)
+    facts = _lib.prof_read()
+    _lib.lib.gtars_prof_enable(0)
+    assert "ailist_nested_on_lds" not in facts and np.array_equal(off_y, off_o) and np.array_equal(ids_y, ids_o)
+
+
 def test_config1_1k_by_1k(ga):
     # BASELINE config 1: 1k x 1k single chromosome (SURVEY 8d C1)
     from gtars_amd import synth

@@ -37,7 +37,8 @@ def main():
     if int(os.environ.get("SORTED", "0")):  # position-sorted batch (a sorted BED / fragment file): neighbours share records
         order = np.lexsort((q["start"], q["chrom"]))
         q = {k: v[order] for k, v in q.items()}
-    ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+    kind = int(os.environ.get("KIND", "0"))  # 1: AIList order (with OVERLAP=1: nested sub-lists -> flat companion + reorder)
+    ix = gtars_amd.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM, kind=kind)
     sizes = [int(x) for x in os.environ.get("SIZES", "1000000,16000000,64000000").split(",")]
     configs = [c for c in os.environ.get("CONFIGS", "512:0:4").split(",")]
     for cfg in configs:
