@@ -423,3 +423,46 @@ def test_host_thread_budget_is_shared_between_the_ranks_of_a_node(monkeypatch):
     monkeypatch.setenv("GTARS_HOST_THREADS", "5")
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     assert L.lib.gtars_host_threads(2) == 5
+
+
+def test_gzip_reader_follows_the_multi_member_decoder(tmp_path):
+    """Round 5: the host layer inflates with zlib's inflate() on the whole compressed file (the gz layer of zlib cost half as
+    much again as the inflate).  What a reader of gtars-core/src/utils.rs:115-126 (flate2's MultiGzDecoder behind the "gz"
+    extension) and zlib's gzread both do: concatenated members are decoded one after the other, a large file (several output
+    growth steps: its ISIZE lies about the length when members are concatenated), bytes behind the last member that do not
+    start another one are ignored, a ".gz" without the gzip magic is read as it is, an empty file is empty; a file that ends
+    inside a member, or whose CRC is wrong, is an error."""
+    import gzip
+
+    from gtars_amd import utils
+
+    rng = np.random.default_rng(3)
+    lines = [f"chr{1 + i // 4000}\t{1000 + 37 * i}\t{1200 + 37 * i}\tBC{int(rng.integers(0, 300)):03d}\t{1 + i % 3}\n" for i in range(20_000)]
+    text = "".join(lines)
+
+    def check(path, n_lines):
+        d = utils.read_fragments(str(path))
+        assert len(d["start"]) == n_lines
+        if n_lines:
+            assert int(d["start"][0]) == 1000 and int(d["start"][n_lines - 1]) == 1000 + 37 * ((n_lines - 1) % 20_000)
+
+    one = gzip.compress(text.encode())
+    (tmp_path / "one.bed.gz").write_bytes(one)
+    check(tmp_path / "one.bed.gz", 20_000)
+    # three members (the last one's ISIZE says a third of the total), then the same with garbage behind the last member
+    (tmp_path / "three.bed.gz").write_bytes(one + gzip.compress(text.encode(), 1) + one)
+    check(tmp_path / "three.bed.gz", 60_000)
+    (tmp_path / "tail.bed.gz").write_bytes(one + b"\x00\x00garbage that is no gzip header")
+    check(tmp_path / "tail.bed.gz", 20_000)
+    (tmp_path / "plain.bed.gz").write_text(text)  # no magic: passed through
+    check(tmp_path / "plain.bed.gz", 20_000)
+    (tmp_path / "empty.bed.gz").write_bytes(b"")
+    check(tmp_path / "empty.bed.gz", 0)
+    (tmp_path / "cut.bed.gz").write_bytes(one[: len(one) // 2])
+    with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error"):
+        utils.read_fragments(str(tmp_path / "cut.bed.gz"))
+    bad = bytearray(one)
+    bad[-6] ^= 0x55  # the CRC in the trailer
+    (tmp_path / "crc.bed.gz").write_bytes(bytes(bad))
+    with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error"):
+        utils.read_fragments(str(tmp_path / "crc.bed.gz"))
