@@ -28,6 +28,14 @@ struct FragSlot {
     uint32_t pad;
 };
 
+// One gzip member of a file whose CRC-32 the DEVICE checks (round 5): the host thread inflated the member's deflate stream raw --
+// zlib's crc32 is a quarter of its inflate time, and the inflated bytes go to the GPU anyway -- and hands over where the member's
+// bytes lie in the file's text and what its trailer says.
+struct FragGzMember {
+    uint64_t off, len;  // bytes [off, off + len) of the file's text
+    uint32_t crc;       // CRC-32 of the trailer (RFC 1952)
+};
+
 // one fragment file of a wave, inflated, as the host hands it over
 struct FragFileIn {
     const char *text = nullptr;  // the whole file; ends with '\n' unless empty (the caller appends one when the file lacks it)
@@ -37,6 +45,10 @@ struct FragFileIn {
     uint32_t n_slots = 0;  // a power of two (>= 1)
     const char *keys = nullptr;
     uint32_t n_key_bytes = 0;
+    // gzip members whose CRC-32 is still to be checked (empty: the host has verified the file, or it is not gzip).  NOTE: the
+    // newline the caller may append behind the last line is not part of any member.
+    const FragGzMember *members = nullptr;
+    uint32_t n_members = 0;
 };
 
 // what comes back for a wave: the routed fragments CLUSTER-MAJOR (clusters ascending; inside a cluster files in wave order, lines
@@ -53,8 +65,9 @@ struct FragWaveOut {
     std::unique_ptr<uint64_t[]> off;   // [n + 1], or null
     uint32_t *ids = nullptr;           // malloc'ed (free)
     std::vector<uint64_t> n_reads, n_written;  // per file: lines, routed lines ('#' lines included)
-    int64_t first_error_file = -1;     // first file (wave order) with a line the reference fails on; -1: none.  The caller re-parses
-                                       // that file on the host for the reference's message.
+    int64_t first_error_file = -1;     // first file (wave order) with a line the reference fails on, or with a gzip member whose
+                                       // CRC-32 is not its trailer's; -1: none.  The caller reads that file again on the host (zlib's
+                                       // own check, the host parser) for the reference's message.
     double t_h2d = 0, t_parse = 0, t_group = 0, t_tok = 0, t_d2h = 0;  // seconds (GTARS_HOST_TIMING)
 };
 

@@ -288,6 +288,133 @@ __global__ void k_frag_cluster_bases(const u64 *__restrict__ off, const u32 *__r
     if (c <= n_clusters) base[c] = off[coff[c]];
 }
 
+// ---- CRC-32 (RFC 1952: reflected polynomial 0xEDB88320) of the gzip members on the device ----------------------------------
+// The register after processing bytes B from register s is  shift_|B|(s) ^ f(0, B)  (the CRC is linear over GF(2)), shift_n =
+// "process n zero bytes".  So: (1) one lane per 512-byte chunk forms f(0, chunk) byte by byte (table of 256 words in LDS);
+// (2) one lane per group of 64 chunks folds them left to right with shift_512 (four tables of 256 words: one per byte of s);
+// (3) one lane per member folds its groups with shift_32768, starting from 0xFFFFFFFF, and compares the complement with the
+// trailer's CRC.  The last chunk / group of a member is short: its shift is applied 512 bytes, then a byte at a time.
+constexpr u32 CRC_CHUNK = 512, CRC_GROUP = 64;
+struct CrcTables {
+    u32 byte[256];         // one byte of data
+    u32 s512[4][256];      // shift by 512 zero bytes, per byte of the register
+    u32 s32k[4][256];      // shift by 512 * 64 zero bytes
+};
+__device__ __forceinline__ u32 crc_shift(const u32 (*t)[256], u32 s) {
+    return t[0][s & 0xFFu] ^ t[1][(s >> 8) & 0xFFu] ^ t[2][(s >> 16) & 0xFFu] ^ t[3][s >> 24];
+}
+__device__ __forceinline__ u32 crc_zero_bytes(const u32 *byte_tab, u32 s, u32 n) {  // n < 512 zero bytes, one at a time
+    for (u32 i = 0; i < n; ++i) s = byte_tab[s & 0xFFu] ^ (s >> 8);
+    return s;
+}
+struct CrcMember {
+    u32 off, len, crc, file;   // text bytes [off, off + len), trailer CRC, file of the wave
+    u32 chunk0, group0;        // first chunk / group of the member in the flattened arrays
+};
+// (1) f(0, chunk) for every chunk of every member
+__global__ void __launch_bounds__(256)
+k_crc_chunks(const unsigned char *__restrict__ text, const CrcMember *__restrict__ mem, u32 n_mem, u32 n_chunks, const CrcTables *__restrict__ tb,
+             u32 *__restrict__ part) {
+    __shared__ u32 s_t[256];
+    s_t[threadIdx.x] = tb->byte[threadIdx.x];
+    __syncthreads();
+    const u32 c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n_chunks) return;
+    u32 lo = 0, hi = n_mem;  // the chunk's member: last m with chunk0 <= c
+    while (lo + 1 < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (mem[mid].chunk0 <= c)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const CrcMember m = mem[lo];
+    const u32 b0 = (c - m.chunk0) * CRC_CHUNK, n = min(CRC_CHUNK, m.len - b0);
+    const unsigned char *p = text + m.off + b0;
+    u32 s = 0;
+    u32 i = 0;
+    for (; i + 4 <= n && ((uintptr_t)(p + i) & 3u) != 0; ++i) s = s_t[(s ^ p[i]) & 0xFFu] ^ (s >> 8);
+    for (; i + 4 <= n; i += 4) {
+        u32 w = *reinterpret_cast<const u32 *>(p + i);
+        s ^= w;
+        s = s_t[s & 0xFFu] ^ (s >> 8);
+        s = s_t[s & 0xFFu] ^ (s >> 8);
+        s = s_t[s & 0xFFu] ^ (s >> 8);
+        s = s_t[s & 0xFFu] ^ (s >> 8);
+    }
+    for (; i < n; ++i) s = s_t[(s ^ p[i]) & 0xFFu] ^ (s >> 8);
+    part[c] = s;
+}
+// (2) f(0, group) for every group of <= 64 chunks of a member
+__global__ void k_crc_groups(const CrcMember *__restrict__ mem, u32 n_mem, u32 n_groups, const CrcTables *__restrict__ tb, const u32 *__restrict__ part,
+                             u32 *__restrict__ gpart) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    u32 lo = 0, hi = n_mem;
+    while (lo + 1 < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (mem[mid].group0 <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const CrcMember m = mem[lo];
+    const u32 n_ch = (m.len + CRC_CHUNK - 1) / CRC_CHUNK, c0 = (g - m.group0) * CRC_GROUP, c1 = min(n_ch, c0 + CRC_GROUP);
+    u32 s = 0;
+    for (u32 c = c0; c < c1; ++c) {
+        const u32 n = min(CRC_CHUNK, m.len - c * CRC_CHUNK);
+        s = (n == CRC_CHUNK ? crc_shift(tb->s512, s) : crc_zero_bytes(tb->byte, s, n)) ^ part[m.chunk0 + c];
+    }
+    gpart[g] = s;
+}
+// (3) the member's CRC against its trailer; the first file (wave order) with a mismatch is noted
+__global__ void k_crc_members(const CrcMember *__restrict__ mem, u32 n_mem, const CrcTables *__restrict__ tb, const u32 *__restrict__ gpart,
+                              u32 *__restrict__ err_file) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_mem) return;
+    const CrcMember m = mem[i];
+    const u32 n_ch = (m.len + CRC_CHUNK - 1) / CRC_CHUNK, n_g = (n_ch + CRC_GROUP - 1) / CRC_GROUP;
+    u32 s = 0xFFFFFFFFu;
+    for (u32 g = 0; g < n_g; ++g) {
+        const u32 bytes = min(CRC_CHUNK * CRC_GROUP, m.len - g * CRC_CHUNK * CRC_GROUP);
+        if (bytes == CRC_CHUNK * CRC_GROUP) {
+            s = crc_shift(tb->s32k, s);
+        } else {
+            for (u32 k = 0; k < bytes / CRC_CHUNK; ++k) s = crc_shift(tb->s512, s);
+            s = crc_zero_bytes(tb->byte, s, bytes % CRC_CHUNK);
+        }
+        s ^= gpart[m.group0 + g];
+    }
+    if ((s ^ 0xFFFFFFFFu) != m.crc) atomicMin(err_file, m.file);
+}
+
+// the three tables, built once per process on the host
+const CrcTables &crc_tables_host() {
+    static const CrcTables t = [] {
+        CrcTables x;
+        for (u32 i = 0; i < 256; ++i) {
+            u32 c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            x.byte[i] = c;
+        }
+        auto zeros = [&](u32 s, u32 n) {
+            for (u32 i = 0; i < n; ++i) s = x.byte[s & 0xFFu] ^ (s >> 8);
+            return s;
+        };
+        for (u32 b = 0; b < 4; ++b)
+            for (u32 v = 0; v < 256; ++v) x.s512[b][v] = zeros(v << (8 * b), CRC_CHUNK);
+        auto sh512 = [&](u32 s) { return x.s512[0][s & 0xFFu] ^ x.s512[1][(s >> 8) & 0xFFu] ^ x.s512[2][(s >> 16) & 0xFFu] ^ x.s512[3][s >> 24]; };
+        for (u32 b = 0; b < 4; ++b)
+            for (u32 v = 0; v < 256; ++v) {
+                u32 s = v << (8 * b);
+                for (u32 k = 0; k < CRC_GROUP; ++k) s = sh512(s);
+                x.s32k[b][v] = s;
+            }
+        return x;
+    }();
+    return t;
+}
+
 struct DevMem {
     void *p = nullptr;
     ~DevMem() {
@@ -344,7 +471,7 @@ void build_table(const std::vector<std::pair<const char *, u32>> &keys, const st
 }  // namespace
 
 struct FragChroms {
-    DevMem slots, keys;
+    DevMem slots, keys, crc;  // the chromosome table; the CRC-32 tables (device copy, made with it)
     u32 n_slots = 0;
     int device = 0;
 };
@@ -369,6 +496,8 @@ gtars_status frag_chroms_create(const std::vector<std::string> &names, FragChrom
     GT_HIP(hipMemcpy(c->slots.p, slots.data(), slots.size() * sizeof(FragSlot), hipMemcpyHostToDevice));
     if (!blob.empty()) GT_HIP(hipMemcpy(c->keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     c->n_slots = (u32)slots.size();
+    if ((st = c->crc.alloc(sizeof(CrcTables)))) return st;
+    GT_HIP(hipMemcpy(c->crc.p, &crc_tables_host(), sizeof(CrcTables), hipMemcpyHostToDevice));
     *out = c.release();
     return GTARS_OK;
 }
@@ -444,6 +573,37 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
     GT_HIP(hipMemcpyAsync(d_key_off, key_off.data(), m1 * 4, hipMemcpyHostToDevice, st));
     GT_HIP(hipMemsetAsync(d_written, 0, (size_t)n_files * 4, st));
     GT_HIP(hipMemsetAsync(d_err, 0xFF, 4, st));
+    // ---- the gzip members' CRC-32 (the host threads inflated them raw) ----
+    std::vector<CrcMember> h_mem;
+    u32 crc_chunks = 0, crc_groups = 0;
+    for (u32 f = 0; f < n_files; ++f)
+        for (u32 k = 0; k < files[f].n_members; ++k) {
+            const FragGzMember &gm = files[f].members[k];
+            if (gm.off + gm.len > files[f].n) return fail(GTARS_ERR_INTERNAL, "fragment wave: a gzip member lies outside its file's text");
+            CrcMember m{file_off[f] + (u32)gm.off, (u32)gm.len, gm.crc, f, crc_chunks, crc_groups};
+            const u32 n_ch = ((u32)gm.len + CRC_CHUNK - 1) / CRC_CHUNK;
+            crc_chunks += n_ch;
+            crc_groups += (n_ch + CRC_GROUP - 1) / CRC_GROUP;
+            h_mem.push_back(m);
+        }
+    if (!h_mem.empty()) {
+        Workspace &ws_crc = tls_workspace(8, st);
+        if ((s = ws_crc.reserve(pad(h_mem.size() * sizeof(CrcMember)) + pad((size_t)crc_chunks * 4) + pad((size_t)crc_groups * 4) + 1024))) return s;
+        Carve cc{(char *)ws_crc.ptr, 0};
+        CrcMember *d_mem = cc.take<CrcMember>(h_mem.size());
+        u32 *d_part = cc.take<u32>(crc_chunks), *d_gpart = cc.take<u32>(crc_groups);
+        GT_HIP(hipMemcpyAsync(d_mem, h_mem.data(), h_mem.size() * sizeof(CrcMember), hipMemcpyHostToDevice, st));
+        const CrcTables *d_tb = chroms->crc.as<CrcTables>();
+        const u32 nm = (u32)h_mem.size();
+        if (crc_chunks)
+            hipLaunchKernelGGL(k_crc_chunks, dim3((crc_chunks + 255) / 256), dim3(256), 0, st, d_text.as<unsigned char>(), (const CrcMember *)d_mem, nm,
+                               crc_chunks, d_tb, d_part);
+        if (crc_groups)
+            hipLaunchKernelGGL(k_crc_groups, dim3((crc_groups + 63) / 64), dim3(64), 0, st, (const CrcMember *)d_mem, nm, crc_groups, d_tb,
+                               (const u32 *)d_part, d_gpart);
+        hipLaunchKernelGGL(k_crc_members, dim3((nm + 63) / 64), dim3(64), 0, st, (const CrcMember *)d_mem, nm, d_tb, (const u32 *)d_gpart, d_err);
+        GT_HIP(hipGetLastError());
+    }
     GT_HIP(hipStreamSynchronize(st));
     const double t1 = now_s();
     out.t_h2d = t1 - t0;
@@ -456,6 +616,11 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         hipLaunchKernelGGL(k_frag_scan_chunks, dim3(1), dim3(1024), 0, st, (const u32 *)d_cnt, n_chunks, d_base);
         GT_HIP(hipMemcpyAsync(&n_lines, d_base + n_chunks, 4, hipMemcpyDeviceToHost, st));
         GT_HIP(hipStreamSynchronize(st));
+    }
+    if (!n_lines) {  // (no text at all: a member's CRC may still be wrong)
+        u32 h_err0 = 0xFFFFFFFFu;
+        GT_HIP(hipMemcpy(&h_err0, d_err, 4, hipMemcpyDeviceToHost));
+        if (h_err0 != 0xFFFFFFFFu) out.first_error_file = h_err0;
     }
     if (n_lines) {
         const size_t sort_ws = radix_sort_ws_bytes(n_lines);

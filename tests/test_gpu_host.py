@@ -1006,6 +1006,38 @@ def test_device_fragment_parser_follows_the_reference_line_rules(tk, golden_dir,
     expect_error("gzip|read error|Failed to")
     os.remove(fd / "bb.bed.gz")
     both_parsers(good)
+    # gzip framing.  The device path inflates every member RAW on the host threads and checks its CRC-32 on the GPU: a file of
+    # many members (bgzip-like, with an extra field, a name and a comment in the headers) gives the same result ...
+    import io
+    import struct
+
+    body = ("\n".join(b) + "\n").encode()
+    pieces = [body[i:i + 3000] for i in range(0, len(body), 3000)]
+    multi = b""
+    for k, piece in enumerate(pieces):
+        member = gzip.compress(piece, 1 + k % 9)
+        if k % 3 == 1:  # FEXTRA (bgzip's block-size field looks like this) + FNAME + FCOMMENT
+            extra = b"BC\x02\x00\x34\x12"
+            member = member[:3] + bytes([4 | 8 | 16]) + member[4:10] + struct.pack("<H", len(extra)) + extra + b"name.bed\x00" + b"a comment\x00" + member[10:]
+        multi += member
+    (fd / "b.bed.gz").write_bytes(multi)
+    both_parsers(good)
+    monkeypatch.setenv("GTARS_FRAG_HOST_CRC", "1")  # (the host's own CRC check instead of the device's)
+    good("device parser, host CRC")
+    monkeypatch.delenv("GTARS_FRAG_HOST_CRC")
+    # ... a member whose CRC is not its trailer's is the reference's (zlib's, flate2's) data error, whoever computes the CRC
+    bad_crc = bytearray(multi)
+    first_len = len(gzip.compress(pieces[0], 1))
+    bad_crc[first_len - 8] ^= 0x01  # the first member's CRC field
+    (fd / "b.bed.gz").write_bytes(bytes(bad_crc))
+    expect_error("gzip read error")
+    # ... and so is a flipped bit in the LAST member's data (a valid deflate stream may survive it: then only the CRC tells)
+    flipped = bytearray(keep)
+    flipped[len(flipped) // 2] ^= 0x10
+    (fd / "b.bed.gz").write_bytes(bytes(flipped))
+    expect_error("gzip read error|Failed to parse")
+    (fd / "b.bed.gz").write_bytes(keep)
+    both_parsers(good)
 
 
 def test_lola_universe_helpers_kats():
