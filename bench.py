@@ -639,7 +639,9 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
         t = time.perf_counter(); res2 = tokenize_fragment_files(cluster_files, tok, workers=16); t_tok = time.perf_counter() - t
         fragsplit_tokenize(fd, m, tok, as_arrays=True)  # warm-up (device buffers)
         t_runs = []
+        fused = None
         for _ in range(3):
+            fused = None  # (the previous call's result is released outside the timed region: its arrays are views of C memory)
             t = time.perf_counter(); fused = fragsplit_tokenize(fd, m, tok, as_arrays=True); t_runs.append(time.perf_counter() - t)
         t_fused = statistics.median(t_runs)
         # where the last call's time went (the library's own stage clock: gtars_fragsplit_last_stages)
