@@ -2922,46 +2922,51 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
             return fail(e, msg);
         }
     const double t_tok_done = now();
-    if (device_path) {
-        // the cluster-level barcode ids of the device waves' fragments: first-seen order over the waves, i.e. over the files in
-        // order and the lines in order -- what one pass over the cluster's file would see.  A barcode belongs to ONE cluster, so
-        // the clusters' threads touch different slots of the files' tables.
+    if (device_path)
         for (Wave &w : waves)
             if (w.device) {
                 reads += w.reads;
                 n_all += w.n;
             }
-        over_clusters([&](size_t c) {
-            Cluster &k = cl[c];
+    // every cluster regrouped by barcode: its fragments' ids wave after wave (= the cluster file's line order)
+    auto **arr = (gtars_fragment_tokens_t **)calloc(nc ? nc : 1, sizeof(gtars_fragment_tokens_t *));
+    over_clusters([&](size_t c) {
+        Cluster &k = cl[c];
+        std::vector<uint64_t> cnt;
+        uint64_t i = 0;
+        if (device_path) {
+            // device waves: the cluster-level barcode ids of the fragments -- first-seen order over the waves, i.e. over the files in
+            // order and the lines in order, what one pass over the cluster's file would see -- and the ids per barcode, in ONE pass.
+            // A barcode belongs to one cluster, so the clusters' threads touch different slots of the files' tables.
             uint64_t total = 0;
             for (Wave &w : waves) total += w.coff[c + 1] - w.coff[c];
-            k.b.reserve(k.b.size() + (size_t)total);
-            for (Wave &w : waves) {
-                if (!w.device) continue;  // (never: a call is all device waves or all host waves)
+            k.b.reserve((size_t)total);
+            std::vector<uint64_t> per;
+            for (Wave &w : waves)
                 for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r) {
                     TextFile &f = w.tf[w.file[r]];
                     uint32_t &id = f.local[w.slot[r]];
                     if (id == 0xFFFFFFFFu) {
                         const gtars::FragSlot &sl = f.slots[w.slot[r]];
                         id = k.barcodes.get_or_add(f.keys.data() + sl.off, sl.len);
+                        if (id >= per.size()) per.resize((size_t)id + 1, 0);
                     }
                     k.b.push_back(id);
+                    const uint64_t hits = w.cnt ? w.cnt[r] : w.off[r + 1] - w.off[r];
+                    per[id] += hits ? hits : 1;  // a fragment without hits contributes one unk id
                 }
-            }
-        });
-    }
-    // every cluster regrouped by barcode: its fragments' ids wave after wave (= the cluster file's line order)
-    auto **arr = (gtars_fragment_tokens_t **)calloc(nc ? nc : 1, sizeof(gtars_fragment_tokens_t *));
-    over_clusters([&](size_t c) {
-        Cluster &k = cl[c];
+            cnt.assign(per.size() + 1, 0);
+            for (size_t b = 0; b < per.size(); ++b) cnt[b + 1] = per[b];
+        }
         const uint64_t nb = k.barcodes.names.size();
-        std::vector<uint64_t> cnt(nb + 1, 0);
-        uint64_t i = 0;
-        for (Wave &w : waves)
-            for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
-                const uint64_t hits = w.cnt ? w.cnt[r] : w.off[r + 1] - w.off[r];
-                cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
-            }
+        if (!device_path) {
+            cnt.assign(nb + 1, 0);
+            for (Wave &w : waves)
+                for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
+                    const uint64_t hits = w.cnt ? w.cnt[r] : w.off[r + 1] - w.off[r];
+                    cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
+                }
+        }
         for (uint64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
         auto *ft = (gtars_fragment_tokens_t *)calloc(1, sizeof(gtars_fragment_tokens_t));
         ft->n_barcodes = nb;
