@@ -2556,26 +2556,99 @@ void load_text_file(const std::string &path, const gtars_barcode_map &m, TextFil
     out.local.assign(cap, 0xFFFFFFFFu);
 }
 
-// files in waves (inflated in parallel, one per host thread), handed to `sink(first_file_index, wave)` in file order
-template <class Sink>
-gtars_status for_each_text_wave(const std::vector<std::string> &files, const gtars_barcode_map &m, Sink &&sink) {
-    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_thread_budget(64), files.size()));
-    const size_t wave = (size_t)nt;
-    for (size_t base = 0; base < files.size(); base += wave) {
-        const size_t n = std::min(wave, files.size() - base);
-        std::vector<TextFile> res(n);
-        std::atomic<size_t> next{0};
-        auto work = [&] {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) load_text_file(files[base + i], m, res[i]);
-        };
-        std::vector<std::thread> th;
-        for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
-        work();
-        for (auto &t : th) t.join();
-        gtars_status st = sink(base, res);
-        if (st) return st;
+// The files inflated by a pool of host threads that never waits for a wave to complete (round 5, second cut): threads take the
+// next file as they finish one, at most `window` files ahead of what has been handed on, and the CALLING thread hands batches of
+// consecutive loaded files to `sink(first_file_index, batch)` in file order -- a new batch whenever `wait_idle()` says that the
+// consumer (the device thread) has nothing to do, holding whatever has been loaded by then: batches size themselves to the
+// consumer's pace, and behind the last file only the files loaded since the previous batch are left to do.  `failed()`: the
+// consumer has met an error (stop producing).  A file that could not be read ends the stream with ITS error -- every earlier file
+// has been handed on by then, so an earlier file's parse error (known once the consumer is done) still comes first.
+// `too_large`: a single file beyond the device parser's text limit.
+template <class Sink, class Idle, class Failed>
+gtars_status stream_text_files(const std::vector<std::string> &files, const gtars_barcode_map &m, uint64_t byte_limit, Sink &&sink,
+                               Idle &&wait_idle, Failed &&failed, bool *too_large) {
+    const size_t n = files.size();
+    if (!n) return GTARS_OK;
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_thread_budget(64), n));
+    const size_t window = (size_t)nt * 4, max_batch = std::min<size_t>((size_t)nt * 4, 60000);
+    std::vector<TextFile> tf(n);
+    std::vector<char> done(n, 0);
+    std::mutex mx;
+    std::condition_variable cvx;
+    size_t consumed = 0;
+    bool stop = false;
+    std::atomic<size_t> next{0};
+    auto loader = [&] {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) return;
+            {
+                std::unique_lock<std::mutex> lk(mx);
+                cvx.wait(lk, [&] { return stop || i < consumed + window; });
+                if (stop) return;
+            }
+            load_text_file(files[i], m, tf[i]);
+            {
+                std::lock_guard<std::mutex> lk(mx);
+                done[i] = 1;
+            }
+            cvx.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k) th.emplace_back(loader);
+    struct Join {
+        std::vector<std::thread> &th;
+        std::mutex &mx;
+        std::condition_variable &cvx;
+        bool &stop;
+        ~Join() {
+            {
+                std::lock_guard<std::mutex> lk(mx);
+                stop = true;
+            }
+            cvx.notify_all();
+            for (auto &t : th)
+                if (t.joinable()) t.join();
+        }
+    } join{th, mx, cvx, stop};
+    gtars_status st = GTARS_OK;
+    size_t lo = 0;
+    while (lo < n) {
+        wait_idle();
+        if (failed()) break;
+        size_t hi = lo;
+        uint64_t bytes = 0;
+        {
+            std::unique_lock<std::mutex> lk(mx);
+            cvx.wait(lk, [&] { return done[lo] != 0; });
+            while (hi < n && done[hi] && !tf[hi].st && hi - lo < max_batch && (hi == lo ? tf[hi].data.size() < byte_limit : bytes + tf[hi].data.size() < byte_limit)) {
+                bytes += tf[hi].data.size();
+                ++hi;
+            }
+        }
+        if (hi == lo) {
+            if (tf[lo].st) {
+                st = fail(tf[lo].st, tf[lo].err);
+            } else {
+                *too_large = true;
+                st = fail(GTARS_ERR_INTERNAL, "fragment file too large for the device parser");
+            }
+            break;
+        }
+        std::vector<TextFile> batch;
+        batch.reserve(hi - lo);
+        for (size_t i = lo; i < hi; ++i) batch.push_back(std::move(tf[i]));
+        st = sink(lo, batch);
+        if (st) break;
+        lo = hi;
+        {
+            std::lock_guard<std::mutex> lk(mx);
+            consumed = lo;
+        }
+        cvx.notify_all();
     }
-    return GTARS_OK;
+    return st;
 }
 
 // files in waves of `wave` (parsed in parallel), handed to `sink(first_file_index, wave_results)` in file order
@@ -2755,6 +2828,8 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
     std::condition_variable cv;
     std::deque<Wave *> jobs;
     bool closing = false;
+    size_t in_flight = 0;       // waves queued or on the device
+    bool wave_failed = false;   // a wave ended with an error (the producer stops)
     std::thread tok_thread([&] {
         (void)gtars::frag_select_device(caller_device);  // (HIP's current device belongs to the thread and starts at 0)
         for (;;) {
@@ -2810,6 +2885,12 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                 if (w->st) w->err = gtars_last_error();
             }
             t_tok += now() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                --in_flight;
+                if (w->st) wave_failed = true;
+            }
+            cv.notify_all();
         }
     });
     auto finish_tokenizer = [&] {
@@ -2867,6 +2948,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         if (n) {
             std::lock_guard<std::mutex> lk(mu);
             jobs.push_back(&w);
+            ++in_flight;
         }
         cv.notify_all();
         t_append += now() - t_a;
@@ -2875,52 +2957,51 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
     if (!device_path) {
         st = for_each_split_wave(files, *m, false, &t->chroms, host_sink);
     } else {
-        st = for_each_text_wave(files, *m, [&](size_t base, std::vector<TextFile> &tf) -> gtars_status {
-            // a file that could not be read: the reference fails there -- unless an EARLIER file of the wave has a line it fails
-            // on (files are visited in order): those are parsed on the host for their message
-            for (size_t i = 0; i < tf.size(); ++i)
-                if (tf[i].st) {
-                    for (size_t j = 0; j < i; ++j) {
-                        SplitFile chk;
-                        split_one_file(files[base + j], *m, false, chk, &t->chroms);
-                        if (chk.st) return fail(chk.st, chk.err);
-                    }
-                    return fail(tf[i].st, tf[i].err);
+        const char *cap_mb = cfg_get("GTARS_FRAG_DEVICE_WAVE_MB");  // (test hook: a small limit)
+        const uint64_t byte_limit = (cap_mb ? (uint64_t)atoll(cap_mb) : 3500ull) << 20;  // the device path's 32-bit text positions
+        bool too_large = false;
+        st = stream_text_files(
+            files, *m, byte_limit,
+            [&](size_t base, std::vector<TextFile> &tf) -> gtars_status {
+                waves.emplace_back();
+                Wave &w = waves.back();
+                w.device = true;
+                w.first_file = base;
+                w.tf = std::move(tf);
+                w.coff.assign(nc + 1, 0);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    jobs.push_back(&w);
+                    ++in_flight;
                 }
-            uint64_t bytes = 0;
-            for (const TextFile &f : tf) bytes += f.data.size();
-            const char *cap_mb = cfg_get("GTARS_FRAG_DEVICE_WAVE_MB");  // (test hook: a small limit)
-            if (bytes >= ((cap_mb ? (uint64_t)atoll(cap_mb) : 3500ull) << 20)) {  // beyond the device path's 32-bit text positions
-                *redo_on_host = true;
-                return fail(GTARS_ERR_INTERNAL, "fragment wave too large for the device parser");
-            }
-            waves.emplace_back();
-            Wave &w = waves.back();
-            w.device = true;
-            w.first_file = base;
-            w.tf = std::move(tf);
-            w.coff.assign(nc + 1, 0);
-            {
+                cv.notify_all();
+                return GTARS_OK;
+            },
+            [&] {  // the device thread has nothing queued and nothing running
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return in_flight == 0; });
+            },
+            [&] {
                 std::lock_guard<std::mutex> lk(mu);
-                jobs.push_back(&w);
-            }
-            cv.notify_all();
-            return GTARS_OK;
-        });
+                return wave_failed;
+            },
+            &too_large);
+        if (too_large) *redo_on_host = true;
     }
     const double t_split_done = now();
     finish_tokenizer();
-    if (st) {
-        free_waves();
-        return st;
-    }
-    for (Wave &w : waves)
+    for (Wave &w : waves)  // (in file order: a wave's error lies in front of whatever stopped the producer)
         if (w.st) {
             const gtars_status e = w.st;
             const std::string msg = w.err;
             free_waves();
             return fail(e, msg);
         }
+    if (st) {
+        const std::string msg = gtars_last_error();
+        free_waves();
+        return fail(st, msg);
+    }
     const double t_tok_done = now();
     if (device_path)
         for (Wave &w : waves)
