@@ -181,6 +181,7 @@ _HOST_SIG = {
     "gtars_fragsplit_tokenize": (C.c_int, [vp, cstr, vp, C.POINTER(C.POINTER(C.POINTER(FragmentTokens))), pu64]),
     "gtars_fragsplit_tokenize_files": (C.c_int, [vp, vp, u64, vp, C.POINTER(C.POINTER(C.POINTER(FragmentTokens))), pu64]),
     "gtars_host_threads": (u32, [u32]),
+    "gtars_read_file": (C.c_int, [cstr, pp, pu64]),
     "gtars_fragsplit_last_stages": (None, [vp]),
     "gtars_gtok_write": (C.c_int, [cstr, vp, u64]),
     "gtars_gtok_read": (C.c_int, [cstr, pp, pu64]),

@@ -6,6 +6,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -13,6 +14,68 @@
 #include "../../include/gtars_amd_host.h"
 
 namespace gtars {
+
+// Host memory the GPU's copy engines read and write directly (pinned), from a process-wide pool (round 5).  The fused pipeline
+// moves ~45 bytes of text per fragment to the device and ~12 back; from ordinary (pageable) memory the runtime stages every copy
+// through its own bounce buffers -- 11 to 37 ms for config 5's 216 MB of text, the longest stage of the call once the inflate was
+// fast, and 2 to 3 API calls per file on top (1000 small files: 30 to 40 ms).  The host threads therefore inflate straight INTO
+// pinned blocks, and the results come back into pinned blocks.  Pinning costs (the driver maps and locks the pages), so blocks are
+// cached when released -- up to GTARS_PINNED_POOL_MB (default 4096) -- and a warm call allocates nothing; a pooled block is also
+// already faulted in, which an ordinary 4.5-MB allocation is not (first touch: a page fault per 4 KiB).
+// acquire: a block of at least `bytes` (*capacity = its size), or nullptr when pinned memory is not to be had (the caller then
+// uses ordinary memory: slower copies, same results).
+void *frag_pinned_acquire(size_t bytes, size_t *capacity);
+void frag_pinned_release(void *p, size_t capacity);
+
+// a block of host memory for device transfers: pinned when the pool has it, malloc'ed otherwise; move-only
+struct HostBlock {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    HostBlock() = default;
+    HostBlock(const HostBlock &) = delete;
+    HostBlock &operator=(const HostBlock &) = delete;
+    HostBlock(HostBlock &&o) noexcept : p(o.p), cap(o.cap), pinned(o.pinned) { o.p = nullptr, o.cap = 0; }
+    HostBlock &operator=(HostBlock &&o) noexcept {
+        if (this != &o) {
+            reset();
+            p = o.p, cap = o.cap, pinned = o.pinned;
+            o.p = nullptr, o.cap = 0;
+        }
+        return *this;
+    }
+    ~HostBlock() { reset(); }
+    void reset() {
+        if (p) {
+            if (pinned)
+                frag_pinned_release(p, cap);
+            else
+                free(p);
+        }
+        p = nullptr, cap = 0;
+    }
+    bool alloc(size_t bytes, bool want_pinned = true) {  // (contents undefined; false: out of memory)
+        reset();
+        if (want_pinned && (p = frag_pinned_acquire(bytes, &cap))) {
+            pinned = true;
+            return true;
+        }
+        pinned = false;
+        cap = bytes ? bytes : 1;
+        p = malloc(cap);
+        if (!p) cap = 0;
+        return p != nullptr;
+    }
+};
+template <class T>
+struct HostArray {
+    HostBlock b;
+    bool alloc(size_t n, bool want_pinned = true) { return b.alloc((n ? n : 1) * sizeof(T), want_pinned); }
+    void reset() { b.reset(); }
+    T *get() const { return (T *)b.p; }
+    T &operator[](size_t i) const { return ((T *)b.p)[i]; }
+    explicit operator bool() const { return b.p != nullptr; }
+};
 
 // 32-bit FNV-1a with a final mix: the ONE hash of the open-addressing tables both sides use
 inline uint32_t frag_hash(const char *p, uint32_t n) {
@@ -56,14 +119,14 @@ struct FragFileIn {
 struct FragWaveOut {
     std::vector<uint64_t> coff;        // [n_clusters + 1] fragments of every cluster
     uint64_t n = 0;                    // routed fragments that are tokenized (lines whose chromosome field starts with '#' are not)
-    std::unique_ptr<uint16_t[]> file;  // [n] file of the fragment (index into the wave)
-    std::unique_ptr<uint32_t[]> slot;  // [n] slot of its barcode in that file's table
+    HostArray<uint16_t> file;  // [n] file of the fragment (index into the wave)
+    HostArray<uint32_t> slot;  // [n] slot of its barcode in that file's table
     // the token CSR: ids of fragment r at ids[x .. x + cnt[r]), x running from cbase[c] at the cluster's first fragment -- one BYTE
     // per fragment over the link instead of an 8-byte offset; `off` ([n + 1]) instead when some fragment has more than 255 ids
-    std::unique_ptr<uint8_t[]> cnt;    // [n], or null
-    std::vector<uint64_t> cbase;       // [n_clusters + 1] offset of every cluster's first id
-    std::unique_ptr<uint64_t[]> off;   // [n + 1], or null
-    uint32_t *ids = nullptr;           // malloc'ed (free)
+    HostArray<uint8_t> cnt;       // [n], or null
+    std::vector<uint64_t> cbase;  // [n_clusters + 1] offset of every cluster's first id
+    HostArray<uint64_t> off;      // [n + 1], or null
+    HostArray<uint32_t> ids;
     std::vector<uint64_t> n_reads, n_written;  // per file: lines, routed lines ('#' lines included)
     int64_t first_error_file = -1;     // first file (wave order) with a line the reference fails on, or with a gzip member whose
                                        // CRC-32 is not its trailer's; -1: none.  The caller reads that file again on the host (zlib's

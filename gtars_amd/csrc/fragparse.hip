@@ -21,6 +21,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstring>
+#include <mutex>
 
 namespace gtars {
 
@@ -503,6 +505,70 @@ gtars_status frag_chroms_create(const std::vector<std::string> &names, FragChrom
 }
 void frag_chroms_free(FragChroms *c) { delete c; }
 
+// ---- the pinned host memory pool (frag_device.h) ----
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> free_blocks;
+    size_t cached = 0, limit = (size_t)4096 << 20;
+    bool off = false;
+    PinnedPool() {
+        if (const char *e = cfg_get("GTARS_PINNED_POOL_MB")) limit = (size_t)std::max(0ll, atoll(e)) << 20;
+        off = cfg_get("GTARS_NO_PINNED") != nullptr;  // (A/B and tests: ordinary memory everywhere)
+    }
+};
+PinnedPool &pinned_pool() {
+    static PinnedPool *p = new PinnedPool;  // (never destroyed: its blocks must not be freed behind the HIP runtime's own teardown)
+    return *p;
+}
+}  // namespace
+
+void *frag_pinned_acquire(size_t bytes, size_t *capacity) {
+    PinnedPool &pp = pinned_pool();
+    if (pp.off) return nullptr;
+    const size_t need = std::max<size_t>(bytes, 4096);
+    {
+        std::lock_guard<std::mutex> lk(pp.mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < pp.free_blocks.size(); ++i) {
+            const size_t c = pp.free_blocks[i].second;
+            // (a block far larger than the request stays for the large requests: text blocks for texts, small ones for counters)
+            if (c >= need && c <= 2 * need + (1u << 20) && (best == (size_t)-1 || c < pp.free_blocks[best].second)) best = i;
+        }
+        if (best != (size_t)-1) {
+            void *p = pp.free_blocks[best].first;
+            *capacity = pp.free_blocks[best].second;
+            pp.cached -= *capacity;
+            pp.free_blocks[best] = pp.free_blocks.back();
+            pp.free_blocks.pop_back();
+            return p;
+        }
+    }
+    // a little more than asked: the next file of a folder is about as large as this one, not exactly as large
+    const size_t cap = (need + need / 8 + (256u << 10) - 1) & ~(size_t)((256u << 10) - 1);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    *capacity = cap;
+    return p;
+}
+
+void frag_pinned_release(void *p, size_t capacity) {
+    if (!p) return;
+    PinnedPool &pp = pinned_pool();
+    {
+        std::lock_guard<std::mutex> lk(pp.mu);
+        if (pp.cached + capacity <= pp.limit) {
+            pp.free_blocks.emplace_back(p, capacity);
+            pp.cached += capacity;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
 int frag_current_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
@@ -525,7 +591,7 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
     out.n_reads.assign(n_files, 0);
     out.n_written.assign(n_files, 0);
     out.first_error_file = -1;
-    out.ids = nullptr;
+    out.ids.reset();
     if (!n_files) return GTARS_OK;
     if (n_clusters >= NO_CLUSTER || n_files >= 65535) return fail(GTARS_ERR_INVALID_ARG, "fragment wave: too many clusters or files for the device path");
     u64 total = 0, total_slots = 0, total_keys = 0;
@@ -554,27 +620,38 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
     Carve cin{(char *)ws_in.ptr, 0};
     View d_text{cin.take<char>(text_bytes)}, d_slots{cin.take<FragSlot>(std::max<u64>(total_slots, 1))}, d_keys{cin.take<char>(total_keys + 16)};
     View d_meta{cin.take<u32>(m1 * 4 + n_files + 1 + n_clusters + 1)}, d_chunks{cin.take<u32>(((size_t)n_chunks + 1) * 2)};
-    std::vector<u32> file_off(n_files + 1, 0), slot_off(n_files + 1, 0), key_off(n_files + 1, 0);
+    // The texts go file by file (they lie in pinned blocks: the host threads inflated into them, so every copy is one DMA); the
+    // files' barcode tables and the offset arrays are gathered into ONE pinned staging block first -- three copies for the wave
+    // instead of two per file and three small ones from pageable memory (1000 files: 2000 calls of 20 us each before).
+    // staging: file_off | slot_off | key_off [m1 words each] | slots | keys | gzip members
+    size_t n_members = 0;
+    for (const FragFileIn &f : files) n_members += f.n_members;
+    const size_t stage_slots = pad(3 * m1 * 4), stage_keys = stage_slots + pad(total_slots * sizeof(FragSlot)),
+                 stage_mem = stage_keys + pad(total_keys + 16), stage_bytes = stage_mem + pad(n_members * sizeof(CrcMember)) + 256;
+    HostBlock staging;
+    if (!staging.alloc(stage_bytes)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    u32 *file_off = (u32 *)staging.p, *slot_off = file_off + m1, *key_off = slot_off + m1;
+    file_off[0] = slot_off[0] = key_off[0] = 0;
     for (u32 f = 0; f < n_files; ++f) {
         file_off[f + 1] = file_off[f] + (u32)files[f].n;
         slot_off[f + 1] = slot_off[f] + files[f].n_slots;
         key_off[f + 1] = key_off[f] + files[f].n_key_bytes;
         if (files[f].n) GT_HIP(hipMemcpyAsync(d_text.as<char>() + file_off[f], files[f].text, files[f].n, hipMemcpyHostToDevice, st));
-        if (files[f].n_slots)
-            GT_HIP(hipMemcpyAsync(d_slots.as<FragSlot>() + slot_off[f], files[f].slots, (size_t)files[f].n_slots * sizeof(FragSlot), hipMemcpyHostToDevice, st));
-        if (files[f].n_key_bytes) GT_HIP(hipMemcpyAsync(d_keys.as<char>() + key_off[f], files[f].keys, files[f].n_key_bytes, hipMemcpyHostToDevice, st));
+        if (files[f].n_slots) memcpy((char *)staging.p + stage_slots + (size_t)slot_off[f] * sizeof(FragSlot), files[f].slots, (size_t)files[f].n_slots * sizeof(FragSlot));
+        if (files[f].n_key_bytes) memcpy((char *)staging.p + stage_keys + key_off[f], files[f].keys, files[f].n_key_bytes);
     }
+    if (total_slots) GT_HIP(hipMemcpyAsync(d_slots.as<FragSlot>(), (char *)staging.p + stage_slots, total_slots * sizeof(FragSlot), hipMemcpyHostToDevice, st));
+    if (total_keys) GT_HIP(hipMemcpyAsync(d_keys.as<char>(), (char *)staging.p + stage_keys, total_keys, hipMemcpyHostToDevice, st));
     GT_HIP(hipMemsetAsync(d_text.as<char>() + n_bytes, 0, (size_t)std::max<u32>(n_chunks, 1) * FP_CHUNK + 64 - n_bytes, st));
     // meta: file_off | slot_off | key_off | file_line [n_files + 1 each] | n_written [n_files] | err_file | coff [n_clusters + 1]
     u32 *d_file_off = d_meta.as<u32>(), *d_slot_off = d_file_off + m1, *d_key_off = d_slot_off + m1, *d_file_line = d_key_off + m1;
     u32 *d_written = d_file_line + m1, *d_err = d_written + n_files, *d_coff = d_err + 1;
-    GT_HIP(hipMemcpyAsync(d_file_off, file_off.data(), m1 * 4, hipMemcpyHostToDevice, st));
-    GT_HIP(hipMemcpyAsync(d_slot_off, slot_off.data(), m1 * 4, hipMemcpyHostToDevice, st));
-    GT_HIP(hipMemcpyAsync(d_key_off, key_off.data(), m1 * 4, hipMemcpyHostToDevice, st));
+    GT_HIP(hipMemcpyAsync(d_file_off, file_off, 3 * m1 * 4, hipMemcpyHostToDevice, st));
     GT_HIP(hipMemsetAsync(d_written, 0, (size_t)n_files * 4, st));
     GT_HIP(hipMemsetAsync(d_err, 0xFF, 4, st));
     // ---- the gzip members' CRC-32 (the host threads inflated them raw) ----
-    std::vector<CrcMember> h_mem;
+    CrcMember *h_mem_p = (CrcMember *)((char *)staging.p + stage_mem);
+    size_t h_mem_n = 0;
     u32 crc_chunks = 0, crc_groups = 0;
     for (u32 f = 0; f < n_files; ++f)
         for (u32 k = 0; k < files[f].n_members; ++k) {
@@ -584,17 +661,17 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             const u32 n_ch = ((u32)gm.len + CRC_CHUNK - 1) / CRC_CHUNK;
             crc_chunks += n_ch;
             crc_groups += (n_ch + CRC_GROUP - 1) / CRC_GROUP;
-            h_mem.push_back(m);
+            h_mem_p[h_mem_n++] = m;
         }
-    if (!h_mem.empty()) {
+    if (h_mem_n) {
         Workspace &ws_crc = tls_workspace(8, st);
-        if ((s = ws_crc.reserve(pad(h_mem.size() * sizeof(CrcMember)) + pad((size_t)crc_chunks * 4) + pad((size_t)crc_groups * 4) + 1024))) return s;
+        if ((s = ws_crc.reserve(pad(h_mem_n * sizeof(CrcMember)) + pad((size_t)crc_chunks * 4) + pad((size_t)crc_groups * 4) + 1024))) return s;
         Carve cc{(char *)ws_crc.ptr, 0};
-        CrcMember *d_mem = cc.take<CrcMember>(h_mem.size());
+        CrcMember *d_mem = cc.take<CrcMember>(h_mem_n);
         u32 *d_part = cc.take<u32>(crc_chunks), *d_gpart = cc.take<u32>(crc_groups);
-        GT_HIP(hipMemcpyAsync(d_mem, h_mem.data(), h_mem.size() * sizeof(CrcMember), hipMemcpyHostToDevice, st));
+        GT_HIP(hipMemcpyAsync(d_mem, h_mem_p, h_mem_n * sizeof(CrcMember), hipMemcpyHostToDevice, st));
         const CrcTables *d_tb = chroms->crc.as<CrcTables>();
-        const u32 nm = (u32)h_mem.size();
+        const u32 nm = (u32)h_mem_n;
         if (crc_chunks)
             hipLaunchKernelGGL(k_crc_chunks, dim3((crc_chunks + 255) / 256), dim3(256), 0, st, d_text.as<unsigned char>(), (const CrcMember *)d_mem, nm,
                                crc_chunks, d_tb, d_part);
@@ -668,8 +745,7 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         for (u32 c = 0; c <= n_clusters; ++c) out.coff[c] = h_coff[c];
         const u32 n = h_coff[n_clusters];
         out.n = n;
-        out.file.reset(new uint16_t[(size_t)n + 1]);
-        out.slot.reset(new uint32_t[(size_t)n + 1]);
+        if (!out.file.alloc((size_t)n + 1) || !out.slot.alloc((size_t)n + 1)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
         out.cbase.assign((size_t)n_clusters + 1, 0);
         if (n) {
             // cluster-major columns c | s | e | slot (u32 each), file (u16), then the token CSR
@@ -705,8 +781,8 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             }
             const double t4 = now_s();
             out.t_tok = t4 - t3;
-            out.ids = (uint32_t *)malloc(std::max<u64>(h, 1) * 4);
-            if (!out.ids) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+            // (the results land in pinned blocks as well: one DMA each, no staging by the runtime)
+            if (!out.ids.alloc(std::max<u64>(h, 1)) || !out.cnt.alloc((size_t)n + 1)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
             // the CSR as one byte per fragment + the clusters' bases (8-byte offsets only when a fragment has more than 255 ids)
             GT_HIP(hipMemsetAsync(d_err, 0, 4, st));  // (reused as the "wide" flag)
             hipLaunchKernelGGL(k_frag_counts8, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *)d_off, n, d_cnt8, d_err);
@@ -717,14 +793,13 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             GT_HIP(hipMemcpyAsync(out.cbase.data(), d_cbase, ((size_t)n_clusters + 1) * 8, hipMemcpyDeviceToHost, st));
             GT_HIP(hipMemcpyAsync(out.file.get(), ofile, (size_t)n * 2, hipMemcpyDeviceToHost, st));
             GT_HIP(hipMemcpyAsync(out.slot.get(), oslot, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-            if (h) GT_HIP(hipMemcpyAsync(out.ids, d_ids_p, h * 4, hipMemcpyDeviceToHost, st));
+            if (h) GT_HIP(hipMemcpyAsync(out.ids.get(), d_ids_p, h * 4, hipMemcpyDeviceToHost, st));
+            GT_HIP(hipMemcpyAsync(out.cnt.get(), d_cnt8, (size_t)n, hipMemcpyDeviceToHost, st));  // (the common case, sent along unasked)
             GT_HIP(hipStreamSynchronize(st));
             if (wide) {
-                out.off.reset(new uint64_t[(size_t)n + 1]);
+                out.cnt.reset();
+                if (!out.off.alloc((size_t)n + 1)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
                 GT_HIP(hipMemcpy(out.off.get(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
-            } else {
-                out.cnt.reset(new uint8_t[(size_t)n + 1]);
-                GT_HIP(hipMemcpy(out.cnt.get(), d_cnt8, (size_t)n, hipMemcpyDeviceToHost));
             }
             out.t_d2h = now_s() - t4;
         }

@@ -33,6 +33,7 @@
 
 #include "../../include/gtars_amd_host.h"
 #include "frag_device.h"
+#include "inflate_fast.h"
 
 namespace gtars {
 gtars_status fail(gtars_status st, const std::string &msg);
@@ -129,26 +130,146 @@ bool is_regular_file(const std::string &p) {
 // Same behaviour as gzread: concatenated members are decoded one after the other (flate2's MultiGzDecoder, utils.rs:115-126),
 // bytes behind the last member that do not start another one are ignored, a file without the gzip magic is passed through as it
 // is, the CRC and length of every member are checked (inflate does, with the gzip wrapper).
+// the file's bytes, followed by 16 zero bytes the decoders may read into (inflate_fast.h); n = the file's length
+bool read_file_padded(const std::string &path, std::string &raw, size_t &n) {
+    raw.clear();
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    struct stat sb;
+    if (fstat(fileno(f), &sb) == 0 && sb.st_size > 0) raw.reserve((size_t)sb.st_size + 17);
+    char buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) raw.append(buf, k);
+    fclose(f);
+    n = raw.size();
+    raw.append(16, '\0');
+    return true;
+}
+
+// A gzip file inflated member by member with RAW inflate -- no CRC on the host: zlib's crc32 is a quarter of its inflate time
+// (1.8 of 7.4 ms per 3.5 MB of text on the GPU box's host), and the device path of the fused fragment pipeline ships the inflated
+// bytes to the GPU anyway, which checks every member's CRC-32 there (fragparse.hip).  The gzip framing (RFC 1952: header with its
+// optional fields -- bgzip's extra field, names, comments, a header CRC --, deflate stream, CRC-32 + ISIZE trailer) is parsed here;
+// ISIZE is checked here.  -> false for anything but a clean sequence of members (not gzip, truncated, garbage behind the last
+// member, a length that does not match ...): the caller then reads the file with read_all, i.e. zlib's own checks and messages.
+// `p` must be readable for 16 bytes beyond n (read_file_padded).  The deflate streams are decoded by inflate_fast.h (round 5; zlib's
+// raw inflate with GTARS_ZLIB_INFLATE, the A/B switch).
+// Out: std::string, or the device path's pinned TextBuf.
+template <class Out>
+bool inflate_gzip_members_raw(const unsigned char *p, size_t n, Out &out, std::vector<gtars::FragGzMember> &members) {
+    out.clear();
+    members.clear();
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b) return false;
+    size_t guess = n * 4;
+    {
+        const unsigned char *t = p + n - 4;
+        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+        if (isize >= n / 2 && isize <= n * 1024) guess = isize;
+    }
+    out.resize(guess + 512);
+    const bool use_zlib = cfg_get("GTARS_ZLIB_INFLATE") != nullptr;
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (use_zlib && inflateInit2(&z, -MAX_WBITS) != Z_OK) return false;
+    struct End {
+        z_stream &z;
+        bool on;
+        ~End() {
+            if (on) inflateEnd(&z);
+        }
+    } end{z, use_zlib};
+    size_t at = 0, out_done = 0;
+    while (at < n) {
+        if (n - at < 18 || p[at] != 0x1f || p[at + 1] != 0x8b || p[at + 2] != 8) return false;  // (also: bytes behind the last member)
+        const unsigned flg = p[at + 3];
+        if (flg & 0xE0) return false;  // reserved bits
+        size_t h = at + 10;
+        if (flg & 4) {  // FEXTRA
+            if (h + 2 > n) return false;
+            h += 2 + ((size_t)p[h] | ((size_t)p[h + 1] << 8));
+        }
+        for (unsigned bit : {8u, 16u})  // FNAME, FCOMMENT: zero-terminated
+            if (flg & bit) {
+                while (h < n && p[h]) ++h;
+                ++h;
+            }
+        if (flg & 2) {  // FHCRC: the low half of the header's CRC-32 (flate2 and zlib both check it)
+            if (h + 2 > n) return false;
+            const uint32_t want = (uint32_t)p[h] | ((uint32_t)p[h + 1] << 8);
+            if ((crc32(crc32(0L, Z_NULL, 0), p + at, (uInt)(h - at)) & 0xFFFFu) != want) return false;
+            h += 2;
+        }
+        if (h + 8 > n) return false;
+        const size_t member_out0 = out_done;
+        size_t t;  // the trailer
+        if (!use_zlib) {
+            size_t used = 0;
+            if (!gtars::fastinf::inflate_raw(p + h, n - h, &used, out, out_done)) return false;
+            t = h + used;
+        } else {
+            if (inflateReset(&z) != Z_OK) return false;
+            z.next_in = (Bytef *)(p + h);
+            size_t in_left = n - h;
+            z.avail_in = (uInt)std::min<size_t>(in_left, 0x7FFFFFFFu);
+            for (;;) {
+                if (out_done == out.size()) out.resize(out.size() + out.size() / 2 + (1 << 16));
+                z.next_out = (Bytef *)&out[out_done];
+                const size_t room = std::min<size_t>(out.size() - out_done, 0x7FFFFFFFu);
+                z.avail_out = (uInt)room;
+                const uInt in_before = z.avail_in;
+                const int r = inflate(&z, Z_NO_FLUSH);
+                out_done += room - z.avail_out;
+                in_left -= in_before - z.avail_in;
+                if (r == Z_STREAM_END) break;
+                if (r != Z_OK && !(r == Z_BUF_ERROR && z.avail_out == 0)) return false;
+                if (z.avail_in == 0) {
+                    if (!in_left) return false;  // the input ends inside the member
+                    z.avail_in = (uInt)std::min<size_t>(in_left, 0x7FFFFFFFu);
+                }
+            }
+            t = n - in_left;
+        }
+        if (t + 8 > n) return false;
+        const uint32_t crc = (uint32_t)p[t] | ((uint32_t)p[t + 1] << 8) | ((uint32_t)p[t + 2] << 16) | ((uint32_t)p[t + 3] << 24);
+        const uint32_t isize = (uint32_t)p[t + 4] | ((uint32_t)p[t + 5] << 8) | ((uint32_t)p[t + 6] << 16) | ((uint32_t)p[t + 7] << 24);
+        if (isize != (uint32_t)(out_done - member_out0)) return false;
+        members.push_back(gtars::FragGzMember{member_out0, out_done - member_out0, crc});
+        at = t + 8;
+    }
+    out.resize(out_done);
+    return true;
+}
+
 bool read_all(const std::string &path, std::string &out, std::string &err) {
     out.clear();
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) {
+    std::string raw;
+    size_t n_raw = 0;
+    if (!read_file_padded(path, raw, n_raw)) {
         err = "Failed to open file: \"" + path + "\": " + strerror(errno);
         return false;
     }
-    std::string raw;
-    {
-        struct stat sb;
-        if (fstat(fileno(f), &sb) == 0 && sb.st_size > 0) raw.reserve((size_t)sb.st_size + 1);
-        char buf[1 << 16];
-        size_t n;
-        while ((n = fread(buf, 1, sizeof buf, f)) > 0) raw.append(buf, n);
-        fclose(f);
-    }
-    if (extension_of(path) != "gz" || raw.size() < 2 || (unsigned char)raw[0] != 0x1f || (unsigned char)raw[1] != 0x8b) {
+    if (extension_of(path) != "gz" || n_raw < 2 || (unsigned char)raw[0] != 0x1f || (unsigned char)raw[1] != 0x8b) {
+        raw.resize(n_raw);
         out.swap(raw);  // plain text (or a ".gz" without the magic: zlib's transparent mode)
         return true;
     }
+    if (!cfg_get("GTARS_ZLIB_INFLATE")) {
+        // the whole-buffer decoder (inflate_fast.h) + zlib's crc32 over every member; whatever it refuses, and any mismatch, goes
+        // through zlib below -- its checks, its messages
+        std::vector<gtars::FragGzMember> members;
+        if (inflate_gzip_members_raw((const unsigned char *)raw.data(), n_raw, out, members)) {
+            bool ok = true;
+            for (const gtars::FragGzMember &g : members) {
+                uLong c = crc32(0L, Z_NULL, 0);
+                for (uint64_t at = 0; at < g.len; at += 1u << 30)
+                    c = crc32(c, (const Bytef *)out.data() + g.off + at, (uInt)std::min<uint64_t>(g.len - at, 1u << 30));
+                ok = ok && (uint32_t)c == g.crc;
+            }
+            if (ok) return true;
+        }
+        out.clear();
+    }
+    raw.resize(n_raw);
     // the last member's ISIZE (uncompressed length mod 2^32) sizes the result; several members, or a lie, just grow it
     size_t guess = raw.size() * 4;
     if (raw.size() >= 18) {
@@ -439,6 +560,21 @@ std::vector<uint32_t> translate_chroms(const gtars_regionset *q, const Dict &d) 
 }  // namespace
 
 extern "C" uint32_t gtars_host_threads(uint32_t cap) { return host_thread_budget(cap ? cap : 0xFFFFFFFFu); }
+
+extern "C" gtars_status gtars_read_file(const char *path, char **out, uint64_t *out_n) {
+    if (!path || !out || !out_n) return fail(GTARS_ERR_INVALID_ARG, "gtars_read_file: null argument");
+    *out = nullptr;
+    *out_n = 0;
+    std::string data, err;
+    if (!read_all(path, data, err)) return fail(GTARS_ERR_IO, err);
+    char *buf = (char *)malloc(data.size() + 1);
+    if (!buf) return fail(GTARS_ERR_INTERNAL, "gtars_read_file: out of memory");
+    memcpy(buf, data.data(), data.size());
+    buf[data.size()] = 0;
+    *out = buf;
+    *out_n = data.size();
+    return GTARS_OK;
+}
 
 extern "C" {
 
@@ -2425,86 +2561,47 @@ void split_one_file(const std::string &path, const gtars_barcode_map &m, bool wa
     }
 }
 
-// A gzip file inflated member by member with RAW inflate -- no CRC on the host: zlib's crc32 is a quarter of its inflate time
-// (1.8 of 7.4 ms per 3.5 MB of text on the GPU box's host), and the device path of the fused fragment pipeline ships the inflated
-// bytes to the GPU anyway, which checks every member's CRC-32 there (fragparse.hip).  The gzip framing (RFC 1952: header with its
-// optional fields -- bgzip's extra field, names, comments, a header CRC --, deflate stream, CRC-32 + ISIZE trailer) is parsed here;
-// ISIZE is checked here.  -> false for anything but a clean sequence of members (not gzip, truncated, garbage behind the last
-// member, a length that does not match ...): the caller then reads the file with read_all, i.e. zlib's own checks and messages.
-bool inflate_gzip_members_raw(const std::string &raw, std::string &out, std::vector<gtars::FragGzMember> &members) {
-    out.clear();
-    members.clear();
-    const unsigned char *p = (const unsigned char *)raw.data();
-    const size_t n = raw.size();
-    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b) return false;
-    size_t guess = n * 4;
-    {
-        const unsigned char *t = p + n - 4;
-        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
-        if (isize >= n / 2 && isize <= n * 1024) guess = isize;
-    }
-    out.resize(guess + 64);
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (inflateInit2(&z, -MAX_WBITS) != Z_OK) return false;
-    struct End {
-        z_stream &z;
-        ~End() { inflateEnd(&z); }
-    } end{z};
-    size_t at = 0, out_done = 0;
-    while (at < n) {
-        if (n - at < 18 || p[at] != 0x1f || p[at + 1] != 0x8b || p[at + 2] != 8) return false;  // (also: bytes behind the last member)
-        const unsigned flg = p[at + 3];
-        if (flg & 0xE0) return false;  // reserved bits
-        size_t h = at + 10;
-        if (flg & 4) {  // FEXTRA
-            if (h + 2 > n) return false;
-            h += 2 + ((size_t)p[h] | ((size_t)p[h + 1] << 8));
-        }
-        for (unsigned bit : {8u, 16u})  // FNAME, FCOMMENT: zero-terminated
-            if (flg & bit) {
-                while (h < n && p[h]) ++h;
-                ++h;
-            }
-        if (flg & 2) h += 2;  // FHCRC
-        if (h + 8 > n) return false;
-        if (inflateReset(&z) != Z_OK) return false;
-        z.next_in = (Bytef *)(p + h);
-        size_t in_left = n - h;
-        z.avail_in = (uInt)std::min<size_t>(in_left, 0x7FFFFFFFu);
-        const size_t member_out0 = out_done;
-        for (;;) {
-            if (out_done == out.size()) out.resize(out.size() + out.size() / 2 + (1 << 16));
-            z.next_out = (Bytef *)&out[out_done];
-            const size_t room = std::min<size_t>(out.size() - out_done, 0x7FFFFFFFu);
-            z.avail_out = (uInt)room;
-            const uInt in_before = z.avail_in;
-            const int r = inflate(&z, Z_NO_FLUSH);
-            out_done += room - z.avail_out;
-            in_left -= in_before - z.avail_in;
-            if (r == Z_STREAM_END) break;
-            if (r != Z_OK && !(r == Z_BUF_ERROR && z.avail_out == 0)) return false;
-            if (z.avail_in == 0) {
-                if (!in_left) return false;  // the input ends inside the member
-                z.avail_in = (uInt)std::min<size_t>(in_left, 0x7FFFFFFFu);
-            }
-        }
-        const size_t t = n - in_left;  // the trailer
-        if (t + 8 > n) return false;
-        const uint32_t crc = (uint32_t)p[t] | ((uint32_t)p[t + 1] << 8) | ((uint32_t)p[t + 2] << 16) | ((uint32_t)p[t + 3] << 24);
-        const uint32_t isize = (uint32_t)p[t + 4] | ((uint32_t)p[t + 5] << 8) | ((uint32_t)p[t + 6] << 16) | ((uint32_t)p[t + 7] << 24);
-        if (isize != (uint32_t)(out_done - member_out0)) return false;
-        members.push_back(gtars::FragGzMember{member_out0, out_done - member_out0, crc});
-        at = t + 8;
-    }
-    out.resize(out_done);
-    return true;
-}
-
 // One input file for the DEVICE path of the fused pipeline (fragparse.hip): the inflated text as it is -- the GPU splits and
 // parses it -- and the file's barcode table in the device's format (FileBarcodes above, keyed by the barcode alone).
+// The inflated text of a file in a block of the pinned pool (frag_device.h): the host thread's decoder writes into memory the GPU's
+// copy engine reads directly.  The interface the decoders need of a std::string; no zero fill on resize; a buffer that must
+// grow moves to a larger block.
+struct TextBuf {
+    gtars::HostBlock b;
+    size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    char *data() const { return (char *)b.p; }
+    char &operator[](size_t i) const { return ((char *)b.p)[i]; }
+    char back() const { return ((char *)b.p)[n - 1]; }
+    void clear() { n = 0; }
+    void reserve(size_t m) {
+        if (m <= b.cap) return;
+        gtars::HostBlock nb;
+        if (!nb.alloc(m + m / 4)) throw std::bad_alloc();
+        if (n) memcpy(nb.p, b.p, n);
+        b = std::move(nb);
+    }
+    void resize(size_t m) {
+        reserve(m);
+        n = m;
+    }
+    void push_back(char c) {
+        reserve(n + 1);
+        ((char *)b.p)[n++] = c;
+    }
+    void assign(const std::string &s) {
+        resize(s.size());
+        if (n) memcpy(b.p, s.data(), n);
+    }
+    void release() {
+        b.reset();
+        n = 0;
+    }
+};
+
 struct TextFile {
-    std::string data;
+    TextBuf data;
     std::vector<gtars::FragGzMember> members;  // gzip members whose CRC-32 the device still has to check
     std::vector<gtars::FragSlot> slots;
     std::string keys;
@@ -2518,23 +2615,18 @@ void load_text_file(const std::string &path, const gtars_barcode_map &m, TextFil
     bool have = false;
     if (extension_of(path) == "gz" && !cfg_get("GTARS_FRAG_HOST_CRC")) {  // (the switch: A/B and tests)
         std::string raw;
-        if (FILE *f = fopen(path.c_str(), "rb")) {
-            struct stat sb;
-            if (fstat(fileno(f), &sb) == 0 && sb.st_size > 0) raw.reserve((size_t)sb.st_size + 1);
-            char buf[1 << 16];
-            size_t k;
-            while ((k = fread(buf, 1, sizeof buf, f)) > 0) raw.append(buf, k);
-            fclose(f);
-            have = inflate_gzip_members_raw(raw, out.data, out.members);
-        }
+        size_t n_raw = 0;
+        if (read_file_padded(path, raw, n_raw)) have = inflate_gzip_members_raw((const unsigned char *)raw.data(), n_raw, out.data, out.members);
     }
     if (!have) {
         out.members.clear();
-        if (!read_all(path, out.data, err)) {  // (everything else, and whatever the raw reader did not like: zlib's own checks)
+        std::string plain;
+        if (!read_all(path, plain, err)) {  // (everything else, and whatever the raw reader did not like: zlib's own checks)
             out.st = GTARS_ERR_IO;
             out.err = err;
             return;
         }
+        out.data.assign(plain);
     }
     if (!out.data.empty() && out.data.back() != '\n') out.data.push_back('\n');  // (BufRead::lines: a last line without one still counts)
     const std::string prefix = remove_all_extensions(path) + "+";
@@ -2587,7 +2679,12 @@ gtars_status stream_text_files(const std::vector<std::string> &files, const gtar
                 cvx.wait(lk, [&] { return stop || i < consumed + window; });
                 if (stop) return;
             }
-            load_text_file(files[i], m, tf[i]);
+            try {
+                load_text_file(files[i], m, tf[i]);
+            } catch (const std::exception &ex) {  // (out of memory on a loader thread: the file's error, not the process's end)
+                tf[i].st = GTARS_ERR_INTERNAL;
+                tf[i].err = std::string("fragment pipeline: ") + ex.what();
+            }
             {
                 std::lock_guard<std::mutex> lk(mx);
                 done[i] = 1;
@@ -2788,9 +2885,12 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         bool device = false;
         size_t first_file = 0;
         std::vector<TextFile> tf;
-        std::unique_ptr<uint16_t[]> file;
-        std::unique_ptr<uint32_t[]> slot;
-        std::unique_ptr<uint8_t[]> cnt;  // ids per fragment, with cbase[c] = the cluster's first id, instead of `off` (FragWaveOut)
+        gtars::HostArray<uint16_t> file;
+        gtars::HostArray<uint32_t> slot;
+        gtars::HostArray<uint8_t> cnt;  // ids per fragment, with cbase[c] = the cluster's first id, instead of `off` (FragWaveOut)
+        gtars::HostArray<uint64_t> doff;  // (the device wave's 8-byte offsets when a fragment has more than 255 ids)
+        gtars::HostArray<uint32_t> dids;  // the device wave's ids (`ids` points here)
+        const uint64_t *offs() const { return device ? doff.get() : off.get(); }
         std::vector<uint64_t> cbase;
         uint64_t reads = 0;
         double td[5] = {0, 0, 0, 0, 0};
@@ -2871,14 +2971,15 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                     w->n = o.n;
                     w->file = std::move(o.file);
                     w->slot = std::move(o.slot);
-                    w->off = std::move(o.off);
+                    w->doff = std::move(o.off);
                     w->cnt = std::move(o.cnt);
                     w->cbase = std::move(o.cbase);
-                    w->ids = o.ids;
+                    w->dids = std::move(o.ids);
+                    w->ids = w->dids.get();
                     for (uint64_t r : o.n_reads) w->reads += r;
                     w->td[0] = o.t_h2d, w->td[1] = o.t_parse, w->td[2] = o.t_group, w->td[3] = o.t_tok, w->td[4] = o.t_d2h;
                 }
-                for (TextFile &f : w->tf) std::string().swap(f.data);  // the text is on the device (or no longer needed)
+                for (TextFile &f : w->tf) f.data.release();  // the text is on the device (or no longer needed): the block back to the pool
             } else {
                 uint64_t h = 0;
                 w->st = gtars_tokenize(t->index, w->c.get(), w->s.get(), w->e.get(), w->n, w->off.get(), &w->ids, &h);
@@ -2906,7 +3007,8 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         ~AtExit() { f(); }
     } join_at_exit{finish_tokenizer};
     auto free_waves = [&] {
-        for (Wave &w : waves) gtars_free(w.ids);
+        for (Wave &w : waves)
+            if (!w.device) gtars_free(w.ids);  // (a device wave's ids lie in a block of the pinned pool: Wave::dids)
     };
     auto host_sink = [&](size_t, std::vector<SplitFile> &res) -> gtars_status {
         const double t_a = now();
@@ -3033,7 +3135,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                         if (id >= per.size()) per.resize((size_t)id + 1, 0);
                     }
                     k.b.push_back(id);
-                    const uint64_t hits = w.cnt ? w.cnt[r] : w.off[r + 1] - w.off[r];
+                    const uint64_t hits = w.cnt ? w.cnt[r] : w.offs()[r + 1] - w.offs()[r];
                     per[id] += hits ? hits : 1;  // a fragment without hits contributes one unk id
                 }
             cnt.assign(per.size() + 1, 0);
@@ -3044,7 +3146,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
             cnt.assign(nb + 1, 0);
             for (Wave &w : waves)
                 for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
-                    const uint64_t hits = w.cnt ? w.cnt[r] : w.off[r + 1] - w.off[r];
+                    const uint64_t hits = w.cnt ? w.cnt[r] : w.offs()[r + 1] - w.offs()[r];
                     cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
                 }
         }
@@ -3066,10 +3168,10 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                     const uint64_t hits = w.cnt[r];
                     if (!hits) ft->ids[at++] = t->unk_id;
                     for (uint64_t e = x + hits; x < e; ++x) ft->ids[at++] = w.ids[x];
-                } else if (w.off[r + 1] == w.off[r]) {
+                } else if (w.offs()[r + 1] == w.offs()[r]) {
                     ft->ids[at++] = t->unk_id;
                 } else {
-                    for (uint64_t y = w.off[r]; y < w.off[r + 1]; ++y) ft->ids[at++] = w.ids[y];
+                    for (uint64_t y = w.offs()[r]; y < w.offs()[r + 1]; ++y) ft->ids[at++] = w.ids[y];
                 }
             }
         }

@@ -216,6 +216,12 @@ void gtars_fragsplit_last_stages(double *out12);
  * GTARS_HOST_THREADS overrides.  Diagnostic: the reference has no threads on this path (gtars-fragsplit/src/split.rs:36-151). */
 uint32_t gtars_host_threads(uint32_t cap);
 
+/* get_dynamic_reader (gtars-core/src/utils.rs:115-126) as one call: the file's bytes, gunzipped iff its extension is "gz"
+ * (concatenated members decoded one after the other, every member's CRC-32 and length checked; a ".gz" without the gzip magic is
+ * returned as it is).  What every file front end above reads through.  *out: malloc'ed (gtars_free), *out_n bytes.
+ * GTARS_ERR_IO with the reader's message otherwise. */
+gtars_status gtars_read_file(const char *path, char **out, uint64_t *out_n);
+
 /* ------------------------------------------------------------------------
  * .gtok  (gtars-io/src/gtok.rs:125-210, consts.rs:1-3)
  * ---------------------------------------------------------------------- */

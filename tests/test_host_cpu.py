@@ -466,3 +466,88 @@ def test_gzip_reader_follows_the_multi_member_decoder(tmp_path):
     (tmp_path / "crc.bed.gz").write_bytes(bytes(bad))
     with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error"):
         utils.read_fragments(str(tmp_path / "crc.bed.gz"))
+
+
+def _read_file(path):
+    import ctypes as C
+
+    from gtars_amd import _lib
+
+    out, n = C.c_void_p(), C.c_uint64()
+    _lib.check(_lib.lib.gtars_read_file(str(path).encode(), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        _lib.lib.gtars_free(out)
+
+
+@pytest.mark.parametrize("decoder", ["fast", "zlib"])
+def test_whole_buffer_inflate_decodes_what_zlib_writes(tmp_path, monkeypatch, decoder):
+    """Round 5: the deflate streams of a ".gz" are decoded by the library's own whole-buffer decoder (csrc/inflate_fast.h; zlib's
+    behind GTARS_ZLIB_INFLATE) -- gtars_read_file, the get_dynamic_reader of gtars-core/src/utils.rs:115-126 as one call, must
+    return the bytes that went in for every block type zlib can write: stored (level 0), fixed codes (Z_FIXED), dynamic codes
+    at several levels / strategies / memory levels (short and long codes, long matches, distance 1 runs, incompressible bytes),
+    an optional-field header (FEXTRA as bgzip writes it, FNAME, FCOMMENT, FHCRC), concatenated and empty members; damaged
+    files are errors with zlib's messages (the decoder refuses, zlib diagnoses).  tests/soak/fuzz_inflate.cpp is the long form."""
+    import zlib
+
+    from gtars_amd import _lib
+
+    if decoder == "zlib":
+        monkeypatch.setenv("GTARS_ZLIB_INFLATE", "1")
+    _lib.lib.gtars_debug_reload_env()
+    try:
+        rng = np.random.default_rng(11)
+
+        def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8):
+            c = zlib.compressobj(level, zlib.DEFLATED, 31, mem, strategy)
+            return c.compress(data) + c.flush()
+
+        frag = "".join(f"chr{1 + int(c)}\t{int(s)}\t{int(s) + 300}\tBC{int(b):05d}\t1\n"
+                       for c, s, b in zip(rng.integers(0, 22, 30_000), rng.integers(0, 10**8, 30_000), rng.integers(0, 500, 30_000))).encode()
+        samples = [b"", b"a", b"a" * 100_000, b"ab" * 70_000, b"abc" * 50_000 + b"xyz", rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes(),
+                   rng.integers(0, 4, 200_000, dtype=np.uint8).tobytes(), frag, (b"0123456" * 9 + b"\n") * 40_000,
+                   rng.integers(0, 256, 1_200_000, dtype=np.uint8).tobytes()]
+        p = tmp_path / "x.bed.gz"
+        for k, data in enumerate(samples):
+            for level in (0, 1, 6, 9):
+                for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                    for mem in (1, 8):
+                        p.write_bytes(gz(data, level, strategy, mem))
+                        assert _read_file(p) == data, (k, level, strategy, mem)
+        # optional header fields, three members (one of them empty)
+        a, b = b"hello\n" * 1000, rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()
+        raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = raw.compress(a) + raw.flush()
+        hdr = bytes([0x1F, 0x8B, 8, 4 | 8 | 16 | 2, 0, 0, 0, 0, 0, 3]) + bytes([6, 0]) + b"BC\x02\x00\x12\x34" + b"name\x00" + b"comment\x00"
+        tail = body + zlib.crc32(a).to_bytes(4, "little") + len(a).to_bytes(4, "little")
+        p.write_bytes(hdr + (zlib.crc32(hdr) & 0xFFFF).to_bytes(2, "little") + tail + gz(b) + gz(b""))
+        assert _read_file(p) == a + b
+        p.write_bytes(hdr + ((zlib.crc32(hdr) ^ 1) & 0xFFFF).to_bytes(2, "little") + tail)
+        with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error: header crc mismatch"):
+            _read_file(p)
+        p.write_bytes(gz(a) + b"garbage")  # (gzread: ignored)
+        assert _read_file(p) == a
+        blob = bytearray(gz(frag))
+        blob[-5] ^= 1
+        p.write_bytes(bytes(blob))
+        with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error: incorrect data check"):
+            _read_file(p)
+        p.write_bytes(gz(frag)[:-20])
+        with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error: unexpected end of file"):
+            _read_file(p)
+        blob = gz(frag)
+        rejected = 0
+        for pos in range(20, len(blob) - 8, 4001):
+            bad = bytearray(blob)
+            bad[pos] ^= 0x55
+            p.write_bytes(bytes(bad))
+            try:
+                got = _read_file(p)
+                assert got == frag  # (a flipped bit that changes nothing does not exist in a deflate stream, but be exact)
+            except (RuntimeError, ValueError, OSError):
+                rejected += 1
+        assert rejected >= (len(blob) - 28) // 4001
+    finally:
+        monkeypatch.delenv("GTARS_ZLIB_INFLATE", raising=False)
+        _lib.lib.gtars_debug_reload_env()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Config 5, the fused call alone, repeated: for same-box A/Bs of library variants (GTARS_AMD_LIB).
-usage: r05_frag_stream_ab.py [lib ...]   -- inputs are written once, every variant runs in a child process over the same files."""
+usage: r05_frag_stream_ab.py [lib | NAME=VALUE ...]   -- inputs are written once, every variant (a library, or an environment
+switch of the in-tree library such as GTARS_ZLIB_INFLATE=1) runs in a child process over the same files."""
 import json, os, shutil, statistics, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,17 +20,21 @@ def child(tmp):
         tok = Tokenizer.from_bed(p["universe"])
         m = BarcodeToClusterMap.from_file(p["map"])
         fd = p["fragments"]
-        ts = []
+        ts, stages = [], []
         for i in range(9):
             o_, nr_ = C.POINTER(C.POINTER(_lib.FragmentTokens))(), C.c_uint64()
             t = time.perf_counter()
             _lib.check(_lib.lib.gtars_fragsplit_tokenize(tok._h, os.fspath(fd).encode(), m._h, C.byref(o_), C.byref(nr_)))
             ts.append(time.perf_counter() - t)
+            st = (C.c_double * 12)()
+            _lib.lib.gtars_fragsplit_last_stages(st)
+            stages.append([round(x * 1e3, 1) for x in st[2:12]])
             for c in range(m.n_clusters()): _lib.lib.gtars_fragment_tokens_free(o_[c])
             _lib.lib.gtars_free(o_)
         ts = ts[2:]
-        out[name] = {"median_ms": round(statistics.median(ts) * 1e3, 2), "min_ms": round(min(ts) * 1e3, 2), "reads": int(nr_.value)}
-    print(json.dumps({"lib": os.environ.get("GTARS_AMD_LIB", "in-tree"), **out}), flush=True)
+        out[name] = {"median_ms": round(statistics.median(ts) * 1e3, 2), "min_ms": round(min(ts) * 1e3, 2), "reads": int(nr_.value),
+                     "calls_ms": [round(x * 1e3, 1) for x in ts], "stages_ms[inflate,append,device,device_tail,regroup|h2d,parse,gather,tokenize,d2h]": stages[2:]}
+    print(json.dumps({"lib": os.environ.get("GTARS_AMD_LIB", "in-tree"), "switches": {k: v for k, v in os.environ.items() if k.startswith("GTARS_") and k != "GTARS_AMD_LIB"}, **out}), flush=True)
 
 
 def main():
@@ -46,7 +51,8 @@ def main():
         for rep in range(2):
             for lib in sys.argv[1:] or [""]:
                 env = dict(os.environ)
-                if lib: env["GTARS_AMD_LIB"] = os.path.abspath(lib)
+                if "=" in lib and not os.path.exists(lib): env[lib.split("=", 1)[0]] = lib.split("=", 1)[1]
+                elif lib: env["GTARS_AMD_LIB"] = os.path.abspath(lib)
                 subprocess.run([sys.executable, os.path.abspath(__file__), "--child", tmp], env=env, check=False)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
