@@ -41,6 +41,7 @@ ingests only its chromosomes, counts, and ONE all-reduce of the per-file vector(
 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries: larger batches (`roofline_large`), a hit-heavy batch
 (`roofline_hit_heavy`: 1 Mbp-wide queries, ~33 ids each; `roofline_hit_heavy_overlapping`: the same on the ChIP-like universe),
+universes of 140k / 200k / 1M regions at 64M queries (`roofline_universe_*`: beyond the LDS key budget of the tokenizer kernel),
 BASELINE config 3
 (`igd_config3`) and config 4 on one GPU (`lola_config4`), each with a sampled CPU baseline and a parity check of the
 sample against the oracle, config 5 at a reduced file count (`fragsplit_config5`), the PCIe-inclusive host-buffer rate
@@ -1269,6 +1270,19 @@ def main():
             ho["universe"] = "synth.make_universe(overlapping=True), position-sorted"
             out["roofline_hit_heavy_overlapping"] = ho
             del ixo
+            # universes beyond the LDS key budget of k_tok_lds (~65k 16-bit keys = 130k regions): 2 blocks per key at 140k / 200k
+            # regions, 8 at 1M ("the universe-size cliff") -- the same 64M-query measurement as roofline_large,
+            # against each universe's own oracle tokenization
+            for nu2, key in ((140_000, "roofline_universe_140k"), (200_000, "roofline_universe_200k"), (1_000_000, "roofline_universe_1M")):
+                u2 = synth.make_universe(nu2)
+                q2 = synth.make_queries(u2, nq)
+                ix2 = gtars_amd.OverlapIndex(u2["chrom"], u2["start"], u2["end"], n_chrom=synth.N_CHROM)
+                r2 = bench_large(ix2, u2, q2, nu2, [64_000_000], dev, stream)[0]
+                r2["universe_regions"] = nu2
+                r2["batch"] = f"1M queries drawn against this universe (synth.make_queries), tiled 64x on the device"
+                out[key] = r2
+                del ix2
+                torch.cuda.empty_cache()
             # PCIe-inclusive rates through the host-pointer entry points (H2D of the queries, kernel, D2H of offsets +
             # ids).  Reported for context only; never `value`.  `streaming`: gtars_tokenize_into with
             # output arrays the caller reuses (chunked copy / kernel / copy-back pipeline, nothing allocated);

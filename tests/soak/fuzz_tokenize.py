@@ -15,9 +15,14 @@ UNK = 0xFFFFFFFF
 def one(seed):
     rng = np.random.default_rng(seed)
     n_chrom = int(rng.integers(1, 60))
-    n = int(rng.choice([1, 2, 3, 7, 50, 1000, 20_000, 150_000]))
+    # (universes beyond the LDS key budget of the tokenizer kernel -- 130k regions -- up to 2M: units of 2 .. 16 blocks per key)
+    n = int(rng.choice([1, 2, 3, 7, 50, 1000, 20_000, 150_000, 400_000, 2_000_000], p=[.12, .12, .12, .12, .12, .12, .12, .1, .04, .02]))
     span = int(rng.choice([50, 5_000, 1_000_000, 200_000_000, 4_000_000_000 // max(n_chrom, 1)]))
+    if n >= 400_000:  # (a dense small span under millions of intervals is 1e10 ids per batch: keep the large ones genome-like)
+        span = max(span, 200_000_000)
     wmax = int(rng.choice([1, 20, 2_000, max(2, span // 3)]))
+    if n >= 400_000:
+        wmax = min(wmax, 2_000)
     c = rng.integers(0, n_chrom, n)
     s = rng.integers(0, max(span, 2), n)
     w = rng.integers(0 if rng.random() < 0.3 else 1, wmax + 1, n)
