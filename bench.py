@@ -659,7 +659,7 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
         if sg[0]:
             stages.update({"device_text_in_s": round(sg[7], 4), "device_split_parse_sort_s": round(sg[8], 4), "device_gather_s": round(sg[9], 4),
                            "device_tokenize_s": round(sg[10], 4), "device_results_out_s": round(sg[11], 4),
-                           "note": "the host threads only read and inflate (zlib); everything else of split.rs:84-131 / fragments.rs:12-56 runs on "
+                           "note": "the host threads only read and inflate (csrc/inflate_fast.h, into pinned memory); everything else of split.rs:84-131 / fragments.rs:12-56 runs on "
                                    "the GPU while the next wave inflates; the call's floor is the inflate time on the box's usable host threads"})
         else:
             stages["host_per_cluster_append_s"] = round(sg[3], 4)
