@@ -2657,7 +2657,7 @@ void load_text_file(const std::string &path, const gtars_barcode_map &m, TextFil
 // has been handed on by then, so an earlier file's parse error (known once the consumer is done) still comes first.
 // `too_large`: a single file beyond the device parser's text limit.
 template <class Sink, class Idle, class Failed>
-gtars_status stream_text_files(const std::vector<std::string> &files, const gtars_barcode_map &m, uint64_t byte_limit, Sink &&sink,
+gtars_status stream_text_files(const std::vector<std::string> &files, const gtars_barcode_map &m, uint64_t byte_limit, int device, Sink &&sink,
                                Idle &&wait_idle, Failed &&failed, bool *too_large) {
     const size_t n = files.size();
     if (!n) return GTARS_OK;
@@ -2671,6 +2671,8 @@ gtars_status stream_text_files(const std::vector<std::string> &files, const gtar
     bool stop = false;
     std::atomic<size_t> next{0};
     auto loader = [&] {
+        // (the texts are inflated into pinned blocks: allocated against the CALLER's device, not this new thread's default device 0)
+        (void)gtars::frag_select_device(device);
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= n) return;
@@ -3063,7 +3065,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         const uint64_t byte_limit = (cap_mb ? (uint64_t)atoll(cap_mb) : 3500ull) << 20;  // the device path's 32-bit text positions
         bool too_large = false;
         st = stream_text_files(
-            files, *m, byte_limit,
+            files, *m, byte_limit, caller_device,
             [&](size_t base, std::vector<TextFile> &tf) -> gtars_status {
                 waves.emplace_back();
                 Wave &w = waves.back();
