@@ -510,12 +510,13 @@ namespace {
 struct PinnedPool {
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> free_blocks;
-    size_t cached = 0, limit = (size_t)4096 << 20;
-    bool off = false;
-    PinnedPool() {
-        if (const char *e = cfg_get("GTARS_PINNED_POOL_MB")) limit = (size_t)std::max(0ll, atoll(e)) << 20;
-        off = cfg_get("GTARS_NO_PINNED") != nullptr;  // (A/B and tests: ordinary memory everywhere)
+    size_t cached = 0;
+    // (read at every call, not once: tests switch them between calls -- gtars_debug_reload_env)
+    static size_t limit() {
+        const char *e = cfg_get("GTARS_PINNED_POOL_MB");
+        return e ? (size_t)std::max(0ll, atoll(e)) << 20 : (size_t)4096 << 20;
     }
+    static bool off() { return cfg_get("GTARS_NO_PINNED") != nullptr; }  // (A/B and tests: ordinary memory everywhere)
 };
 PinnedPool &pinned_pool() {
     static PinnedPool *p = new PinnedPool;  // (never destroyed: its blocks must not be freed behind the HIP runtime's own teardown)
@@ -525,7 +526,7 @@ PinnedPool &pinned_pool() {
 
 void *frag_pinned_acquire(size_t bytes, size_t *capacity) {
     PinnedPool &pp = pinned_pool();
-    if (pp.off) return nullptr;
+    if (pp.off()) return nullptr;
     const size_t need = std::max<size_t>(bytes, 4096);
     {
         std::lock_guard<std::mutex> lk(pp.mu);
@@ -560,7 +561,7 @@ void frag_pinned_release(void *p, size_t capacity) {
     PinnedPool &pp = pinned_pool();
     {
         std::lock_guard<std::mutex> lk(pp.mu);
-        if (pp.cached + capacity <= pp.limit) {
+        if (pp.cached + capacity <= pp.limit()) {
             pp.free_blocks.emplace_back(p, capacity);
             pp.cached += capacity;
             return;

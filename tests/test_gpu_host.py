@@ -915,6 +915,60 @@ def test_fused_fragment_pipeline_errors_between_waves(tk, golden_dir, tmp_path, 
 
 
 
+def test_fused_fragment_pipeline_gives_the_same_result_under_every_switch(tk, golden_dir, tmp_path, monkeypatch):
+    """Round 5's host half of the fused pipeline has several forms, each behind a switch: files streamed to the device thread in
+    batches that depend on thread timing (1 / 2 / many host threads), the library's own inflate decoder or zlib's
+    (GTARS_ZLIB_INFLATE), the gzip members' CRC-32 on the device or on the host (GTARS_FRAG_HOST_CRC), text and results in blocks
+    of the pinned pool, in ordinary memory (GTARS_NO_PINNED), or in pinned blocks that are never cached (GTARS_PINNED_POOL_MB=0),
+    the host parser (GTARS_FRAG_HOST_PARSE).  Same per-cluster result -- barcodes in first-seen order, offsets, ids -- every time,
+    and equal to the oracle's restatement of the two-step pipeline (split.rs:84-131 + fragments.rs:12-56)."""
+    import gzip
+
+    from gtars_amd import _lib
+    from gtars_amd.fragsplit import BarcodeToClusterMap, fragsplit_tokenize, list_fragment_files
+    from test_sharding_gloo import oracle_fragment_pipeline, same_cluster_results
+    import oracle
+
+    tok = tk("peaks.bed")
+    ub = os.path.join(golden_dir, "tokenizers", "peaks.bed")
+    peaks = [l.split()[:3] for l in open(ub) if l.strip()]
+    rng = np.random.default_rng(23)
+    fd = tmp_path / "frags"
+    fd.mkdir()
+    lines_map = []
+    for fi in range(23):
+        n = int(rng.integers(1, 4000)) if fi != 7 else 0  # (an empty file among them)
+        text = "".join(f"{peaks[int(k)][0]}\t{int(peaks[int(k)][1]) + int(d)}\t{int(peaks[int(k)][2]) + 5}\tBC{int(b)}\t1\n"
+                       for k, d, b in zip(rng.integers(0, len(peaks), n), rng.integers(0, 50, n), rng.integers(0, 12, n)))
+        # levels 0 .. 9: stored, fixed and dynamic blocks; every third file as two gzip members
+        blob = gzip.compress(text.encode(), compresslevel=fi % 10)
+        if fi % 3 == 0 and n > 10:
+            half = text[: len(text) // 2].rfind("\n") + 1
+            blob = gzip.compress(text[:half].encode(), compresslevel=6) + gzip.compress(text[half:].encode(), compresslevel=1)
+        (fd / f"f{fi:02d}.bed.gz").write_bytes(blob)
+        lines_map += [f"f{fi:02d}+BC{b}\tk{(fi + b) % 4}" for b in range(9)]  # (BC9 .. BC11 are not mapped)
+    mp = tmp_path / "map.tsv"
+    mp.write_text("\n".join(lines_map) + "\n")
+    m = BarcodeToClusterMap.from_file(str(mp))
+    om, otok = oracle.OracleBarcodeMap(str(mp)), oracle.OracleTokenizer(ub)
+    want = oracle_fragment_pipeline(list_fragment_files(str(fd)), om, otok)
+    switches = [{}, {"GTARS_HOST_THREADS": "1"}, {"GTARS_HOST_THREADS": "2"}, {"GTARS_HOST_THREADS": "5"}, {"GTARS_ZLIB_INFLATE": "1"},
+                {"GTARS_FRAG_HOST_CRC": "1"}, {"GTARS_NO_PINNED": "1"}, {"GTARS_PINNED_POOL_MB": "0"}, {"GTARS_FRAG_HOST_PARSE": "1"},
+                {"GTARS_NO_PINNED": "1", "GTARS_ZLIB_INFLATE": "1", "GTARS_HOST_THREADS": "3"}]
+    try:
+        for sw in switches:
+            for k, v in sw.items():
+                monkeypatch.setenv(k, v)
+            _lib.lib.gtars_debug_reload_env()
+            for _ in range(2):  # (twice: the second call runs on whatever the first one left in the pools)
+                got = fragsplit_tokenize(str(fd), m, tok, as_arrays=True)
+                assert same_cluster_results(got, want), sw
+            for k in sw:
+                monkeypatch.delenv(k)
+    finally:
+        _lib.lib.gtars_debug_reload_env()
+
+
 def test_device_fragment_parser_follows_the_reference_line_rules(tk, golden_dir, tmp_path, monkeypatch):
     """Round 5: the fused pipeline's text is split and parsed ON THE GPU (fragparse.hip).  Every line rule of
     gtars-fragsplit/src/split.rs:84-131 and gtars-tokenizers/src/utils/fragments.rs:12-82 on hand-made files, the device parser
