@@ -20,7 +20,8 @@ namespace gtars {
 // through its own bounce buffers -- 11 to 37 ms for config 5's 216 MB of text, the longest stage of the call once the inflate was
 // fast, and 2 to 3 API calls per file on top (1000 small files: 30 to 40 ms).  The host threads therefore inflate straight INTO
 // pinned blocks, and the results come back into pinned blocks.  Pinning costs (the driver maps and locks the pages), so blocks are
-// cached when released -- up to GTARS_PINNED_POOL_MB (default 4096) -- and a warm call allocates nothing; a pooled block is also
+// cached when released -- up to GTARS_PINNED_POOL_MB (default 4096) -- and a warm call allocates nothing (at most
+// GTARS_PINNED_MAX_MB, default 16384, are handed out at once: beyond that callers get ordinary memory); a pooled block is also
 // already faulted in, which an ordinary 4.5-MB allocation is not (first touch: a page fault per 4 KiB).
 // acquire: a block of at least `bytes` (*capacity = its size), or nullptr when pinned memory is not to be had (the caller then
 // uses ordinary memory: slower copies, same results).

@@ -511,7 +511,12 @@ struct PinnedPool {
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> free_blocks;
     size_t cached = 0;
+    size_t outstanding = 0;  // bytes of the blocks in callers' hands
     // (read at every call, not once: tests switch them between calls -- gtars_debug_reload_env)
+    static size_t max_outstanding() {  // beyond this much pinned memory in use at once, callers get ordinary memory
+        const char *e = cfg_get("GTARS_PINNED_MAX_MB");
+        return e ? (size_t)std::max(0ll, atoll(e)) << 20 : (size_t)16384 << 20;
+    }
     static size_t limit() {
         const char *e = cfg_get("GTARS_PINNED_POOL_MB");
         return e ? (size_t)std::max(0ll, atoll(e)) << 20 : (size_t)4096 << 20;
@@ -540,10 +545,12 @@ void *frag_pinned_acquire(size_t bytes, size_t *capacity) {
             void *p = pp.free_blocks[best].first;
             *capacity = pp.free_blocks[best].second;
             pp.cached -= *capacity;
+            pp.outstanding += *capacity;
             pp.free_blocks[best] = pp.free_blocks.back();
             pp.free_blocks.pop_back();
             return p;
         }
+        if (pp.outstanding + need > pp.max_outstanding()) return nullptr;  // (a folder of thousands of files holds its results until the end)
     }
     // a little more than asked: the next file of a folder is about as large as this one, not exactly as large
     const size_t cap = (need + need / 8 + (256u << 10) - 1) & ~(size_t)((256u << 10) - 1);
@@ -553,6 +560,10 @@ void *frag_pinned_acquire(size_t bytes, size_t *capacity) {
         return nullptr;
     }
     *capacity = cap;
+    {
+        std::lock_guard<std::mutex> lk(pp.mu);
+        pp.outstanding += cap;
+    }
     return p;
 }
 
@@ -561,6 +572,7 @@ void frag_pinned_release(void *p, size_t capacity) {
     PinnedPool &pp = pinned_pool();
     {
         std::lock_guard<std::mutex> lk(pp.mu);
+        pp.outstanding -= std::min(pp.outstanding, capacity);
         if (pp.cached + capacity <= pp.limit()) {
             pp.free_blocks.emplace_back(p, capacity);
             pp.cached += capacity;

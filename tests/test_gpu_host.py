@@ -919,7 +919,8 @@ def test_fused_fragment_pipeline_gives_the_same_result_under_every_switch(tk, go
     """Round 5's host half of the fused pipeline has several forms, each behind a switch: files streamed to the device thread in
     batches that depend on thread timing (1 / 2 / many host threads), the library's own inflate decoder or zlib's
     (GTARS_ZLIB_INFLATE), the gzip members' CRC-32 on the device or on the host (GTARS_FRAG_HOST_CRC), text and results in blocks
-    of the pinned pool, in ordinary memory (GTARS_NO_PINNED), or in pinned blocks that are never cached (GTARS_PINNED_POOL_MB=0),
+    of the pinned pool, in ordinary memory (GTARS_NO_PINNED), in pinned blocks that are never cached (GTARS_PINNED_POOL_MB=0), or in a
+    mix of both (GTARS_PINNED_MAX_MB=1: the pool hands out one block and refuses the rest),
     the host parser (GTARS_FRAG_HOST_PARSE).  Same per-cluster result -- barcodes in first-seen order, offsets, ids -- every time,
     and equal to the oracle's restatement of the two-step pipeline (split.rs:84-131 + fragments.rs:12-56)."""
     import gzip
@@ -953,7 +954,7 @@ def test_fused_fragment_pipeline_gives_the_same_result_under_every_switch(tk, go
     om, otok = oracle.OracleBarcodeMap(str(mp)), oracle.OracleTokenizer(ub)
     want = oracle_fragment_pipeline(list_fragment_files(str(fd)), om, otok)
     switches = [{}, {"GTARS_HOST_THREADS": "1"}, {"GTARS_HOST_THREADS": "2"}, {"GTARS_HOST_THREADS": "5"}, {"GTARS_ZLIB_INFLATE": "1"},
-                {"GTARS_FRAG_HOST_CRC": "1"}, {"GTARS_NO_PINNED": "1"}, {"GTARS_PINNED_POOL_MB": "0"}, {"GTARS_FRAG_HOST_PARSE": "1"},
+                {"GTARS_FRAG_HOST_CRC": "1"}, {"GTARS_NO_PINNED": "1"}, {"GTARS_PINNED_POOL_MB": "0"}, {"GTARS_PINNED_MAX_MB": "1"}, {"GTARS_FRAG_HOST_PARSE": "1"},
                 {"GTARS_NO_PINNED": "1", "GTARS_ZLIB_INFLATE": "1", "GTARS_HOST_THREADS": "3"}]
     try:
         for sw in switches:
