@@ -26,7 +26,8 @@ namespace fastinf {
 
 constexpr unsigned LL_BITS = 11, OFF_BITS = 8, PRE_BITS = 7;
 constexpr unsigned LL_SIZE = (1u << LL_BITS) + 288 * 16, OFF_SIZE = (1u << OFF_BITS) + 32 * 128, PRE_SIZE = 1u << PRE_BITS;
-// a table entry: bits 0-5 bits to consume | 8-11 extra bits (or a sub-table's index width) | 12 end of block | 13 sub-table
+// a table entry: bits 0-5 bits to consume (a length's / distance's code AND its extra bits: their value is picked out of the bits
+// as they were before, off the chain bit buffer -> lookup -> bit buffer) | 8-11 extra bits (or a sub-table's index width) | 12 end of block | 13 sub-table
 // pointer | 14 exceptional (12, 13 or an unused code) | 15 literal | 16-31 base value / literal / sub-table start
 constexpr uint32_t E_EOB = 1u << 12, E_SUB = 1u << 13, E_EXC = 1u << 14, E_LIT = 1u << 15;
 
@@ -63,7 +64,10 @@ inline bool build_table(const unsigned char *lens, unsigned n, int kind, unsigne
         if (used)
             for (unsigned s = 0; s < n; ++s)
                 if (lens[s])
-                    for (unsigned i = 0; i < (1u << tb); i += 2) table[i] = symbol_entry(kind, s) | 1u;  // (code "0")
+                    for (unsigned i = 0; i < (1u << tb); i += 2) {  // (code "0")
+                        const uint32_t e = symbol_entry(kind, s);
+                        table[i] = e | (1u + ((e & E_EXC) ? 0u : (e >> 8) & 15u));
+                    }
         return true;
     }
     int left = 1;
@@ -114,12 +118,14 @@ inline bool build_table(const unsigned char *lens, unsigned n, int kind, unsigne
         if (!l) continue;
         const unsigned r = reversed(next_code[l]++, l);
         if (l <= tb) {
-            const uint32_t e = symbol_entry(kind, s) | l;
+            uint32_t e = symbol_entry(kind, s);
+            e |= l + (kind != 2 && !(e & (E_LIT | E_EXC)) ? (e >> 8) & 15u : 0u);  // (bits to consume: the code and its extra bits)
             for (unsigned i = r; i < (1u << tb); i += 1u << l) table[i] = e;
         } else {
             const uint32_t ptr = table[r & ((1u << tb) - 1u)];
             const unsigned start = ptr >> 16, bits = (ptr >> 8) & 15u;
-            const uint32_t e = symbol_entry(kind, s) | (l - tb);
+            uint32_t e = symbol_entry(kind, s);
+            e |= (l - tb) + (kind != 2 && !(e & (E_LIT | E_EXC)) ? (e >> 8) & 15u : 0u);
             for (unsigned i = r >> tb; i < (1u << bits); i += 1u << (l - tb)) table[start + i] = e;
         }
     }
@@ -266,10 +272,10 @@ static inline __attribute__((always_inline)) bool inflate_raw_body(const FixedTa
             break;                                                                                   \
         }                                                                                            \
     }                                                                                                \
+    saved = bitbuf;                                                                                  \
     GTARS_INF_TAKE(e & 63u);                                                                         \
     xb = (e >> 8) & 15u;                                                                             \
-    len = (e >> 16) + ((unsigned)bitbuf & ((1u << xb) - 1u));                                        \
-    GTARS_INF_TAKE(xb)
+    len = (e >> 16) + ((unsigned)(saved >> ((e & 63u) - xb)) & ((1u << xb) - 1u))
         // (the NEXT symbol's table entry is looked up before a match is copied: the lookup's latency hides behind the copy)
 #define GTARS_INF_NEXT()                               \
     do {                                               \
@@ -281,6 +287,7 @@ static inline __attribute__((always_inline)) bool inflate_raw_body(const FixedTa
         GTARS_INF_NEXT();
         for (;;) {
             unsigned xb, len;
+            uint64_t saved;
             if (e & E_LIT) {
                 GTARS_INF_TAKE(e & 63u);
                 *out_next++ = (unsigned char)(e >> 16);
@@ -309,10 +316,10 @@ static inline __attribute__((always_inline)) bool inflate_raw_body(const FixedTa
                 e = off[(e >> 16) + ((unsigned)bitbuf & ((1u << ((e >> 8) & 15u)) - 1u))];
                 if (e & E_EXC) return false;
             }
+            saved = bitbuf;
             GTARS_INF_TAKE(e & 63u);
             xb = (e >> 8) & 15u;
-            const size_t dist = (e >> 16) + ((unsigned)bitbuf & ((1u << xb) - 1u));
-            GTARS_INF_TAKE(xb);
+            const size_t dist = (e >> 16) + ((unsigned)(saved >> ((e & 63u) - xb)) & ((1u << xb) - 1u));
             if (dist > (size_t)(out_next - out_base) - member_start) return false;
             const unsigned char *src = out_next - dist;
             unsigned char *dst = out_next;

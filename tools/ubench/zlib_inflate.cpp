@@ -15,7 +15,7 @@ int main(){
   long pos=10000;
   for(int i=0;i<100000;i++){ char b[128]; pos+=rnd()%3000; int n=snprintf(b,sizeof b,"chr%d\t%ld\t%ld\tBC%04u-1\t%d\n",1+i/5000,pos,pos+100+rnd()%500,rnd()%500,1+rnd()%3); text.append(b,n);}  
   printf("text %zu bytes\n", text.size());
-  gzFile f=gzopen("t.gz","wb6"); gzwrite(f,text.data(),text.size()); gzclose(f);
+  gzFile f=gzopen("t.gz", getenv("GZLEVEL") ? getenv("GZLEVEL") : "wb6"); gzwrite(f,text.data(),text.size()); gzclose(f);
   FILE*fp=fopen("t.gz","rb"); std::vector<unsigned char> comp(8<<20); size_t cn=fread(comp.data(),1,comp.size(),fp); fclose(fp); printf("gz %zu bytes\n",cn);
   std::vector<char> out(text.size()+1024);
   for(int rep=0;rep<3;rep++){
