@@ -159,7 +159,9 @@ Workspace &tls_workspace(int slot, hipStream_t stream) {
                 // ... also in the 64 bytes at its head that outlive a call (launch_igd_sweep's order flags: "zero when the buffer
                 // is new" must hold for an adopted buffer as well)
                 w.igd_calls = 0;
-                if (w.ptr) (void)hipMemset(w.ptr, 0, 64);
+                // (on the stream this workspace will serve: a memset on the null stream is not ordered in front of work on a
+                // non-blocking stream, and may land in the middle of the first kernel that writes there)
+                if (w.ptr) (void)hipMemsetAsync(w.ptr, 0, 64, stream);
                 pool.idle[i] = pool.idle.back();
                 pool.idle.pop_back();
                 break;

@@ -596,6 +596,37 @@ gtars_status frag_select_device(int device) {
     return GTARS_OK;
 }
 
+// Wait for the stream WITHOUT spinning: the thread that drives the device shares the host's cores with the threads that inflate the
+// next files -- hipStreamSynchronize polls, i.e. it takes one of 16 cores away from 16 loaders, and 48 files then need four rounds on
+// some core instead of three (12.8 ms instead of 9.6).  An event created with hipEventBlockingSync puts the thread to sleep until the
+// GPU's interrupt (tens of microseconds later than a poll would notice: nothing here is that urgent).
+static gtars_status wait_stream(hipStream_t st) {
+    struct Event {  // (one per thread and device it waits on; destroyed with the thread)
+        hipEvent_t e[16] = {};
+        ~Event() {
+            for (hipEvent_t x : e)
+                if (x) (void)hipEventDestroy(x);
+        }
+    };
+    static thread_local Event tl;
+    if (cfg_get("GTARS_FRAG_SPIN_WAIT")) {  // (A/B)
+        GT_HIP(hipStreamSynchronize(st));
+        return GTARS_OK;
+    }
+    int dev = 0;
+    GT_HIP(hipGetDevice(&dev));
+    hipEvent_t &ev = tl.e[dev & 15];
+    if (!ev) GT_HIP(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
+    GT_HIP(hipEventRecord(ev, st));
+    GT_HIP(hipEventSynchronize(ev));
+    return GTARS_OK;
+}
+#define GT_WAIT(st_)                                   \
+    do {                                               \
+        const gtars_status ws_ = wait_stream(st_);     \
+        if (ws_) return ws_;                           \
+    } while (0)
+
 gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms, const std::vector<FragFileIn> &files, uint32_t n_clusters,
                               FragWaveOut &out) {
     const u32 n_files = (u32)files.size();
@@ -616,7 +647,24 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
     }
     if (total >= 0xFFFF0000ull) return fail(GTARS_ERR_INVALID_ARG, "fragment wave: more than 4 GiB of text");
     const double t0 = now_s();
+    // a stream of the calling thread's own (per device): the host pipeline drives the device from two threads, whose batches must
+    // overlap -- copies of one with kernels of the other -- and the null stream would serialise them
     hipStream_t st = nullptr;
+    {
+        struct Streams {  // (the pipeline's device threads live for one call: their streams go with them)
+            hipStream_t s[16] = {};
+            ~Streams() {
+                for (hipStream_t x : s)
+                    if (x) (void)hipStreamDestroy(x);
+            }
+        };
+        static thread_local Streams tl;
+        int dev = 0;
+        GT_HIP(hipGetDevice(&dev));
+        hipStream_t &slot = tl.s[dev & 15];
+        if (!slot && !cfg_get("GTARS_FRAG_NULL_STREAM")) GT_HIP(hipStreamCreateWithFlags(&slot, hipStreamNonBlocking));
+        st = slot;
+    }
     const u32 n_bytes = (u32)total;
     const u32 n_chunks = (n_bytes + FP_CHUNK - 1) / FP_CHUNK;
     // ---- text + tables to the device ----
@@ -643,6 +691,13 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
                  stage_mem = stage_keys + pad(total_keys + 16), stage_bytes = stage_mem + pad(n_members * sizeof(CrcMember)) + 256;
     HostBlock staging;
     if (!staging.alloc(stage_bytes)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    // the small answers (line count, error file, per-cluster and per-file counts) land in a pinned mailbox: a copy into pageable
+    // memory is synchronous, and that wait polls
+    HostBlock mailbox;
+    const size_t mb_coff = 64, mb_written = mb_coff + pad(((size_t)n_clusters + 1) * 4), mb_fline = mb_written + pad((size_t)n_files * 4),
+                 mb_cbase = mb_fline + pad(m1 * 4), mb_bytes = mb_cbase + pad(((size_t)n_clusters + 1) * 8);
+    if (!mailbox.alloc(mb_bytes)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+    volatile u32 *mb_words = (volatile u32 *)mailbox.p;  // [0] line count, [1] error file, [2] wide flag
     u32 *file_off = (u32 *)staging.p, *slot_off = file_off + m1, *key_off = slot_off + m1;
     file_off[0] = slot_off[0] = key_off[0] = 0;
     for (u32 f = 0; f < n_files; ++f) {
@@ -694,7 +749,7 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         hipLaunchKernelGGL(k_crc_members, dim3((nm + 63) / 64), dim3(64), 0, st, (const CrcMember *)d_mem, nm, d_tb, (const u32 *)d_gpart, d_err);
         GT_HIP(hipGetLastError());
     }
-    GT_HIP(hipStreamSynchronize(st));
+    GT_WAIT(st);
     const double t1 = now_s();
     out.t_h2d = t1 - t0;
     // ---- line ends ----
@@ -704,12 +759,16 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         hipLaunchKernelGGL(k_frag_lines<false>, dim3(n_chunks), dim3(FP_TPB), 0, st, d_text.as<u32>(), n_bytes, d_cnt, (const u32 *)nullptr,
                            (u32 *)nullptr);
         hipLaunchKernelGGL(k_frag_scan_chunks, dim3(1), dim3(1024), 0, st, (const u32 *)d_cnt, n_chunks, d_base);
-        GT_HIP(hipMemcpyAsync(&n_lines, d_base + n_chunks, 4, hipMemcpyDeviceToHost, st));
-        GT_HIP(hipStreamSynchronize(st));
+        GT_HIP(hipMemcpyAsync((void *)&mb_words[0], d_base + n_chunks, 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipMemcpyAsync((void *)&mb_words[1], d_err, 4, hipMemcpyDeviceToHost, st));
+        GT_WAIT(st);
+        n_lines = mb_words[0];
+    } else {
+        GT_HIP(hipMemcpyAsync((void *)&mb_words[1], d_err, 4, hipMemcpyDeviceToHost, st));
+        GT_WAIT(st);
     }
     if (!n_lines) {  // (no text at all: a member's CRC may still be wrong)
-        u32 h_err0 = 0xFFFFFFFFu;
-        GT_HIP(hipMemcpy(&h_err0, d_err, 4, hipMemcpyDeviceToHost));
+        const u32 h_err0 = mb_words[1];
         if (h_err0 != 0xFFFFFFFFu) out.first_error_file = h_err0;
     }
     if (n_lines) {
@@ -738,13 +797,14 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         if ((s = radix_sort_pairs(d_key, d_v0, d_k1, d_v1, n_lines, 0, 16, ws, sort_ws, &res, st))) return s;
         const u32 *sk = res ? d_k1 : d_key, *sp = res ? d_v1 : d_v0;
         hipLaunchKernelGGL(k_frag_cluster_offsets, dim3((n_clusters + 1 + 255) / 256), dim3(256), 0, st, sk, n_lines, n_clusters, d_coff);
-        std::vector<u32> h_coff((size_t)n_clusters + 1), h_written(n_files), h_file_line(m1);
-        u32 h_err = 0xFFFFFFFFu;
-        GT_HIP(hipMemcpyAsync(h_coff.data(), d_coff, ((size_t)n_clusters + 1) * 4, hipMemcpyDeviceToHost, st));
-        GT_HIP(hipMemcpyAsync(h_written.data(), d_written, (size_t)n_files * 4, hipMemcpyDeviceToHost, st));
-        GT_HIP(hipMemcpyAsync(h_file_line.data(), d_file_line, m1 * 4, hipMemcpyDeviceToHost, st));
-        GT_HIP(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
-        GT_HIP(hipStreamSynchronize(st));
+        const u32 *h_coff = (const u32 *)((char *)mailbox.p + mb_coff), *h_written = (const u32 *)((char *)mailbox.p + mb_written),
+                  *h_file_line = (const u32 *)((char *)mailbox.p + mb_fline);
+        GT_HIP(hipMemcpyAsync((void *)h_coff, d_coff, ((size_t)n_clusters + 1) * 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipMemcpyAsync((void *)h_written, d_written, (size_t)n_files * 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipMemcpyAsync((void *)h_file_line, d_file_line, m1 * 4, hipMemcpyDeviceToHost, st));
+        GT_HIP(hipMemcpyAsync((void *)&mb_words[1], d_err, 4, hipMemcpyDeviceToHost, st));
+        GT_WAIT(st);
+        const u32 h_err = mb_words[1];
         const double t2 = now_s();
         out.t_parse = t2 - t1;
         for (u32 f = 0; f < n_files; ++f) {
@@ -777,7 +837,7 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             hipLaunchKernelGGL(k_frag_gather, dim3((n + 255) / 256), dim3(256), 0, st, sp, n, (const u32 *)d_qc, (const u32 *)d_qs,
                                (const u32 *)d_qe, (const u32 *)d_qslot, (const u32 *)d_file_line, n_files, oc, os, oe, oslot, ofile);
             GT_HIP(hipGetLastError());
-            GT_HIP(hipStreamSynchronize(st));
+            GT_WAIT(st);
             const double t3 = now_s();
             out.t_group = t3 - t2;
             // ---- tokenize where the columns lie: one fused pass with a guessed capacity, the fill pass when it was short ----
@@ -788,7 +848,7 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
                 if ((s = bigger.alloc(h * 4))) return s;
                 d_ids_p = bigger.as<u32>();
                 if ((s = gtars_fill_device_n(ix, oc, os, oe, n, (const uint64_t *)d_off, d_ids_p, h, st))) return s;
-                GT_HIP(hipStreamSynchronize(st));
+                GT_WAIT(st);
             } else if (s) {
                 return s;
             }
@@ -801,14 +861,15 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             hipLaunchKernelGGL(k_frag_counts8, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *)d_off, n, d_cnt8, d_err);
             hipLaunchKernelGGL(k_frag_cluster_bases, dim3((n_clusters + 1 + 255) / 256), dim3(256), 0, st, (const u64 *)d_off, (const u32 *)d_coff,
                                n_clusters, d_cbase);
-            u32 wide = 0;
-            GT_HIP(hipMemcpyAsync(&wide, d_err, 4, hipMemcpyDeviceToHost, st));
-            GT_HIP(hipMemcpyAsync(out.cbase.data(), d_cbase, ((size_t)n_clusters + 1) * 8, hipMemcpyDeviceToHost, st));
+            GT_HIP(hipMemcpyAsync((void *)&mb_words[2], d_err, 4, hipMemcpyDeviceToHost, st));
+            GT_HIP(hipMemcpyAsync((char *)mailbox.p + mb_cbase, d_cbase, ((size_t)n_clusters + 1) * 8, hipMemcpyDeviceToHost, st));
             GT_HIP(hipMemcpyAsync(out.file.get(), ofile, (size_t)n * 2, hipMemcpyDeviceToHost, st));
             GT_HIP(hipMemcpyAsync(out.slot.get(), oslot, (size_t)n * 4, hipMemcpyDeviceToHost, st));
             if (h) GT_HIP(hipMemcpyAsync(out.ids.get(), d_ids_p, h * 4, hipMemcpyDeviceToHost, st));
             GT_HIP(hipMemcpyAsync(out.cnt.get(), d_cnt8, (size_t)n, hipMemcpyDeviceToHost, st));  // (the common case, sent along unasked)
-            GT_HIP(hipStreamSynchronize(st));
+            GT_WAIT(st);
+            memcpy(out.cbase.data(), (char *)mailbox.p + mb_cbase, ((size_t)n_clusters + 1) * 8);
+            const u32 wide = mb_words[2];
             if (wide) {
                 out.cnt.reset();
                 if (!out.off.alloc((size_t)n + 1)) return fail(GTARS_ERR_INTERNAL, "out of host memory");

@@ -2932,7 +2932,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
     bool closing = false;
     size_t in_flight = 0;       // waves queued or on the device
     bool wave_failed = false;   // a wave ended with an error (the producer stops)
-    std::thread tok_thread([&] {
+    auto tok_body = [&] {
         (void)gtars::frag_select_device(caller_device);  // (HIP's current device belongs to the thread and starts at 0)
         for (;;) {
             Wave *w = nullptr;
@@ -2987,22 +2987,29 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                 w->st = gtars_tokenize(t->index, w->c.get(), w->s.get(), w->e.get(), w->n, w->off.get(), &w->ids, &h);
                 if (w->st) w->err = gtars_last_error();
             }
-            t_tok += now() - t0;
             {
                 std::lock_guard<std::mutex> lk(mu);
+                t_tok += now() - t0;
                 --in_flight;
                 if (w->st) wave_failed = true;
             }
             cv.notify_all();
         }
-    });
+    };
+    // The device path runs TWO of these threads, each with a stream of its own (fragparse.hip): a batch's text goes to the device
+    // while the previous batch's kernels run and its results come back -- on one thread a batch is copy in, kernels, copy out, one
+    // after the other, 10.5 ms of device time per 48 files of which 5 are the text's way over PCIe.  (They sleep in their waits.)
+    const unsigned n_tok_threads = device_path ? (unsigned)std::max(1, std::min(4, atoi(cfg_get("GTARS_FRAG_DEVICE_THREADS") ? cfg_get("GTARS_FRAG_DEVICE_THREADS") : "2"))) : 1u;
+    std::vector<std::thread> tok_threads;
+    for (unsigned q = 0; q < n_tok_threads; ++q) tok_threads.emplace_back(tok_body);
     auto finish_tokenizer = [&] {
         {
             std::lock_guard<std::mutex> lk(mu);
             closing = true;
         }
         cv.notify_all();
-        if (tok_thread.joinable()) tok_thread.join();
+        for (auto &th : tok_threads)
+            if (th.joinable()) th.join();
     };
     struct AtExit {  // (an exception on the way -- out of memory -- must not meet a joinable thread)
         std::function<void()> f;
@@ -3081,9 +3088,9 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                 cv.notify_all();
                 return GTARS_OK;
             },
-            [&] {  // the device thread has nothing queued and nothing running
+            [&] {  // a device thread has nothing queued and nothing running
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return in_flight == 0; });
+                cv.wait(lk, [&] { return in_flight < n_tok_threads; });
             },
             [&] {
                 std::lock_guard<std::mutex> lk(mu);
