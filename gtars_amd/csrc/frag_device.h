@@ -115,19 +115,20 @@ struct FragFileIn {
     uint32_t n_members = 0;
 };
 
-// what comes back for a wave: the routed fragments CLUSTER-MAJOR (clusters ascending; inside a cluster files in wave order, lines
-// in file order -- the order the cluster's output file would have them), tokenized
+// What comes back for a wave: the token ids of its routed, tokenized fragments REGROUPED BY (file, barcode) on the device (round 5,
+// last cut; fragparse.hip k_frag_emit).  The fragments are sorted by (file, slot of the barcode in the file's table), stable, so
+// every (file, barcode) is one run of fragments in line order, and `ids` holds the runs' ids one after the other -- a fragment
+// without hits contributes the unk id (fragments.rs:35-56).  A (file, barcode) belongs to one cluster (the slot's value), so the
+// host is left with: per cluster, its runs in the order their first lines appear (= the first-seen barcode order of a pass over
+// the cluster's file), a dictionary lookup per run, one memcpy per run.
 struct FragWaveOut {
-    std::vector<uint64_t> coff;        // [n_clusters + 1] fragments of every cluster
-    uint64_t n = 0;                    // routed fragments that are tokenized (lines whose chromosome field starts with '#' are not)
-    HostArray<uint16_t> file;  // [n] file of the fragment (index into the wave)
-    HostArray<uint32_t> slot;  // [n] slot of its barcode in that file's table
-    // the token CSR: ids of fragment r at ids[x .. x + cnt[r]), x running from cbase[c] at the cluster's first fragment -- one BYTE
-    // per fragment over the link instead of an 8-byte offset; `off` ([n + 1]) instead when some fragment has more than 255 ids
-    HostArray<uint8_t> cnt;       // [n], or null
-    std::vector<uint64_t> cbase;  // [n_clusters + 1] offset of every cluster's first id
-    HostArray<uint64_t> off;      // [n + 1], or null
-    HostArray<uint32_t> ids;
+    uint64_t n = 0;      // routed fragments that are tokenized (lines whose chromosome field starts with '#' are not)
+    uint64_t n_ids = 0;  // their ids, the unk fills included
+    HostArray<uint32_t> ids;        // [n_ids]
+    std::vector<uint32_t> slot_off;  // [n_files + 1]: file f's slots are [slot_off[f], slot_off[f + 1]) of the two arrays below
+    HostArray<uint32_t> run_start;  // [slots]: first id of the slot's run in `ids`, 0xFFFFFFFF: no tokenized fragment has this barcode;
+                                    // the runs lie in slot order, so a run ends where the next present one starts (the last: n_ids)
+    HostArray<uint32_t> run_line;   // [slots]: the wave-wide number of the line that opens the run (lines count through the files in order)
     std::vector<uint64_t> n_reads, n_written;  // per file: lines, routed lines ('#' lines included)
     int64_t first_error_file = -1;     // first file (wave order) with a line the reference fails on, or with a gzip member whose
                                        // CRC-32 is not its trailer's; -1: none.  The caller reads that file again on the host (zlib's
@@ -141,8 +142,9 @@ gtars_status frag_chroms_create(const std::vector<std::string> &names, FragChrom
 void frag_chroms_free(FragChroms *c);
 
 // One wave on the calling thread's current device.  The text of all files together must stay below 4 GiB.
+// unk_id: the id a fragment without hits contributes.  GTARS_ERR_CAPACITY: the wave yields more than 4e9 ids (the caller parses on the host).
 gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms, const std::vector<FragFileIn> &files, uint32_t n_clusters,
-                              FragWaveOut &out);
+                              uint32_t unk_id, FragWaveOut &out);
 int frag_current_device();  // the calling thread's current HIP device (the wave thread selects the caller's)
 gtars_status frag_select_device(int device);
 

@@ -167,11 +167,12 @@ struct FragTables {
     u32 n_chrom_slots;
 };
 
-// One lane per line.  key[i] = the line's cluster when it is routed AND tokenized, NO_CLUSTER otherwise; counts per file.
+// One lane per line.  key[i] = the line's (file, barcode) -- the slot of its barcode in the wave's concatenated tables -- when it
+// is routed AND tokenized, `no_key` (= the number of slots: sorts behind every real key) otherwise; counts per file.
 __global__ void __launch_bounds__(FP_TPB)
 k_frag_parse(const unsigned char *__restrict__ text, const u32 *__restrict__ line_end, u32 n_lines, const u32 *__restrict__ file_line,
-             u32 n_files, FragTables tb, u32 *__restrict__ key, u32 *__restrict__ q_chrom, u32 *__restrict__ q_start, u32 *__restrict__ q_end,
-             u32 *__restrict__ q_slot, u32 *__restrict__ n_written, u32 *__restrict__ err_file) {
+             u32 n_files, FragTables tb, u32 no_key, u32 *__restrict__ key, u32 *__restrict__ q_chrom, u32 *__restrict__ q_start,
+             u32 *__restrict__ q_end, u32 *__restrict__ n_written, u32 *__restrict__ err_file) {
     const u32 i = blockIdx.x * FP_TPB + threadIdx.x;
     if (i >= n_lines) return;
     const u32 lo = i ? line_end[i - 1] + 1u : 0u, hi = line_end[i];
@@ -199,7 +200,7 @@ k_frag_parse(const unsigned char *__restrict__ text, const u32 *__restrict__ lin
             ++nf;
         }
     }
-    u32 k = NO_CLUSTER;
+    u32 k = no_key;
     bool bad = nf < 5, written = false;  // fewer than five fields: "Failed to parse fragments file at line ..." (routed or not)
     if (!bad) {
         const u32 so = tb.slot_off[f], ns = tb.slot_off[f + 1] - so;
@@ -212,11 +213,10 @@ k_frag_parse(const unsigned char *__restrict__ text, const u32 *__restrict__ lin
                     bad = true;
                 } else {
                     const u32 cs = table_find(tb.chrom_slots, tb.n_chrom_slots, tb.chrom_keys, text + fs[0], fl[0]);
-                    k = tb.slots[so + slot].value;
+                    k = so + slot;
                     q_chrom[i] = cs == 0xFFFFFFFFu ? GTARS_UNKNOWN_CHROM : tb.chrom_slots[cs].value;
                     q_start[i] = s;
                     q_end[i] = e;
-                    q_slot[i] = slot;
                 }
             }
         }
@@ -238,56 +238,77 @@ __global__ void k_frag_iota(u32 *__restrict__ p, u32 n) {
     if (i < n) p[i] = i;
 }
 
-// coff[c] = first position of the sorted keys with key >= c, c = 0 .. n_clusters (coff[n_clusters] = tokenized fragments)
-__global__ void k_frag_cluster_offsets(const u32 *__restrict__ sorted_key, u32 n, u32 n_clusters, u32 *__restrict__ coff) {
-    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > n_clusters) return;
+// *out = first position of the sorted keys with key >= bound (= the number of tokenized fragments for bound = no_key)
+__global__ void k_frag_lower_bound(const u32 *__restrict__ sorted_key, u32 n, u32 bound, u32 *__restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
     u32 lo = 0, hi = n;
     while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
-        if (sorted_key[mid] < c)
+        if (sorted_key[mid] < bound)
             lo = mid + 1;
         else
             hi = mid;
     }
-    coff[c] = lo;
+    *out = lo;
 }
 
-// cluster-major columns of the tokenized fragments: line perm[j] of the wave
+// columns of the tokenized fragments in (file, barcode) order: line perm[j] of the wave
 __global__ void k_frag_gather(const u32 *__restrict__ perm, u32 n, const u32 *__restrict__ q_chrom, const u32 *__restrict__ q_start,
-                              const u32 *__restrict__ q_end, const u32 *__restrict__ q_slot, const u32 *__restrict__ file_line, u32 n_files,
-                              u32 *__restrict__ oc, u32 *__restrict__ os, u32 *__restrict__ oe, u32 *__restrict__ oslot,
-                              unsigned short *__restrict__ ofile) {
+                              const u32 *__restrict__ q_end, u32 *__restrict__ oc, u32 *__restrict__ os, u32 *__restrict__ oe) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const u32 i = perm[j];
     oc[j] = q_chrom[i];
     os[j] = q_start[i];
     oe[j] = q_end[i];
-    oslot[j] = q_slot[i];
-    u32 a = 0, b = n_files;
-    while (a + 1 < b) {
-        const u32 mid = (a + b) >> 1;
-        if (file_line[mid] <= i)
-            a = mid;
-        else
-            b = mid;
-    }
-    ofile[j] = (unsigned short)a;
 }
 
-// cnt[j] = min(off[j + 1] - off[j], 255); *wide = 1 when some fragment has more than 255 ids
-__global__ void k_frag_counts8(const u64 *__restrict__ off, u32 n, unsigned char *__restrict__ cnt, u32 *__restrict__ wide) {
-    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const u64 h = off[j + 1] - off[j];
-    cnt[j] = (unsigned char)(h > 255 ? 255 : h);
-    if (h > 255) *wide = 1u;
+// ---- the per-barcode regrouping on the device (round 5, last cut) --------------------------------------------------------------
+// tokenize_fragment_file groups a cluster file's token ids by barcode (fragments.rs:35-56: HashMap<String, Vec<u32>>; a fragment
+// without hits contributes the unk id).  The fragments arrive here SORTED by (file, barcode slot) -- stable, so a barcode's
+// fragments keep their line order -- which makes every (file, barcode) one RUN of consecutive fragments, and the ids of a run,
+// concatenated, are that barcode's share of the result from this file.  k_frag_emit writes the runs' ids one after the other
+// (with the unk fill), and per slot where its run starts and which line opened it; the host is left with one memcpy per run and
+// a dictionary lookup per (file, barcode) instead of three passes over every fragment.
+constexpr u32 EM_TPB = 1024;
+// ids a chunk of EM_TPB fragments emits
+__global__ void __launch_bounds__(EM_TPB)
+k_frag_emit_counts(const u64 *__restrict__ off, u32 n, u32 *__restrict__ chunk_tot) {
+    __shared__ u32 s_scan[16];
+    const u32 j = blockIdx.x * EM_TPB + threadIdx.x;
+    u32 c = 0;
+    if (j < n) {
+        const u64 h = off[j + 1] - off[j];
+        c = h ? (u32)h : 1u;
+    }
+    u32 total;
+    (void)block_exclusive_scan<EM_TPB>(c, s_scan, total);
+    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = total;
 }
-// base[c] = off[coff[c]]
-__global__ void k_frag_cluster_bases(const u64 *__restrict__ off, const u32 *__restrict__ coff, u32 n_clusters, u64 *__restrict__ base) {
-    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= n_clusters) base[c] = off[coff[c]];
+__global__ void __launch_bounds__(EM_TPB)
+k_frag_emit(const u64 *__restrict__ off, const u32 *__restrict__ ids, u32 n, const u32 *__restrict__ chunk_base, const u32 *__restrict__ sorted_key,
+            const u32 *__restrict__ perm, u32 unk_id, u32 *__restrict__ out_ids, u32 *__restrict__ run_start, u32 *__restrict__ run_line) {
+    __shared__ u32 s_scan[16];
+    const u32 j = blockIdx.x * EM_TPB + threadIdx.x;
+    u64 o = 0;
+    u32 h = 0;
+    if (j < n) {
+        o = off[j];
+        h = (u32)(off[j + 1] - o);
+    }
+    u32 total;
+    const u32 dst = chunk_base[blockIdx.x] + block_exclusive_scan<EM_TPB>(j < n ? (h ? h : 1u) : 0u, s_scan, total);
+    if (j >= n) return;
+    const u32 g = sorted_key[j];
+    if (j == 0 || sorted_key[j - 1] != g) {  // the fragment that opens its (file, barcode)'s run
+        run_start[g] = dst;
+        run_line[g] = perm[j];
+    }
+    if (!h) {
+        out_ids[dst] = unk_id;
+    } else {
+        for (u32 k = 0; k < h; ++k) out_ids[dst + k] = ids[o + k];
+    }
 }
 
 // ---- CRC-32 (RFC 1952: reflected polynomial 0xEDB88320) of the gzip members on the device ----------------------------------
@@ -628,10 +649,11 @@ static gtars_status wait_stream(hipStream_t st) {
     } while (0)
 
 gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms, const std::vector<FragFileIn> &files, uint32_t n_clusters,
-                              FragWaveOut &out) {
+                              uint32_t unk_id, FragWaveOut &out) {
     const u32 n_files = (u32)files.size();
-    out.coff.assign((size_t)n_clusters + 1, 0);
     out.n = 0;
+    out.n_ids = 0;
+    out.slot_off.assign((size_t)n_files + 1, 0);
     out.n_reads.assign(n_files, 0);
     out.n_written.assign(n_files, 0);
     out.first_error_file = -1;
@@ -645,7 +667,7 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         total_slots += f.n_slots;
         total_keys += f.n_key_bytes;
     }
-    if (total >= 0xFFFF0000ull) return fail(GTARS_ERR_INVALID_ARG, "fragment wave: more than 4 GiB of text");
+    if (total >= 0xFFFF0000ull || total_slots >= 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "fragment wave: more than 4 GiB of text");
     const double t0 = now_s();
     // a stream of the calling thread's own (per device): the host pipeline drives the device from two threads, whose batches must
     // overlap -- copies of one with kernels of the other -- and the null stream would serialise them
@@ -708,6 +730,7 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         if (files[f].n_slots) memcpy((char *)staging.p + stage_slots + (size_t)slot_off[f] * sizeof(FragSlot), files[f].slots, (size_t)files[f].n_slots * sizeof(FragSlot));
         if (files[f].n_key_bytes) memcpy((char *)staging.p + stage_keys + key_off[f], files[f].keys, files[f].n_key_bytes);
     }
+    for (u32 f = 0; f <= n_files; ++f) out.slot_off[f] = slot_off[f];
     if (total_slots) GT_HIP(hipMemcpyAsync(d_slots.as<FragSlot>(), (char *)staging.p + stage_slots, total_slots * sizeof(FragSlot), hipMemcpyHostToDevice, st));
     if (total_keys) GT_HIP(hipMemcpyAsync(d_keys.as<char>(), (char *)staging.p + stage_keys, total_keys, hipMemcpyHostToDevice, st));
     GT_HIP(hipMemsetAsync(d_text.as<char>() + n_bytes, 0, (size_t)std::max<u32>(n_chunks, 1) * FP_CHUNK + 64 - n_bytes, st));
@@ -782,24 +805,25 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
                            d_line_end);
         hipLaunchKernelGGL(k_frag_file_lines, dim3((n_files + 1 + 63) / 64), dim3(64), 0, st, (const u32 *)d_line_end, n_lines,
                            (const u32 *)d_file_off, n_files, d_file_line);
-        // ---- parse: per-line columns key | chrom | start | end | slot ----
-        u32 *d_key = d_cols.as<u32>(), *d_qc = d_key + n_lines, *d_qs = d_qc + n_lines, *d_qe = d_qs + n_lines, *d_qslot = d_qe + n_lines;
+        // ---- parse: per-line columns key | chrom | start | end ----
+        u32 *d_key = d_cols.as<u32>(), *d_qc = d_key + n_lines, *d_qs = d_qc + n_lines, *d_qe = d_qs + n_lines;
         FragTables tb{d_slots.as<FragSlot>(), d_keys.as<unsigned char>(), d_slot_off, d_key_off, chroms->slots.as<FragSlot>(),
                       chroms->keys.as<unsigned char>(), chroms->n_slots};
+        const u32 no_key = (u32)total_slots;  // (< 2^32: the tables of a wave's files are 16 bytes a slot, of < 4 GiB of text)
         hipLaunchKernelGGL(k_frag_parse, dim3((n_lines + FP_TPB - 1) / FP_TPB), dim3(FP_TPB), 0, st, d_text.as<unsigned char>(),
-                           (const u32 *)d_line_end, n_lines, (const u32 *)d_file_line, n_files, tb, d_key, d_qc, d_qs, d_qe, d_qslot, d_written, d_err);
+                           (const u32 *)d_line_end, n_lines, (const u32 *)d_file_line, n_files, tb, no_key, d_key, d_qc, d_qs, d_qe, d_written, d_err);
         GT_HIP(hipGetLastError());
-        // ---- the lines by cluster (stable: wave order inside a cluster), the tokenized ones in front ----
+        // ---- the lines by (file, barcode) (stable: line order inside a barcode), the tokenized ones in front ----
         u32 *d_v0 = d_sort.as<u32>(), *d_k1 = d_v0 + n_lines, *d_v1 = d_k1 + n_lines;
         void *ws = (void *)(((uintptr_t)(d_v1 + n_lines) + 63) & ~(uintptr_t)63);
         hipLaunchKernelGGL(k_frag_iota, dim3((n_lines + 255) / 256), dim3(256), 0, st, d_v0, n_lines);
-        int res = 0;
-        if ((s = radix_sort_pairs(d_key, d_v0, d_k1, d_v1, n_lines, 0, 16, ws, sort_ws, &res, st))) return s;
+        int res = 0, key_bits = 1;
+        while (key_bits < 32 && (no_key >> key_bits)) ++key_bits;
+        if ((s = radix_sort_pairs(d_key, d_v0, d_k1, d_v1, n_lines, 0, key_bits, ws, sort_ws, &res, st))) return s;
         const u32 *sk = res ? d_k1 : d_key, *sp = res ? d_v1 : d_v0;
-        hipLaunchKernelGGL(k_frag_cluster_offsets, dim3((n_clusters + 1 + 255) / 256), dim3(256), 0, st, sk, n_lines, n_clusters, d_coff);
-        const u32 *h_coff = (const u32 *)((char *)mailbox.p + mb_coff), *h_written = (const u32 *)((char *)mailbox.p + mb_written),
-                  *h_file_line = (const u32 *)((char *)mailbox.p + mb_fline);
-        GT_HIP(hipMemcpyAsync((void *)h_coff, d_coff, ((size_t)n_clusters + 1) * 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_frag_lower_bound, dim3(1), dim3(64), 0, st, sk, n_lines, no_key, d_coff);
+        const u32 *h_written = (const u32 *)((char *)mailbox.p + mb_written), *h_file_line = (const u32 *)((char *)mailbox.p + mb_fline);
+        GT_HIP(hipMemcpyAsync((void *)&mb_words[3], d_coff, 4, hipMemcpyDeviceToHost, st));
         GT_HIP(hipMemcpyAsync((void *)h_written, d_written, (size_t)n_files * 4, hipMemcpyDeviceToHost, st));
         GT_HIP(hipMemcpyAsync((void *)h_file_line, d_file_line, m1 * 4, hipMemcpyDeviceToHost, st));
         GT_HIP(hipMemcpyAsync((void *)&mb_words[1], d_err, 4, hipMemcpyDeviceToHost, st));
@@ -815,27 +839,24 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             out.first_error_file = h_err;
             return GTARS_OK;  // (the caller reports it)
         }
-        for (u32 c = 0; c <= n_clusters; ++c) out.coff[c] = h_coff[c];
-        const u32 n = h_coff[n_clusters];
+        const u32 n = mb_words[3];
         out.n = n;
-        if (!out.file.alloc((size_t)n + 1) || !out.slot.alloc((size_t)n + 1)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
-        out.cbase.assign((size_t)n_clusters + 1, 0);
         if (n) {
-            // cluster-major columns c | s | e | slot (u32 each), file (u16), then the token CSR
+            // columns c | s | e (u32 each) in (file, barcode) order, the token CSR, the emit pass's tables
             u64 cap = (u64)n * 2 + 1024, h = 0;  // ids: a guessed capacity, the fill pass when it was short
-            const size_t cols_bytes = (size_t)n * 4 * 4 + (size_t)n * 2 + 64 + ((size_t)n + 1) * 8 + ((size_t)n_clusters + 2) * 8 + (size_t)n + 64;
+            const u32 n_em = (n + EM_TPB - 1) / EM_TPB;
+            const size_t cols_bytes = (size_t)n * 4 * 3 + 64 + ((size_t)n + 1) * 8 + ((size_t)n_em + 1) * 2 * 4 + ((size_t)no_key + 1) * 2 * 4 + 64;
             Workspace &ws_out = tls_workspace(7, st);
             if ((s = ws_out.reserve(pad(cols_bytes) + pad(cap * 4) + 1024))) return s;
             Carve cout_{(char *)ws_out.ptr, 0};
             View d_outcols{cout_.take<char>(cols_bytes)};
             u32 *d_ids_ws = cout_.take<u32>(cap);
-            u32 *oc = d_outcols.as<u32>(), *os = oc + n, *oe = os + n, *oslot = oe + n;
-            u64 *d_off = reinterpret_cast<u64 *>(((uintptr_t)(oslot + n) + 7) & ~(uintptr_t)7);
-            u64 *d_cbase = d_off + n + 1;
-            unsigned short *ofile = reinterpret_cast<unsigned short *>(d_cbase + n_clusters + 1);
-            unsigned char *d_cnt8 = reinterpret_cast<unsigned char *>(ofile + n);
+            u32 *oc = d_outcols.as<u32>(), *os = oc + n, *oe = os + n;
+            u64 *d_off = reinterpret_cast<u64 *>(((uintptr_t)(oe + n) + 7) & ~(uintptr_t)7);
+            u32 *d_em_tot = reinterpret_cast<u32 *>(d_off + n + 1), *d_em_base = d_em_tot + n_em + 1;
+            u32 *d_run_start = d_em_base + n_em + 1, *d_run_line = d_run_start + no_key + 1;
             hipLaunchKernelGGL(k_frag_gather, dim3((n + 255) / 256), dim3(256), 0, st, sp, n, (const u32 *)d_qc, (const u32 *)d_qs,
-                               (const u32 *)d_qe, (const u32 *)d_qslot, (const u32 *)d_file_line, n_files, oc, os, oe, oslot, ofile);
+                               (const u32 *)d_qe, oc, os, oe);
             GT_HIP(hipGetLastError());
             GT_WAIT(st);
             const double t3 = now_s();
@@ -854,27 +875,28 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
             }
             const double t4 = now_s();
             out.t_tok = t4 - t3;
-            // (the results land in pinned blocks as well: one DMA each, no staging by the runtime)
-            if (!out.ids.alloc(std::max<u64>(h, 1)) || !out.cnt.alloc((size_t)n + 1)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
-            // the CSR as one byte per fragment + the clusters' bases (8-byte offsets only when a fragment has more than 255 ids)
-            GT_HIP(hipMemsetAsync(d_err, 0, 4, st));  // (reused as the "wide" flag)
-            hipLaunchKernelGGL(k_frag_counts8, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *)d_off, n, d_cnt8, d_err);
-            hipLaunchKernelGGL(k_frag_cluster_bases, dim3((n_clusters + 1 + 255) / 256), dim3(256), 0, st, (const u64 *)d_off, (const u32 *)d_coff,
-                               n_clusters, d_cbase);
-            GT_HIP(hipMemcpyAsync((void *)&mb_words[2], d_err, 4, hipMemcpyDeviceToHost, st));
-            GT_HIP(hipMemcpyAsync((char *)mailbox.p + mb_cbase, d_cbase, ((size_t)n_clusters + 1) * 8, hipMemcpyDeviceToHost, st));
-            GT_HIP(hipMemcpyAsync(out.file.get(), ofile, (size_t)n * 2, hipMemcpyDeviceToHost, st));
-            GT_HIP(hipMemcpyAsync(out.slot.get(), oslot, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-            if (h) GT_HIP(hipMemcpyAsync(out.ids.get(), d_ids_p, h * 4, hipMemcpyDeviceToHost, st));
-            GT_HIP(hipMemcpyAsync(out.cnt.get(), d_cnt8, (size_t)n, hipMemcpyDeviceToHost, st));  // (the common case, sent along unasked)
+            // ---- the ids regrouped by (file, barcode), the unk id where a fragment has none (k_frag_emit) ----
+            if (h + n >= 0xFFFFFFF0ull) return fail(GTARS_ERR_CAPACITY, "fragment wave: more than 4e9 token ids");  // (the caller: host parser)
+            Workspace &ws_ids = tls_workspace(9, st);
+            if ((s = ws_ids.reserve(pad((h + n) * 4) + 256))) return s;
+            u32 *d_ids2 = (u32 *)ws_ids.ptr;
+            hipLaunchKernelGGL(k_frag_emit_counts, dim3(n_em), dim3(EM_TPB), 0, st, (const u64 *)d_off, n, d_em_tot);
+            hipLaunchKernelGGL(k_frag_scan_chunks, dim3(1), dim3(1024), 0, st, (const u32 *)d_em_tot, n_em, d_em_base);
+            GT_HIP(hipMemsetAsync(d_run_start, 0xFF, ((size_t)no_key + 1) * 2 * 4, st));  // (run_start | run_line)
+            hipLaunchKernelGGL(k_frag_emit, dim3(n_em), dim3(EM_TPB), 0, st, (const u64 *)d_off, (const u32 *)d_ids_p, n, (const u32 *)d_em_base, sk, sp,
+                               unk_id, d_ids2, d_run_start, d_run_line);
+            GT_HIP(hipGetLastError());
+            GT_HIP(hipMemcpyAsync((void *)&mb_words[2], d_em_base + n_em, 4, hipMemcpyDeviceToHost, st));
+            if (!out.run_start.alloc((size_t)no_key + 1) || !out.run_line.alloc((size_t)no_key + 1)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+            GT_HIP(hipMemcpyAsync(out.run_start.get(), d_run_start, ((size_t)no_key + 1) * 4, hipMemcpyDeviceToHost, st));
+            GT_HIP(hipMemcpyAsync(out.run_line.get(), d_run_line, ((size_t)no_key + 1) * 4, hipMemcpyDeviceToHost, st));
             GT_WAIT(st);
-            memcpy(out.cbase.data(), (char *)mailbox.p + mb_cbase, ((size_t)n_clusters + 1) * 8);
-            const u32 wide = mb_words[2];
-            if (wide) {
-                out.cnt.reset();
-                if (!out.off.alloc((size_t)n + 1)) return fail(GTARS_ERR_INTERNAL, "out of host memory");
-                GT_HIP(hipMemcpy(out.off.get(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
-            }
+            const u32 n_ids = mb_words[2];
+            out.n_ids = n_ids;
+            // (the results land in pinned blocks: one DMA each, no staging by the runtime)
+            if (!out.ids.alloc(std::max<u32>(n_ids, 1))) return fail(GTARS_ERR_INTERNAL, "out of host memory");
+            GT_HIP(hipMemcpyAsync(out.ids.get(), d_ids2, (size_t)n_ids * 4, hipMemcpyDeviceToHost, st));
+            GT_WAIT(st);
             out.t_d2h = now_s() - t4;
         }
     }

@@ -2605,7 +2605,6 @@ struct TextFile {
     std::vector<gtars::FragGzMember> members;  // gzip members whose CRC-32 the device still has to check
     std::vector<gtars::FragSlot> slots;
     std::string keys;
-    std::vector<uint32_t> local;  // slot -> id of the barcode among its cluster's barcodes (first-seen order; filled at regroup)
     gtars_status st = GTARS_OK;
     std::string err;
 };
@@ -2645,7 +2644,6 @@ void load_text_file(const std::string &path, const gtars_barcode_map &m, TextFil
         out.slots[k] = gtars::FragSlot{(uint32_t)out.keys.size(), n, it->second, 0};
         out.keys.append(bc, n);
     }
-    out.local.assign(cap, 0xFFFFFFFFu);
 }
 
 // The files inflated by a pool of host threads that never waits for a wave to complete (round 5, second cut): threads take the
@@ -2887,13 +2885,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         bool device = false;
         size_t first_file = 0;
         std::vector<TextFile> tf;
-        gtars::HostArray<uint16_t> file;
-        gtars::HostArray<uint32_t> slot;
-        gtars::HostArray<uint8_t> cnt;  // ids per fragment, with cbase[c] = the cluster's first id, instead of `off` (FragWaveOut)
-        gtars::HostArray<uint64_t> doff;  // (the device wave's 8-byte offsets when a fragment has more than 255 ids)
-        gtars::HostArray<uint32_t> dids;  // the device wave's ids (`ids` points here)
-        const uint64_t *offs() const { return device ? doff.get() : off.get(); }
-        std::vector<uint64_t> cbase;
+        gtars::FragWaveOut dev;  // the device's answer: ids regrouped by (file, barcode), where every run starts, which line opens it
         uint64_t reads = 0;
         double td[5] = {0, 0, 0, 0, 0};
     };
@@ -2930,6 +2922,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
     std::condition_variable cv;
     std::deque<Wave *> jobs;
     bool closing = false;
+    bool device_overflow = false;  // a device wave with more than 4e9 ids
     size_t in_flight = 0;       // waves queued or on the device
     bool wave_failed = false;   // a wave ended with an error (the producer stops)
     auto tok_body = [&] {
@@ -2959,7 +2952,11 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                     in.push_back(x);
                 }
                 gtars::FragWaveOut o;
-                w->st = gtars::frag_wave_device(t->index, d_chroms, in, (uint32_t)nc, o);
+                w->st = gtars::frag_wave_device(t->index, d_chroms, in, (uint32_t)nc, t->unk_id, o);
+                if (w->st == GTARS_ERR_CAPACITY) {  // more ids than the device path's 32-bit positions: the whole call on the host parser
+                    std::lock_guard<std::mutex> lk(mu);
+                    device_overflow = true;
+                }
                 if (w->st) {
                     w->err = gtars_last_error();
                 } else if (o.first_error_file >= 0) {
@@ -2969,17 +2966,10 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                     w->st = again.st ? again.st : GTARS_ERR_INTERNAL;
                     w->err = again.st ? again.err : "fragment pipeline: the device parser rejected a line that the host parser accepts";
                 } else {
-                    w->coff = std::move(o.coff);
                     w->n = o.n;
-                    w->file = std::move(o.file);
-                    w->slot = std::move(o.slot);
-                    w->doff = std::move(o.off);
-                    w->cnt = std::move(o.cnt);
-                    w->cbase = std::move(o.cbase);
-                    w->dids = std::move(o.ids);
-                    w->ids = w->dids.get();
                     for (uint64_t r : o.n_reads) w->reads += r;
                     w->td[0] = o.t_h2d, w->td[1] = o.t_parse, w->td[2] = o.t_group, w->td[3] = o.t_tok, w->td[4] = o.t_d2h;
+                    w->dev = std::move(o);
                 }
                 for (TextFile &f : w->tf) f.data.release();  // the text is on the device (or no longer needed): the block back to the pool
             } else {
@@ -3101,6 +3091,11 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
     }
     const double t_split_done = now();
     finish_tokenizer();
+    if (device_overflow) {
+        free_waves();
+        *redo_on_host = true;
+        return fail(GTARS_ERR_INTERNAL, "fragment pipeline: a device wave with more than 4e9 token ids");
+    }
     for (Wave &w : waves)  // (in file order: a wave's error lies in front of whatever stopped the producer)
         if (w.st) {
             const gtars_status e = w.st;
@@ -3122,31 +3117,55 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
             }
     // every cluster regrouped by barcode: its fragments' ids wave after wave (= the cluster file's line order)
     auto **arr = (gtars_fragment_tokens_t **)calloc(nc ? nc : 1, sizeof(gtars_fragment_tokens_t *));
+    // Device waves arrive regrouped by (file, barcode) (FragWaveOut): what is left is, per cluster, the runs in the order their first
+    // lines appear -- wave after wave, and inside a wave by line number: the first-seen barcode order of one pass over the cluster's
+    // file -- a dictionary lookup per run (the same barcode string of several files is ONE barcode of the cluster) and a copy per run.
+    struct Run {
+        uint32_t wave, line, file, slot, start, len;
+    };
+    std::vector<std::vector<Run>> runs(device_path ? nc : 0);
+    if (device_path) {
+        uint32_t wi = 0;
+        for (Wave &w : waves) {
+            const gtars::FragWaveOut &o = w.dev;
+            if (o.n) {
+                const uint32_t total = o.slot_off.back();
+                size_t pc = nc, pi = 0;  // the previous present run (the runs lie in slot order: one ends where the next one starts)
+                for (uint32_t f = 0; f + 1 < (uint32_t)o.slot_off.size(); ++f)
+                    for (uint32_t g = o.slot_off[f]; g < o.slot_off[f + 1]; ++g) {
+                        const uint32_t st0 = o.run_start[g];
+                        if (st0 == 0xFFFFFFFFu) continue;
+                        if (pc < nc) runs[pc][pi].len = st0 - runs[pc][pi].start;
+                        const uint32_t c = w.tf[f].slots[g - o.slot_off[f]].value;
+                        runs[c].push_back(Run{wi, o.run_line[g], f, g - o.slot_off[f], st0, 0});
+                        pc = c, pi = runs[c].size() - 1;
+                    }
+                (void)total;
+                if (pc < nc) runs[pc][pi].len = (uint32_t)o.n_ids - runs[pc][pi].start;
+            }
+            ++wi;
+        }
+    }
+    std::vector<Wave *> wave_at;
+    for (Wave &w : waves) wave_at.push_back(&w);
     over_clusters([&](size_t c) {
         Cluster &k = cl[c];
         std::vector<uint64_t> cnt;
         uint64_t i = 0;
+        std::vector<uint32_t> run_id;
         if (device_path) {
-            // device waves: the cluster-level barcode ids of the fragments -- first-seen order over the waves, i.e. over the files in
-            // order and the lines in order, what one pass over the cluster's file would see -- and the ids per barcode, in ONE pass.
-            // A barcode belongs to one cluster, so the clusters' threads touch different slots of the files' tables.
-            uint64_t total = 0;
-            for (Wave &w : waves) total += w.coff[c + 1] - w.coff[c];
-            k.b.reserve((size_t)total);
+            std::vector<Run> &rc = runs[c];
+            std::sort(rc.begin(), rc.end(), [](const Run &a, const Run &b) { return a.wave != b.wave ? a.wave < b.wave : a.line < b.line; });
+            run_id.resize(rc.size());
             std::vector<uint64_t> per;
-            for (Wave &w : waves)
-                for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r) {
-                    TextFile &f = w.tf[w.file[r]];
-                    uint32_t &id = f.local[w.slot[r]];
-                    if (id == 0xFFFFFFFFu) {
-                        const gtars::FragSlot &sl = f.slots[w.slot[r]];
-                        id = k.barcodes.get_or_add(f.keys.data() + sl.off, sl.len);
-                        if (id >= per.size()) per.resize((size_t)id + 1, 0);
-                    }
-                    k.b.push_back(id);
-                    const uint64_t hits = w.cnt ? w.cnt[r] : w.offs()[r + 1] - w.offs()[r];
-                    per[id] += hits ? hits : 1;  // a fragment without hits contributes one unk id
-                }
+            for (size_t r = 0; r < rc.size(); ++r) {
+                const TextFile &f = wave_at[rc[r].wave]->tf[rc[r].file];
+                const gtars::FragSlot &sl = f.slots[rc[r].slot];
+                const uint32_t id = k.barcodes.get_or_add(f.keys.data() + sl.off, sl.len);
+                if (id >= per.size()) per.resize((size_t)id + 1, 0);
+                per[id] += rc[r].len;
+                run_id[r] = id;
+            }
             cnt.assign(per.size() + 1, 0);
             for (size_t b = 0; b < per.size(); ++b) cnt[b + 1] = per[b];
         }
@@ -3155,7 +3174,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
             cnt.assign(nb + 1, 0);
             for (Wave &w : waves)
                 for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
-                    const uint64_t hits = w.cnt ? w.cnt[r] : w.offs()[r + 1] - w.offs()[r];
+                    const uint64_t hits = w.off[r + 1] - w.off[r];
                     cnt[k.b[i] + 1] += hits ? hits : 1;  // a fragment without hits contributes one unk id
                 }
         }
@@ -3168,19 +3187,25 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         memcpy(ft->offsets, cnt.data(), (nb + 1) * sizeof(uint64_t));
         for (uint64_t b = 0; b < nb; ++b) ft->barcodes[b] = dup_cstr(k.barcodes.names[b]);
         std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
+        if (device_path) {
+            // (a barcode's runs in (wave, line) order = file order: the fragments of a cluster lie file after file)
+            const std::vector<Run> &rc = runs[c];
+            for (size_t r = 0; r < rc.size(); ++r) {
+                uint64_t &at = fill[run_id[r]];
+                memcpy(ft->ids + at, wave_at[rc[r].wave]->dev.ids.get() + rc[r].start, (size_t)rc[r].len * sizeof(uint32_t));
+                at += rc[r].len;
+            }
+            arr[c] = ft;
+            return;
+        }
         i = 0;
         for (Wave &w : waves) {
-            uint64_t x = w.cnt ? w.cbase[c] : 0;  // (device waves: the ids of the cluster's fragments follow one another from here)
             for (uint64_t r = w.coff[c]; r < w.coff[c + 1]; ++r, ++i) {
                 uint64_t &at = fill[k.b[i]];
-                if (w.cnt) {
-                    const uint64_t hits = w.cnt[r];
-                    if (!hits) ft->ids[at++] = t->unk_id;
-                    for (uint64_t e = x + hits; x < e; ++x) ft->ids[at++] = w.ids[x];
-                } else if (w.offs()[r + 1] == w.offs()[r]) {
+                if (w.off[r + 1] == w.off[r]) {
                     ft->ids[at++] = t->unk_id;
                 } else {
-                    for (uint64_t y = w.offs()[r]; y < w.offs()[r + 1]; ++y) ft->ids[at++] = w.ids[y];
+                    for (uint64_t y = w.off[r]; y < w.off[r + 1]; ++y) ft->ids[at++] = w.ids[y];
                 }
             }
         }
