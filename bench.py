@@ -651,16 +651,16 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
         from gtars_amd import _lib as L_
         sg = (C_.c_double * 12)()
         L_.lib.gtars_fragsplit_last_stages(C_.cast(sg, C_.c_void_p))
-        stages = {"text_parsed_on": "device (fragparse.hip: line split, fields, barcode and chromosome lookup, grouping by cluster)" if sg[0]
+        stages = {"text_parsed_on": "device (fragparse.hip: line split, fields, barcode and chromosome lookup, tokenization, ids regrouped by (file, barcode), gzip CRC-32)" if sg[0]
                   else "host threads", "waves": int(sg[1]),
                   "host_read_inflate_s" if sg[0] else "host_read_inflate_parse_route_s": round(sg[2], 4),
-                  "device_waves_s" if sg[0] else "tokenizer_calls_s": round(sg[4], 4), "of_which_behind_the_last_wave_s": round(sg[5], 4),
-                  "regroup_by_barcode_s": round(sg[6], 4)}
+                  "device_waves_s_summed_over_the_device_threads" if sg[0] else "tokenizer_calls_s": round(sg[4], 4),
+                  "of_which_behind_the_last_wave_s": round(sg[5], 4), "regroup_by_barcode_host_share_s" if sg[0] else "regroup_by_barcode_s": round(sg[6], 4)}
         if sg[0]:
             stages.update({"device_text_in_s": round(sg[7], 4), "device_split_parse_sort_s": round(sg[8], 4), "device_gather_s": round(sg[9], 4),
-                           "device_tokenize_s": round(sg[10], 4), "device_results_out_s": round(sg[11], 4),
+                           "device_tokenize_s": round(sg[10], 4), "device_regroup_and_results_out_s": round(sg[11], 4),
                            "note": "the host threads only read and inflate (csrc/inflate_fast.h, into pinned memory); everything else of split.rs:84-131 / fragments.rs:12-56 runs on "
-                                   "the GPU while the next wave inflates; the call's floor is the inflate time on the box's usable host threads"})
+                                   "the GPU (two device threads, a stream each) while the next files inflate; the call's floor is the inflate time on the box's usable host threads"})
         else:
             stages["host_per_cluster_append_s"] = round(sg[3], 4)
         ids_two = sum(sum(len(v) for v in d.values()) for d in res2)
