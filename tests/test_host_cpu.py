@@ -551,3 +551,25 @@ def test_whole_buffer_inflate_decodes_what_zlib_writes(tmp_path, monkeypatch, de
     finally:
         monkeypatch.delenv("GTARS_ZLIB_INFLATE", raising=False)
         _lib.lib.gtars_debug_reload_env()
+
+
+def test_inflate_decoder_under_the_sanitizers(tmp_path):
+    """tests/soak/fuzz_inflate.cpp, a short run, built with AddressSanitizer + UBSan (the GPU pool has no sanitizers: the decoder is
+    host code, so it is checked here): random data kinds x zlib level / strategy / window / memory level / flush points decode
+    bit-exact, and damaged streams (flipped bits, cut tails) never take the decoder out of its buffers."""
+    import shutil
+    import subprocess
+
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        pytest.skip("no host C++ compiler")
+    exe = tmp_path / "fuzz_inflate"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "soak", "fuzz_inflate.cpp")
+    build = subprocess.run([cxx, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe), src, "-lz"],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("the host compiler has no sanitizer runtime")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe), "250", "77"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
+    assert "decoded bit-exact" in run.stdout
