@@ -641,7 +641,7 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
         fragsplit_tokenize(fd, m, tok, as_arrays=True)  # warm-up (device buffers)
         t_runs = []
         fused = None
-        for _ in range(3):
+        for _ in range(7):
             fused = None  # (the previous call's result is released outside the timed region: its arrays are views of C memory)
             t = time.perf_counter(); fused = fragsplit_tokenize(fd, m, tok, as_arrays=True); t_runs.append(time.perf_counter() - t)
         t_fused = statistics.median(t_runs)
@@ -674,7 +674,7 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
                "two_step": {"fragsplit_s": round(t_split, 3), "tokenize_cluster_files_s": round(t_tok, 3),
                             "fragments_per_s": round(n / (t_split + t_tok))},
                "fused": {"s": round(t_fused, 4), "fragments_per_s": round(n / t_fused), "runs_s": [round(x, 4) for x in t_runs],
-                         "timing": "median of 3 calls from Python, result conversion included", "stages_of_the_last_call": stages},
+                         "timing": "median of 7 calls from Python, result conversion included", "stages_of_the_last_call": stages},
                "value": n / t_fused, "unit": "fragments/s end to end (fused route + tokenize)"}
         if ids_two != ids_fused:
             raise SystemExit("bench.py: fragsplit_config5: fused and two-step pipelines disagree")
