@@ -62,3 +62,15 @@ def read_fragments(path: str):
         }
     finally:
         _lib.lib.gtars_fragments_free(h)
+
+
+def read_file(path: str) -> bytes:
+    """The bytes of ``path``, gunzipped iff its extension is ``gz`` -- the reader every file front end of the library goes
+    through (``get_dynamic_reader``, gtars-core/src/utils.rs:115-126: flate2's MultiGzDecoder behind the extension): concatenated
+    members one after the other, every member's CRC-32 and length checked, a ".gz" without the gzip magic as it is."""
+    p, n = C.c_void_p(), C.c_uint64()
+    check(lib.gtars_read_file(str(path).encode(), C.byref(p), C.byref(n)))
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        lib.gtars_free(p)

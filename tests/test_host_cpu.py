@@ -469,16 +469,9 @@ def test_gzip_reader_follows_the_multi_member_decoder(tmp_path):
 
 
 def _read_file(path):
-    import ctypes as C
+    from gtars_amd import utils
 
-    from gtars_amd import _lib
-
-    out, n = C.c_void_p(), C.c_uint64()
-    _lib.check(_lib.lib.gtars_read_file(str(path).encode(), C.byref(out), C.byref(n)))
-    try:
-        return C.string_at(out, n.value)
-    finally:
-        _lib.lib.gtars_free(out)
+    return utils.read_file(path)
 
 
 @pytest.mark.parametrize("decoder", ["fast", "zlib"])
