@@ -31,6 +31,9 @@ namespace {
 constexpr int FP_TPB = 256;
 constexpr u32 FP_BYTES = 64;                  // text bytes per lane
 constexpr u32 FP_CHUNK = FP_TPB * FP_BYTES;   // ... per workgroup
+#ifndef GTARS_FRAG_PARSE_GLOBAL
+#define GTARS_FRAG_PARSE_GLOBAL 0  // 1: k_frag_parse reads its lines in global memory (A/B build)
+#endif
 constexpr u32 NO_CLUSTER = 0xFFFFu;           // sort key of a line that is not tokenized (clusters are < 65535)
 
 // 0x80 in every byte of v that equals '\n'
@@ -116,13 +119,29 @@ __global__ void k_frag_file_lines(const u32 *__restrict__ line_end, u32 n_lines,
 
 __device__ __forceinline__ bool dev_is_ws(unsigned char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); }  // isspace(), C locale
 
+// The text is read through a READER rd(p) = byte p: the workgroup's piece of the text staged in LDS (ds_read_u8), or global memory.
+// (Not one generic pointer for both: flat loads that land in LDS cost several times what the LDS instructions do.)
+typedef u32 u32_a1 __attribute__((aligned(1)));  // (a 4-byte load at any address: gfx950 takes unaligned global and LDS accesses)
+struct GlobalBytes {
+    const unsigned char *t;
+    __device__ __forceinline__ unsigned char operator()(u32 p) const { return t[p]; }
+    __device__ __forceinline__ u32 word(u32 p) const { return *reinterpret_cast<const u32_a1 *>(t + p); }
+};
+struct LdsBytes {
+    const unsigned char *t;  // (a __shared__ array: the compiler keeps the address space through the inlined calls)
+    u32 rel;
+    __device__ __forceinline__ unsigned char operator()(u32 p) const { return t[p - rel]; }
+    __device__ __forceinline__ u32 word(u32 p) const { return *reinterpret_cast<const u32_a1 *>(t + (p - rel)); }
+};
+
 // str::parse::<u32>(): optional '+', ASCII digits, must fit
-__device__ __forceinline__ bool dev_parse_u32(const unsigned char *p, u32 n, u32 &out) {
-    u32 i = (n && p[0] == '+') ? 1u : 0u;
+template <class R>
+__device__ __forceinline__ bool dev_parse_u32(const R &rd, u32 p, u32 n, u32 &out) {
+    u32 i = (n && rd(p) == '+') ? 1u : 0u;
     if (i >= n) return false;
     u64 v = 0;
     for (; i < n; ++i) {
-        const u32 d = (u32)p[i] - '0';
+        const u32 d = (u32)rd(p + i) - '0';
         if (d > 9) return false;
         v = v * 10 + d;
         if (v > 0xFFFFFFFFull) return false;
@@ -131,26 +150,33 @@ __device__ __forceinline__ bool dev_parse_u32(const unsigned char *p, u32 n, u32
     return true;
 }
 
-__device__ __forceinline__ u32 dev_hash(const unsigned char *p, u32 n) {  // frag_hash (frag_device.h)
+template <class R>
+__device__ __forceinline__ u32 dev_hash(const R &rd, u32 p, u32 n) {  // frag_hash (frag_device.h)
     u32 h = 2166136261u;
-    for (u32 i = 0; i < n; ++i) h = (h ^ p[i]) * 16777619u;
+    for (u32 i = 0; i < n; ++i) h = (h ^ rd(p + i)) * 16777619u;
     return h ^ (h >> 15);
 }
 
-// slot of key [p, p + n) in an open-addressing table, or 0xFFFFFFFF
-__device__ __forceinline__ u32 table_find(const FragSlot *__restrict__ slots, u32 n_slots, const unsigned char *__restrict__ blob,
-                                          const unsigned char *p, u32 n) {
+// slot of key [p, p + n) of the text in an open-addressing table, or 0xFFFFFFFF
+template <class R>
+__device__ __forceinline__ u32 table_find(const FragSlot *__restrict__ slots, u32 n_slots, const unsigned char *__restrict__ blob, const R &rd,
+                                          u32 p, u32 n) {
     if (!n) return 0xFFFFFFFFu;
     const u32 mask = n_slots - 1u;
-    u32 k = dev_hash(p, n) & mask;
+    u32 k = dev_hash(rd, p, n) & mask;
     for (u32 probes = 0; probes < n_slots; ++probes) {
         const FragSlot s = slots[k];
         if (!s.len) return 0xFFFFFFFFu;
         if (s.len == n) {
+            // four bytes at a time (both sides are readable a word past the key: the blob and the text are padded); a byte-wise
+            // compare is a chain of dependent L2 loads, one per byte of the barcode
             const unsigned char *q = blob + s.off;
-            u32 i = 0;
-            while (i < n && q[i] == p[i]) ++i;
-            if (i == n) return k;
+            bool same = true;
+            for (u32 i = 0; same && i < n; i += 4) {
+                const u32 left = n - i, m = left >= 4 ? 0xFFFFFFFFu : (1u << (8u * left)) - 1u;
+                same = ((*reinterpret_cast<const u32_a1 *>(q + i) ^ rd.word(p + i)) & m) == 0u;
+            }
+            if (same) return k;
         }
         k = (k + 1u) & mask;
     }
@@ -172,65 +198,111 @@ struct FragTables {
 __global__ void __launch_bounds__(FP_TPB)
 k_frag_parse(const unsigned char *__restrict__ text, const u32 *__restrict__ line_end, u32 n_lines, const u32 *__restrict__ file_line,
              u32 n_files, FragTables tb, u32 no_key, u32 *__restrict__ key, u32 *__restrict__ q_chrom, u32 *__restrict__ q_start,
-             u32 *__restrict__ q_end, u32 *__restrict__ n_written, u32 *__restrict__ err_file) {
+             u32 *__restrict__ q_end, u32 *__restrict__ n_written, u32 *__restrict__ wg_written, u32 *__restrict__ err_file) {
+    // The workgroup's 256 lines are one contiguous piece of the text (~11 KB): it is brought into LDS by 16-byte loads, every lane
+    // 16 consecutive bytes, and the lanes parse their lines THERE -- a lane that walks its line byte by byte in global memory
+    // makes every byte a wave instruction over 64 different cache lines (310 us per 0.7M lines before: 100 GB/s of text).  A piece
+    // larger than the buffer (very long lines) is parsed where it lies.  The pointer `tp` is a generic one.
+    constexpr u32 PARSE_LDS = 32u << 10;
+    __shared__ uint4 s_text4[PARSE_LDS / 16];
+    const u32 first = blockIdx.x * FP_TPB, last = min(first + (u32)FP_TPB, n_lines) - 1u;  // (the grid covers n_lines: first <= last)
+    const u32 span_lo = first ? line_end[first - 1] + 1u : 0u, span_hi = line_end[last] + 1u, base = span_lo & ~15u;
+    const bool staged = span_hi - base <= PARSE_LDS && !(GTARS_FRAG_PARSE_GLOBAL);  // (uniform)
+    if (staged) {
+        for (u32 o = threadIdx.x * 16u; o < span_hi - base; o += FP_TPB * 16u)  // (the text buffer is padded: a whole last vector)
+            s_text4[o >> 4] = *reinterpret_cast<const uint4 *>(text + base + o);
+        __syncthreads();
+    }
+    __shared__ u32 s_written;
+    if (threadIdx.x == 0) s_written = 0;
     const u32 i = blockIdx.x * FP_TPB + threadIdx.x;
-    if (i >= n_lines) return;
-    const u32 lo = i ? line_end[i - 1] + 1u : 0u, hi = line_end[i];
-    // the line's file: last f with file_line[f] <= i
-    u32 f = 0;
-    {
+    const bool valid = i < n_lines;
+    const u32 il = valid ? i : n_lines - 1u;  // (lanes behind the last line read its bounds and do nothing)
+    const u32 lo = il ? line_end[il - 1] + 1u : 0u, hi = valid ? line_end[il] : lo;
+    // the line's file: last f with file_line[f] <= i -- for the workgroup's first line (uniform: scalar loads), which is every
+    // line's file unless a file ends inside the workgroup's lines
+    auto file_of = [&](u32 line) {
         u32 a = 0, b = n_files;
         while (a + 1 < b) {
             const u32 mid = (a + b) >> 1;
-            if (file_line[mid] <= i)
+            if (file_line[mid] <= line)
                 a = mid;
             else
                 b = mid;
         }
-        f = a;
-    }
-    u32 fs[5], fl[5], nf = 0, p = lo;
-    while (p < hi && nf < 5) {
-        while (p < hi && dev_is_ws(text[p])) ++p;
-        const u32 st = p;
-        while (p < hi && !dev_is_ws(text[p])) ++p;
-        if (p > st) {
-            fs[nf] = st;
-            fl[nf] = p - st;
-            ++nf;
-        }
-    }
+        return a;
+    };
+    u32 f = file_of(first);
+    const bool one_file = f + 1 >= n_files || file_line[f + 1] > last;  // (uniform)
+    if (!one_file) f = file_of(il);
     u32 k = no_key;
-    bool bad = nf < 5, written = false;  // fewer than five fields: "Failed to parse fragments file at line ..." (routed or not)
-    if (!bad) {
-        const u32 so = tb.slot_off[f], ns = tb.slot_off[f + 1] - so;
-        const u32 slot = table_find(tb.slots + so, ns, tb.keys + tb.key_off[f], text + fs[3], fl[3]);
-        if (slot != 0xFFFFFFFFu) {  // else: most likely a cell dropped in QC -- nothing else of the line is looked at
-            written = true;
-            if (text[fs[0]] != '#') {  // (the cluster file's reader skips '#' lines: fragments.rs:70-73)
-                u32 s = 0, e = 0;
-                if (!dev_parse_u32(text + fs[1], fl[1], s) || !dev_parse_u32(text + fs[2], fl[2], e)) {
-                    bad = true;
-                } else {
-                    const u32 cs = table_find(tb.chrom_slots, tb.n_chrom_slots, tb.chrom_keys, text + fs[0], fl[0]);
-                    k = so + slot;
-                    q_chrom[i] = cs == 0xFFFFFFFFu ? GTARS_UNKNOWN_CHROM : tb.chrom_slots[cs].value;
-                    q_start[i] = s;
-                    q_end[i] = e;
-                }
+    bool bad = false, written = false;
+    auto parse = [&](const auto &rd) {
+        u32 fs[5], fl[5], nf = 0, p = lo;
+        while (p < hi && nf < 5) {
+            while (p < hi && dev_is_ws(rd(p))) ++p;
+            const u32 st = p;
+            while (p < hi && !dev_is_ws(rd(p))) ++p;
+            if (p > st) {
+                fs[nf] = st;
+                fl[nf] = p - st;
+                ++nf;
             }
         }
+        bad = nf < 5;  // fewer than five fields: "Failed to parse fragments file at line ..." (routed or not)
+        if (bad) return;
+        const u32 so = tb.slot_off[f], ns = tb.slot_off[f + 1] - so;
+        const u32 slot = table_find(tb.slots + so, ns, tb.keys + tb.key_off[f], rd, fs[3], fl[3]);
+        if (slot == 0xFFFFFFFFu) return;  // most likely a cell dropped in QC -- nothing else of the line is looked at
+        written = true;
+        if (rd(fs[0]) == '#') return;  // (the cluster file's reader skips '#' lines: fragments.rs:70-73)
+        u32 s = 0, e = 0;
+        if (!dev_parse_u32(rd, fs[1], fl[1], s) || !dev_parse_u32(rd, fs[2], fl[2], e)) {
+            bad = true;
+            return;
+        }
+        const u32 cs = table_find(tb.chrom_slots, tb.n_chrom_slots, tb.chrom_keys, rd, fs[0], fl[0]);
+        k = so + slot;
+        q_chrom[i] = cs == 0xFFFFFFFFu ? GTARS_UNKNOWN_CHROM : tb.chrom_slots[cs].value;
+        q_start[i] = s;
+        q_end[i] = e;
+    };
+    if (valid) {
+        if (staged)
+            parse(LdsBytes{reinterpret_cast<const unsigned char *>(s_text4), base});
+        else
+            parse(GlobalBytes{text});
     }
-    key[i] = k;
+    if (valid) key[i] = k;
     if (bad) atomicMin(err_file, f);
-    // routed lines per file: one atomic per wave when the wave's lines share a file (they nearly always do)
-    const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)f);
-    if (__all(f == f0)) {
+    // Routed lines per file.  A workgroup whose lines share a file (nearly all do) leaves ONE number, in its own word -- summed per
+    // file by k_frag_sum_written; one atomic per wave on the file's counter was 12 500 atomics per batch on two or three addresses,
+    // which the L2 serves one after the other: 170 of the kernel's 173 us.
+    if (one_file) {
         const u64 m = __ballot(written);
-        if (m && (threadIdx.x & 63) == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&n_written[f0], (u32)__popcll(m));
-    } else if (written) {
-        atomicAdd(&n_written[f], 1u);
+        __syncthreads();  // s_written is zero
+        if (m && (threadIdx.x & 63) == 0) atomicAdd(&s_written, (u32)__popcll(m));
+        __syncthreads();
+        if (threadIdx.x == 0) wg_written[blockIdx.x] = s_written;
+    } else {
+        if (threadIdx.x == 0) wg_written[blockIdx.x] = 0;
+        if (written) atomicAdd(&n_written[f], 1u);
     }
+}
+
+// n_written[f] += the counts of the workgroups of k_frag_parse whose first line lies in file f (a workgroup that spans files left 0
+// and counted by atomics)
+__global__ void __launch_bounds__(256)
+k_frag_sum_written(const u32 *__restrict__ wg_written, const u32 *__restrict__ file_line, u32 n_files, u32 *__restrict__ n_written) {
+    __shared__ u32 s_scan[4];
+    const u32 f = blockIdx.x;
+    if (f >= n_files) return;
+    const u32 w0 = (file_line[f] + FP_TPB - 1) / FP_TPB, w1 = (file_line[f + 1] + FP_TPB - 1) / FP_TPB;
+    u32 sum = 0;
+    for (u32 w = w0 + threadIdx.x; w < w1; w += 256) sum += wg_written[w];
+    u32 total;
+    (void)block_exclusive_scan<256>(sum, s_scan, total);
+    if (threadIdx.x == 0 && total) atomicAdd(&n_written[f], total);
 }
 
 __global__ void k_frag_iota(u32 *__restrict__ p, u32 n) {
@@ -797,9 +869,12 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
     if (n_lines) {
         const size_t sort_ws = radix_sort_ws_bytes(n_lines);
         Workspace &ws_ln = tls_workspace(6, st);
-        if ((s = ws_ln.reserve(pad((size_t)n_lines * 4) + pad((size_t)n_lines * 4 * 5) + pad((size_t)n_lines * 4 * 3 + sort_ws + 64) + 1024))) return s;
+        if ((s = ws_ln.reserve(pad((size_t)n_lines * 4) + pad((size_t)n_lines * 4 * 5) + pad((size_t)n_lines * 4 * 3 + sort_ws + 64) +
+                               pad(((size_t)n_lines / FP_TPB + 2) * 4) + 1024)))
+            return s;
         Carve cln{(char *)ws_ln.ptr, 0};
         View d_lines{cln.take<u32>(n_lines)}, d_cols{cln.take<u32>((size_t)n_lines * 5)}, d_sort{cln.take<char>((size_t)n_lines * 4 * 3 + sort_ws + 64)};
+        u32 *d_wg_written = cln.take<u32>((size_t)n_lines / FP_TPB + 2);
         u32 *d_line_end = d_lines.as<u32>();
         hipLaunchKernelGGL(k_frag_lines<true>, dim3(n_chunks), dim3(FP_TPB), 0, st, d_text.as<u32>(), n_bytes, (u32 *)nullptr, (const u32 *)d_base,
                            d_line_end);
@@ -810,8 +885,10 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         FragTables tb{d_slots.as<FragSlot>(), d_keys.as<unsigned char>(), d_slot_off, d_key_off, chroms->slots.as<FragSlot>(),
                       chroms->keys.as<unsigned char>(), chroms->n_slots};
         const u32 no_key = (u32)total_slots;  // (< 2^32: the tables of a wave's files are 16 bytes a slot, of < 4 GiB of text)
-        hipLaunchKernelGGL(k_frag_parse, dim3((n_lines + FP_TPB - 1) / FP_TPB), dim3(FP_TPB), 0, st, d_text.as<unsigned char>(),
-                           (const u32 *)d_line_end, n_lines, (const u32 *)d_file_line, n_files, tb, no_key, d_key, d_qc, d_qs, d_qe, d_written, d_err);
+        const u32 n_parse_wg = (n_lines + FP_TPB - 1) / FP_TPB;
+        hipLaunchKernelGGL(k_frag_parse, dim3(n_parse_wg), dim3(FP_TPB), 0, st, d_text.as<unsigned char>(), (const u32 *)d_line_end, n_lines,
+                           (const u32 *)d_file_line, n_files, tb, no_key, d_key, d_qc, d_qs, d_qe, d_written, d_wg_written, d_err);
+        hipLaunchKernelGGL(k_frag_sum_written, dim3(n_files), dim3(256), 0, st, (const u32 *)d_wg_written, (const u32 *)d_file_line, n_files, d_written);
         GT_HIP(hipGetLastError());
         // ---- the lines by (file, barcode) (stable: line order inside a barcode), the tokenized ones in front ----
         u32 *d_v0 = d_sort.as<u32>(), *d_k1 = d_v0 + n_lines, *d_v1 = d_k1 + n_lines;
