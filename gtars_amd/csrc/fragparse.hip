@@ -440,9 +440,20 @@ k_crc_chunks(const unsigned char *__restrict__ text, const CrcMember *__restrict
     for (; i < n; ++i) s = s_t[(s ^ p[i]) & 0xFFu] ^ (s >> 8);
     part[c] = s;
 }
+// the three tables in LDS: the folds below are chains of dependent table lookups (64 / ~140 steps a lane), an L2 round trip each
+// when the tables lie in global memory
+__device__ __forceinline__ const CrcTables *crc_tables_to_lds(const CrcTables *__restrict__ tb, CrcTables *s_tb) {
+    const u32 *src = reinterpret_cast<const u32 *>(tb);
+    u32 *dst = reinterpret_cast<u32 *>(s_tb);
+    for (u32 w = threadIdx.x; w < sizeof(CrcTables) / 4; w += blockDim.x) dst[w] = src[w];
+    __syncthreads();
+    return s_tb;
+}
 // (2) f(0, group) for every group of <= 64 chunks of a member
-__global__ void k_crc_groups(const CrcMember *__restrict__ mem, u32 n_mem, u32 n_groups, const CrcTables *__restrict__ tb, const u32 *__restrict__ part,
+__global__ void k_crc_groups(const CrcMember *__restrict__ mem, u32 n_mem, u32 n_groups, const CrcTables *__restrict__ tb_g, const u32 *__restrict__ part,
                              u32 *__restrict__ gpart) {
+    __shared__ CrcTables s_tb;
+    const CrcTables *tb = crc_tables_to_lds(tb_g, &s_tb);
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     u32 lo = 0, hi = n_mem;
@@ -463,8 +474,10 @@ __global__ void k_crc_groups(const CrcMember *__restrict__ mem, u32 n_mem, u32 n
     gpart[g] = s;
 }
 // (3) the member's CRC against its trailer; the first file (wave order) with a mismatch is noted
-__global__ void k_crc_members(const CrcMember *__restrict__ mem, u32 n_mem, const CrcTables *__restrict__ tb, const u32 *__restrict__ gpart,
+__global__ void k_crc_members(const CrcMember *__restrict__ mem, u32 n_mem, const CrcTables *__restrict__ tb_g, const u32 *__restrict__ gpart,
                               u32 *__restrict__ err_file) {
+    __shared__ CrcTables s_tb;
+    const CrcTables *tb = crc_tables_to_lds(tb_g, &s_tb);
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_mem) return;
     const CrcMember m = mem[i];
