@@ -212,15 +212,27 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
             unsigned short *__restrict__ key, u32 *__restrict__ table, u32 *__restrict__ tot, const u32 *__restrict__ run_if,
             u32 *__restrict__ ctot, u32 cshift, const u32 *__restrict__ route_kq, IgdView v, const u32 *__restrict__ tile_first,
             const u32 *__restrict__ tile_cnt, const u32 *__restrict__ tile_chrom, const u32 *__restrict__ cq_off, u32 *__restrict__ ql,
-            u32 *__restrict__ qh, HeavyBins heavy) {
+            u32 *__restrict__ qh, HeavyBins heavy, u32 n_sets_io) {
     if (run_if && *run_if == 0) {
         // the batch is in owner order (the order check in front of this kernel): nothing to route, the sweep takes it as it lies --
         // and this launch computes the tiles' query ranges instead (what k_igd_tile_ranges did in a launch of its own)
         // (tile t goes to workgroup t mod grid: the binary searches are chains of dependent loads, so they want to be spread
         // over every CU's memory path rather than packed into the first few workgroups)
-        if (ql)
-            for (u32 t = threadIdx.x * gridDim.x + blockIdx.x; t < n_tiles; t += gridDim.x * RT_TPB)
-                igd_tile_range_one<true>(v, tile_first, tile_cnt, tile_chrom, t, qs, cq_off, ql, qh, heavy);
+        // (several sets in order: one row of ranges per set -- stride n_tiles -- from that set's chromosome offsets; no heavy-tile
+        // parts there: a part is a range of ONE list of queries)
+        if (ql) {
+            if (n_sets_io <= 1) {
+                for (u32 t = threadIdx.x * gridDim.x + blockIdx.x; t < n_tiles; t += gridDim.x * RT_TPB)
+                    igd_tile_range_one<true>(v, tile_first, tile_cnt, tile_chrom, t, qs, cq_off, ql, qh, heavy);
+            } else {
+                // (a thread per (tile, set): the searches are chains of dependent loads -- the sets side by side, not one after the other)
+                for (u32 x = threadIdx.x * gridDim.x + blockIdx.x; x < n_tiles * n_sets_io; x += gridDim.x * RT_TPB) {
+                    const u32 k = x / n_tiles, t = x - k * n_tiles;
+                    igd_tile_range_one<true>(v, tile_first, tile_cnt, tile_chrom, t, qs, cq_off + k * (n_chrom + 2u), ql + (size_t)k * n_tiles,
+                                             qh + (size_t)k * n_tiles, HeavyBins{});
+                }
+            }
+        }
         return;
     }
     extern __shared__ u32 rt_lds[];
@@ -467,15 +479,23 @@ k_igd_call_init(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restr
     }
 }
 
+// Row ranges of a batch of several query sets (gtars_igd_count_sets): set k = rows [lo(k), hi(k)).  n = 1: the whole batch.
+constexpr u32 IGD_MAX_SETS = 4;
+struct SetRows {
+    u32 n = 1, b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu, b3 = 0xFFFFFFFFu, nq = 0;
+    __host__ __device__ u32 lo(u32 k) const { return k == 0 ? 0u : min(k == 1 ? b1 : k == 2 ? b2 : b3, nq); }
+    __host__ __device__ u32 hi(u32 k) const { return k + 1 >= n ? nq : lo(k + 1); }
+    __host__ __device__ u32 of(u32 row) const { return (row >= b1 ? 1u : 0u) + (row >= b2 ? 1u : 0u) + (row >= b3 ? 1u : 0u); }
+};
 constexpr int ORD_TPB = 256;
 // Start of a call on the partition path, ONE launch (round 3: k_igd_call_init + k_igd_order_check; a launch costs ~5 us): every thread
 // zeroes its words of the result vector and of the split's totals / cursors, workgroup 0 the next call's flag and the heavy-tile
 // count; then the order check -- a workgroup leaves as soon as it (or anybody) has seen disorder: no probe launch in front.
-template <bool VEC>
+template <bool VEC, bool MS = false>  // MS: several query sets, each checked by itself (SetRows)
 __global__ void __launch_bounds__(ORD_TPB)
 k_igd_begin(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict__ tot, u32 n_tot, u32 *__restrict__ flag,
             u32 *__restrict__ next_flag, u32 *__restrict__ heavy_count, u32 flag0, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
-            const u32 *__restrict__ qe, u32 nq, u32 n_chrom, u32 *__restrict__ cq_off) {
+            const u32 *__restrict__ qe, u32 nq, u32 n_chrom, u32 *__restrict__ cq_off, SetRows sets) {
     for (u32 i = blockIdx.x * ORD_TPB + threadIdx.x; i < max(n_files, n_tot); i += gridDim.x * ORD_TPB) {
         if (i < n_files) hits[i] = 0ull;
         if (i < n_tot) tot[i] = 0u;
@@ -485,7 +505,15 @@ k_igd_begin(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict_
         heavy_count[0] = 0u;
         if (flag0) flag[0] = 1u;
     }
-    if (flag0) return;  // the partition is certain (several query sets, or forced): nothing to check
+    if (flag0) return;  // the partition is certain (forced, or a form of several sets the in-order sweep does not serve): nothing to check
+    // Several query sets (round 5): "in order" means every set is in order BY ITSELF -- what a LOLA call's universe and user sets
+    // are (sorted region sets) --, and cq_off holds one row of chromosome offsets per set (stride n_chrom + 2).  The sweep then
+    // serves the sets one after the other from a tile's staged records, and nothing is partitioned.
+    const u32 cq_stride = n_chrom + 2u;
+    if (MS && blockIdx.x == 0)
+        for (u32 k = 0; k < sets.n; ++k)
+            if (sets.lo(k) == sets.hi(k))  // an empty set: no row writes its offsets
+                for (u32 x = threadIdx.x; x <= n_chrom; x += ORD_TPB) cq_off[k * cq_stride + x] = sets.lo(k);
     const int lane = threadIdx.x & 63;
     bool bad = false;
     for (u64 base = (u64)blockIdx.x * (ORD_TPB * 4); base < nq; base += (u64)gridDim.x * (ORD_TPB * 4)) {
@@ -523,7 +551,9 @@ k_igd_begin(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict_
         const u32 pc0 = pc;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u < nq && i0 + u > 0 && igd_out_of_order(pc, ps, c[u], s[u])) bad = true;
+            const u32 row = (u32)(i0 + u);
+            const bool opens = MS ? row == sets.lo(sets.of(row)) : row == 0;  // (the first row of its set follows nothing)
+            if (i0 + u < nq && !opens && igd_out_of_order(pc, ps, c[u], s[u])) bad = true;
             pc = c[u];
             ps = s[u];
         }
@@ -538,11 +568,14 @@ k_igd_begin(unsigned long long *__restrict__ hits, u32 n_files, u32 *__restrict_
         for (int u = 0; u < 4; ++u) {
             const u64 i = i0 + u;
             if (i < nq) {
-                const u32 from = i == 0 ? 0u : pc + 1u;
-                if (i == 0 || c[u] > pc)
-                    for (u32 k = from; k <= c[u]; ++k) cq_off[k] = (u32)i;
-                if (i == (u64)nq - 1)
-                    for (u32 k = c[u] + 1u; k <= n_chrom; ++k) cq_off[k] = nq;
+                const u32 set = MS ? sets.of((u32)i) : 0u, row0 = MS ? sets.lo(set) : 0u, row1 = MS ? sets.hi(set) : nq;
+                u32 *__restrict__ co = cq_off + set * cq_stride;
+                const bool opens = (u32)i == row0;
+                const u32 from = opens ? 0u : pc + 1u;
+                if (opens || c[u] > pc)
+                    for (u32 k = from; k <= c[u]; ++k) co[k] = (u32)i;
+                if ((u32)i == row1 - 1u)
+                    for (u32 k = c[u] + 1u; k <= n_chrom; ++k) co[k] = row1;
             }
             pc = c[u];
         }
@@ -778,23 +811,31 @@ __device__ __forceinline__ u32 sweep_query_slot(int lane, int wave) {
 // LDS per workgroup: starts (4 B) + {end, file} or {end, pme_file} pairs (8 B, ONE ds_read_b64 per candidate) [+ u16 file ids for
 // MODE 2]: 28 / 32 KB instead of 32 / 42, so the pme_file form keeps 4 workgroups per CU.
 constexpr u32 LO_REFINE = 24;
-template <int MODE, bool MO1, bool B16 = false, bool PIECES = false>
+// SIO: the instantiation that serves several query sets in order (n_sets_io rows of tile ranges); the others compile the one-set
+// loop as it was (the set bookkeeping cost the one-set binary sweep 1.6 % when it shared the instantiation)
+template <int MODE, bool MO1, bool B16 = false, bool PIECES = false, bool SIO = false>
 __global__ void __launch_bounds__(SW_TPB, MODE == 1 ? 4 : 8)
 k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__ pm, const unsigned short *__restrict__ files16,
             const u32 *__restrict__ tile_tab, u32 n_tiles, const u32 *__restrict__ sqs, const u32 *__restrict__ sqe, int interleaved,
             const u32 *__restrict__ ql, const u32 *__restrict__ qh, i32 min_overlap, unsigned long long *__restrict__ hits,
             const u32 *__restrict__ part_flag, const u32 *__restrict__ part_ab, const u32 *__restrict__ part_ql, u32 n_bins,
-            const uint2 *__restrict__ heavy_list, const u32 *__restrict__ heavy_count, u32 heavy_part, u32 heavy_cap) {
+            const uint2 *__restrict__ heavy_list, const u32 *__restrict__ heavy_count, u32 heavy_part, u32 heavy_cap, u32 n_sets_io) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
     // whether the batch had to be partitioned was decided on the device (the routing kernel): take the partition's
     // interleaved (start, end) pairs and bin offsets, or the batch as it arrived with the tile ranges
+    // n_sets_io > 1: a batch of several query sets that are each in order (k_igd_begin) -- the batch as it arrived, ONE row of tile
+    // ranges per set (stride n_tiles); a tile serves its queries set after set, counter row = set.  The partitioned continuation
+    // carries the sets as tags of the pairs instead.
     if (part_flag && *part_flag) {
         sqs = part_ab;
         sqe = nullptr;
         interleaved = 1;
         ql = part_ql;
         qh = part_ql + 1;
+        n_sets_io = 1;
     }
+    if (!SIO) n_sets_io = 1;
+    if (SIO && n_sets_io > 1) heavy_part = 0;  // (no parts of heavy tiles in that form)
     constexpr int CAP = IGD_TILE + IGD_HALO;
     // The columns are staged as whole 16-byte vectors from the 16-byte boundary at or below the tile's first record (a dword-per-
     // lane copy is 5 x 5 loads and as many LDS stores per thread and tile: a fifth of the kernel's instructions): LDS slot j of a
@@ -871,8 +912,11 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
             tile = hp.x;
             part = hp.y;
         }
-        const u32 *__restrict__ src = lane < TAB_DESC ? tile_tab + (size_t)tile * TAB_WORDS + lane : (lane == TAB_DESC ? ql : qh) + tile;
-        return lane < TAB_DESC + 2 ? *src : 0u;
+        // (lanes 12 + 2k / 13 + 2k: the tile's range of set k)
+        const u32 rel = (u32)lane - TAB_DESC;
+        const u32 *__restrict__ src = lane < TAB_DESC ? tile_tab + (size_t)tile * TAB_WORDS + lane
+                                                      : ((rel & 1u) ? qh : ql) + (size_t)(rel >> 1) * n_tiles + tile;
+        return lane < TAB_DESC + 2 * (SIO ? (int)max(n_sets_io, 1u) : 1) ? *src : 0u;
     };
     u32 n_tile = 0, n_part = 0, n_desc = 0;
     if (blockIdx.x < n_items) n_desc = request(blockIdx.x, n_tile, n_part);
@@ -888,11 +932,36 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
         }
         const u32 *__restrict__ tab = tile_tab + (size_t)tile * TAB_WORDS;
         if (item + gridDim.x < n_items) n_desc = request(item + gridDim.x, n_tile, n_part);
+        // The tile's queries as ONE index space j = 0 .. vt - 1: set 0's range first, then (several sets served in order) the further
+        // sets' ranges -- one loop over all of them, so that a small set does not cost a loop turn of its own per tile (a LOLA
+        // user set leaves ~4 queries per tile next to the universe's ~41).  c1 <= c2 <= c3: where sets 1, 2, 3 begin in it.
+        const u32 n_set0 = q_hi - q_lo;
+        u32 lo1 = 0, lo2 = 0, lo3 = 0, c1 = n_set0, c2 = n_set0, c3 = n_set0, vt = n_set0;
+        if (SIO && n_sets_io > 1) {
+            lo1 = word(TAB_DESC + 2);
+            c2 = c3 = vt = c1 + (word(TAB_DESC + 3) - lo1);
+        }
+        if (SIO && n_sets_io > 2) {
+            lo2 = word(TAB_DESC + 4);
+            c3 = vt = c2 + (word(TAB_DESC + 5) - lo2);
+        }
+        if (SIO && n_sets_io > 3) {
+            lo3 = word(TAB_DESC + 6);
+            vt = c3 + (word(TAB_DESC + 7) - lo3);
+        }
+        auto query_at = [&](u32 j, u32 &set) -> u32 {  // (j < vt)
+            set = 0;
+            if (!SIO || n_sets_io <= 1) return q_lo + j;  // (uniform)
+            set = (j >= c1 ? 1u : 0u) + (j >= c2 ? 1u : 0u) + (j >= c3 ? 1u : 0u);
+            return set == 0 ? q_lo + j : set == 1 ? lo1 + (j - c1) : set == 2 ? lo2 + (j - c2) : lo3 + (j - c3);
+        };
         // the tile's first SW_TPB queries: loaded now, used once the tile is staged (MODE 0 / 2)
         i32 pf_s = 0, pf_e = 0;
         if constexpr (MODE != 1) {
-            const u32 qi = q_lo + sweep_query_slot(lane, wave);
-            if (qi < q_hi) {
+            const u32 j0 = sweep_query_slot(lane, wave);
+            u32 set0_ = 0;
+            const u32 qi = j0 < vt ? query_at(j0, set0_) : 0u;
+            if (j0 < vt) {
                 if (interleaved) {
                     const uint2 se2 = reinterpret_cast<const uint2 *>(sqs)[qi];
                     pf_s = (i32)se2.x;
@@ -997,7 +1066,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
             constexpr int GL = IGD_GROUP_LANES;
             const int sub = lane % GL;
             const u32 kq = sweep_query_slot(lane, wave);
-            for (u32 qb = q_lo; qb < q_hi; qb += SW_TPB) {
+            for (u32 qb = 0; qb < vt; qb += SW_TPB) {
                 if (B16) {
                     if (since + SW_TPB > 65535u) {  // (uniform) the 16-bit counters could wrap: hand them over first
                         __syncthreads();
@@ -1007,11 +1076,13 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                     }
                     since += SW_TPB;
                 }
-                const u32 qi = qb + kq;
+                const u32 j = qb + kq;
                 i32 s = 0, e = 0;
                 u32 lo = 0, len = 0, boff = 0;
-                if (qi < q_hi) {
-                    if (qb == q_lo) {  // loaded at the top of the tile
+                if (j < vt) {
+                    u32 set;
+                    const u32 qi = query_at(j, set);
+                    if (qb == 0) {  // loaded at the top of the tile
                         s = pf_s;
                         e = pf_e;
                     } else if (interleaved) {
@@ -1022,6 +1093,7 @@ k_igd_sweep(IgdView v, const i32 *__restrict__ pme_file, const i32 *__restrict__
                         s = max((i32)sqs[qi], 0);
                         e = (i32)sqe[qi];
                     }
+                    boff = __umul24(set, v.n_files);
                     if (interleaved) boff = untag(s, e);
                     u32 a, b;
                     if (GTARS_IGD_ABLATE & 16) {
@@ -1872,7 +1944,8 @@ constexpr u32 HEAVY_PART_MIN = 4096;  // queries per part of a heavy tile, at le
 size_t igd_sweep_ws_bytes(u64 nq, u32 n_tiles, u32 n_chrom) {
     // kc ks ke | sorted qs qe chrom | perm (or owner tiles) | ql qh | cq_off | bin offsets | slack | heavy-tile parts |
     // partition / sort scratch
-    return 64 + (size_t)nq * 4 * 7 + (size_t)n_tiles * 12 + ((size_t)n_chrom + 2) * 4 + 512 + ((size_t)nq / HEAVY_PART_MIN + 16) * 8 +
+    return 64 + (size_t)nq * 4 * 7 + (size_t)n_tiles * (8 * IGD_MAX_SETS + 4) + ((size_t)n_chrom + 2) * 4 * IGD_MAX_SETS + 512 +
+           ((size_t)nq / HEAVY_PART_MIN + 16) * 8 +
            std::max(device_sort_perm_ws_bytes((u32)nq), multisplit_ws_bytes(n_tiles + 1, (u32)nq));
 }
 
@@ -1933,8 +2006,8 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     u32 *persist = (u32 *)ws;
     u32 *kc = persist + 16, *ks = kc + nq, *ke = ks + nq;
     u32 *sc = ke + nq, *ss = sc + nq, *se = ss + nq, *perm = se + nq;  // perm doubles as the owner-tile column
-    u32 *ql = perm + nq, *qh = ql + n_tiles, *cq_off = qh + n_tiles;
-    u32 *bin_off = cq_off + v.n_chrom + 2;  // [n_tiles + 2]
+    u32 *ql = perm + nq, *qh = ql + (size_t)IGD_MAX_SETS * n_tiles, *cq_off = qh + (size_t)IGD_MAX_SETS * n_tiles;  // (a row per set)
+    u32 *bin_off = cq_off + (size_t)IGD_MAX_SETS * (v.n_chrom + 2);  // [n_tiles + 2]
     u32 *d_unsorted = persist + (call_no & 1u), *d_next_flag = persist + ((call_no + 1u) & 1u);  // the "not in owner order" flag
     u32 *after_off = bin_off + n_tiles + 2;
     // tiles that own far more queries than the average are served in parts of heavy_part queries (k_igd_sweep's work items)
@@ -1951,7 +2024,19 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
     // GTARS_IGD_ALWAYS_SORT (tests): start from "not in order" -- the order check only ever raises the flag.  Several sets: always
     // partitioned (a concatenation of sets is not in order, and the partition is what tags the pairs)
     const bool always_sort = cfg_flag("GTARS_IGD_ALWAYS_SORT");
-    const u32 flag0 = always_sort || set_bounds ? 1u : 0u;
+    // Several sets that are each in (chromosome, start) order -- a LOLA call's universe and user sets -- are swept as they arrive, a
+    // row of tile ranges per set (round 5; the walked min_overlap >= 1 forms without the credited-file list); otherwise, and always
+    // for the remaining forms, a batch of several sets is partitioned (the partition is what tags the pairs).
+    const int mode_ = !binary ? 0 : (min_overlap == 1 && tl.pme_file ? 2 : 1);
+    const bool sets_in_order_ok = set_bounds && mode_ != 1 && !v.pieces && !cfg_flag("GTARS_IGD_SETS_ALWAYS_PARTITION");
+    SetRows rows;
+    rows.nq = nq;
+    if (sets_in_order_ok) {
+        rows.n = n_sets;
+        rows.b1 = set_bounds[0], rows.b2 = set_bounds[1], rows.b3 = set_bounds[2];
+    }
+    const u32 n_sets_io = sets_in_order_ok ? n_sets : 1u;
+    const u32 flag0 = always_sort || (set_bounds && !sets_in_order_ok) ? 1u : 0u;
     bool fine = false;
     const bool routed = igd_route_fits(v, tl, &fine);
     int dev = 0, cus = 256;
@@ -1999,8 +2084,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
             // flight for a batch that IS in order and cost a shuffled one 12 MB, not 25)
             const u64 og_check = std::min<u64>((u64)cus * 4, ((u64)nq + ORD_TPB * 4 - 1) / (ORD_TPB * 4));
             const unsigned og = (unsigned)std::max<u64>(1, flag0 ? (n_init + ORD_TPB - 1) / ORD_TPB : std::max<u64>(og_check, std::min<u64>(64, (n_init + ORD_TPB - 1) / ORD_TPB)));
-            hipLaunchKernelGGL(vec ? k_igd_begin<true> : k_igd_begin<false>, dim3(og), dim3(ORD_TPB), 0, st, (unsigned long long *)hits, n_bins,
-                               d_tot, n_tot0, d_unsorted, d_next_flag, heavy.count, flag0, qc, qs, qe, nq, v.n_chrom, cq_off);
+            auto begin = n_sets_io > 1 ? (vec ? k_igd_begin<true, true> : k_igd_begin<false, true>) : (vec ? k_igd_begin<true, false> : k_igd_begin<false, false>);
+            hipLaunchKernelGGL(begin, dim3(og), dim3(ORD_TPB), 0, st, (unsigned long long *)hits, n_bins,
+                               d_tot, n_tot0, d_unsorted, d_next_flag, heavy.count, flag0, qc, qs, qe, nq, v.n_chrom, cq_off, rows);
         }
         {
             ProfScope p("k_igd_route", st);
@@ -2010,7 +2096,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
                                fine ? tl.route_fn : tl.route_n, fine ? tl.route_fshift : tl.route_shift, n_tiles, rt_chunk,
                                reinterpret_cast<unsigned short *>(perm), multisplit_table(scratch), d_tot, d_unsorted,
                                d_tot ? multisplit_coarse_totals(scratch, n_tiles + 1, nq) : (u32 *)nullptr, multisplit_coarse_shift(n_tiles + 1),
-                               tl.route_kq, v, tl.first, tl.cnt, tl.chrom, (const u32 *)cq_off, flag0 ? (u32 *)nullptr : ql, qh, heavy);
+                               tl.route_kq, v, tl.first, tl.cnt, tl.chrom, (const u32 *)cq_off, flag0 ? (u32 *)nullptr : ql, qh, heavy, n_sets_io);
         }
         // No host round trip: both continuations are enqueued and the flag the order check leaves on the device picks one -- the
         // partition kernels return at once for a batch that is already in owner order (the routing launch has computed its tile
@@ -2076,6 +2162,9 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         kern = k_igd_sweep<2, true, true>;
         lds = lds16;
     }
+    if (n_sets_io > 1)  // (several sets served in order: the instantiations with the set bookkeeping; not for pieces views -- below)
+        kern = mode == 2 ? (b16 ? k_igd_sweep<2, true, true, false, true> : k_igd_sweep<2, true, false, false, true>)
+                         : mo1 ? k_igd_sweep<0, true, false, false, true> : k_igd_sweep<0, false, false, false, true>;
     if (v.pieces) {
         if (mode == 1 || !mo1) return fail(GTARS_ERR_INTERNAL, "IGD sweep: a pieces view serves min_overlap == 1 only");
         kern = mode == 2 ? (b16 ? k_igd_sweep<2, true, true, true> : k_igd_sweep<2, true, false, true>) : k_igd_sweep<0, true, false, true>;
@@ -2114,10 +2203,10 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         // the dynamic-LDS limit belongs to the function, not to the calling thread: raised once per device to the largest
         // size any launch can ask for (5 staged arrays + 16384 file bins) and never lowered
         static std::mutex mu;
-        static bool done[10][64] = {};
+        static bool done[20][64] = {};
         int dev = 0;
         GT_HIP(hipGetDevice(&dev));
-        const int slot = (b16 ? 4 : mode == 0 && !mo1 ? 3 : mode) + (v.pieces ? 5 : 0);
+        const int slot = (b16 ? 4 : mode == 0 && !mo1 ? 3 : mode) + (v.pieces ? 5 : 0) + (n_sets_io > 1 ? 10 : 0);
         std::lock_guard<std::mutex> lock(mu);
         if (dev >= 0 && dev < 64 && !done[slot][dev]) {
             GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2133,7 +2222,7 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
         ProfScope p(binary ? "k_igd_sweep<binary>" : "k_igd_sweep<pairwise>", st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SW_TPB), lds, st, v, tl.pme_file, tl.pm, tl.files16, tl.tab, n_tiles, ss, se,
                            interleaved, t_ql, t_qh, min_overlap, (unsigned long long *)hits, part_flag, part_ab, part_ql, n_bins,
-                           (const uint2 *)heavy.list, (const u32 *)heavy.count, heavy.part, heavy.cap);
+                           (const uint2 *)heavy.list, (const u32 *)heavy.count, heavy.part, heavy.cap, n_sets_io);
     }
     GT_HIP(hipGetLastError());
     // which continuation the device took (profiling mode: a deterministic fact for the tests, not a timing)

@@ -1660,6 +1660,83 @@ def test_igd_query_sets_share_one_pass(ga, n_db, sizes):
         ga.reload_env()
 
 
+def test_igd_query_sets_in_order_are_swept_as_they_arrive(ga, monkeypatch):
+    """Round 5: several query sets that are each in (chromosome, start) order -- what a LOLA call's universe and user sets are
+    (enrichment.rs:198-215 counts them over the same Igd) -- are not partitioned: the sweep serves a tile's queries set after
+    set from one row of tile ranges per set.  Every row must equal the oracle's count for that set alone; which continuation the
+    device took is read from the profiling facts.  Cases: two to four sets, an empty set in the middle, rejected queries at a
+    set's end (they sort last), one set out of order (-> the partition, same rows), the credited-file-list form of binary counts
+    (min_overlap 3: always partitioned), a set with far more queries in one tile than the average (no heavy-tile parts in the
+    in-order form: the tile serves them all), and the forced partition."""
+    monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
+    ga.reload_env()
+    try:
+        rng = np.random.default_rng(77)
+        n_db, n_chrom, F, span = 300_000, 3, 40, 30_000_000
+        c = rng.integers(0, n_chrom, n_db)
+        s = rng.integers(0, span, n_db)
+        e = s + rng.integers(1, 3_000, n_db)
+        f = rng.integers(0, F, n_db)
+        g, o = _igd_pair(ga, c, s, e, f, np.arange(n_db), n_chrom=n_chrom, n_files=F)
+
+        def ordered(n, dense=False):
+            qc, qs, qe = _random_query_set(rng, n, n_chrom, span + 5_000, 800, spoiled=0.0)
+            if dense:  # a third of the set inside one 20-kb window
+                k = n // 3
+                qc[:k] = 1
+                qs[:k] = 12_000_000 + rng.integers(0, 20_000, k)
+                qe[:k] = qs[:k] + rng.integers(1, 800, k)
+            order = np.lexsort((qs, qc))
+            qc, qs, qe = qc[order], qs[order], qe[order]
+            tail = 7  # rejected queries behind the last real one: unknown chromosome / inverted
+            return (np.concatenate([qc, np.full(tail, UNK, dtype=np.uint32)]), np.concatenate([qs, np.arange(tail, dtype=np.uint32) + 5]),
+                    np.concatenate([qe, np.arange(tail, dtype=np.uint32) + 9]))
+
+        empty = (np.zeros(0, dtype=np.uint32),) * 3
+        cases = {"two": [ordered(400_000), ordered(50_000)], "four with an empty one": [ordered(120_000), empty, ordered(60_000), ordered(90_000)],
+                 "dense tile": [ordered(300_000, dense=True), ordered(40_000)]}
+        _lib = ga._lib
+
+        def took(prof):
+            return {k: v["launches"] for k, v in prof.items() if k.startswith("igd_batch_")}
+
+        def run(sets, mo, binary):
+            _lib.lib.gtars_prof_reset()
+            _lib.lib.gtars_prof_enable(1)
+            got = g.count_sets(sets, mo, binary)
+            prof = _lib.prof_read()
+            _lib.lib.gtars_prof_enable(0)
+            return got, took(prof), prof.get("igd_sets_shared_pass", {"launches": 0})["launches"]
+
+        g.count_sets(cases["two"][:1], 1, True)  # builds pme_file outside the profiled calls
+        for name, sets in cases.items():
+            for binary, mo in ((True, 1), (False, 1), (False, 3), (True, 3)):
+                ref = o.count_region_hits if binary else o.count_set_overlaps
+                want = np.stack([ref(qc, qs, qe, mo, n_files=F) for qc, qs, qe in sets])
+                got, path, shared = run(sets, mo, binary)
+                assert np.array_equal(got, want), (name, binary, mo, np.argwhere(got != want)[:5])
+                assert shared == 1, (name, binary, mo)
+                # (binary counts with min_overlap 3 keep a list of credited files per query: that form is always partitioned)
+                assert path == ({"igd_batch_partitioned": 1} if (binary and mo == 3) else {"igd_batch_in_owner_order": 1}), (name, binary, mo, path)
+        # one set out of order: the partition, same rows
+        a, b = cases["two"]
+        sh = rng.permutation(len(b[0]))
+        mixed = [a, tuple(x[sh] for x in b)]
+        want = np.stack([o.count_region_hits(qc, qs, qe, 1, n_files=F) for qc, qs, qe in mixed])
+        got, path, _ = run(mixed, 1, True)
+        assert np.array_equal(got, want) and path == {"igd_batch_partitioned": 1}, path
+        # ... and the switch that always partitions
+        monkeypatch.setenv("GTARS_IGD_SETS_ALWAYS_PARTITION", "1")
+        ga.reload_env()
+        want = np.stack([o.count_region_hits(qc, qs, qe, 1, n_files=F) for qc, qs, qe in cases["two"]])
+        got, path, _ = run(cases["two"], 1, True)
+        assert np.array_equal(got, want) and path == {"igd_batch_partitioned": 1}, path
+    finally:
+        monkeypatch.delenv("GTARS_IGD_SETS_ALWAYS_PARTITION", raising=False)
+        monkeypatch.delenv("GTARS_IGD_SWEEP_MIN", raising=False)
+        ga.reload_env()
+
+
 def test_igd_query_sets_argument_checks(ga):
     rng = np.random.default_rng(5)
     g = ga.IgdIndex(np.zeros(10, dtype=np.uint32), np.arange(10) * 10, np.arange(10) * 10 + 5, np.zeros(10, dtype=np.uint32), n_chrom=1, n_files=1)
