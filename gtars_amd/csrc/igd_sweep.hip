@@ -21,7 +21,9 @@
 //   k_igd_sweep<0/2>   the candidate walk by quads out of LDS: pairwise counts for other min_overlap values and pieces views,
 //                      binary counts (LOLA support) for min_overlap == 1 through pme_file -- a record is the FIRST hit of its
 //                      file for a query iff it overlaps and no earlier record of the file ends after q.start, a per-record
-//                      constant of the database -- also for up to four query sets in one pass (set tags in the pairs' top bits);
+//                      constant of the database -- also for up to four query sets in one pass: set tags in the pairs' top bits
+//                      when the batch was partitioned, or (sets that are each in order, k_igd_begin<.., MS>: a LOLA call's universe
+//                      and user sets) the batch as it arrived with a row of tile ranges per set (the SIO instantiations);
 //   k_igd_sweep<1>     binary counts with a per-query list of credited files (other min_overlap values).
 // Everything a tile's queries need that depends on the database only (search tables, u16 file ids, prefix maxima, sorted ends and
 // their ranks, routing tables) is built once with the index (k_igd_tile_tables, k_igd_tile_tables_rank, api.hip finish_tiles).
