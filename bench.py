@@ -63,7 +63,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def algorithmic_bytes(nq: int, h: int, nu: int) -> int:
@@ -235,14 +235,41 @@ def _child_env(tmp):
     return env
 
 
+def traffic_from_counter_csvs(csv_paths):
+    """{"FETCH_SIZE": path, "WRITE_SIZE": path} (rocprofv3 counter_collection CSVs of two SEPARATE passes) ->
+    {kernel: {"fetch": bytes summed over the dispatches of the FETCH_SIZE pass (x2: the gfx950 note of MI355X_MICROARCH.md; the
+    counters are in KB), "write": bytes summed over the WRITE_SIZE pass, "fetch_dispatches": n, "write_dispatches": n,
+    "fetch_per_dispatch", "write_per_dispatch", "bytes_per_dispatch"}}.
+    The two passes are two runs and may launch a kernel a different number of times (a --min-seconds loop does), so EVERY
+    counter's sum is divided by the dispatch count of ITS OWN pass (round 5 divided both by the FETCH_SIZE pass's count: 550
+    vs 450 dispatches scaled the write bytes, and the figure drifted from run to run on an unchanged kernel)."""
+    import csv
+
+    res = {}
+    for counter, path in csv_paths.items():
+        key = "fetch" if counter == "FETCH_SIZE" else "write"
+        scale = 2048.0 if counter == "FETCH_SIZE" else 1024.0
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("gtars::", "").strip()
+                e = res.setdefault(name, {"fetch": 0.0, "write": 0.0, "fetch_dispatches": 0, "write_dispatches": 0})
+                e[key] += float(row["Counter_Value"]) * scale
+                e[key + "_dispatches"] += 1
+    for e in res.values():
+        e["fetch_per_dispatch"] = e["fetch"] / e["fetch_dispatches"] if e["fetch_dispatches"] else None
+        e["write_per_dispatch"] = e["write"] / e["write_dispatches"] if e["write_dispatches"] else None
+        e["bytes_per_dispatch"] = (None if e["fetch_per_dispatch"] is None or e["write_per_dispatch"] is None
+                                   else e["fetch_per_dispatch"] + e["write_per_dispatch"])
+    return res
+
+
 def measure_traffic_with_rocprof(child_args):
     """HBM-side bytes per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE; children of this process,
-    never combined with a trace domain) over a short invocation of this script.
-    -> {kernel name: {"fetch": bytes summed over its dispatches (FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md),
-    "write": bytes, "dispatches": n}} or None.  Not attempted when a profiler is already attached to this process
-    (bench.py under rocprofv3 needs --no-pmc: a child profiler started from a process the tool library has initialised
-    would be the forbidden exec-after-GPU-init hop)."""
-    import csv
+    never combined with a trace domain) over a short invocation of this script -> traffic_from_counter_csvs' dict, or None.
+    Not attempted when a profiler is already attached to this process (bench.py under rocprofv3 needs --no-pmc: a child
+    profiler started from a process the tool library has initialised would be the forbidden exec-after-GPU-init hop)."""
     import glob
     import shutil
     import subprocess
@@ -252,8 +279,8 @@ def measure_traffic_with_rocprof(child_args):
     if exe is None or _profiler_attached():
         return None
     tmp = tempfile.mkdtemp(prefix="gtars_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    res = {}
     try:
+        paths = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__)] + child_args
@@ -261,17 +288,8 @@ def measure_traffic_with_rocprof(child_args):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
-            key = "fetch" if counter == "FETCH_SIZE" else "write"
-            scale = 2048.0 if counter == "FETCH_SIZE" else 1024.0  # the counters are in KB
-            for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
-                if row["Counter_Name"] != counter:
-                    continue
-                name = row["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("gtars::", "").strip()
-                e = res.setdefault(name, {"fetch": 0.0, "write": 0.0, "dispatches": 0})
-                e[key] += float(row["Counter_Value"]) * scale
-                if counter == "FETCH_SIZE":
-                    e["dispatches"] += 1
-        return res or None
+            paths[counter] = max(files, key=os.path.getmtime)
+        return traffic_from_counter_csvs(paths) or None
     except Exception:
         return None
     finally:
@@ -406,9 +424,13 @@ def bench_igd_config3(dev, stream, ndb=IGD3["ndb"], nq=IGD3["nq"], n_files=IGD3[
         if live is not None:
             # every kernel of the count path (prep, partition, tile ranges, sweep), summed over the child's IGD_PMC_CALLS calls
             path = {k: v for k, v in live.items() if k.startswith(IGD_COUNT_KERNELS)}
+            # (the child makes a FIXED number of calls, so both passes launch every kernel equally often: sums / calls)
             per_call = sum(v["fetch"] + v["write"] for v in path.values()) / IGD_PMC_CALLS
             if path:
                 tr = {"bytes_per_call": per_call, "vs_algorithmic": per_call / byts,
+                      "fetch_bytes_per_call": sum(v["fetch"] for v in path.values()) / IGD_PMC_CALLS,
+                      "write_bytes_per_call": sum(v["write"] for v in path.values()) / IGD_PMC_CALLS,
+                      "dispatch_counts_agree": all(v["fetch_dispatches"] == v["write_dispatches"] for v in path.values()),
                       "by_kernel_per_call": {k: round((v["fetch"] + v["write"]) / IGD_PMC_CALLS) for k, v in sorted(path.items())},
                       "source": f"measured in this run: child rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py "
                                 f"--igd-pmc-child` ({IGD_PMC_CALLS} shuffled-batch calls, pairwise and binary alternating; FETCH_SIZE x2)"}
@@ -569,6 +591,7 @@ def bench_lola_config4(dev, stream, n_sets=LOLA4["n_sets"], per_set=LOLA4["per_s
            "identities_hold": ok, "support_sum": int(a.sum())}
     if not ok:
         raise SystemExit("bench.py: lola_config4: the contingency identities do not hold")
+    out.update(_lola_end_to_end(db, uni, sel, n_sets, per_set, a, b, c, d))
     if cpu:
         # B1: the oracle's Igd over the whole region DB; the user set's support vector in full (the GPU's must equal it) and
         # the first `ns` universe regions as the timing sample of the pooled-support count
@@ -593,6 +616,72 @@ def bench_lola_config4(dev, stream, n_sets=LOLA4["n_sets"], per_set=LOLA4["per_s
     del db, g
     torch.cuda.empty_cache()
     return out
+
+
+def _lola_end_to_end(db, uni, sel, n_sets, per_set, a, b, c, d):
+    """The drop-in call itself, `gtars.lola.run_lola(user_sets, universe, region_db)` (gtars-python/src/lola/mod.rs:180-271), timed
+    end to end on config 4: host region sets in, the reference's column dict out -- encode + copy of the 1.1M query regions,
+    the shared count pass, the contingency cells, the statistics tail for the 2000 tables (Fisher p-values, conditional-MLE
+    odds ratios, ranks, global order, BH q-values: gtars_lola_stats, compiled and threaded; round 5: a Python loop, ~15 s) and
+    the column layout.  `statistics_ms` is the tail alone on the same cells."""
+    import ctypes as C
+
+    from gtars_amd import lola, synth
+    from gtars_amd._lib import check, cstr_array, lib, ptr
+    from gtars_amd.igd import Igd
+    from gtars_amd.models import RegionSet
+
+    names = list(synth.CHROM_NAMES)
+    narr, _k1 = cstr_array(names)
+    fnames = [f"set{i:04d}.bed" for i in range(n_sets)]
+    farr, _k2 = cstr_array(fnames)
+    cnt = np.bincount(db["file"], minlength=n_sets).astype(np.uint32)
+    avgw = np.bincount(db["file"], weights=(db["end"].astype(np.int64) - db["start"].astype(np.int64)), minlength=n_sets) / np.maximum(cnt, 1)
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    check(lib.gtars_igddb_from_arrays(C.cast(narr, C.c_void_p), len(names), ptr(np.ascontiguousarray(db["chrom"], dtype=np.uint32)),
+                                      ptr(np.ascontiguousarray(db["start"]).view(np.int32)), ptr(np.ascontiguousarray(db["end"]).view(np.int32)),
+                                      ptr(np.zeros(len(db["chrom"]), np.int32)), ptr(np.ascontiguousarray(db["file"], dtype=np.uint32)),
+                                      len(db["chrom"]), C.cast(farr, C.c_void_p), ptr(cnt), ptr(avgw.astype(np.float64)), n_sets, C.byref(h)))
+    igd = Igd._from_db(h)
+    t_db = time.perf_counter() - t0
+
+    class _Sized:  # a database set as run_lola's `size` column sees it
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    rdb = lola.RegionDB(igd, [_Sized(int(x)) for x in cnt], [lola.RegionDB._anno(f, collection="synthetic") for f in fnames])
+    cn = np.asarray(names, dtype=object)
+    uni_rs = RegionSet.from_vectors(cn[uni["chrom"]].tolist(), uni["start"], uni["end"])
+    user_rs = RegionSet.from_vectors(cn[uni["chrom"][sel]].tolist(), uni["start"][sel], uni["end"][sel])
+    res = lola.run_lola([user_rs], uni_rs, rdb)  # warm-up (workspaces, host threads)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        res = lola.run_lola([user_rs], uni_rs, rdb)
+        times.append(time.perf_counter() - t0)
+    st_times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        st = lola.lola_stats(a, b, c, d, True)
+        st_times.append(time.perf_counter() - t0)
+    # the drop-in's rows against the cells of the device-resident run above
+    dbs = np.asarray(res["dbSet"])
+    ok = (len(dbs) == n_sets and np.array_equal(np.asarray(res["support"]), a[dbs]) and np.array_equal(np.asarray(res["b"]), b[dbs])
+          and np.array_equal(np.asarray(res["d"]), d[dbs]) and np.array_equal(st["order"].astype(np.int64), dbs)
+          and np.array_equal(np.asarray(res["pValueLog"]), st["pValueLog"][0][dbs])
+          and bool((np.diff(np.asarray(res["pValueLog"])) <= 0).all()))
+    if not ok:
+        raise SystemExit("bench.py: lola_config4: run_lola's rows differ from the device-resident cells / statistics")
+    del rdb, igd
+    return {"run_lola_end_to_end_ms": round(statistics.median(times) * 1e3, 2), "run_lola_calls_ms": [round(t * 1e3, 2) for t in times],
+            "statistics_ms": round(statistics.median(st_times) * 1e3, 2), "statistics_host_threads": int(lib.gtars_host_threads(64)),
+            "run_lola_how": "gtars.lola.run_lola([user RegionSet], universe RegionSet, RegionDB of the 2000 sets), host objects in, "
+                            "column dict out: encode + H2D of 1.1M regions, one shared count pass, cells, gtars_lola_stats (2000 tables), "
+                            f"columns; rows checked against the device-resident cells; RegionDB handle built in {t_db:.2f} s (not counted)"}
 
 
 def _usable_host_threads() -> int:
@@ -1099,20 +1188,24 @@ def main():
         name = names[0] if len(names) == 1 else "+".join(names)
         bytes_per_launch = algorithmic_bytes(nq, round(h_mean), nu)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, "not measured in this run (needs rocprofv3 --pmc passes)"
+        traffic, traffic_source, fetch_b, write_b = None, "not measured in this run (needs rocprofv3 --pmc passes)", None, None
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_tokenize_1M.json")
         if world == 1 and not args.no_extras and not args.no_pmc:
             live = measure_traffic_with_rocprof(["--steps", "20", "--warmup", "5", "--queries", str(nq), "--universe", str(args.universe),
                                                  "--no-cpu-baseline", "--no-extras", "--no-pmc", "--min-seconds", "0.05"])
-            tok = [v for k, v in (live or {}).items() if "k_tok_lds" in k]
+            tok = [v for k, v in (live or {}).items() if "k_tok_lds" in k and v["fetch_dispatches"] and v["write_dispatches"]]
             if tok:
-                traffic = sum(v["fetch"] + v["write"] for v in tok) / sum(v["dispatches"] for v in tok)
-                traffic_source = ("measured in this run: mean over k_tok_lds dispatches of two child rocprofv3 --pmc passes "
-                                  "(FETCH_SIZE x2 for gfx950 + WRITE_SIZE) of a short invocation of this script")
+                # each counter's sum over ITS OWN pass's dispatches (the passes are separate runs of a --min-seconds loop)
+                fetch_b = sum(v["fetch"] for v in tok) / sum(v["fetch_dispatches"] for v in tok)
+                write_b = sum(v["write"] for v in tok) / sum(v["write_dispatches"] for v in tok)
+                traffic = fetch_b + write_b
+                traffic_source = ("measured in this run: two child rocprofv3 --pmc passes (FETCH_SIZE x2 for gfx950, then WRITE_SIZE) of a "
+                                  "short invocation of this script; each counter's mean over the k_tok_lds dispatches of its own pass")
         if traffic is None and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj["workload"]["queries_per_step"] == nq and tj["workload"]["universe_regions"] == args.universe:
                 traffic = tj["traffic_bytes_per_launch"]
+                fetch_b, write_b = tj.get("fetch_bytes_per_launch"), tj.get("write_bytes_per_launch")
                 traffic_source = f"replayed from profiles/{PROFILE_ROUND}/traffic_tokenize_1M.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         roofline = {
             "bound": "hbm",
@@ -1123,6 +1216,8 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_vs_algorithmic": (traffic / bytes_per_launch) if traffic else None,
+            "fetch_bytes": fetch_b,
+            "write_bytes": write_b,
             "traffic_source": traffic_source,
             "avg_kernel_ms": avg_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,

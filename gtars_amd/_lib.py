@@ -214,6 +214,11 @@ _HOST_SIG = {
     "gtars_igddb_from_arrays": (C.c_int, [vp, u32, vp, vp, vp, vp, vp, u64, vp, vp, vp, u32, pp]),
     "gtars_igddb_save": (C.c_int, [vp, cstr, i32]),
     "gtars_igddb_load": (C.c_int, [cstr, pp, C.POINTER(C.c_int32)]),
+    "gtars_lola_stats": (C.c_int, [vp, vp, vp, vp, u64, u64, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gtars_lola_rank": (C.c_int, [vp, vp, vp, u64, vp, vp, vp, vp, vp]),
+    "gtars_lola_fdr": (C.c_int, [vp, vp, u64, vp]),
+    "gtars_lola_fisher_pvalue": (C.c_double, [u64, u64, u64, u64, C.c_int]),
+    "gtars_lola_odds_ratio": (C.c_double, [u64, u64, u64, u64]),
 }
 
 # every symbol the headers declare must resolve -- fail loudly otherwise (GTARS_AMD_LIB_OLDER=1, A/B tooling only: an older

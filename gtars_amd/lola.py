@@ -166,21 +166,14 @@ def _parse_index_txt(path: str, coll: str) -> List[dict]:
     return out
 
 
-# --------------------------------------------------------------------------- statistics (host f64)
+# --------------------------------------------------------------------------- statistics (host f64, compiled: csrc/lola_stats.cpp)
 
 
 def fisher_pvalue(a: int, b: int, c: int, d: int, enrichment: bool = True) -> float:
     """ContingencyTable::fisher_pvalue (enrichment.rs:19-53)."""
-    from scipy.stats import hypergeom
+    from ._lib import lib
 
-    n_pop, k_success, n_draws = a + b + c + d, a + b, a + c
-    if n_pop == 0 or k_success == 0 or n_draws == 0:
-        return 1.0
-    if k_success > n_pop or n_draws > n_pop:
-        return 1.0
-    if enrichment:
-        return 1.0 if a == 0 else float(hypergeom.sf(a - 1, n_pop, k_success, n_draws))
-    return float(hypergeom.cdf(a, n_pop, k_success, n_draws))
+    return float(lib.gtars_lola_fisher_pvalue(int(a), int(b), int(c), int(d), 0 if enrichment else 1))
 
 
 def p_value_log(a: int, b: int, c: int, d: int, enrichment: bool = True) -> float:
@@ -192,114 +185,64 @@ def odds_ratio(a: int, b: int, c: int, d: int) -> float:
     """ContingencyTable::odds_ratio (enrichment.rs:62-160): the conditional maximum-likelihood estimate of the odds ratio,
     as R's fisher.test reports it -- the omega for which the noncentral hypergeometric distribution of the table's margins
     has mean a.  Same definition and the same edge values (NaN for a one-point support, 0 / inf at the ends) as the
-    reference; the numerics are this module's own: the support's log-weights come from lgamma, the equation is solved in
-    theta = log(omega), where the mean is strictly increasing with the variance as its derivative, by Newton steps kept
-    inside a sign-change bracket.  (The reference finds the root of the same equation in omega with Brent's method, to an
-    absolute 1e-8 in omega; its own tests pin the value to 1e-3.)"""
-    from scipy.special import gammaln, logsumexp
+    reference; the numerics are the library's own (csrc/lola_stats.cpp): Newton in theta = log(omega) inside a sign-change
+    bracket, mean and variance summed over the window of terms that matter by the exact term ratio.  (The reference finds
+    the root of the same equation in omega with Brent's method, to an absolute 1e-8 in omega; its own tests pin the value
+    to 1e-3.)"""
+    from ._lib import lib
 
-    m, n, k, x = a + c, b + d, a + b, a
-    lo = k - n if k > n else 0
-    hi = min(k, m)
-    if lo == hi:
-        return float("nan")
-    if x == lo:
-        return 0.0
-    if x == hi:
-        return float("inf")
-    ys = np.arange(lo, hi + 1, dtype=np.float64)
-    # log of C(m, y) * C(n, k - y) up to a constant
-    lw = -(gammaln(ys + 1) + gammaln(m - ys + 1) + gammaln(k - ys + 1) + gammaln(n - k + ys + 1))
-
-    def moments(theta: float):
-        lv = lw + theta * ys
-        p = np.exp(lv - logsumexp(lv))
-        mu = float(np.dot(p, ys))
-        return mu, float(np.dot(p, (ys - mu) ** 2))
-
-    target = float(x)
-    mu0, _ = moments(0.0)
-    if abs(mu0 - target) < 1e-12:
-        return 1.0
-    # bracket the root: the mean runs from lo to hi as theta goes from -inf to +inf, and lo < x < hi here
-    step = 1.0
-    if mu0 < target:
-        t_lo, t_hi = 0.0, step
-        while moments(t_hi)[0] < target:
-            t_lo, t_hi, step = t_hi, t_hi + 2.0 * step, 2.0 * step
-    else:
-        t_lo, t_hi = -step, 0.0
-        while moments(t_lo)[0] > target:
-            t_lo, t_hi, step = t_lo - 2.0 * step, t_lo, 2.0 * step
-    theta = 0.5 * (t_lo + t_hi)
-    for _ in range(200):
-        mu, var = moments(theta)
-        if mu < target:
-            t_lo = theta
-        else:
-            t_hi = theta
-        nxt = theta - (mu - target) / var if var > 0.0 else float("nan")
-        if not (t_lo < nxt < t_hi):  # Newton left the bracket (flat tail of the mean): bisect
-            nxt = 0.5 * (t_lo + t_hi)
-        if abs(nxt - theta) <= 1e-13 * max(1.0, abs(theta)) or t_hi - t_lo <= 1e-14 * max(1.0, abs(theta)):
-            theta = nxt
-            break
-        theta = nxt
-    return math.exp(theta)
-
-
-def _min_ranks(order: List[int], key) -> Dict[int, int]:
-    """assign_min_ranks_* (enrichment.rs:310-351): ties.method = "min" on a pre-sorted index list."""
-    ranks: Dict[int, int] = {}
-    rank = 1
-    for pos, idx in enumerate(order):
-        if pos > 0:
-            p, c = key(order[pos - 1]), key(idx)
-            tied = (p == c) or (isinstance(p, float) and isinstance(c, float) and math.isnan(p) and math.isnan(c))
-            if not tied:
-                rank = pos + 1
-        ranks[idx] = rank
-    return ranks
+    return float(lib.gtars_lola_odds_ratio(int(a), int(b), int(c), int(d)))
 
 
 def _rank_results(rows: List[dict]) -> None:
-    """rank_results (enrichment.rs:353-394); Python's sort is stable like Rust's sort_by."""
+    """rank_results (enrichment.rs:353-394) on one user set's rows (gtars_lola_rank)."""
+    from ._lib import check, lib
+
     n = len(rows)
-    idx = list(range(n))
-    by_pv = sorted(idx, key=lambda i: -rows[i]["pValueLog"])
-    r_pv = _min_ranks(by_pv, lambda i: rows[i]["pValueLog"])
-
-    def or_key(i):
-        v = rows[i]["oddsRatio"]
-        return (1, 0.0) if math.isnan(v) else (0, -v)
-
-    by_or = sorted(idx, key=or_key)
-    r_or = _min_ranks(by_or, lambda i: rows[i]["oddsRatio"])
-    by_sup = sorted(idx, key=lambda i: -rows[i]["support"])
-    r_sup = _min_ranks(by_sup, lambda i: rows[i]["support"])
-    for i in idx:
-        rows[i]["rnkPV"], rows[i]["rnkOR"], rows[i]["rnkSup"] = r_pv[i], r_or[i], r_sup[i]
-        rows[i]["maxRnk"] = max(r_pv[i], r_or[i], r_sup[i])
-        rows[i]["meanRnk"] = (r_pv[i] + r_or[i] + r_sup[i]) / 3.0
+    if n == 0:
+        return
+    pv = np.array([r["pValueLog"] for r in rows], dtype=np.float64)
+    orr = np.array([r["oddsRatio"] for r in rows], dtype=np.float64)
+    sup = np.array([r["support"] for r in rows], dtype=np.uint64)
+    rk = [np.empty(n, dtype=np.uint32) for _ in range(4)]
+    mean = np.empty(n, dtype=np.float64)
+    check(lib.gtars_lola_rank(pv.ctypes.data, orr.ctypes.data, sup.ctypes.data, n, *[x.ctypes.data for x in rk], mean.ctypes.data))
+    for i, r in enumerate(rows):
+        r["rnkPV"], r["rnkOR"], r["rnkSup"], r["maxRnk"] = int(rk[0][i]), int(rk[1][i]), int(rk[2][i]), int(rk[3][i])
+        r["meanRnk"] = float(mean[i])
 
 
 def _apply_fdr(rows: List[dict]) -> None:
-    """apply_fdr_correction (output.rs:35-113): Benjamini-Hochberg per user set."""
-    if not rows:
+    """apply_fdr_correction (output.rs:35-113): Benjamini-Hochberg per user set (gtars_lola_fdr)."""
+    from ._lib import check, lib
+
+    n = len(rows)
+    if n == 0:
         return
-    for us in range(max(r["userSet"] for r in rows) + 1):
-        idx = [i for i, r in enumerate(rows) if r["userSet"] == us]
-        if not idx:
-            continue
-        n = len(idx)
-        idx.sort(key=lambda i: -rows[i]["pValueLog"])
-        p = [0.0 if rows[i]["pValueLog"] == float("inf") else 10.0 ** (-rows[i]["pValueLog"]) for i in idx]
-        q = [0.0] * n
-        q[n - 1] = min(p[n - 1] * n / n, 1.0)
-        for i in range(n - 2, -1, -1):
-            q[i] = min(min(p[i] * n / (i + 1), q[i + 1]), 1.0)
-        for j, i in enumerate(idx):
-            rows[i]["qValue"] = q[j]
+    pv = np.array([r["pValueLog"] for r in rows], dtype=np.float64)
+    us = np.array([r["userSet"] for r in rows], dtype=np.uint64)
+    q = np.empty(n, dtype=np.float64)
+    check(lib.gtars_lola_fdr(pv.ctypes.data, us.ctypes.data, n, q.ctypes.data))
+    for i, r in enumerate(rows):
+        r["qValue"] = float(q[i])
+
+
+def lola_stats(a, b, c, d, enrichment: bool = True) -> Dict[str, np.ndarray]:
+    """Everything run_lola derives from the cells, for all tables at once (gtars_lola_stats, threaded over the tables).
+    a, b, c, d: int64 [n_user_sets, n_db].  Returns the per-table columns in that layout plus ``order`` (flat row indices,
+    user set * n_db + db set, in the reference's output order) and ``qValue``."""
+    from ._lib import check, lib
+
+    a, b, c, d = (np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64) for x in (a, b, c, d))
+    n_sets, n_db = a.shape
+    out = {"pValueLog": np.empty(a.shape, np.float64), "oddsRatio": np.empty(a.shape, np.float64),
+           "rnkPV": np.empty(a.shape, np.uint32), "rnkOR": np.empty(a.shape, np.uint32), "rnkSup": np.empty(a.shape, np.uint32),
+           "maxRnk": np.empty(a.shape, np.uint32), "meanRnk": np.empty(a.shape, np.float64),
+           "order": np.empty(a.size, np.uint64), "qValue": np.empty(a.shape, np.float64)}
+    check(lib.gtars_lola_stats(a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, n_db, n_sets, 0 if enrichment else 1,
+                               *[out[k].ctypes.data for k in ("pValueLog", "oddsRatio", "rnkPV", "rnkOR", "rnkSup", "maxRnk",
+                                                               "meanRnk", "order", "qValue")]))
+    return out
 
 
 # --------------------------------------------------------------------------- run_lola
@@ -307,11 +250,15 @@ def _apply_fdr(rows: List[dict]) -> None:
 
 def _as_regions(x):
     """What Igd.count_region_hits takes: a RegionSet goes through as columns (no per-region Python objects: a 1e6-region
-    universe is three numpy arrays), a {"chr", "start", "end"} dict becomes a RegionSet, anything else a list of tuples."""
+    universe is three numpy arrays), a {"chr", "start", "end"} dict becomes a RegionSet by its columns (arrays stay arrays),
+    anything else -- an iterable of (chr, start, end) tuples or of objects with .chr / .start / .end -- a list of tuples."""
     if isinstance(x, RegionSet):
         return x
     if isinstance(x, dict):
-        return RegionSet.from_vectors(list(x["chr"]), list(x["start"]), list(x["end"]))
+        return RegionSet.from_vectors(list(x["chr"]), x["start"], x["end"])
+    x = list(x)
+    if x and not isinstance(x[0], (tuple, list)):  # Region objects
+        return [(r.chr, int(r.start), int(r.end)) for r in x]
     return [(r[0], int(r[1]), int(r[2])) for r in x]
 
 
@@ -338,21 +285,24 @@ def lola_counts(user_sets, universe, region_db: RegionDB, min_overlap: int = 1):
     dev = torch.device("cuda", torch.cuda.current_device())
     d_uni = torch.from_numpy(universe_hits.astype(np.int64)).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
-    all_hits, cells = [], []
+    all_hits, outs = [], []
     for k, regs in enumerate(user_regs):
         hits = support[1 + k]
         d_user = torch.from_numpy(hits.astype(np.int64)).to(dev)
-        out = [torch.empty(n_db, dtype=torch.int64, device=dev) for _ in range(4)]
+        out = torch.empty((4, n_db), dtype=torch.int64, device=dev)
         check(lib.gtars_lola_contingency_device(d_user.data_ptr(), d_uni.data_ptr(), n_db, len(regs), len(uni),
-                                                *[o.data_ptr() for o in out], stream))
-        torch.cuda.synchronize()
+                                                *[out[j].data_ptr() for j in range(4)], stream))
         all_hits.append(hits)
-        cells.append(tuple(o.cpu().numpy() for o in out))
+        outs.append(out)
+    cells = [tuple(o.cpu().numpy()) for o in outs]  # (the copies synchronise)
     return universe_hits, all_hits, cells
 
 
 def run_lola(user_sets, universe, region_db: RegionDB, min_overlap: int = 1, direction: str = "enrichment") -> Dict[str, list]:
-    """py_run_lola (gtars-python/src/lola/mod.rs:180-271): column dict, rows ordered like the reference."""
+    """py_run_lola (gtars-python/src/lola/mod.rs:180-271): column dict, rows ordered like the reference.  Counts on the GPU
+    (lola_counts), then ONE call into the library's compiled statistics tail for all tables (lola_stats): values, ranks
+    inside a user set, the global order (pValueLog descending, then meanRnk ascending: enrichment.rs:285-294) and the
+    q-values; what is left here is laying out the columns."""
     if direction in ("depletion", "less"):
         enrichment = False
     elif direction in ("enrichment", "greater"):
@@ -361,36 +311,38 @@ def run_lola(user_sets, universe, region_db: RegionDB, min_overlap: int = 1, dir
         raise ValueError("direction must be 'enrichment' or 'depletion'")
     _, _, cells = lola_counts(user_sets, universe, region_db, min_overlap)
     igd = region_db.igd
-    rows_all: List[dict] = []
-    for us_idx, (a, b, c, d) in enumerate(cells):
-        rows = []
-        for f in range(len(a)):
-            av, bv, cv, dv = int(a[f]), int(b[f]), int(c[f]), int(d[f])
-            if bv < 0 or cv < 0 or dv < 0:
-                pv_log, orr = 0.0, float("nan")
-            else:
-                pv_log = p_value_log(av, bv, cv, dv, enrichment)
-                orr = odds_ratio(av, bv, cv, dv)
-            rows.append({"userSet": us_idx, "dbSet": f, "pValueLog": pv_log, "oddsRatio": orr, "support": av,
-                         "b": bv, "c": cv, "d": dv, "qValue": None,
-                         "filename": igd.file_info[f].filename if f < len(igd.file_info) else ""})
-        _rank_results(rows)
-        rows_all.extend(rows)
-    # global order: pValueLog descending, then meanRnk ascending (enrichment.rs:285-294)
-    rows_all.sort(key=lambda r: (-r["pValueLog"], r["meanRnk"]))
-    anno = region_db.region_anno
-    for r in rows_all:
-        a = anno[r["dbSet"]] if r["dbSet"] < len(anno) else {}
-        desc = a.get("description")
-        r.update({"collection": a.get("collection"), "description": desc[:80] if desc is not None else None,
-                  "cellType": a.get("cellType"), "tissue": a.get("tissue"), "antibody": a.get("antibody"),
-                  "treatment": a.get("treatment"), "dataSource": a.get("dataSource"),
-                  "size": len(region_db.region_sets[r["dbSet"]]) if r["dbSet"] < len(region_db.region_sets) else 0})
-    _apply_fdr(rows_all)
     cols = ["userSet", "dbSet", "collection", "pValueLog", "oddsRatio", "support", "rnkPV", "rnkOR", "rnkSup", "maxRnk",
             "meanRnk", "b", "c", "d", "description", "cellType", "tissue", "antibody", "treatment", "dataSource",
             "filename", "qValue", "size"]
-    return {c: [r.get(c) for r in rows_all] for c in cols}
+    if not cells:
+        return {c: [] for c in cols}
+    a, b, c, d = (np.stack([cell[j] for cell in cells]) for j in range(4))
+    n_db = a.shape[1]
+    st = lola_stats(a, b, c, d, enrichment)
+    order = st["order"].astype(np.int64)
+    db = order % n_db
+    out: Dict[str, list] = {"userSet": (order // n_db).tolist(), "dbSet": db.tolist()}
+    for k, src in (("pValueLog", st["pValueLog"]), ("oddsRatio", st["oddsRatio"]), ("support", a), ("rnkPV", st["rnkPV"]),
+                   ("rnkOR", st["rnkOR"]), ("rnkSup", st["rnkSup"]), ("maxRnk", st["maxRnk"]), ("meanRnk", st["meanRnk"]),
+                   ("b", b), ("c", c), ("d", d), ("qValue", st["qValue"])):
+        out[k] = src.reshape(-1)[order].tolist()
+    # per database set: the annotation columns (output.rs:13-29) and the file name (enrichment.rs:249-253)
+    anno = region_db.region_anno
+    per_db: Dict[str, list] = {k: [] for k in ("collection", "description", "cellType", "tissue", "antibody", "treatment",
+                                                 "dataSource", "filename", "size")}
+    for f in range(n_db):
+        an = anno[f] if f < len(anno) else {}
+        desc = an.get("description")
+        per_db["collection"].append(an.get("collection"))
+        per_db["description"].append(desc[:80] if desc is not None else None)
+        for k in ("cellType", "tissue", "antibody", "treatment", "dataSource"):
+            per_db[k].append(an.get(k))
+        per_db["filename"].append(igd.file_info[f].filename if f < len(igd.file_info) else "")
+        per_db["size"].append(len(region_db.region_sets[f]) if f < len(region_db.region_sets) else 0)
+    dbl = out["dbSet"]
+    for k, v in per_db.items():
+        out[k] = [v[f] for f in dbl]
+    return {c: out[c] for c in cols}
 
 
 def _rust_exp6(x: float) -> str:

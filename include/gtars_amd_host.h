@@ -268,6 +268,36 @@ gtars_status gtars_igddb_from_arrays(const char *const *chrom_names, uint32_t n_
 gtars_status gtars_igddb_save(const gtars_igddb_t *db, const char *path, int32_t nbp);
 gtars_status gtars_igddb_load(const char *path, gtars_igddb_t **out, int32_t *nbp);
 
+/* ------------------------------------------------------------------------
+ * LOLA statistics tail  (gtars-lola/src/enrichment.rs:19-169, 243-394; output.rs:35-113)
+ * ---------------------------------------------------------------------- */
+/* Everything run_lola computes from the contingency cells, for all tables of a run in one threaded call.
+ * a, b, c, d: [n_user_sets x n_db] row-major i64 cells (what gtars_lola_contingency_device leaves; b, c, d may be
+ * negative: such a table gets pValueLog 0 and oddsRatio NaN, enrichment.rs:226-247).  direction: 0 enrichment
+ * (p = sf(a - 1)), 1 depletion (p = cdf(a)).  Outputs, same layout, row = user set * n_db + db set:
+ *   p_value_log  -log10(p + 1e-322)                                  (enrichment.rs:166-169)
+ *   odds_ratio   conditional MLE as R's fisher.test: NaN for a one-point support, 0 / inf at its ends (:62-160)
+ *   rnk_pv / rnk_or / rnk_sup / max_rnk / mean_rnk: min-ranks inside a user set, descending, NaN odds ratios last,
+ *                ties by bit pattern (NaN == NaN, 0.0 != -0.0)       (:296-394)  -- all five NULL: values only
+ *   order        the rows in the reference's output order: pValueLog descending, then meanRnk ascending, stable (:285-294)
+ *   q_value      Benjamini-Hochberg per user set over the rows in that order (output.rs:35-113)
+ * order / q_value may be NULL.  Hypergeometric sums and the odds-ratio equation are evaluated over the window of terms that
+ * matter (see csrc/lola_stats.cpp); parity with the reference's statrs 0.18 values is to floating-point tolerance. */
+gtars_status gtars_lola_stats(const int64_t *a, const int64_t *b, const int64_t *c, const int64_t *d, uint64_t n_db,
+                              uint64_t n_user_sets, int direction, double *p_value_log, double *odds_ratio,
+                              uint32_t *rnk_pv, uint32_t *rnk_or, uint32_t *rnk_sup, uint32_t *max_rnk, double *mean_rnk,
+                              uint64_t *order, double *q_value);
+/* rank_results (enrichment.rs:353-394) on the n rows of ONE user set, values given: min-ranks by pValueLog, oddsRatio (NaN
+ * last) and support, all descending; maxRnk and meanRnk. */
+gtars_status gtars_lola_rank(const double *p_value_log, const double *odds_ratio, const uint64_t *support, uint64_t n,
+                             uint32_t *rnk_pv, uint32_t *rnk_or, uint32_t *rnk_sup, uint32_t *max_rnk, double *mean_rnk);
+/* apply_fdr_correction (output.rs:35-113) on n_rows result rows in the order they stand: Benjamini-Hochberg q-values per
+ * user set (q_value[r] for row r). */
+gtars_status gtars_lola_fdr(const double *p_value_log, const uint64_t *user_set, uint64_t n_rows, double *q_value);
+/* ContingencyTable::fisher_pvalue / odds_ratio of one table (enrichment.rs:19-53, 62-160) */
+double gtars_lola_fisher_pvalue(uint64_t a, uint64_t b, uint64_t c, uint64_t d, int direction);
+double gtars_lola_odds_ratio(uint64_t a, uint64_t b, uint64_t c, uint64_t d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -971,6 +971,75 @@ def bh_qvalues(p_value_logs: Sequence[float]) -> List[float]:
     return out
 
 
+def rank_results(p_value_log: Sequence[float], odds_ratio: Sequence[float], support: Sequence[int]):
+    """rank_results + assign_min_ranks_* + f64_tied (gtars-lola/src/enrichment.rs:296-394) on ONE user set's rows, statement by
+    statement: one index list sorted three times by stable sorts (so a sort's ties keep the previous sort's order), min-ranks
+    with ties by BIT PATTERN (NaN ties with NaN; 0.0 and -0.0 do not tie although they compare equal), then maxRnk / meanRnk.
+    Returns (rnk_pv, rnk_or, rnk_sup, max_rnk, mean_rnk) in input order."""
+    import functools
+    import math
+    import struct
+
+    n = len(p_value_log)
+
+    def tied(a: float, b: float) -> bool:
+        if math.isnan(a) and math.isnan(b):
+            return True
+        return struct.pack("<d", a) == struct.pack("<d", b)
+
+    def partial_desc(a: float, b: float) -> int:  # b.partial_cmp(&a).unwrap_or(Equal)
+        return -1 if b < a else (1 if b > a else 0)
+
+    def min_ranks(idx, val, same):
+        out = [0] * n
+        rank = 1
+        for i, j in enumerate(idx):
+            if i > 0 and not same(val[idx[i - 1]], val[j]):
+                rank = i + 1
+            out[j] = rank
+        return out
+
+    idx = list(range(n))
+    idx.sort(key=functools.cmp_to_key(lambda x, y: partial_desc(p_value_log[x], p_value_log[y])))
+    r_pv = min_ranks(idx, p_value_log, tied)
+
+    def or_cmp(x, y):
+        ra, rb = odds_ratio[x], odds_ratio[y]
+        na, nb = math.isnan(ra), math.isnan(rb)
+        if na and nb:
+            return 0
+        if na:
+            return 1
+        if nb:
+            return -1
+        return partial_desc(ra, rb)
+
+    idx.sort(key=functools.cmp_to_key(or_cmp))
+    r_or = min_ranks(idx, odds_ratio, tied)
+    idx.sort(key=functools.cmp_to_key(lambda x, y: (support[y] > support[x]) - (support[y] < support[x])))
+    r_sup = min_ranks(idx, support, lambda a, b: a == b)
+    mx = [max(a, b, c) for a, b, c in zip(r_pv, r_or, r_sup)]
+    mean = [(a + b + c) / 3.0 for a, b, c in zip(r_pv, r_or, r_sup)]
+    return r_pv, r_or, r_sup, mx, mean
+
+
+def lola_row_order(p_value_log: Sequence[float], mean_rnk: Sequence[float]) -> List[int]:
+    """The final sort of run_lola (gtars-lola/src/enrichment.rs:285-294) over the concatenated rows: pValueLog descending, then
+    meanRnk ascending, stable."""
+    import functools
+
+    def cmp(x, y):
+        a, b = p_value_log[x], p_value_log[y]
+        if b < a:
+            return -1
+        if b > a:
+            return 1
+        a, b = mean_rnk[x], mean_rnk[y]
+        return -1 if a < b else (1 if a > b else 0)
+
+    return sorted(range(len(p_value_log)), key=functools.cmp_to_key(cmp))
+
+
 class MutableBits:
     """Bits with ``insert`` and ``seek`` -- a literal restatement on Python lists of gtars-overlaprs/src/bits.rs:
     build 101-128, insert 209-222, lower_bound 250-264, bsearch_seq_ref 304-322, seek 364-386, IterFind 433-446.

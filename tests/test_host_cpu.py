@@ -566,3 +566,36 @@ def test_inflate_decoder_under_the_sanitizers(tmp_path):
     run = subprocess.run([str(exe), "250", "77"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
     assert "decoded bit-exact" in run.stdout
+
+
+def test_bench_traffic_is_each_counters_mean_over_its_own_pass(tmp_path):
+    """bench.py's roofline.traffic: FETCH_SIZE and WRITE_SIZE come from two SEPARATE rocprofv3 passes that may launch the kernel
+    a different number of times; each counter's bytes per launch is its own sum over its own dispatch count (round 5 divided
+    both sums by the FETCH_SIZE pass's count, which scaled the write bytes by 550 / 450)."""
+    import bench
+
+    head = '"Correlation_Id","Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n'
+    kname = "void gtars::k_tok_lds<1024, 4, 1, 1, false, true, false, 5>(gtars::AccelView, unsigned int const*)"
+    other = "void gtars::k_scan_blocks(unsigned int const*)"
+
+    def write(path, counter, n_tok, kb, n_other):
+        with open(path, "w") as f:
+            f.write(head)
+            for i in range(n_tok):
+                f.write(f'"{i}","{i}","{kname}","{counter}","{kb:.6f}"\n')
+            for i in range(n_other):
+                f.write(f'"{i}","{i}","{other}","{counter}","1.000000"\n')
+            f.write(f'"9","9","{kname}","SOMETHING_ELSE","5.0"\n')
+
+    fp, wp = tmp_path / "fetch.csv", tmp_path / "write.csv"
+    write(fp, "FETCH_SIZE", 550, 12800.0, 3)   # 12800 KB x 2 (gfx950 correction) = 26 214 400 B per launch
+    write(wp, "WRITE_SIZE", 450, 10400.0, 2)   # 10400 KB = 10 649 600 B per launch
+    res = bench.traffic_from_counter_csvs({"FETCH_SIZE": str(fp), "WRITE_SIZE": str(wp)})
+    tok = res["k_tok_lds"]
+    assert tok["fetch_dispatches"] == 550 and tok["write_dispatches"] == 450
+    assert tok["fetch_per_dispatch"] == 12800.0 * 2048 and tok["write_per_dispatch"] == 10400.0 * 1024
+    assert tok["bytes_per_dispatch"] == 12800.0 * 2048 + 10400.0 * 1024
+    # what round 5 reported for the same files: (sum fetch + sum write) / 550 -- 8.5 MB instead of 10.6 MB of writes
+    wrong = (tok["fetch"] + tok["write"]) / tok["fetch_dispatches"]
+    assert abs(wrong - tok["bytes_per_dispatch"]) > 1.9e6
+    assert res["k_scan_blocks"]["fetch_dispatches"] == 3 and res["k_scan_blocks"]["write_dispatches"] == 2

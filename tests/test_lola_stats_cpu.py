@@ -239,3 +239,151 @@ def test_odds_ratio_grid_against_the_reference_method():
         assert abs(ours - ref) <= tol, (a, b, c, d, ours, ref)
         worst = max(worst, abs(ours - ref) / ref)
     assert worst < 1e-3
+
+
+# ---------------------------------------------------------------- the compiled tail (csrc/lola_stats.cpp), all tables in one call
+
+
+def _config4_like_tables(n_tables, seed, enrich):
+    """Cells shaped like BASELINE config 4: universe 1e6 regions, user set 1e5, database sets hit by up to 6e4 universe regions."""
+    rng = np.random.default_rng(seed)
+    n_uni, n_user = 1_000_000, 100_000
+    uni_hits = rng.integers(0, 60_000, n_tables)
+    frac = n_user / n_uni * (rng.uniform(0.3, 4.0, n_tables) if enrich else 1.0)
+    a = rng.binomial(uni_hits, np.minimum(1.0, frac))
+    b = uni_hits - a
+    c = n_user - a
+    d = n_uni - a - b - c
+    return tuple(x.astype(np.int64) for x in (a, b, c, d))
+
+
+def test_compiled_tail_against_round_5_python_on_2000_tables():
+    """gtars_lola_stats against the implementation it replaced (tests/lola_py_reference.py: scipy.stats.hypergeom + a numpy
+    Newton solve with lgamma weights), on 2000 tables of config 4's shape, half of them enriched / depleted up to 4x.
+    pValueLog: 2e-9 relative (absolute 1e-12 near p = 1; below p = 1e-300, where a double has lost its digits and scipy is off
+    by tens of per cent -- 3.38e-320 for an exact 2.66e-320 --, 0.15 absolute: the exact-arithmetic test below covers that
+    range).  oddsRatio: 5e-9 relative -- the OLD implementation is the
+    inexact side there: its weights come from double-precision gammaln at arguments of ~1e6, 2e-9 of absolute noise each
+    (the next test measures both against 60-digit arithmetic)."""
+    import lola_py_reference as ref
+
+    for enrich, direction, seed in ((False, True, 11), (True, True, 12), (True, False, 13), (False, False, 14)):
+        a, b, c, d = _config4_like_tables(500, seed, enrich)
+        st = lola.lola_stats(a, b, c, d, direction)
+        for i in range(len(a)):
+            t = (int(a[i]), int(b[i]), int(c[i]), int(d[i]))
+            pvl, pvl_ref = st["pValueLog"][0, i], ref.p_value_log(*t, direction)
+            tol = 0.15 if pvl_ref > 300.0 else 2e-9 * abs(pvl_ref) + 1e-12
+            assert abs(pvl - pvl_ref) <= tol, (t, pvl, pvl_ref)
+            orr, or_ref = st["oddsRatio"][0, i], ref.odds_ratio(*t)
+            if math.isnan(or_ref) or math.isinf(or_ref) or or_ref == 0.0:
+                assert (math.isnan(orr) and math.isnan(or_ref)) or orr == or_ref, (t, orr, or_ref)
+            else:
+                assert abs(orr - or_ref) <= 5e-9 * or_ref, (t, orr, or_ref)
+
+
+def test_compiled_p_values_against_exact_arithmetic():
+    """Fisher tail probabilities (enrichment.rs:19-53) against big-integer binomials / 60-digit decimals, from p ~ 0.5 down to
+    the denormal range: 1e-13 relative while p is a normal double, the denormal spacing (4.94e-324) below."""
+    from decimal import Decimal, getcontext
+    from math import comb
+
+    getcontext().prec = 60
+    tables = [(5, 15, 10, 100), (50, 10, 5, 1000), (300, 700, 1700, 17300), (900, 100, 1100, 17900), (1200, 300, 800, 17700),
+              (1990, 10, 10, 17990), (40, 960, 1960, 17040), (2, 998, 1998, 17002), (1000, 0, 1000, 18000)]
+    for a, b, c, d in tables:
+        n_pop, k_s, n_d = a + b + c + d, a + b, a + c
+        lo, hi = max(0, k_s + n_d - n_pop), min(k_s, n_d)
+        den = Decimal(comb(n_pop, n_d))
+        pmf = [Decimal(comb(k_s, y) * comb(n_pop - k_s, n_d - y)) / den for y in range(lo, hi + 1)]
+        for enrichment in (True, False):
+            exact = sum(pmf[a - lo:]) if enrichment else sum(pmf[: a - lo + 1])
+            got = lola.fisher_pvalue(a, b, c, d, enrichment)
+            if a == 0 and enrichment:
+                assert got == 1.0
+            elif exact > Decimal("1e-300"):
+                assert abs(Decimal(got) - exact) <= Decimal("1e-13") * exact, (a, b, c, d, enrichment, got, exact)
+            else:
+                assert abs(Decimal(got) - exact) <= Decimal("5e-324"), (a, b, c, d, enrichment, got, exact)
+
+
+def test_compiled_odds_ratio_solves_the_equation_in_60_digit_arithmetic():
+    """E[X | omega] = a (enrichment.rs:62-71) checked directly: the mean of the noncentral hypergeometric distribution at the
+    returned omega, summed in 60-digit decimals over +-4000 terms around a, must equal a to 1e-11."""
+    from decimal import Decimal, getcontext
+
+    getcontext().prec = 60
+    a_, b_, c_, d_ = _config4_like_tables(6, 21, True)
+    for i in range(6):
+        a, b, c, d = int(a_[i]), int(b_[i]), int(c_[i]), int(d_[i])
+        m, n, k, x = a + c, b + d, a + b, a
+        lo, hi = max(0, k - n), min(k, m)
+        if not lo < x < hi:
+            continue
+        om = Decimal(lola.odds_ratio(a, b, c, d))
+        w, s0, s1 = Decimal(1), Decimal(1), Decimal(0)
+        for y in range(x, min(hi, x + 4000)):
+            w = w * Decimal((m - y) * (k - y)) / Decimal((y + 1) * (n - k + y + 1)) * om
+            s0 += w
+            s1 += w * (y + 1 - x)
+        w = Decimal(1)
+        for y in range(x, max(lo, x - 4000), -1):
+            w = w * Decimal(y * (n - k + y)) / Decimal((m - y + 1) * (k - y + 1)) / om
+            s0 += w
+            s1 -= w * (x - y + 1)
+        assert abs(s1 / s0) < Decimal("1e-11"), (a, b, c, d, float(s1 / s0))
+
+
+def test_compiled_tail_ranks_order_and_q_values_follow_the_reference_rules():
+    """Ranks, the global row order and the q-values of gtars_lola_stats against the oracle's statement-level restatement of
+    rank_results / the final sort / apply_fdr_correction (enrichment.rs:285-394, output.rs:35-113), fed with the library's own
+    values: exact.  Three user sets; tables with a negative cell (pValueLog 0.0, oddsRatio NaN, enrichment.rs:226-247) next to
+    tables with p = 1 (pValueLog -0.0: equal in the sort, NOT tied in the ranks -- f64_tied compares bits), duplicated tables
+    (real ties), boundary tables (oddsRatio 0 / inf / NaN)."""
+    rng = np.random.default_rng(5)
+    n_db = 300
+    cells = []
+    for s in range(3):
+        a, b, c, d = _config4_like_tables(n_db, 30 + s, True)
+        a[:40], b[:40], c[:40], d[:40] = a[40:80], b[40:80], c[40:80], d[40:80]  # ties
+        b[100:110] = -rng.integers(1, 5, 10)  # user regions outside the universe
+        a[120:130], b[120:130] = 0, 0  # no universe region hits the set: p = 1, one-point support
+        a[130:135], b[130:135], c[130:135], d[130:135] = 0, 7, 9, 50
+        a[135:140], b[135:140], c[135:140], d[135:140] = 9, 0, 3, 50
+        cells.append((a, b, c, d))
+    a, b, c, d = (np.stack([x[j] for x in cells]) for j in range(4))
+    for enrichment in (True, False):
+        st = lola.lola_stats(a, b, c, d, enrichment)
+        pv, orr = st["pValueLog"], st["oddsRatio"]
+        assert (pv[:, 100:110] == 0.0).all() and not np.signbit(pv[:, 100:110]).any() and np.isnan(orr[:, 100:110]).all()
+        if enrichment:
+            assert (pv[:, 120:130] == 0.0).all() and np.signbit(pv[:, 120:130]).all()  # -log10(1 + 1e-322) = -0.0
+        assert np.isnan(orr[:, 120:130]).all() and (orr[:, 130:135] == 0.0).all() and np.isinf(orr[:, 135:140]).all()
+        for s in range(3):
+            exp = oracle.rank_results(pv[s].tolist(), orr[s].tolist(), a[s].tolist())
+            for got, e in zip((st["rnkPV"][s], st["rnkOR"][s], st["rnkSup"][s], st["maxRnk"][s]), exp[:4]):
+                assert got.tolist() == e
+            assert st["meanRnk"][s].tolist() == exp[4]
+            if enrichment:  # the zero of a negative-cell row and the negative zero of a p = 1 row are different rank groups
+                assert len({int(st["rnkPV"][s][i]) for i in (100, 120)}) == 2
+        order = oracle.lola_row_order(pv.reshape(-1).tolist(), st["meanRnk"].reshape(-1).tolist())
+        assert st["order"].tolist() == order
+        us = [r // n_db for r in order]
+        for s in range(3):
+            rows = [r for r, u in zip(order, us) if u == s]
+            q = oracle.bh_qvalues([pv.reshape(-1)[r] for r in rows])
+            assert [st["qValue"].reshape(-1)[r] for r in rows] == q
+
+
+def test_compiled_tail_argument_errors_and_values_only_form():
+    from gtars_amd._lib import lib
+
+    a, b, c, d = _config4_like_tables(16, 3, False)
+    pv, orr = np.empty(16), np.empty(16)
+    args = [x.ctypes.data for x in (a, b, c, d)]
+    assert lib.gtars_lola_stats(*args, 16, 1, 0, pv.ctypes.data, orr.ctypes.data, *([None] * 7)) == 0
+    assert pv.tolist() == [lola.p_value_log(*(int(x[i]) for x in (a, b, c, d))) for i in range(16)]
+    assert lib.gtars_lola_stats(*args, 16, 1, 2, pv.ctypes.data, orr.ctypes.data, *([None] * 7)) != 0  # direction
+    q = np.empty(16)
+    assert lib.gtars_lola_stats(*args, 16, 1, 0, pv.ctypes.data, orr.ctypes.data, *([None] * 6), q.ctypes.data) != 0
+    assert lib.gtars_lola_stats(None, *args[1:], 16, 1, 0, pv.ctypes.data, orr.ctypes.data, *([None] * 7)) != 0
