@@ -1335,6 +1335,13 @@ def main():
                        "max_ms_per_step": max(rep_wall) / args.steps * 1e3},
             "roofline": roofline,
         }
+        if world > 1:
+            out["headline_scaling_note"] = (
+                "the headline is weak-scaled replicas by construction: every rank tokenizes its own 1M-query batches against a replicated "
+                "index and nothing crosses ranks, so value at N GPUs is ~N x the single-GPU value and says nothing about the interconnect. "
+                "Read scaling from the objects that exchange or partition data: with_allgather (CSR all-gatherv), igd_config3_weak "
+                "(chromosome buckets + one all-reduce per call, the genome grows with the ranks), igd_config3_sharded / "
+                "lola_config4_sharded (strong-scaled, latency-bound at 8 ranks: see their per_rank_ms) and fragsplit_config5_weak")
         if sorted_input:
             out["sorted_input"] = sorted_input
         if with_allgather:

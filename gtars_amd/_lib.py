@@ -74,6 +74,7 @@ _SIG = {
     "gtars_index_len": (u64, [vp]),
     "gtars_index_n_chrom": (u32, [vp]),
     "gtars_index_kind": (C.c_int, [vp]),
+    "gtars_index_device": (C.c_int, [vp]),
     "gtars_index_chrom_len": (u64, [vp, u32]),
     "gtars_index_stored": (C.c_int, [vp, u32, vp, vp, vp]),
     "gtars_index_insert": (C.c_int, [vp, u32, u32, u32, u32, vp]),
@@ -87,7 +88,6 @@ _SIG = {
     "gtars_tokenize_device_ex": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64, vp, C.c_int]),
     "gtars_histogram_u32_device": (C.c_int, [vp, u64, u32, vp, vp]),
     "gtars_histogram_rows_device": (C.c_int, [vp, vp, vp, u64, u32, u32, u32, vp, vp]),
-    "gtars_debug_occupy_device": (C.c_int, [vp, u32, u32, u32]),
     "gtars_tokenize": (C.c_int, [vp, vp, vp, vp, u64, vp, pp, pu64]),
     "gtars_tokenize_into": (C.c_int, [vp, vp, vp, vp, u64, vp, vp, u64, pu64]),
     "gtars_count_overlaps_device": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, i32, vp, vp]),
@@ -104,6 +104,7 @@ _SIG = {
     "gtars_igd_free": (None, [vp]),
     "gtars_igd_len": (u64, [vp]),
     "gtars_igd_n_files": (u32, [vp]),
+    "gtars_igd_device": (C.c_int, [vp]),
     "gtars_igd_total_records": (u64, [vp, i32]),
     "gtars_igd_export": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "gtars_igd_count_device": (C.c_int, [vp, vp, vp, vp, u64, i32, C.c_int, vp, vp]),
@@ -113,7 +114,6 @@ _SIG = {
     "gtars_igd_count_per_query": (C.c_int, [vp, vp, vp, vp, u64, i32, vp]),
     "gtars_igd_find_pairs": (C.c_int, [vp, vp, vp, vp, u64, i32, pp, pp, pu64]),
     "gtars_lola_contingency_device": (C.c_int, [vp, vp, u64, i64, i64, vp, vp, vp, vp, vp]),
-    "gtars_debug_reload_env": (None, []),
     "gtars_prof_enable": (None, [C.c_int]),
     "gtars_prof_reset": (None, []),
     "gtars_prof_read": (C.c_int, [vp, vp, vp, C.c_int]),
@@ -221,10 +221,17 @@ _HOST_SIG = {
     "gtars_lola_odds_ratio": (C.c_double, [u64, u64, u64, u64]),
 }
 
+# include/gtars_amd_debug.h: test / A-B / diagnostics hooks, not part of the drop-in boundary
+_DEBUG_SIG = {
+    "gtars_debug_occupy_device": (C.c_int, [vp, u32, u32, u32]),
+    "gtars_debug_reload_env": (None, []),
+    "gtars_debug_set_handle_device": (C.c_int, [vp, C.c_int, C.c_int]),
+}
+
 # every symbol the headers declare must resolve -- fail loudly otherwise (GTARS_AMD_LIB_OLDER=1, A/B tooling only: an older
 # build loaded through GTARS_AMD_LIB may lack the newest entry points; calling one of those then fails at the call)
 _older = bool(os.environ.get("GTARS_AMD_LIB")) and os.environ.get("GTARS_AMD_LIB_OLDER") == "1"
-for _table in (_SIG, _HOST_SIG):
+for _table in (_SIG, _HOST_SIG, _DEBUG_SIG):
     for _name, (_res, _args) in _table.items():
         if _older and not hasattr(lib, _name):
             continue
@@ -234,6 +241,7 @@ for _table in (_SIG, _HOST_SIG):
 
 EXPORTED_SYMBOLS = tuple(_SIG)
 EXPORTED_HOST_SYMBOLS = tuple(_HOST_SIG)
+EXPORTED_DEBUG_SYMBOLS = tuple(_DEBUG_SIG)
 
 
 def cstr_array(strings):

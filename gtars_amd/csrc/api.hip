@@ -17,6 +17,7 @@
 #include <unordered_map>
 
 #include "common.h"
+#include "../../include/gtars_amd_debug.h"
 
 namespace gtars {
 
@@ -283,12 +284,38 @@ struct DeviceScope {
             e = hipSetDevice(want);
             switched = e == hipSuccess;
         }
-        if (e != hipSuccess) st = hip_fail(e, "select the index's device", __FILE__, __LINE__);
+        if (e != hipSuccess) st = hip_fail(e, "select the handle's device", __FILE__, __LINE__);
     }
     ~DeviceScope() {
         if (switched) (void)hipSetDevice(before);
     }
 };
+
+// Device affinity of a handle (round 6: every entry point that takes one).  A handle's device memory -- and everything built
+// lazily on it later -- lives on the device that was current when it was built.
+//  * host-buffer entry points run ON that device whatever the calling thread's current device is, and put the caller's device
+//    back afterwards:   GT_ON_DEVICE_OF(h);
+//  * `*_device` entry points take the CALLER's device pointers and stream, which belong to the caller's current device: a handle
+//    that lives elsewhere is an argument error, not a memory fault:   GT_SAME_DEVICE_AS(h);
+static gtars_status require_handle_device(int handle_device) {
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return hip_fail(e, "query the current device", __FILE__, __LINE__);
+    if (cur != handle_device)
+        return fail(GTARS_ERR_INVALID_ARG, "handle lives on device " + std::to_string(handle_device) + ", current device is " +
+                                               std::to_string(cur) + ": device pointers and stream must belong to the handle's device");
+    return GTARS_OK;
+}
+#define GT_ON_DEVICE_OF(h)                                \
+    DeviceScope gt_device_scope_((h) ? (h)->device : -1); \
+    if (gt_device_scope_.st) return gt_device_scope_.st
+#define GT_SAME_DEVICE_AS(h)                                                 \
+    do {                                                                     \
+        if (h) {                                                             \
+            const gtars_status gt_dev_st_ = require_handle_device((h)->device); \
+            if (gt_dev_st_) return gt_dev_st_;                               \
+        }                                                                    \
+    } while (0)
 
 }  // namespace gtars
 
@@ -432,6 +459,7 @@ struct gtars_index {
 struct gtars_igd {
     u32 n_chrom = 0, n_files = 0;
     u64 n = 0;
+    int device = 0;  // the device the database was built on (and everything built lazily later lives on)
     // Databases with records longer than the piece length keep a second index of PIECES for the min_overlap == 1 counts (see
     // build_pieces_view below); null otherwise.  Owned.
     gtars_igd *pieces = nullptr;
@@ -1172,6 +1200,7 @@ void gtars_index_free(gtars_index_t *ix) {
 uint64_t gtars_index_len(const gtars_index_t *ix) { return ix ? ix->n : 0; }
 uint32_t gtars_index_n_chrom(const gtars_index_t *ix) { return ix ? ix->n_chrom : 0; }
 int gtars_index_kind(const gtars_index_t *ix) { return ix ? ix->kind : -1; }
+int gtars_index_device(const gtars_index_t *ix) { return ix ? ix->device : -1; }
 
 uint64_t gtars_index_chrom_len(const gtars_index_t *ix, uint32_t c) {
     if (!ix || c >= ix->n_chrom) return 0;
@@ -1305,6 +1334,7 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
 gtars_status gtars_tokenize_device_ex(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
                                       const uint32_t *d_qe, uint64_t nq, uint64_t *d_offsets, uint32_t *d_ids,
                                       uint64_t ids_capacity, uint64_t *total_hits, void *stream, int hint) {
+    GT_SAME_DEVICE_AS(ix);
     gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (!d_offsets) return fail(GTARS_ERR_INVALID_ARG, "d_offsets is NULL");
@@ -1371,6 +1401,7 @@ gtars_status gtars_fill_device_n(const gtars_index_t *ix, const uint32_t *d_qc, 
 
 static gtars_status fill_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs, const uint32_t *d_qe, uint64_t nq,
                                 const uint64_t *d_offsets, uint32_t *d_ids, u64 capacity, int hint, void *stream) {
+    GT_SAME_DEVICE_AS(ix);
     gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (!d_offsets || !d_ids) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
@@ -1395,6 +1426,7 @@ gtars_status gtars_count_overlaps_device(const gtars_index_t *ix, const uint32_t
                                          const uint32_t *d_qs, const uint32_t *d_qe, uint64_t nq,
                                          int has_min, int32_t min_overlap, uint32_t *d_counts,
                                          void *stream) {
+    GT_SAME_DEVICE_AS(ix);
     gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (nq && !d_counts) return fail(GTARS_ERR_INVALID_ARG, "d_counts is NULL");
@@ -1848,6 +1880,7 @@ static gtars_status gtars_tokenize_impl(const gtars_index_t *ix, const uint32_t 
 gtars_status gtars_count_overlaps(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
                                   const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
                                   uint32_t *counts) {
+    GT_ON_DEVICE_OF(ix);
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
     if (st) return st;
     if (nq && !counts) return fail(GTARS_ERR_INVALID_ARG, "counts is NULL");
@@ -1880,6 +1913,7 @@ static gtars_status bits_count_prepare(const gtars_index_t *ix) {
 
 gtars_status gtars_bits_count_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
                                      const uint32_t *d_qe, uint64_t nq, uint64_t *d_counts, void *stream) {
+    GT_SAME_DEVICE_AS(ix);
     if (!ix) return fail(GTARS_ERR_INVALID_ARG, "index is NULL");
     if (nq && (!d_qc || !d_qs || !d_qe || !d_counts)) return fail(GTARS_ERR_INVALID_ARG, "NULL device pointer");
     gtars_status st = require_device();
@@ -1890,6 +1924,7 @@ gtars_status gtars_bits_count_device(const gtars_index_t *ix, const uint32_t *d_
 
 gtars_status gtars_bits_count(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
                               uint64_t nq, uint64_t *counts) {
+    GT_ON_DEVICE_OF(ix);
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
     if (st) return st;
     if (nq && !counts) return fail(GTARS_ERR_INVALID_ARG, "counts is NULL");
@@ -1912,6 +1947,7 @@ gtars_status gtars_bits_count(const gtars_index_t *ix, const uint32_t *qc, const
 gtars_status gtars_any_overlaps(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
                                 const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
                                 uint8_t *out) {
+    GT_ON_DEVICE_OF(ix);
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
     if (st) return st;
     if (nq && !out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
@@ -1934,6 +1970,7 @@ gtars_status gtars_find_overlaps(const gtars_index_t *ix, const uint32_t *qc, co
                                  const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
                                  uint64_t *offsets, uint32_t **out_start, uint32_t **out_end,
                                  uint32_t **out_val, uint64_t *out_n) {
+    GT_ON_DEVICE_OF(ix);
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
     if (st) return st;
     if (out_start) *out_start = nullptr;
@@ -1946,6 +1983,7 @@ gtars_status gtars_find_overlaps(const gtars_index_t *ix, const uint32_t *qc, co
 gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
                                         const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
                                         uint64_t *offsets, uint32_t **out_idx, uint64_t *out_n) {
+    GT_ON_DEVICE_OF(ix);
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
     if (st) return st;
     if (!out_idx || !out_n || !offsets) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
@@ -2011,6 +2049,7 @@ gtars_status gtars_find_overlap_indices(const gtars_index_t *ix, const uint32_t 
 gtars_status gtars_mark_overlapped_device(const gtars_index_t *ix, const uint32_t *d_qc, const uint32_t *d_qs,
                                           const uint32_t *d_qe, uint64_t nq, int has_min, int32_t min_overlap,
                                           uint32_t *d_mark, void *stream) {
+    GT_SAME_DEVICE_AS(ix);
     gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (!d_mark && ix->n) return fail(GTARS_ERR_INVALID_ARG, "d_mark is NULL");
@@ -2062,6 +2101,7 @@ extern "C" {
 static gtars_status gtars_subset_by_overlaps_impl(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
                                                   uint64_t nq, int has_min, int32_t min_overlap, uint32_t **out_chrom,
                                                   uint32_t **out_start, uint32_t **out_end, uint64_t *out_n) {
+    GT_ON_DEVICE_OF(ix);
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
     if (st) return st;
     if (!out_chrom || !out_start || !out_end || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
@@ -2133,6 +2173,7 @@ gtars_status gtars_subset_by_overlaps(const gtars_index_t *ix, const uint32_t *q
 static gtars_status gtars_subset_source_indices_impl(const gtars_index_t *ix, const uint32_t *qc, const uint32_t *qs,
                                                      const uint32_t *qe, uint64_t nq, int has_min, int32_t min_overlap,
                                                      uint32_t **out_idx, uint64_t *out_n) {
+    GT_ON_DEVICE_OF(ix);
     gtars_status st = check_query_args(ix, qc, qs, qe, nq);
     if (st) return st;
     if (!out_idx || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
@@ -2210,6 +2251,7 @@ static gtars_status gtars_igd_build_core(const uint32_t *chrom, const int32_t *s
         }
         for (u32 c = 0; c < n_chrom; ++c) hoff[c + 1] += hoff[c];
         auto *g = new gtars_igd();
+        (void)hipGetDevice(&g->device);
         g->piece_flags = piece_flags;
         g->n_chrom = n_chrom;
         g->n_files = n_files;
@@ -2299,6 +2341,7 @@ static gtars_status gtars_igd_build_core(const uint32_t *chrom, const int32_t *s
         return start[a] < start[b];
     });
     auto *g = new gtars_igd();
+    (void)hipGetDevice(&g->device);
     g->piece_flags = piece_flags;
     g->n_chrom = n_chrom;
     g->n_files = n_files;
@@ -2508,11 +2551,31 @@ void gtars_igd_free(gtars_igd_t *g) {
 
 uint64_t gtars_igd_len(const gtars_igd_t *g) { return g ? g->n : 0; }
 uint32_t gtars_igd_n_files(const gtars_igd_t *g) { return g ? g->n_files : 0; }
+int gtars_igd_device(const gtars_igd_t *g) { return g ? g->device : -1; }
+
+// include/gtars_amd_debug.h: forge the device id a handle records (tests of the device-affinity checks on a one-GPU box)
+int gtars_debug_set_handle_device(void *handle, int is_igd, int device) {
+    if (!handle) return -1;
+    int before;
+    if (is_igd) {
+        gtars_igd *g = (gtars_igd *)handle;
+        before = g->device;
+        g->device = device;
+        if (g->pieces) g->pieces->device = device;
+    } else {
+        gtars_index *ix = (gtars_index *)handle;
+        before = ix->device;
+        ix->device = device;
+        if (ix->flat) ix->flat->device = device;
+    }
+    return before;
+}
 
 uint64_t gtars_igd_total_records(const gtars_igd_t *g, int32_t nbp) {
     if (!g) return 0;
     if (nbp <= 0) nbp = 16384;
-    if (g->ensure_mirror()) return 0;
+    DeviceScope on_handle_device(g->device);
+    if (on_handle_device.st || g->ensure_mirror()) return 0;
     u64 t = 0;
     for (u64 i = 0; i < g->n; ++i) t += (u64)((g->h_ends[i] - 1) / nbp - g->h_starts[i] / nbp + 1);
     return t;
@@ -2520,6 +2583,7 @@ uint64_t gtars_igd_total_records(const gtars_igd_t *g, int32_t nbp) {
 
 gtars_status gtars_igd_export(const gtars_igd_t *g, uint32_t *chrom, int32_t *start, int32_t *end, int32_t *value,
                               uint32_t *file_idx) {
+    GT_ON_DEVICE_OF(g);
     if (!g) return fail(GTARS_ERR_INVALID_ARG, "NULL handle");
     const size_t n = g->n;
     if (!n) return GTARS_OK;
@@ -2543,6 +2607,7 @@ gtars_status gtars_igd_export(const gtars_igd_t *g, uint32_t *chrom, int32_t *st
 gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, const uint32_t *d_qs,
                                     const uint32_t *d_qe, uint64_t nq, int32_t min_overlap, int binary,
                                     uint64_t *d_hits, void *stream) {
+    GT_SAME_DEVICE_AS(g);
     gtars_status st = check_query_args(g, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (!d_hits) return fail(GTARS_ERR_INVALID_ARG, "d_hits is NULL");
@@ -2580,6 +2645,7 @@ gtars_status gtars_igd_count_device(const gtars_igd_t *g, const uint32_t *d_qc, 
 gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d_qc, const uint32_t *d_qs, const uint32_t *d_qe,
                                          const uint64_t *set_off, uint32_t n_sets, int32_t min_overlap, int binary,
                                          uint64_t *d_hits, void *stream) {
+    GT_SAME_DEVICE_AS(g);
     if (!g) return fail(GTARS_ERR_INVALID_ARG, "NULL handle");
     if (!set_off || n_sets == 0) return fail(GTARS_ERR_INVALID_ARG, "set_off is NULL or n_sets is 0");
     if (set_off[0] != 0) return fail(GTARS_ERR_INVALID_ARG, "set_off[0] must be 0");
@@ -2625,6 +2691,7 @@ gtars_status gtars_igd_count_sets_device(const gtars_igd_t *g, const uint32_t *d
 
 gtars_status gtars_igd_count_sets(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
                                   const uint64_t *set_off, uint32_t n_sets, int32_t min_overlap, int binary, uint64_t *hits) {
+    GT_ON_DEVICE_OF(g);
     if (!set_off || n_sets == 0) return fail(GTARS_ERR_INVALID_ARG, "set_off is NULL or n_sets is 0");
     const u64 nq = set_off[n_sets];
     gtars_status st = check_query_args(g, qc, qs, qe, nq);
@@ -2647,6 +2714,7 @@ gtars_status gtars_igd_count_sets(const gtars_igd_t *g, const uint32_t *qc, cons
 
 gtars_status gtars_igd_count(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs, const uint32_t *qe,
                              uint64_t nq, int32_t min_overlap, int binary, uint64_t *hits) {
+    GT_ON_DEVICE_OF(g);
     gtars_status st = check_query_args(g, qc, qs, qe, nq);
     if (st) return st;
     if (!hits && g->n_files) return fail(GTARS_ERR_INVALID_ARG, "hits is NULL");
@@ -2667,6 +2735,7 @@ gtars_status gtars_igd_count(const gtars_igd_t *g, const uint32_t *qc, const uin
 gtars_status gtars_igd_count_per_query(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs,
                                        const uint32_t *qe, uint64_t nq, int32_t min_overlap,
                                        uint32_t *counts) {
+    GT_ON_DEVICE_OF(g);
     gtars_status st = check_query_args(g, qc, qs, qe, nq);
     if (st) return st;
     st = require_device();
@@ -2690,6 +2759,7 @@ gtars_status gtars_igd_count_per_query(const gtars_igd_t *g, const uint32_t *qc,
 gtars_status gtars_igd_find_pairs(const gtars_igd_t *g, const uint32_t *qc, const uint32_t *qs,
                                   const uint32_t *qe, uint64_t nq, int32_t min_overlap, uint32_t **out_q,
                                   uint32_t **out_s, uint64_t *out_n) {
+    GT_ON_DEVICE_OF(g);
     gtars_status st = check_query_args(g, qc, qs, qe, nq);
     if (st) return st;
     if (!out_q || !out_s || !out_n) return fail(GTARS_ERR_INVALID_ARG, "NULL output");
@@ -2760,6 +2830,7 @@ static u32 bits_insert_pos(const u32 *S, const u32 *E, u32 n, u32 start, u32 end
 
 static gtars_status gtars_index_insert_impl(const gtars_index_t *ix, uint32_t chrom, uint32_t start, uint32_t end,
                                             uint32_t val, gtars_index_t **out) {
+    GT_ON_DEVICE_OF(ix);
     if (!out) return fail(GTARS_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (!ix) return fail(GTARS_ERR_INVALID_ARG, "NULL index");

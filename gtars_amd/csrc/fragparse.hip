@@ -8,11 +8,15 @@
 //                     barcode -> cluster lookup in the FILE's own key table (the map keys that start with "{stem}+",
 //                     split.rs:100-106), the '#' rule of the cluster file's reader (fragments.rs:61-82), the two integers as
 //                     str::parse::<u32> takes them, the chromosome id of the tokenizer's dictionary;
-//   a stable radix sort of the lines by cluster (sort.hip) and a gather put the routed fragments cluster-major, files in wave
-//   order and lines in file order inside a cluster -- the order the cluster's output file would have them;
-//   the fused tokenizer (tokenize_lds.hip) runs on those columns where they lie.
-// Back to the host go, per routed fragment, its file, the slot of its barcode in the file's table and its token ids: the
-// per-barcode regrouping (HashMap<String, Vec<u32>> of fragments.rs:35-56) stays with the host threads.
+//   a stable radix sort of the lines by (file, barcode) -- the key is the slot of the line's barcode in the wave's concatenated
+//   tables (sort.hip; unrouted and '#' lines sort last) -- and a gather of the three query columns in that order;
+//   the fused tokenizer (tokenize_lds.hip) runs on those columns where they lie;
+//   k_frag_emit       the per-barcode regrouping (HashMap<String, Vec<u32>> of fragments.rs:35-56): sorted as they are, the
+//                     fragments of one (file, barcode) are one run in line order; the runs' ids are written one after the other
+//                     (the unk id where a fragment has none), with where every run starts and which line opens it;
+//   k_crc_*           the gzip members' CRC-32 (the host threads decode the deflate streams raw).
+// Back to the host go the regrouped ids and two words per (file, barcode) slot; the host is left with one dictionary lookup and
+// one memcpy per run (host.cpp).
 // A line the reference would fail on is only DETECTED here (first file in wave order); the host re-parses that file for the
 // reference's message.  Bound: PCIe for the text in (45 bytes per fragment), then HBM; no MFMA.
 #include "common.h"
@@ -772,6 +776,15 @@ gtars_status frag_wave_device(const gtars_index_t *ix, const FragChroms *chroms,
         if (!slot && !cfg_get("GTARS_FRAG_NULL_STREAM")) GT_HIP(hipStreamCreateWithFlags(&slot, hipStreamNonBlocking));
         st = slot;
     }
+    // Whatever way this call ends, the stream is idle when it does (round-5 advisor): copies and kernels queued on `st` read and
+    // write pinned pool blocks (the files' texts, `staging`, `mailbox`) and pooled workspaces that go back to their pools when
+    // this frame unwinds -- an early error return with work still in flight would let a loader thread inflate the next file
+    // into a block the DMA engine is still reading.  The success paths have waited already: a second wait on an idle stream
+    // returns at once.
+    struct DrainStream {
+        hipStream_t s;
+        ~DrainStream() { (void)hipStreamSynchronize(s); }
+    } drain_on_exit{st};
     const u32 n_bytes = (u32)total;
     const u32 n_chunks = (n_bytes + FP_CHUNK - 1) / FP_CHUNK;
     // ---- text + tables to the device ----

@@ -127,9 +127,10 @@ bool is_regular_file(const std::string &p) {
 // gzopen / gzread + std::string::append: on a 1-MB fragment file that layer costs half as much again as the inflate itself
 // (19-21 ms against 13.7 for 3.5 MB of text on this image's zlib 1.2.11: the gz layer copies every byte out of its own buffer, and
 // the string grows by reallocation) -- and inflate is what bounds the fused fragment pipeline now that its parse runs on the GPU.
-// Same behaviour as gzread: concatenated members are decoded one after the other (flate2's MultiGzDecoder, utils.rs:115-126),
-// bytes behind the last member that do not start another one are ignored, a file without the gzip magic is passed through as it
-// is, the CRC and length of every member are checked (inflate does, with the gzip wrapper).
+// Behaviour: concatenated members are decoded one after the other (flate2's MultiGzDecoder, utils.rs:115-126), bytes behind the
+// last member that do not start another one are an error as in the reference ("invalid gzip header"; gzread would ignore them), a
+// file without the gzip magic is passed through as it is, the CRC and length of every member are checked (inflate does, with
+// the gzip wrapper).
 // the file's bytes, followed by 16 zero bytes the decoders may read into (inflate_fast.h); n = the file's length
 bool read_file_padded(const std::string &path, std::string &raw, size_t &n) {
     raw.clear();
@@ -164,7 +165,9 @@ bool inflate_gzip_members_raw(const unsigned char *p, size_t n, Out &out, std::v
     {
         const unsigned char *t = p + n - 4;
         const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
-        if (isize >= n / 2 && isize <= n * 1024) guess = isize;
+        // (trusted only up to 16x the compressed size: a crafted trailer must not pin gigabytes per loader thread before a byte is
+        // decoded -- the output grows on demand beyond the guess)
+        if (isize >= n / 2 && isize <= n * 1024) guess = std::min<size_t>(isize, 16 * n + (64u << 10));
     }
     out.resize(guess + 512);
     const bool use_zlib = cfg_get("GTARS_ZLIB_INFLATE") != nullptr;
@@ -275,7 +278,7 @@ bool read_all(const std::string &path, std::string &out, std::string &err) {
     if (raw.size() >= 18) {
         const unsigned char *t = (const unsigned char *)raw.data() + raw.size() - 4;
         const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
-        if (isize >= raw.size() / 2 && isize <= raw.size() * 1024) guess = isize;
+        if (isize >= raw.size() / 2 && isize <= raw.size() * 1024) guess = std::min<size_t>(isize, 16 * raw.size() + (64u << 10));
     }
     out.resize(guess + 64);
     z_stream z;
@@ -297,15 +300,19 @@ bool read_all(const std::string &path, std::string &out, std::string &err) {
         out_done += room - z.avail_out;
         in_done += in_before - z.avail_in;
         if (r == Z_STREAM_END) {
-            // another member?  (gzread: "concatenated gzip streams"; anything else behind the trailer is ignored)
-            if (z.avail_in == 0 && in_done < raw.size()) z.avail_in = (uInt)std::min<size_t>(raw.size() - in_done, 0x7FFFFFFFu);
+            // another member?  flate2's MultiGzDecoder (what get_dynamic_reader wraps, utils.rs:115-126) parses a header out of
+            // whatever follows a member's trailer and FAILS on bytes that are none ("invalid gzip header"); zlib's gzread would
+            // ignore them -- round 5 did, round 6 follows the reference.
+            if (in_done == raw.size()) break;
             if (raw.size() - in_done >= 2 && (unsigned char)raw[in_done] == 0x1f && (unsigned char)raw[in_done + 1] == 0x8b) {
                 inflateReset(&z);
                 z.next_in = (Bytef *)raw.data() + in_done;
                 z.avail_in = (uInt)std::min<size_t>(raw.size() - in_done, 0x7FFFFFFFu);
                 continue;
             }
-            break;
+            err = "gzip read error: invalid gzip header";
+            inflateEnd(&z);
+            return false;
         }
         if (r == Z_OK || (r == Z_BUF_ERROR && z.avail_out == 0)) {
             if (z.avail_in == 0 && in_done < raw.size()) {  // (files beyond 2 GiB compressed: the next piece)
@@ -889,18 +896,25 @@ struct gtars_tokenizer {
     // kept with the tokenizer: building it per call cost 23 ms of a 65-ms call (device allocations synchronise)
     mutable std::mutex frag_mu;
     mutable gtars::FragChroms *frag_chroms = nullptr;
-    mutable int frag_chroms_device = -1;
+    // the device the tokenizer's index lives on: where the fused fragment pipeline runs (its loaders' pinned blocks, its device
+    // threads, this table), whatever the calling thread's current device is
+    int device() const {
+        const int d = gtars_index_device(index);
+        return d >= 0 ? d : gtars::frag_current_device();
+    }
+    // Built once, on the index's device, and never freed under a running call (round 5 kept one table keyed by the CALLER's current
+    // device and freed it when a call arrived from another device -- under a concurrent call that still used it).
     gtars_status device_chroms(gtars::FragChroms **out) const {
         std::lock_guard<std::mutex> lk(frag_mu);
-        const int dev = gtars::frag_current_device();
-        if (frag_chroms && frag_chroms_device != dev) {
-            gtars::frag_chroms_free(frag_chroms);
-            frag_chroms = nullptr;
-        }
         if (!frag_chroms) {
+            const int before = gtars::frag_current_device(), want = device();
+            if (before != want) {
+                gtars_status st = gtars::frag_select_device(want);
+                if (st) return st;
+            }
             gtars_status st = gtars::frag_chroms_create(chroms.names, &frag_chroms);
+            if (before != want && before >= 0) (void)gtars::frag_select_device(before);
             if (st) return st;
-            frag_chroms_device = dev;
         }
         *out = frag_chroms;
         return GTARS_OK;
@@ -2907,7 +2921,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         st = t->device_chroms(&d_chroms);
         if (st) return st;
     }
-    const int caller_device = gtars::frag_current_device();
+    const int pipeline_device = t->device();  // the INDEX's device (round 5: the calling thread's current device)
     uint64_t reads = 0, n_all = 0;
     const bool timing = cfg_get("GTARS_HOST_TIMING") != nullptr;  // stderr: seconds per stage (tools/fragsplit_bench.py)
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -2934,7 +2948,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
     size_t in_flight = 0;       // waves queued or on the device
     bool wave_failed = false;   // a wave ended with an error (the producer stops)
     auto tok_body = [&] {
-        (void)gtars::frag_select_device(caller_device);  // (HIP's current device belongs to the thread and starts at 0)
+        (void)gtars::frag_select_device(pipeline_device);  // (HIP's current device belongs to the thread and starts at 0)
         for (;;) {
             Wave *w = nullptr;
             {
@@ -2945,6 +2959,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                 jobs.pop_front();
             }
             const double t0 = now();
+            try {  // (the body allocates: an exception on this thread must end the wave with a status, not the process)
             if (w->device) {
                 std::vector<gtars::FragFileIn> in;
                 for (TextFile &f : w->tf) {
@@ -2984,6 +2999,16 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                 uint64_t h = 0;
                 w->st = gtars_tokenize(t->index, w->c.get(), w->s.get(), w->e.get(), w->n, w->off.get(), &w->ids, &h);
                 if (w->st) w->err = gtars_last_error();
+            }
+            } catch (const std::bad_alloc &) {
+                w->st = GTARS_ERR_INTERNAL;
+                w->err = "out of host memory";
+            } catch (const std::exception &ex) {
+                w->st = GTARS_ERR_INTERNAL;
+                try {
+                    w->err = std::string("internal error: ") + ex.what();
+                } catch (...) {
+                }
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -3070,7 +3095,7 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         const uint64_t byte_limit = (cap_mb ? (uint64_t)atoll(cap_mb) : 3500ull) << 20;  // the device path's 32-bit text positions
         bool too_large = false;
         st = stream_text_files(
-            files, *m, byte_limit, caller_device,
+            files, *m, byte_limit, pipeline_device,
             [&](size_t base, std::vector<TextFile> &tf) -> gtars_status {
                 waves.emplace_back();
                 Wave &w = waves.back();

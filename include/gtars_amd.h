@@ -85,6 +85,12 @@ void gtars_index_free(gtars_index_t *ix);
 uint64_t gtars_index_len(const gtars_index_t *ix);
 uint32_t gtars_index_n_chrom(const gtars_index_t *ix);
 int gtars_index_kind(const gtars_index_t *ix);
+/* The HIP device the handle's memory lives on: the device that was current when it was built (-1 for NULL).  Host-buffer
+ * entry points run there whatever the calling thread's current device is and put the caller's device back; `*_device` entry
+ * points take the caller's device pointers and stream, so they require the calling thread's current device to BE the
+ * handle's and return GTARS_ERR_INVALID_ARG ("handle lives on device k, current device is j") otherwise.  One process per
+ * GPU (the multi-GPU layout of this library) never sees the difference; a process that drives several GPUs does. */
+int gtars_index_device(const gtars_index_t *ix);
 /* Overlapper::iter(): stored order of one chromosome copied back to the host
  * (Bits: sorted (start,end); AIList: sub-list major).  Returns its length;
  * out pointers may be NULL. */
@@ -175,17 +181,6 @@ gtars_status gtars_tokenize_into(const gtars_index_t *ix, const uint32_t *qchrom
                                  const uint32_t *qstart, const uint32_t *qend, uint64_t nq,
                                  uint64_t *offsets, uint32_t *ids, uint64_t ids_capacity,
                                  uint64_t *out_n);
-
-/* Test / diagnostics hook: launches `workgroups` workgroups of 1024 threads that each hold `lds_bytes` of LDS and spin
- * for `microseconds` on `stream` -- a stand-in for foreign work that occupies CUs while a tokenizer launch runs on
- * another stream (tests/test_gpu_parity.py: the chained scan must complete with the right result whatever is resident). */
-gtars_status gtars_debug_occupy_device(void *stream, uint32_t workgroups, uint32_t lds_bytes, uint32_t microseconds);
-
-/* Test / A-B hook.  The library reads its GTARS_* environment switches (test and ablation knobs: GTARS_IGD_SWEEP_MIN,
- * GTARS_NO_LDS_PATH, GTARS_HOST_THREADS ...) ONCE, into an immutable snapshot taken at first use -- never with a getenv per
- * call, which races with a host program's setenv.  A process that changes a switch afterwards calls this to make the library take
- * a new snapshot; no other library call may be in flight. */
-void gtars_debug_reload_env(void);
 
 /* bins[id] += 1 for every id < n_bins (device pointers): the scatter-add of gtars-scoring's count matrices
  * (CountMatrix::increment, gtars-scoring/src/fragment_scoring.rs:88-105) -- one matrix row per call, the ids being
@@ -290,6 +285,7 @@ gtars_status gtars_igd_build(const uint32_t *chrom, const int32_t *start,
 void gtars_igd_free(gtars_igd_t *g);
 uint64_t gtars_igd_len(const gtars_igd_t *g);          /* stored intervals */
 uint32_t gtars_igd_n_files(const gtars_igd_t *g);
+int gtars_igd_device(const gtars_igd_t *g); /* see gtars_index_device */
 /* what Igd::total_records() would report for nbp (tile replicas counted) */
 uint64_t gtars_igd_total_records(const gtars_igd_t *g, int32_t nbp);
 /* copy the stored records back to the host, in device order = (chrom, start, insertion order), which

@@ -40,6 +40,9 @@ def test_ctypes_binding_covers_the_header():
     assert declared == set(L.EXPORTED_SYMBOLS)
     declared_host = set(_declared_symbols("gtars_amd_host.h"))
     assert declared_host == set(L.EXPORTED_HOST_SYMBOLS)
+    # test / diagnostics hooks live in a header of their own, outside the drop-in boundary
+    assert set(_declared_symbols("gtars_amd_debug.h")) == set(L.EXPORTED_DEBUG_SYMBOLS)
+    assert not [s for s in declared | declared_host if s.startswith("gtars_debug_")]
 
 
 def test_library_is_gfx950_code_object():

@@ -2079,3 +2079,129 @@ def test_igd_routing_with_tile_bounds_in_global_memory(ga, monkeypatch):
     got = g.count_sets(sets, 1, True)
     for k, (a, b, d) in enumerate(sets):
         assert np.array_equal(got[k], o.count_region_hits(a, b, d, 1, n_files=F)), k
+
+
+def test_handles_carry_their_device_and_every_entry_point_checks_it(ga):
+    """Round 6: a handle records the device it was built on (gtars_index_device / gtars_igd_device).  `*_device` entry points take
+    the caller's device pointers, so a handle that lives elsewhere is GTARS_ERR_INVALID_ARG ("handle lives on device k, current
+    device is j") and nothing is launched; host-buffer entry points switch to the handle's device and put the caller's back.
+    The test box has one GPU: the handle's device id is forged through gtars_debug_set_handle_device (include/gtars_amd_debug.h)
+    -- the device forms must refuse, the host forms must TRY to switch (device 1 does not exist here: a HIP error, not a memory
+    fault, and the calling thread's current device stays 0), and with the real id back everything answers as before."""
+    import torch
+
+    from gtars_amd import _lib
+
+    lib = _lib.lib
+    rng = np.random.default_rng(3)
+    n, nq, F = 50_000, 80_000, 30
+    c = rng.integers(0, 3, n)
+    s = rng.integers(0, 5_000_000, n)
+    e = s + rng.integers(1, 2_000, n)
+    f = rng.integers(0, F, n)
+    g, o = _pair(ga, c, s, e, n_chrom=3)
+    ig, io = _igd_pair(ga, c, s, e, f, n_chrom=3, n_files=F)
+    qc = rng.integers(0, 3, nq).astype(np.uint32)
+    qs = rng.integers(0, 5_000_000, nq).astype(np.uint32)
+    qe = (qs + rng.integers(1, 3_000, nq)).astype(np.uint32)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cur = torch.cuda.current_device()
+    assert lib.gtars_index_device(g._h) == cur and lib.gtars_igd_device(ig._h) == cur
+    d = [torch.from_numpy(x.view(np.int32)).to(dev) for x in (qc, qs, qe)]
+    off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+    ids = torch.empty(8 * nq, dtype=torch.int32, device=dev)
+    cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+    hits = torch.zeros(F, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    want_cnt = o.count_overlaps(qc, qs, qe, None)
+    want_hits = io.count_set_overlaps(qc, qs, qe, 1, n_files=F)
+
+    def device_calls():
+        h = g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), ids.data_ptr(), ids.numel(), st)
+        g.count_overlaps_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, cnt.data_ptr(), None, st)
+        ig.count_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, hits.data_ptr(), 1, False, st)
+        torch.cuda.synchronize()
+        return h
+
+    assert device_calls() == int(want_cnt.sum())
+    assert np.array_equal(cnt.cpu().numpy().view(np.uint32), want_cnt) and np.array_equal(hits.cpu().numpy(), want_hits.astype(np.int64))
+    forged = cur + 1
+    assert lib.gtars_debug_set_handle_device(g._h, 0, forged) == cur
+    assert lib.gtars_debug_set_handle_device(ig._h, 1, forged) == cur
+    try:
+        assert lib.gtars_index_device(g._h) == forged and lib.gtars_igd_device(ig._h) == forged
+        for call in (
+            lambda: g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), ids.data_ptr(), ids.numel(), st),
+            lambda: g.count_overlaps_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, cnt.data_ptr(), None, st),
+            lambda: g.fill_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), ids.data_ptr(), st),
+            lambda: ig.count_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, hits.data_ptr(), 1, False, st),
+            lambda: ig.count_sets_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), [0, nq // 2, nq], hits.data_ptr(), 1, True, st),
+        ):
+            with pytest.raises(ValueError, match=f"handle lives on device {forged}, current device is {cur}"):
+                call()
+        # host-buffer forms select the handle's device: on this box that device does not exist
+        if torch.cuda.device_count() == forged:
+            for call in (lambda: ig.count_set_overlaps(qc, qs, qe, 1), lambda: ig.count_sets([(qc, qs, qe)], 1, True),
+                         lambda: g.count_overlaps(qc, qs, qe, None), lambda: g.tokenize(qc, qs, qe)):
+                with pytest.raises(_lib.GtarsError, match="select the handle's device"):
+                    call()
+            assert torch.cuda.current_device() == cur
+    finally:
+        assert lib.gtars_debug_set_handle_device(g._h, 0, cur) == forged
+        assert lib.gtars_debug_set_handle_device(ig._h, 1, cur) == forged
+    assert device_calls() == int(want_cnt.sum())
+    assert np.array_equal(ig.count_set_overlaps(qc, qs, qe, 1), want_hits)
+    assert np.array_equal(g.count_overlaps(qc, qs, qe, None), want_cnt)
+
+
+def test_igd_counts_from_four_host_threads_on_one_handle(ga, monkeypatch):
+    """One Igd handle, four host threads, all of them starting at once on a handle nobody has queried yet: the handle's lazily
+    built, mutex-guarded members (pme_file for the binary sweep, the contig tile counts for min_overlap <= 0, the host mirror,
+    the values-unique flag) are built under contention, every thread has its own stream workspace.  Every result against the
+    oracle (igd.rs:504-590: counts are pure functions of the database and the batch)."""
+    import threading
+
+    monkeypatch.setenv("GTARS_IGD_SWEEP_MIN", "1")
+    rng = np.random.default_rng(41)
+    n, F, n_chrom, span = 400_000, 50, 3, 40_000_000
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 3_000, n)
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, np.arange(n), n_chrom=n_chrom, n_files=F)
+    sets = [_random_query_set(rng, m, n_chrom, span + 5_000, 800) for m in (150_000, 90_000, 40_000, 70_000)]
+    want = {}
+    for k, (qc, qs, qe) in enumerate(sets):
+        want[k] = (o.count_set_overlaps(qc, qs, qe, 1, n_files=F), o.count_region_hits(qc, qs, qe, 1, n_files=F),
+                   o.count_region_hits(qc[:2000], qs[:2000], qe[:2000], 0, n_files=F),
+                   o.count_overlaps_per_query(qc[:5000], qs[:5000], qe[:5000], 1))
+    want_sets = np.stack([o.count_region_hits(qc, qs, qe, 1, n_files=F) for qc, qs, qe in sets])
+    errors, start = [], threading.Barrier(4)
+
+    def body(k):
+        try:
+            qc, qs, qe = sets[k]
+            start.wait()
+            for rep in range(3):
+                order = [(k + rep + j) % 5 for j in range(5)]  # every thread starts with a different call
+                for what in order:
+                    if what == 0:
+                        assert np.array_equal(g.count_set_overlaps(qc, qs, qe, 1), want[k][0]), (k, "pairwise")
+                    elif what == 1:
+                        assert np.array_equal(g.count_region_hits(qc, qs, qe, 1), want[k][1]), (k, "binary")
+                    elif what == 2:
+                        assert np.array_equal(g.count_region_hits(qc[:2000], qs[:2000], qe[:2000], 0), want[k][2]), (k, "min_overlap 0")
+                    elif what == 3:
+                        assert np.array_equal(g.count_overlaps_per_query(qc[:5000], qs[:5000], qe[:5000], 1), want[k][3]), (k, "per query")
+                    else:
+                        assert np.array_equal(g.count_sets(sets, 1, True), want_sets), (k, "sets")
+        except BaseException as ex:  # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(ex))
+
+    th = [threading.Thread(target=body, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert g.total_records() == o.total_records()

@@ -430,7 +430,7 @@ def test_gzip_reader_follows_the_multi_member_decoder(tmp_path):
     much again as the inflate).  What a reader of gtars-core/src/utils.rs:115-126 (flate2's MultiGzDecoder behind the "gz"
     extension) and zlib's gzread both do: concatenated members are decoded one after the other, a large file (several output
     growth steps: its ISIZE lies about the length when members are concatenated), bytes behind the last member that do not
-    start another one are ignored, a ".gz" without the gzip magic is read as it is, an empty file is empty; a file that ends
+    start another one are an error (MultiGzDecoder: "invalid gzip header"; round 5 ignored them like gzread), a ".gz" without the gzip magic is read as it is, an empty file is empty; a file that ends
     inside a member, or whose CRC is wrong, is an error."""
     import gzip
 
@@ -453,7 +453,8 @@ def test_gzip_reader_follows_the_multi_member_decoder(tmp_path):
     (tmp_path / "three.bed.gz").write_bytes(one + gzip.compress(text.encode(), 1) + one)
     check(tmp_path / "three.bed.gz", 60_000)
     (tmp_path / "tail.bed.gz").write_bytes(one + b"\x00\x00garbage that is no gzip header")
-    check(tmp_path / "tail.bed.gz", 20_000)
+    with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error: invalid gzip header"):
+        utils.read_fragments(str(tmp_path / "tail.bed.gz"))  # (MultiGzDecoder fails on it; gzread would ignore it)
     (tmp_path / "plain.bed.gz").write_text(text)  # no magic: passed through
     check(tmp_path / "plain.bed.gz", 20_000)
     (tmp_path / "empty.bed.gz").write_bytes(b"")
@@ -519,8 +520,12 @@ def test_whole_buffer_inflate_decodes_what_zlib_writes(tmp_path, monkeypatch, de
         p.write_bytes(hdr + ((zlib.crc32(hdr) ^ 1) & 0xFFFF).to_bytes(2, "little") + tail)
         with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error: header crc mismatch"):
             _read_file(p)
-        p.write_bytes(gz(a) + b"garbage")  # (gzread: ignored)
-        assert _read_file(p) == a
+        p.write_bytes(gz(a) + b"garbage")  # (gzread: ignored; flate2's MultiGzDecoder, the reference's reader: an error)
+        with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error: invalid gzip header"):
+            _read_file(p)
+        p.write_bytes(gz(a) + b"\x1f")  # one stray byte
+        with pytest.raises((RuntimeError, ValueError, OSError), match="gzip read error: invalid gzip header"):
+            _read_file(p)
         blob = bytearray(gz(frag))
         blob[-5] ^= 1
         p.write_bytes(bytes(blob))
