@@ -1252,6 +1252,11 @@ static bool use_lds_path(const gtars_index *ix) {
     return !disabled && ix->has_accel && tokenize_lds_supported(ix->accel());
 }
 
+static bool sweep_wanted(const gtars_index *ix, const EnumOut &out) {
+    if (cfg_flag("GTARS_NO_LDS_PATH") || cfg_flag("GTARS_NO_LDS_PATH_FOR_TEST") || cfg_flag("GTARS_TOK_NO_SWEEP")) return false;
+    return (out.sorted || cfg_flag("GTARS_TOK_SWEEP")) && ix->has_accel && tokenize_sweep_supported(ix->accel());
+}
+
 // K2 dispatch: Bits-kind indexes with the blocked structure count through k_count_lds, everything else
 // (AIList order is irrelevant for counts, but its index has no blocked structure) through k_count
 // the index whose blocked structure answers an ORDER-INDEPENDENT call on `ix`: ix itself, the flat companion of a nested AIList
@@ -1273,6 +1278,11 @@ static gtars_status run_fused(const gtars_index *ix, const u32 *qc, const u32 *q
     // of the tile overlapping every interval of the largest chromosome) instead of returning wrapped offsets
     if ((u64)ix->max_chrom_n() * (u64)enumerate_fused_tile_queries() > 0xFFFFFFFFull)
         return fail(GTARS_ERR_INVALID_ARG, "index too dense: a tile of queries could have more than 2^32 - 1 hits");
+    // a batch in (chromosome, start) order (the caller's hint, or GTARS_TOK_SWEEP=1: tests and A/B runs): the sweep form -- needs the
+    // blocked records only, not the LDS search image, so it also serves universes beyond k_tok_lds' key budget
+    if (sweep_wanted(ix, out) && !out.starts && !out.ends)
+        return launch_tokenize_sweep(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s, nullptr, nullptr,
+                                     ix->kind == GTARS_KIND_AILIST);
     if (use_lds_path(ix) && !out.starts && !out.ends)
         return launch_tokenize_lds(ix->accel(), qc, qs, qe, nq, has_min, min_overlap, out, ws, ws_bytes, ep, s, nullptr, nullptr,
                                    ix->kind == GTARS_KIND_AILIST);
@@ -1338,13 +1348,13 @@ gtars_status gtars_tokenize_device_ex(const gtars_index_t *ix, const uint32_t *d
     gtars_status st = check_query_args(ix, d_qc, d_qs, d_qe, nq);
     if (st) return st;
     if (!d_offsets) return fail(GTARS_ERR_INVALID_ARG, "d_offsets is NULL");
-    if (hint != GTARS_TOK_AUTO && hint != GTARS_TOK_NARROW && hint != GTARS_TOK_WIDE) return fail(GTARS_ERR_INVALID_ARG, "unknown tokenizer hint");
+    if ((hint & ~(3 | GTARS_TOK_SORTED)) || (hint & 3) == 3) return fail(GTARS_ERR_INVALID_ARG, "unknown tokenizer hint");
     hipStream_t s = (hipStream_t)stream;
     Workspace &ws = tls_workspace(0, s);
     const size_t wsb = fused_ws_bytes(ix, nq);
     st = ws.reserve(wsb);
     if (st) return st;
-    EnumOut out{d_offsets, d_ids, nullptr, nullptr, d_ids ? ids_capacity : 0, hint};
+    EnumOut out{d_offsets, d_ids, nullptr, nullptr, d_ids ? ids_capacity : 0, hint & 3, (hint & GTARS_TOK_SORTED) != 0};
     if (!total_hits) return run_fused(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s);
     {
         st = run_fused_sync(ix, d_qc, d_qs, d_qe, nq, 0, 0, out, ws.ptr, ws.bytes, ws.ep, s, total_hits);

@@ -185,6 +185,7 @@ struct EnumOut {
     u32 *ends;       // may be null
     u64 capacity;    // elements available in each non-null output
     int hint = 0;    // GTARS_TOK_AUTO / _NARROW / _WIDE (gtars_amd.h): which build of the LDS tokenizer a launch runs
+    bool sorted = false;  // GTARS_TOK_SORTED: the batch is in (chromosome, start) order -> the sweep form (k_tok_sweep)
 };
 
 // Head of every fused-scan workspace; after the launch has completed the host
@@ -213,6 +214,12 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
                                  u64 *d_total_out = nullptr, bool reverse = false);
 size_t tokenize_lds_ws_bytes(u64 nq);
 bool tokenize_lds_supported(const AccelView &a);
+// the same call for a batch in (chromosome, start) order (k_tok_sweep: a tile of consecutive queries stages its contiguous slice of the
+// blocked records in LDS; any universe size)
+gtars_status launch_tokenize_sweep(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min, i32 min_overlap,
+                                   const EnumOut &out, void *scan_ws, size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st,
+                                   const u64 *d_base, u64 *d_total_out, bool reverse);
+bool tokenize_sweep_supported(const AccelView &a);
 
 gtars_status launch_count_lds(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min,
                               i32 min_overlap, u32 *counts, u8 *any, hipStream_t st);

@@ -843,7 +843,10 @@ __device__ __forceinline__ void igd_walk_ref_order(const IgdView &v, u32 c, i32 
     if (c >= v.n_chrom) return;
     const u32 seg_lo = v.chrom_off[c], seg_hi = v.chrom_off[c + 1];
     if (seg_lo == seg_hi) return;
-    if (qs < 0) return;  // the reference indexes tiles[n1] with n1 < 0 -> panic; no result defined
+    // A negative start (a u32 start >= 2^31 `as i32`, igd.rs:709) is not validated here: n1 = qs / nbp truncates towards zero, so
+    // -nbp < qs < 0 walks from tile 0 with the raw start (the same hits as a start of 0); from -nbp down the reference indexes
+    // tiles[n1] with n1 < 0 and panics -- no result defined, none returned.
+    if (qs <= -IGD_NBP) return;
     const i32 n1 = qs / IGD_NBP;
     const bool tiled = min_overlap < 1;  // see IgdQual: the first tile then only serves the records PRESENT in it
     if (tiled && n1 >= v.chrom_ntiles[c]) return;

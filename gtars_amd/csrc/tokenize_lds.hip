@@ -1202,6 +1202,535 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
 #endif
 }
 
+// ---------------------------------------------------------------- k_tok_sweep: batches in (chromosome, start) order
+// What Tokenizer.tokenize(path) always delivers: a file-loaded RegionSet is stably sorted by (chr, start)
+// (gtars-core/src/models/region_set.rs:182, 502-505), and sorted BED input is the norm.  k_tok_lds serves such a batch like any
+// other: 132 KB of search keys copied into every workgroup's LDS, one record request per query.  But 256 CONSECUTIVE sorted queries
+// -- a wave's share of a round -- need a CONTIGUOUS slice of the blocked records (13 blocks at config 2's density, less than one in
+// a 64M-query batch) and nothing else of the index: no search image, no prologue, and universes of any size (the 16-bit key image
+// of k_tok_lds holds ~65k keys: beyond ~130k regions it pays a dependent global read per query).
+// Every WAVE works for itself until the tile's scan -- no workgroup barrier in the count phase, so the sixteen waves' dependent
+// round trips overlap each other (a first cut with workgroup-wide runs, ranges and staging behind four barriers per tile ran at half
+// the speed of k_tok_lds: profiles/r06).  Per wave and round of 256 queries:
+//   1. RUNS.  A query opens a run when its chromosome differs from its predecessor's or its start is smaller (DPP; the wave's first
+//      query always opens one).  A wave inside one chromosome of a sorted batch has ONE run, a chromosome boundary makes two.
+//   2. WINDOW.  64 probes per round trip narrow the chromosome's blocks to a window of <= 64 that holds the first block whose key
+//      (the prefix maximum of the ends, blk_first) is > the run's first start: nothing in front of that block can overlap any
+//      query of the run -- the argument of k_tok_lds' search (Bits::find starts at lower_bound(start - max_len), bits.rs:141-156:
+//      same hits, same order).  One round for a chromosome of <= 4096 blocks.
+//   3. STAGE.  From the window's start on, 64 blocks per round trip (own two intervals + key, 20 bytes per block) go to the wave's
+//      LDS region until a block starts at or beyond the run's largest end (bits.rs:441-443 ends every scan there): one round trip
+//      for a run that spans <= ~60 blocks.
+//   4. COUNT.  Per query a binary search of the staged keys and a forward walk of the staged intervals, all in LDS: the first
+//      candidate block and a 32-bit hit mask over the 32 intervals from it on travel to the write phase (a query with hits beyond
+//      them walks the rest from global memory, like k_tok_lds' walk_tail: rare).
+// Then, per tile: scan, publish, chained look-back, id compaction (in the wave's region, dead by then) and stores as in k_tok_lds,
+// one tile behind.  Anything else still gets the right answer, slowly: a third run in a wave's round (a shuffled batch), a run
+// that outgrows the region -- those queries search and walk in global memory (sweep_query_global).  The caller chooses this
+// kernel (GTARS_TOK_SORTED; the host-buffer entry points probe the batch's order on the host first).
+constexpr u32 SWP_RUNS = 2;      // runs per wave and round that are staged
+constexpr u32 SWP_MASK_IV = 32;  // intervals covered by a query's hit mask, from its first candidate block on
+
+// a query on the global arrays: first candidate block, hit mask over the first SWP_MASK_IV intervals, hit count, "hits beyond"
+template <bool FILTER>
+__device__ __forceinline__ void sweep_query_global(const AccelView &a, u32 c, u32 s, u32 e, i32 min_bp, u32 &b0, u32 &mask, u32 &n,
+                                                   bool &more) {
+    const u32 bb = c ? a.chrom_tab[c - 1].w : 0u, be = a.chrom_tab[c].w;
+    u32 lo = bb, hi = be;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (a.blk_first[mid] <= s)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    b0 = lo;
+    mask = 0;
+    n = 0;
+    more = false;
+    u32 idx = 0;
+    for (u32 b = lo; b < be; ++b, idx += 2) {
+        const uint4 S = a.rec2[(size_t)b * 2], E = a.rec2[(size_t)b * 2 + 1];
+        if (!(S.x < e)) break;  // starts ascend: the scan ends at the first start >= q_end (bits.rs:441-443)
+        const bool h0 = hit_test<FILTER>(S.x, E.x, s, e, min_bp);
+        const bool go = S.y < e;
+        const bool h1 = go && hit_test<FILTER>(S.y, E.y, s, e, min_bp);
+        if (idx < SWP_MASK_IV)
+            mask |= ((h0 ? 1u : 0u) | (h1 ? 2u : 0u)) << idx;
+        else
+            more = more || h0 || h1;
+        n += (h0 ? 1u : 0u) + (h1 ? 1u : 0u);
+        if (!go) break;
+    }
+}
+// the hits of a query from block `from` on (global memory): f(block, slot) in scan order
+template <bool FILTER, class F>
+__device__ __forceinline__ void sweep_walk_from(const AccelView &a, u32 from, u32 be, u32 s, u32 e, i32 min_bp, F &&f) {
+    for (u32 b = from; b < be; ++b) {
+        const uint4 S = a.rec2[(size_t)b * 2], E = a.rec2[(size_t)b * 2 + 1];
+        if (!(S.x < e)) break;
+        if (hit_test<FILTER>(S.x, E.x, s, e, min_bp)) f(b, 0u);
+        if (!(S.y < e)) break;
+        if (hit_test<FILTER>(S.y, E.y, s, e, min_bp)) f(b, 1u);
+    }
+}
+template <bool FILTER>
+__device__ __forceinline__ u64 help_count_tile_sweep(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 q_begin,
+                                                     u64 q_end, i32 min_bp) {
+    u64 n = 0;
+    for (u64 q = q_begin + (threadIdx.x & 63); q < q_end; q += 64) {
+        const u32 c = qc[q];
+        if (c >= a.n_chrom) continue;
+        u32 b0, m, k;
+        bool more;
+        sweep_query_global<FILTER>(a, c, qs[q], qe[q], min_bp, b0, m, k, more);
+        n += k;
+    }
+    return wave_reduce_sum_u64(n);
+}
+// largest value of the wave (every lane gets it): the DPP steps of wave_inclusive_scan_u32 with an unsigned maximum
+__device__ __forceinline__ u32 wave_max_u32(u32 x) {
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return (u32)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// what a lane keeps about its four queries of a round between the count phase and the write phase
+struct SweepQ {
+    u32 st[4];      // ids that follow from the position: ACC_OWN * b0 + idc[chrom]; otherwise the first candidate block b0
+    u32 mask[4];    // hits among the SWP_MASK_IV intervals from block b0 on
+    u32 excl, wtotal;
+    u32 more_bits;  // bit j: query j has hits beyond the mask
+};
+
+// count phase of one wave's round: runs, window, staging into the wave's region `reg` (cap_w blocks: starts | ends | keys), counts.
+template <bool FILTER, bool IMPL>
+__device__ __forceinline__ u32 sweep_count_round(const AccelView &a, const u32 (&c)[4], const u32 (&s)[4], const u32 (&e)[4], i32 min_bp,
+                                                 u32 *reg, u32 cap_w, u32 max_runs, int lane, SweepQ &t, u64 *ts_acc, u64 &ts_last) {
+    constexpr int QPT = 4;
+    (void)ts_acc;
+    (void)ts_last;
+#if GTARS_TOK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (diagnostic build only: separates the query-load wait)
+#endif
+    TSTAMP(0);
+    // the region: {start, end} of the blocks' own intervals (16 bytes per block: one write per block, one 8-byte read per interval) | keys
+    uint2 *r_iv = reinterpret_cast<uint2 *>(reg);
+    u32 *r_key = reg + 4u * cap_w;
+    // ---- 1. runs
+    bool valid[QPT], nr[QPT];
+    {
+        // the previous lane's last query (wave_shr:1; lane 0 reads `old`: an unknown chromosome, so its first query opens a run)
+        const u32 upc = (u32)__builtin_amdgcn_update_dpp((int)GTARS_UNKNOWN_CHROM, (int)c[QPT - 1], 0x138, 0xf, 0xf, false);
+        const u32 ups = (u32)__builtin_amdgcn_update_dpp(0, (int)s[QPT - 1], 0x138, 0xf, 0xf, false);
+        u32 lc = upc, ls = ups;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            valid[j] = c[j] < a.n_chrom;
+            nr[j] = valid[j] && (c[j] != lc || s[j] < ls);  // (an invalid predecessor never equals a valid chromosome)
+            lc = c[j];
+            ls = s[j];
+        }
+    }
+    u32 cnt = 0;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) cnt += nr[j] ? 1u : 0u;
+    const u32 inc_r = wave_inclusive_scan_u32(cnt, lane);
+    const u32 n_runs = (u32)__builtin_amdgcn_readlane((int)inc_r, 63);
+    u32 rid[QPT];
+    {
+        u32 r = inc_r - cnt;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            r += nr[j] ? 1u : 0u;
+            rid[j] = r - 1u;  // (a valid query always has a run: the wave's first valid query opens one)
+        }
+    }
+    // ---- 2. + 3. per run: window, staging.  Wave-uniform results: first staged block, staged blocks, region offset, id correction
+    u32 run_lo[SWP_RUNS], run_len[SWP_RUNS], run_off[SWP_RUNS], run_idc[SWP_RUNS], run_be[SWP_RUNS];
+    u32 used = 0;
+#pragma unroll
+    for (u32 r = 0; r < SWP_RUNS; ++r) {
+        run_lo[r] = run_len[r] = run_idc[r] = run_be[r] = 0;
+        run_off[r] = 0xFFFFFFFFu;  // not staged
+        if (r >= n_runs || r >= max_runs) continue;  // (wave-uniform)
+        // the run's first query and largest end
+        u32 cc = 0, ss = 0, me = 0;
+        bool has = false;
+#pragma unroll
+        for (int j = QPT - 1; j >= 0; --j) {
+            const bool mine = valid[j] && rid[j] == r;
+            me = mine ? max(me, e[j]) : me;
+            if (nr[j] && rid[j] == r) {
+                has = true;
+                cc = c[j];
+                ss = s[j];
+            }
+        }
+        const unsigned long long hb = __ballot(has);
+        const int src = __ffsll((long long)hb) - 1;  // (exactly one lane opens run r)
+        const u32 cr = (u32)__builtin_amdgcn_readlane((int)cc, src), s0 = (u32)__builtin_amdgcn_readlane((int)ss, src);
+        const u32 max_e = wave_max_u32(me);
+        const u32 bb = cr ? a.chrom_tab[cr - 1].w : 0u, be = a.chrom_tab[cr].w;
+        run_idc[r] = a.idc[cr];
+        run_be[r] = be;
+        // window: [lo, hi] holds the first block with key > s0 (hi == be: possibly none)
+        u32 lo = bb, hi = be;
+        bool hi_holds = false;  // blk_first[hi] > s0 is known (hi < be)
+        while (hi - lo > 64u) {
+            const u32 n = hi - lo, chunk = (n + 63u) >> 6;
+            const u32 last = lo + min(n - 1u, (u32)lane * chunk + chunk - 1u);  // the last block of the lane's chunk
+            const bool p = (u32)lane * chunk < n && a.blk_first[last] > s0;
+            const unsigned long long b = __ballot(p);
+            if (!b) {  // nothing in [lo, hi): the block at hi if it is known to hold, otherwise no key of the chromosome is > s0
+                lo = hi = hi_holds ? hi : be;
+                break;
+            }
+            const u32 f = (u32)__ffsll((long long)b) - 1u;
+            const u32 nlo = lo + f * chunk;
+            hi = lo + min(n - 1u, f * chunk + chunk - 1u);
+            hi_holds = true;
+            lo = nlo;
+        }
+        TSTAMP(1);
+        // stage from `lo` on, 64 blocks per round trip, until a block starts at or beyond the run's largest end
+        run_lo[r] = lo;
+        run_off[r] = used;
+        u32 len = 0;
+        bool fits = true;
+        for (u32 b0 = lo; b0 < be;) {
+            const u32 nb = min(64u, be - b0);
+            if (used + len + nb > cap_w) {
+                fits = false;
+                break;
+            }
+            const bool in = (u32)lane < nb;
+            uint4 S = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0), E = make_uint4(0, 0, 0, 0);
+            u32 key = 0xFFFFFFFFu;
+            if (in) {
+                const u32 b = b0 + (u32)lane;
+                S = a.rec2[(size_t)b * 2];
+                E = a.rec2[(size_t)b * 2 + 1];
+                key = a.blk_first[b];
+                const u32 w = used + len + (u32)lane;
+                *reinterpret_cast<uint4 *>(r_iv + 2u * w) = make_uint4(S.x, E.x, S.y, E.y);
+                r_key[w] = key;
+            }
+            len += nb;
+            b0 += nb;
+            if (__ballot(in && S.x >= max_e)) break;  // (padding blocks start at 0xFFFFFFFF)
+        }
+        if (fits) {
+            run_len[r] = len;
+            used += len;
+        } else {
+            run_off[r] = 0xFFFFFFFFu;  // the run outgrows the region: its queries go to global memory
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if GTARS_TOK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    TSTAMP(2);
+    auto run_be_of = [&](int j) -> u32 {
+        u32 b = 0;
+#pragma unroll
+        for (u32 r = 0; r < SWP_RUNS; ++r) b = valid[j] && rid[j] == r ? run_be[r] : b;
+        return b;
+    };
+    // ---- 4. count
+    // Everything below is written so that a lane's four queries have their LDS reads in flight TOGETHER and no read sits behind
+    // a branch: reads at clamped addresses, selects instead of conditions.  (The first cut's `if (left) { read; compare }` came out
+    // as four guarded reads per step, each with its own wait: 28 dependent LDS round trips per search, 6000 cycles per round and
+    // wave by the in-kernel stamps -- a quarter of the kernel.)
+    u32 tsum = 0;
+    t.more_bits = 0;
+    u32 off[QPT], len[QPT], pos[QPT], left[QPT], lo_b[QPT], idc[QPT];
+    bool lds_q[QPT];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        u32 o = 0xFFFFFFFFu, l = 0, lb = 0, ic = 0;
+#pragma unroll
+        for (u32 r = 0; r < SWP_RUNS; ++r) {
+            const bool mine = valid[j] && rid[j] == r;
+            o = mine ? run_off[r] : o;
+            l = mine ? run_len[r] : l;
+            lb = mine ? run_lo[r] : lb;
+            ic = mine ? run_idc[r] : ic;
+        }
+        lds_q[j] = o != 0xFFFFFFFFu;
+        off[j] = lds_q[j] ? o : 0u;
+        len[j] = lds_q[j] ? l : 0u;
+        lo_b[j] = lb;
+        idc[j] = ic;
+        pos[j] = 0;
+        left[j] = len[j];
+    }
+    // lockstep binary searches of the staged keys: first key > q_start (the trip count is the wave's: the runs' lengths are uniform)
+    u32 steps = 0;
+#pragma unroll
+    for (u32 r = 0; r < SWP_RUNS; ++r) steps = max(steps, 32u - (u32)__clz((int)run_len[r]));
+    for (u32 it = 0; it < steps; ++it) {
+        u32 key[QPT], half[QPT], mid[QPT];
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            half[j] = left[j] >> 1;
+            mid[j] = pos[j] + half[j];
+            key[j] = r_key[off[j] + (mid[j] < len[j] ? mid[j] : 0u)];  // (an address inside the region whatever the lane's state)
+        }
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const bool below = (left[j] != 0u) & (key[j] <= s[j]);
+            pos[j] = below ? mid[j] + 1u : pos[j];
+            left[j] = below ? left[j] - half[j] - 1u : half[j];
+        }
+    }
+    TSTAMP(3);
+    // lockstep walks of the staged intervals from the block found
+    u32 m[QPT], n[QPT], i[QPT], i0[QPT], i1[QPT];
+    bool act[QPT], more[QPT], redo[QPT];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        m[j] = n[j] = 0;
+        more[j] = redo[j] = false;
+        i0[j] = 2u * (off[j] + pos[j]);
+        i1[j] = 2u * (off[j] + len[j]);
+        i[j] = i0[j];
+        act[j] = lds_q[j] & (i0[j] < i1[j]);
+        any = any | act[j];
+    }
+    while (__ballot(any)) {
+        uint2 iv[QPT];
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) iv[j] = r_iv[i[j] < i1[j] ? i[j] : 2u * off[j]];
+        any = false;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const bool go = act[j] & (iv[j].x < e[j]);  // (bits.rs:441-443: the scan ends at the first start >= q_end)
+            const bool h = go & hit_test<FILTER>(iv[j].x, iv[j].y, s[j], e[j], min_bp);
+            const u32 rel = i[j] - i0[j];
+            m[j] |= (h & (rel < SWP_MASK_IV)) ? 1u << (rel & 31u) : 0u;
+            more[j] = more[j] | (h & (rel >= SWP_MASK_IV));
+            n[j] += h ? 1u : 0u;
+            i[j] += go ? 1u : 0u;
+            act[j] = go & (i[j] < i1[j]);
+            any = any | act[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        u32 b0 = lo_b[j] + pos[j];
+        // the walk ran off the staged blocks before a start >= q_end (cannot happen: staging ends behind the run's largest end or at
+        // the chromosome's end -- kept as a guard): the whole query again on the global arrays
+        const bool ran_off = lds_q[j] && i[j] == i1[j] && i1[j] > i0[j] && r_iv[i1[j] - 1u].x < e[j] && lo_b[j] + len[j] < run_be_of(j);
+        if ((valid[j] && !lds_q[j]) || ran_off) {
+            bool mo = false;
+            sweep_query_global<FILTER>(a, c[j], s[j], e[j], min_bp, b0, m[j], n[j], mo);
+            more[j] = mo;
+            idc[j] = a.idc[c[j]];
+        }
+        t.mask[j] = m[j];
+        t.st[j] = IMPL ? (u32)ACC_OWN * b0 + idc[j] : b0;
+        t.more_bits |= (more[j] ? 1u : 0u) << j;
+        tsum += n[j];
+    }
+    TSTAMP(4);
+    return tsum;
+}
+
+// Emits the hits of a lane's four queries of a round in result order (emit_queries' contract): put(position, id) when want_ids,
+// o4[j] = position of query j's first hit.
+template <bool FILTER, bool IMPL, bool REV, class Put>
+__device__ __forceinline__ void emit_sweep(const AccelView &a, const u32 *__restrict__ qc, const u32 *__restrict__ qs,
+                                           const u32 *__restrict__ qe, i32 min_bp, const SweepQ &t, u64 q0, u64 run, bool want_ids,
+                                           u64 (&o4)[4], Put &&put) {
+    const u32 *recw = reinterpret_cast<const u32 *>(a.rec4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o4[j] = run;
+        u32 m = t.mask[j];
+        u32 n_all = __popc(m);
+        const bool more = (t.more_bits & (1u << j)) != 0;
+        u32 cq = 0, sq = 0, eq = 0, b0 = IMPL ? 0u : t.st[j], be = 0;
+        if (more) {  // hits beyond the mask's intervals: counted, then walked (rare)
+            cq = qc[q0 + j];
+            sq = qs[q0 + j];
+            eq = qe[q0 + j];
+            be = a.chrom_tab[cq].w;
+            if (IMPL) b0 = (t.st[j] - a.idc[cq]) / (u32)ACC_OWN;
+            sweep_walk_from<FILTER>(a, b0 + SWP_MASK_IV / 2u, be, sq, eq, min_bp, [&](u32, u32) { ++n_all; });
+        }
+        if (want_ids && n_all) {
+            auto slot = [&](u32 i) -> u64 { return REV ? run + (n_all - 1u - i) : run + i; };
+            u32 i = 0;
+            while (m) {
+                const u32 k = (u32)__ffs((int)m) - 1u;
+                m &= m - 1u;
+                put(slot(i++), IMPL ? t.st[j] + k : recw[(size_t)(b0 + (k >> 1)) * 16u + 8u + (k & 1u)]);
+            }
+            if (more)
+                sweep_walk_from<FILTER>(a, b0 + SWP_MASK_IV / 2u, be, sq, eq, min_bp, [&](u32 b, u32 k) {
+                    put(slot(i++), IMPL ? t.st[j] + (u32)ACC_OWN * (b - b0) + k : recw[(size_t)b * 16u + 8u + k]);
+                });
+        }
+        run += n_all;
+    }
+}
+
+template <int TPB, int R, bool FILTER, bool IMPL, bool REV>
+__global__ void __launch_bounds__(TPB, 4)
+k_tok_sweep(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe, u64 nq, i32 min_bp,
+            u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws, u32 epoch, u32 ticket_base, u32 region_words,
+            u32 spin_limit, const u64 *__restrict__ d_base, u64 *__restrict__ d_total_out, u32 cap_w, u32 max_runs) {
+    extern __shared__ __attribute__((aligned(16))) u32 smem[];
+    constexpr int QPT = 4, NW = TPB / 64;
+    constexpr u32 ROUND = TPB * QPT, TILE = ROUND * R;
+    static_assert(NW * R <= 64, "one lane per wave part in the tile's scan");
+    __shared__ u32 s_tile, s_scan[NW * R];
+    __shared__ u64 s_prefix;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32 *reg = smem + (size_t)wave * region_words;  // the wave's region: staged blocks in the count phase, id staging in the write phase
+    const u32 num_tiles = (u32)((nq + TILE - 1) / TILE);
+    const bool vec_ok = ((((uintptr_t)qc) | ((uintptr_t)qs) | ((uintptr_t)qe)) & 15u) == 0;
+    const bool off_vec_ok = (((uintptr_t)offsets) & 15u) == 0;
+    const u64 base = d_base ? *d_base : 0ull;
+    const u32 first_tiles = gridDim.x;
+    const bool draw = num_tiles > first_tiles;
+    auto help = [&](u32 t) -> u64 {
+        const u64 qb = (u64)t * TILE, qn = qb + TILE < nq ? qb + TILE : nq;
+        return help_count_tile_sweep<FILTER>(a, qc, qs, qe, qb, qn, min_bp);
+    };
+    struct Prev {
+        SweepQ q[R];
+        u32 wbase[R], total, tile;
+    } cur, prev;
+    bool have_prev = false;
+    u32 tile = blockIdx.x;
+    u64 ts_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_last = 0;
+#if GTARS_TOK_STAMPS
+    ts_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (;;) {
+        const bool has_cur = tile < num_tiles;
+        u32 next_tile = num_tiles;
+        if (has_cur) {
+            u32 ticket = 0;
+            if (draw && threadIdx.x == 0) ticket = atomicAdd(&ws->ticket, 1u);
+            u32 tsum[R], inc[R];
+            // a wave's rounds one after the other, the next round's queries in flight while the current one is served
+            u32 c[QPT], s[QPT], e[QPT];
+            load_queries<QPT>(qc, qs, qe, nq, (u64)tile * TILE + (u64)threadIdx.x * QPT, vec_ok, c, s, e);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                u32 c2[QPT], s2[QPT], e2[QPT];
+                if (r + 1 < R) load_queries<QPT>(qc, qs, qe, nq, (u64)tile * TILE + (u64)(r + 1) * ROUND + (u64)threadIdx.x * QPT, vec_ok, c2, s2, e2);
+                tsum[r] = sweep_count_round<FILTER, IMPL>(a, c, s, e, min_bp, reg, cap_w, max_runs, lane, cur.q[r], ts_acc, ts_last);
+                if (r + 1 < R) {
+#pragma unroll
+                    for (int j = 0; j < QPT; ++j) {
+                        c[j] = c2[j];
+                        s[j] = s2[j];
+                        e[j] = e2[j];
+                    }
+                }
+                inc[r] = wave_inclusive_scan_u32(tsum[r], lane);
+                if (lane == 63) s_scan[r * NW + wave] = inc[r];
+            }
+            if (draw && threadIdx.x == 0) s_tile = first_tiles + (ticket - ticket_base);
+            lds_barrier();
+            TSTAMP(5);
+            if (draw) next_tile = s_tile;
+            const u32 v = lane < NW * R ? s_scan[lane] : 0u;
+            const u32 vinc = wave_inclusive_scan_u32(v, lane);
+            cur.total = __builtin_amdgcn_readlane(vinc, 63);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                cur.q[r].wtotal = __builtin_amdgcn_readlane(v, r * NW + wave);
+                cur.wbase[r] = __builtin_amdgcn_readlane(vinc, r * NW + wave) - cur.q[r].wtotal;
+                cur.q[r].excl = inc[r] - tsum[r];
+            }
+            cur.tile = tile;
+            if (threadIdx.x == 0) publish_aggregate(ws->state, tile, (u64)cur.total + (tile == 0 ? base : 0ull), epoch);
+        }
+        // ---- resolve + write the PREVIOUS tile (round 0's ids are staged before the base is known: by waves 1.. while wave 0 looks
+        // back, by wave 0 right after)
+        u32 orel[QPT];
+        auto stage_round = [&](int r) -> bool {
+            if (cap && prev.q[r].wtotal > region_words) return false;
+            u64 o4[QPT];
+            emit_sweep<FILTER, IMPL, REV>(a, qc, qs, qe, min_bp, prev.q[r], (u64)prev.tile * TILE + (u64)r * ROUND + (u64)threadIdx.x * QPT,
+                                          (u64)prev.q[r].excl, cap != 0, o4, [&](u64 pos, u32 id) { reg[(u32)pos] = id; });
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) orel[j] = (u32)o4[j];
+            return true;
+        };
+        bool pre0 = false;
+        if (have_prev && wave != 0) pre0 = stage_round(0);
+        if (have_prev && wave == 0) {
+            const u64 excl = resolve_prefix_helping<1>(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help);
+            if (lane == 0) {
+                s_prefix = excl;
+                if (prev.tile == num_tiles - 1) {
+                    offsets[nq] = excl + (u64)prev.total;
+                    ws->total = excl + (u64)prev.total;
+                    if (d_total_out) *d_total_out = excl + (u64)prev.total;
+                }
+            }
+            pre0 = stage_round(0);
+        }
+        TSTAMP(6);
+        if (have_prev) {
+            lds_barrier();  // s_prefix
+            TSTAMP(7);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const u64 q0 = (u64)prev.tile * TILE + (u64)r * ROUND + (u64)threadIdx.x * QPT;
+                const u64 wave_base = s_prefix + prev.wbase[r];
+                const bool staged = r == 0 ? pre0 : stage_round(r);
+                if (staged) {
+                    flush_queries<QPT>(nq, prev.q[r].wtotal, orel, q0, wave_base, offsets, ovals, cap, off_vec_ok, reg, lane);
+                } else {
+                    u64 o4[QPT];
+                    emit_sweep<FILTER, IMPL, REV>(a, qc, qs, qe, min_bp, prev.q[r], q0, wave_base + prev.q[r].excl, cap != 0, o4,
+                                                  [&](u64 pos, u32 id) {
+                                                      if (pos < cap) ovals[pos] = id;
+                                                  });
+                    if (off_vec_ok && q0 + QPT <= nq) {
+#pragma unroll
+                        for (int h = 0; h < QPT / 2; ++h) st_stream2(offsets + q0 + 2 * h, o4[2 * h], o4[2 * h + 1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < QPT; ++j)
+                            if (q0 + j < nq) offsets[q0 + j] = o4[j];
+                    }
+                }
+                // (the region is reused by the next round's ids / the next tile's blocks: LDS operations of a wave execute in order)
+            }
+        }
+        TSTAMP(8);
+        lds_barrier();  // s_tile / s_prefix / s_scan reuse
+        TSTAMP(9);
+        if (!has_cur) break;
+        prev = cur;
+        have_prev = true;
+        tile = next_tile;
+    }
+#if GTARS_TOK_STAMPS
+    if (lane == 0 && wave < 2) {
+        for (int k = 0; k < 11; ++k) atomicAdd(&g_tok_stamps[wave][k], ts_acc[k]);
+        atomicAdd(&g_tok_stamps[wave][11], 1ull);
+    }
+#endif
+}
+
 // branch-free form of load_queries for 16-byte-aligned arrays: lanes past the end load element 0 and are
 // masked afterwards; a lane's 16 bytes never leave the array's last 16-byte chunk
 __device__ __forceinline__ void load_queries_bf4(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
@@ -1409,8 +1938,8 @@ static int choose_groups(u64 nq, int cus) {
 }
 
 size_t tokenize_lds_ws_bytes(u64 nq) {
-    // sized for the smallest tile (1024 threads x 2 queries)
-    return scan_ws_bytes_for_tiles((nq + 2047) / 2048);
+    // sized for the smallest tile (k_tok_sweep: 256 threads x 4 queries)
+    return scan_ws_bytes_for_tiles((nq + 1023) / 1024);
 }
 
 // words of id staging per wave: what is left of the LDS budget, at most 512 (a wave-tile of 256 queries rarely has more hits)
@@ -1549,6 +2078,104 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
 #undef GT_TOK_GEOM
 #undef GT_TOK_CASE
     return fail(GTARS_ERR_INTERNAL, "unsupported tokenizer launch geometry");
+}
+
+// ---- the sweep form (k_tok_sweep): batches in (chromosome, start) order
+bool tokenize_sweep_supported(const AccelView &a) {
+    return a.n_blocks > 0 && a.rec2 && a.blk_first && a.chrom_tab && a.idc && (a.ids_affine || a.rec4) &&
+           (u64)a.max_chrom_n * 4096ull <= 0xFFFFFFFFull;  // a tile's 32-bit hit total
+}
+
+// Geometry: workgroups of 256 threads, FOUR per CU (16 waves per CU either way: the kernel sits at ~115 VGPRs).  A tile's phases are a
+// chain of dependent round trips -- queries, window probes, staging, then scan, look-back, stores -- and the waves of ONE workgroup
+// go through them together, so a CU with one 1024-thread workgroup idles at every link; four small workgroups are in different
+// phases of different tiles (1024-thread workgroups: 661 us per 64M queries in order; GTARS_TOK_SWEEP_TPB=1024 is the A/B switch
+// of the main variant).
+template <int TPB, int R, bool FILTER, bool IMPL, bool REV>
+static gtars_status launch_sweep_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, i32 min_bp, const EnumOut &out,
+                                   ScanWs *ws, ScanEpoch &ep, const u64 *d_base, u64 *d_total_out, hipStream_t st) {
+    static KernelSetup setup;
+    int dev = 0, cus = 256;
+    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_sweep<TPB, R, FILTER, IMPL, REV>), dev, cus);
+    if (s0) return s0;
+    // LDS: one region per wave -- 20 bytes per staged block in the count phase, the wave's id staging in the write phase.  9.5 KB per
+    // wave = 486 blocks = 972 intervals under a wave's 256 queries.  (GTARS_TOK_SWEEP_BLOCKS / _RUNS: tests -- small budgets force
+    // the global path.)
+    const u32 cap_w = (u32)std::min(486, std::max(1, env_int("GTARS_TOK_SWEEP_BLOCKS", 486)));
+    const u32 max_runs = (u32)std::min<int>((int)SWP_RUNS, std::max(0, env_int("GTARS_TOK_SWEEP_RUNS", (int)SWP_RUNS)));
+    const u32 region_words = 2432;  // (>= 5 * 486, a multiple of 4)
+    const size_t lds = (size_t)region_words * (TPB / 64) * 4;
+    const u32 spin_limit = (u32)env_int("GTARS_TOK_SPIN_LIMIT", 4096);
+    const u64 tile_q = (u64)TPB * 4 * R;
+    const u64 tiles = (nq + tile_q - 1) / tile_q;
+    const u64 grid = std::min<u64>((u64)cus * (1024 / TPB), tiles);
+    const u64 cap = out.vals ? out.capacity : 0;
+    hipLaunchKernelGGL((k_tok_sweep<TPB, R, FILTER, IMPL, REV>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq, min_bp,
+                       out.offsets, out.vals, cap, ws, ep.epoch, ep.ticket_base, region_words, spin_limit, d_base, d_total_out, cap_w, max_runs);
+    GT_HIP(hipGetLastError());
+    if (tiles > grid) ep.ticket_base += (u32)tiles;
+    return GTARS_OK;
+}
+
+gtars_status launch_tokenize_sweep(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq, int has_min, i32 min_overlap,
+                                   const EnumOut &out, void *scan_ws, size_t scan_ws_bytes, ScanEpoch &ep, hipStream_t st,
+                                   const u64 *d_base, u64 *d_total_out, bool reverse) {
+    if (out.starts || out.ends) return fail(GTARS_ERR_INTERNAL, "the sweep tokenizer writes vals only");
+    if (nq == 0)  // (the empty batch: offsets[0] and the totals, no kernel)
+        return launch_tokenize_lds(a, qc, qs, qe, nq, has_min, min_overlap, out, scan_ws, scan_ws_bytes, ep, st, d_base, d_total_out, reverse);
+    const bool impl = a.ids_affine != 0;
+    const bool filter = has_min && min_overlap > 1;
+    int cus = 256;
+    {
+        int dev = 0;
+        GT_HIP(hipGetDevice(&dev));
+        GT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    // rounds per tile: 2 once every workgroup has several two-round tiles (the per-tile costs -- scan barrier, ticket, look-back --
+    // paid half as often, a wave's rounds pipelined; 4 rounds keep 88 registers of query state across the scan: scratch);
+    // GTARS_TOK_SWEEP_ROUNDS / _TPB: tests, A/B
+    const int tpb = env_int("GTARS_TOK_SWEEP_TPB", 256) == 1024 && !filter && impl && !reverse ? 1024 : 256;
+    int rounds = !filter && nq >= (u64)cus * 8192ull * 2ull ? 2 : 1;
+    {
+        const int forced = env_int("GTARS_TOK_SWEEP_ROUNDS", 0);
+        if (forced == 1 || (forced == 2 && !filter)) rounds = forced;
+    }
+    if ((u64)std::max<u32>(a.max_chrom_n, 1) * 4ull * (u64)tpb * (u64)rounds > 0xFFFFFFFFull) rounds = 1;  // a tile's 32-bit hit total
+    const u64 tile_q = 4ull * (u64)tpb * (u64)rounds;
+    const u64 tiles = (nq + tile_q - 1) / tile_q;
+    if (tiles > 0xFFFFFFF0ull) return fail(GTARS_ERR_INVALID_ARG, "query batch too large for one launch");
+    const size_t need = scan_ws_bytes_for_tiles(tiles);
+    if (scan_ws_bytes < need) return fail(GTARS_ERR_INTERNAL, "fused scan workspace too small");
+    if (ep.epoch == 0 || ep.epoch >= EP_MAX || need > ep.cleared_bytes) {
+        GT_HIP(hipMemsetAsync(scan_ws, 0, scan_ws_bytes, st));
+        ep.cleared_bytes = scan_ws_bytes;
+        ep.epoch = 0;
+        ep.ticket_base = 0;
+    }
+    ep.epoch += 1;
+    const i32 min_bp = has_min ? min_overlap : 0;
+    ScanWs *ws = (ScanWs *)scan_ws;
+    prof_note_fact("tok_build_sweep");
+    ProfScope p("k_tok_sweep", st);
+#define GT_SWEEP_CASE(T, N, F, I, V) \
+    if (tpb == T && rounds == N && filter == F && impl == I && reverse == V) \
+        return launch_sweep_t<T, N, F, I, V>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
+    GT_SWEEP_CASE(256, 1, false, true, false)
+    GT_SWEEP_CASE(256, 1, false, true, true)
+    GT_SWEEP_CASE(256, 1, true, true, false)
+    GT_SWEEP_CASE(256, 1, true, true, true)
+    GT_SWEEP_CASE(256, 1, false, false, false)
+    GT_SWEEP_CASE(256, 1, false, false, true)
+    GT_SWEEP_CASE(256, 1, true, false, false)
+    GT_SWEEP_CASE(256, 1, true, false, true)
+    GT_SWEEP_CASE(256, 2, false, true, false)
+    GT_SWEEP_CASE(256, 2, false, true, true)
+    GT_SWEEP_CASE(256, 2, false, false, false)
+    GT_SWEEP_CASE(256, 2, false, false, true)
+    GT_SWEEP_CASE(1024, 1, false, true, false)
+    GT_SWEEP_CASE(1024, 2, false, true, false)
+#undef GT_SWEEP_CASE
+    return fail(GTARS_ERR_INTERNAL, "unsupported sweep tokenizer variant");
 }
 
 }  // namespace gtars

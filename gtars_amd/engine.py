@@ -197,11 +197,13 @@ class OverlapIndex:
         check(lib.gtars_mark_overlapped_device(self._h, d_qc, d_qs, d_qe, nq, hm, mo, d_mark, stream))
 
     TOK_AUTO, TOK_NARROW, TOK_WIDE = 0, 1, 2  # gtars_amd.h: which build of the fused tokenizer a launch runs
+    TOK_SORTED = 4  # OR-ed in: the batch is in (chromosome, start) order -> the sweep form of the tokenizer
 
     def tokenize_device(self, d_qc: int, d_qs: int, d_qe: int, nq: int, d_offsets: int, d_ids: int,
                         ids_capacity: int, stream: int = 0, sync: bool = True, hint: int = 0) -> Optional[int]:
         """Single fused pass on device buffers.  Returns H when ``sync`` (else None).  ``hint``: TOK_NARROW for batches of about
-        one id per query whatever the id buffer's size, TOK_WIDE for hit-heavy ones; TOK_AUTO decides by the capacity."""
+        one id per query whatever the id buffer's size, TOK_WIDE for hit-heavy ones; TOK_AUTO decides by the capacity; ``| TOK_SORTED``
+        for a batch in (chromosome, start) order (a file-loaded RegionSet, a sorted BED file): the sweep form."""
         total = C.c_uint64()
         check(lib.gtars_tokenize_device_ex(self._h, d_qc, d_qs, d_qe, nq, d_offsets, d_ids, ids_capacity,
                                            C.byref(total) if sync else None, stream, hint))

@@ -147,6 +147,13 @@ gtars_status gtars_tokenize_device(const gtars_index_t *ix, const uint32_t *d_qc
 #define GTARS_TOK_AUTO 0
 #define GTARS_TOK_NARROW 1
 #define GTARS_TOK_WIDE 2
+/* ... OR-ed with GTARS_TOK_SORTED: the batch is in (chromosome id, start) order -- what Tokenizer::tokenize receives from a
+ * file-loaded RegionSet (gtars-core/src/models/region_set.rs:182, 502-505) -- and the launch runs the SWEEP form of the tokenizer
+ * (k_tok_sweep: every wave stages the contiguous slice of the blocked records its 256 consecutive queries need in LDS; no search
+ * image, any universe size).  Same offsets and ids for ANY batch.  EXPERIMENTAL, opt-in, and measured SLOWER than the default
+ * kernel, which on a batch in order already runs at its best rate because neighbouring lanes' record requests coalesce: 18.9 vs
+ * 14.4 us per 1M queries, 568 vs 411 us per 64M (profiles/r06/sweep_*.txt).  Nothing selects it by itself. */
+#define GTARS_TOK_SORTED 4
 gtars_status gtars_tokenize_device_ex(const gtars_index_t *ix, const uint32_t *d_qchrom,
                                       const uint32_t *d_qstart, const uint32_t *d_qend,
                                       uint64_t nq, uint64_t *d_offsets, uint32_t *d_ids,

@@ -2109,7 +2109,7 @@ def test_handles_carry_their_device_and_every_entry_point_checks_it(ga):
     assert lib.gtars_index_device(g._h) == cur and lib.gtars_igd_device(ig._h) == cur
     d = [torch.from_numpy(x.view(np.int32)).to(dev) for x in (qc, qs, qe)]
     off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
-    ids = torch.empty(8 * nq, dtype=torch.int32, device=dev)
+    ids = torch.empty(16 * nq, dtype=torch.int32, device=dev)
     cnt = torch.empty(nq, dtype=torch.int32, device=dev)
     hits = torch.zeros(F, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
@@ -2176,6 +2176,16 @@ def test_igd_counts_from_four_host_threads_on_one_handle(ga, monkeypatch):
                    o.count_region_hits(qc[:2000], qs[:2000], qe[:2000], 0, n_files=F),
                    o.count_overlaps_per_query(qc[:5000], qs[:5000], qe[:5000], 1))
     want_sets = np.stack([o.count_region_hits(qc, qs, qe, 1, n_files=F) for qc, qs, qe in sets])
+    # the same calls one after the other on a handle of their own first: what fails here is not a threading matter
+    g1 = ga.IgdIndex(c, s, e, f, np.arange(n), n_chrom=n_chrom, n_files=F)
+    for k, (qc, qs, qe) in enumerate(sets):
+        assert np.array_equal(g1.count_set_overlaps(qc, qs, qe, 1), want[k][0]), (k, "pairwise, sequential")
+        assert np.array_equal(g1.count_region_hits(qc, qs, qe, 1), want[k][1]), (k, "binary, sequential")
+        assert np.array_equal(g1.count_region_hits(qc[:2000], qs[:2000], qe[:2000], 0), want[k][2]), (k, "min_overlap 0, sequential")
+        got = g1.count_overlaps_per_query(qc[:5000], qs[:5000], qe[:5000], 1)
+        assert np.array_equal(got, want[k][3]), (k, "per query, sequential", np.argwhere(got != want[k][3])[:5].tolist())
+    assert np.array_equal(g1.count_sets(sets, 1, True), want_sets)
+    del g1
     errors, start = [], threading.Barrier(4)
 
     def body(k):
@@ -2205,3 +2215,110 @@ def test_igd_counts_from_four_host_threads_on_one_handle(ga, monkeypatch):
         t.join()
     assert not errors, errors
     assert g.total_records() == o.total_records()
+
+
+def _sorted_batch(rng, n_chrom, nq, span, wmax, unknown=0.0):
+    """queries in (chromosome id, start) order, as a sorted BED file / file-loaded RegionSet delivers them"""
+    qc = rng.integers(0, n_chrom, nq).astype(np.uint32)
+    qs = rng.integers(0, span, nq).astype(np.uint32)
+    qe = (qs + rng.integers(0, wmax, nq)).astype(np.uint32)  # (zero-length queries included)
+    if unknown:
+        qc = np.where(rng.random(nq) < unknown, UNK, qc).astype(np.uint32)
+    o = np.lexsort((qs, qc))
+    return qc[o], qs[o], qe[o]
+
+
+def _tok_device(ga, g, qc, qs, qe, hint, cap_factor=6):
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nq = len(qc)
+    d = [torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(dev) for x in (qc, qs, qe)]
+    off = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+    ids = torch.empty(max(cap_factor * nq, 1024), dtype=torch.int32, device=dev)
+    h = g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), nq, off.data_ptr(), ids.data_ptr(), ids.numel(),
+                          torch.cuda.current_stream().cuda_stream, hint=hint)
+    return off.cpu().numpy().view(np.uint64), ids[:h].cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("kind", BOTH)
+@pytest.mark.parametrize("explicit_ids", [False, True])
+def test_sweep_tokenizer_on_batches_in_order(ga, monkeypatch, kind, explicit_ids):
+    """Round 6: GTARS_TOK_SORTED -- the sweep form of the tokenizer (k_tok_sweep) for batches in (chromosome, start) order, what a
+    file-loaded RegionSet is (region_set.rs:182, 502-505).  Same offsets and ids as Bits::find / AIList::find (bits.rs:141-156,
+    433-446; ailist.rs:238-263) and as the default kernel, on: disjoint and overlapping universes with position-derived and
+    explicit ids, several tiles with chromosome boundaries inside tiles (two and more runs per tile), unknown chromosomes
+    inside the batch, zero-length and wide queries (hits beyond the 32-interval mask: the global walk), a universe far beyond
+    k_tok_lds' LDS key budget, min-overlap filters, an id buffer that is too short (offsets complete, GTARS_ERR_CAPACITY)."""
+    rng = np.random.default_rng(17 + kind)
+    for n, n_chrom, span, wmax, qwmax, nq in ((60_000, 5, 4_000_000, 400, 600, 70_000), (3_000, 40, 100_000, 90, 200, 30_000),
+                                              (400_000, 3, 60_000_000, 300, 500, 50_000), (20_000, 2, 1_000_000, 3000, 40_000, 20_000)):
+        c = np.sort(rng.integers(0, n_chrom, n)).astype(np.uint32)
+        s = rng.integers(0, span, n).astype(np.uint32)
+        o = np.lexsort((s, c))
+        c, s = c[o], s[o]
+        e = (s + rng.integers(1, wmax, n)).astype(np.uint32)
+        if wmax <= 400 and kind == KIND_BITS:  # a disjoint universe: clip at the next start
+            nxt = np.r_[s[1:], np.uint32(0xFFFFFFFF)]
+            same = np.r_[c[1:] == c[:-1], False]
+            e = np.where(same, np.minimum(e, np.maximum(nxt, s + 1)), e).astype(np.uint32)
+        val = rng.permutation(n).astype(np.uint32) if explicit_ids else None
+        g, o_ = _pair(ga, c, s, e, val, n_chrom=n_chrom, kind=kind)
+        qc, qs, qe = _sorted_batch(rng, n_chrom, nq, span + 1000, qwmax, unknown=0.01)
+        want_off, want_ids = o_.tokenize(qc, qs, qe)
+        _lib = ga._lib
+        _lib.lib.gtars_prof_reset()
+        _lib.lib.gtars_prof_enable(1)
+        off, ids = _tok_device(ga, g, qc, qs, qe, g.TOK_SORTED, cap_factor=2 + qwmax // 40)
+        prof = _lib.prof_read()
+        _lib.lib.gtars_prof_enable(0)
+        if kind == KIND_BITS or "tok_build_sweep" in prof:  # (a nested AIList universe has no blocked structure: generic kernel)
+            assert "tok_build_sweep" in prof, sorted(prof)
+        assert np.array_equal(off, want_off), (n, np.argwhere(off != want_off)[:3])
+        assert np.array_equal(ids, want_ids), (n, np.argwhere(ids != want_ids)[:3])
+        off2, ids2 = _tok_device(ga, g, qc, qs, qe, g.TOK_AUTO, cap_factor=2 + qwmax // 40)
+        assert np.array_equal(off2, want_off) and np.array_equal(ids2, want_ids)
+        # the same batch SHUFFLED under the hint: still right (many runs per tile -> the global path)
+        p = rng.permutation(nq)[: 6000]
+        w_off, w_ids = o_.tokenize(qc[p], qs[p], qe[p])
+        off3, ids3 = _tok_device(ga, g, qc[p], qs[p], qe[p], g.TOK_SORTED, cap_factor=2 + qwmax // 40)
+        assert np.array_equal(off3, w_off) and np.array_equal(ids3, w_ids)
+    # forced small budgets: 8 staged blocks per wave (every run beyond -> global memory), one run per wave and round (the second
+    # run -> global memory), none; two rounds per tile on a batch this small
+    for env, val_ in (("GTARS_TOK_SWEEP_BLOCKS", "8"), ("GTARS_TOK_SWEEP_RUNS", "1"), ("GTARS_TOK_SWEEP_RUNS", "0"),
+                      ("GTARS_TOK_SWEEP_ROUNDS", "2")):
+        monkeypatch.setenv(env, val_)
+        off5, ids5 = _tok_device(ga, g, qc, qs, qe, g.TOK_SORTED, cap_factor=2 + qwmax // 40)
+        monkeypatch.delenv(env)
+        assert np.array_equal(off5, want_off) and np.array_equal(ids5, want_ids), env
+    # min-overlap filter through count_overlaps is another kernel; the tokenizer's filter form through find_overlaps' values
+    # is covered by the fuzzer (GTARS_TOK_SWEEP=1); here: an id buffer that is too short
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = [torch.from_numpy(x.view(np.int32)).to(dev) for x in (qc, qs, qe)]
+    off_t = torch.empty(len(qc) + 1, dtype=torch.int64, device=dev)
+    short = torch.empty(max(len(want_ids) // 3, 1), dtype=torch.int32, device=dev)
+    with pytest.raises(ga.CapacityError) as ei:
+        g.tokenize_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(qc), off_t.data_ptr(), short.data_ptr(), short.numel(),
+                          torch.cuda.current_stream().cuda_stream, hint=g.TOK_SORTED)
+    assert ei.value.needed == len(want_ids)
+    assert np.array_equal(off_t.cpu().numpy().view(np.uint64), want_off)
+    assert np.array_equal(short.cpu().numpy().view(np.uint32), want_ids[: short.numel()])
+
+
+def test_sweep_tokenizer_config2_in_order_and_large_universes(ga):
+    """BASELINE config 2's batch in (chromosome, start) order through the sweep form: ids AND order == oracle at 1M queries; then
+    universes of 200k and 1M regions (beyond the LDS key image of the default kernel), same batch law, in order."""
+    from gtars_amd import synth
+
+    for nu in (100_000, 200_000, 1_000_000):
+        u = synth.make_universe(nu)
+        q = synth.make_queries(u, 1_000_000 if nu == 100_000 else 400_000)
+        o = np.lexsort((q["start"], q["chrom"]))
+        qc, qs, qe = (np.ascontiguousarray(q[k][o]) for k in ("chrom", "start", "end"))
+        g = ga.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+        ref = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM)
+        want_off, want_ids = ref.tokenize(qc, qs, qe)
+        off, ids = _tok_device(ga, g, qc, qs, qe, g.TOK_SORTED | g.TOK_NARROW, cap_factor=2)
+        assert np.array_equal(off, want_off) and np.array_equal(ids, want_ids), nu
