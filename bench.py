@@ -170,11 +170,14 @@ def verify_tokenization(u, q, offsets_t, ids_t, h, where):
     return True
 
 
-def bench_large(ix, u, q, nu, sizes, dev, stream):
+def bench_large(ix, u, q, nu, sizes, dev, stream, in_order=False):
     """The same kernel on larger batches: queries/s and fraction of the HBM peak, median of 5 single-launch timings each
     (HIP events on the launch stream).  The batch is the 1M-query base batch TILED on the device (query values repeat with
     period 1M; the batch stays shuffled).  Checked in the run: the first and the last period's ids equal the oracle's
-    tokenization of the base batch, offsets ascend and end at the hit count."""
+    tokenization of the base batch, offsets ascend and end at the hit count.
+    in_order: the tiled batch is then SORTED on the device by (chromosome, start) -- what a file-loaded RegionSet / a sorted BED
+    file delivers (gtars-core/src/models/region_set.rs:182) at that size; checked: the first and the last million queries of the
+    sorted batch against the oracle's tokenization of exactly those queries."""
     import torch
 
     import oracle
@@ -190,6 +193,12 @@ def bench_large(ix, u, q, nu, sizes, dev, stream):
         rep = max(n2 // nq0, 1)
         big = {k: v.repeat(rep) for k, v in base.items()}
         n2 = nq0 * rep
+        if in_order:
+            key = ((big["chrom"].to(torch.int64) & 0xFFFFFFFF) << 32) | (big["start"].to(torch.int64) & 0xFFFFFFFF)
+            perm = torch.argsort(key, stable=True)
+            del key
+            big = {k: v[perm].contiguous() for k, v in big.items()}
+            del perm
         off = torch.empty(n2 + 1, dtype=torch.int64, device=dev)
         run = lambda ids, s=False: ix.tokenize_device(big["chrom"].data_ptr(), big["start"].data_ptr(), big["end"].data_ptr(),
                                                       n2, off.data_ptr(), ids.data_ptr() if ids is not None else 0,
@@ -208,14 +217,24 @@ def bench_large(ix, u, q, nu, sizes, dev, stream):
             times.append(e0.elapsed_time(e1) * 1e-3)
         dt = statistics.median(times)
         h0 = len(ids_o)
-        ok = (h2 == h0 * rep and int(off[-1]) == h2 and bool((off[1:] >= off[:-1]).all())
-              and torch.equal(ids[:h0], ids_o_t) and torch.equal(ids[h2 - h0:h2], ids_o_t))
+        ok = h2 == h0 * rep and int(off[-1]) == h2 and bool((off[1:] >= off[:-1]).all())
+        if not in_order:
+            ok = ok and torch.equal(ids[:h0], ids_o_t) and torch.equal(ids[h2 - h0:h2], ids_o_t)
+        else:
+            for lo in (0, n2 - min(n2, 1_000_000)):
+                hi = lo + min(n2, 1_000_000)
+                qs_ = {k: big[k][lo:hi].cpu().numpy().view(np.uint32) for k in ("chrom", "start", "end")}
+                off_s, ids_s = ref.tokenize(qs_["chrom"], qs_["start"], qs_["end"])
+                o_d = off[lo:hi + 1].cpu().numpy().view(np.uint64)
+                ok = ok and np.array_equal(o_d - o_d[0], off_s) and np.array_equal(
+                    ids[int(o_d[0]):int(o_d[-1])].cpu().numpy().view(np.uint32), ids_s)
         if not ok:
             raise SystemExit(f"bench.py: the {n2}-query launch differs from the oracle")
         byts = algorithmic_bytes(n2, h2, nu)
         out.append({"queries": n2, "hits": h2, "ms": dt * 1e3, "qps": n2 / dt, "achieved_GBps": byts / dt / 1e9,
                     "frac": byts / dt / 1e9 / HBM_PEAK_GBS, "verified": True,
-                    "batch": f"the 1M-query base batch tiled {rep}x on the device (values repeat with period {nq0}; still shuffled)"})
+                    "batch": (f"the 1M-query base batch tiled {rep}x on the device, then sorted on the device by (chromosome, start)" if in_order
+                              else f"the 1M-query base batch tiled {rep}x on the device (values repeat with period {nq0}; still shuffled)")})
         del big, off, ids
         torch.cuda.empty_cache()
     return out
@@ -789,6 +808,62 @@ def bench_fragsplit_config5(files=48, frags=100_000, clusters=20, cpu_files=48):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def bench_fragsplit_many_files(files=1000, frags=10_000, clusters=20, cpu_files=48):
+    """Config 5 towards the config's FILE COUNT (10,000 files; `fragsplit_config5` times 48 files of the config's per-file size): a
+    folder of `files` small fragment files through the fused fragsplit -> tokenizer pipeline -- many gzip members, many barcode
+    tables, many batches.  The first call (cold: pinned pool, workspaces, device tables) is reported apart; `value` is the median of
+    the six calls behind it."""
+    import shutil
+    import tempfile
+
+    import oracle
+    from gtars_amd import synth
+    from gtars_amd.fragsplit import BarcodeToClusterMap, fragsplit_tokenize, fragsplit_tokenize_files
+    from gtars_amd.tokenizers import Tokenizer
+
+    tmp = tempfile.mkdtemp(prefix="gtars_c5m_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        u = synth.make_universe(100_000)
+        t = time.time()
+        ub, fd, mp, gz_bytes = synth.write_config5_inputs(tmp, u, files, frags, clusters)
+        t_gen = time.time() - t
+        tok = Tokenizer.from_bed(ub)
+        m = BarcodeToClusterMap.from_file(mp)
+        runs = []
+        fused = None
+        for _ in range(7):
+            fused = None
+            t = time.perf_counter(); fused = fragsplit_tokenize(fd, m, tok, as_arrays=True); runs.append(time.perf_counter() - t)
+        n = files * frags
+        steady = statistics.median(runs[1:])
+        import ctypes as C_
+
+        from gtars_amd import _lib as L_
+        sg = (C_.c_double * 12)()
+        L_.lib.gtars_fragsplit_last_stages(C_.cast(sg, C_.c_void_p))
+        out = {"files": files, "fragments_per_file": frags, "fragments": n, "clusters": m.n_clusters(), "input_gz_MB": round(gz_bytes / 1e6, 1),
+               "gen_s": round(t_gen, 1), "host_threads": _usable_host_threads(),
+               "first_call_s": round(runs[0], 4), "steady_calls_s": [round(x, 4) for x in runs[1:]], "s": round(steady, 4),
+               "value": n / steady, "unit": "fragments/s end to end (fused route + tokenize), median of the 6 calls behind the first",
+               "token_ids": sum(int(v[1][-1]) for v in fused.values()),
+               "stages_of_the_last_call": {"batches": int(sg[1]), "host_read_inflate_s": round(sg[2], 4),
+                                           "device_batches_s_summed_over_the_device_threads": round(sg[4], 4),
+                                           "of_which_behind_the_last_batch_s": round(sg[5], 4), "regroup_host_share_s": round(sg[6], 4),
+                                           "device_text_in_s": round(sg[7], 4), "device_split_parse_sort_s": round(sg[8], 4),
+                                           "device_tokenize_s": round(sg[10], 4), "device_regroup_and_results_out_s": round(sg[11], 4)},
+               "scale_note": f"{files} files x {frags} fragments = {n} of the config's 1e9 fragments in 10,000 files (a tenth of the files, a "
+                             "tenth of the per-file size)"}
+        paths = sorted(os.path.join(fd, f) for f in os.listdir(fd))[:cpu_files]
+        cpu = oracle.fragsplit_tokenize_compiled(paths, oracle.OracleBarcodeMap(mp), oracle.OracleTokenizer(ub))
+        dev = fragsplit_tokenize_files(paths, m, tok, as_arrays=True)
+        if {k: int(v[1][-1]) for k, v in dev.items()} != {k: v[0] for k, v in cpu.items()}:
+            raise SystemExit("bench.py: fragsplit_config5_1000: device pipeline and the compiled CPU restatement disagree")
+        out["verified"] = f"per-cluster id counts of the first {len(paths)} files == the compiled CPU restatement's"
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 # ------------------------------------------------------------------------------------------------ N > 1
 
 def _lib_host_threads() -> int:
@@ -1351,6 +1426,9 @@ def main():
         if world == 1 and not args.no_extras:
             sizes = [int(t) for t in args.large.split(",") if t]
             out["roofline_large"] = bench_large(ix, u, q0, nu, sizes, dev, stream)
+            # the same kernel on a 64M-query batch IN ORDER (what Tokenizer.tokenize(path) delivers at that size): neighbouring
+            # lanes' record requests coalesce.  Next to the shuffled headline, never instead of it.
+            out["sorted_input_large"] = bench_large(ix, u, q0, nu, [64_000_000], dev, stream, in_order=True)[0]
             # hit-heavy batches (not a BASELINE config): every query of the base batch widened to 1 Mbp -- ~33 ids per query,
             # the ids dominate the bytes; wide queries' tails are measured instead of walked and their ids leave by wave-wide
             # stores (tokenize_lds.hip: tail_run / coop_runs)
@@ -1383,6 +1461,9 @@ def main():
                 r2["universe_regions"] = nu2
                 r2["batch"] = f"1M queries drawn against this universe (synth.make_queries), tiled 64x on the device"
                 out[key] = r2
+                r3 = bench_large(ix2, u2, q2, nu2, [64_000_000], dev, stream, in_order=True)[0]
+                r3["universe_regions"] = nu2
+                out[key + "_in_order"] = r3
                 del ix2
                 torch.cuda.empty_cache()
             # PCIe-inclusive rates through the host-pointer entry points (H2D of the queries, kernel, D2H of offsets +
@@ -1408,6 +1489,7 @@ def main():
             out["igd_config3_broad_peaks"] = bench_igd_broad_peaks(dev, stream)
             out["lola_config4"] = bench_lola_config4(dev, stream, cpu=cpu)
             out["fragsplit_config5"] = bench_fragsplit_config5(files=args.c5_files)
+            out["fragsplit_config5_1000"] = bench_fragsplit_many_files()
         if not args.no_cpu_baseline and world == 1:  # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(u, q0)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(u, q0)

@@ -261,11 +261,20 @@ u32 multisplit_workgroups(u32 n) {
 // long: pass A splits by coarse bin (key >> shift, <= 256 bins: runs of ~40 elements), pass B splits each coarse segment by
 // the full key -- a tile of pass A's output spans only a few coarse bins, i.e. <= SP_BINS neighbouring keys; an element
 // outside that window (tiny coarse segments) is placed with its own global atomic.  Not stable.
-constexpr int SP_TPB = 1024;
+// Geometry.  Pass A: 1024 threads, one workgroup per CU, tiles of 8192 elements (runs of ~32 elements per coarse bin: 256-byte
+// stores; its prologue -- the column sums of the routing workgroups' rows -- wants the threads).  Pass B: 512 threads, tiles of 4096,
+// TWO workgroups per CU in different phases of different tiles: every tile is a chain of load / rank / reserve / reorder / store
+// round trips behind five barriers, which one workgroup per CU goes through with all its waves together (round 6, same-box A/B:
+// pass B 48.7 -> 42.1 us per 10M pairs; pass A with 512 threads 53.7 -> 81.0, so it keeps 1024; profiles/r06/igd_split_geometry_ab.txt).
+#ifndef GTARS_SP_TPB_A
+#define GTARS_SP_TPB_A 1024
+#endif
+#ifndef GTARS_SP_TPB_B
+#define GTARS_SP_TPB_B 512
+#endif
+constexpr int SP_TPB_A = GTARS_SP_TPB_A, SP_TPB_B = GTARS_SP_TPB_B;
+static_assert((SP_TPB_A == 1024 || SP_TPB_A == 512) && (SP_TPB_B == 1024 || SP_TPB_B == 512), "split-pass workgroups of 1024 or 512 threads");
 constexpr int SP_ITEMS = 8;
-constexpr int SP_TILE = SP_TPB * SP_ITEMS;
-constexpr int SP_BINS = 1024;
-static_assert(SP_BINS == SP_TPB, "one thread per tile-local bin (counter reset, layout scan, run reservation)");
 
 // KeyT: u32, or unsigned short when every bin fits 16 bits (2 bytes per element less to read and write in both passes).
 // CLAMP (first pass on raw query columns): a = max((i32)a, 0) -- the start clamp of Igd::count_overlaps (igd.rs:517) applied
@@ -277,20 +286,21 @@ static_assert(SP_BINS == SP_TPB, "one thread per tile-local bin (counter reset, 
 //           workgroups' rows over the fine bins of coarse bin w, w + grid, ..., scans them and writes the fine offsets bin_off[]
 //           (what pass B and the consumer read), and notes the heavy bins;
 //   pass B: a run is reserved at bin_off[bin] + atomicAdd(relative cursor).
-template <bool FINE, class KeyT, bool CLAMP>
-__global__ void __launch_bounds__(SP_TPB)
+template <int TPB, bool FINE, class KeyT, bool CLAMP>
+__global__ void __launch_bounds__(TPB, 4)
 k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
              u32 shift, u32 drop_bin, u32 *__restrict__ cursor, KeyT *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if,
              SetTags tags, const u32 *__restrict__ rows = nullptr, u32 n_bins = 0, u32 *__restrict__ bin_off = nullptr, HeavyBins heavy = HeavyBins{},
              const u32 *__restrict__ ctot = nullptr, u32 n_rows = 0) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
+    constexpr int TILE_ = TPB * SP_ITEMS, BINS_ = TPB;  // one thread per tile-local bin (counter reset, layout scan, run reservation)
     extern __shared__ u32 sp_lds[];
-    u32 *s_k = sp_lds, *s_a = s_k + SP_TILE, *s_b = s_a + SP_TILE;
-    u32 *cnt = s_b + SP_TILE, *toff = cnt + SP_BINS, *gbase = toff + SP_BINS;
-    __shared__ u32 s_scan[SP_TPB / 64];
+    u32 *s_k = sp_lds, *s_a = s_k + TILE_, *s_b = s_a + TILE_;
+    u32 *cnt = s_b + TILE_, *toff = cnt + BINS_, *gbase = toff + BINS_;
+    __shared__ u32 s_scan[TPB / 64];
     __shared__ u32 s_min;
     __shared__ u32 s_cbase[!FINE ? 257 : 1];  // exclusive offsets of the coarse bins (+ the grand total)
-    const u32 n_tiles = (n + SP_TILE - 1) / SP_TILE;
+    const u32 n_tiles = (n + TILE_ - 1) / TILE_;
     // One workgroup per CU (its tile fills the LDS), so nothing else hides a tile's memory latencies: the NEXT tile's elements
     // are requested into a second set of registers before the current tile is ranked (in flight during ranking, reservation,
     // LDS reorder and write-out), and a bin's run reservation -- a global atomic WITH return -- is only waited for after the
@@ -298,10 +308,10 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
     // load round trip and an atomic round trip back to back, 13 us per 8192-element tile (164 KB moved: 12.6 GB/s per CU).
     u32 nk[SP_ITEMS], na[SP_ITEMS], nb[SP_ITEMS];
     auto request = [&](u32 tile) {
-        const u32 base = tile * SP_TILE;
+        const u32 base = tile * TILE_;
 #pragma unroll
         for (int j = 0; j < SP_ITEMS; ++j) {
-            const u32 i = base + (u32)j * SP_TPB + threadIdx.x;
+            const u32 i = base + (u32)j * TPB + threadIdx.x;
             const u32 ic = i < n ? i : n - 1u;  // (unconditional loads: the wait counts stay exact; the copy is ignored)
             nk[j] = (u32)key[ic];
             if (FINE) {
@@ -320,7 +330,7 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
         const u32 n_coarse = ((n_bins - 1u) >> shift) + 1u;
         u32 grand;
         const u32 mine = threadIdx.x < n_coarse ? ctot[threadIdx.x] : 0u;  // coarse bin threadIdx.x
-        const u32 ex = block_exclusive_scan<SP_TPB>(mine, s_scan, grand);
+        const u32 ex = block_exclusive_scan<TPB>(mine, s_scan, grand);
         if (threadIdx.x < 256u) s_cbase[threadIdx.x] = ex;
         if (threadIdx.x == 0) s_cbase[256] = grand;
         __syncthreads();
@@ -330,14 +340,14 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             // 2^shift / 8 16-byte vectors per row, as many rows side by side as the workgroup has threads for, partial sums
             // combined in LDS
             const u32 vpr = (1u << shift) >> 3, rw = multisplit_row_words(n_bins), w0 = (jc << shift) >> 1;  // (shift >= 3)
-            cnt[threadIdx.x] = 0;  // (2^shift <= 256 <= SP_BINS counters)
+            cnt[threadIdx.x] = 0;  // (2^shift <= 256 <= BINS_ counters)
             __syncthreads();
             const u32 vec = threadIdx.x % vpr, wv = w0 + 4u * vec;
-            for (u32 r0 = 0; r0 < n_rows; r0 += 4u * (SP_TPB / vpr)) {
+            for (u32 r0 = 0; r0 < n_rows; r0 += 4u * (TPB / vpr)) {
                 uint4 x[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const u32 r = r0 + (u32)q * (SP_TPB / vpr) + threadIdx.x / vpr;
+                    const u32 r = r0 + (u32)q * (TPB / vpr) + threadIdx.x / vpr;
                     x[q] = r < n_rows && wv < rw ? *reinterpret_cast<const uint4 *>(rows + (size_t)r * rw + wv) : make_uint4(0, 0, 0, 0);
                 }
                 u32 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
@@ -359,7 +369,7 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             const bool in = threadIdx.x < (1u << shift) && fb < n_bins;
             const u32 v = in ? cnt[threadIdx.x] : 0u;
             u32 tt;
-            const u32 fe = block_exclusive_scan<SP_TPB>(v, s_scan, tt);
+            const u32 fe = block_exclusive_scan<TPB>(v, s_scan, tt);
             if (in) {
                 bin_off[fb] = s_cbase[jc] + fe;
                 heavy.note(fb, v);
@@ -369,14 +379,14 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
         __syncthreads();  // cnt is the tile loop's again
     }
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const u32 base = tile * SP_TILE;
-        cnt[threadIdx.x] = 0;  // SP_BINS == SP_TPB
+        const u32 base = tile * TILE_;
+        cnt[threadIdx.x] = 0;  // BINS_ == TPB
         if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
         u32 k[SP_ITEMS], va[SP_ITEMS], vb[SP_ITEMS], lb[SP_ITEMS], rank[SP_ITEMS];
         u32 kmin = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < SP_ITEMS; ++j) {
-            const u32 i = base + (u32)j * SP_TPB + threadIdx.x;
+            const u32 i = base + (u32)j * TPB + threadIdx.x;
             const bool ok = i < n;
             k[j] = ok ? nk[j] : 0xFFFFFFFFu;
             va[j] = ok ? na[j] : 0u;
@@ -410,7 +420,7 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             rank[j] = 0;
             if (k[j] == 0xFFFFFFFFu) continue;
             const u32 x = FINE ? k[j] - bin0 : k[j] >> shift;
-            if (x < (u32)SP_BINS) {
+            if (x < (u32)BINS_) {
                 lb[j] = x;
                 rank[j] = atomicAdd(&cnt[x], 1u);
             } else {
@@ -424,7 +434,7 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             // tile-local layout + one reserved run per non-empty bin (the reservation's answer is picked up after the reorder)
             my_cnt = cnt[threadIdx.x];
             u32 total;
-            toff[threadIdx.x] = block_exclusive_scan<SP_TPB>(my_cnt, s_scan, total);
+            toff[threadIdx.x] = block_exclusive_scan<TPB>(my_cnt, s_scan, total);
             if (my_cnt) {
                 const u32 bin = FINE ? bin0 + threadIdx.x : threadIdx.x;
                 u32 rel0;
@@ -446,10 +456,10 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
         }
         gbase[threadIdx.x] = my_base;
         __syncthreads();
-        const u32 staged = toff[SP_BINS - 1] + cnt[SP_BINS - 1];
+        const u32 staged = toff[BINS_ - 1] + cnt[BINS_ - 1];
 #pragma unroll
         for (int r = 0; r < SP_ITEMS; ++r) {  // (a fixed number of rounds: the compiler then knows how many stores are in flight)
-            const u32 j = threadIdx.x + (u32)r * SP_TPB;
+            const u32 j = threadIdx.x + (u32)r * TPB;
             if (j < staged) {
                 const u32 kk = s_k[j];
                 const u32 x = FINE ? kk - bin0 : kk >> shift;
@@ -524,7 +534,7 @@ gtars_status multisplit_pairs(const unsigned short *key, const u32 *a, const u32
     KeyT *tmp_key = (KeyT *)(((uintptr_t)(cur_b + n_bins) + 63) & ~(uintptr_t)63);
     uint2 *tmp_ab = reinterpret_cast<uint2 *>(reinterpret_cast<u32 *>(tmp_key) + (((size_t)n + 15) & ~(size_t)15));
     const size_t lds = (size_t)n_bins * 4;  // (one-level kernel only: n_bins <= MS_MAX_BINS there)
-    constexpr size_t sp_lds = ((size_t)SP_TILE * 3 + (size_t)SP_BINS * 3) * 4;
+    constexpr size_t sp_lds_a = ((size_t)SP_TPB_A * SP_ITEMS * 3 + (size_t)SP_TPB_A * 3) * 4, sp_lds_b = ((size_t)SP_TPB_B * SP_ITEMS * 3 + (size_t)SP_TPB_B * 3) * 4;
     // the dynamic-LDS limits belong to the functions (per device); a failed attempt is retried by the next call
     static std::mutex mu;
     static bool done[16] = {};
@@ -535,9 +545,10 @@ gtars_status multisplit_pairs(const unsigned short *key, const u32 *a, const u32
         if (!done[dev & 15]) {
             GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ms_scatter<KeyT, CLAMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(MS_MAX_BINS * 4)));
-            const void *sp[] = {reinterpret_cast<const void *>(k_split_pass<false, KeyT, CLAMP>),
-                                reinterpret_cast<const void *>(k_split_pass<true, KeyT, false>)};
-            for (const void *fn : sp) GT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds));
+            GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_split_pass<SP_TPB_A, false, KeyT, CLAMP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds_a));
+            GT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_split_pass<SP_TPB_B, true, KeyT, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds_b));
             done[dev & 15] = true;
         }
     }
@@ -545,15 +556,15 @@ gtars_status multisplit_pairs(const unsigned short *key, const u32 *a, const u32
     if (two_level) {
         // the bin scan is part of the two passes (k_split_pass: relative cursors, column sums of the counting workgroups' rows)
         const u32 shift = multisplit_coarse_shift(n_bins);
-        const u32 tiles = (n + SP_TILE - 1) / SP_TILE;
-        const unsigned grid = std::min<u32>(256, tiles);
+        const u32 tiles_a = (n + SP_TPB_A * SP_ITEMS - 1) / (SP_TPB_A * SP_ITEMS), tiles_b = (n + SP_TPB_B * SP_ITEMS - 1) / (SP_TPB_B * SP_ITEMS);
+        const unsigned grid_a = std::min<u32>(256 * (1024 / SP_TPB_A), tiles_a), grid_b = std::min<u32>(256 * (1024 / SP_TPB_B), tiles_b);
         ProfScope p("k_split_pass", st);
         const SetTags no_tags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        hipLaunchKernelGGL((k_split_pass<false, KeyT, CLAMP>), dim3(grid), dim3(SP_TPB), sp_lds, st, key, a, b, (const uint2 *)nullptr, n, shift,
-                           drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)table, n_bins, bin_off, heavy ? *heavy : HeavyBins{},
+        hipLaunchKernelGGL((k_split_pass<SP_TPB_A, false, KeyT, CLAMP>), dim3(grid_a), dim3(SP_TPB_A), sp_lds_a, st, key, a, b, (const uint2 *)nullptr, n,
+                           shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)table, n_bins, bin_off, heavy ? *heavy : HeavyBins{},
                            (const u32 *)(cur_a + 256), n_count_rows);
-        hipLaunchKernelGGL((k_split_pass<true, KeyT, false>), dim3(grid), dim3(SP_TPB), sp_lds, st, (const KeyT *)tmp_key, (const u32 *)nullptr,
-                           (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if, no_tags,
+        hipLaunchKernelGGL((k_split_pass<SP_TPB_B, true, KeyT, false>), dim3(grid_b), dim3(SP_TPB_B), sp_lds_b, st, (const KeyT *)tmp_key,
+                           (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if, no_tags,
                            (const u32 *)nullptr, n_bins, bin_off, HeavyBins{}, (const u32 *)nullptr, 0u);
     } else {
         {

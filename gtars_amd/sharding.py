@@ -313,13 +313,51 @@ class ShardedIgd:
         lo, hi = shard_range(len(q["chrom"]), self.rank, self.world)
         return {k: q[k][lo:hi] for k in ("chrom", "start", "end")}
 
+    def exchange_queries(self, q: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+        """Bucket mode without the redundant host pass: ``local_queries`` makes EVERY rank filter the WHOLE batch for its
+        chromosomes (world x the batch of host work per call).  Here rank r looks only at ITS contiguous 1 / world of the batch
+        (``shard_range``), groups those queries by owner rank, and ONE variable-size all-to-all (counts, then the packed
+        (chrom, start, end) rows: RCCL on device tensors, gloo through the host) hands every query to the rank that owns its
+        chromosome.  Queries on chromosomes nobody owns (unknown ids) are dropped where they are found: no count sees them
+        (igd.rs:504-512: an unknown contig contributes nothing).  The rows arrive grouped by sending rank -- per-file counts are
+        sums over queries, so their order does not matter.  Same totals as ``local_queries`` (tests/test_sharding_gloo.py).
+        ``q``: the global batch as every rank sees it (only the rank's own range of it is read)."""
+        if self.world == 1 or self.mode != "bucket" or not self.collective:
+            return self.local_queries(q)
+        import torch
+        import torch.distributed as dist
+
+        lo, hi = shard_range(len(q["chrom"]), self.rank, self.world)
+        c = np.asarray(q["chrom"][lo:hi])
+        lut = np.full(len(self.owner) + 1, self.world, dtype=np.int64)  # (+ one slot for "no owner")
+        lut[: len(self.owner)] = self.owner
+        dest = lut[np.minimum(c.astype(np.int64), len(self.owner))]
+        keep = dest < self.world
+        order = np.argsort(dest[keep], kind="stable")
+        counts = np.bincount(dest[keep], minlength=self.world)[: self.world].astype(np.int64)
+        rows = np.empty((int(keep.sum()), 3), dtype=np.uint32)
+        for j, k in enumerate(("chrom", "start", "end")):
+            rows[:, j] = np.asarray(q[k][lo:hi])[keep][order]
+        on_device = _backend(self.group) != "gloo" and hasattr(self.engine, "device")
+        dev = self.engine.device if on_device else torch.device("cpu")
+        cnt_in = torch.from_numpy(counts).to(dev)
+        cnt_out = torch.empty(self.world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(cnt_out, cnt_in, group=self.group)
+        n_out = cnt_out.cpu().tolist()
+        send = torch.from_numpy(rows.view(np.int32)).to(dev)
+        recv = torch.empty((sum(n_out), 3), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(recv, send, output_split_sizes=n_out, input_split_sizes=counts.tolist(), group=self.group)
+        got = recv.cpu().numpy().view(np.uint32)
+        return {k: np.ascontiguousarray(got[:, j]) for j, k in enumerate(("chrom", "start", "end"))}
+
     def count_local(self, q, min_overlap: int = 1, binary: bool = False):
         lq = self.local_queries(q)
         return self.engine.igd_count(self.g, lq["chrom"], lq["start"], lq["end"], min_overlap, binary)
 
-    def upload_local(self, q):
-        """this rank's share of ``q``, resident on the engine's device (for repeated counts: ``count_resident``)"""
-        lq = self.local_queries(q)
+    def upload_local(self, q, exchange: bool = False):
+        """this rank's share of ``q``, resident on the engine's device (for repeated counts: ``count_resident``).  ``exchange``:
+        through ``exchange_queries`` (a collective: every rank of the group must then call with it)."""
+        lq = self.exchange_queries(q) if exchange else self.local_queries(q)
         return self.engine.upload(lq["chrom"], lq["start"], lq["end"])
 
     def upload_local_sets(self, sets):

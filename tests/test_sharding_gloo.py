@@ -83,6 +83,13 @@ def sharded_checks(engine, rank, world):
             out[f"igd_{mode}_{'binary' if binary else 'pairwise'}"] = bool(torch.equal(got, exp) and torch.equal(got2, exp))
             if mode == "bucket" and world > 1:
                 out["bucket_db_is_cut"] = sdb.local_intervals < len(db["chrom"])
+            if mode == "bucket":
+                # the all-to-all hand-over of the queries (every rank looks at its 1 / world of the batch only): the same totals,
+                # and the rank's share is exactly the queries of its chromosomes (as a multiset: they arrive grouped by sender)
+                got3 = sdb.count_resident(sdb.upload_local(bq, exchange=True), 1, binary).cpu()
+                mine, via = sdb.local_queries(bq), sdb.exchange_queries(bq)
+                rows = lambda d: sorted(zip(d["chrom"].tolist(), d["start"].tolist(), d["end"].tolist()))
+                out[f"igd_bucket_exchange_{'binary' if binary else 'pairwise'}"] = bool(torch.equal(got3, exp) and rows(mine) == rows(via))
     # LOLA support vectors + contingency cells: two user sets, one all-reduce
     uni = synth.make_universe(30_000, seed=3)
     rng = np.random.default_rng(5)
