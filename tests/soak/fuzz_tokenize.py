@@ -63,6 +63,16 @@ def one(seed):
             os.environ[name] = "1"
         else:
             os.environ.pop(name, None)
+    # round 6: the sweep form of the tokenizer (k_tok_sweep) on a quarter of the cases, with random budgets (staged blocks per wave,
+    # runs per wave and round, rounds per tile), and half of those cases with the batch in (chromosome, start) order
+    sweep = rng.random() < 0.25
+    for name, choices in (("GTARS_TOK_SWEEP", ["1"]), ("GTARS_TOK_SWEEP_BLOCKS", ["", "", "3", "40"]), ("GTARS_TOK_SWEEP_RUNS", ["", "", "0", "1"]),
+                          ("GTARS_TOK_SWEEP_ROUNDS", ["", "1", "2"])):
+        v = str(rng.choice(choices)) if sweep else ""
+        if v:
+            os.environ[name] = v
+        else:
+            os.environ.pop(name, None)
     gtars_amd.reload_env()  # (the library snapshots its switches at first use)
     g = gtars_amd.OverlapIndex(c, s, e, val, n_chrom=n_chrom, kind=kind)
     o = oracle.Index(c, s, e, val, n_chrom=n_chrom, kind=kind)
@@ -76,6 +86,9 @@ def one(seed):
         qe[k] = np.maximum(qs[k] - rng.integers(0, 10, len(k)), 0)
         qs[:2] = 0xFFFFFFFF
         qe[:2] = 0xFFFFFFFF
+    if (sweep and rng.random() < 0.5) or os.environ.get("SORTED") == "1":  # (SORTED=1: every case in order)
+        order = np.lexsort((qs, qc))
+        qc, qs, qe = qc[order], qs[order], qe[order]
     off_g, ids_g = g.tokenize(qc, qs, qe)
     off_o, ids_o = o.tokenize(qc, qs, qe)
     assert np.array_equal(off_g, off_o), ("offsets", seed)
