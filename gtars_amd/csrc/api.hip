@@ -371,7 +371,7 @@ struct gtars_index {
     std::vector<u32> h_chrom_off, h_chrom_aux, h_chrom_sub, h_sub_off;
     DevBuf<u32> starts, ends, vals, max_ends, chrom_off, chrom_aux, chrom_sub, sub_off;
     // blocked acceleration structure (Bits kind), see AccelView in common.h
-    DevBuf<u32> acc_rec2, acc_rec4, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab, acc_idc, acc_idc_pos, acc_chrom_iv_end;
+    DevBuf<u32> acc_rec2, acc_rec4, acc_rec8, acc_blk_first, acc_lut, acc_qkeys, acc_chrom_tab, acc_idc, acc_idc_pos, acc_chrom_iv_end;
     bool acc_ids_affine = false, acc_ends_mono = false, acc_runs_ok = false;
     u32 acc_n_blocks = 0, acc_n_units = 0, acc_n_buckets = 0, acc_lut_words = 0, acc_q_words = 0;
     u32 acc_lut_shift = 0, acc_q_shift = 0, acc_search_top = 0, acc_top_shift = 0;
@@ -403,6 +403,7 @@ struct gtars_index {
         AccelView a;
         a.rec2 = reinterpret_cast<const uint4 *>(acc_rec2.p);
         a.rec4 = reinterpret_cast<const uint4 *>(acc_rec4.p);
+        a.rec8 = cfg_flag("GTARS_TOK_NO_UNIT_RECORDS") ? nullptr : reinterpret_cast<const uint4 *>(acc_rec8.p);  // (the switch: A/B, tests)
         a.idc = acc_idc.p;
         a.ids_affine = acc_ids_affine ? 1u : 0u;
         a.blk_first = acc_blk_first.p;
@@ -1097,6 +1098,30 @@ static gtars_status gtars_index_build_impl(const uint32_t *chrom, const uint32_t
     st = ix->starts.upload(ix->h_starts);
     if (!st && ix->has_accel) st = ix->acc_rec2.upload(h_rec2);
     if (!st && ix->has_accel && !ix->acc_ids_affine) st = ix->acc_rec4.upload(h_rec4);
+    if (!st && ix->has_accel && ix->acc_ids_affine && ix->acc_top_shift == 1) {
+        // unit records (AccelView::rec8): unit u = blocks 2u, 2u + 1; slots 0-3 = their own intervals (= the four slots of block 2u's
+        // 32-byte record), slots 4-7 = the own intervals of blocks 2u + 2, 2u + 3 (= the four slots of block 2u + 2's record), or
+        // sentinels behind the chromosome's last unit
+        const u32 nbk = ix->acc_n_blocks, nun = nbk >> 1;
+        std::vector<u32> h_rec8((size_t)nun * 16);
+        std::vector<u32> blk_chrom_end(nbk, 0);
+        for (u32 c = 0; c < n_chrom; ++c)
+            for (u32 b = h_cblk[c]; b < h_cblk[c + 1]; ++b) blk_chrom_end[b] = h_cblk[c + 1];
+        for (u32 u = 0; u < nun; ++u) {
+            const u32 b = 2u * u;
+            u32 *r = &h_rec8[(size_t)u * 16];
+            const u32 *lo = &h_rec2[(size_t)b * 8];
+            const bool has_next = b + 2u < blk_chrom_end[b];
+            const u32 *hi = has_next ? &h_rec2[(size_t)(b + 2u) * 8] : nullptr;
+            for (int k = 0; k < 4; ++k) {
+                r[k] = lo[k];
+                r[8 + k] = lo[4 + k];
+                r[4 + k] = hi ? hi[k] : 0xFFFFFFFFu;
+                r[12 + k] = hi ? hi[4 + k] : 0u;
+            }
+        }
+        st = ix->acc_rec8.upload(h_rec8);
+    }
     if (!st && ix->has_accel) st = ix->acc_idc.upload(h_idc);
     if (!st && ix->has_accel) {
         std::vector<u32> h_idc_pos(n_chrom, 0);
@@ -1186,6 +1211,7 @@ void gtars_index_free(gtars_index_t *ix) {
     ix->sub_off.release();
     ix->acc_rec2.release();
     ix->acc_rec4.release();
+    ix->acc_rec8.release();
     ix->acc_idc.release();
     ix->acc_idc_pos.release();
     ix->acc_blk_first.release();

@@ -105,6 +105,10 @@ constexpr int ACC_SLOTS = 4; // intervals a record carries (own + look-ahead)
 struct AccelView {
     const uint4 *rec2;        // [n_blocks * 2] starts | ends (32 B per block)
     const uint4 *rec4;        // [n_blocks * 4] starts | ends | ids | unused; null when ids_affine
+    // [n_units * 4] when top_shift == 1 (two blocks per LDS key: universes of ~130k-260k regions) and ids_affine, null otherwise: the
+    // UNIT's record -- the four own intervals of its two blocks and, as look-ahead, the four of the next two blocks: 8 starts | 8 ends,
+    // 64 bytes.  One request per query instead of the block key (blk_first) and then a 32-byte record (k_tok_lds<.., U64>).
+    const uint4 *rec8;
     const u32 *blk_first;     // [n_blocks] prefix-max end up to each block (local coordinates)
     const u32 *lut;           // [lut_words] packed u16, n_buckets + 1 entries (16-byte padded)
     const u32 *qkeys;         // [q_words] packed u16, n_units entries (16-byte padded)

@@ -156,7 +156,8 @@ __device__ __forceinline__ u32 walk_tail(const uint4 *__restrict__ recs, u32 b0,
 // range to a handful of units; the in-bucket search then runs the same scalar step sequence in every
 // lane, clamped to the lane's own range: per step one add, one min, one LDS read, one compare, one select.
 // b0[j] >= be[j] means "no candidate" (also for an unknown chromosome: be = 0).
-template <int SUB>
+// IN_UNIT = false (unit records, AccelView::rec8): a two-block unit is not resolved to its block -- the caller reads the unit's record
+template <int SUB, bool IN_UNIT = true>
 __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_lut, const u32 *s_q, const uint4 *s_ctab,
                                               const u32 *c, const u32 *s, u32 *b0, u32 *be) {
     // LDS byte addresses (32-bit, address space 3) so that a step needs no address math
@@ -247,7 +248,7 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
                     // test): slower -- 941 vs 731 us per 64M queries at 140k regions -- because a first candidate in the record's
                     // later slots sends the scan into walk_tail, whose dependent loads cost more than the key load saved.
 #if GTARS_TOK_UNIT2_EXACT
-                    b += a.blk_first[b] <= s[j] ? 1u : 0u;
+                    if constexpr (IN_UNIT) b += a.blk_first[b] <= s[j] ? 1u : 0u;
 #endif
                 } else {
                     u32 l2 = b, n2 = min(1u << shift, be[j] - b);
@@ -483,15 +484,19 @@ __device__ __forceinline__ void load_queries(const u32 *__restrict__ qc, const u
 // and then waiting for all eight loads leaves the CU's vector-memory pipe idle during every search: 586 -> 555 us per 64M
 // queries for the two-unit split alone).
 // REV: the ids kept for the write phase are those of the LAST two hits (they are emitted first)
-template <int R, int QPT, bool FILTER, bool IMPL, bool REV, int RUNS>
+// U64 (unit records, AccelView::rec8: two-block units, ids that follow from the position, no run form): the burst is the UNIT's
+// 64-byte record -- eight intervals, an 8-bit mask, the state word's block = the unit's first block -- and the in-unit key read is gone
+template <int R, int QPT, bool FILTER, bool IMPL, bool REV, int RUNS, bool U64 = false>
 __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds &L, const u32 (&c)[R][QPT], const u32 (&s)[R][QPT],
                                              const u32 (&e)[R][QPT], i32 min_bp, TileQ<QPT, IMPL> (&t)[R], u32 (&tsum)[R]) {
     static_assert(QPT == 4, "two units of two queries per round");
+    static_assert(!U64 || (IMPL && RUNS == 0 && R == 1), "unit records: position ids, the narrow build, one round");
     constexpr u32 STRIDE = IMPL ? 2 : 4;
     constexpr int UQ = 2, NU = R * QPT / UQ;  // queries per unit, units
     const uint4 *__restrict__ recs = IMPL ? a.rec2 : a.rec4;
     u32 b0[2][UQ], be[2][UQ];
     uint4 S[2][UQ], E[2][UQ], V[2][IMPL ? 1 : UQ];
+    uint4 S2[2][U64 ? UQ : 1], E2[2][U64 ? UQ : 1];  // (unit records: slots 4-7)
     bool act[2][UQ];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -508,7 +513,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
                 be[p][k] = c[r][j0 + k] < a.n_chrom ? a.n_blocks : 0u;
             }
         } else {
-            search_blocks<UQ>(a, L.lut, L.q, L.ctab, c[r] + j0, s[r] + j0, b0[p], be[p]);
+            search_blocks<UQ, !U64>(a, L.lut, L.q, L.ctab, c[r] + j0, s[r] + j0, b0[p], be[p]);
             if (GTARS_TOK_ABLATE & 32) {  // the LDS image was not filled: keep the made-up blocks inside the record array
 #pragma unroll
                 for (int k = 0; k < UQ; ++k) {
@@ -520,6 +525,14 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
 #pragma unroll
         for (int k = 0; k < UQ; ++k) {
             act[p][k] = b0[p][k] < be[p][k];
+            if constexpr (U64) {
+                const uint4 *ur = a.rec8 + (size_t)((act[p][k] ? b0[p][k] : 0u) >> 1) * 4;
+                S[p][k] = ur[0];
+                S2[p][k] = ur[1];
+                E[p][k] = ur[2];
+                E2[p][k] = ur[3];
+                continue;
+            }
             const uint4 *rec = recs + (size_t)(act[p][k] ? b0[p][k] : 0u) * STRIDE;
             if (GTARS_TOK_ABLATE & 8) {
                 S[p][k] = make_uint4(s[r][j0 + k] ^ 8u, ~0u, ~0u, ~0u);
@@ -539,14 +552,16 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
             const int j = j0 + k;
             const u32 qs_ = s[r][j], qe_ = e[r][j];
             u32 m = block_mask4<FILTER>(S[p][k], E[p][k], qs_, qe_, min_bp);
+            if constexpr (U64) m |= block_mask4<FILTER>(S2[p][k], E2[p][k], qs_, qe_, min_bp) << 4;
             m = act[p][k] ? m : 0u;
-            const bool more = act[p][k] && (S[p][k].w < qe_) && (b0[p][k] + 2 < be[p][k]);
+            const bool more = U64 ? act[p][k] && (S2[p][k].w < qe_) && (b0[p][k] + 4 < be[p][k])
+                                  : act[p][k] && (S[p][k].w < qe_) && (b0[p][k] + 2 < be[p][k]);
             u32 n = __popc(m);
             if (more) {
                 if ((RUNS & 1) && !FILTER && a.runs_ok)  // run form: the tail is measured below, by ONE copy of the code (bit 16 + ..:
                     pend |= (1u | (run_form(a, m, S[p][k].w, qs_) ? 0x10000u : 0u)) << (r * QPT + j);  // nothing to test in front)
-                else
-                    n += walk_tail<FILTER, STRIDE>(recs, b0[p][k], be[p][k], qs_, qe_, min_bp, [](u32, int) {});
+                else  // (unit records: the walk goes on behind the record's eight intervals, at block b0 + 4)
+                    n += walk_tail<FILTER, STRIDE>(recs, b0[p][k] + (U64 ? 2u : 0u), be[p][k], qs_, qe_, min_bp, [](u32, int) {});
             }
             tsum[r] += n;
             t[r].st[j] = (b0[p][k] & B0_MASK) | (m << B0_BITS);
@@ -629,7 +644,7 @@ __device__ __forceinline__ void count_rounds(const AccelView &a, const SearchLds
 // Run form (ids that follow from the position, no min-overlap filter; run_form above): a wide query's ids are id0, id0 + 1,
 // ... -- nothing is walked; with `defer` (the wave's ids go straight to memory) a query of >= COOP_MIN ids is not emitted here:
 // the caller writes it with the whole wave (coop_runs).
-template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS, class Put>
+template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS, bool U64 = false, class Put>
 __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                              const u32 *__restrict__ qs, const u32 *__restrict__ qe, i32 min_bp,
                                              const TileQ<QPT, IMPL> &t, u64 q0, u64 run, bool want_ids, u64 (&o4)[QPT], bool defer,
@@ -641,7 +656,8 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
     for (int j = 0; j < QPT; ++j) {
         o4[j] = run;
         const u32 b0 = t.st[j] & B0_MASK;
-        u32 m = (t.st[j] >> B0_BITS) & 15u;
+        u32 m = (t.st[j] >> B0_BITS) & (U64 ? 255u : 15u);
+        const u32 b_tail = b0 + (U64 ? 2u : 0u);  // walk_tail goes on two blocks behind its argument
         const bool more = (t.more_bits & (1u << j)) != 0;
         if constexpr (IMPL && !FILTER && (RUNS & 1) != 0) {
             if (t.more_bits & (1u << (RUN_Q_BIT + j))) {  // run form (count_rounds): the state word holds the run's length
@@ -687,7 +703,7 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
             eq = qe[q0 + j];
             be = L.ctab[cq].w;
             if (REV || !want_ids) {
-                n_all += walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [](u32, int) {});
+                n_all += walk_tail<FILTER, STRIDE>(recs, b_tail, be, sq, eq, min_bp, [](u32, int) {});
                 tail_counted = true;
             }
         }
@@ -728,7 +744,7 @@ __device__ __forceinline__ void emit_queries(const AccelView &a, const SearchLds
             i = __popc(m);
         }
         if (more && want_ids) {
-            const u32 n_tail = walk_tail<FILTER, STRIDE>(recs, b0, be, sq, eq, min_bp, [&](u32 b, int k) {
+            const u32 n_tail = walk_tail<FILTER, STRIDE>(recs, b_tail, be, sq, eq, min_bp, [&](u32 b, int k) {
                 put(slot(i++), IMPL ? t.aux[IMPL ? j : 0] + (u32)ACC_OWN * (b - b0) + (u32)k : recw[b * 16u + 8u + (u32)k]);
             });
             if (!tail_counted) n_all += n_tail;
@@ -820,7 +836,7 @@ __device__ __forceinline__ void coop_runs(const TileQ<QPT, true> &t, const u64 (
 // write phase: CSR offsets and token ids of the lane's QPT queries.  wave_base = global offset
 // of the wave's first id.  When the wave's ids fit the wave's LDS buffer (`stage`, stage_cap words) they are
 // compacted there and leave as contiguous stores; otherwise (and beyond the caller's capacity) one by one.
-template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS>
+template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS, bool U64 = false>
 __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                               const u32 *__restrict__ qs, const u32 *__restrict__ qe, u64 nq, i32 min_bp,
                                               const TileQ<QPT, IMPL> &t, u64 q0, u64 wave_base, u64 *__restrict__ offsets,
@@ -829,7 +845,7 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
     const bool staged = cap && t.wtotal <= stage_cap && wave_base + t.wtotal <= cap;
     u64 o4[QPT];
     // ids go either to the wave's LDS buffer (index relative to wave_base) or straight to memory
-    emit_queries<QPT, FILTER, IMPL, REV, RUNS>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, !staged, [&](u64 pos, u32 id) {
+    emit_queries<QPT, FILTER, IMPL, REV, RUNS, U64>(a, L, qc, qs, qe, min_bp, t, q0, wave_base + t.excl, cap != 0, o4, !staged, [&](u64 pos, u32 id) {
         if (GTARS_TOK_ABLATE & 2) return;
         if (staged)
             stage[(u32)(pos - wave_base)] = id;
@@ -859,7 +875,7 @@ __device__ __forceinline__ void write_queries(const AccelView &a, const SearchLd
 // go to the wave's LDS buffer at wave-relative positions while wave 0 is still busy with the look-back (the other
 // waves would only wait for it), and once the base is there the buffer is flushed and the offsets are stored.
 // stage_queries returns false when the wave's ids do not fit the buffer (write_queries then serves the round).
-template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS>
+template <int QPT, bool FILTER, bool IMPL, bool REV, int RUNS, bool U64 = false>
 __device__ __forceinline__ bool stage_queries(const AccelView &a, const SearchLds &L, const u32 *__restrict__ qc,
                                               const u32 *__restrict__ qs, const u32 *__restrict__ qe, i32 min_bp,
                                               const TileQ<QPT, IMPL> &t, u64 q0, u64 cap, u32 *stage, u32 stage_cap,
@@ -872,7 +888,7 @@ __device__ __forceinline__ bool stage_queries(const AccelView &a, const SearchLd
     if (IMPL && !FILTER && (RUNS & 1) && __ballot((t.more_bits >> RUN_Q_BIT) & 15u)) return false;
 #endif
     u64 o4[QPT];
-    emit_queries<QPT, FILTER, IMPL, REV, (GTARS_TOK_STAGE_RUNS != 0 ? RUNS : 0)>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, false, [&](u64 pos, u32 id) {
+    emit_queries<QPT, FILTER, IMPL, REV, (GTARS_TOK_STAGE_RUNS != 0 ? RUNS : 0), U64>(a, L, qc, qs, qe, min_bp, t, q0, (u64)t.excl, cap != 0, o4, false, [&](u64 pos, u32 id) {
         if (GTARS_TOK_ABLATE & 2) return;
         stage[(u32)pos] = id;
     });
@@ -1030,7 +1046,7 @@ __device__ __forceinline__ void group_barrier(u32 *ctr, u32 &phase, u32 members,
     asm volatile("" ::: "memory");
 }
 
-template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV, int RUNS>
+template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV, int RUNS, bool U64 = false>
 __global__ void __launch_bounds__(TPB, TPB / 256)
 k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *__restrict__ qe,
           u64 nq, i32 min_bp, u64 *__restrict__ offsets, u32 *__restrict__ ovals, u64 cap, ScanWs *ws,
@@ -1114,7 +1130,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
 #if GTARS_TOK_PRIO & 1
             __builtin_amdgcn_s_setprio(1);  // the group that feeds the vector-memory path goes first
 #endif
-            count_rounds<R, QPT, FILTER, IMPL, REV, RUNS>(a, L, c, s, e, min_bp, cur.q, tsum);
+            count_rounds<R, QPT, FILTER, IMPL, REV, RUNS, U64>(a, L, c, s, e, min_bp, cur.q, tsum);
 #if GTARS_TOK_PRIO & 1
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1147,7 +1163,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         bool pre0 = false;
         const u64 prev_q0 = (u64)prev.tile * TILE + (u64)gtid * QPT;
         if (have_prev && gwave != 0)
-            pre0 = stage_queries<QPT, FILTER, IMPL, REV, RUNS>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
+            pre0 = stage_queries<QPT, FILTER, IMPL, REV, RUNS, U64>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
         if (have_prev && gwave == 0) {
             const u64 excl = (GTARS_TOK_ABLATE & 1) ? (u64)prev.tile * 2400u
                                                     : (draw ? resolve_prefix_helping<1>(ws->state, prev.tile, (u64)prev.total, lane, epoch, spin_limit, base, help)
@@ -1165,7 +1181,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
         TSTAMP(7);
         if (have_prev) {
             if (gwave == 0)
-                pre0 = stage_queries<QPT, FILTER, IMPL, REV, RUNS>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
+                pre0 = stage_queries<QPT, FILTER, IMPL, REV, RUNS, U64>(a, L, qc, qs, qe, min_bp, prev.q[0], prev_q0, cap, stage, stage_cap, orel0);
             TSTAMP(3);
             bar();
             TSTAMP(4);
@@ -1179,7 +1195,7 @@ k_tok_lds(AccelView a, const u32 *__restrict__ qc, const u32 *__restrict__ qs, c
                     flush_queries<QPT>(nq, prev.q[0].wtotal, orel0, q0, s_prefix[grp] + prev.wbase[0], offsets, ovals, cap, off_vec_ok,
                                        stage, lane);
                 else
-                    write_queries<QPT, FILTER, IMPL, REV, RUNS>(a, L, qc, qs, qe, nq, min_bp, prev.q[r], q0, s_prefix[grp] + prev.wbase[r],
+                    write_queries<QPT, FILTER, IMPL, REV, RUNS, U64>(a, L, qc, qs, qe, nq, min_bp, prev.q[r], q0, s_prefix[grp] + prev.wbase[r],
                                                           offsets, ovals, cap, off_vec_ok, stage, stage_cap, lane);
             }
         }
@@ -1953,13 +1969,13 @@ static u32 stage_words(const AccelView &a, int tpb, int per_cu) {
     return w >= 128 ? (u32)w : 0u;
 }
 
-template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV, int RUNS>
+template <int TPB, int QPT, int R, int G, bool FILTER, bool IMPL, bool REV, int RUNS, bool U64 = false>
 static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *qs, const u32 *qe, u64 nq,
                                  i32 min_bp, const EnumOut &out, ScanWs *ws, ScanEpoch &ep, const u64 *d_base, u64 *d_total_out,
                                  hipStream_t st) {
     static KernelSetup setup;
     int dev = 0, cus = 256;
-    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV, RUNS>), dev, cus);
+    gtars_status s0 = setup.get(reinterpret_cast<const void *>(k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV, RUNS, U64>), dev, cus);
     if (s0) return s0;
     // one 1024-thread workgroup per CU: one LDS copy of the search keys, 16 waves -- what 128 VGPRs admit
     const u32 stage = stage_words(a, TPB, 1);
@@ -1969,7 +1985,7 @@ static gtars_status launch_tok_t(const AccelView &a, const u32 *qc, const u32 *q
     const u64 tiles = (nq + tile_q - 1) / tile_q;
     const u64 grid = std::min<u64>((u64)cus, (tiles + G - 1) / G);
     const u64 cap = out.vals ? out.capacity : 0;
-    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV, RUNS>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
+    hipLaunchKernelGGL((k_tok_lds<TPB, QPT, R, G, FILTER, IMPL, REV, RUNS, U64>), dim3((unsigned)grid), dim3(TPB), lds, st, a, qc, qs, qe, nq,
                        min_bp, out.offsets, out.vals, cap, ws, ep.epoch, ep.ticket_base, stage, spin_limit, d_base, d_total_out);
     GT_HIP(hipGetLastError());
     // tickets drawn by this launch: one per tile beyond the first `grid * G`, plus one failing draw per group
@@ -2027,6 +2043,11 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
     // with the run form gain nothing from the second round (16M queries of 33 ids: 1125 us with one round, 1139 with two)
     int rounds = impl && !wide ? choose_rounds(nq, cus) : 1;
     int groups = choose_groups(nq, cus);
+    // unit records (AccelView::rec8: universes of ~130k-260k regions, two blocks per LDS key): one 64-byte request per query instead
+    // of the block key and then a 32-byte record; the narrow build, one round (eight more registers of record per pipelined query)
+    const bool unit_rec = a.rec8 && a.top_shift == 1 && impl && !filter && !reverse && !wide;
+    if (unit_rec) rounds = 1;
+    prof_note_fact(unit_rec ? "tok_unit_records" : "tok_block_records");
     // a tile's hits are summed in 32 bits: tile queries x (most intervals on one chromosome) must fit
     const u64 dense = std::max<u64>(a.max_chrom_n, 1);
     if (dense * tok_tile_queries(TPB / groups, 4 * rounds) > 0xFFFFFFFFull) rounds = 1;
@@ -2062,6 +2083,8 @@ gtars_status launch_tokenize_lds(const AccelView &a, const u32 *qc, const u32 *q
 #define GT_TOK_WIDE(GG, I)                                                                                                  \
     GT_TOK_CASE(1, GG, false, I, false, GTARS_TOK_RUNS)                                                                     \
     GT_TOK_CASE(1, GG, false, I, true, GTARS_TOK_RUNS)
+    if (unit_rec && groups == 1) return launch_tok_t<TPB, 4, 1, 1, false, true, false, 0, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
+    if (unit_rec && groups == 2) return launch_tok_t<TPB, 4, 1, 2, false, true, false, 0, true>(a, qc, qs, qe, nq, min_bp, out, ws, ep, d_base, d_total_out, st);
     GT_TOK_GEOM(1, 1, true)
     GT_TOK_GEOM(2, 1, true)
     GT_TOK_GEOM(1, 2, true)

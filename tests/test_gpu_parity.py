@@ -2322,3 +2322,60 @@ def test_sweep_tokenizer_config2_in_order_and_large_universes(ga):
         want_off, want_ids = ref.tokenize(qc, qs, qe)
         off, ids = _tok_device(ga, g, qc, qs, qe, g.TOK_SORTED | g.TOK_NARROW, cap_factor=2)
         assert np.array_equal(off, want_off) and np.array_equal(ids, want_ids), nu
+
+
+def test_unit_records_for_universes_of_two_block_units(ga, monkeypatch):
+    """Round 6: universes beyond the LDS key budget of the tokenizer whose units are TWO blocks (~130k-260k regions) get a record
+    per UNIT -- eight intervals, 64 bytes, one request per query (AccelView::rec8) -- instead of a key read that picks the block and
+    then the block's 32-byte record.  Same hits in the same order as Bits::find (bits.rs:141-156, 433-446): synthetic universes of
+    150k and 250k regions (both kinds of launch geometry), a small universe forced onto two-block units (GTARS_TOP_MAX) with queries
+    that reach past the record's eight intervals (the tail walk from block b0 + 4), chromosome ends (sentinel slots), and the
+    switch that turns the records off (GTARS_TOK_NO_UNIT_RECORDS: the round-5 path) -- which record form a launch read is taken
+    from the profiling facts."""
+    from gtars_amd import synth
+
+    _lib = ga._lib
+
+    def facts(f):
+        _lib.lib.gtars_prof_reset()
+        _lib.lib.gtars_prof_enable(1)
+        r = f()
+        p = _lib.prof_read()
+        _lib.lib.gtars_prof_enable(0)
+        return r, p
+
+    for nu, nq in ((150_000, 300_000), (250_000, 2_300_000)):
+        u = synth.make_universe(nu)
+        q = synth.make_queries(u, nq)
+        g = ga.OverlapIndex(u["chrom"], u["start"], u["end"], n_chrom=synth.N_CHROM)
+        ref = oracle.Index(u["chrom"], u["start"], u["end"], None, n_chrom=synth.N_CHROM)
+        want = ref.tokenize(q["chrom"], q["start"], q["end"])
+        (off, ids), p = facts(lambda: _tok_device(ga, g, q["chrom"], q["start"], q["end"], g.TOK_NARROW, cap_factor=2))
+        assert "tok_unit_records" in p, sorted(p)
+        assert np.array_equal(off, want[0]) and np.array_equal(ids, want[1]), nu
+        monkeypatch.setenv("GTARS_TOK_NO_UNIT_RECORDS", "1")
+        (off2, ids2), p2 = facts(lambda: _tok_device(ga, g, q["chrom"], q["start"], q["end"], g.TOK_NARROW, cap_factor=2))
+        monkeypatch.delenv("GTARS_TOK_NO_UNIT_RECORDS")
+        assert "tok_block_records" in p2 and "tok_unit_records" not in p2
+        assert np.array_equal(off2, want[0]) and np.array_equal(ids2, want[1]), nu
+    # a small universe on two-block units, queries of up to 40 intervals, 7 chromosomes of uneven length (padding units)
+    monkeypatch.setenv("GTARS_TOP_MAX", "512")
+    rng = np.random.default_rng(8)
+    n = 1_500
+    c = np.sort(rng.choice(7, n, p=[.3, .25, .2, .1, .08, .05, .02])).astype(np.uint32)
+    s = rng.integers(0, 2_000_000, n).astype(np.uint32)
+    o = np.lexsort((s, c))
+    c, s = c[o], s[o]
+    e = (s + rng.integers(1, 3_000, n)).astype(np.uint32)
+    g, o_ = _pair(ga, c, s, e, n_chrom=7)
+    monkeypatch.delenv("GTARS_TOP_MAX")
+    nq = 50_000
+    qc = rng.integers(0, 8, nq).astype(np.uint32)
+    qs = rng.integers(0, 2_010_000, nq).astype(np.uint32)
+    qe = (qs + rng.integers(0, 60_000, nq)).astype(np.uint32)
+    want = o_.tokenize(qc, qs, qe)
+    (off, ids), p = facts(lambda: _tok_device(ga, g, qc, qs, qe, g.TOK_NARROW, cap_factor=40))
+    if "tok_unit_records" in p:  # (the forced budget gave two-block units)
+        assert np.array_equal(off, want[0]) and np.array_equal(ids, want[1])
+    else:
+        pytest.skip("GTARS_TOP_MAX=512 did not give two-block units for this universe")
