@@ -2891,6 +2891,11 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         std::vector<uint32_t> b;  // barcode ids (the cluster's first-seen order) of its fragments, wave after wave
         ViewDict barcodes;
     };
+    // a (file, barcode) run of regrouped ids in a device wave's answer: which line opens it, the file and the barcode's slot in the
+    // file's table, where the run lies in the wave's id array
+    struct Run {
+        uint32_t line, file, slot, start, len;
+    };
     // one wave's routed fragments as tokenizer input, cluster after cluster, and what the tokenizer made of them
     struct Wave {
         std::vector<uint64_t> coff;     // [n_clusters + 1]
@@ -2908,6 +2913,10 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         size_t first_file = 0;
         std::vector<TextFile> tf;
         gtars::FragWaveOut dev;  // the device's answer: ids regrouped by (file, barcode), where every run starts, which line opens it
+        // ... cut into its runs per cluster, in line order: made by the device thread that received the answer, while later waves are
+        // still inflating (round 6: this pass over every slot of every file ran on the calling thread behind the last wave --
+        // 11 ms of a 38-ms call on a folder of 1000 files)
+        std::vector<std::vector<Run>> runs;
         uint64_t reads = 0;
         double td[5] = {0, 0, 0, 0, 0};
     };
@@ -2993,6 +3002,23 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
                     for (uint64_t r : o.n_reads) w->reads += r;
                     w->td[0] = o.t_h2d, w->td[1] = o.t_parse, w->td[2] = o.t_group, w->td[3] = o.t_tok, w->td[4] = o.t_d2h;
                     w->dev = std::move(o);
+                    // the wave's runs per cluster (they lie in slot order: one ends where the next present one starts), by line
+                    w->runs.assign(nc, {});
+                    const gtars::FragWaveOut &d = w->dev;
+                    if (d.n) {
+                        size_t pc = nc, pi = 0;
+                        for (uint32_t f = 0; f + 1 < (uint32_t)d.slot_off.size(); ++f)
+                            for (uint32_t g = d.slot_off[f]; g < d.slot_off[f + 1]; ++g) {
+                                const uint32_t st0 = d.run_start[g];
+                                if (st0 == 0xFFFFFFFFu) continue;
+                                if (pc < nc) w->runs[pc][pi].len = st0 - w->runs[pc][pi].start;
+                                const uint32_t c = w->tf[f].slots[g - d.slot_off[f]].value;
+                                w->runs[c].push_back(Run{d.run_line[g], f, g - d.slot_off[f], st0, 0});
+                                pc = c, pi = w->runs[c].size() - 1;
+                            }
+                        if (pc < nc) w->runs[pc][pi].len = (uint32_t)d.n_ids - w->runs[pc][pi].start;
+                        for (auto &rc : w->runs) std::sort(rc.begin(), rc.end(), [](const Run &a, const Run &b) { return a.line < b.line; });
+                    }
                 }
                 for (TextFile &f : w->tf) f.data.release();  // the text is on the device (or no longer needed): the block back to the pool
             } else {
@@ -3153,32 +3179,6 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
     // Device waves arrive regrouped by (file, barcode) (FragWaveOut): what is left is, per cluster, the runs in the order their first
     // lines appear -- wave after wave, and inside a wave by line number: the first-seen barcode order of one pass over the cluster's
     // file -- a dictionary lookup per run (the same barcode string of several files is ONE barcode of the cluster) and a copy per run.
-    struct Run {
-        uint32_t wave, line, file, slot, start, len;
-    };
-    std::vector<std::vector<Run>> runs(device_path ? nc : 0);
-    if (device_path) {
-        uint32_t wi = 0;
-        for (Wave &w : waves) {
-            const gtars::FragWaveOut &o = w.dev;
-            if (o.n) {
-                const uint32_t total = o.slot_off.back();
-                size_t pc = nc, pi = 0;  // the previous present run (the runs lie in slot order: one ends where the next one starts)
-                for (uint32_t f = 0; f + 1 < (uint32_t)o.slot_off.size(); ++f)
-                    for (uint32_t g = o.slot_off[f]; g < o.slot_off[f + 1]; ++g) {
-                        const uint32_t st0 = o.run_start[g];
-                        if (st0 == 0xFFFFFFFFu) continue;
-                        if (pc < nc) runs[pc][pi].len = st0 - runs[pc][pi].start;
-                        const uint32_t c = w.tf[f].slots[g - o.slot_off[f]].value;
-                        runs[c].push_back(Run{wi, o.run_line[g], f, g - o.slot_off[f], st0, 0});
-                        pc = c, pi = runs[c].size() - 1;
-                    }
-                (void)total;
-                if (pc < nc) runs[pc][pi].len = (uint32_t)o.n_ids - runs[pc][pi].start;
-            }
-            ++wi;
-        }
-    }
     std::vector<Wave *> wave_at;
     for (Wave &w : waves) wave_at.push_back(&w);
     over_clusters([&](size_t c) {
@@ -3187,17 +3187,22 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         uint64_t i = 0;
         std::vector<uint32_t> run_id;
         if (device_path) {
-            std::vector<Run> &rc = runs[c];
-            std::sort(rc.begin(), rc.end(), [](const Run &a, const Run &b) { return a.wave != b.wave ? a.wave < b.wave : a.line < b.line; });
-            run_id.resize(rc.size());
+            // the cluster's runs wave after wave, inside a wave by line: the first-seen barcode order of one pass over its file
+            size_t n_runs = 0;
+            for (Wave *w : wave_at)
+                if (w->device && c < w->runs.size()) n_runs += w->runs[c].size();
+            run_id.reserve(n_runs);
             std::vector<uint64_t> per;
-            for (size_t r = 0; r < rc.size(); ++r) {
-                const TextFile &f = wave_at[rc[r].wave]->tf[rc[r].file];
-                const gtars::FragSlot &sl = f.slots[rc[r].slot];
-                const uint32_t id = k.barcodes.get_or_add(f.keys.data() + sl.off, sl.len);
-                if (id >= per.size()) per.resize((size_t)id + 1, 0);
-                per[id] += rc[r].len;
-                run_id[r] = id;
+            for (Wave *w : wave_at) {
+                if (!w->device || c >= w->runs.size()) continue;
+                for (const Run &r : w->runs[c]) {
+                    const TextFile &f = w->tf[r.file];
+                    const gtars::FragSlot &sl = f.slots[r.slot];
+                    const uint32_t id = k.barcodes.get_or_add(f.keys.data() + sl.off, sl.len);
+                    if (id >= per.size()) per.resize((size_t)id + 1, 0);
+                    per[id] += r.len;
+                    run_id.push_back(id);
+                }
             }
             cnt.assign(per.size() + 1, 0);
             for (size_t b = 0; b < per.size(); ++b) cnt[b + 1] = per[b];
@@ -3222,11 +3227,15 @@ static gtars_status fragsplit_tokenize_mode(const gtars_tokenizer_t *t, const st
         std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
         if (device_path) {
             // (a barcode's runs in (wave, line) order = file order: the fragments of a cluster lie file after file)
-            const std::vector<Run> &rc = runs[c];
-            for (size_t r = 0; r < rc.size(); ++r) {
-                uint64_t &at = fill[run_id[r]];
-                memcpy(ft->ids + at, wave_at[rc[r].wave]->dev.ids.get() + rc[r].start, (size_t)rc[r].len * sizeof(uint32_t));
-                at += rc[r].len;
+            size_t x = 0;
+            for (Wave *w : wave_at) {
+                if (!w->device || c >= w->runs.size()) continue;
+                const uint32_t *src = w->dev.ids.get();
+                for (const Run &r : w->runs[c]) {
+                    uint64_t &at = fill[run_id[x++]];
+                    memcpy(ft->ids + at, src + r.start, (size_t)r.len * sizeof(uint32_t));
+                    at += r.len;
+                }
             }
             arr[c] = ft;
             return;
