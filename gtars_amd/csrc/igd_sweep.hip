@@ -333,20 +333,31 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
             if (ok[u]) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
         }
         if (base + RT_TPB * RT_U < hi_q) RT_FETCH(base + RT_TPB * RT_U);
+        // The owner: first tile of the chromosome whose bound is > start, bracketed by the static table.  Written so that a lane's
+        // four queries have their LDS reads in flight TOGETHER and no read sits behind a branch -- reads at clamped addresses,
+        // selects instead of conditions (round 6).  The form `if (owned) { read; ... }` per query came out as one guarded read
+        // after the other, each with its own s_waitcnt: ~18 dependent LDS round trips per step, which is what the kernel's
+        // "70 % of the wave cycles waiting" were (found on k_tok_sweep with in-kernel stamps, then seen in this kernel's listing).
+        {
+            uint2 bl[RT_U];
 #pragma unroll
-        for (int u = 0; u < RT_U; ++u) {
-            // the owner: first tile of the chromosome whose bound is > start, bracketed by the static table
-            l[u] = h[u] = 0;
-            const uint2 bl = s_bl[min(c[u], n_chrom)];  // {table base, last bound} of the chromosome
-            owned[u] = c[u] < n_chrom && (u32)s[u] < bl.y;  // otherwise: invalid, unknown chromosome or past every bound
-            if (owned[u]) {
-                const u32 j = bl.x + ((u32)s[u] >> route_shift);
-                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                typedef us2 us2_a2 __attribute__((aligned(2)));
-                typedef const __attribute__((address_space(3))) us2_a2 *lds_us2;
-                const us2 p = *(lds_us2)(uintptr_t)(s_lut + j);  // both entries by one 4-byte read (2-byte aligned)
-                l[u] = p.x;
-                h[u] = p.y;
+            for (int u = 0; u < RT_U; ++u) bl[u] = s_bl[min(c[u], n_chrom)];  // {table base, last bound} of the chromosome
+            u32 j[RT_U];
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) {
+                owned[u] = (c[u] < n_chrom) & ((u32)s[u] < bl[u].y);  // otherwise: invalid, unknown chromosome or past every bound
+                j[u] = owned[u] ? bl[u].x + ((u32)s[u] >> route_shift) : 0u;
+            }
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            typedef us2 us2_a2 __attribute__((aligned(2)));
+            typedef const __attribute__((address_space(3))) us2_a2 *lds_us2;
+            us2 p[RT_U];
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) p[u] = *(lds_us2)(uintptr_t)(s_lut + j[u]);  // both entries by one 4-byte read (2-byte aligned)
+#pragma unroll
+            for (int u = 0; u < RT_U; ++u) {
+                l[u] = owned[u] ? (u32)p[u].x : 0u;
+                h[u] = owned[u] ? (u32)p[u].y : 0u;
             }
         }
         if constexpr (FINE) {
@@ -354,21 +365,21 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
             // or equal and, with buckets wider than 2^16, really >= (the exact bound, global memory: one query in 2^16)
             const u32 qsh = route_shift - 16u, msk = (1u << route_shift) - 1u;
             bool more = true;
-            while (more) {
+            while (__ballot(more)) {
+                u32 kq[RT_U];
+#pragma unroll
+                for (int u = 0; u < RT_U; ++u) kq[u] = s_kq[l[u] < n_tiles ? l[u] : 0u];  // (an address inside the table whatever the state)
                 more = false;
 #pragma unroll
                 for (int u = 0; u < RT_U; ++u) {
-                    if (l[u] < h[u]) {
-                        const u32 kq = s_kq[l[u]], sq = ((u32)s[u] & msk) >> qsh;
-                        bool below = kq < sq;
-                        if (kq == sq && qsh) below = bnd[l[u]] <= (u32)s[u];
-                        if (below) {
-                            l[u] += 1;
-                            more = more || l[u] < h[u];
-                        } else {
-                            h[u] = l[u];
-                        }
-                    }
+                    const bool act = l[u] < h[u];
+                    const u32 sq = ((u32)s[u] & msk) >> qsh;
+                    bool below = kq[u] < sq;
+                    if (act && kq[u] == sq && qsh) below = bnd[l[u]] <= (u32)s[u];  // (rare: the exact bound)
+                    const u32 nl = l[u] + 1u;
+                    h[u] = (act & !below) ? l[u] : h[u];
+                    l[u] = (act & below) ? nl : l[u];
+                    more = more | (act & below & (l[u] < h[u]));
                 }
             }
         } else {

@@ -457,15 +457,34 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
         gbase[threadIdx.x] = my_base;
         __syncthreads();
         const u32 staged = toff[BINS_ - 1] + cnt[BINS_ - 1];
+        // (a fixed number of rounds: the compiler then knows how many stores are in flight; the LDS reads of ALL rounds at clamped
+        // addresses and in flight together -- with `if (j < staged) { read; read; store }` per round every round was two dependent
+        // LDS round trips behind the previous round's: 16 in a chain per tile)
+        {
+            u32 kk[SP_ITEMS], va_[SP_ITEMS], vb_[SP_ITEMS], gb_[SP_ITEMS], to_[SP_ITEMS];
 #pragma unroll
-        for (int r = 0; r < SP_ITEMS; ++r) {  // (a fixed number of rounds: the compiler then knows how many stores are in flight)
-            const u32 j = threadIdx.x + (u32)r * TPB;
-            if (j < staged) {
-                const u32 kk = s_k[j];
-                const u32 x = FINE ? kk - bin0 : kk >> shift;
-                const u32 pos = gbase[x] + (j - toff[x]);
-                out_ab[pos] = make_uint2(s_a[j], s_b[j]);
-                if (!FINE) out_key[pos] = (KeyT)kk;
+            for (int r = 0; r < SP_ITEMS; ++r) {
+                const u32 j = threadIdx.x + (u32)r * TPB, jj = j < staged ? j : 0u;
+                kk[r] = s_k[jj];
+                va_[r] = s_a[jj];
+                vb_[r] = s_b[jj];
+            }
+#pragma unroll
+            for (int r = 0; r < SP_ITEMS; ++r) {
+                const u32 j = threadIdx.x + (u32)r * TPB;
+                u32 x = FINE ? kk[r] - bin0 : kk[r] >> shift;
+                x = j < staged && x < (u32)BINS_ ? x : 0u;
+                gb_[r] = gbase[x];
+                to_[r] = toff[x];
+            }
+#pragma unroll
+            for (int r = 0; r < SP_ITEMS; ++r) {
+                const u32 j = threadIdx.x + (u32)r * TPB;
+                if (j < staged) {
+                    const u32 pos = gb_[r] + (j - to_[r]);
+                    out_ab[pos] = make_uint2(va_[r], vb_[r]);
+                    if (!FINE) out_key[pos] = (KeyT)kk[r];
+                }
             }
         }
         // LDS is reused by the next tile: order the LDS accesses only -- a full barrier would also drain this tile's stores
