@@ -1,6 +1,6 @@
 """A short run of the soak fuzzers inside the GPU suite (round-5 verdict: most of the randomised evidence lived outside the
 driver-run suite).  The fuzzers proper -- tests/soak/fuzz_tokenize.py, fuzz_igd.py, fuzz_fragments.py: hundreds to a thousand
-cases each, minutes of run time -- stay outside; here 40 + 40 + 2 + 25 cases from their own generators with seeds of this file,
+cases each, minutes of run time -- stay outside; here 120 + 100 + 3 + 60 cases from their own generators with seeds of this file,
 every case bit-exact against the oracle like there (their assertions are the test)."""
 import importlib.util
 import os
@@ -38,16 +38,16 @@ def clean_switches():
 def test_short_soak_tokenize(clean_switches):
     fz = _load("fuzz_tokenize")
     ids = 0
-    for seed in range(40):
+    for seed in range(120):
         ids += fz.one(910_000 + seed)[2]
     assert ids > 0
 
 
 def test_short_soak_igd(clean_switches):
     fz = _load("fuzz_igd")
-    for seed in range(40):
+    for seed in range(100):
         fz.one(920_000 + seed)
-    for seed in range(2):
+    for seed in range(3):
         fz.one_big(930_000 + seed)
 
 
@@ -61,7 +61,7 @@ def test_short_soak_fragments(clean_switches):
     tok, otok = Tokenizer.from_bed(ub), oracle.OracleTokenizer(ub)
     tmp = tempfile.mkdtemp(prefix="gtars_fuzzfrag_")
     try:
-        for seed in range(25):
+        for seed in range(60):
             fz.one(940_000 + seed, tmp, tok, otok, chroms, ub)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
