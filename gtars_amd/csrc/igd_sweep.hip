@@ -318,21 +318,10 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
                      f0 + 3 < hi_q ? qe[f0 + 3] : 0u};                                                      \
         }                                                                                                   \
     } while (0)
-    RT_FETCH(lo_q);
-    for (u32 base = lo_q; base < hi_q; base += RT_TPB * RT_U) {
-        const u32 i0 = base + threadIdx.x * RT_U;
-        u32 c[RT_U], l[RT_U], h[RT_U];
-        i32 s[RT_U], e[RT_U];
-        bool ok[RT_U], owned[RT_U];
-        const u32 rc[RT_U] = {nc.x, nc.y, nc.z, nc.w}, rs[RT_U] = {ns.x, ns.y, ns.z, ns.w}, re[RT_U] = {ne.x, ne.y, ne.z, ne.w};
-#pragma unroll
-        for (int u = 0; u < RT_U; ++u) {
-            ok[u] = i0 + u < hi_q;
-            c[u] = n_chrom;
-            s[u] = e[u] = 0;
-            if (ok[u]) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
-        }
-        if (base + RT_TPB * RT_U < hi_q) RT_FETCH(base + RT_TPB * RT_U);
+    // the owner tile of a lane's four prepared queries (n_tiles: none -- invalid, unknown chromosome, past every bound)
+    auto owners = [&](const u32 (&c)[RT_U], const i32 (&s)[RT_U], u32 (&tt)[RT_U]) {
+        u32 l[RT_U], h[RT_U];
+        bool owned[RT_U];
         // The owner: first tile of the chromosome whose bound is > start, bracketed by the static table.  Written so that a lane's
         // four queries have their LDS reads in flight TOGETHER and no read sits behind a branch -- reads at clamped addresses,
         // selects instead of conditions (round 6).  The form `if (owned) { read; ... }` per query came out as one guarded read
@@ -399,12 +388,71 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
                 }
             }
         }
-        u32 tt[RT_U];
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u) tt[u] = owned[u] ? l[u] : n_tiles;
+    };
+    const u32 STEP = RT_TPB * RT_U;
+    u32 base = lo_q;
+    if constexpr (VEC) {
+        // FULL steps (every lane's four queries are in range): no branch around any memory operation, so that the compiler's wait
+        // for the prefetched columns is a COUNTED one.  With the range checks inside the loop (the general form below) every wait
+        // came out as s_waitcnt vmcnt(0), which also waits for the step's own key store, issued a few instructions earlier: a
+        // store's round trip on the critical path of every step (round 6, from the listing).
+        if (base + STEP <= hi_q) {
+            const u32 f_first = base + threadIdx.x * RT_U;
+            v4u pc = *reinterpret_cast<const v4u *>(qc + f_first), ps = *reinterpret_cast<const v4u *>(qs + f_first),
+                pe = *reinterpret_cast<const v4u *>(qe + f_first);
+            // (a step's keys are stored at the START of the next step, in front of that step's loads: a store issued BEHIND the
+            // prefetch is the youngest operation when the loop comes round, and the wait for the prefetched columns -- which the
+            // compiler cannot count past the loop's entry, where there is no store yet -- would be a wait for that store as well)
+            uint2 k_prev = make_uint2(0u, 0u);
+            u32 i_prev = 0;
+            bool have_prev = false;
+            for (; base + STEP <= hi_q; base += STEP) {
+                const u32 i0 = base + threadIdx.x * RT_U;
+                const u32 rc[RT_U] = {pc.x, pc.y, pc.z, pc.w}, rs[RT_U] = {ps.x, ps.y, ps.z, ps.w}, re[RT_U] = {pe.x, pe.y, pe.z, pe.w};
+                u32 c[RT_U], tt[RT_U];
+                i32 s[RT_U], e[RT_U];
+#pragma unroll
+                for (int u = 0; u < RT_U; ++u) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
+                // (the empty statement ties the store to the columns just waited for, so that it is not scheduled in front of that wait)
+                asm volatile("" : "+v"(k_prev.x), "+v"(k_prev.y) : "v"(rc[0]), "v"(rs[0]), "v"(re[0]));
+                if (have_prev) *reinterpret_cast<uint2 *>(key + i_prev) = k_prev;
+                // the next full step's columns (behind the last one: this step's again -- an unconditional load)
+                const u32 fn = (base + 2u * STEP <= hi_q ? base + STEP : base) + threadIdx.x * RT_U;
+                pc = *reinterpret_cast<const v4u *>(qc + fn);
+                ps = *reinterpret_cast<const v4u *>(qs + fn);
+                pe = *reinterpret_cast<const v4u *>(qe + fn);
+                owners(c, s, tt);
+#pragma unroll
+                for (int u = 0; u < RT_U; ++u) atomicAdd(&bins[tt[u] >> 1], 1u << ((tt[u] & 1u) * 16u));
+                k_prev = make_uint2(tt[0] | (tt[1] << 16), tt[2] | (tt[3] << 16));
+                i_prev = i0;
+                have_prev = true;
+            }
+            if (have_prev) *reinterpret_cast<uint2 *>(key + i_prev) = k_prev;
+        }
+    }
+    // the rest of the chunk (a partial step; every step of a batch whose columns are not 16-byte aligned)
+    if (base < hi_q) RT_FETCH(base);
+    for (; base < hi_q; base += STEP) {
+        const u32 i0 = base + threadIdx.x * RT_U;
+        u32 c[RT_U], tt[RT_U];
+        i32 s[RT_U], e[RT_U];
+        bool ok[RT_U];
+        const u32 rc[RT_U] = {nc.x, nc.y, nc.z, nc.w}, rs[RT_U] = {ns.x, ns.y, ns.z, ns.w}, re[RT_U] = {ne.x, ne.y, ne.z, ne.w};
 #pragma unroll
         for (int u = 0; u < RT_U; ++u) {
-            tt[u] = owned[u] ? l[u] : n_tiles;
-            if (ok[u]) atomicAdd(&bins[tt[u] >> 1], 1u << ((tt[u] & 1u) * 16u));
+            ok[u] = i0 + u < hi_q;
+            c[u] = n_chrom;
+            s[u] = e[u] = 0;
+            if (ok[u]) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
         }
+        if (base + STEP < hi_q) RT_FETCH(base + STEP);
+        owners(c, s, tt);
+#pragma unroll
+        for (int u = 0; u < RT_U; ++u)
+            if (ok[u]) atomicAdd(&bins[tt[u] >> 1], 1u << ((tt[u] & 1u) * 16u));
         if (VEC && i0 + RT_U <= hi_q) {
             *reinterpret_cast<uint2 *>(key + i0) = make_uint2(tt[0] | (tt[1] << 16), tt[2] | (tt[3] << 16));
         } else {
