@@ -72,7 +72,7 @@ __device__ __forceinline__ u32 lut_shift(u32 span) {
     return bits > K ? (u32)(bits - K) : 0u;
 }
 // first index i in [0, n) with key[i] >= x, through the table: the answer lies in [lut[b], lut[b + 1]] for b = bucket(x) -- the
-// two entries come by ONE 4-byte LDS read (2-byte aligned: gfx950 allows unaligned DS access)
+// two entries come by two 2-byte LDS reads
 __device__ __forceinline__ void lut_range(const unsigned short *lut, i32 x, i32 k0, i32 k1, u32 sh, u32 n, u32 &l, u32 &h) {
     if (x <= k0) {
         l = h = 0;
@@ -80,12 +80,21 @@ __device__ __forceinline__ void lut_range(const unsigned short *lut, i32 x, i32 
         l = h = n;
     } else {
         const u32 b = (u32)(x - k0) >> sh;
+#ifdef GTARS_IGD_LUT_B32
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         typedef us2 us2_a2 __attribute__((aligned(2)));
         typedef const __attribute__((address_space(3))) us2_a2 *lds_us2;
         const us2 p = *(lds_us2)(uintptr_t)(lut + b);
         l = p.x;
         h = p.y;
+#else
+        // (volatile: left to itself the compiler fuses the two into one 4-byte read at a 2-byte-aligned address, and a misaligned
+        // LDS read is no fast path -- round 6, measured on k_igd_route)
+        typedef const volatile __attribute__((address_space(3))) unsigned short *lds_vu16;
+        const lds_vu16 pp = (lds_vu16)(uintptr_t)(lut + b);
+        l = pp[0];
+        h = pp[1];
+#endif
     }
 }
 // lanes that walk one query's candidate records together (pair loop of the sweep; measured 4 / 8 / 16: 0.263 / 0.278 / 0.318 ms):
@@ -337,16 +346,21 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
                 owned[u] = (c[u] < n_chrom) & ((u32)s[u] < bl[u].y);  // otherwise: invalid, unknown chromosome or past every bound
                 j[u] = owned[u] ? bl[u].x + ((u32)s[u] >> route_shift) : 0u;
             }
-            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-            typedef us2 us2_a2 __attribute__((aligned(2)));
-            typedef const __attribute__((address_space(3))) us2_a2 *lds_us2;
-            us2 p[RT_U];
+            // the bucket's pair of entries by TWO 2-byte reads (inline assembly, or the compiler fuses them): as ONE 4-byte read at a
+            // 2-byte-aligned address -- every other bucket -- they cost 7 of the kernel's 47.6 us; misaligned LDS reads are no fast path
+            u32 pl[RT_U], ph[RT_U], pa[RT_U];
 #pragma unroll
-            for (int u = 0; u < RT_U; ++u) p[u] = *(lds_us2)(uintptr_t)(s_lut + j[u]);  // both entries by one 4-byte read (2-byte aligned)
+            for (int u = 0; u < RT_U; ++u) pa[u] = (u32)(uintptr_t)(s_lut + j[u]);
+            asm volatile("ds_read_u16 %0, %8\n\tds_read_u16 %1, %8 offset:2\n\tds_read_u16 %2, %9\n\tds_read_u16 %3, %9 offset:2\n\t"
+                         "ds_read_u16 %4, %10\n\tds_read_u16 %5, %10 offset:2\n\tds_read_u16 %6, %11\n\tds_read_u16 %7, %11 offset:2\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(pl[0]), "=&v"(ph[0]), "=&v"(pl[1]), "=&v"(ph[1]), "=&v"(pl[2]), "=&v"(ph[2]), "=&v"(pl[3]), "=&v"(ph[3])
+                         : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3])
+                         : "memory");
 #pragma unroll
             for (int u = 0; u < RT_U; ++u) {
-                l[u] = owned[u] ? (u32)p[u].x : 0u;
-                h[u] = owned[u] ? (u32)p[u].y : 0u;
+                l[u] = owned[u] ? pl[u] : 0u;
+                h[u] = owned[u] ? ph[u] : 0u;
             }
         }
         if constexpr (FINE) {
@@ -417,6 +431,7 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
                 for (int u = 0; u < RT_U; ++u) igd_prep_one(rc[u], rs[u], re[u], n_chrom, c[u], s[u], e[u]);
                 // (the empty statement ties the store to the columns just waited for, so that it is not scheduled in front of that wait)
                 asm volatile("" : "+v"(k_prev.x), "+v"(k_prev.y) : "v"(rc[0]), "v"(rs[0]), "v"(re[0]));
+                STAMP(4);  // (diagnostic build) the wait for the columns
                 if (have_prev) *reinterpret_cast<uint2 *>(key + i_prev) = k_prev;
                 // the next full step's columns (behind the last one: this step's again -- an unconditional load)
                 const u32 fn = (base + 2u * STEP <= hi_q ? base + STEP : base) + threadIdx.x * RT_U;
@@ -424,8 +439,10 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
                 ps = *reinterpret_cast<const v4u *>(qs + fn);
                 pe = *reinterpret_cast<const v4u *>(qe + fn);
                 owners(c, s, tt);
+                STAMP(5);  // the owner search
 #pragma unroll
                 for (int u = 0; u < RT_U; ++u) atomicAdd(&bins[tt[u] >> 1], 1u << ((tt[u] & 1u) * 16u));
+                STAMP(6);  // the counters
                 k_prev = make_uint2(tt[0] | (tt[1] << 16), tt[2] | (tt[3] << 16));
                 i_prev = i0;
                 have_prev = true;

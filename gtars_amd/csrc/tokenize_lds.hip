@@ -72,6 +72,9 @@ __device__ __forceinline__ void st_stream2(u64 *p, u64 a, u64 b) {
 #ifndef GTARS_TOK_LB_W1
 #define GTARS_TOK_LB_W1 1  // look-back windows per round in one-tile-per-group launches (see resolve_prefix_helping)
 #endif
+#ifndef GTARS_TOK_KEYS_U16
+#define GTARS_TOK_KEYS_U16 1  // the in-bucket keys by eight 2-byte reads instead of one 16-byte read at a 2-byte-aligned address (1-2 % at the 100k universe)
+#endif
 #ifndef GTARS_TOK_SEARCH8
 #define GTARS_TOK_SEARCH8 1  // in-bucket search by one 16-byte read of 8 keys instead of halving steps
 #endif
@@ -189,6 +192,43 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
     // before).  Larger buckets are first narrowed by halving steps.  Keys past the bucket's end belong to the next bucket and
     // restart low, so only the LEADING run counts: c_i = c_(i-1) & (key_i < target), and the sum is clamped to the bucket.
     (void)last;
+#if GTARS_TOK_KEYS_U16
+    // (the eight keys by EIGHT 2-byte reads, all queries' reads in flight together: a 16-byte LDS read at a 2-byte-aligned address
+    // is not a fast path -- found on k_igd_route, whose 4-byte reads at odd 2-byte offsets cost a fifth of that kernel)
+    u32 lo_b[SUB], n[SUB], kk[SUB][8];
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+        lo_b[j] = pos[j] + 2u, n[j] = (last[j] - pos[j]) >> 1;  // byte address of the bucket's first key, keys in the bucket
+        while (n[j] > 8u) {
+            const u32 half = n[j] >> 1, mid = lo_b[j] + (half << 1);
+            const bool below = (u32) * (lds_cu16)(uintptr_t)mid < tq[j];
+            lo_b[j] = below ? mid + 2u : lo_b[j];
+            n[j] = below ? n[j] - half - 1u : half;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SUB; ++j)
+        asm volatile("ds_read_u16 %0, %8\n\tds_read_u16 %1, %8 offset:2\n\tds_read_u16 %2, %8 offset:4\n\tds_read_u16 %3, %8 offset:6\n\t"
+                     "ds_read_u16 %4, %8 offset:8\n\tds_read_u16 %5, %8 offset:10\n\tds_read_u16 %6, %8 offset:12\n\tds_read_u16 %7, %8 offset:14"
+                     : "=&v"(kk[j][0]), "=&v"(kk[j][1]), "=&v"(kk[j][2]), "=&v"(kk[j][3]), "=&v"(kk[j][4]), "=&v"(kk[j][5]), "=&v"(kk[j][6]),
+                       "=&v"(kk[j][7])
+                     : "v"(lo_b[j])
+                     : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+        asm volatile("" : "+v"(kk[j][0]), "+v"(kk[j][1]), "+v"(kk[j][2]), "+v"(kk[j][3]), "+v"(kk[j][4]), "+v"(kk[j][5]), "+v"(kk[j][6]),
+                     "+v"(kk[j][7]));  // (the keys are only valid behind the wait)
+        u32 cnt = 0;
+        bool run = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            run = run && kk[j][i] < tq[j];
+            cnt += run ? 1u : 0u;
+        }
+        pos[j] = lo_b[j] - 2u + (min(cnt, n[j]) << 1);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < SUB; ++j) {
         u32 lo_b = pos[j] + 2u, n = (last[j] - pos[j]) >> 1;  // byte address of the bucket's first key, keys in the bucket
@@ -211,6 +251,7 @@ __device__ __forceinline__ void search_blocks(const AccelView &a, const u32 *s_l
         }
         pos[j] = lo_b - 2u + (min(cnt, n) << 1);  // &q[first key >= target] - 2, what the stepwise search leaves
     }
+#endif
 #else
     for (u32 step = a.search_top << 1; step >= 2; step >>= 1) {  // byte steps
 #pragma unroll

@@ -20,7 +20,7 @@ hits = torch.zeros(F, dtype=torch.int64, device=dev)
 fn = _lib.lib.gtars_debug_sweep_stamps
 fr = _lib.lib.gtars_debug_route_stamps
 buf = (C.c_ulonglong * 8)()
-RNAMES = ["LDS fill", "routing loop", "barrier", "flush counters"]
+RNAMES = ["LDS fill", "routing loop (rest)", "barrier", "flush counters", "loop: wait for the columns", "loop: owner search", "loop: counters"]
 def run(q, binary, label):
     d = [torch.from_numpy(np.ascontiguousarray(q[k]).view(np.int32)).to(dev) for k in ("chrom", "start", "end")]
     n = d[0].numel()
@@ -34,10 +34,10 @@ def run(q, binary, label):
     fr(buf, 0)
     v = list(buf)
     if v[7]:
-        tot = sum(v[:4])
+        tot = sum(v[:7])
         print(f"== {label}: k_igd_route, {v[7]} workgroups, {tot / v[7]:.0f} cycles per workgroup")
-        for nme, x in zip(RNAMES, v[:4]):
-            print(f"   {nme:22s} {x / v[7]:10.0f}  {100 * x / tot:5.1f} %")
+        for nme, x in zip(RNAMES, v[:7]):
+            print(f"   {nme:28s} {x / v[7]:10.0f}  {100 * x / tot:5.1f} %")
     fn(buf, 0)
     v = list(buf)
     wg = max(v[7], 1)
