@@ -273,6 +273,22 @@ u32 multisplit_workgroups(u32 n) {
 #define GTARS_SP_TPB_B 512
 #endif
 constexpr int SP_TPB_A = GTARS_SP_TPB_A, SP_TPB_B = GTARS_SP_TPB_B;
+#ifndef SP_STAMPS
+#define SP_STAMPS 0  // diagnostic build: per-phase shader-clock totals of wave 0 of every workgroup (tools/r06_split_stamps.py)
+#endif
+#if SP_STAMPS
+__device__ unsigned long long g_split_stamps[2][16];
+#define SPSTAMP(k)                                   \
+    do {                                             \
+        const u64 _t = __builtin_amdgcn_s_memtime(); \
+        sp_acc[k] += _t - sp_last;                   \
+        sp_last = _t;                                \
+    } while (0)
+#else
+#define SPSTAMP(k) \
+    do {           \
+    } while (0)
+#endif
 static_assert((SP_TPB_A == 1024 || SP_TPB_A == 512) && (SP_TPB_B == 1024 || SP_TPB_B == 512), "split-pass workgroups of 1024 or 512 threads");
 constexpr int SP_ITEMS = 8;
 
@@ -291,14 +307,13 @@ __global__ void __launch_bounds__(TPB, 4)
 k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 *__restrict__ b, const uint2 *__restrict__ ab_in, u32 n,
              u32 shift, u32 drop_bin, u32 *__restrict__ cursor, KeyT *__restrict__ out_key, uint2 *__restrict__ out_ab, const u32 *__restrict__ run_if,
              SetTags tags, const u32 *__restrict__ rows = nullptr, u32 n_bins = 0, u32 *__restrict__ bin_off = nullptr, HeavyBins heavy = HeavyBins{},
-             const u32 *__restrict__ ctot = nullptr, u32 n_rows = 0) {
+             const u32 *__restrict__ ctot = nullptr, u32 n_rows = 0, uint2 *__restrict__ trash = nullptr) {
     if (run_if && *run_if == 0) return;  // the caller found nothing to partition (decided on the device)
     constexpr int TILE_ = TPB * SP_ITEMS, BINS_ = TPB;  // one thread per tile-local bin (counter reset, layout scan, run reservation)
     extern __shared__ u32 sp_lds[];
     u32 *s_k = sp_lds, *s_a = s_k + TILE_, *s_b = s_a + TILE_;
     u32 *cnt = s_b + TILE_, *toff = cnt + BINS_, *gbase = toff + BINS_;
     __shared__ u32 s_scan[TPB / 64];
-    __shared__ u32 s_min;
     __shared__ u32 s_cbase[!FINE ? 257 : 1];  // exclusive offsets of the coarse bins (+ the grand total)
     const u32 n_tiles = (n + TILE_ - 1) / TILE_;
     // One workgroup per CU (its tile fills the LDS), so nothing else hides a tile's memory latencies: the NEXT tile's elements
@@ -306,9 +321,10 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
     // LDS reorder and write-out), and a bin's run reservation -- a global atomic WITH return -- is only waited for after the
     // tile has been reordered in LDS (the reorder needs the tile-local layout, not the global base).  Before: every tile paid a
     // load round trip and an atomic round trip back to back, 13 us per 8192-element tile (164 KB moved: 12.6 GB/s per CU).
-    u32 nk[SP_ITEMS], na[SP_ITEMS], nb[SP_ITEMS];
+    u32 nk[SP_ITEMS], na[SP_ITEMS], nb[SP_ITEMS], nfirst = 0;
     auto request = [&](u32 tile) {
         const u32 base = tile * TILE_;
+        if (FINE) nfirst = (u32)key[base];  // (every lane the same address: the tile's first element, see bin0 below)
 #pragma unroll
         for (int j = 0; j < SP_ITEMS; ++j) {
             const u32 i = base + (u32)j * TPB + threadIdx.x;
@@ -324,6 +340,9 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
             }
         }
     };
+#if SP_STAMPS
+    u64 sp_acc[12] = {}, sp_last = __builtin_amdgcn_s_memtime();
+#endif
     if (blockIdx.x < n_tiles) request(blockIdx.x);
     if constexpr (!FINE) {
         // the coarse totals were left by the caller's counting kernel (multisplit_coarse_totals)
@@ -378,12 +397,16 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
         if (blockIdx.x == 0 && threadIdx.x == 0) bin_off[n_bins] = s_cbase[256];
         __syncthreads();  // cnt is the tile loop's again
     }
+    SPSTAMP(0);  // prologue
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const u32 base = tile * TILE_;
         cnt[threadIdx.x] = 0;  // BINS_ == TPB
-        if (threadIdx.x == 0) s_min = 0xFFFFFFFFu;
         u32 k[SP_ITEMS], va[SP_ITEMS], vb[SP_ITEMS], lb[SP_ITEMS], rank[SP_ITEMS];
-        u32 kmin = 0xFFFFFFFFu;
+        // FINE: the tile's window of keys starts at its smallest coarse bin -- the coarse bin of its FIRST element: the first pass
+        // left the elements grouped by coarse bin, ascending.  (Round 6: the minimum over the tile's keys -- a wave reduction, an LDS
+        // atomic and two barriers -- was a sixth of this pass by the in-kernel stamps.  Elements of a coarse bin below the first
+        // element's cannot exist; a first element that is dropped only makes the window start no later than it must.)
+        const u32 bin0 = FINE ? (nfirst >> shift) << shift : 0u;
 #pragma unroll
         for (int j = 0; j < SP_ITEMS; ++j) {
             const u32 i = base + (u32)j * TPB + threadIdx.x;
@@ -399,28 +422,17 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
                 if (CLAMP) va[j] = (i32)va[j] < 0 ? 0u : va[j];
                 tags.apply(i, va[j], vb[j]);  // (the second pass carries the pairs as they are)
             }
-            if (k[j] != 0xFFFFFFFFu) kmin = min(kmin, k[j]);
         }
+        SPSTAMP(1);  // the tile's elements (wait for the prefetch)
         if (tile + gridDim.x < n_tiles) request(tile + gridDim.x);
-        u32 bin0 = 0;
-        if (FINE) {
-            // the tile's window of keys starts at its smallest coarse bin
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) kmin = min(kmin, (u32)__shfl_xor((int)kmin, d, 64));
-            __syncthreads();  // s_min initialised
-            if ((threadIdx.x & 63) == 0 && kmin != 0xFFFFFFFFu) atomicMin(&s_min, kmin);
-            __syncthreads();
-            bin0 = s_min == 0xFFFFFFFFu ? 0u : (s_min >> shift) << shift;
-        } else {
-            __syncthreads();  // cnt zeroed
-        }
+        __syncthreads();  // cnt zeroed
 #pragma unroll
         for (int j = 0; j < SP_ITEMS; ++j) {
             lb[j] = 0xFFFFFFFFu;
             rank[j] = 0;
             if (k[j] == 0xFFFFFFFFu) continue;
             const u32 x = FINE ? k[j] - bin0 : k[j] >> shift;
-            if (x < (u32)BINS_) {
+            if (!FINE || x < (u32)BINS_) {  // (pass A: <= 256 coarse bins)
                 lb[j] = x;
                 rank[j] = atomicAdd(&cnt[x], 1u);
             } else {
@@ -428,34 +440,48 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
                 out_ab[bin_off[k[j]] + atomicAdd(&cursor[k[j]], 1u)] = make_uint2(va[j], vb[j]);
             }
         }
+        SPSTAMP(2);  // window + rank (LDS atomics)
         __syncthreads();
-        u32 my_cnt, my_base = 0;
+        SPSTAMP(3);  // barrier
+        u32 my_cnt, my_rel0 = 0, my_got = 0;
         {
-            // tile-local layout + one reserved run per non-empty bin (the reservation's answer is picked up after the reorder)
+            // tile-local layout + one reserved run per non-empty bin.  The reservation's answer is picked up after the reorder: the
+            // sum base + answer is formed THERE -- formed inside this branch, the compiler waited for the atomic's round trip here
+            // (round 6, from the listing: global_atomic_add / s_waitcnt vmcnt(0) back to back).
             my_cnt = cnt[threadIdx.x];
             u32 total;
             toff[threadIdx.x] = block_exclusive_scan<TPB>(my_cnt, s_scan, total);
             if (my_cnt) {
                 const u32 bin = FINE ? bin0 + threadIdx.x : threadIdx.x;
-                u32 rel0;
                 if constexpr (FINE)
-                    rel0 = bin_off[bin];
+                    my_rel0 = bin_off[bin];
                 else
-                    rel0 = s_cbase[bin];
-                my_base = rel0 + atomicAdd(&cursor[bin], my_cnt);
+                    my_rel0 = s_cbase[bin];
+                my_got = atomicAdd(&cursor[bin], my_cnt);
             }
         }
+        SPSTAMP(4);  // layout scan + reservation issued
         __syncthreads();
+        {
+            // (the layout's offsets of all eight elements first, at clamped addresses: behind `if (lb[j] == ~0) continue` every
+            // element's read / write pair waited for the one before)
+            u32 tf[SP_ITEMS];
 #pragma unroll
-        for (int j = 0; j < SP_ITEMS; ++j) {
-            if (lb[j] == 0xFFFFFFFFu) continue;
-            const u32 slot = toff[lb[j]] + rank[j];
-            s_k[slot] = k[j];
-            s_a[slot] = va[j];
-            s_b[slot] = vb[j];
+            for (int j = 0; j < SP_ITEMS; ++j) tf[j] = toff[lb[j] != 0xFFFFFFFFu ? lb[j] : 0u];
+#pragma unroll
+            for (int j = 0; j < SP_ITEMS; ++j) {
+                if (lb[j] == 0xFFFFFFFFu) continue;
+                const u32 slot = tf[j] + rank[j];
+                s_k[slot] = k[j];
+                s_a[slot] = va[j];
+                s_b[slot] = vb[j];
+            }
         }
-        gbase[threadIdx.x] = my_base;
+        SPSTAMP(5);  // reorder in LDS
+        gbase[threadIdx.x] = my_rel0 + my_got;
+        SPSTAMP(6);  // the reservation's answer
         __syncthreads();
+        SPSTAMP(7);  // barrier
         const u32 staged = toff[BINS_ - 1] + cnt[BINS_ - 1];
         // (a fixed number of rounds: the compiler then knows how many stores are in flight; the LDS reads of ALL rounds at clamped
         // addresses and in flight together -- with `if (j < staged) { read; read; store }` per round every round was two dependent
@@ -477,21 +503,44 @@ k_split_pass(const KeyT *__restrict__ key, const u32 *__restrict__ a, const u32 
                 gb_[r] = gbase[x];
                 to_[r] = toff[x];
             }
+            // (EVERY lane stores in every round -- a lane without an element into a trash slot of the workspace: with the stores
+            // behind `if (j < staged)` the compiler cannot count them, and its wait for the NEXT tile's prefetched elements at the top
+            // of the loop became s_waitcnt vmcnt(0): a wait for this tile's stores to be acknowledged, on every tile)
+            uint2 *const trash_ab = trash + (threadIdx.x & 63u);
+            KeyT *const trash_key = reinterpret_cast<KeyT *>(trash + 64) + (threadIdx.x & 63u);
 #pragma unroll
             for (int r = 0; r < SP_ITEMS; ++r) {
                 const u32 j = threadIdx.x + (u32)r * TPB;
-                if (j < staged) {
-                    const u32 pos = gb_[r] + (j - to_[r]);
-                    out_ab[pos] = make_uint2(va_[r], vb_[r]);
-                    if (!FINE) out_key[pos] = (KeyT)kk[r];
-                }
+                const u32 pos = gb_[r] + (j - to_[r]);
+                *(j < staged ? out_ab + pos : trash_ab) = make_uint2(va_[r], vb_[r]);
+                if (!FINE) *(j < staged ? out_key + pos : trash_key) = (KeyT)kk[r];
             }
         }
+        SPSTAMP(8);  // write-out
         // LDS is reused by the next tile: order the LDS accesses only -- a full barrier would also drain this tile's stores
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        SPSTAMP(9);  // closing barrier
     }
+#if SP_STAMPS
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 10; ++k) atomicAdd(&g_split_stamps[FINE ? 1 : 0][k], sp_acc[k]);
+        atomicAdd(&g_split_stamps[FINE ? 1 : 0][15], 1ull);
+    }
+#endif
 }
 
+#if SP_STAMPS
+}  // namespace gtars
+extern "C" int gtars_debug_split_stamps(unsigned long long *out, int reset) {  // out[2][16]: pass A, pass B
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gtars::g_split_stamps), 256) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gtars::g_split_stamps), z, 256) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace gtars {
+#endif
 // table [max(256, n / 65532 + 2)][n_bins] | tot [n_bins] | cursors (coarse [1024], fine [n_bins]) | first-level output: keys [n], pairs [n]
 // (the table region also holds a table_ready caller's rows of packed 16-bit counts: one row per counting workgroup -- at most
 // max(512, n / 65532 + 2) of them, a workgroup counts <= 65535 elements -- of multisplit_row_words(n_bins) words)
@@ -500,7 +549,7 @@ static size_t multisplit_table_words(u32 n_bins, u32 n) {
                             (size_t)std::max<u32>(512u, n / 65532u + 2u) * multisplit_row_words(n_bins));
 }
 size_t multisplit_ws_bytes(u32 n_bins, u32 n) {
-    return (multisplit_table_words(n_bins, n) + 2 * (size_t)n_bins + 1024 + 256) * 4 + (size_t)n * 12 + 256;
+    return (multisplit_table_words(n_bins, n) + 2 * (size_t)n_bins + 1024 + 256) * 4 + (size_t)n * 12 + 256 + 1024;  // (+ the passes' trash slots)
 }
 
 // elements per workgroup of the counting / scatter grid: a multiple of 4 (callers that count the keys themselves take four
@@ -552,6 +601,7 @@ gtars_status multisplit_pairs(const unsigned short *key, const u32 *a, const u32
     u32 *cur_a = tot + n_bins, *cur_b = cur_a + 1024;
     KeyT *tmp_key = (KeyT *)(((uintptr_t)(cur_b + n_bins) + 63) & ~(uintptr_t)63);
     uint2 *tmp_ab = reinterpret_cast<uint2 *>(reinterpret_cast<u32 *>(tmp_key) + (((size_t)n + 15) & ~(size_t)15));
+    uint2 *trash = tmp_ab + n;  // 64 pairs + 64 keys nobody reads (k_split_pass: lanes without an element store there)
     const size_t lds = (size_t)n_bins * 4;  // (one-level kernel only: n_bins <= MS_MAX_BINS there)
     constexpr size_t sp_lds_a = ((size_t)SP_TPB_A * SP_ITEMS * 3 + (size_t)SP_TPB_A * 3) * 4, sp_lds_b = ((size_t)SP_TPB_B * SP_ITEMS * 3 + (size_t)SP_TPB_B * 3) * 4;
     // the dynamic-LDS limits belong to the functions (per device); a failed attempt is retried by the next call
@@ -581,10 +631,10 @@ gtars_status multisplit_pairs(const unsigned short *key, const u32 *a, const u32
         const SetTags no_tags{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         hipLaunchKernelGGL((k_split_pass<SP_TPB_A, false, KeyT, CLAMP>), dim3(grid_a), dim3(SP_TPB_A), sp_lds_a, st, key, a, b, (const uint2 *)nullptr, n,
                            shift, drop_bin, cur_a, tmp_key, tmp_ab, run_if, tags, (const u32 *)table, n_bins, bin_off, heavy ? *heavy : HeavyBins{},
-                           (const u32 *)(cur_a + 256), n_count_rows);
+                           (const u32 *)(cur_a + 256), n_count_rows, trash);
         hipLaunchKernelGGL((k_split_pass<SP_TPB_B, true, KeyT, false>), dim3(grid_b), dim3(SP_TPB_B), sp_lds_b, st, (const KeyT *)tmp_key,
                            (const u32 *)nullptr, (const u32 *)nullptr, tmp_ab, n, shift, drop_bin, cur_b, (KeyT *)nullptr, out_ab, run_if, no_tags,
-                           (const u32 *)nullptr, n_bins, bin_off, HeavyBins{}, (const u32 *)nullptr, 0u);
+                           (const u32 *)nullptr, n_bins, bin_off, HeavyBins{}, (const u32 *)nullptr, 0u, trash);
     } else {
         {
             ProfScope p("k_ms_scan", st);
