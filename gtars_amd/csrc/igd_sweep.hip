@@ -277,6 +277,15 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
 #if IGD_STAMPS
     u64 st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
+    // (the first full step's columns are requested HERE, in front of the 97-KB table copy: their round trip to HBM overlaps it)
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const u32 lo_q = blockIdx.x * chunk, hi_q = min(nq, lo_q + chunk);
+    v4u pc0 = v4u{0, 0, 0, 0}, ps0 = pc0, pe0 = pc0;
+    if (VEC && lo_q + RT_TPB * RT_U <= hi_q) {
+        const u32 f_first = lo_q + threadIdx.x * RT_U;
+        pc0 = *reinterpret_cast<const v4u *>(qc + f_first), ps0 = *reinterpret_cast<const v4u *>(qs + f_first),
+        pe0 = *reinterpret_cast<const v4u *>(qe + f_first);
+    }
     for (u32 c = threadIdx.x; c <= n_chrom; c += RT_TPB) s_bl[c] = make_uint2(route_base[c], c < n_chrom ? route_len[c] : 0u);
     {
         // the tables: 16-byte loads, four in flight per thread (a dword-per-step copy loop is a chain of L2 round trips)
@@ -300,7 +309,6 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
     for (u32 w = threadIdx.x; w < (n_tiles + 2) / 2; w += RT_TPB) bins[w] = 0;
     __syncthreads();
     STAMP(0);
-    const u32 lo_q = blockIdx.x * chunk, hi_q = min(nq, lo_q + chunk);
     // A lane takes RT_U = 4 CONSECUTIVE queries per step.  VEC (16-byte aligned columns, chunk a multiple of 4): three 16-byte
     // loads and one 8-byte key store per step instead of twelve loads and four stores (the loop was instruction-bound: 17.8k
     // cycles per step by the in-kernel stamps, ~500 VALU instructions per wave and step).  The raw columns of the NEXT step
@@ -308,7 +316,6 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
     // batch is in order is decided in front of this kernel (k_igd_begin).
     // (three plain vectors, not arrays filled through a lambda: those stayed in scratch memory -- 48 bytes per lane written and
     // read back through the vector-memory pipe on every step)
-    typedef u32 v4u __attribute__((ext_vector_type(4)));
     static_assert(RT_U == 4, "a lane's four queries travel as one vector per column");
     v4u nc, ns, ne;
 #define RT_FETCH(base_)                                                                                     \
@@ -413,9 +420,7 @@ k_igd_route(const u32 *__restrict__ qc, const u32 *__restrict__ qs, const u32 *_
         // came out as s_waitcnt vmcnt(0), which also waits for the step's own key store, issued a few instructions earlier: a
         // store's round trip on the critical path of every step (round 6, from the listing).
         if (base + STEP <= hi_q) {
-            const u32 f_first = base + threadIdx.x * RT_U;
-            v4u pc = *reinterpret_cast<const v4u *>(qc + f_first), ps = *reinterpret_cast<const v4u *>(qs + f_first),
-                pe = *reinterpret_cast<const v4u *>(qe + f_first);
+            v4u pc = pc0, ps = ps0, pe = pe0;  // (requested in front of the table copy)
             // (a step's keys are stored at the START of the next step, in front of that step's loads: a store issued BEHIND the
             // prefetch is the youngest operation when the loop comes round, and the wait for the prefetched columns -- which the
             // compiler cannot count past the loop's entry, where there is no store yet -- would be a wait for that store as well)
@@ -2159,6 +2164,14 @@ gtars_status launch_igd_sweep(const IgdView &v, const IgdTiles &tl, const u32 *q
             const u32 cap = (u32)std::min<long>(65532, std::max<long>(64, cfg_int("GTARS_IGD_ROUTE_CHUNK_MAX", 65532)));
             rt_wg = std::max<u32>(rt_wg, std::min<u32>(512u, (nq + cap - 1) / cap));  // (<= 512 rows: multisplit_ws_bytes)
             rt_chunk = ((nq + rt_wg - 1) / rt_wg + 3u) & ~3u;
+            // whole steps of 4096 queries when the chunks are long: the partial last step of a chunk runs through the general loop
+            // without a prefetch and cost 7.1k cycles against 3.9k for a full step (in-kernel stamps, 10M queries: nine full steps and
+            // 54 % of a tenth on 256 workgroups -> ten full steps on 245)
+            const u32 whole = (rt_chunk + 4095u) & ~4095u;
+            if (rt_chunk >= 8u * 4096u && whole <= 61440u && !cfg_flag("GTARS_IGD_ROUTE_NO_WHOLE_STEPS")) {
+                rt_chunk = whole;
+                rt_wg = (nq + rt_chunk - 1) / rt_chunk;
+            }
         }
         if (rt_chunk > 65535u) return fail(GTARS_ERR_INTERNAL, "IGD sweep: routing chunk exceeds the 16-bit counters");  // (cannot happen)
         {
