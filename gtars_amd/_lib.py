@@ -226,6 +226,7 @@ _DEBUG_SIG = {
     "gtars_debug_occupy_device": (C.c_int, [vp, u32, u32, u32]),
     "gtars_debug_reload_env": (None, []),
     "gtars_debug_set_handle_device": (C.c_int, [vp, C.c_int, C.c_int]),
+    "gtars_debug_inflate_streams": (C.c_int, [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
 }
 
 # every symbol the headers declare must resolve -- fail loudly otherwise (GTARS_AMD_LIB_OLDER=1, A/B tooling only: an older

@@ -30,6 +30,17 @@ void gtars_debug_reload_env(void);
  * any other use. */
 int gtars_debug_set_handle_device(void *handle, int is_igd, int device);
 
+/* Test / measurement entry of the device-side DEFLATE decoder (csrc/inflate_dev.hip; the fused fragment pipeline's input stage,
+ * gtars-fragsplit/src/split.rs:84-131 reads its files through flate2's MultiGzDecoder): n_streams raw DEFLATE streams (RFC 1951, no
+ * gzip header or trailer), one wave each.  ALL pointers are device memory.  Stream i is comp[in_off[i] .. + in_len[i]) -- in_off a
+ * multiple of 16, and 32 readable bytes behind every stream -- and is written to out[out_off[i] ..) -- out_off a multiple of 16,
+ * capacity out_cap[i] bytes.  out_len[i] = bytes produced, consumed[i] = input bytes used, status[i] = 0 or the reason the decoder
+ * refused the stream (1 block type / stored length, 2 code lengths, 3 symbol or distance, 4 input exhausted, 5 capacity).
+ * Enqueued on `stream`; returns a gtars_status. */
+int gtars_debug_inflate_streams(const void *comp, const uint64_t *in_off, const uint32_t *in_len, void *out, const uint64_t *out_off,
+                                const uint32_t *out_cap, uint32_t n_streams, uint32_t *out_len, uint32_t *consumed, uint32_t *status,
+                                void *stream);
+
 /* (Stamp builds -- tools/build_variant.sh with -DGTARS_TOK_STAMPS=1 / -DIGD_STAMPS=1 -- additionally export
  * gtars_debug_tok_stamps / gtars_debug_route_stamps / gtars_debug_sweep_stamps: s_memtime at the phase boundaries of the tile
  * loops, read by tools/r03_tok_stamps.py, tools/r03_sweep_stamps.py, tools/r05_rank_stamps.py.  The shipped library has none.) */

@@ -9,7 +9,7 @@ cd "$(dirname "$0")/.."
 name=$1; flags=$2; shift 2 || true
 mkdir -p build/variants build/vobj/$name
 objs=""
-for src in host.cpp lola_stats.cpp api.hip kernels.hip sort.hip igd_sweep.hip tokenize_lds.hip fragparse.hip; do
+for src in host.cpp lola_stats.cpp api.hip kernels.hip sort.hip igd_sweep.hip tokenize_lds.hip fragparse.hip inflate_dev.hip; do
   o=build/obj/$src.o
   if [ $# -eq 0 ] || echo " $* " | grep -q " $src "; then
     o=build/vobj/$name/$src.o
