@@ -830,6 +830,44 @@ def test_igd_sweep_matches_oracle(ga, monkeypatch, seed, n, nq, F, span, wmax):
     assert g.count_region_hits(qc, qs, qe, 1).tolist() == exp_b
 
 
+def test_igd_routing_chunks_of_whole_steps_on_a_long_shuffled_batch(ga, monkeypatch):
+    """Round 6: for long batches the routing kernel's chunks are whole 4096-query steps (fewer workgroups than CUs, no partial
+    last step) and the first step's columns are requested in front of the table copy.  8.4M shuffled queries -- 256 chunks of
+    32 816 become 228 of 36 864, the last one short and ragged -- against a two-level partition (1270 tiles), pairwise and binary,
+    checked against the oracle and against the plain ceil(n / workgroups) geometry."""
+    rng = np.random.default_rng(77)
+    n, F, n_chrom, span = 2_600_000, 40, 3, 120_000_000
+    c = rng.integers(0, n_chrom, n)
+    s = rng.integers(0, span, n)
+    e = s + rng.integers(1, 400, n)
+    f = rng.integers(0, F, n)
+    g, o = _igd_pair(ga, c, s, e, f, n_chrom=n_chrom, n_files=F)
+    nq = 8 * 4096 * 256 + 3 * 4096 + 7
+    qc = rng.integers(0, n_chrom + 1, nq)
+    qc = np.where(qc >= n_chrom, UNK, qc)
+    qs = rng.integers(0, span, nq).astype(np.int64)
+    qe = qs + rng.integers(0, 300, nq)
+    qs[-3:] = 0xFFFFFFF0  # (the ragged tail: clamped starts)
+    qe[-3:] = 5000
+    want_p = o.count_set_overlaps(qc, qs, qe, 1, n_files=F).tolist()
+    want_b = o.count_region_hits(qc, qs, qe, 1, n_files=F).tolist()
+    _lib = ga._lib
+    _lib.lib.gtars_prof_reset()
+    _lib.lib.gtars_prof_enable(1)
+    assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == want_p
+    names = set(_lib.prof_read())
+    _lib.lib.gtars_prof_enable(0)
+    assert "k_split_pass" in names, names  # the two-level partition (the whole-step geometry only applies there)
+    assert g.count_region_hits(qc, qs, qe, 1).tolist() == want_b
+    monkeypatch.setenv("GTARS_IGD_ROUTE_NO_WHOLE_STEPS", "1")
+    ga.reload_env()
+    try:
+        assert g.count_set_overlaps(qc, qs, qe, 1).tolist() == want_p
+    finally:
+        monkeypatch.delenv("GTARS_IGD_ROUTE_NO_WHOLE_STEPS")
+        ga.reload_env()
+
+
 def test_igd_non_positive_min_overlap_follows_the_tile_walk(ga):
     """igd.rs:772-846 with min_overlap <= 0: the walk also admits records that do NOT overlap the query, depending on the
     16384-bp tile they fall in.  Every IGD query against the oracle's literal tile walk, incl. records that straddle tile
